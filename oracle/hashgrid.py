@@ -1,0 +1,121 @@
+"""Oracle (test infrastructure): multi-resolution hash grid, restated in PyTorch.
+
+The arithmetic is that of ``tinycudann``'s ``GridEncoding`` (NVlabs/tiny-cuda-nn,
+``include/tiny-cuda-nn/encodings/grid.h``; installed by the reference from git
+master with no version pin: reference ``README.md:48``, ``Dockerfile:96``).  The
+package is CUDA-only and not vendored under ``/root/reference`` so it cannot be
+built or run here: **parity unpinned** at this boundary.  Call sites this
+restatement serves: ``fields/sdf_field.py:230-241`` (16 levels, F=2, T=2^19,
+Smoothstep) and ``fields/density_fields.py:89-94`` (5 levels, F=2, T=2^17,
+Linear).
+
+Published algorithm (restated):
+  per level l:  scale_l = exp2(l * log2(per_level_scale)) * base_res - 1  (fp32)
+                res_l   = ceil(scale_l) + 1
+                size_l  = min(next_multiple(res_l^3, 8), 2^log2_hashmap_size)
+  position:     pos = x * scale_l + 0.5 ; cell = floor(pos) ; w = pos - cell
+                Smoothstep: w <- w^2 (3 - 2 w)
+  corner index: dense  (res_l^3 <= size_l):  (cx + cy*res + cz*res^2)        mod size_l
+                hashed (otherwise):          (cx*1 ^ cy*2654435761 ^ cz*805459861) mod size_l   (uint32)
+  output:       [P, L*F] level-major, trilinear blend of the 8 corner feature vectors.
+Autograd supplies d/dx, d/dtable and the mixed second derivative.
+"""
+from dataclasses import dataclass
+from typing import List
+
+import numpy as np
+import torch
+
+PRIME_Y = 2654435761
+PRIME_Z = 805459861
+
+
+@dataclass
+class GridLevels:
+    n_levels: int
+    n_features: int
+    log2_hashmap_size: int
+    base_resolution: int
+    per_level_scale: float
+    smoothstep: bool
+    scale: np.ndarray  # float32 [L]
+    resolution: np.ndarray  # int64 [L]
+    size: np.ndarray  # int64 [L]  entries in level
+    offset: np.ndarray  # int64 [L+1] entry offsets
+    hashed: np.ndarray  # bool [L]
+
+    @property
+    def n_entries(self) -> int:
+        return int(self.offset[-1])
+
+    @property
+    def n_params(self) -> int:
+        return self.n_entries * self.n_features
+
+    @property
+    def n_output_dims(self) -> int:
+        return self.n_levels * self.n_features
+
+
+def make_levels(
+    n_levels: int,
+    n_features: int,
+    log2_hashmap_size: int,
+    base_resolution: int,
+    per_level_scale: float,
+    smoothstep: bool,
+) -> GridLevels:
+    """Per-level scale / resolution / table extent, in fp32 like tcnn's host code."""
+    l2 = np.log2(np.float32(per_level_scale)).astype(np.float32)
+    scale = np.zeros(n_levels, np.float32)
+    res = np.zeros(n_levels, np.int64)
+    size = np.zeros(n_levels, np.int64)
+    hashed = np.zeros(n_levels, bool)
+    offset = np.zeros(n_levels + 1, np.int64)
+    for lvl in range(n_levels):
+        s = np.float32(np.exp2(np.float32(lvl) * l2) * np.float32(base_resolution) - np.float32(1.0))
+        r = int(np.ceil(s)) + 1
+        n = r**3
+        n = (n + 7) // 8 * 8
+        n = min(n, 1 << log2_hashmap_size)
+        scale[lvl], res[lvl], size[lvl] = s, r, n
+        hashed[lvl] = r**3 > n
+        offset[lvl + 1] = offset[lvl] + n
+    return GridLevels(
+        n_levels, n_features, log2_hashmap_size, base_resolution, float(per_level_scale), smoothstep,
+        scale, res, size, offset, hashed,
+    )
+
+
+def corner_index(cx: torch.Tensor, cy: torch.Tensor, cz: torch.Tensor, res: int, size: int, hashed: bool):
+    """uint32 index arithmetic carried in int64."""
+    m = 0xFFFFFFFF
+    if hashed:
+        idx = (cx & m) ^ ((cy * PRIME_Y) & m) ^ ((cz * PRIME_Z) & m)
+    else:
+        idx = (cx + cy * res + cz * res * res) & m
+    return idx % size
+
+
+def grid_encode(x: torch.Tensor, table: torch.Tensor, lv: GridLevels) -> torch.Tensor:
+    """x: [P,3] in [0,1]; table: [n_entries, F]; returns [P, L*F]."""
+    outs: List[torch.Tensor] = []
+    for lvl in range(lv.n_levels):
+        scale = float(lv.scale[lvl])
+        res, size, off = int(lv.resolution[lvl]), int(lv.size[lvl]), int(lv.offset[lvl])
+        pos = x * scale + 0.5
+        cell = torch.floor(pos)
+        w = pos - cell
+        if lv.smoothstep:
+            w = w * w * (3.0 - 2.0 * w)
+        c = cell.detach().to(torch.int64)
+        acc = 0.0
+        for corner in range(8):
+            bx, by, bz = corner & 1, (corner >> 1) & 1, (corner >> 2) & 1
+            wx = w[:, 0] if bx else 1.0 - w[:, 0]
+            wy = w[:, 1] if by else 1.0 - w[:, 1]
+            wz = w[:, 2] if bz else 1.0 - w[:, 2]
+            idx = corner_index(c[:, 0] + bx, c[:, 1] + by, c[:, 2] + bz, res, size, bool(lv.hashed[lvl]))
+            acc = acc + (wx * wy * wz)[:, None] * table[off + idx]
+        outs.append(acc)
+    return torch.cat(outs, dim=-1)

@@ -1,0 +1,520 @@
+"""Oracle (test infrastructure): the NeuS-facto / SDF-field hot path restated in plain PyTorch.
+
+Functional, CPU, dtype follows the inputs (fp32 for golden vectors, fp64 for
+tie-breaking).  Each function cites the reference file:line it follows
+(paths relative to ``/root/reference/nerfstudio``).  Parameters are passed as a flat
+dict whose keys are the reference ``state_dict`` names (``glin0.weight_v`` ...), so a
+reference module's ``state_dict()`` can be dropped in unchanged.
+
+Tensor conventions differ from the reference on purpose (this is a restatement, not a
+copy): per-sample scalars are ``[N,S]`` (the reference carries a trailing 1), ray
+scalars are ``[N]``.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from oracle import hashgrid
+
+Params = Dict[str, torch.Tensor]
+
+
+# ----------------------------------------------------------------------------- config
+@dataclass
+class FieldCfg:
+    """Mirror of SDFFieldConfig (fields/sdf_field.py:121-185), only the knobs on the path."""
+
+    num_layers: int = 8
+    hidden_dim: int = 256
+    geo_feat_dim: int = 256
+    num_layers_color: int = 4
+    hidden_dim_color: int = 256
+    appearance_embedding_dim: int = 32
+    use_appearance_embedding: bool = False
+    bias: float = 0.5
+    inside_outside: bool = False
+    use_grid_feature: bool = True
+    beta_init: float = 0.3
+    position_encoding_max_degree: int = 6
+    use_position_encoding: bool = True
+    rgb_padding: float = 0.001
+    use_numerical_gradients: bool = False
+    num_levels: int = 16
+    max_res: int = 2048
+    base_res: int = 16
+    log2_hashmap_size: int = 19
+    hash_features_per_level: int = 2
+    hash_smoothstep: bool = True
+    skip_in: Tuple[int, ...] = (4,)
+
+    def growth_factor(self) -> float:
+        # sdf_field.py:226
+        return math.exp((math.log(self.max_res) - math.log(self.base_res)) / (self.num_levels - 1))
+
+    def grid_levels(self) -> hashgrid.GridLevels:
+        return hashgrid.make_levels(
+            self.num_levels, self.hash_features_per_level, self.log2_hashmap_size, self.base_res,
+            self.growth_factor(), self.hash_smoothstep,
+        )
+
+    def geo_in_dim(self) -> int:
+        return 3 + 3 * 2 * self.position_encoding_max_degree + self.num_levels * self.hash_features_per_level
+
+    def geo_dims(self) -> List[int]:
+        # sdf_field.py:279-282
+        return [self.geo_in_dim()] + [self.hidden_dim] * self.num_layers + [1 + self.geo_feat_dim]
+
+    def color_in_dim(self) -> int:
+        # sdf_field.py:338-347 (point, view dir PE, normal, feature, embedding)
+        return 3 + 27 + 3 + self.geo_feat_dim + self.appearance_embedding_dim
+
+    def color_dims(self) -> List[int]:
+        return [self.color_in_dim()] + [self.hidden_dim_color] * self.num_layers_color + [3]
+
+
+@dataclass
+class ProposalCfg:
+    """Mirror of HashMLPDensityField's ctor args (fields/density_fields.py:52-65) as used by neus_facto.py:59-64."""
+
+    hidden_dim: int = 16
+    num_levels: int = 5
+    max_res: int = 64
+    base_res: int = 16
+    log2_hashmap_size: int = 17
+    features_per_level: int = 2
+
+    def grid_levels(self) -> hashgrid.GridLevels:
+        g = math.exp((math.log(self.max_res) - math.log(self.base_res)) / (self.num_levels - 1))
+        return hashgrid.make_levels(
+            self.num_levels, self.features_per_level, self.log2_hashmap_size, self.base_res, g, False
+        )
+
+
+@dataclass
+class ModelCfg:
+    """The NeuS-facto knobs on the path (models/neus_facto.py:43-97, base_surface_model.py:69-134)."""
+
+    field: FieldCfg = field(default_factory=FieldCfg)
+    proposals: Tuple[ProposalCfg, ...] = (ProposalCfg(max_res=64), ProposalCfg(max_res=256))
+    num_proposal_samples: Tuple[int, ...] = (256, 96)
+    num_neus_samples: int = 128
+    eikonal_loss_mult: float = 0.1
+    interlevel_loss_mult: float = 1.0
+    near: float = 0.5
+    far: float = 4.5
+    histogram_padding: float = 0.01
+
+
+# ----------------------------------------------------------------------------- small pieces
+def nerf_encoding(x: torch.Tensor, num_frequencies: int, include_input: bool) -> torch.Tensor:
+    """field_components/encodings.py:167-208 with min_freq_exp=0, max_freq_exp=num_frequencies-1.
+
+    Layout: [sin(x_d * 2^f) for d, f] ++ [sin(x_d * 2^f + pi/2) for d, f] (++ x).
+    """
+    freqs = 2.0 ** torch.arange(num_frequencies, dtype=x.dtype, device=x.device)
+    scaled = (x[..., None] * freqs).reshape(*x.shape[:-1], -1)
+    enc = torch.sin(torch.cat([scaled, scaled + math.pi / 2.0], dim=-1))
+    if include_input:
+        enc = torch.cat([enc, x], dim=-1)
+    return enc
+
+
+def contract_inf(x: torch.Tensor) -> torch.Tensor:
+    """field_components/spatial_distortions.py:66-73 with order=inf (base_surface_model.py:148-155)."""
+    mag = x.abs().amax(dim=-1, keepdim=True)
+    safe = torch.where(mag >= 1, mag, torch.ones_like(mag))
+    return torch.where(mag >= 1, (2.0 - 1.0 / safe) * (x / safe), x)
+
+
+def fold_weight_norm(v: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
+    """torch.nn.utils.weight_norm(dim=0) as applied at sdf_field.py:312-313: W = g * v / ||v||_row."""
+    return g * v / v.norm(dim=1, keepdim=True)
+
+
+def linear_wn(p: Params, name: str, x: torch.Tensor) -> torch.Tensor:
+    if f"{name}.weight_v" in p:
+        w = fold_weight_norm(p[f"{name}.weight_v"], p[f"{name}.weight_g"])
+    else:
+        w = p[f"{name}.weight"]
+    return x @ w.t() + p[f"{name}.bias"]
+
+
+def softplus100(x: torch.Tensor) -> torch.Tensor:
+    return F.softplus(x, beta=100)
+
+
+# ----------------------------------------------------------------------------- SDF field
+def geo_network(x: torch.Tensor, p: Params, cfg: FieldCfg, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fields/sdf_field.py:380-410 forward_geonetwork.  x: [P,3] -> [P, 1+geo_feat_dim]."""
+    if cfg.use_grid_feature:
+        lv = cfg.grid_levels()
+        table = p["encoding.params"].view(lv.n_entries, lv.n_features)
+        feat = hashgrid.grid_encode((x + 2.0) / 4.0, table, lv)
+        if mask is not None:
+            feat = feat * mask.to(feat)
+    else:
+        feat = torch.zeros(x.shape[0], cfg.num_levels * cfg.hash_features_per_level, dtype=x.dtype)
+    pe = nerf_encoding(x, cfg.position_encoding_max_degree, include_input=False)
+    if not cfg.use_position_encoding:
+        pe = torch.zeros_like(pe)
+    inputs = torch.cat([x, pe, feat], dim=-1)
+    h = inputs
+    n_lin = cfg.num_layers + 1
+    for l in range(n_lin):
+        if l in cfg.skip_in:
+            h = torch.cat([h, inputs], dim=1) / math.sqrt(2)
+        h = linear_wn(p, f"glin{l}", h)
+        if l < n_lin - 1:
+            h = softplus100(h)
+    return h
+
+
+def sdf_and_gradient(x: torch.Tensor, p: Params, cfg: FieldCfg, mask=None, create_graph=True):
+    """fields/sdf_field.py:631-654: geonetwork under enable_grad, analytic d sdf / d x."""
+    x = x.detach().requires_grad_(True)
+    with torch.enable_grad():
+        h = geo_network(x, p, cfg, mask)
+        sdf = h[:, :1]
+        grad = torch.autograd.grad(sdf, x, torch.ones_like(sdf), create_graph=create_graph, retain_graph=True)[0]
+    return sdf[:, 0], h[:, 1:], grad
+
+
+def color_network(x, dirs, grad, feat, emb, p: Params, cfg: FieldCfg) -> torch.Tensor:
+    """fields/sdf_field.py:532-612 get_colors with the ref-nerf options off. Note the RAW gradient enters (572-578)."""
+    d = nerf_encoding(dirs, 4, include_input=True)
+    h = torch.cat([x, d, grad, feat, emb], dim=-1)
+    n_lin = cfg.num_layers_color + 1
+    for l in range(n_lin):
+        h = linear_wn(p, f"clin{l}", h)
+        if l < n_lin - 1:
+            h = torch.relu(h)
+    rgb = torch.sigmoid(h)
+    return rgb * (1 + 2 * cfg.rgb_padding) - cfg.rgb_padding
+
+
+def laplace_density(sdf: torch.Tensor, beta: torch.Tensor) -> torch.Tensor:
+    """fields/sdf_field.py:49-71. beta = |beta_param| + beta_min."""
+    return (1.0 / beta) * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta))
+
+
+def neus_inv_s(variance: torch.Tensor) -> torch.Tensor:
+    """fields/sdf_field.py:116-118."""
+    return torch.exp(variance * 10.0).clip(1e-6, 1e6)
+
+
+def neus_alpha(sdf, grad, dirs, deltas, inv_s, cos_anneal_ratio: float) -> torch.Tensor:
+    """fields/sdf_field.py:494-516.  sdf, deltas: [N,S]; grad: [N,S,3]; dirs: [N,3]."""
+    true_cos = (dirs[:, None, :] * grad).sum(-1)
+    iter_cos = -(F.relu(-true_cos * 0.5 + 0.5) * (1.0 - cos_anneal_ratio) + F.relu(-true_cos) * cos_anneal_ratio)
+    est_next = sdf + iter_cos * deltas * 0.5
+    est_prev = sdf - iter_cos * deltas * 0.5
+    prev_cdf = torch.sigmoid(est_prev * inv_s)
+    next_cdf = torch.sigmoid(est_next * inv_s)
+    return ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).clip(0.0, 1.0)
+
+
+def field_outputs(origins, dirs, starts, deltas, cam_idx, p: Params, cfg: FieldCfg, mask=None,
+                  cos_anneal_ratio: float = 1.0, training: bool = True) -> Dict[str, torch.Tensor]:
+    """fields/sdf_field.py:614-689 get_outputs(return_alphas=True) for a dense [N,S] sample set."""
+    n, s = starts.shape
+    pos = origins[:, None, :] + dirs[:, None, :] * starts[..., None]  # cameras/rays.py:61-73 (START positions)
+    x = contract_inf(pos.reshape(-1, 3))  # sdf_field.py:629
+    points_norm = x.norm(dim=-1)
+    sdf, feat, grad = sdf_and_gradient(x, p, cfg, mask)
+    dirs_flat = dirs[:, None, :].expand(n, s, 3).reshape(-1, 3)
+    if training and cfg.use_appearance_embedding:
+        emb = p["embedding_appearance.embedding.weight"][cam_idx][:, None, :].expand(n, s, -1).reshape(n * s, -1)
+    else:
+        emb = torch.zeros(n * s, cfg.appearance_embedding_dim, dtype=x.dtype)  # sdf_field.py:554-564
+    rgb = color_network(x, dirs_flat, grad, feat, emb, p, cfg)
+    beta = p["laplace_density.beta"].abs() + p["laplace_density.beta_min"]
+    density = laplace_density(sdf, beta)
+    inv_s = neus_inv_s(p["deviation_network.variance"])
+    alpha = neus_alpha(sdf.view(n, s), grad.view(n, s, 3), dirs, deltas, inv_s, cos_anneal_ratio)
+    return {
+        "rgb": rgb.view(n, s, 3), "density": density.view(n, s), "sdf": sdf.view(n, s),
+        "gradient": grad.view(n, s, 3), "normal": F.normalize(grad, p=2, dim=-1).view(n, s, 3),
+        "points_norm": points_norm.view(n, s), "alpha": alpha, "geo_feature": feat.view(n, s, -1),
+    }
+
+
+# ----------------------------------------------------------------------------- proposal density
+def proposal_density(positions: torch.Tensor, p: Params, prefix: str, cfg: ProposalCfg) -> torch.Tensor:
+    """fields/density_fields.py:99-118 (+ base_field.py:48-65): contraction, (x+2)/4, grid -> ReLU MLP -> exp."""
+    shape = positions.shape[:-1]
+    x = (contract_inf(positions.reshape(-1, 3)) + 2.0) / 4.0
+    lv = cfg.grid_levels()
+    feat = hashgrid.grid_encode(x, p[f"{prefix}.table"].view(lv.n_entries, lv.n_features), lv)
+    pre = torch.relu(feat @ p[f"{prefix}.w1"].t()) @ p[f"{prefix}.w2"].t()
+    return trunc_exp(pre[:, 0]).view(shape)
+
+
+class _TruncExp(torch.autograd.Function):
+    """field_components/activations.py:23-39: exp forward, backward clamps the exponent to [-15,15]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return g * torch.exp(x.clamp(-15, 15))
+
+
+trunc_exp = _TruncExp.apply
+
+
+# ----------------------------------------------------------------------------- weights + renderers
+def weights_from_density(density: torch.Tensor, deltas: torch.Tensor) -> torch.Tensor:
+    """cameras/rays.py:146-167."""
+    dd = deltas * density
+    acc = torch.cumsum(dd[:, :-1], dim=-1)
+    trans = torch.exp(-torch.cat([torch.zeros_like(dd[:, :1]), acc], dim=-1))
+    return (1 - torch.exp(-dd)) * trans
+
+
+def weights_from_alphas(alpha: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """cameras/rays.py:194-230: T = exclusive cumprod(1 - alpha + 1e-7). Returns weights [N,S], T [N,S+1]."""
+    trans = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-7], dim=1), dim=1)
+    return alpha * trans[:, :-1], trans
+
+
+def render(weights, rgb, normals, starts, ends, background: Optional[torch.Tensor] = None):
+    """model_components/renderers.py:81-92 (rgb), 196 (accumulation), 245-259 (expected depth), 294 (normals)."""
+    acc = weights.sum(dim=1)
+    out_rgb = (weights[..., None] * rgb).sum(dim=1)
+    if background is not None:
+        out_rgb = out_rgb + background * (1.0 - acc[:, None])
+    steps = (starts + ends) / 2
+    depth = (weights * steps).sum(dim=1) / (acc + 1e-10)
+    depth = torch.clip(depth, steps.min(), steps.max())
+    normal = (weights[..., None] * normals).sum(dim=1)
+    return out_rgb, depth, normal, acc
+
+
+# ----------------------------------------------------------------------------- samplers
+def piecewise_spacing(x: torch.Tensor) -> torch.Tensor:
+    """ray_samplers.py:240 spacing_fn of UniformLinDispPiecewiseSampler."""
+    return torch.where(x < 1, x / 2, 1 - 1 / (2 * x))
+
+
+def piecewise_spacing_inv(x: torch.Tensor) -> torch.Tensor:
+    """ray_samplers.py:241."""
+    return torch.where(x < 0.5, 2 * x, 1 / (2 - 2 * x))
+
+
+def spacing_to_euclidean(bins: torch.Tensor, nears: torch.Tensor, fars: torch.Tensor) -> torch.Tensor:
+    """ray_samplers.py:115-117."""
+    s_near, s_far = piecewise_spacing(nears)[:, None], piecewise_spacing(fars)[:, None]
+    return piecewise_spacing_inv(bins * s_far + (1 - bins) * s_near)
+
+
+def initial_bins(n_rays: int, num_samples: int, t_rand: Optional[torch.Tensor], dtype=torch.float32):
+    """ray_samplers.py:101-113. t_rand: [N,1] single-jitter draw, or None for eval-mode (deterministic) bins."""
+    bins = torch.linspace(0.0, 1.0, num_samples + 1, dtype=dtype)[None, :].expand(n_rays, -1)
+    if t_rand is not None:
+        centers = (bins[:, 1:] + bins[:, :-1]) / 2.0
+        upper = torch.cat([centers, bins[:, -1:]], -1)
+        lower = torch.cat([bins[:, :1], centers], -1)
+        bins = lower + (upper - lower) * t_rand
+    return bins
+
+
+def pdf_sample(weights: torch.Tensor, existing_bins: torch.Tensor, num_samples: int,
+               u_rand: Optional[torch.Tensor], histogram_padding: float = 0.01, eps: float = 1e-5) -> torch.Tensor:
+    """ray_samplers.py:303-358, include_original=False.  weights [N,S_in], existing_bins [N,S_in+1] (spacing).
+
+    u_rand: [N,1] uniform draw (single jitter) or None (eval: bin centres).  Returns new bins [N,num_samples+1].
+    """
+    num_bins = num_samples + 1
+    w = weights + histogram_padding
+    w_sum = w.sum(dim=-1, keepdim=True)
+    padding = torch.relu(eps - w_sum)
+    w = w + padding / w.shape[-1]
+    w_sum = w_sum + padding
+    pdf = w / w_sum
+    cdf = torch.min(torch.ones_like(pdf), torch.cumsum(pdf, dim=-1))
+    cdf = torch.cat([torch.zeros_like(cdf[:, :1]), cdf], dim=-1)
+    u = torch.linspace(0.0, 1.0 - (1.0 / num_bins), steps=num_bins, dtype=w.dtype)
+    if u_rand is not None:
+        u = u[None, :] + u_rand / num_bins
+    else:
+        u = (u + 1.0 / (2 * num_bins))[None, :].expand(w.shape[0], -1)
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u, side="right")
+    hi = existing_bins.shape[-1] - 1
+    below = torch.clamp(inds - 1, 0, hi)
+    above = torch.clamp(inds, 0, hi)
+    cdf_g0, cdf_g1 = torch.gather(cdf, -1, below), torch.gather(cdf, -1, above)
+    b_g0, b_g1 = torch.gather(existing_bins, -1, below), torch.gather(existing_bins, -1, above)
+    t = torch.clip(torch.nan_to_num((u - cdf_g0) / (cdf_g1 - cdf_g0), 0), 0, 1)
+    return (b_g0 + t * (b_g1 - b_g0)).detach()
+
+
+def proposal_sampler(origins, dirs, nears, fars, p: Params, cfg: ModelCfg, anneal: float,
+                     rand: Optional[List[torch.Tensor]]):
+    """ray_samplers.py:537-578 with update_sched == -1 (neus_facto.py:138): proposal nets always in the graph.
+
+    rand: [t_rand0 [N,1], u_rand1 [N,1], u_rand2 [N,1]] for training-mode jitter, or None for eval-mode.
+    Returns final (bins, starts, ends) and the per-level lists used by the interlevel loss.
+    """
+    n = origins.shape[0]
+    weights_list, bins_list = [], []
+    bins = initial_bins(n, cfg.num_proposal_samples[0], None if rand is None else rand[0], origins.dtype)
+    weights = None
+    n_prop = len(cfg.proposals)
+    for lvl in range(n_prop + 1):
+        if lvl > 0:
+            ns = cfg.num_proposal_samples[lvl] if lvl < n_prop else cfg.num_neus_samples
+            bins = pdf_sample(torch.pow(weights, anneal), bins, ns, None if rand is None else rand[lvl],
+                              cfg.histogram_padding)
+        eu = spacing_to_euclidean(bins, nears, fars)
+        starts, ends = eu[:, :-1], eu[:, 1:]
+        if lvl < n_prop:
+            mid = origins[:, None, :] + dirs[:, None, :] * ((starts + ends) / 2)[..., None]  # rays.py:46-55 MIDPOINT
+            dens = proposal_density(mid, p, f"proposal_networks.{lvl}", cfg.proposals[lvl])
+            weights = weights_from_density(dens, ends - starts)
+            weights_list.append(weights)
+            bins_list.append(bins)
+    return bins, starts, ends, weights_list, bins_list
+
+
+# ----------------------------------------------------------------------------- losses
+def _blur_stepfun(x, y, r):
+    """model_components/losses.py:116-128."""
+    xc = torch.cat([x - r, x + r], dim=-1)
+    xr, idx = torch.sort(xc, dim=-1)
+    zeros = torch.zeros_like(y[:, :1])
+    y1 = (torch.cat([y, zeros], dim=-1) - torch.cat([zeros, y], dim=-1)) / (2 * r)
+    y2 = torch.gather(torch.cat([y1, -y1], dim=-1), -1, idx[:, :-1])
+    yr = torch.cumsum((xr[:, 1:] - xr[:, :-1]) * torch.cumsum(y2, dim=-1), dim=-1)
+    return xr, torch.cat([zeros, yr], dim=-1)
+
+
+def interlevel_loss_zip(weights_list: List[torch.Tensor], bins_list: List[torch.Tensor]) -> torch.Tensor:
+    """model_components/losses.py:131-172. Last entries are the (detached) field weights / bins."""
+    c = bins_list[-1].detach()
+    w = weights_list[-1].detach()
+    wn = w / (c[:, 1:] - c[:, :-1])
+    loss = 0.0
+    for cp, wp, r in zip(bins_list[:-1], weights_list[:-1], [0.03, 0.003]):
+        xr, yr = _blur_stepfun(c, wn, r)
+        yr = torch.clip(yr, min=0)
+        ycum = torch.cumsum((yr[:, 1:] + yr[:, :-1]) * 0.5 * (xr[:, 1:] - xr[:, :-1]), dim=-1)
+        ycum = torch.cat([torch.zeros_like(ycum[:, :1]), ycum], dim=-1)
+        inds = torch.searchsorted(xr, cp.contiguous(), side="right")
+        below = torch.clamp(inds - 1, 0, xr.shape[-1] - 1)
+        above = torch.clamp(inds, 0, xr.shape[-1] - 1)
+        x0, x1 = torch.gather(xr, -1, below), torch.gather(xr, -1, above)
+        y0, y1 = torch.gather(ycum, -1, below), torch.gather(ycum, -1, above)
+        t = torch.clip(torch.nan_to_num((cp - x0) / (x1 - x0), 0), 0, 1)
+        b = y0 + t * (y1 - y0)
+        w_gt = b[:, 1:] - b[:, :-1]
+        loss = loss + torch.mean(torch.clip(w_gt - wp, min=0) ** 2 / (wp + 1e-5))
+    return loss
+
+
+# ----------------------------------------------------------------------------- full model step
+def neus_facto_forward(origins, dirs, cam_idx, p: Params, cfg: ModelCfg, anneal: float = 1.0,
+                       cos_anneal_ratio: float = 1.0, rand=None, mask=None, training=True):
+    """models/neus_facto.py:282-302 + base_surface_model.py:292-365 with background_model == 'none', black bg."""
+    n = origins.shape[0]
+    nears = torch.full((n,), cfg.near, dtype=origins.dtype)  # scene_colliders.py:124-129
+    fars = torch.full((n,), cfg.far, dtype=origins.dtype)
+    bins, starts, ends, weights_list, bins_list = proposal_sampler(origins, dirs, nears, fars, p, cfg, anneal, rand)
+    deltas = ends - starts
+    fo = field_outputs(origins, dirs, starts, deltas, cam_idx, p, cfg.field, mask, cos_anneal_ratio, training)
+    weights, trans = weights_from_alphas(fo["alpha"])
+    rgb, depth, normal, acc = render(weights, fo["rgb"], fo["normal"], starts, ends)
+    return {
+        "rgb": rgb, "depth": depth, "normal": normal, "accumulation": acc, "weights": weights,
+        "field": fo, "starts": starts, "ends": ends, "bins": bins,
+        "weights_list": weights_list + [weights], "bins_list": bins_list + [bins],
+    }
+
+
+def neus_facto_loss(out, image, cfg: ModelCfg) -> Dict[str, torch.Tensor]:
+    """base_surface_model.py:399-406 (L1 rgb, eikonal) + neus_facto.py:304-310 (interlevel)."""
+    g = out["field"]["gradient"]
+    return {
+        "rgb_loss": F.l1_loss(out["rgb"], image),
+        "eikonal_loss": ((g.norm(2, dim=-1) - 1) ** 2).mean() * cfg.eikonal_loss_mult,
+        "interlevel_loss": cfg.interlevel_loss_mult * interlevel_loss_zip(out["weights_list"], out["bins_list"]),
+    }
+
+
+# ----------------------------------------------------------------------------- parameter init
+def init_field_params(cfg: FieldCfg, num_images: int = 49, seed: int = 0, dtype=torch.float32) -> Params:
+    """Geometric init of fields/sdf_field.py:286-313, colour init :354-363, grid U(-1e-4,1e-4) (tcnn default)."""
+    g = torch.Generator().manual_seed(seed)
+    p: Params = {}
+    dims = cfg.geo_dims()
+    n_lin = len(dims) - 1
+    for l in range(n_lin):
+        out_dim = dims[l + 1] - dims[0] if (l + 1) in cfg.skip_in else dims[l + 1]
+        w = torch.zeros(out_dim, dims[l])
+        b = torch.zeros(out_dim)
+        if l == n_lin - 1:
+            sign = -1.0 if cfg.inside_outside else 1.0
+            w.normal_(mean=sign * math.sqrt(math.pi) / math.sqrt(dims[l]), std=0.0001, generator=g)
+            b.fill_(-sign * cfg.bias)
+        elif l == 0:
+            w[:, :3].normal_(0.0, math.sqrt(2) / math.sqrt(out_dim), generator=g)
+        elif l in cfg.skip_in:
+            w.normal_(0.0, math.sqrt(2) / math.sqrt(out_dim), generator=g)
+            w[:, -(dims[0] - 3):] = 0.0
+        else:
+            w.normal_(0.0, math.sqrt(2) / math.sqrt(out_dim), generator=g)
+        p[f"glin{l}.weight_v"] = w
+        p[f"glin{l}.weight_g"] = w.norm(dim=1, keepdim=True)
+        p[f"glin{l}.bias"] = b
+    cd = cfg.color_dims()
+    for l in range(len(cd) - 1):
+        bound = math.sqrt(6.0 / cd[l])  # kaiming_uniform_, a=0, fan_in
+        w = (torch.rand(cd[l + 1], cd[l], generator=g) * 2 - 1) * bound
+        p[f"clin{l}.weight_v"] = w
+        p[f"clin{l}.weight_g"] = w.norm(dim=1, keepdim=True)
+        p[f"clin{l}.bias"] = torch.zeros(cd[l + 1])
+    lv = cfg.grid_levels()
+    p["encoding.params"] = (torch.rand(lv.n_params, generator=g) * 2 - 1) * 1e-4
+    p["laplace_density.beta"] = torch.full((1,), cfg.beta_init)
+    p["laplace_density.beta_min"] = torch.full((1,), 1e-4)
+    p["deviation_network.variance"] = torch.full((1,), cfg.beta_init)
+    p["embedding_appearance.embedding.weight"] = torch.randn(num_images, cfg.appearance_embedding_dim, generator=g)
+    return {k: v.to(dtype) for k, v in p.items()}
+
+
+def init_proposal_params(cfgs, seed: int = 1, dtype=torch.float32) -> Params:
+    g = torch.Generator().manual_seed(seed)
+    p: Params = {}
+    for i, c in enumerate(cfgs):
+        lv = c.grid_levels()
+        d_in = lv.n_output_dims
+        p[f"proposal_networks.{i}.table"] = (torch.rand(lv.n_params, generator=g) * 2 - 1) * 1e-4
+        a1 = math.sqrt(6.0 / (d_in + c.hidden_dim))
+        p[f"proposal_networks.{i}.w1"] = (torch.rand(c.hidden_dim, d_in, generator=g) * 2 - 1) * a1
+        a2 = math.sqrt(6.0 / (c.hidden_dim + 1))
+        p[f"proposal_networks.{i}.w2"] = (torch.rand(1, c.hidden_dim, generator=g) * 2 - 1) * a2
+    return {k: v.to(dtype) for k, v in p.items()}
+
+
+def synthetic_rays(n: int, seed: int = 42, radius: float = 2.73, dtype=torch.float32):
+    """cameras on a sphere of radius ~2.73 looking at the origin, pinhole jitter."""
+    g = torch.Generator().manual_seed(seed)
+    cam = torch.randint(0, 49, (n,), generator=g)
+    # 49 camera centres on the upper hemisphere
+    k = torch.arange(49, dtype=torch.float64)
+    phi = k * 2.399963229728653  # golden angle
+    z = 0.15 + 0.7 * (k + 0.5) / 49
+    r = torch.sqrt(1 - z * z)
+    centers = torch.stack([r * torch.cos(phi), r * torch.sin(phi), z], dim=-1) * radius
+    o = centers[cam]
+    target = (torch.rand(n, 3, generator=g, dtype=torch.float64) * 2 - 1) * 0.6
+    d = target - o
+    d = d / d.norm(dim=-1, keepdim=True)
+    return o.to(dtype), d.to(dtype), cam

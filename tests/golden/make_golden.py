@@ -1,0 +1,243 @@
+"""Mint the golden vectors by running the REFERENCE's own Python (build container only).
+
+    python tests/golden/make_golden.py            # writes tests/golden/neus_facto_small_{train,eval}.npz
+
+What it does
+  1. imports ``/root/reference/nerfstudio`` unmodified through ``oracle.ref_harness`` (stub modules for the
+     absent third-party packages + the documented PyTorch ``tinycudann`` shim for the hash grid);
+  2. builds the reference ``SDFField`` (fields/sdf_field.py), two ``HashMLPDensityField`` (fields/density_fields.py),
+     ``ProposalNetworkSampler`` (model_components/ray_samplers.py:497), the renderers (model_components/renderers.py)
+     and ``interlevel_loss_zip`` (model_components/losses.py:131), loads seeded parameters, and runs
+     sample -> field -> weights -> render -> loss -> backward exactly as ``NeuSFactoModel`` does
+     (models/neus_facto.py:282-310, models/base_surface_model.py:292-406);
+  3. runs ``oracle.sdf_path`` on the same inputs and asserts it reproduces the reference (this pins the oracle);
+  4. stores inputs, parameters, every output and every parameter gradient as a small ``.npz``.
+
+The stratified-sampling draws (``torch.rand`` at ray_samplers.py:107,326) are injected so both sides see the same u.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle import ref_harness, sdf_path as O  # noqa: E402
+
+torch.set_float32_matmul_precision("highest")
+
+
+def small_cfg() -> O.ModelCfg:
+    f = O.FieldCfg(
+        num_layers=8, hidden_dim=64, geo_feat_dim=64, num_layers_color=4, hidden_dim_color=64,
+        bias=0.5, inside_outside=False, use_grid_feature=True, beta_init=0.3,
+        num_levels=8, max_res=128, base_res=4, log2_hashmap_size=11, hash_features_per_level=2, hash_smoothstep=True,
+    )
+    props = (
+        O.ProposalCfg(hidden_dim=16, num_levels=5, max_res=32, base_res=4, log2_hashmap_size=9),
+        O.ProposalCfg(hidden_dim=16, num_levels=5, max_res=64, base_res=4, log2_hashmap_size=9),
+    )
+    return O.ModelCfg(field=f, proposals=props, num_proposal_samples=(32, 24), num_neus_samples=16)
+
+
+def perturbed_params(cfg: O.ModelCfg, seed=0):
+    """Geometric init + noise everywhere, so that no input column / table entry is dead in the test."""
+    g = torch.Generator().manual_seed(seed + 100)
+    p = O.init_field_params(cfg.field, num_images=49, seed=seed)
+    p.update(O.init_proposal_params(cfg.proposals, seed=seed + 1))
+    for k in list(p.keys()):
+        if k.endswith("weight_v"):
+            p[k] = p[k] + 0.05 * torch.randn(p[k].shape, generator=g)
+        elif k.endswith("weight_g"):
+            p[k] = p[k] * (1.0 + 0.1 * torch.randn(p[k].shape, generator=g))
+        elif k.endswith(".bias"):
+            p[k] = p[k] + 0.02 * torch.randn(p[k].shape, generator=g)
+        elif k.endswith("encoding.params") or k.endswith(".table"):
+            p[k] = (torch.rand(p[k].shape, generator=g) * 2 - 1) * 0.3
+    return p
+
+
+def build_reference(ns, cfg: O.ModelCfg, p):
+    fc = cfg.field
+    rcfg = ns.sf.SDFFieldConfig(
+        num_layers=fc.num_layers, hidden_dim=fc.hidden_dim, geo_feat_dim=fc.geo_feat_dim,
+        num_layers_color=fc.num_layers_color, hidden_dim_color=fc.hidden_dim_color, bias=fc.bias,
+        inside_outside=fc.inside_outside, use_grid_feature=True, beta_init=fc.beta_init, num_levels=fc.num_levels,
+        max_res=fc.max_res, base_res=fc.base_res, log2_hashmap_size=fc.log2_hashmap_size,
+        hash_features_per_level=fc.hash_features_per_level, hash_smoothstep=fc.hash_smoothstep,
+    )
+    aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+    contraction = ns.sd.SceneContraction(order=float("inf"))
+    field = ns.sf.SDFField(rcfg, aabb, num_images=49, spatial_distortion=contraction)
+    sd = field.state_dict()
+    for k in sd:
+        if k in p:
+            assert sd[k].shape == p[k].shape, (k, sd[k].shape, p[k].shape)
+            sd[k] = p[k].clone()
+    field.load_state_dict(sd)
+    nets = []
+    for i, pc in enumerate(cfg.proposals):
+        net = ns.df.HashMLPDensityField(
+            aabb, spatial_distortion=contraction, hidden_dim=pc.hidden_dim, num_levels=pc.num_levels,
+            max_res=pc.max_res, base_res=pc.base_res, log2_hashmap_size=pc.log2_hashmap_size,
+            features_per_level=pc.features_per_level,
+        )
+        with torch.no_grad():
+            net.mlp_base.encoding.params.copy_(p[f"proposal_networks.{i}.table"])
+            net.mlp_base.w1.copy_(p[f"proposal_networks.{i}.w1"])
+            net.mlp_base.w2.copy_(p[f"proposal_networks.{i}.w2"])
+        nets.append(net)
+    sampler = ns.rs.ProposalNetworkSampler(
+        num_nerf_samples_per_ray=cfg.num_neus_samples, num_proposal_samples_per_ray=cfg.num_proposal_samples,
+        num_proposal_network_iterations=len(cfg.proposals), single_jitter=True, update_sched=lambda step: -1,
+    )
+    return field, nets, sampler
+
+
+class _RandQueue:
+    """Replays preset tensors for torch.rand so the reference's stratified jitter is reproducible."""
+
+    def __init__(self, items):
+        self.items = list(items)
+        self._orig = torch.rand
+
+    def __enter__(self):
+        def fake(*size, **kw):
+            t = self.items.pop(0)
+            shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else size
+            assert tuple(t.shape) == tuple(shape), (t.shape, shape)
+            return t.clone()
+
+        torch.rand = fake
+        return self
+
+    def __exit__(self, *a):
+        torch.rand = self._orig
+
+
+def run_reference(ns, field, nets, sampler, cfg, origins, dirs, cam, image, rand, training, cos_anneal, anneal):
+    H = ns.FieldHeadNames
+    for m in [field, sampler, *nets]:
+        m.train(training)
+    field.set_cos_anneal_ratio(cos_anneal)
+    sampler.set_anneal(anneal)
+    n = origins.shape[0]
+    rb = ns.rays.RayBundle(
+        origins=origins, directions=dirs, pixel_area=torch.ones(n, 1), directions_norm=torch.ones(n, 1),
+        camera_indices=cam[:, None], nears=torch.full((n, 1), cfg.near), fars=torch.full((n, 1), cfg.far),
+    )
+    with _RandQueue(rand if training else []):
+        ray_samples, weights_list, rs_list = sampler(rb, density_fns=[m.density_fn for m in nets])
+    fo = field(ray_samples, return_alphas=True)
+    weights = ray_samples.get_weights_from_alphas(fo[H.ALPHA])
+    rgb_r = ns.rd.RGBRenderer(background_color=torch.zeros(3))
+    rgb_r.train(training)
+    rgb = rgb_r(rgb=fo[H.RGB], weights=weights)
+    depth = ns.rd.DepthRenderer(method="expected")(weights=weights, ray_samples=ray_samples)
+    normal = ns.rd.SemanticRenderer()(semantics=fo[H.NORMAL], weights=weights)
+    acc = ns.rd.AccumulationRenderer()(weights=weights)
+    out = {
+        "starts": ray_samples.frustums.starts[..., 0], "ends": ray_samples.frustums.ends[..., 0],
+        "bins": torch.cat([ray_samples.spacing_starts[..., 0], ray_samples.spacing_ends[..., -1:, 0]], -1),
+        "sdf": fo[H.SDF][..., 0], "gradient": fo[H.GRADIENT], "field_rgb": fo[H.RGB], "alpha": fo[H.ALPHA][..., 0],
+        "density": fo[H.DENSITY][..., 0], "field_normal": fo[H.NORMAL], "points_norm": fo["points_norm"][..., 0],
+        "weights": weights[..., 0], "rgb": rgb, "depth": depth[..., 0], "normal": normal, "accumulation": acc[..., 0],
+        "prop_weights0": weights_list[0][..., 0], "prop_weights1": weights_list[1][..., 0],
+    }
+    losses = {}
+    if training:
+        losses["rgb_loss"] = torch.nn.L1Loss()(image, rgb)
+        losses["eikonal_loss"] = ((fo[H.GRADIENT].norm(2, dim=-1) - 1) ** 2).mean() * cfg.eikonal_loss_mult
+        losses["interlevel_loss"] = cfg.interlevel_loss_mult * ns.losses.interlevel_loss_zip(
+            weights_list + [weights], rs_list + [ray_samples]
+        )
+    return out, losses
+
+
+def main():
+    ns = ref_harness.import_reference()
+    cfg = small_cfg()
+    p = perturbed_params(cfg)
+    n = 64
+    origins, dirs, cam = O.synthetic_rays(n, seed=42)
+    g = torch.Generator().manual_seed(7)
+    image = torch.rand(n, 3, generator=g)
+    rand = [torch.rand(n, 1, generator=g) for _ in range(3)]
+    cos_anneal, anneal = 0.3, 0.7
+    field, nets, sampler = build_reference(ns, cfg, p)
+
+    for mode in ("train", "eval"):
+        training = mode == "train"
+        out, losses = run_reference(ns, field, nets, sampler, cfg, origins, dirs, cam, image, rand, training,
+                                    cos_anneal, anneal)
+        ref_grads = {}
+        if training:
+            for m in [field, *nets]:
+                m.zero_grad()
+            total = sum(losses.values())
+            total.backward()
+            for k, v in field.named_parameters():
+                if v.grad is not None:
+                    ref_grads[k] = v.grad.clone()
+            for i, m in enumerate(nets):
+                ref_grads[f"proposal_networks.{i}.table"] = m.mlp_base.encoding.params.grad.clone()
+                ref_grads[f"proposal_networks.{i}.w1"] = m.mlp_base.w1.grad.clone()
+                ref_grads[f"proposal_networks.{i}.w2"] = m.mlp_base.w2.grad.clone()
+
+        # ---- oracle on the same inputs; must reproduce the reference -------------------------------------
+        po = {k: v.clone().requires_grad_(v.is_floating_point() and k != "laplace_density.beta_min")
+              for k, v in p.items()}
+        o = O.neus_facto_forward(origins, dirs, cam, po, cfg, anneal=anneal, cos_anneal_ratio=cos_anneal,
+                                 rand=rand if training else None, training=training)
+        if not training:
+            o["rgb"] = o["rgb"].clamp(0.0, 1.0)  # renderers.py:116-117
+        omap = {
+            "starts": o["starts"], "ends": o["ends"], "bins": o["bins"], "sdf": o["field"]["sdf"],
+            "gradient": o["field"]["gradient"], "field_rgb": o["field"]["rgb"], "alpha": o["field"]["alpha"],
+            "density": o["field"]["density"], "field_normal": o["field"]["normal"],
+            "points_norm": o["field"]["points_norm"], "weights": o["weights"], "rgb": o["rgb"], "depth": o["depth"],
+            "normal": o["normal"], "accumulation": o["accumulation"], "prop_weights0": o["weights_list"][0],
+            "prop_weights1": o["weights_list"][1],
+        }
+        worst = 0.0
+        for k, v in out.items():
+            err = (omap[k].detach() - v.detach()).abs().max().item()
+            scale = v.detach().abs().max().item() + 1e-12
+            worst = max(worst, err / scale)
+            # expected depth divides by the accumulated weight (renderers.py:255): ill-conditioned on empty rays
+            tol = 1e-4 if k == "depth" else 2e-5
+            assert err <= tol * scale + 1e-6, f"oracle != reference on {k}: abs {err:.3e} (scale {scale:.3e})"
+        if training:
+            ol = O.neus_facto_loss(o, image, cfg)
+            for k in losses:
+                assert abs(ol[k].item() - losses[k].item()) <= 1e-5 * abs(losses[k].item()) + 1e-8, k
+            sum(ol.values()).backward()
+            for k, gref in ref_grads.items():
+                gor = po[k].grad
+                err = (gor - gref).abs().max().item()
+                scale = gref.abs().max().item() + 1e-12
+                worst = max(worst, err / scale)
+                assert err <= 1e-3 * scale + 1e-9, f"oracle grad != reference on {k}: {err:.3e} / {scale:.3e}"
+        print(f"[{mode}] oracle reproduces the reference; worst rel err {worst:.2e}")
+
+        blob = {"in/origins": origins, "in/dirs": dirs, "in/cam": cam, "in/image": image,
+                "in/cos_anneal": torch.tensor(cos_anneal), "in/anneal": torch.tensor(anneal)}
+        for i, r in enumerate(rand):
+            blob[f"in/rand{i}"] = r
+        for k, v in p.items():
+            blob[f"param/{k}"] = v
+        for k, v in out.items():
+            blob[f"out/{k}"] = v.detach()
+        for k, v in losses.items():
+            blob[f"loss/{k}"] = v.detach()
+        for k, v in ref_grads.items():
+            blob[f"grad/{k}"] = v
+        path = os.path.join(HERE, f"neus_facto_small_{mode}.npz")
+        np.savez_compressed(path, **{k: v.numpy() for k, v in blob.items()})
+        print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()
