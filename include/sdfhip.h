@@ -1,0 +1,164 @@
+/* sdfhip — C ABI of the MI355X-native SDF volume-rendering hot path (libsdfhip.so, gfx950).
+ *
+ * Drop-in boundary for sdfstudio's Field / Sampler / Renderer plugin surface.  Each entry point names the
+ * reference interface it replaces (paths relative to the upstream `nerfstudio/` package).  Conventions:
+ *   - plain C, device pointers + sizes only, no torch / C++ types; row-major contiguous fp32 unless stated;
+ *   - every call takes the HIP stream to launch on (pass torch's current stream) and never synchronises;
+ *   - no hidden allocation on the hot path: the caller owns workspaces (sizes from the *_size queries);
+ *     only *_create allocates (small immutable descriptor tables);
+ *   - returns 0 on success, negative on error; sdfhip_last_error() returns a thread-local message;
+ *   - per-point outputs are sized to sdfhip_padded_points(P) (P rounded up to 128) rows.
+ */
+#ifndef SDFHIP_H_
+#define SDFHIP_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sdfhip_stream_t; /* hipStream_t */
+
+int sdfhip_version(void);
+const char* sdfhip_last_error(void);
+int64_t sdfhip_padded_points(int64_t n_points);
+
+/* ---------------------------------------------------------------------------------------------- hash grid
+ * Replaces tcnn.Encoding(otype="HashGrid") as configured at fields/sdf_field.py:230-241 and
+ * fields/density_fields.py:75-94 (n_levels, n_features_per_level, log2_hashmap_size, base_resolution,
+ * per_level_scale, interpolation). */
+typedef struct {
+  int32_t n_levels;            /* <= 16 */
+  int32_t n_features;          /* 2 */
+  int32_t log2_hashmap_size;
+  int32_t base_resolution;
+  float per_level_scale;
+  int32_t smoothstep;          /* 1: Smoothstep, 0: Linear */
+} SdfHipGridCfg;
+
+typedef struct {
+  float scale;
+  uint32_t resolution;
+  uint32_t size;    /* entries */
+  uint32_t offset;  /* first entry */
+  uint32_t hashed;
+} SdfHipGridLevel;
+
+/* Host-only: per-level table (no GPU needed). levels: [n_levels]. Returns total entries via n_entries. */
+int sdfhip_grid_levels(const SdfHipGridCfg* cfg, SdfHipGridLevel* levels, int64_t* n_entries);
+
+/* ---------------------------------------------------------------------------------------------- SDF field
+ * Replaces nerfstudio.fields.sdf_field.SDFField's compute: forward_geonetwork (:380-410), get_sdf (:412-418),
+ * the analytic gradient (:646-654), get_colors (:532-612), and their autograd backward (including the
+ * double-backward of the gradient path). */
+typedef struct {
+  int32_t num_layers;            /* SDFFieldConfig.num_layers (hidden layers of the geometry MLP) */
+  int32_t hidden_dim;
+  int32_t geo_feat_dim;
+  int32_t num_layers_color;
+  int32_t hidden_dim_color;
+  int32_t skip_layer;            /* 4 (SDFField.skip_in) or -1 when num_layers < 4 */
+  int32_t pe_degree;             /* position_encoding_max_degree */
+  int32_t use_position_encoding;
+  int32_t appearance_dim;        /* appearance_embedding_dim */
+  int32_t contract;              /* 1: SceneContraction(order=inf) on the sample positions, 0: none */
+  float rgb_padding;
+  SdfHipGridCfg grid;
+} SdfHipFieldCfg;
+
+typedef struct SdfHipField SdfHipField;
+
+int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out);
+void sdfhip_field_destroy(SdfHipField* f);
+
+/* Flat EFFECTIVE (weight-norm folded) parameter vector theta: for each geometry layer l = 0..num_layers
+ * (glin{l}): W [out,in] row-major then b [out]; then each colour layer (clin{l}) likewise.
+ * n_linear = (num_layers + 1) + (num_layers_color + 1). w_off/b_off/out_dim/in_dim: [n_linear]. */
+int64_t sdfhip_field_theta_size(const SdfHipField* f);
+int32_t sdfhip_field_num_linear(const SdfHipField* f);
+int sdfhip_field_theta_layout(const SdfHipField* f, int64_t* w_off, int64_t* b_off, int32_t* out_dim, int32_t* in_dim);
+int64_t sdfhip_field_table_size(const SdfHipField* f);    /* floats in the hash table (tcnn `params`) */
+int64_t sdfhip_field_packed_size(const SdfHipField* f);   /* floats in the MFMA-packed weight blob */
+int64_t sdfhip_field_workspace_size(const SdfHipField* f, int64_t n_points, int32_t training); /* bytes */
+
+/* theta -> MFMA operand order (once per optimiser step). */
+int sdfhip_field_pack(const SdfHipField* f, const float* theta, float* packed, sdfhip_stream_t stream);
+
+enum {
+  SDFHIP_MODE_SDF = 0,     /* get_sdf: sdf only                                  */
+  SDFHIP_MODE_GEO = 1,     /* forward_geonetwork: sdf + geometry feature         */
+  SDFHIP_MODE_FULL = 2     /* get_outputs: sdf, d sdf/dx, rgb (+ saves for backward when training) */
+};
+
+/* Sample positions are origins[ray] + dirs[ray] * starts[ray, s] (cameras/rays.py:61-73); pass dirs = starts = NULL
+ * and n_samples = 1 to evaluate at explicit positions origins[P,3].
+ * Outputs (rows = sdfhip_padded_points(P)): sdf [rows], grad [rows,3], rgb [rows,3], feat [rows, geo_feat_dim]
+ * (feat may be NULL; grad/rgb only written in MODE_FULL). emb: per-ray appearance embedding [n_rays, appearance_dim]
+ * or NULL (zeros, sdf_field.py:554-564). level_mask: [n_levels*n_features] (hash_encoding_mask). */
+int sdfhip_field_forward(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
+                         const float* origins, const float* dirs, const float* starts, int64_t n_rays, int32_t n_samples,
+                         const float* emb, int32_t mode, int32_t training, void* workspace,
+                         float* sdf, float* grad, float* rgb, float* feat, sdfhip_stream_t stream);
+
+/* Backward of a MODE_FULL training forward with the same workspace.  Upstream gradients (any may be NULL):
+ * sdf_bar [P], grad_bar [P,3], rgb_bar [P,3].  theta_bar [theta_size] is overwritten; table_bar [table_size] and
+ * emb_bar [n_rays, appearance_dim] (may be NULL) are accumulated into (caller zeroes). */
+int sdfhip_field_backward(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
+                          int64_t n_rays, int32_t n_samples, void* workspace,
+                          const float* sdf_bar, const float* grad_bar, const float* rgb_bar,
+                          float* theta_bar, float* table_bar, float* emb_bar, sdfhip_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------- proposal density field
+ * Replaces nerfstudio.fields.density_fields.HashMLPDensityField.get_density / density_fn (:99-118; base_field.py:48-65):
+ * L-inf contraction of the frustum MIDPOINT, (x+2)/4, tcnn HashGrid(5 levels, F=2, linear) + FullyFusedMLP(16, ReLU,
+ * no bias) -> trunc_exp.  Parameters: table, w1 [16,10], w2 [1,16]. */
+int sdfhip_proposal_forward(const SdfHipGridCfg* grid, const float* table, const float* w1, const float* w2,
+                            const float* origins, const float* dirs, const float* starts, const float* ends,
+                            int64_t n_rays, int32_t n_samples, int32_t contract, float* density, sdfhip_stream_t stream);
+/* workspace: sdfhip_proposal_workspace_size() bytes. table_bar accumulated (caller zeroes); w1_bar / w2_bar overwritten. */
+int64_t sdfhip_proposal_workspace_size(void);
+int sdfhip_proposal_backward(const SdfHipGridCfg* grid, const float* table, const float* w1, const float* w2,
+                             const float* origins, const float* dirs, const float* starts, const float* ends,
+                             int64_t n_rays, int32_t n_samples, int32_t contract, const float* density_bar,
+                             void* workspace, float* table_bar, float* w1_bar, float* w2_bar, sdfhip_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------- samplers
+ * spaced bins: UniformLinDispPiecewiseSampler (model_components/ray_samplers.py:80-127, 221-247).
+ * jitter: [n_rays] single-jitter draw (training) or NULL (eval).  bins: [n_rays, S+1]; starts/ends [n_rays, S]. */
+int sdfhip_sample_spaced(const float* nears, const float* fars, const float* jitter, int64_t n_rays, int32_t n_samples,
+                         float* bins, float* starts, float* ends, sdfhip_stream_t stream);
+/* PDFSampler(include_original=False, single_jitter) (ray_samplers.py:275-370) applied to weights^anneal
+ * (ProposalNetworkSampler :562).  Outputs are constants w.r.t. autograd (bins.detach(), :358). */
+int sdfhip_sample_pdf(const float* weights, const float* bins_in, const float* nears, const float* fars,
+                      const float* jitter, int64_t n_rays, int32_t s_in, int32_t s_out, float anneal,
+                      float histogram_padding, float* bins_out, float* starts, float* ends, sdfhip_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------- weights + renderers
+ * RaySamples.get_weights (cameras/rays.py:146-167) and its backward. */
+int sdfhip_density_weights_forward(const float* density, const float* starts, const float* ends, int64_t n_rays,
+                                   int32_t n_samples, float* weights, sdfhip_stream_t stream);
+int sdfhip_density_weights_backward(const float* density, const float* starts, const float* ends, int64_t n_rays,
+                                    int32_t n_samples, const float* weights_bar, float* density_bar, sdfhip_stream_t stream);
+
+/* SDFField.get_alpha (fields/sdf_field.py:476-525) -> RaySamples.get_weights_from_alphas (cameras/rays.py:194-208)
+ * -> RGBRenderer / DepthRenderer("expected") / SemanticRenderer(normals) / AccumulationRenderer
+ * (model_components/renderers.py:81-92,245-259,294,196), fused, one wavefront per ray.
+ * background: [3] or NULL (black).  steps_minmax: [2] scratch. depth is clipped to the batch-global [min,max] mid point. */
+int sdfhip_neus_render_forward(const float* sdf, const float* grad, const float* rgb, const float* dirs,
+                               const float* starts, const float* ends, const float* variance, const float* background,
+                               float cos_anneal, int64_t n_rays, int32_t n_samples,
+                               float* alpha, float* weights, float* out_rgb, float* out_depth_raw, float* out_depth,
+                               float* out_normal, float* out_acc, float* steps_minmax, sdfhip_stream_t stream);
+int sdfhip_neus_render_backward(const float* sdf, const float* grad, const float* rgb, const float* dirs,
+                                const float* starts, const float* ends, const float* variance, const float* background,
+                                float cos_anneal, int64_t n_rays, int32_t n_samples,
+                                const float* alpha, const float* weights, const float* out_depth_raw, const float* out_acc,
+                                const float* steps_minmax,
+                                const float* rgb_bar, const float* depth_bar, const float* normal_bar, const float* acc_bar,
+                                const float* weights_bar,
+                                float* sdf_bar, float* grad_bar, float* rgbs_bar, float* variance_bar, sdfhip_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDFHIP_H_ */

@@ -1,0 +1,143 @@
+"""ctypes binding of libsdfhip.so (the C ABI declared in include/sdfhip.h).
+
+There is NO fallback: if the shared object is missing or a call fails, an exception is raised.  The HIP
+extension is the product; PyTorch only provides device memory, streams and torch.distributed.
+"""
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsdfhip.so")
+
+c_float_p = ctypes.c_void_p  # device pointers travel as raw addresses
+c_i64 = ctypes.c_int64
+c_i32 = ctypes.c_int32
+c_f32 = ctypes.c_float
+
+
+class GridCfg(ctypes.Structure):
+    _fields_ = [
+        ("n_levels", c_i32), ("n_features", c_i32), ("log2_hashmap_size", c_i32), ("base_resolution", c_i32),
+        ("per_level_scale", c_f32), ("smoothstep", c_i32),
+    ]
+
+
+class GridLevel(ctypes.Structure):
+    _fields_ = [
+        ("scale", c_f32), ("resolution", ctypes.c_uint32), ("size", ctypes.c_uint32), ("offset", ctypes.c_uint32),
+        ("hashed", ctypes.c_uint32),
+    ]
+
+
+class FieldCfg(ctypes.Structure):
+    _fields_ = [
+        ("num_layers", c_i32), ("hidden_dim", c_i32), ("geo_feat_dim", c_i32), ("num_layers_color", c_i32),
+        ("hidden_dim_color", c_i32), ("skip_layer", c_i32), ("pe_degree", c_i32), ("use_position_encoding", c_i32),
+        ("appearance_dim", c_i32), ("contract", c_i32), ("rgb_padding", c_f32), ("grid", GridCfg),
+    ]
+
+
+MODE_SDF, MODE_GEO, MODE_FULL = 0, 1, 2
+
+_SIGNATURES = {
+    "sdfhip_version": (c_i32, []),
+    "sdfhip_last_error": (ctypes.c_char_p, []),
+    "sdfhip_padded_points": (c_i64, [c_i64]),
+    "sdfhip_grid_levels": (c_i32, [ctypes.POINTER(GridCfg), ctypes.POINTER(GridLevel), ctypes.POINTER(c_i64)]),
+    "sdfhip_field_create": (c_i32, [ctypes.POINTER(FieldCfg), ctypes.POINTER(ctypes.c_void_p)]),
+    "sdfhip_field_destroy": (None, [ctypes.c_void_p]),
+    "sdfhip_field_theta_size": (c_i64, [ctypes.c_void_p]),
+    "sdfhip_field_num_linear": (c_i32, [ctypes.c_void_p]),
+    "sdfhip_field_theta_layout": (c_i32, [ctypes.c_void_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64),
+                                          ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
+    "sdfhip_field_table_size": (c_i64, [ctypes.c_void_p]),
+    "sdfhip_field_packed_size": (c_i64, [ctypes.c_void_p]),
+    "sdfhip_field_workspace_size": (c_i64, [ctypes.c_void_p, c_i64, c_i32]),
+    "sdfhip_field_pack": (c_i32, [ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_void_p]),
+    "sdfhip_field_forward": (c_i32, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
+                                     c_i64, c_i32, c_float_p, c_i32, c_i32, ctypes.c_void_p, c_float_p, c_float_p,
+                                     c_float_p, c_float_p, ctypes.c_void_p]),
+    "sdfhip_field_backward": (c_i32, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_i64, c_i32, ctypes.c_void_p,
+                                      c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
+    "sdfhip_proposal_forward": (c_i32, [ctypes.POINTER(GridCfg), c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
+                                        c_float_p, c_float_p, c_i64, c_i32, c_i32, c_float_p, ctypes.c_void_p]),
+    "sdfhip_proposal_workspace_size": (c_i64, []),
+    "sdfhip_proposal_backward": (c_i32, [ctypes.POINTER(GridCfg), c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
+                                         c_float_p, c_float_p, c_i64, c_i32, c_i32, c_float_p, ctypes.c_void_p, c_float_p,
+                                         c_float_p, c_float_p, ctypes.c_void_p]),
+    "sdfhip_sample_spaced": (c_i32, [c_float_p, c_float_p, c_float_p, c_i64, c_i32, c_float_p, c_float_p, c_float_p,
+                                     ctypes.c_void_p]),
+    "sdfhip_sample_pdf": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_i64, c_i32, c_i32, c_f32, c_f32,
+                                  c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
+    "sdfhip_density_weights_forward": (c_i32, [c_float_p, c_float_p, c_float_p, c_i64, c_i32, c_float_p, ctypes.c_void_p]),
+    "sdfhip_density_weights_backward": (c_i32, [c_float_p, c_float_p, c_float_p, c_i64, c_i32, c_float_p, c_float_p,
+                                                ctypes.c_void_p]),
+    "sdfhip_neus_render_forward": (c_i32, [c_float_p] * 8 + [c_f32, c_i64, c_i32] + [c_float_p] * 8 + [ctypes.c_void_p]),
+    "sdfhip_neus_render_backward": (c_i32, [c_float_p] * 8 + [c_f32, c_i64, c_i32] + [c_float_p] * 14 + [ctypes.c_void_p]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+class SdfHipError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES.keys())
+
+
+def load() -> ctypes.CDLL:
+    """Load libsdfhip.so; raises if it has not been built (python -m sdfstudio_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SdfHipError(
+            f"{LIB_PATH} is missing: build the HIP extension first (python -m sdfstudio_amd.build or "
+            "__graft_entry__.build()). There is no CPU / PyTorch fallback for this path."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().sdfhip_last_error()
+        raise SdfHipError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Device address of a contiguous fp32 CUDA(HIP) tensor, or NULL."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SdfHipError("sdfhip kernels need HIP device tensors (got a CPU tensor); there is no CPU fallback")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise SdfHipError(f"expected a contiguous float32 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def padded_points(n: int) -> int:
+    return (n + 127) // 128 * 128
+
+
+def grid_levels(cfg: GridCfg):
+    """Host-only query (works without a GPU)."""
+    lib = load()
+    levels = (GridLevel * cfg.n_levels)()
+    n = c_i64(0)
+    check(lib.sdfhip_grid_levels(ctypes.byref(cfg), levels, ctypes.byref(n)), "sdfhip_grid_levels")
+    return list(levels), int(n.value)

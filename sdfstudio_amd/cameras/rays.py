@@ -1,0 +1,122 @@
+"""Ray containers mirroring nerfstudio/cameras/rays.py (RayBundle :233, Frustums :30, RaySamples :109).
+
+Same attribute names and tensor shapes as the reference (``[N,S,1]`` per-sample scalars) so host code written
+against sdfstudio reads them unchanged; in addition each object carries the flat ``[N,S]`` / ``[N,3]`` tensors the HIP
+kernels consume, so no broadcast views are materialised on the hot path.
+"""
+from dataclasses import dataclass
+from typing import Callable, Dict, Optional
+
+import torch
+
+
+@dataclass
+class Frustums:
+    """Region of space along a ray (rays.py:30-106). origins/directions are [N,1,3] broadcast views."""
+
+    origins: torch.Tensor
+    directions: torch.Tensor
+    starts: torch.Tensor  # [N,S,1]
+    ends: torch.Tensor  # [N,S,1]
+    pixel_area: torch.Tensor
+    offsets: Optional[torch.Tensor] = None
+
+    def get_positions(self) -> torch.Tensor:
+        """Frustum mid points (rays.py:46-55)."""
+        pos = self.origins + self.directions * (self.starts + self.ends) / 2
+        return pos if self.offsets is None else pos + self.offsets
+
+    def get_start_positions(self) -> torch.Tensor:
+        """Frustum start points, used by the SDF field (rays.py:61-73)."""
+        return self.origins + self.directions * self.starts
+
+    @property
+    def shape(self):
+        return self.starts.shape[:-1]
+
+
+@dataclass
+class RaySamples:
+    """Samples along rays (rays.py:109-230)."""
+
+    frustums: Frustums
+    camera_indices: Optional[torch.Tensor] = None  # [N,1,1]
+    deltas: Optional[torch.Tensor] = None  # [N,S,1]
+    spacing_starts: Optional[torch.Tensor] = None  # [N,S,1]
+    spacing_ends: Optional[torch.Tensor] = None
+    spacing_to_euclidean_fn: Optional[Callable] = None
+    metadata: Optional[Dict[str, torch.Tensor]] = None
+    times: Optional[torch.Tensor] = None
+    # ---- flat views for the kernels (ours)
+    flat_origins: Optional[torch.Tensor] = None  # [N,3]
+    flat_directions: Optional[torch.Tensor] = None  # [N,3]
+    flat_starts: Optional[torch.Tensor] = None  # [N,S]
+    flat_ends: Optional[torch.Tensor] = None  # [N,S]
+    flat_bins: Optional[torch.Tensor] = None  # [N,S+1] spacing-domain bins
+    nears: Optional[torch.Tensor] = None  # [N]
+    fars: Optional[torch.Tensor] = None  # [N]
+
+    @property
+    def shape(self):
+        return self.frustums.shape
+
+    # -- compositing math (rays.py:131-230), served by the HIP kernels
+    def get_weights(self, densities: torch.Tensor) -> torch.Tensor:
+        from sdfstudio_amd.model_components.renderers import density_to_weights
+
+        return density_to_weights(densities[..., 0], self.flat_starts, self.flat_ends)[..., None]
+
+
+@dataclass
+class RayBundle:
+    """A bundle of rays (rays.py:233-339)."""
+
+    origins: torch.Tensor  # [N,3]
+    directions: torch.Tensor  # [N,3]
+    pixel_area: Optional[torch.Tensor] = None  # [N,1]
+    directions_norm: Optional[torch.Tensor] = None  # [N,1]
+    camera_indices: Optional[torch.Tensor] = None  # [N,1]
+    nears: Optional[torch.Tensor] = None  # [N,1]
+    fars: Optional[torch.Tensor] = None  # [N,1]
+    metadata: Optional[Dict[str, torch.Tensor]] = None
+    times: Optional[torch.Tensor] = None
+
+    def __len__(self):
+        return self.origins.shape[0]
+
+    def get_ray_samples(self, bin_starts, bin_ends, spacing_starts=None, spacing_ends=None,
+                        spacing_to_euclidean_fn=None, flat_bins=None) -> RaySamples:
+        """rays.py:295-339. bin_starts / bin_ends: [N,S,1] (or [N,S])."""
+        if bin_starts.dim() == 2:
+            bin_starts, bin_ends = bin_starts[..., None], bin_ends[..., None]
+        n = self.origins.shape[0]
+        pa = self.pixel_area if self.pixel_area is not None else torch.ones(n, 1, device=self.origins.device)
+        fr = Frustums(
+            origins=self.origins[:, None, :], directions=self.directions[:, None, :], starts=bin_starts, ends=bin_ends,
+            pixel_area=pa[:, None, :],
+        )
+        cam = None if self.camera_indices is None else self.camera_indices[..., None]
+        return RaySamples(
+            frustums=fr, camera_indices=cam, deltas=bin_ends - bin_starts, spacing_starts=spacing_starts,
+            spacing_ends=spacing_ends, spacing_to_euclidean_fn=spacing_to_euclidean_fn, metadata=self.metadata,
+            flat_origins=self.origins.contiguous(), flat_directions=self.directions.contiguous(),
+            flat_starts=bin_starts[..., 0].contiguous(), flat_ends=bin_ends[..., 0].contiguous(), flat_bins=flat_bins,
+            nears=None if self.nears is None else self.nears.reshape(-1).contiguous(),
+            fars=None if self.fars is None else self.fars.reshape(-1).contiguous(),
+        )
+
+
+def unpack_ray_samples(rs):
+    """(origins [N,3], dirs [N,3], starts [N,S], ends [N,S]) from our RaySamples OR the reference's (duck-typed)."""
+    if getattr(rs, "flat_starts", None) is not None:
+        return rs.flat_origins, rs.flat_directions, rs.flat_starts, rs.flat_ends
+    fr = rs.frustums
+    starts = fr.starts
+    if starts.dim() != 3:
+        raise ValueError(f"expected ray samples with batch shape [N,S], got starts {tuple(starts.shape)}")
+    n, s = starts.shape[0], starts.shape[1]
+    o = fr.origins.expand(n, s, 3)[:, 0, :].contiguous().float()
+    d = fr.directions.expand(n, s, 3)[:, 0, :].contiguous().float()
+    if not (torch.equal(fr.origins.expand(n, s, 3)[:, -1, :], fr.origins.expand(n, s, 3)[:, 0, :])):
+        raise ValueError("ray samples whose origins vary along the sample axis are not supported by the fused path")
+    return o, d, starts[..., 0].contiguous().float(), fr.ends[..., 0].contiguous().float()

@@ -1,0 +1,981 @@
+// sdfhip — C ABI implementation (include/sdfhip.h): descriptor tables, workspace carving, kernel sequencing.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/sdfhip.h"
+#include "field_inst.h"
+#include "point_kernels.h"
+#include "ray_kernels.h"
+
+const FieldKernels* sdfhip_kernels_A();
+const FieldKernels* sdfhip_kernels_B();
+
+static thread_local char g_err[1024] = "";
+void sdfhip_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int sdfhip_version(void) { return 100; }
+extern "C" const char* sdfhip_last_error(void) { return g_err; }
+extern "C" int64_t sdfhip_padded_points(int64_t n) { return (n + 127) / 128 * 128; }
+
+// ------------------------------------------------------------------------------------------------ grid descriptor
+extern "C" int sdfhip_grid_levels(const SdfHipGridCfg* cfg, SdfHipGridLevel* levels, int64_t* n_entries) {
+  SDFHIP_REQUIRE(cfg != nullptr, "grid cfg is null");
+  SDFHIP_REQUIRE(cfg->n_levels >= 1 && cfg->n_levels <= kMaxLevels, "n_levels %d out of range [1,%d]", cfg->n_levels, kMaxLevels);
+  SDFHIP_REQUIRE(cfg->n_features == 2, "only n_features_per_level == 2 is built (got %d)", cfg->n_features);
+  SDFHIP_REQUIRE(cfg->log2_hashmap_size >= 4 && cfg->log2_hashmap_size <= 24, "log2_hashmap_size %d unsupported", cfg->log2_hashmap_size);
+  // tiny-cuda-nn GridEncoding constructor arithmetic, in fp32 (see oracle/hashgrid.py for the statement)
+  const float l2 = log2f(cfg->per_level_scale);
+  uint64_t off = 0;
+  for (int l = 0; l < cfg->n_levels; ++l) {
+    const float scale = exp2f((float)l * l2) * (float)cfg->base_resolution - 1.0f;
+    const uint32_t res = (uint32_t)ceilf(scale) + 1u;
+    uint64_t n = (uint64_t)res * res * res;
+    n = (n + 7) / 8 * 8;
+    const uint64_t cap = 1ull << cfg->log2_hashmap_size;
+    if (n > cap) n = cap;
+    if (levels != nullptr) {
+      levels[l].scale = scale;
+      levels[l].resolution = res;
+      levels[l].size = (uint32_t)n;
+      levels[l].offset = (uint32_t)off;
+      levels[l].hashed = ((uint64_t)res * res * res > n) ? 1u : 0u;
+    }
+    off += n;
+  }
+  if (n_entries != nullptr) *n_entries = (int64_t)off;
+  return 0;
+}
+
+static int make_grid_dev(const SdfHipGridCfg* cfg, GridDev* g) {
+  SdfHipGridLevel lv[kMaxLevels];
+  int64_t n = 0;
+  const int rc = sdfhip_grid_levels(cfg, lv, &n);
+  if (rc != 0) return rc;
+  memset(g, 0, sizeof(*g));
+  g->n_levels = cfg->n_levels;
+  g->n_features = cfg->n_features;
+  g->smoothstep = cfg->smoothstep;
+  for (int l = 0; l < cfg->n_levels; ++l) {
+    g->lv[l].scale = lv[l].scale;
+    g->lv[l].res = lv[l].resolution;
+    g->lv[l].size = lv[l].size;
+    g->lv[l].offset = lv[l].offset;
+    g->lv[l].hashed = lv[l].hashed;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ field handle
+struct LinearInfo {
+  int out_dim, in_dim;
+  int64_t w_off, b_off;
+};
+
+struct SdfHipField {
+  SdfHipFieldCfg cfg;
+  const FieldKernels* k;
+  GridDev grid;
+  int d0, n_geo, n_col, n_feat;  // in0 dims, #linear layers, grid features
+  std::vector<LinearInfo> lin;   // geometry layers then colour layers
+  int64_t theta_size, table_floats, packed_size;
+  int64_t g_wp[kMaxLayers], g_wpT[kMaxLayers], g_bias[kMaxLayers], g_wsdf, g_bsdf;
+  int64_t c_wp[kMaxLayers], c_wpT[kMaxLayers], c_bias[kMaxLayers], c_wout, c_bout;
+  int g_rowmap[kMaxLayers], g_colmap[kMaxLayers], c_rowmap[kMaxLayers], c_colmap[kMaxLayers];
+  float g_scale[kMaxLayers];
+  std::vector<PackDesc> pack;
+  std::vector<VecDesc> vec;
+  PackDesc* d_pack = nullptr;
+  VecDesc* d_vec = nullptr;
+  int32_t* d_maps = nullptr;
+  int max_pack_elems = 0, max_vec_n = 0;
+  int64_t max_partial_elems = 0, max_partial_rows = 0;
+
+  int kb_geo(int l) const { return l == 0 ? k->nb0 : (l == k->skip ? k->nb3 + k->nb0 : k->nbh); }
+  int nbo_geo(int l) const { return l == k->nl ? k->nbf : ((l + 1 == k->skip) ? k->nb3 : k->nbh); }
+  int kb_col(int l) const { return l == 0 ? k->nbf + k->nbs : k->nbc; }
+};
+
+static int add_map(std::vector<int32_t>& maps, const std::vector<int32_t>& m) {
+  const int off = (int)maps.size();
+  maps.insert(maps.end(), m.begin(), m.end());
+  return off;
+}
+
+extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out) {
+  SDFHIP_REQUIRE(cfg != nullptr && out != nullptr, "null argument");
+  SdfHipField* f = new SdfHipField();
+  f->cfg = *cfg;
+  int rc = make_grid_dev(&cfg->grid, &f->grid);
+  if (rc != 0) {
+    delete f;
+    return rc;
+  }
+  int64_t entries = 0;
+  sdfhip_grid_levels(&cfg->grid, nullptr, &entries);
+  f->table_floats = entries * cfg->grid.n_features;
+  f->n_feat = cfg->grid.n_levels * cfg->grid.n_features;
+  const int H = cfg->hidden_dim, GF = cfg->geo_feat_dim, HC = cfg->hidden_dim_color, NL = cfg->num_layers,
+            NLC = cfg->num_layers_color, E = cfg->appearance_dim;
+  const int D0 = 3 + 6 * cfg->pe_degree + f->n_feat;
+  f->d0 = D0;
+  const int skip = cfg->skip_layer;
+  auto fail = [&](const char* why) {
+    sdfhip_set_error("unsupported field configuration: %s (hidden %d, layers %d, in0 %d, geo_feat %d, colour %dx%d, skip %d)", why, H,
+                     NL, D0, GF, NLC, HC, skip);
+    delete f;
+    return -1;
+  };
+  if (H % 32 || GF % 32 || HC % 32) return fail("dims must be multiples of 32");
+  if (skip >= 0 && (skip < 1 || skip >= NL || H - D0 <= 0)) return fail("bad skip layer");
+  if (NL + 1 > kMaxLayers || NLC + 1 > kMaxLayers) return fail("too many layers");
+  const int nb0 = (D0 + 31) / 32, nb3 = skip >= 0 ? (H - D0 + 31) / 32 : 0, nbs = (33 + E + 31) / 32;
+  const FieldKernels* cands[] = {sdfhip_kernels_A(), sdfhip_kernels_B()};
+  f->k = nullptr;
+  for (const FieldKernels* k : cands) {
+    if (k->nbh == H / 32 && k->nb0 == nb0 && k->nb3 == nb3 && k->nl == NL && k->skip == skip && k->nbf == GF / 32 && k->nbs == nbs &&
+        k->nbc == HC / 32 && k->nlc == NLC)
+      f->k = k;
+  }
+  if (f->k == nullptr) return fail("no kernel instantiation was built for this shape");
+  const FieldKernels* k = f->k;
+
+  // ---- natural theta layout
+  f->n_geo = NL + 1;
+  f->n_col = NLC + 1;
+  int64_t off = 0;
+  for (int l = 0; l <= NL; ++l) {
+    LinearInfo li;
+    li.in_dim = l == 0 ? D0 : H;
+    li.out_dim = l == NL ? 1 + GF : ((skip >= 0 && l + 1 == skip) ? H - D0 : H);
+    li.w_off = off;
+    off += (int64_t)li.out_dim * li.in_dim;
+    li.b_off = off;
+    off += li.out_dim;
+    f->lin.push_back(li);
+  }
+  for (int l = 0; l <= NLC; ++l) {
+    LinearInfo li;
+    li.in_dim = l == 0 ? 33 + GF + E : HC;
+    li.out_dim = l == NLC ? 3 : HC;
+    li.w_off = off;
+    off += (int64_t)li.out_dim * li.in_dim;
+    li.b_off = off;
+    off += li.out_dim;
+    f->lin.push_back(li);
+  }
+  f->theta_size = off;
+
+  // ---- maps + pack descriptors
+  std::vector<int32_t> maps;
+  int64_t poff = 0;
+  auto ident = [](int n, int valid, int add = 0) {
+    std::vector<int32_t> m(n);
+    for (int i = 0; i < n; ++i) m[i] = i < valid ? i + add : -1;
+    return m;
+  };
+  auto add_pack = [&](int64_t src, int ld, int kb, int nbo, int rowmap, int colmap, int transpose, float scale) {
+    PackDesc d;
+    memset(&d, 0, sizeof(d));
+    d.src_off = src;
+    d.dst_off = poff;
+    d.ld = ld;
+    d.kb = kb;
+    d.nbo = nbo;
+    d.rowmap_off = rowmap;
+    d.colmap_off = colmap;
+    d.transpose = transpose;
+    d.scale = scale;
+    f->pack.push_back(d);
+    const int64_t at = poff;
+    poff += (int64_t)kb * nbo * 1024;
+    f->max_pack_elems = std::max(f->max_pack_elems, kb * nbo * 1024);
+    return at;
+  };
+  auto add_vec = [&](int64_t src, int n, int map, int stride) {
+    VecDesc d;
+    memset(&d, 0, sizeof(d));
+    d.src_off = src;
+    d.dst_off = poff;
+    d.n = n;
+    d.map_off = map;
+    d.stride = stride;
+    f->vec.push_back(d);
+    const int64_t at = poff;
+    poff += (n + 31) / 32 * 32;
+    f->max_vec_n = std::max(f->max_vec_n, n);
+    return at;
+  };
+  for (int l = 0; l <= NL; ++l) {
+    const LinearInfo& li = f->lin[l];
+    const int kb = f->kb_geo(l), nbo = f->nbo_geo(l);
+    std::vector<int32_t> rowmap, colmap;
+    float scale = 1.0f;
+    if (l == NL) {
+      rowmap = ident(nbo * 32, GF, 1);  // feature rows 1..GF of the output layer (row 0 = sdf)
+      colmap = ident(kb * 32, H);
+    } else {
+      rowmap = ident(nbo * 32, li.out_dim);
+      if (l == 0) {
+        colmap = ident(kb * 32, D0);
+      } else if (l == skip) {
+        // layer input = cat([h, in0]) / sqrt(2)  (sdf_field.py:403-404): h occupies nb3 blocks, in0 nb0 blocks
+        colmap.assign(kb * 32, -1);
+        for (int i = 0; i < H - D0; ++i) colmap[i] = i;
+        for (int j = 0; j < D0; ++j) colmap[k->nb3 * 32 + j] = (H - D0) + j;
+        scale = (float)(1.0 / std::sqrt(2.0));
+      } else {
+        colmap = ident(kb * 32, li.in_dim);
+      }
+    }
+    f->g_rowmap[l] = add_map(maps, rowmap);
+    f->g_colmap[l] = add_map(maps, colmap);
+    f->g_scale[l] = scale;
+    f->g_wp[l] = add_pack(li.w_off, li.in_dim, kb, nbo, f->g_rowmap[l], f->g_colmap[l], 0, scale);
+    f->g_wpT[l] = add_pack(li.w_off, li.in_dim, nbo, kb, f->g_rowmap[l], f->g_colmap[l], 1, scale);
+    f->g_bias[l] = add_vec(li.b_off, nbo * 32, f->g_rowmap[l], 1);
+  }
+  {
+    const LinearInfo& li = f->lin[NL];
+    const int m = add_map(maps, ident(k->nbh * 32, H));
+    f->g_wsdf = add_vec(li.w_off, k->nbh * 32, m, 1);
+    const int m1 = add_map(maps, ident(1, 1));
+    f->g_bsdf = add_vec(li.b_off, 1, m1, 1);
+  }
+  for (int l = 0; l < NLC; ++l) {
+    const LinearInfo& li = f->lin[f->n_geo + l];
+    const int kb = f->kb_col(l), nbo = k->nbc;
+    std::vector<int32_t> rowmap = ident(nbo * 32, HC), colmap;
+    if (l == 0) {
+      // reference column order (sdf_field.py:572-578): x(3) d(27) grad(3) feat(GF) emb(E); ours: [feat | x d grad emb]
+      colmap.assign(kb * 32, -1);
+      for (int i = 0; i < GF; ++i) colmap[i] = 33 + i;
+      for (int j = 0; j < 33; ++j) colmap[k->nbf * 32 + j] = j;
+      for (int j = 0; j < E; ++j) colmap[k->nbf * 32 + 33 + j] = 33 + GF + j;
+    } else {
+      colmap = ident(kb * 32, HC);
+    }
+    f->c_rowmap[l] = add_map(maps, rowmap);
+    f->c_colmap[l] = add_map(maps, colmap);
+    f->c_wp[l] = add_pack(li.w_off, li.in_dim, kb, nbo, f->c_rowmap[l], f->c_colmap[l], 0, 1.0f);
+    f->c_wpT[l] = add_pack(li.w_off, li.in_dim, nbo, kb, f->c_rowmap[l], f->c_colmap[l], 1, 1.0f);
+    f->c_bias[l] = add_vec(li.b_off, nbo * 32, f->c_rowmap[l], 1);
+  }
+  {
+    const LinearInfo& li = f->lin[f->n_geo + NLC];
+    f->c_rowmap[NLC] = add_map(maps, ident(32, 3));
+    f->c_colmap[NLC] = add_map(maps, ident(k->nbc * 32, HC));
+    f->c_wout = poff;
+    for (int c = 0; c < 3; ++c) add_vec(li.w_off + (int64_t)c * HC, k->nbc * 32, f->c_colmap[NLC], 1);
+    const int m3 = add_map(maps, ident(3, 3));
+    f->c_bout = add_vec(li.b_off, 3, m3, 1);
+  }
+  f->packed_size = poff;
+  // largest split-K partial
+  auto upd = [&](int rows_blocks, int col_blocks) {
+    f->max_partial_elems = std::max<int64_t>(f->max_partial_elems, (int64_t)rows_blocks * 32 * col_blocks * 32);
+    f->max_partial_rows = std::max<int64_t>(f->max_partial_rows, (int64_t)rows_blocks * 32);
+  };
+  for (int l = 0; l <= NL; ++l) upd(f->nbo_geo(l), f->kb_geo(l));
+  for (int l = 0; l < NLC; ++l) upd(k->nbc, f->kb_col(l));
+  upd(1, k->nbc);
+  f->max_partial_elems = std::max<int64_t>(f->max_partial_elems, k->nbh * 32 + 32);
+
+  hipError_t e = hipMalloc((void**)&f->d_pack, f->pack.size() * sizeof(PackDesc));
+  if (e == hipSuccess) e = hipMalloc((void**)&f->d_vec, f->vec.size() * sizeof(VecDesc));
+  if (e == hipSuccess) e = hipMalloc((void**)&f->d_maps, maps.size() * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemcpy(f->d_pack, f->pack.data(), f->pack.size() * sizeof(PackDesc), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(f->d_vec, f->vec.data(), f->vec.size() * sizeof(VecDesc), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(f->d_maps, maps.data(), maps.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    sdfhip_set_error("field_create: device table upload failed: %s", hipGetErrorString(e));
+    sdfhip_field_destroy(f);
+    return -2;
+  }
+  *out = f;
+  return 0;
+}
+
+extern "C" void sdfhip_field_destroy(SdfHipField* f) {
+  if (f == nullptr) return;
+  if (f->d_pack) (void)hipFree(f->d_pack);
+  if (f->d_vec) (void)hipFree(f->d_vec);
+  if (f->d_maps) (void)hipFree(f->d_maps);
+  delete f;
+}
+
+extern "C" int64_t sdfhip_field_theta_size(const SdfHipField* f) { return f->theta_size; }
+extern "C" int32_t sdfhip_field_num_linear(const SdfHipField* f) { return (int32_t)f->lin.size(); }
+extern "C" int sdfhip_field_theta_layout(const SdfHipField* f, int64_t* w_off, int64_t* b_off, int32_t* out_dim, int32_t* in_dim) {
+  for (size_t i = 0; i < f->lin.size(); ++i) {
+    w_off[i] = f->lin[i].w_off;
+    b_off[i] = f->lin[i].b_off;
+    out_dim[i] = f->lin[i].out_dim;
+    in_dim[i] = f->lin[i].in_dim;
+  }
+  return 0;
+}
+extern "C" int64_t sdfhip_field_table_size(const SdfHipField* f) { return f->table_floats; }
+extern "C" int64_t sdfhip_field_packed_size(const SdfHipField* f) { return f->packed_size; }
+
+// ---- workspace carving
+struct FieldWs {
+  float *x, *in0, *dydp, *z[kMaxLayers], *r[kMaxLayers], *feat, *e, *csmall, *h[kMaxLayers];
+  float *rgb;
+  float *gtot, *ebar, *sdfbar, *qb[kMaxLayers + 1], *zb[kMaxLayers], *in0bar, *d[kMaxLayers], *dout, *featbar, *csmallbar;
+  float *partial, *bpartial;
+  int n_split;
+  size_t bytes;
+};
+
+static void carve(const SdfHipField* f, int64_t n_points, int full, void* base, FieldWs* w) {
+  const FieldKernels* k = f->k;
+  const int64_t np = sdfhip_padded_points(n_points);
+  size_t off = 0;
+  auto take = [&](int64_t floats) {
+    float* p = base ? reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off) : nullptr;
+    off += ((size_t)floats * sizeof(float) + 255) / 256 * 256;
+    return p;
+  };
+  memset(w, 0, sizeof(*w));
+  w->x = take(np * 3);
+  w->in0 = take(np * k->nb0 * 32);
+  w->feat = take(np * k->nbf * 32);
+  if (full) {
+    w->dydp = take(np * f->n_feat * 3);
+    for (int l = 0; l < k->nl; ++l) {
+      w->z[l] = take(np * f->nbo_geo(l) * 32);
+      w->r[l] = take(np * f->nbo_geo(l) * 32);
+    }
+    w->e = take(np * k->nb0 * 32);
+    w->csmall = take(np * k->nbs * 32);
+    for (int l = 0; l < k->nlc; ++l) w->h[l] = take(np * k->nbc * 32);
+    w->rgb = take(np * 3);
+    w->gtot = take(np * 3);
+    w->ebar = take(np * k->nb0 * 32);
+    w->sdfbar = take(np);
+    for (int l = 1; l <= k->nl; ++l) w->qb[l] = take(np * f->kb_geo(l) * 32);
+    for (int l = 0; l < k->nl; ++l) w->zb[l] = take(np * f->nbo_geo(l) * 32);
+    w->in0bar = take(np * k->nb0 * 32);
+    for (int l = 0; l < k->nlc; ++l) w->d[l] = take(np * k->nbc * 32);
+    w->dout = take(np * 32);
+    w->featbar = take(np * k->nbf * 32);
+    w->csmallbar = take(np * k->nbs * 32);
+    const int64_t n_tiles = np / 32;
+    w->n_split = (int)std::min<int64_t>(256, n_tiles);
+    w->partial = take((int64_t)w->n_split * f->max_partial_elems);
+    w->bpartial = take((int64_t)w->n_split * f->max_partial_rows);
+  }
+  w->bytes = off;
+}
+
+extern "C" int64_t sdfhip_field_workspace_size(const SdfHipField* f, int64_t n_points, int32_t training) {
+  FieldWs w;
+  carve(f, n_points, training, nullptr, &w);
+  return (int64_t)w.bytes;
+}
+
+extern "C" int sdfhip_field_pack(const SdfHipField* f, const float* theta, float* packed, sdfhip_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  dim3 g1((f->max_pack_elems + 255) / 256, (unsigned)f->pack.size());
+  pack_kernel<<<g1, 256, 0, s>>>(theta, f->d_pack, f->d_maps, packed);
+  dim3 g2((f->max_vec_n + 255) / 256, (unsigned)f->vec.size());
+  packvec_kernel<<<g2, 256, 0, s>>>(theta, f->d_vec, f->d_maps, packed);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+static void fill_geo_ptrs(const SdfHipField* f, const float* packed, GeoPtrs* p) {
+  memset(p, 0, sizeof(*p));
+  for (int l = 0; l <= f->k->nl; ++l) {
+    p->wp[l] = packed + f->g_wp[l];
+    p->wpT[l] = packed + f->g_wpT[l];
+    p->bias[l] = packed + f->g_bias[l];
+  }
+  p->w_sdf = packed + f->g_wsdf;
+  p->b_sdf = packed + f->g_bsdf;
+}
+static void fill_col_ptrs(const SdfHipField* f, const float* packed, ColPtrs* p) {
+  memset(p, 0, sizeof(*p));
+  for (int l = 0; l < f->k->nlc; ++l) {
+    p->wp[l] = packed + f->c_wp[l];
+    p->wpT[l] = packed + f->c_wpT[l];
+    p->bias[l] = packed + f->c_bias[l];
+  }
+  p->w_out = packed + f->c_wout;
+  p->b_out = packed + f->c_bout;
+  p->rgb_padding = f->cfg.rgb_padding;
+}
+
+__global__ void untp_kernel(const float* __restrict__ tp, const int nb, const int n_feat, const int64_t n_rows, float* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_rows * n_feat) return;
+  const int64_t p = idx / n_feat;
+  const int c = (int)(idx % n_feat);
+  out[idx] = tp[tp_index(p, c, nb)];
+}
+
+extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
+                                    const float* origins, const float* dirs, const float* starts, int64_t n_rays, int32_t n_samples,
+                                    const float* emb, int32_t mode, int32_t training, void* workspace, float* sdf, float* grad,
+                                    float* rgb, float* feat, sdfhip_stream_t stream) {
+  (void)training;
+  SDFHIP_REQUIRE(f && packed && table && level_mask && origins && workspace && sdf, "field_forward: null argument");
+  SDFHIP_REQUIRE(mode >= SDFHIP_MODE_SDF && mode <= SDFHIP_MODE_FULL, "field_forward: bad mode %d", mode);
+  SDFHIP_REQUIRE(n_samples >= 1 && n_rays >= 0, "field_forward: bad shape");
+  SDFHIP_REQUIRE(mode != SDFHIP_MODE_FULL || (dirs && starts && grad && rgb), "field_forward: MODE_FULL needs dirs, starts, grad, rgb");
+  if (n_rays == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const FieldKernels* k = f->k;
+  const int64_t P = n_rays * n_samples, NP = sdfhip_padded_points(P);
+  const int full = mode == SDFHIP_MODE_FULL;
+  FieldWs w;
+  carve(f, P, full, workspace, &w);
+
+  EncodeArgs ea;
+  memset(&ea, 0, sizeof(ea));
+  ea.grid = f->grid;
+  ea.origins = origins;
+  ea.dirs = dirs;
+  ea.starts = starts;
+  ea.n_points = P;
+  ea.n_padded = NP;
+  ea.S = n_samples;
+  // get_outputs contracts the sample positions (sdf_field.py:629); get_sdf / forward_geonetwork do NOT (:412-418, :380)
+  ea.contract = (f->cfg.contract && full) ? 1 : 0;
+  ea.pe_degree = f->cfg.pe_degree;
+  ea.use_pe = f->cfg.use_position_encoding;
+  ea.nb0 = k->nb0;
+  ea.table = table;
+  ea.mask = level_mask;
+  ea.x_out = w.x;
+  ea.in0_tp = w.in0;
+  ea.dydp = full ? w.dydp : nullptr;
+  geo_encode_kernel<<<dim3((unsigned)(NP / 256 + (NP % 256 != 0)), f->grid.n_levels + 1), 256, 0, s>>>(ea);
+
+  GeoFwdArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  fill_geo_ptrs(f, packed, &ga.p);
+  ga.in0_tp = w.in0;
+  for (int l = 0; l < k->nl; ++l) {
+    ga.z_tp[l] = w.z[l];
+    ga.r_tp[l] = w.r[l];
+  }
+  ga.feat_tp = w.feat;
+  ga.sdf = sdf;
+  ga.e_tp = w.e;
+  const unsigned grid = (unsigned)(NP / 128);
+  k->geo_fwd(full ? 0 : (mode == SDFHIP_MODE_GEO ? 1 : 2), ga, grid, s);
+
+  if (full) {
+    AssembleArgs aa;
+    memset(&aa, 0, sizeof(aa));
+    aa.e_tp = w.e;
+    aa.x = w.x;
+    aa.dydp = w.dydp;
+    aa.mask = level_mask;
+    aa.dirs = dirs;
+    aa.emb = emb;
+    aa.n_points = P;
+    aa.n_padded = NP;
+    aa.S = n_samples;
+    aa.pe_degree = f->cfg.pe_degree;
+    aa.use_pe = f->cfg.use_position_encoding;
+    aa.n_feat = f->n_feat;
+    aa.nb0 = k->nb0;
+    aa.nbs = k->nbs;
+    aa.emb_dim = f->cfg.appearance_dim;
+    aa.grad = grad;
+    aa.csmall_tp = w.csmall;
+    grad_assemble_kernel<<<(unsigned)(NP / 256 + (NP % 256 != 0)), 256, 0, s>>>(aa);
+
+    ColFwdArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    fill_col_ptrs(f, packed, &ca.p);
+    ca.feat_tp = w.feat;
+    ca.csmall_tp = w.csmall;
+    for (int l = 0; l < k->nlc; ++l) ca.h_tp[l] = w.h[l];
+    ca.rgb = w.rgb;  // kept for the backward's sigmoid derivative; the caller gets a copy
+    k->col_fwd(ca, grid, s);
+    SDFHIP_CHECK_HIP(hipMemcpyAsync(rgb, w.rgb, (size_t)NP * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
+  if (feat != nullptr && mode != SDFHIP_MODE_SDF) {
+    const int64_t total = P * f->cfg.geo_feat_dim;
+    untp_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(w.feat, k->nbf, f->cfg.geo_feat_dim, P, feat);
+  }
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void sdfrow_reduce_kernel(const float* __restrict__ partial, const int n_split, const int stride, const int hidden,
+                                     float* __restrict__ w_row, float* __restrict__ b0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= stride) return;
+  float s = 0.0f;
+  for (int k = 0; k < n_split; ++k) s += partial[(size_t)k * stride + i];
+  if (i < hidden) w_row[i] = s;
+  if (i == stride - 32) b0[0] = s;
+}
+
+static void run_wgrad(const SdfHipField* f, const FieldWs& w, const WgradArgs& base, int rowmap, int colmap, int64_t w_off, int ld,
+                      float scale, int64_t b_off, float* theta_bar, hipStream_t s) {
+  WgradArgs a = base;
+  a.n_ib_groups = (a.nbb + 3) / 4;
+  const int n_obg = (a.nba + 3) / 4;
+  a.tiles_per_split = (int)((a.n_tiles + w.n_split - 1) / w.n_split);
+  a.partial = w.partial;
+  a.bpartial = b_off >= 0 ? w.bpartial : nullptr;
+  wgrad_kernel<<<dim3((unsigned)w.n_split, (unsigned)(n_obg * a.n_ib_groups)), 64, 0, s>>>(a);
+  WreduceArgs r;
+  memset(&r, 0, sizeof(r));
+  r.partial = w.partial;
+  r.bpartial = a.bpartial;
+  r.n_split = w.n_split;
+  r.rows = a.nba * 32;
+  r.cols = a.nbb * 32;
+  r.rowmap = f->d_maps + rowmap;
+  r.colmap = f->d_maps + colmap;
+  r.theta_bar = theta_bar;
+  r.w_off = w_off;
+  r.ld = ld;
+  r.scale = scale;
+  r.b_off = b_off;
+  r.accumulate = 0;
+  const int total = r.rows * r.cols;
+  wreduce_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(r);
+}
+
+extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
+                                     int64_t n_rays, int32_t n_samples, void* workspace, const float* sdf_bar, const float* grad_bar,
+                                     const float* rgb_bar, float* theta_bar, float* table_bar, float* emb_bar,
+                                     sdfhip_stream_t stream) {
+  (void)table;
+  SDFHIP_REQUIRE(f && packed && level_mask && workspace && theta_bar && table_bar, "field_backward: null argument");
+  if (n_rays == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const FieldKernels* k = f->k;
+  const int64_t P = n_rays * n_samples, NP = sdfhip_padded_points(P);
+  FieldWs w;
+  carve(f, P, 1, workspace, &w);
+  const unsigned grid = (unsigned)(NP / 128);
+  const unsigned pgrid = (unsigned)(NP / 256 + (NP % 256 != 0));
+
+  // 1. colour network backward
+  ColBwdArgs cb;
+  memset(&cb, 0, sizeof(cb));
+  fill_col_ptrs(f, packed, &cb.p);
+  cb.rgb = w.rgb;
+  cb.rgbbar = rgb_bar;
+  cb.n_points = rgb_bar != nullptr ? P : 0;
+  for (int l = 0; l < k->nlc; ++l) {
+    cb.h_tp[l] = w.h[l];
+    cb.d_tp[l] = w.d[l];
+  }
+  cb.dout_tp = w.dout;
+  cb.featbar_tp = w.featbar;
+  cb.csmallbar_tp = w.csmallbar;
+  k->col_bwd(cb, grid, s);
+
+  // 2. total d L / d grad, tangent seed, padded sdfbar
+  BwdPrepArgs pa;
+  memset(&pa, 0, sizeof(pa));
+  pa.gradbar = grad_bar;
+  pa.sdfbar_in = sdf_bar;
+  pa.csmallbar_tp = w.csmallbar;
+  pa.x = w.x;
+  pa.dydp = w.dydp;
+  pa.mask = level_mask;
+  pa.n_points = P;
+  pa.n_padded = NP;
+  pa.pe_degree = f->cfg.pe_degree;
+  pa.use_pe = f->cfg.use_position_encoding;
+  pa.n_feat = f->n_feat;
+  pa.nb0 = k->nb0;
+  pa.nbs = k->nbs;
+  pa.emb_dim = f->cfg.appearance_dim;
+  pa.S = n_samples;
+  pa.gtot = w.gtot;
+  pa.ebar_tp = w.ebar;
+  pa.sdfbar = w.sdfbar;
+  pa.embbar = emb_bar;
+  bwd_prep_kernel<<<pgrid, 256, 0, s>>>(pa);
+
+  // 3. geometry network: tangent pass + data backward
+  GeoBwdArgs gb;
+  memset(&gb, 0, sizeof(gb));
+  fill_geo_ptrs(f, packed, &gb.p);
+  gb.ebar_tp = w.ebar;
+  gb.featbar_tp = w.featbar;
+  gb.sdfbar = w.sdfbar;
+  for (int l = 0; l < k->nl; ++l) {
+    gb.z_tp[l] = w.z[l];
+    gb.r_tp[l] = w.r[l];
+    gb.zb_tp[l] = w.zb[l];
+  }
+  for (int l = 1; l <= k->nl; ++l) gb.qb_tp[l] = w.qb[l];
+  gb.in0bar_tp = w.in0bar;
+  k->geo_bwd(gb, grid, s);
+
+  // 4. hash table gradient (first-order through the features + second-order through d feature / d x)
+  GridBwdArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  ga.grid = f->grid;
+  ga.x = w.x;
+  ga.in0bar_tp = w.in0bar;
+  ga.e_tp = w.e;
+  ga.gtot = w.gtot;
+  ga.mask = level_mask;
+  ga.n_points = P;
+  ga.pe_degree = f->cfg.pe_degree;
+  ga.nb0 = k->nb0;
+  ga.tablebar = table_bar;
+  grid_bwd_kernel<<<dim3((unsigned)((P + 255) / 256), f->grid.n_levels), 256, 0, s>>>(ga);
+
+  // 5. weight gradients: split-K GEMMs over points
+  const int64_t n_tiles = NP / 32;
+  auto seg1 = [](const float* p, int nb, int xf) {
+    TpOperand o;
+    memset(&o, 0, sizeof(o));
+    o.ptr[0] = p;
+    o.nb[0] = nb;
+    o.xf[0] = xf;
+    return o;
+  };
+  auto seg2 = [](const float* p0, int nb0, int xf0, const float* p1, int nb1, int xf1) {
+    TpOperand o;
+    memset(&o, 0, sizeof(o));
+    o.ptr[0] = p0;
+    o.nb[0] = nb0;
+    o.xf[0] = xf0;
+    o.ptr[1] = p1;
+    o.nb[1] = nb1;
+    o.xf[1] = xf1;
+    return o;
+  };
+  for (int l = 0; l < k->nl; ++l) {
+    const LinearInfo& li = f->lin[l];
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_pairs = 2;
+    a.nba = f->nbo_geo(l);
+    a.nbb = f->kb_geo(l);
+    a.n_tiles = n_tiles;
+    a.A[0] = seg1(w.zb[l], a.nba, 0);
+    a.A[1] = seg1(w.r[l], a.nba, 0);
+    if (l == 0) {
+      a.B[0] = seg1(w.in0, k->nb0, 0);
+      a.B[1] = seg1(w.ebar, k->nb0, 0);
+    } else if (l == k->skip) {
+      a.B[0] = seg2(w.z[l - 1], k->nb3, 1, w.in0, k->nb0, 0);
+      a.B[1] = seg1(w.qb[l], a.nbb, 0);
+    } else {
+      a.B[0] = seg1(w.z[l - 1], a.nbb, 1);
+      a.B[1] = seg1(w.qb[l], a.nbb, 0);
+    }
+    run_wgrad(f, w, a, f->g_rowmap[l], f->g_colmap[l], li.w_off, li.in_dim, f->g_scale[l], li.b_off, theta_bar, s);
+  }
+  {
+    // output layer: feature rows through the GEMM, sdf row through its own reduction
+    const LinearInfo& li = f->lin[k->nl];
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_pairs = 1;
+    a.nba = k->nbf;
+    a.nbb = k->nbh;
+    a.n_tiles = n_tiles;
+    a.A[0] = seg1(w.featbar, k->nbf, 0);
+    a.B[0] = seg1(w.z[k->nl - 1], k->nbh, 1);
+    run_wgrad(f, w, a, f->g_rowmap[k->nl], f->g_colmap[k->nl], li.w_off, li.in_dim, 1.0f, li.b_off, theta_bar, s);
+    const int tps = (int)((n_tiles + w.n_split - 1) / w.n_split);
+    k->sdfrow(w.z[k->nl - 1], w.qb[k->nl], w.sdfbar, n_tiles, tps, w.partial, (unsigned)w.n_split, s);
+    const int stride = k->nbh * 32 + 32;
+    sdfrow_reduce_kernel<<<(stride + 255) / 256, 256, 0, s>>>(w.partial, w.n_split, stride, f->cfg.hidden_dim, theta_bar + li.w_off,
+                                                              theta_bar + li.b_off);
+  }
+  for (int l = 0; l < k->nlc; ++l) {
+    const LinearInfo& li = f->lin[f->n_geo + l];
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_pairs = 1;
+    a.nba = k->nbc;
+    a.nbb = f->kb_col(l);
+    a.n_tiles = n_tiles;
+    a.A[0] = seg1(w.d[l], k->nbc, 0);
+    a.B[0] = l == 0 ? seg2(w.feat, k->nbf, 0, w.csmall, k->nbs, 0) : seg1(w.h[l - 1], k->nbc, 0);
+    run_wgrad(f, w, a, f->c_rowmap[l], f->c_colmap[l], li.w_off, li.in_dim, 1.0f, li.b_off, theta_bar, s);
+  }
+  {
+    const LinearInfo& li = f->lin[f->n_geo + k->nlc];
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_pairs = 1;
+    a.nba = 1;
+    a.nbb = k->nbc;
+    a.n_tiles = n_tiles;
+    a.A[0] = seg1(w.dout, 1, 0);
+    a.B[0] = seg1(w.h[k->nlc - 1], k->nbc, 0);
+    run_wgrad(f, w, a, f->c_rowmap[k->nlc], f->c_colmap[k->nlc], li.w_off, li.in_dim, 1.0f, li.b_off, theta_bar, s);
+  }
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ proposal field
+static int prop_args(const SdfHipGridCfg* grid, PropArgs* a) {
+  memset(a, 0, sizeof(*a));
+  SDFHIP_REQUIRE(grid != nullptr && grid->n_levels == kPropLevels && grid->n_features == 2,
+                 "proposal field: only 5 levels x 2 features is built");
+  return make_grid_dev(grid, &a->grid);
+}
+static const int kPropBwdBlocks = 1024;
+extern "C" int64_t sdfhip_proposal_workspace_size(void) { return (int64_t)kPropBwdBlocks * 176 * sizeof(float); }
+
+extern "C" int sdfhip_proposal_forward(const SdfHipGridCfg* grid, const float* table, const float* w1, const float* w2,
+                                       const float* origins, const float* dirs, const float* starts, const float* ends,
+                                       int64_t n_rays, int32_t n_samples, int32_t contract, float* density, sdfhip_stream_t stream) {
+  PropArgs a;
+  const int rc = prop_args(grid, &a);
+  if (rc != 0) return rc;
+  SDFHIP_REQUIRE(table && w1 && w2 && origins && density && (dirs == nullptr || (starts && ends)), "proposal_forward: null argument");
+  a.origins = origins;
+  a.dirs = dirs;
+  a.starts = starts;
+  a.ends = ends;
+  a.n_points = n_rays * n_samples;
+  a.S = n_samples;
+  a.contract = contract;
+  a.table = table;
+  a.w1 = w1;
+  a.w2 = w2;
+  a.density = density;
+  if (a.n_points == 0) return 0;
+  prop_fwd_kernel<<<(unsigned)((a.n_points + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfhip_proposal_backward(const SdfHipGridCfg* grid, const float* table, const float* w1, const float* w2,
+                                        const float* origins, const float* dirs, const float* starts, const float* ends,
+                                        int64_t n_rays, int32_t n_samples, int32_t contract, const float* density_bar, void* workspace,
+                                        float* table_bar, float* w1_bar, float* w2_bar, sdfhip_stream_t stream) {
+  PropArgs a;
+  const int rc = prop_args(grid, &a);
+  if (rc != 0) return rc;
+  SDFHIP_REQUIRE(table && w1 && w2 && origins && (dirs == nullptr || (starts && ends)) && density_bar && workspace && table_bar && w1_bar && w2_bar,
+                 "proposal_backward: null argument");
+  hipStream_t s = (hipStream_t)stream;
+  a.origins = origins;
+  a.dirs = dirs;
+  a.starts = starts;
+  a.ends = ends;
+  a.n_points = n_rays * n_samples;
+  a.S = n_samples;
+  a.contract = contract;
+  a.table = table;
+  a.w1 = w1;
+  a.w2 = w2;
+  a.densbar = density_bar;
+  a.tablebar = table_bar;
+  a.wpartial = (float*)workspace;
+  prop_bwd_kernel<<<kPropBwdBlocks, 256, 0, s>>>(a);
+  colsum_kernel<<<1, 256, 0, s>>>(a.wpartial, kPropBwdBlocks, 160, w1_bar, 0);
+  colsum_kernel<<<1, 64, 0, s>>>(a.wpartial + 160, kPropBwdBlocks, 16, w2_bar, 0);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ samplers
+extern "C" int sdfhip_sample_spaced(const float* nears, const float* fars, const float* jitter, int64_t n_rays, int32_t n_samples,
+                                    float* bins, float* starts, float* ends, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(nears && fars && bins && starts && ends && n_samples >= 1, "sample_spaced: bad argument");
+  BinsArgs a;
+  a.nears = nears;
+  a.fars = fars;
+  a.jitter = jitter;
+  a.N = (int)n_rays;
+  a.S = n_samples;
+  a.bins = bins;
+  a.starts = starts;
+  a.ends = ends;
+  const int64_t total = n_rays * (n_samples + 1);
+  if (total == 0) return 0;
+  spaced_bins_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+#define SDFHIP_DISPATCH_C(S, CALL)                                      \
+  do {                                                                  \
+    const int c_ = ((S) + 63) / 64;                                     \
+    if (c_ <= 1) { constexpr int C = 1; CALL; }                         \
+    else if (c_ <= 2) { constexpr int C = 2; CALL; }                    \
+    else if (c_ <= 4) { constexpr int C = 4; CALL; }                    \
+    else { constexpr int C = 8; CALL; }                                 \
+  } while (0)
+
+extern "C" int sdfhip_sample_pdf(const float* weights, const float* bins_in, const float* nears, const float* fars, const float* jitter,
+                                 int64_t n_rays, int32_t s_in, int32_t s_out, float anneal, float histogram_padding, float* bins_out,
+                                 float* starts, float* ends, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(weights && bins_in && nears && fars && bins_out && starts && ends, "sample_pdf: null argument");
+  SDFHIP_REQUIRE(s_in >= 1 && s_in <= 64 * kMaxPerLane && s_out >= 1, "sample_pdf: s_in %d / s_out %d unsupported", s_in, s_out);
+  PdfArgs a;
+  a.weights = weights;
+  a.bins_in = bins_in;
+  a.nears = nears;
+  a.fars = fars;
+  a.jitter = jitter;
+  a.N = (int)n_rays;
+  a.S_in = s_in;
+  a.S_out = s_out;
+  a.anneal = anneal;
+  a.histogram_padding = histogram_padding;
+  a.eps = 1e-5f;
+  const int nbins = s_out + 1;
+  a.u_end = (float)(1.0 - 1.0 / (double)nbins);
+  a.u_center = (float)(1.0 / (double)(2 * nbins));
+  a.bins_out = bins_out;
+  a.starts = starts;
+  a.ends = ends;
+  if (n_rays == 0) return 0;
+  const unsigned grid = (unsigned)((n_rays + 3) / 4);
+  SDFHIP_DISPATCH_C(s_in, (pdf_sample_kernel<C><<<grid, 256, 0, (hipStream_t)stream>>>(a)));
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ weights + renderers
+extern "C" int sdfhip_density_weights_forward(const float* density, const float* starts, const float* ends, int64_t n_rays,
+                                              int32_t n_samples, float* weights, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(density && starts && ends && weights, "density_weights_forward: null argument");
+  SDFHIP_REQUIRE(n_samples >= 1 && n_samples <= 64 * kMaxPerLane, "density_weights: n_samples %d unsupported", n_samples);
+  DensityWeightsArgs a;
+  memset(&a, 0, sizeof(a));
+  a.density = density;
+  a.starts = starts;
+  a.ends = ends;
+  a.N = (int)n_rays;
+  a.S = n_samples;
+  a.weights = weights;
+  if (n_rays == 0) return 0;
+  const unsigned grid = (unsigned)((n_rays + 3) / 4);
+  SDFHIP_DISPATCH_C(n_samples, (density_weights_fwd_kernel<C><<<grid, 256, 0, (hipStream_t)stream>>>(a)));
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfhip_density_weights_backward(const float* density, const float* starts, const float* ends, int64_t n_rays,
+                                               int32_t n_samples, const float* weights_bar, float* density_bar,
+                                               sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(density && starts && ends && weights_bar && density_bar, "density_weights_backward: null argument");
+  SDFHIP_REQUIRE(n_samples >= 1 && n_samples <= 64 * kMaxPerLane, "density_weights: n_samples %d unsupported", n_samples);
+  DensityWeightsArgs a;
+  memset(&a, 0, sizeof(a));
+  a.density = density;
+  a.starts = starts;
+  a.ends = ends;
+  a.N = (int)n_rays;
+  a.S = n_samples;
+  a.weightsbar = weights_bar;
+  a.densitybar = density_bar;
+  if (n_rays == 0) return 0;
+  const unsigned grid = (unsigned)((n_rays + 3) / 4);
+  SDFHIP_DISPATCH_C(n_samples, (density_weights_bwd_kernel<C><<<grid, 256, 0, (hipStream_t)stream>>>(a)));
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void minmax_init_kernel(float* mm) {
+  mm[0] = __uint_as_float(0x7f800000u);
+  mm[1] = 0.0f;
+}
+
+extern "C" int sdfhip_neus_render_forward(const float* sdf, const float* grad, const float* rgb, const float* dirs, const float* starts,
+                                          const float* ends, const float* variance, const float* background, float cos_anneal,
+                                          int64_t n_rays, int32_t n_samples, float* alpha, float* weights, float* out_rgb,
+                                          float* out_depth_raw, float* out_depth, float* out_normal, float* out_acc,
+                                          float* steps_minmax, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(sdf && grad && rgb && dirs && starts && ends && variance && alpha && weights && out_rgb && out_depth_raw && out_depth &&
+                     out_normal && out_acc && steps_minmax,
+                 "neus_render_forward: null argument");
+  SDFHIP_REQUIRE(n_samples >= 1 && n_samples <= 64 * kMaxPerLane, "neus_render: n_samples %d unsupported", n_samples);
+  hipStream_t s = (hipStream_t)stream;
+  NeusRenderArgs a;
+  memset(&a, 0, sizeof(a));
+  a.sdf = sdf;
+  a.grad = grad;
+  a.rgb = rgb;
+  a.dirs = dirs;
+  a.starts = starts;
+  a.ends = ends;
+  a.variance = variance;
+  a.bg = background;
+  a.cos_anneal = cos_anneal;
+  a.N = (int)n_rays;
+  a.S = n_samples;
+  a.alpha = alpha;
+  a.weights = weights;
+  a.out_rgb = out_rgb;
+  a.out_depth = out_depth_raw;
+  a.out_normal = out_normal;
+  a.out_acc = out_acc;
+  a.steps_minmax = steps_minmax;
+  if (n_rays == 0) return 0;
+  minmax_init_kernel<<<1, 1, 0, s>>>(steps_minmax);
+  const unsigned grid = (unsigned)((n_rays + 3) / 4);
+  SDFHIP_DISPATCH_C(n_samples, (neus_render_fwd_kernel<C><<<grid, 256, 0, s>>>(a)));
+  depth_clip_kernel<<<(unsigned)((n_rays + 255) / 256), 256, 0, s>>>(out_depth_raw, steps_minmax, (int)n_rays, out_depth);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfhip_neus_render_backward(const float* sdf, const float* grad, const float* rgb, const float* dirs, const float* starts,
+                                           const float* ends, const float* variance, const float* background, float cos_anneal,
+                                           int64_t n_rays, int32_t n_samples, const float* alpha, const float* weights,
+                                           const float* out_depth_raw, const float* out_acc, const float* steps_minmax,
+                                           const float* rgb_bar, const float* depth_bar, const float* normal_bar, const float* acc_bar,
+                                           const float* weights_bar, float* sdf_bar, float* grad_bar, float* rgbs_bar,
+                                           float* variance_bar, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(sdf && grad && rgb && dirs && starts && ends && variance && alpha && weights && out_depth_raw && out_acc && steps_minmax &&
+                     sdf_bar && grad_bar && rgbs_bar,
+                 "neus_render_backward: null argument");
+  SDFHIP_REQUIRE(n_samples >= 1 && n_samples <= 64 * kMaxPerLane, "neus_render: n_samples %d unsupported", n_samples);
+  NeusRenderArgs a;
+  memset(&a, 0, sizeof(a));
+  a.sdf = sdf;
+  a.grad = grad;
+  a.rgb = rgb;
+  a.dirs = dirs;
+  a.starts = starts;
+  a.ends = ends;
+  a.variance = variance;
+  a.bg = background;
+  a.cos_anneal = cos_anneal;
+  a.N = (int)n_rays;
+  a.S = n_samples;
+  a.alpha = const_cast<float*>(alpha);
+  a.weights = const_cast<float*>(weights);
+  a.out_depth = const_cast<float*>(out_depth_raw);
+  a.out_acc = const_cast<float*>(out_acc);
+  a.steps_minmax = const_cast<float*>(steps_minmax);
+  a.rgbbar = rgb_bar;
+  a.depthbar = depth_bar;
+  a.normalbar = normal_bar;
+  a.accbar = acc_bar;
+  a.weightsbar = weights_bar;
+  a.sdfbar = sdf_bar;
+  a.gradbar = grad_bar;
+  a.rgbsbar = rgbs_bar;
+  a.variancebar = variance_bar;
+  if (n_rays == 0) return 0;
+  const unsigned grid = (unsigned)((n_rays + 3) / 4);
+  SDFHIP_DISPATCH_C(n_samples, (neus_render_bwd_kernel<C><<<grid, 256, 0, (hipStream_t)stream>>>(a)));
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}

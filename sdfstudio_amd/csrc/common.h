@@ -1,0 +1,80 @@
+// sdfhip — shared device/host helpers (gfx950 only).
+//
+// "Tile-packed" (TP) activation layout
+// ------------------------------------
+// Every per-point feature matrix that an MFMA kernel produces or consumes lives in HBM in the
+// accumulator layout of v_mfma_f32_32x32x2_f32 so that a wave can load / store it with perfectly
+// coalesced 256-byte rows and feed it to the next MFMA with no LDS round trip and no transposition:
+//
+//     A[tile][blk][reg][lane]      tile = point / 32, blk = feature / 32, reg in [0,16), lane in [0,64)
+//     point   = 32*tile + (lane & 31)
+//     feature = 32*blk  + (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5)
+//
+// i.e. lane l of a wave owns point (l & 31); the two half-waves own complementary halves of that point's
+// features.  A "layer" D[out][point] = sum_k W[out][k] * H[point][k] then runs with W as the MFMA A operand
+// (pre-packed in the matching k order, see pack_kernel) and the wave's own registers as the B operand.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define SDFHIP_HD __host__ __device__ __forceinline__
+#define SDFHIP_D __device__ __forceinline__
+
+SDFHIP_HD int tp_row(int reg, int hf) { return (reg & 3) + 8 * (reg >> 2) + 4 * hf; }
+SDFHIP_HD int tp_reg_of_row(int row) { return (row & 3) | ((row >> 3) << 2); }
+SDFHIP_HD int tp_hf_of_row(int row) { return (row >> 2) & 1; }
+// flat index of (point p, feature f) in a TP array with nb feature blocks
+SDFHIP_HD size_t tp_index(int64_t p, int f, int nb) {
+  const int64_t tile = p >> 5;
+  const int row = f & 31;
+  return (size_t)(((tile * nb + (f >> 5)) * 16 + tp_reg_of_row(row)) * 64 + (p & 31) + 32 * tp_hf_of_row(row));
+}
+
+template <int I, int N, class F>
+SDFHIP_D void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// ---- softplus(beta=100, threshold=20) and its derivatives, matching torch's CPU kernels
+// (aten softplus / softplus_backward / softplus_double_backward) used at sdf_field.py:365,409.
+SDFHIP_D void softplus100(float z, float& h, float& d1) {
+  const float t = 100.0f * z;
+  if (t > 20.0f) {
+    h = z;
+    d1 = 1.0f;
+  } else {
+    const float e = expf(t);
+    h = log1pf(e) * 0.01f;
+    d1 = e / (e + 1.0f);
+  }
+}
+SDFHIP_D float softplus100_d1(float z) {
+  const float t = 100.0f * z;
+  if (t > 20.0f) return 1.0f;
+  const float e = expf(t);
+  return e / (e + 1.0f);
+}
+
+// thread-local last-error string (extern "C" API returns 0 or a negative code)
+void sdfhip_set_error(const char* fmt, ...);
+#define SDFHIP_CHECK_HIP(expr)                                                            \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      sdfhip_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      return -2;                                                                          \
+    }                                                                                     \
+  } while (0)
+#define SDFHIP_REQUIRE(cond, ...)       \
+  do {                                  \
+    if (!(cond)) {                      \
+      sdfhip_set_error(__VA_ARGS__);    \
+      return -1;                        \
+    }                                   \
+  } while (0)

@@ -1,0 +1,56 @@
+// sdfhip — per-configuration instantiation of the fused network kernels.  Each supported network shape is
+// compiled in its own translation unit (inst_*.hip) so the build parallelises; the API layer picks the table.
+#pragma once
+#include "col_kernels.h"
+#include "wgrad_kernels.h"
+
+struct FieldKernels {
+  int nbh, nb0, nb3, nl, skip, nbf, nbs, nbc, nlc;
+  size_t geo_lds, col_lds;
+  void (*geo_fwd)(int mode_train_geo_sdf, const GeoFwdArgs&, unsigned grid, hipStream_t);
+  void (*geo_bwd)(const GeoBwdArgs&, unsigned grid, hipStream_t);
+  void (*col_fwd)(const ColFwdArgs&, unsigned grid, hipStream_t);
+  void (*col_bwd)(const ColBwdArgs&, unsigned grid, hipStream_t);
+  void (*sdfrow)(const float* z_last, const float* qb_last, const float* sdfbar, int64_t n_tiles, int tiles_per_split,
+                 float* partial, unsigned grid, hipStream_t);
+};
+
+// Kernels that want more than 64 KiB of dynamic LDS must raise the per-function limit first.
+template <class K, class A>
+static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned block, size_t lds, hipStream_t s) {
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, s, a);
+}
+
+// mode: 0 = train/full (GRAD, SAVE, FEAT), 1 = geonetwork (FEAT only), 2 = sdf only
+#define SDFHIP_DEFINE_FIELD_KERNELS(NAME, NBH, NB0, NB3, NL, SKIP, NBF, NBS, NBC, NLC)                              \
+  namespace NAME##_ns {                                                                                              \
+  using GD = GeoDims<NBH, NB0, NB3, NL, SKIP, NBF>;                                                                  \
+  using CD = ColDims<NBF, NBS, NBC, NLC>;                                                                            \
+  static void geo_fwd(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s) {                                 \
+    const size_t lds = GD::LDS_FLOATS * sizeof(float);                                                               \
+    if (mode == 0) launch_lds(geo_fwd_kernel<GD, true, true, true>, a, grid, 256, lds, s);                                   \
+    else if (mode == 1) launch_lds(geo_fwd_kernel<GD, false, false, true>, a, grid, 256, lds, s);                            \
+    else launch_lds(geo_fwd_kernel<GD, false, false, false>, a, grid, 256, lds, s);                                     \
+  }                                                                                                                  \
+  static void geo_bwd(const GeoBwdArgs& a, unsigned grid, hipStream_t s) {                                           \
+    launch_lds(geo_bwd_kernel<GD>, a, grid, 256, GD::LDS_FLOATS * sizeof(float), s);                                         \
+  }                                                                                                                  \
+  static void col_fwd(const ColFwdArgs& a, unsigned grid, hipStream_t s) {                                           \
+    launch_lds(col_fwd_kernel<CD, true>, a, grid, 256, CD::LDS_FLOATS * sizeof(float), s);                                   \
+  }                                                                                                                  \
+  static void col_bwd(const ColBwdArgs& a, unsigned grid, hipStream_t s) {                                           \
+    launch_lds(col_bwd_kernel<CD>, a, grid, 256, CD::LDS_FLOATS * sizeof(float), s);                                         \
+  }                                                                                                                  \
+  static void sdfrow(const float* z, const float* q, const float* sb, int64_t nt, int tps, float* part,             \
+                     unsigned grid, hipStream_t s) {                                                                 \
+    sdfrow_grad_kernel<NBH><<<grid, 64, 0, s>>>(z, q, sb, nt, tps, part);                                            \
+  }                                                                                                                  \
+  }                                                                                                                  \
+  const FieldKernels* sdfhip_kernels_##NAME() {                                                                      \
+    static const FieldKernels k = {NBH, NB0, NB3, NL, SKIP, NBF, NBS, NBC, NLC,                                      \
+                                   NAME##_ns::GD::LDS_FLOATS * sizeof(float), NAME##_ns::CD::LDS_FLOATS * sizeof(float), \
+                                   NAME##_ns::geo_fwd, NAME##_ns::geo_bwd, NAME##_ns::col_fwd, NAME##_ns::col_bwd,   \
+                                   NAME##_ns::sdfrow};                                                               \
+    return &k;                                                                                                       \
+  }

@@ -1,0 +1,493 @@
+// sdfhip — per-point kernels around the fused networks (gfx950; HBM / cache-bandwidth bound gather work):
+//   geo_encode_kernel      start position -> L-inf contraction -> [x | NeRF-PE(x) | hash-grid features * mask]  (TP)
+//                          + d feature / d p for the analytic normal            (sdf_field.py:380-392, 629)
+//   grad_assemble_kernel   d sdf / d x = J_in0^T e ; builds the colour network's small-input block
+//   bwd_prep_kernel        total d L / d grad -> tangent seed ebar = J_in0 gbar (TP), sdfbar padded
+//   grid_bwd_kernel        scatter-add (fp32 hardware atomics) of first- and second-order terms into the table gradient
+//   prop_fwd / prop_bwd    fused proposal density field: contraction, 5-level linear grid, 10->16->1 ReLU MLP, exp
+//                          (density_fields.py:99-118, activations.py:23-39)
+// The grid arithmetic restates tinycudann's GridEncoding (see oracle/hashgrid.py for the algorithm statement).
+#pragma once
+#include "common.h"
+
+constexpr int kMaxLevels = 16;
+struct GridLevelDev {
+  float scale;
+  uint32_t res;
+  uint32_t size;    // entries in level
+  uint32_t offset;  // first entry
+  uint32_t hashed;
+};
+struct GridDev {
+  int32_t n_levels, n_features, smoothstep, pad_;
+  GridLevelDev lv[kMaxLevels];
+};
+
+SDFHIP_D void contract_inf(float x[3]) {
+  // spatial_distortions.py:66-73 with ord = inf
+  const float mag = fmaxf(fabsf(x[0]), fmaxf(fabsf(x[1]), fabsf(x[2])));
+  if (mag >= 1.0f) {
+    const float k = (2.0f - 1.0f / mag);
+    x[0] = k * (x[0] / mag);
+    x[1] = k * (x[1] / mag);
+    x[2] = k * (x[2] / mag);
+  }
+}
+
+struct GridCell {
+  uint32_t idx[8];
+  float w[3], dw[3];  // interpolation weight along each axis and its derivative w.r.t. the [0,1] position
+};
+SDFHIP_D void grid_cell(const GridLevelDev& L, const bool smooth, const float p[3], GridCell& c) {
+  uint32_t g[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float pos = fmaf(L.scale, p[d], 0.5f);
+    const float fl = floorf(pos);
+    const float f = pos - fl;
+    g[d] = (uint32_t)(int)fl;
+    if (smooth) {
+      c.w[d] = f * f * (3.0f - 2.0f * f);
+      c.dw[d] = 6.0f * f * (1.0f - f) * L.scale;
+    } else {
+      c.w[d] = f;
+      c.dw[d] = L.scale;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const uint32_t cx = g[0] + (k & 1), cy = g[1] + ((k >> 1) & 1), cz = g[2] + ((k >> 2) & 1);
+    uint32_t idx;
+    if (L.hashed) {
+      idx = (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & (L.size - 1u);  // hashed levels: size is a power of two
+    } else {
+      idx = cx + cy * L.res + cz * L.res * L.res;
+      if (idx >= L.size) idx -= L.size;  // only the x == 1.0 face wraps
+    }
+    c.idx[k] = L.offset + idx;
+  }
+}
+SDFHIP_D float corner_w(const GridCell& c, const int k) {
+  const float wx = (k & 1) ? c.w[0] : 1.0f - c.w[0];
+  const float wy = (k & 2) ? c.w[1] : 1.0f - c.w[1];
+  const float wz = (k & 4) ? c.w[2] : 1.0f - c.w[2];
+  return wx * wy * wz;
+}
+// d corner weight / d p_d
+SDFHIP_D void corner_dw(const GridCell& c, const int k, float out[3]) {
+  const float wx = (k & 1) ? c.w[0] : 1.0f - c.w[0];
+  const float wy = (k & 2) ? c.w[1] : 1.0f - c.w[1];
+  const float wz = (k & 4) ? c.w[2] : 1.0f - c.w[2];
+  out[0] = ((k & 1) ? c.dw[0] : -c.dw[0]) * wy * wz;
+  out[1] = ((k & 2) ? c.dw[1] : -c.dw[1]) * wx * wz;
+  out[2] = ((k & 4) ? c.dw[2] : -c.dw[2]) * wx * wy;
+}
+
+SDFHIP_D void start_position(const float* __restrict__ origins, const float* __restrict__ dirs,
+                             const float* __restrict__ starts, const int64_t p, const int S, float x[3]) {
+  if (dirs == nullptr) {  // origins already holds [P,3] positions
+    x[0] = origins[p * 3 + 0];
+    x[1] = origins[p * 3 + 1];
+    x[2] = origins[p * 3 + 2];
+  } else {
+    const int64_t ray = p / S;
+    const float t = starts[p];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) x[d] = origins[ray * 3 + d] + dirs[ray * 3 + d] * t;  // rays.py:61-73
+  }
+}
+
+struct EncodeArgs {
+  GridDev grid;
+  const float* origins;  // [N,3] (or [P,3] positions when dirs == null)
+  const float* dirs;     // [N,3] or null
+  const float* starts;   // [N,S] or null
+  int64_t n_points, n_padded;
+  int32_t S, contract, pe_degree, use_pe;
+  int32_t nb0;           // in0 blocks
+  const float* table;    // [entries][F]
+  const float* mask;     // [L*F]
+  float* x_out;          // [n_padded][3] contracted positions
+  float* in0_tp;         // [n_padded/32][nb0][16][64]
+  float* dydp;           // [(L*F)*3][n_padded]  or null
+};
+
+// grid = (n_padded / 256, n_levels + 1), block = 256
+__global__ __launch_bounds__(256) void geo_encode_kernel(const EncodeArgs a) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.n_padded) return;
+  const bool live = p < a.n_points;
+  float x[3] = {0.f, 0.f, 0.f};
+  if (live) {
+    start_position(a.origins, a.dirs, a.starts, p, a.S, x);
+    if (a.contract) contract_inf(x);
+  }
+  const int L = a.grid.n_levels;
+  const int level = blockIdx.y;
+  const int pe_dims = 6 * a.pe_degree;
+  const int feat0 = 3 + pe_dims;
+  if (level == L) {
+    // position + positional encoding + zero padding  (encodings.py:167-208: sin(cat[x f, x f + pi/2]))
+    a.x_out[p * 3 + 0] = x[0];
+    a.x_out[p * 3 + 1] = x[1];
+    a.x_out[p * 3 + 2] = x[2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) a.in0_tp[tp_index(p, d, a.nb0)] = x[d];
+    for (int d = 0; d < 3; ++d)
+      for (int f = 0; f < a.pe_degree; ++f) {
+        const float u = x[d] * (float)(1 << f);
+        const float s1 = (live && a.use_pe) ? sinf(u) : 0.0f;
+        const float s2 = (live && a.use_pe) ? sinf(u + 1.57079632679489661923f) : 0.0f;
+        a.in0_tp[tp_index(p, 3 + d * a.pe_degree + f, a.nb0)] = s1;
+        a.in0_tp[tp_index(p, 3 + 3 * a.pe_degree + d * a.pe_degree + f, a.nb0)] = s2;
+      }
+    for (int c = feat0 + L * a.grid.n_features; c < a.nb0 * 32; ++c) a.in0_tp[tp_index(p, c, a.nb0)] = 0.0f;
+    return;
+  }
+  // ---- one grid level (F == 2)
+  const float m0 = a.mask[level * 2 + 0], m1 = a.mask[level * 2 + 1];
+  float y0 = 0.f, y1 = 0.f, d0[3] = {0.f, 0.f, 0.f}, d1[3] = {0.f, 0.f, 0.f};
+  if (live && (m0 != 0.0f || m1 != 0.0f)) {
+    const float pp[3] = {(x[0] + 2.0f) * 0.25f, (x[1] + 2.0f) * 0.25f, (x[2] + 2.0f) * 0.25f};  // sdf_field.py:384
+    GridCell c;
+    grid_cell(a.grid.lv[level], a.grid.smoothstep != 0, pp, c);
+    const float2* tab = reinterpret_cast<const float2*>(a.table);
+    float2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = tab[c.idx[k]];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float w = corner_w(c, k);
+      y0 = fmaf(w, v[k].x, y0);
+      y1 = fmaf(w, v[k].y, y1);
+      if (a.dydp != nullptr) {
+        float dw[3];
+        corner_dw(c, k, dw);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          d0[d] = fmaf(dw[d], v[k].x, d0[d]);
+          d1[d] = fmaf(dw[d], v[k].y, d1[d]);
+        }
+      }
+    }
+  }
+  a.in0_tp[tp_index(p, feat0 + level * 2 + 0, a.nb0)] = y0 * m0;
+  a.in0_tp[tp_index(p, feat0 + level * 2 + 1, a.nb0)] = y1 * m1;
+  if (a.dydp != nullptr) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      a.dydp[(size_t)((level * 2 + 0) * 3 + d) * a.n_padded + p] = d0[d];
+      a.dydp[(size_t)((level * 2 + 1) * 3 + d) * a.n_padded + p] = d1[d];
+    }
+  }
+}
+
+struct AssembleArgs {
+  const float* e_tp;    // [T][nb0]  d sdf / d in0
+  const float* x;       // [n_padded][3]
+  const float* dydp;    // [(L*F)*3][n_padded]
+  const float* mask;    // [L*F]
+  const float* dirs;    // [N,3]
+  const float* emb;     // [N][emb_dim] per-ray appearance embedding or null (zeros)
+  int64_t n_points, n_padded;
+  int32_t S, pe_degree, use_pe, n_feat, nb0, nbs, emb_dim, pad_;
+  float* grad;          // [n_padded][3]
+  float* csmall_tp;     // [T][nbs]
+};
+
+// block = 256 threads over points
+__global__ __launch_bounds__(256) void grad_assemble_kernel(const AssembleArgs a) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.n_padded) return;
+  const bool live = p < a.n_points;
+  float g[3] = {0.f, 0.f, 0.f}, x[3] = {0.f, 0.f, 0.f}, dir[3] = {0.f, 0.f, 0.f};
+  if (live) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      x[d] = a.x[p * 3 + d];
+      g[d] = a.e_tp[tp_index(p, d, a.nb0)];
+    }
+    if (a.use_pe) {
+      for (int d = 0; d < 3; ++d)
+        for (int f = 0; f < a.pe_degree; ++f) {
+          const float fr = (float)(1 << f);
+          const float u = x[d] * fr;
+          const float e1 = a.e_tp[tp_index(p, 3 + d * a.pe_degree + f, a.nb0)];
+          const float e2 = a.e_tp[tp_index(p, 3 + 3 * a.pe_degree + d * a.pe_degree + f, a.nb0)];
+          g[d] += fr * (cosf(u) * e1 + cosf(u + 1.57079632679489661923f) * e2);
+        }
+    }
+    const int feat0 = 3 + 6 * a.pe_degree;
+    for (int c = 0; c < a.n_feat; ++c) {
+      const float ec = a.e_tp[tp_index(p, feat0 + c, a.nb0)] * a.mask[c] * 0.25f;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) g[d] = fmaf(ec, a.dydp[(size_t)(c * 3 + d) * a.n_padded + p], g[d]);
+    }
+    const int64_t ray = p / a.S;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) dir[d] = a.dirs[ray * 3 + d];
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) a.grad[p * 3 + d] = g[d];
+  // colour-network small inputs: x(3) | PE(dir): sin(d 2^f) (12), sin(d 2^f + pi/2) (12), d (3) | grad (3) | emb
+#pragma unroll
+  for (int d = 0; d < 3; ++d) a.csmall_tp[tp_index(p, d, a.nbs)] = x[d];
+  for (int d = 0; d < 3; ++d)
+    for (int f = 0; f < 4; ++f) {
+      const float u = dir[d] * (float)(1 << f);
+      a.csmall_tp[tp_index(p, 3 + d * 4 + f, a.nbs)] = live ? sinf(u) : 0.0f;
+      a.csmall_tp[tp_index(p, 15 + d * 4 + f, a.nbs)] = live ? sinf(u + 1.57079632679489661923f) : 0.0f;
+    }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    a.csmall_tp[tp_index(p, 27 + d, a.nbs)] = dir[d];
+    a.csmall_tp[tp_index(p, 30 + d, a.nbs)] = g[d];
+  }
+  for (int j = 0; j < a.emb_dim; ++j) {
+    float v = 0.0f;
+    if (live && a.emb != nullptr) v = a.emb[(p / a.S) * a.emb_dim + j];
+    a.csmall_tp[tp_index(p, 33 + j, a.nbs)] = v;
+  }
+  for (int c = 33 + a.emb_dim; c < a.nbs * 32; ++c) a.csmall_tp[tp_index(p, c, a.nbs)] = 0.0f;
+}
+
+struct BwdPrepArgs {
+  const float* gradbar;       // [P][3] upstream d L / d (d sdf/dx)  or null
+  const float* sdfbar_in;     // [P] upstream or null
+  const float* csmallbar_tp;  // [T][nbs] from the colour backward (grad slots 30..32) or null
+  const float* x;
+  const float* dydp;
+  const float* mask;
+  int64_t n_points, n_padded;
+  int32_t pe_degree, use_pe, n_feat, nb0, nbs, emb_dim;
+  int32_t S, pad_;
+  float* gtot;       // [n_padded][3]
+  float* ebar_tp;    // [T][nb0]
+  float* sdfbar;     // [n_padded]
+  float* embbar;     // [N][emb_dim] accumulated with atomics, or null
+};
+
+__global__ __launch_bounds__(256) void bwd_prep_kernel(const BwdPrepArgs a) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.n_padded) return;
+  const bool live = p < a.n_points;
+  float gb[3] = {0.f, 0.f, 0.f}, x[3] = {0.f, 0.f, 0.f};
+  if (live) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      x[d] = a.x[p * 3 + d];
+      if (a.gradbar != nullptr) gb[d] = a.gradbar[p * 3 + d];
+      if (a.csmallbar_tp != nullptr) gb[d] += a.csmallbar_tp[tp_index(p, 30 + d, a.nbs)];
+    }
+    if (a.embbar != nullptr && a.csmallbar_tp != nullptr) {
+      for (int j = 0; j < a.emb_dim; ++j)
+        atomicAdd(a.embbar + (p / a.S) * a.emb_dim + j, a.csmallbar_tp[tp_index(p, 33 + j, a.nbs)]);
+    }
+  }
+  a.sdfbar[p] = (live && a.sdfbar_in != nullptr) ? a.sdfbar_in[p] : 0.0f;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    a.gtot[p * 3 + d] = gb[d];
+    a.ebar_tp[tp_index(p, d, a.nb0)] = gb[d];
+  }
+  for (int d = 0; d < 3; ++d)
+    for (int f = 0; f < a.pe_degree; ++f) {
+      const float fr = (float)(1 << f);
+      const float u = x[d] * fr;
+      const float c1 = (live && a.use_pe) ? fr * cosf(u) * gb[d] : 0.0f;
+      const float c2 = (live && a.use_pe) ? fr * cosf(u + 1.57079632679489661923f) * gb[d] : 0.0f;
+      a.ebar_tp[tp_index(p, 3 + d * a.pe_degree + f, a.nb0)] = c1;
+      a.ebar_tp[tp_index(p, 3 + 3 * a.pe_degree + d * a.pe_degree + f, a.nb0)] = c2;
+    }
+  const int feat0 = 3 + 6 * a.pe_degree;
+  for (int c = 0; c < a.n_feat; ++c) {
+    float v = 0.0f;
+    if (live) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) v = fmaf(a.dydp[(size_t)(c * 3 + d) * a.n_padded + p], gb[d], v);
+      v *= 0.25f * a.mask[c];
+    }
+    a.ebar_tp[tp_index(p, feat0 + c, a.nb0)] = v;
+  }
+  for (int c = feat0 + a.n_feat; c < a.nb0 * 32; ++c) a.ebar_tp[tp_index(p, c, a.nb0)] = 0.0f;
+}
+
+struct GridBwdArgs {
+  GridDev grid;
+  const float* x;          // [n_padded][3] contracted positions
+  const float* in0bar_tp;  // [T][nb0]  d L / d in0 (first-order)
+  const float* e_tp;       // [T][nb0]  d sdf / d in0        (second-order term) or null
+  const float* gtot;       // [n_padded][3] d L / d grad     (second-order term) or null
+  const float* mask;
+  int64_t n_points;
+  int32_t pe_degree, nb0;
+  float* tablebar;         // [entries][F]  (accumulated)
+};
+
+// grid = (ceil(P/256), n_levels)
+__global__ __launch_bounds__(256) void grid_bwd_kernel(const GridBwdArgs a) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.n_points) return;
+  const int level = blockIdx.y;
+  const float m0 = a.mask[level * 2 + 0], m1 = a.mask[level * 2 + 1];
+  if (m0 == 0.0f && m1 == 0.0f) return;
+  const int feat0 = 3 + 6 * a.pe_degree;
+  const float yb0 = a.in0bar_tp[tp_index(p, feat0 + level * 2 + 0, a.nb0)] * m0;
+  const float yb1 = a.in0bar_tp[tp_index(p, feat0 + level * 2 + 1, a.nb0)] * m1;
+  float e0 = 0.f, e1 = 0.f, gb[3] = {0.f, 0.f, 0.f};
+  const bool second = a.e_tp != nullptr && a.gtot != nullptr;
+  if (second) {
+    e0 = a.e_tp[tp_index(p, feat0 + level * 2 + 0, a.nb0)] * m0 * 0.25f;
+    e1 = a.e_tp[tp_index(p, feat0 + level * 2 + 1, a.nb0)] * m1 * 0.25f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) gb[d] = a.gtot[p * 3 + d];
+  }
+  const float pp[3] = {(a.x[p * 3 + 0] + 2.0f) * 0.25f, (a.x[p * 3 + 1] + 2.0f) * 0.25f, (a.x[p * 3 + 2] + 2.0f) * 0.25f};
+  GridCell c;
+  grid_cell(a.grid.lv[level], a.grid.smoothstep != 0, pp, c);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float w = corner_w(c, k);
+    float t0 = w * yb0, t1 = w * yb1;
+    if (second) {
+      float dw[3];
+      corner_dw(c, k, dw);
+      const float s = dw[0] * gb[0] + dw[1] * gb[1] + dw[2] * gb[2];
+      t0 = fmaf(s, e0, t0);
+      t1 = fmaf(s, e1, t1);
+    }
+    float* dst = a.tablebar + (size_t)c.idx[k] * 2;
+    atomicAdd(dst, t0);
+    atomicAdd(dst + 1, t1);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ proposal field
+constexpr int kPropLevels = 5, kPropIn = 10, kPropHidden = 16;
+struct PropArgs {
+  GridDev grid;
+  const float* origins;  // [N,3]
+  const float* dirs;     // [N,3]
+  const float* starts;   // [N,S]
+  const float* ends;     // [N,S]
+  int64_t n_points;
+  int32_t S, contract;
+  const float* table;
+  const float* w1;       // [16][10]
+  const float* w2;       // [16]
+  float* density;        // [N,S]            (forward)
+  const float* densbar;  // [N,S]            (backward)
+  float* tablebar;       // accumulated      (backward)
+  float* wpartial;       // [n_blocks][176]  (backward)
+};
+
+SDFHIP_D float prop_point(const PropArgs& a, const int64_t p, float feat[kPropIn], float hid[kPropHidden], GridCell cells[kPropLevels]) {
+  float x[3];
+  if (a.dirs == nullptr) {  // explicit positions [P,3] (Field.density_fn, base_field.py:48-65)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) x[d] = a.origins[p * 3 + d];
+  } else {
+    const int64_t ray = p / a.S;
+    const float t = 0.5f * (a.starts[p] + a.ends[p]);  // rays.py:46-55: frustum MIDPOINT
+#pragma unroll
+    for (int d = 0; d < 3; ++d) x[d] = a.origins[ray * 3 + d] + a.dirs[ray * 3 + d] * t;
+  }
+  if (a.contract) contract_inf(x);
+  const float pp[3] = {(x[0] + 2.0f) * 0.25f, (x[1] + 2.0f) * 0.25f, (x[2] + 2.0f) * 0.25f};
+  const float2* tab = reinterpret_cast<const float2*>(a.table);
+#pragma unroll
+  for (int l = 0; l < kPropLevels; ++l) {
+    grid_cell(a.grid.lv[l], a.grid.smoothstep != 0, pp, cells[l]);
+    float y0 = 0.f, y1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float2 v = tab[cells[l].idx[k]];
+      const float w = corner_w(cells[l], k);
+      y0 = fmaf(w, v.x, y0);
+      y1 = fmaf(w, v.y, y1);
+    }
+    feat[2 * l] = y0;
+    feat[2 * l + 1] = y1;
+  }
+  float pre = 0.0f;
+#pragma unroll
+  for (int j = 0; j < kPropHidden; ++j) {
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kPropIn; ++i) s = fmaf(a.w1[j * kPropIn + i], feat[i], s);
+    hid[j] = s;
+    pre = fmaf(a.w2[j], fmaxf(s, 0.0f), pre);
+  }
+  return pre;
+}
+
+__global__ __launch_bounds__(256) void prop_fwd_kernel(const PropArgs a) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.n_points) return;
+  float feat[kPropIn], hid[kPropHidden];
+  GridCell cells[kPropLevels];
+  const float pre = prop_point(a, p, feat, hid, cells);
+  a.density[p] = expf(pre);
+}
+
+// grid-stride; per-thread register accumulation of the 176 weight gradients, block reduction through LDS
+__global__ __launch_bounds__(256) void prop_bwd_kernel(const PropArgs a) {
+  __shared__ float red[4][176];
+  float w1b[kPropHidden * kPropIn], w2b[kPropHidden];
+#pragma unroll
+  for (int i = 0; i < kPropHidden * kPropIn; ++i) w1b[i] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kPropHidden; ++i) w2b[i] = 0.0f;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < a.n_points; p += (int64_t)gridDim.x * 256) {
+    const float db = a.densbar[p];
+    if (db == 0.0f) continue;
+    float feat[kPropIn], hid[kPropHidden];
+    GridCell cells[kPropLevels];
+    const float pre = prop_point(a, p, feat, hid, cells);
+    const float pb = db * expf(fminf(fmaxf(pre, -15.0f), 15.0f));  // activations.py:36-39
+    float fb[kPropIn];
+#pragma unroll
+    for (int i = 0; i < kPropIn; ++i) fb[i] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < kPropHidden; ++j) {
+      w2b[j] = fmaf(pb, fmaxf(hid[j], 0.0f), w2b[j]);
+      const float hb = hid[j] > 0.0f ? pb * a.w2[j] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < kPropIn; ++i) {
+        w1b[j * kPropIn + i] = fmaf(hb, feat[i], w1b[j * kPropIn + i]);
+        fb[i] = fmaf(a.w1[j * kPropIn + i], hb, fb[i]);
+      }
+    }
+#pragma unroll
+    for (int l = 0; l < kPropLevels; ++l)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float w = corner_w(cells[l], k);
+        float* dst = a.tablebar + (size_t)cells[l].idx[k] * 2;
+        atomicAdd(dst, w * fb[2 * l]);
+        atomicAdd(dst + 1, w * fb[2 * l + 1]);
+      }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 176; ++i) {
+    float v = i < 160 ? w1b[i < 160 ? i : 0] : w2b[i >= 160 ? i - 160 : 0];
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 176)
+    a.wpartial[(size_t)blockIdx.x * 176 + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// out[i] (+)= sum_k partial[k][i]
+__global__ void colsum_kernel(const float* __restrict__ partial, const int n_rows, const int n_cols, float* __restrict__ out,
+                              const int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_cols) return;
+  float s = 0.0f;
+  for (int k = 0; k < n_rows; ++k) s += partial[(size_t)k * n_cols + i];
+  out[i] = (accumulate ? out[i] : 0.0f) + s;
+}

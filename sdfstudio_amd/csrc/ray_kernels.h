@@ -1,0 +1,528 @@
+// sdfhip — per-ray kernels: one 64-lane wavefront per ray, C = ceil(S/64) consecutive samples per lane,
+// wave-level scans with DPP/shuffle (no LDS round trip), HBM-bound.
+//   neus_render_fwd/bwd     NeuS alpha (sdf_field.py:476-525) -> weights (rays.py:194-230) -> rgb / depth /
+//                           normal / accumulation (renderers.py:81-92,196,245-259,294), fused
+//   density_weights_fwd/bwd proposal weights from density (rays.py:146-167)
+//   spaced_bins_kernel      UniformLinDispPiecewiseSampler bins (ray_samplers.py:101-117, 240-241)
+//   pdf_sample_kernel       PDFSampler, include_original = False (ray_samplers.py:303-358)
+#pragma once
+#include "common.h"
+
+constexpr int kMaxPerLane = 8;  // S <= 512
+
+SDFHIP_D float wave_incl_scan_add(float v, const int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float t = __shfl_up(v, d);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+SDFHIP_D float wave_incl_scan_mul(float v, const int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float t = __shfl_up(v, d);
+    if (lane >= d) v *= t;
+  }
+  return v;
+}
+SDFHIP_D float wave_sum(float v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+  return v;
+}
+SDFHIP_D float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+SDFHIP_D void atomic_min_f(float* addr, float v) {  // valid for non-negative floats (ray distances)
+  atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+SDFHIP_D void atomic_max_f(float* addr, float v) {
+  atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+struct NeusRenderArgs {
+  const float* sdf;      // [N,S]
+  const float* grad;     // [N,S,3]
+  const float* rgb;      // [N,S,3]
+  const float* dirs;     // [N,3]
+  const float* starts;   // [N,S]
+  const float* ends;     // [N,S]
+  const float* variance; // [1]  deviation_network.variance
+  const float* bg;       // [3] background colour or null (black)
+  float cos_anneal;
+  int32_t N, S;
+  // forward outputs
+  float* alpha;    // [N,S]
+  float* weights;  // [N,S]
+  float* out_rgb;  // [N,3]
+  float* out_depth;   // [N] unclipped expected depth
+  float* out_normal;  // [N,3]
+  float* out_acc;     // [N]
+  float* steps_minmax;  // [2] global min / max of sample mid points (pre-initialised to +inf / 0)
+  // backward inputs
+  const float* rgbbar;     // [N,3] or null
+  const float* depthbar;   // [N] or null  (w.r.t. the CLIPPED depth)
+  const float* normalbar;  // [N,3] or null
+  const float* accbar;     // [N] or null
+  const float* weightsbar; // [N,S] or null
+  // backward outputs
+  float* sdfbar;   // [N,S]
+  float* gradbar;  // [N,S,3]
+  float* rgbsbar;  // [N,S,3]
+  float* variancebar;  // [1] accumulated
+};
+
+SDFHIP_D float neus_inv_s(const float variance) {
+  return fminf(fmaxf(expf(variance * 10.0f), 1e-6f), 1e6f);  // sdf_field.py:116-118
+}
+
+// grid = ceil(N/4), block = 256 (4 rays)
+template <int C>
+__global__ __launch_bounds__(256) void neus_render_fwd_kernel(const NeusRenderArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= a.N) return;
+  const int S = a.S;
+  const float inv_s = neus_inv_s(a.variance[0]);
+  const float dx = a.dirs[ray * 3 + 0], dy = a.dirs[ray * 3 + 1], dz = a.dirs[ray * 3 + 2];
+  float al[C], one_m[C];
+  float local = 1.0f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int s = lane * C + c;
+    al[c] = 0.0f;
+    one_m[c] = 1.0f;
+    if (s < S) {
+      const int64_t i = (int64_t)ray * S + s;
+      const float sd = a.sdf[i];
+      const float tc = dx * a.grad[i * 3] + dy * a.grad[i * 3 + 1] + dz * a.grad[i * 3 + 2];
+      const float ic = -(fmaxf(-tc * 0.5f + 0.5f, 0.0f) * (1.0f - a.cos_anneal) + fmaxf(-tc, 0.0f) * a.cos_anneal);
+      const float delta = a.ends[i] - a.starts[i];
+      const float pc = sigmoidf_((sd - ic * delta * 0.5f) * inv_s);
+      const float nc = sigmoidf_((sd + ic * delta * 0.5f) * inv_s);
+      const float v = (pc - nc + 1e-5f) / (pc + 1e-5f);
+      al[c] = fminf(fmaxf(v, 0.0f), 1.0f);
+      one_m[c] = 1.0f - al[c] + 1e-7f;  // rays.py:205
+      a.alpha[i] = al[c];
+    }
+    local *= one_m[c];
+  }
+  const float incl = wave_incl_scan_mul(local, lane);
+  float T = __shfl_up(incl, 1);
+  if (lane == 0) T = 1.0f;
+  float acc = 0.f, r = 0.f, g = 0.f, b = 0.f, dep = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
+  float mn = 3.0e38f, mx = 0.0f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int s = lane * C + c;
+    if (s < S) {
+      const int64_t i = (int64_t)ray * S + s;
+      const float w = al[c] * T;
+      a.weights[i] = w;
+      acc += w;
+      r = fmaf(w, a.rgb[i * 3], r);
+      g = fmaf(w, a.rgb[i * 3 + 1], g);
+      b = fmaf(w, a.rgb[i * 3 + 2], b);
+      const float mid = 0.5f * (a.starts[i] + a.ends[i]);
+      dep = fmaf(w, mid, dep);
+      mn = fminf(mn, mid);
+      mx = fmaxf(mx, mid);
+      const float gx = a.grad[i * 3], gy = a.grad[i * 3 + 1], gz = a.grad[i * 3 + 2];
+      const float inv = 1.0f / fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);  // F.normalize
+      nx = fmaf(w, gx * inv, nx);
+      ny = fmaf(w, gy * inv, ny);
+      nz = fmaf(w, gz * inv, nz);
+      T *= one_m[c];
+    }
+  }
+  acc = wave_sum(acc);
+  r = wave_sum(r);
+  g = wave_sum(g);
+  b = wave_sum(b);
+  dep = wave_sum(dep);
+  nx = wave_sum(nx);
+  ny = wave_sum(ny);
+  nz = wave_sum(nz);
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    mn = fminf(mn, __shfl_xor(mn, m));
+    mx = fmaxf(mx, __shfl_xor(mx, m));
+  }
+  if (lane == 0) {
+    float bgr = 0.f, bgg = 0.f, bgb = 0.f;
+    if (a.bg != nullptr) {
+      bgr = a.bg[0];
+      bgg = a.bg[1];
+      bgb = a.bg[2];
+    }
+    a.out_rgb[ray * 3 + 0] = r + bgr * (1.0f - acc);
+    a.out_rgb[ray * 3 + 1] = g + bgg * (1.0f - acc);
+    a.out_rgb[ray * 3 + 2] = b + bgb * (1.0f - acc);
+    a.out_depth[ray] = dep / (acc + 1e-10f);
+    a.out_normal[ray * 3 + 0] = nx;
+    a.out_normal[ray * 3 + 1] = ny;
+    a.out_normal[ray * 3 + 2] = nz;
+    a.out_acc[ray] = acc;
+    atomic_min_f(a.steps_minmax, mn);
+    atomic_max_f(a.steps_minmax + 1, mx);
+  }
+}
+
+// depth = clip(depth, steps.min(), steps.max())  (renderers.py:257 — a cross-ray reduction)
+__global__ void depth_clip_kernel(const float* __restrict__ raw, const float* __restrict__ minmax, const int n,
+                                  float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = fminf(fmaxf(raw[i], minmax[0]), minmax[1]);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void neus_render_bwd_kernel(const NeusRenderArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= a.N) return;
+  const int S = a.S;
+  const float var = a.variance[0];
+  const float inv_s_raw = expf(var * 10.0f);
+  const float inv_s = fminf(fmaxf(inv_s_raw, 1e-6f), 1e6f);
+  const float dx = a.dirs[ray * 3 + 0], dy = a.dirs[ray * 3 + 1], dz = a.dirs[ray * 3 + 2];
+  float rb[3] = {0.f, 0.f, 0.f}, nb[3] = {0.f, 0.f, 0.f}, db = 0.f, ab = 0.f, bg[3] = {0.f, 0.f, 0.f};
+  if (a.rgbbar != nullptr) {
+    rb[0] = a.rgbbar[ray * 3];
+    rb[1] = a.rgbbar[ray * 3 + 1];
+    rb[2] = a.rgbbar[ray * 3 + 2];
+  }
+  if (a.normalbar != nullptr) {
+    nb[0] = a.normalbar[ray * 3];
+    nb[1] = a.normalbar[ray * 3 + 1];
+    nb[2] = a.normalbar[ray * 3 + 2];
+  }
+  if (a.accbar != nullptr) ab = a.accbar[ray];
+  if (a.bg != nullptr) {
+    bg[0] = a.bg[0];
+    bg[1] = a.bg[1];
+    bg[2] = a.bg[2];
+  }
+  const float acc = a.out_acc[ray];
+  const float depth_raw = a.out_depth[ray];
+  if (a.depthbar != nullptr) {
+    const bool pass = depth_raw >= a.steps_minmax[0] && depth_raw <= a.steps_minmax[1];
+    db = pass ? a.depthbar[ray] : 0.0f;
+  }
+  // pass 1: wbar_i, the transmittance T_i, and the suffix sum of wbar_j w_j
+  float wbar[C], wv[C], al[C], Tv[C];
+  float local = 0.0f, lprod = 1.0f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int s = lane * C + c;
+    wbar[c] = 0.f;
+    wv[c] = 0.f;
+    al[c] = 0.f;
+    if (s < S) {
+      const int64_t i = (int64_t)ray * S + s;
+      const float w = a.weights[i];
+      wv[c] = w;
+      al[c] = a.alpha[i];
+      lprod *= 1.0f - al[c] + 1e-7f;
+      const float mid = 0.5f * (a.starts[i] + a.ends[i]);
+      const float gx = a.grad[i * 3], gy = a.grad[i * 3 + 1], gz = a.grad[i * 3 + 2];
+      const float nrm = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);
+      const float n0 = gx / nrm, n1 = gy / nrm, n2 = gz / nrm;
+      float t = ab + (a.weightsbar != nullptr ? a.weightsbar[i] : 0.0f);
+      t += rb[0] * (a.rgb[i * 3] - bg[0]) + rb[1] * (a.rgb[i * 3 + 1] - bg[1]) + rb[2] * (a.rgb[i * 3 + 2] - bg[2]);
+      t += db * (mid - depth_raw) / (acc + 1e-10f);
+      t += nb[0] * n0 + nb[1] * n1 + nb[2] * n2;
+      wbar[c] = t;
+      // per-sample outputs that do not need the scan
+      a.rgbsbar[i * 3 + 0] = w * rb[0];
+      a.rgbsbar[i * 3 + 1] = w * rb[1];
+      a.rgbsbar[i * 3 + 2] = w * rb[2];
+      local += t * w;
+    }
+  }
+  {
+    const float pincl = wave_incl_scan_mul(lprod, lane);
+    float T = __shfl_up(pincl, 1);
+    if (lane == 0) T = 1.0f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      Tv[c] = T;
+      T *= 1.0f - al[c] + 1e-7f;
+    }
+  }
+  const float incl = wave_incl_scan_add(local, lane);
+  const float total = __shfl(incl, 63);
+  float suffix = total - incl;  // sum over lanes > this lane
+  float vbar_acc = 0.0f;
+  // walk this lane's samples from last to first so `suffix` = sum_{j>i} wbar_j w_j
+#pragma unroll
+  for (int cc = 0; cc < C; ++cc) {
+    const int c = C - 1 - cc;
+    const int s = lane * C + c;
+    if (s < S) {
+      const int64_t i = (int64_t)ray * S + s;
+      // d w_i / d alpha_i = T_i ; d w_j / d alpha_i = -w_j / (1 - alpha_i + 1e-7)  for j > i   (rays.py:204-208)
+      const float one_m = 1.0f - al[c] + 1e-7f;
+      const float abar_i = wbar[c] * Tv[c] - suffix / one_m;
+      suffix += wbar[c] * wv[c];
+      // ---- alpha backward (sdf_field.py:494-516)
+      const float sd = a.sdf[i];
+      const float gx = a.grad[i * 3], gy = a.grad[i * 3 + 1], gz = a.grad[i * 3 + 2];
+      const float tc = dx * gx + dy * gy + dz * gz;
+      const float ca = a.cos_anneal;
+      const float ic = -(fmaxf(-tc * 0.5f + 0.5f, 0.0f) * (1.0f - ca) + fmaxf(-tc, 0.0f) * ca);
+      const float delta = a.ends[i] - a.starts[i];
+      const float ep = sd - ic * delta * 0.5f, en = sd + ic * delta * 0.5f;
+      const float pc = sigmoidf_(ep * inv_s), nc = sigmoidf_(en * inv_s);
+      const float den = pc + 1e-5f;
+      const float v = (pc - nc + 1e-5f) / den;
+      const bool pass = v >= 0.0f && v <= 1.0f;  // torch.clip backward mask
+      float sdb = 0.f, icb = 0.f;
+      if (pass && abar_i != 0.0f) {
+        const float pbar = abar_i / den;              // d/d(p) with p = pc - nc
+        const float cbar = -abar_i * v / den;         // d/d(c) with c = pc
+        const float pcb = pbar + cbar, ncb = -pbar;
+        const float epb = pcb * pc * (1.0f - pc) * inv_s;
+        const float enb = ncb * nc * (1.0f - nc) * inv_s;
+        vbar_acc += pcb * pc * (1.0f - pc) * ep + ncb * nc * (1.0f - nc) * en;  // d/d inv_s
+        sdb = epb + enb;
+        icb = (enb - epb) * delta * 0.5f;
+      }
+      // d iter_cos / d true_cos
+      const float dic = 0.5f * (1.0f - ca) * ((-tc * 0.5f + 0.5f) > 0.0f ? 1.0f : 0.0f) + ca * ((-tc) > 0.0f ? 1.0f : 0.0f);
+      const float tcb = icb * dic;
+      // normal render backward: n = g / |g|
+      const float nrm = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);
+      const float n0 = gx / nrm, n1 = gy / nrm, n2 = gz / nrm;
+      const float w = wv[c];
+      const float q0 = w * nb[0], q1 = w * nb[1], q2 = w * nb[2];
+      const float dotn = n0 * q0 + n1 * q1 + n2 * q2;
+      a.sdfbar[i] = sdb;
+      a.gradbar[i * 3 + 0] = tcb * dx + (q0 - n0 * dotn) / nrm;
+      a.gradbar[i * 3 + 1] = tcb * dy + (q1 - n1 * dotn) / nrm;
+      a.gradbar[i * 3 + 2] = tcb * dz + (q2 - n2 * dotn) / nrm;
+    }
+  }
+  vbar_acc = wave_sum(vbar_acc);
+  if (lane == 0 && a.variancebar != nullptr) {
+    const bool pass = inv_s_raw >= 1e-6f && inv_s_raw <= 1e6f;
+    if (pass) atomicAdd(a.variancebar, vbar_acc * 10.0f * inv_s_raw);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ density weights
+struct DensityWeightsArgs {
+  const float* density;  // [N,S]
+  const float* starts;
+  const float* ends;
+  int32_t N, S;
+  float* weights;           // forward out
+  const float* weightsbar;  // backward in
+  float* densitybar;        // backward out
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void density_weights_fwd_kernel(const DensityWeightsArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= a.N) return;
+  float dd[C];
+  float local = 0.0f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int s = lane * C + c;
+    dd[c] = 0.0f;
+    if (s < a.S) {
+      const int64_t i = (int64_t)ray * a.S + s;
+      dd[c] = (a.ends[i] - a.starts[i]) * a.density[i];
+    }
+    local += dd[c];
+  }
+  const float incl = wave_incl_scan_add(local, lane);
+  float cum = incl - local;  // exclusive
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int s = lane * C + c;
+    if (s < a.S) {
+      const int64_t i = (int64_t)ray * a.S + s;
+      a.weights[i] = (1.0f - expf(-dd[c])) * expf(-cum);
+      cum += dd[c];
+    }
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void density_weights_bwd_kernel(const DensityWeightsArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= a.N) return;
+  float dd[C], wb[C], delta[C];
+  float local = 0.0f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int s = lane * C + c;
+    dd[c] = 0.0f;
+    wb[c] = 0.0f;
+    delta[c] = 0.0f;
+    if (s < a.S) {
+      const int64_t i = (int64_t)ray * a.S + s;
+      delta[c] = a.ends[i] - a.starts[i];
+      dd[c] = delta[c] * a.density[i];
+      wb[c] = a.weightsbar[i];
+    }
+    local += dd[c];
+  }
+  const float incl = wave_incl_scan_add(local, lane);
+  float cum = incl - local;
+  float ww[C];
+  float lsum = 0.0f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const float T = expf(-cum);
+    ww[c] = (1.0f - expf(-dd[c])) * T;
+    lsum += wb[c] * ww[c];
+    cum += dd[c];
+  }
+  const float incl2 = wave_incl_scan_add(lsum, lane);
+  const float total = __shfl(incl2, 63);
+  float suffix = total - incl2;
+  cum = incl;  // cumulative INCLUDING this lane's samples; walk backwards
+#pragma unroll
+  for (int cc = 0; cc < C; ++cc) {
+    const int c = C - 1 - cc;
+    const int s = lane * C + c;
+    cum -= dd[c];  // exclusive cumulative for sample c
+    if (s < a.S) {
+      const int64_t i = (int64_t)ray * a.S + s;
+      // w_i = (1 - e^{-dd_i}) e^{-cum_i}; d w_i / d dd_i = e^{-dd_i} e^{-cum_i}; d w_j / d dd_i = -w_j (j > i)
+      const float g = wb[c] * expf(-dd[c]) * expf(-cum) - suffix;
+      a.densitybar[i] = g * delta[c];
+    }
+    suffix += wb[c] * ww[c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ samplers
+SDFHIP_D float piecewise_fn(const float x) { return x < 1.0f ? x * 0.5f : 1.0f - 1.0f / (2.0f * x); }
+SDFHIP_D float piecewise_inv(const float x) { return x < 0.5f ? 2.0f * x : 1.0f / (2.0f - 2.0f * x); }
+
+struct BinsArgs {
+  const float* nears;  // [N]
+  const float* fars;   // [N]
+  const float* jitter; // [N] single-jitter draw in [0,1) or null (deterministic)
+  int32_t N, S;        // S samples -> S+1 bins
+  float* bins;         // [N,S+1] spacing-domain bins
+  float* starts;       // [N,S] euclidean
+  float* ends;         // [N,S]
+};
+
+// thread per (ray, bin edge)
+__global__ void spaced_bins_kernel(const BinsArgs a) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nb = a.S + 1;
+  if (idx >= (int64_t)a.N * nb) return;
+  const int ray = (int)(idx / nb), j = (int)(idx % nb);
+  // torch.linspace(0, 1, S+1) (ray_samplers.py:101): symmetric formula used by ATen
+  const float step = 1.0f / (float)a.S;
+  auto lin = [&](int k) { return k < nb / 2 ? step * (float)k : 1.0f - step * (float)(a.S - k); };
+  float b = lin(j);
+  if (a.jitter != nullptr) {
+    const float lo = j == 0 ? lin(0) : (lin(j) + lin(j - 1)) * 0.5f;
+    const float hi = j == a.S ? lin(a.S) : (lin(j + 1) + lin(j)) * 0.5f;
+    b = lo + (hi - lo) * a.jitter[ray];
+  }
+  a.bins[idx] = b;
+  const float sn = piecewise_fn(a.nears[ray]), sf = piecewise_fn(a.fars[ray]);
+  const float e = piecewise_inv(b * sf + (1.0f - b) * sn);
+  if (j < a.S) a.starts[(int64_t)ray * a.S + j] = e;
+  if (j > 0) a.ends[(int64_t)ray * a.S + j - 1] = e;
+}
+
+struct PdfArgs {
+  const float* weights;   // [N,S_in]
+  const float* bins_in;   // [N,S_in+1]
+  const float* nears;
+  const float* fars;
+  const float* jitter;    // [N] or null
+  int32_t N, S_in, S_out;
+  float anneal, histogram_padding, eps;
+  float u_end;      // float(1 - 1/(S_out+1))            (ray_samplers.py:323)
+  float u_center;   // float(1 / (2 (S_out+1)))          (ray_samplers.py:333)
+  float* bins_out;        // [N,S_out+1]
+  float* starts;          // [N,S_out]
+  float* ends;            // [N,S_out]
+};
+
+// one wave per ray; cdf staged in LDS.  S_in <= 64*C
+template <int C>
+__global__ __launch_bounds__(256) void pdf_sample_kernel(const PdfArgs a) {
+  __shared__ float cdf_s[4][64 * C + 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ray = blockIdx.x * 4 + wv;
+  if (ray >= a.N) return;
+  float* cdf = cdf_s[wv];
+  const int Si = a.S_in;
+  float w[C];
+  float local = 0.0f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int s = lane * C + c;
+    w[c] = 0.0f;
+    if (s < Si) w[c] = powf(a.weights[(int64_t)ray * Si + s], a.anneal) + a.histogram_padding;
+    local += w[c];
+  }
+  float wsum = wave_sum(local);
+  const float padding = fmaxf(a.eps - wsum, 0.0f);
+  const float add = padding / (float)Si;
+  wsum += padding;
+  local = 0.0f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int s = lane * C + c;
+    if (s < Si) {
+      w[c] = (w[c] + add) / wsum;
+      local += w[c];
+    } else {
+      w[c] = 0.0f;
+    }
+  }
+  const float incl = wave_incl_scan_add(local, lane);
+  float cum = incl - local;
+  if (lane == 0) cdf[0] = 0.0f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int s = lane * C + c;
+    if (s < Si) {
+      cum += w[c];
+      cdf[s + 1] = fminf(1.0f, cum);
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave are done (single-wave producer/consumer)
+  __builtin_amdgcn_wave_barrier();
+  const int nbins = a.S_out + 1;
+  const float sn = piecewise_fn(a.nears[ray]), sf = piecewise_fn(a.fars[ray]);
+  const float* bin = a.bins_in + (int64_t)ray * (Si + 1);
+  for (int j = lane; j < nbins; j += 64) {
+    // u = linspace(0, 1 - 1/nbins, nbins)[j] + (jitter / nbins | 1/(2 nbins))      (ray_samplers.py:321-334)
+    const float end = a.u_end;
+    const float step = end / (float)(nbins - 1);
+    float u = j < nbins / 2 ? step * (float)j : end - step * (float)(nbins - 1 - j);
+    u += a.jitter != nullptr ? a.jitter[ray] / (float)nbins : a.u_center;
+    // searchsorted(cdf, u, side="right"): first index with cdf[idx] > u
+    int lo = 0, hi = Si + 1;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cdf[mid] > u) hi = mid; else lo = mid + 1;
+    }
+    const int below = min(max(lo - 1, 0), Si), above = min(max(lo, 0), Si);
+    const float c0 = cdf[below], c1 = cdf[above];
+    const float b0 = bin[below], b1 = bin[above];
+    float t = (u - c0) / (c1 - c0);
+    if (t != t) t = 0.0f;            // nan_to_num(nan=0)
+    t = fminf(fmaxf(t, 0.0f), 1.0f); // +-inf clip like torch.clip after nan_to_num
+    const float b = b0 + t * (b1 - b0);
+    a.bins_out[(int64_t)ray * nbins + j] = b;
+    const float e = piecewise_inv(b * sf + (1.0f - b) * sn);
+    if (j < a.S_out) a.starts[(int64_t)ray * a.S_out + j] = e;
+    if (j > 0) a.ends[(int64_t)ray * a.S_out + j - 1] = e;
+  }
+}

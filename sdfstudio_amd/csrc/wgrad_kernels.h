@@ -1,0 +1,253 @@
+// sdfhip — weight packing and weight-gradient kernels for the fused networks.
+//
+//  pack_kernel    natural [out][in] fp32 weights -> MFMA A-operand order  Wp[kb][ob][reg][lane]
+//                 (and the transposed pack used by the chain / data-backward passes)
+//  wgrad_kernel   split-K GEMM over points:  C[o][i] = sum_p A[p][o] * B[p][i]  with A, B tile-packed in HBM,
+//                 one wave per (point-split, 4x4 block macro tile); fp32 MFMA 32x32x2, contraction over points.
+//                 Column sums of A (bias gradients) fall out of the same loads.
+//  wreduce_kernel sums the split partials and scatters them into the natural-layout gradient vector.
+#pragma once
+#include "common.h"
+
+// One descriptor per packed matrix. All offsets are in floats / ints relative to the base pointers.
+struct PackDesc {
+  int64_t src_off;   // into theta (natural [n_rows][ld])
+  int64_t dst_off;   // into the packed blob
+  int32_t ld;        // natural leading dimension
+  int32_t kb, nbo;   // packed k blocks / output blocks
+  int32_t rowmap_off;  // int32[nbo*32]  packed output row -> natural row  (-1 = zero)
+  int32_t colmap_off;  // int32[kb*32]   packed k index    -> natural col  (-1 = zero)
+  int32_t transpose;   // 0: out = rows, k = cols ; 1: out = cols, k = rows  (packs W^T)
+  float scale;
+  int32_t pad_;
+};
+
+// grid = (ceil(kb*nbo*1024 / 256), n_desc)
+static __global__ void pack_kernel(const float* __restrict__ theta, const PackDesc* __restrict__ descs,
+                            const int32_t* __restrict__ maps, float* __restrict__ packed) {
+  const PackDesc d = descs[blockIdx.y];
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = d.kb * d.nbo * 1024;
+  if (idx >= total) return;
+  const int lane = idx & 63, reg = (idx >> 6) & 15, ob = (idx >> 10) % d.nbo, kb = (idx >> 10) / d.nbo;
+  const int o = ob * 32 + (lane & 31);             // MFMA A-operand row  (output feature)
+  const int k = kb * 32 + tp_row(reg, lane >> 5);  // contraction index in TP order
+  const int32_t* rowmap = maps + d.rowmap_off;
+  const int32_t* colmap = maps + d.colmap_off;
+  float v = 0.0f;
+  if (!d.transpose) {
+    const int nr = rowmap[o], nc = colmap[k];
+    if (nr >= 0 && nc >= 0) v = theta[d.src_off + (int64_t)nr * d.ld + nc] * d.scale;
+  } else {
+    const int nr = rowmap[k], nc = colmap[o];
+    if (nr >= 0 && nc >= 0) v = theta[d.src_off + (int64_t)nr * d.ld + nc] * d.scale;
+  }
+  packed[d.dst_off + idx] = v;
+}
+
+// padded natural-order vectors (biases, output rows): dst[i] = map[i] >= 0 ? theta[src_off + map[i]*stride] : 0
+struct VecDesc {
+  int64_t src_off, dst_off;
+  int32_t n, map_off, stride, pad_;
+};
+static __global__ void packvec_kernel(const float* __restrict__ theta, const VecDesc* __restrict__ descs,
+                               const int32_t* __restrict__ maps, float* __restrict__ packed) {
+  const VecDesc d = descs[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d.n) return;
+  const int m = maps[d.map_off + i];
+  packed[d.dst_off + i] = m >= 0 ? theta[d.src_off + (int64_t)m * d.stride] : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------ wgrad
+struct TpOperand {
+  const float* ptr[2];  // up to two concatenated TP arrays
+  int32_t nb[2];        // blocks in each
+  int32_t xf[2];        // 0: as stored, 1: softplus(beta=100) applied on load
+};
+struct WgradArgs {
+  TpOperand A[2], B[2];  // up to two (A, B) pairs accumulated into the same C
+  int32_t n_pairs;
+  int32_t nba, nbb;      // total blocks of A (rows of C / 32) and B (cols of C / 32)
+  int32_t n_ib_groups;   // ceil(nbb / 4)
+  int64_t n_tiles;       // point tiles
+  int32_t tiles_per_split;
+  float* partial;        // [n_split][nba*32][nbb*32]
+  float* bpartial;       // [n_split][nba*32]   column sums of pair 0's A   (may be null)
+};
+
+SDFHIP_D f32x4 wg_load(const TpOperand& op, const int blk, const int64_t tile, const int nb_total, const int rowoff) {
+  // rowoff = reg_of_row*64 + 32*hf_of_row + 4*(lane>>5)   (+ 8*g added by the caller)
+  const int seg = blk >= op.nb[0];
+  const int lb = blk - (seg ? op.nb[0] : 0);
+  const float* p = op.ptr[seg] + ((size_t)tile * op.nb[seg] + lb) * 1024 + rowoff;
+  f32x4 v = *reinterpret_cast<const f32x4*>(p);
+  if (op.xf[seg] == 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float h, d1;
+      softplus100(v[i], h, d1);
+      v[i] = h;
+    }
+  }
+  return v;
+}
+
+// grid = (n_split, n_ob_groups * n_ib_groups), block = 64 (one wave)
+static __global__ __launch_bounds__(64, 1) void wgrad_kernel(const WgradArgs a) {
+  const int lane = threadIdx.x;
+  const int split = blockIdx.x;
+  const int ibg = blockIdx.y % a.n_ib_groups, obg = blockIdx.y / a.n_ib_groups;
+  const int ob0 = obg * 4, ib0 = ibg * 4;
+  const int row = lane & 31;
+  const int rowoff = tp_reg_of_row(row) * 64 + 32 * tp_hf_of_row(row) + 4 * (lane >> 5);
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  float colsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  const int64_t t0 = (int64_t)split * a.tiles_per_split;
+  int64_t t1 = t0 + a.tiles_per_split;
+  if (t1 > a.n_tiles) t1 = a.n_tiles;
+
+  for (int pr = 0; pr < a.n_pairs; ++pr) {
+    const TpOperand& A = a.A[pr];
+    const TpOperand& B = a.B[pr];
+    for (int64_t tile = t0; tile < t1; ++tile) {
+#pragma unroll 2
+      for (int g = 0; g < 4; ++g) {
+        f32x4 av[4], bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          av[i] = (ob0 + i < a.nba) ? wg_load(A, ob0 + i, tile, a.nba, rowoff + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+          bv[i] = (ib0 + i < a.nbb) ? wg_load(B, ib0 + i, tile, a.nbb, rowoff + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (pr == 0) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) colsum[i] += (av[i][0] + av[i][1]) + (av[i][2] + av[i][3]);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s], bv[j][s], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+  const int ldc = a.nbb * 32;
+  float* C = a.partial + (size_t)split * a.nba * 32 * ldc;
+  const int hf = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (ob0 + i < a.nba && ib0 + j < a.nbb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          C[(size_t)((ob0 + i) * 32 + tp_row(r, hf)) * ldc + (ib0 + j) * 32 + (lane & 31)] = acc[i][j][r];
+      }
+    }
+  if (a.bpartial != nullptr && ibg == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float t = colsum[i] + __shfl_xor(colsum[i], 32);
+      if (hf == 0 && ob0 + i < a.nba) a.bpartial[(size_t)split * a.nba * 32 + (ob0 + i) * 32 + lane] = t;
+    }
+  }
+}
+
+// out[dst_off + rowmap[o]*ld + colmap[i]] = scale * sum_s partial[s][o][i]      (grid-stride over o,i)
+struct WreduceArgs {
+  const float* partial;
+  const float* bpartial;
+  int32_t n_split, rows, cols;  // packed rows / cols (multiples of 32)
+  const int32_t* rowmap;        // [rows] -> natural row or -1
+  const int32_t* colmap;        // [cols] -> natural col or -1
+  float* theta_bar;
+  int64_t w_off;
+  int32_t ld;
+  float scale;
+  int64_t b_off;   // bias gradient destination (index by natural row), or -1
+  int32_t accumulate;
+};
+static __global__ void wreduce_kernel(const WreduceArgs a) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = a.rows * a.cols;
+  if (idx < total) {
+    const int o = idx / a.cols, i = idx % a.cols;
+    const int nr = a.rowmap[o], nc = a.colmap[i];
+    if (nr >= 0 && nc >= 0) {
+      float s = 0.0f;
+      for (int k = 0; k < a.n_split; ++k) s += a.partial[(size_t)k * total + idx];
+      float* dst = a.theta_bar + a.w_off + (int64_t)nr * a.ld + nc;
+      *dst = (a.accumulate ? *dst : 0.0f) + s * a.scale;
+    }
+  }
+  if (a.bpartial != nullptr && a.b_off >= 0 && idx < a.rows) {
+    const int nr = a.rowmap[idx];
+    if (nr >= 0) {
+      float s = 0.0f;
+      for (int k = 0; k < a.n_split; ++k) s += a.bpartial[(size_t)k * a.rows + idx];
+      float* dst = a.theta_bar + a.b_off + nr;
+      *dst = (a.accumulate ? *dst : 0.0f) + s;
+    }
+  }
+}
+
+// Gradient of the sdf output row (lane-local dot product in geo_fwd_kernel):
+//   w_sdf_bar[k] = sum_p ( sdfbar_p * softplus(z_last[p][k]) + qb_last[p][k] ),   b_sdf_bar = sum_p sdfbar_p
+// grid = n_split, block = 64.  partial: [n_split][NBH*32 + 32]  (last 32-slot holds b_sdf_bar in [0])
+template <int NBH>
+__global__ __launch_bounds__(64, 1) void sdfrow_grad_kernel(const float* __restrict__ z_last, const float* __restrict__ qb_last,
+                                                            const float* __restrict__ sdfbar, const int64_t n_tiles,
+                                                            const int tiles_per_split, float* __restrict__ partial) {
+  const int lane = threadIdx.x, hf = lane >> 5;
+  const int64_t t0 = (int64_t)blockIdx.x * tiles_per_split;
+  int64_t t1 = t0 + tiles_per_split;
+  if (t1 > n_tiles) t1 = n_tiles;
+  f32x16 acc[NBH];
+#pragma unroll
+  for (int b = 0; b < NBH; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
+  float bsum = 0.0f;
+  for (int64_t tile = t0; tile < t1; ++tile) {
+    const float sb = sdfbar[tile * 32 + (lane & 31)];
+    bsum += sb;
+#pragma unroll
+    for (int b = 0; b < NBH; ++b) {
+      const float* zp = z_last + ((size_t)tile * NBH + b) * 1024 + lane;
+      const float* qp = qb_last + ((size_t)tile * NBH + b) * 1024 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float h, d1;
+        softplus100(zp[r * 64], h, d1);
+        acc[b][r] += fmaf(sb, h, qp[r * 64]);
+      }
+    }
+  }
+  // reduce over the 32 points of a half-wave
+#pragma unroll
+  for (int m = 1; m < 32; m <<= 1) {
+    bsum += __shfl_xor(bsum, m);
+#pragma unroll
+    for (int b = 0; b < NBH; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[b][r] += __shfl_xor(acc[b][r], m);
+  }
+  float* dst = partial + (size_t)blockIdx.x * (NBH * 32 + 32);
+  if ((lane & 31) == 0) {
+#pragma unroll
+    for (int b = 0; b < NBH; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[b * 32 + tp_row(r, hf)] = acc[b][r];
+    if (hf == 0) dst[NBH * 32] = bsum;
+  }
+}

@@ -1,0 +1,426 @@
+"""SDF field, mirroring nerfstudio/fields/sdf_field.py (SDFFieldConfig :121-185, SDFField :188-698).
+
+Same constructor, method names, parameter names (``glin{l}.weight_g/weight_v/bias``, ``clin{l}.*``, ``encoding.params``,
+``laplace_density.beta``, ``deviation_network.variance``, ``embedding_appearance.embedding.weight``) and output
+dictionary keys as the reference, but all field arithmetic — hash-grid encode, the geometry MLP and its analytic
+d sdf/dx, the colour MLP, and the complete backward including the second-order terms the eikonal / normal path needs —
+runs in hand-written HIP kernels (include/sdfhip.h: sdfhip_field_forward / sdfhip_field_backward).  There is no
+autograd over the MLP and no PyTorch fallback: without libsdfhip.so or without a HIP device this module raises.
+"""
+import ctypes
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Type
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from sdfstudio_amd import _lib
+from sdfstudio_amd.cameras.rays import unpack_ray_samples
+from sdfstudio_amd.fields.field_heads import FieldHeadNames
+
+
+@dataclass
+class SDFFieldConfig:
+    """fields/sdf_field.py:121-185 (same field names and defaults)."""
+
+    _target: Type = field(default_factory=lambda: SDFField)
+    num_layers: int = 8
+    hidden_dim: int = 256
+    geo_feat_dim: int = 256
+    num_layers_color: int = 4
+    hidden_dim_color: int = 256
+    appearance_embedding_dim: int = 32
+    use_appearance_embedding: bool = False
+    bias: float = 0.8
+    geometric_init: bool = True
+    inside_outside: bool = True
+    weight_norm: bool = True
+    use_grid_feature: bool = False
+    divide_factor: float = 2.0
+    beta_init: float = 0.1
+    encoding_type: str = "hash"
+    position_encoding_max_degree: int = 6
+    use_diffuse_color: bool = False
+    use_specular_tint: bool = False
+    use_reflections: bool = False
+    use_n_dot_v: bool = False
+    rgb_padding: float = 0.001
+    off_axis: bool = False
+    use_numerical_gradients: bool = False
+    num_levels: int = 16
+    max_res: int = 2048
+    base_res: int = 16
+    log2_hashmap_size: int = 19
+    hash_features_per_level: int = 2
+    hash_smoothstep: bool = True
+    use_position_encoding: bool = True
+
+    def setup(self, **kwargs):
+        """configs/base_config.py:58-66."""
+        return self._target(self, **kwargs)
+
+
+class LaplaceDensity(nn.Module):
+    """fields/sdf_field.py:49-71."""
+
+    def __init__(self, init_val, beta_min=0.0001):
+        super().__init__()
+        self.register_parameter("beta_min", nn.Parameter(beta_min * torch.ones(1), requires_grad=False))
+        self.register_parameter("beta", nn.Parameter(init_val * torch.ones(1), requires_grad=True))
+
+    def forward(self, sdf, beta=None):
+        if beta is None:
+            beta = self.get_beta()
+        return (1.0 / beta) * (0.5 + 0.5 * sdf.sign() * torch.expm1(-sdf.abs() / beta))
+
+    def get_beta(self):
+        return self.beta.abs() + self.beta_min
+
+
+class SingleVarianceNetwork(nn.Module):
+    """fields/sdf_field.py:101-118."""
+
+    def __init__(self, init_val):
+        super().__init__()
+        self.register_parameter("variance", nn.Parameter(init_val * torch.ones(1), requires_grad=True))
+
+    def forward(self, x):
+        return torch.ones([len(x), 1], device=x.device) * torch.exp(self.variance * 10.0)
+
+    def get_variance(self):
+        return torch.exp(self.variance * 10.0).clip(1e-6, 1e6)
+
+
+class _HashTable(nn.Module):
+    """Stands where the reference keeps ``tcnn.Encoding`` (sdf_field.py:230): owns the flat fp32 table ``params``."""
+
+    def __init__(self, grid_cfg: _lib.GridCfg):
+        super().__init__()
+        self.grid_cfg = grid_cfg
+        levels, n_entries = _lib.grid_levels(grid_cfg)
+        self.levels = levels
+        self.n_output_dims = grid_cfg.n_levels * grid_cfg.n_features
+        self.params = nn.Parameter((torch.rand(n_entries * grid_cfg.n_features) * 2 - 1) * 1e-4)
+
+
+class _Embedding(nn.Module):
+    """field_components/embedding.py: appearance embedding table."""
+
+    def __init__(self, in_dim: int, out_dim: int):
+        super().__init__()
+        self.embedding = nn.Embedding(in_dim, out_dim)
+
+    def get_out_dim(self):
+        return self.embedding.embedding_dim
+
+    def mean(self, dim=0):
+        return self.embedding.weight.mean(dim)
+
+    def forward(self, idx):
+        return self.embedding(idx)
+
+
+class _FieldFunction(torch.autograd.Function):
+    """One autograd node for the whole field: (theta, table[, emb]) -> (sdf, d sdf/dx, rgb, contracted x)."""
+
+    @staticmethod
+    def forward(ctx, theta, table, emb, fld, origins, dirs, starts, mask):
+        lib = _lib.load()
+        dev = theta.device
+        n, s = starts.shape
+        P = n * s
+        NP = _lib.padded_points(P)
+        h = fld._handle
+        packed = torch.empty(lib.sdfhip_field_packed_size(h), device=dev)
+        _lib.check(lib.sdfhip_field_pack(h, _lib.ptr(theta.contiguous()), _lib.ptr(packed), _lib.stream()), "field_pack")
+        ws = torch.empty(lib.sdfhip_field_workspace_size(h, P, 1), dtype=torch.uint8, device=dev)
+        sdf = torch.empty(NP, device=dev)
+        grad = torch.empty(NP, 3, device=dev)
+        rgb = torch.empty(NP, 3, device=dev)
+        emb_c = None if emb is None else emb.contiguous()
+        _lib.check(lib.sdfhip_field_forward(h, _lib.ptr(packed), _lib.ptr(table), _lib.ptr(mask), _lib.ptr(origins),
+                                            _lib.ptr(dirs), _lib.ptr(starts), n, s, _lib.ptr(emb_c), _lib.MODE_FULL, 1,
+                                            ctypes.c_void_p(ws.data_ptr()), _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(rgb), None,
+                                            _lib.stream()), "field_forward")
+        ctx.save_for_backward(packed, table, mask, ws)
+        ctx.fld, ctx.shape, ctx.has_emb = fld, (n, s), emb is not None
+        x = ws[: NP * 12].view(torch.float32).view(NP, 3)[:P].view(n, s, 3)  # contracted positions live first in the workspace
+        ctx.mark_non_differentiable(x)
+        return sdf[:P].view(n, s), grad[:P].view(n, s, 3), rgb[:P].view(n, s, 3), x
+
+    @staticmethod
+    def backward(ctx, sdf_bar, grad_bar, rgb_bar, _x_bar):
+        packed, table, mask, ws = ctx.saved_tensors
+        lib = _lib.load()
+        fld = ctx.fld
+        n, s = ctx.shape
+        dev = packed.device
+        h = fld._handle
+        theta_bar = torch.empty(lib.sdfhip_field_theta_size(h), device=dev)
+        table_bar = torch.zeros_like(table)
+        emb_bar = torch.zeros(n, fld.config.appearance_embedding_dim, device=dev) if ctx.has_emb else None
+
+        def c(t):
+            return None if t is None else t.contiguous()
+
+        _lib.check(lib.sdfhip_field_backward(h, _lib.ptr(packed), _lib.ptr(table), _lib.ptr(mask), n, s,
+                                             ctypes.c_void_p(ws.data_ptr()), _lib.ptr(c(sdf_bar)), _lib.ptr(c(grad_bar)),
+                                             _lib.ptr(c(rgb_bar)), _lib.ptr(theta_bar), _lib.ptr(table_bar), _lib.ptr(emb_bar),
+                                             _lib.stream()), "field_backward")
+        return theta_bar, table_bar, emb_bar, None, None, None, None, None
+
+
+class SDFField(nn.Module):
+    """fields/sdf_field.py:188-698."""
+
+    config: SDFFieldConfig
+
+    def __init__(self, config: SDFFieldConfig, aabb, num_images: int, use_average_appearance_embedding: bool = False,
+                 spatial_distortion=None) -> None:
+        super().__init__()
+        c = self.config = config
+        unsupported = []
+        if c.encoding_type != "hash":
+            unsupported.append(f"encoding_type={c.encoding_type!r}")
+        if not c.use_grid_feature:
+            unsupported.append("use_grid_feature=False")
+        if c.use_diffuse_color or c.use_specular_tint or c.use_reflections or c.use_n_dot_v:
+            unsupported.append("ref-nerf colour options")
+        if c.off_axis:
+            unsupported.append("off_axis")
+        if c.use_numerical_gradients:
+            unsupported.append("use_numerical_gradients (neus-facto-angelo path, next round)")
+        if not c.weight_norm:
+            unsupported.append("weight_norm=False")
+        if unsupported:
+            raise NotImplementedError("sdfhip does not build: " + ", ".join(unsupported))
+        self.aabb = nn.Parameter(torch.as_tensor(aabb, dtype=torch.float32), requires_grad=False)
+        self.spatial_distortion = spatial_distortion
+        contract = 0
+        if spatial_distortion is not None:
+            order = getattr(spatial_distortion, "order", None)
+            if order != float("inf"):
+                raise NotImplementedError("only SceneContraction(order=inf) is built (base_surface_model.py:148-155)")
+            contract = 1
+        self.num_images = num_images
+        self.embedding_appearance = _Embedding(num_images, c.appearance_embedding_dim)
+        self.use_average_appearance_embedding = use_average_appearance_embedding
+        self.use_grid_feature = c.use_grid_feature
+        self.divide_factor = c.divide_factor
+        self.num_levels, self.max_res, self.base_res = c.num_levels, c.max_res, c.base_res
+        self.log2_hashmap_size, self.features_per_level = c.log2_hashmap_size, c.hash_features_per_level
+        self.growth_factor = np.exp((np.log(self.max_res) - np.log(self.base_res)) / (self.num_levels - 1))  # :226
+
+        grid_cfg = _lib.GridCfg(c.num_levels, c.hash_features_per_level, c.log2_hashmap_size, c.base_res,
+                                float(self.growth_factor), 1 if c.hash_smoothstep else 0)
+        self.encoding = _HashTable(grid_cfg)
+        self.hash_encoding_mask = torch.ones(c.num_levels * c.hash_features_per_level, dtype=torch.float32)  # :242-245
+
+        # ---- geometry MLP, geometric initialisation (sdf_field.py:279-313)
+        pe_dim = 3 * 2 * c.position_encoding_max_degree
+        in_dim = 3 + pe_dim + self.encoding.n_output_dims
+        dims = [in_dim] + [c.hidden_dim] * c.num_layers + [1 + c.geo_feat_dim]
+        self.num_layers = len(dims)
+        self.skip_in = [4]
+        for l in range(self.num_layers - 1):
+            out_dim = dims[l + 1] - dims[0] if (l + 1) in self.skip_in else dims[l + 1]
+            lin = nn.Linear(dims[l], out_dim)
+            if c.geometric_init:
+                with torch.no_grad():
+                    if l == self.num_layers - 2:
+                        sign = -1.0 if c.inside_outside else 1.0
+                        lin.weight.normal_(mean=sign * math.sqrt(math.pi) / math.sqrt(dims[l]), std=0.0001)
+                        lin.bias.fill_(-sign * c.bias)
+                    elif l == 0:
+                        lin.bias.zero_()
+                        lin.weight[:, 3:].zero_()
+                        lin.weight[:, :3].normal_(0.0, math.sqrt(2) / math.sqrt(out_dim))
+                    elif l in self.skip_in:
+                        lin.bias.zero_()
+                        lin.weight.normal_(0.0, math.sqrt(2) / math.sqrt(out_dim))
+                        lin.weight[:, -(dims[0] - 3):].zero_()
+                    else:
+                        lin.bias.zero_()
+                        lin.weight.normal_(0.0, math.sqrt(2) / math.sqrt(out_dim))
+            setattr(self, f"glin{l}", nn.utils.weight_norm(lin))
+
+        self.laplace_density = LaplaceDensity(init_val=c.beta_init)
+        self.deviation_network = SingleVarianceNetwork(init_val=c.beta_init)
+
+        # ---- colour MLP (sdf_field.py:327-363)
+        cin = 3 + 27 + 3 + c.geo_feat_dim + c.appearance_embedding_dim
+        cdims = [cin] + [c.hidden_dim_color] * c.num_layers_color + [3]
+        self.num_layers_color = len(cdims)
+        for l in range(self.num_layers_color - 1):
+            lin = nn.Linear(cdims[l], cdims[l + 1])
+            torch.nn.init.kaiming_uniform_(lin.weight.data)
+            torch.nn.init.zeros_(lin.bias.data)
+            setattr(self, f"clin{l}", nn.utils.weight_norm(lin))
+
+        self._cos_anneal_ratio = 1.0
+        self.numerical_gradients_delta = 0.0001
+
+        # ---- native descriptor
+        skip = 4 if c.num_layers > 4 else -1
+        self._cfg_c = _lib.FieldCfg(c.num_layers, c.hidden_dim, c.geo_feat_dim, c.num_layers_color, c.hidden_dim_color, skip,
+                                    c.position_encoding_max_degree, 1 if c.use_position_encoding else 0,
+                                    c.appearance_embedding_dim, contract, float(c.rgb_padding), grid_cfg)
+        self._handle_v: Optional[ctypes.c_void_p] = None
+        self._lin_names = [f"glin{l}" for l in range(c.num_layers + 1)] + [f"clin{l}" for l in range(c.num_layers_color + 1)]
+
+    # ------------------------------------------------------------------ native handle
+    @property
+    def _handle(self) -> ctypes.c_void_p:
+        if self._handle_v is None:
+            lib = _lib.load()
+            h = ctypes.c_void_p()
+            _lib.check(lib.sdfhip_field_create(ctypes.byref(self._cfg_c), ctypes.byref(h)), "sdfhip_field_create")
+            n_lin = lib.sdfhip_field_num_linear(h)
+            assert n_lin == len(self._lin_names)
+            w_off = (ctypes.c_int64 * n_lin)()
+            b_off = (ctypes.c_int64 * n_lin)()
+            od = (ctypes.c_int32 * n_lin)()
+            idim = (ctypes.c_int32 * n_lin)()
+            lib.sdfhip_field_theta_layout(h, w_off, b_off, od, idim)
+            for i, name in enumerate(self._lin_names):
+                lin = getattr(self, name)
+                assert tuple(lin.weight_v.shape) == (od[i], idim[i]), (name, tuple(lin.weight_v.shape), od[i], idim[i])
+            self._handle_v = h
+        return self._handle_v
+
+    def __del__(self):
+        h = getattr(self, "_handle_v", None)
+        if h is not None:
+            try:
+                _lib.load().sdfhip_field_destroy(h)
+            except Exception:  # noqa: BLE001  (interpreter shutdown)
+                pass
+
+    def _theta(self) -> torch.Tensor:
+        """Flat effective parameter vector in the ABI's layout: per linear layer W = g * v / ||v|| (weight_norm, dim 0), b."""
+        parts = []
+        for name in self._lin_names:
+            lin = getattr(self, name)
+            parts.append(torch._weight_norm(lin.weight_v, lin.weight_g, 0).reshape(-1))
+            parts.append(lin.bias)
+        return torch.cat(parts)
+
+    # ------------------------------------------------------------------ reference API
+    def set_cos_anneal_ratio(self, anneal: float) -> None:
+        """sdf_field.py:372-374."""
+        self._cos_anneal_ratio = anneal
+
+    def update_mask(self, level: int):
+        """sdf_field.py:376-378 (progressive hash levels)."""
+        self.hash_encoding_mask[:] = 1.0
+        self.hash_encoding_mask[level * self.features_per_level:] = 0
+
+    def set_numerical_gradients_delta(self, delta: float) -> None:
+        self.numerical_gradients_delta = delta
+
+    def _mask(self, device):
+        if self.hash_encoding_mask.device != device:
+            self.hash_encoding_mask = self.hash_encoding_mask.to(device)
+        return self.hash_encoding_mask
+
+    def _run_inference(self, mode, origins, dirs, starts, n, s, want_feat):
+        lib = _lib.load()
+        dev = origins.device
+        h = self._handle
+        with torch.no_grad():
+            theta = self._theta()
+            packed = torch.empty(lib.sdfhip_field_packed_size(h), device=dev)
+            _lib.check(lib.sdfhip_field_pack(h, _lib.ptr(theta), _lib.ptr(packed), _lib.stream()), "field_pack")
+            P = n * s
+            NP = _lib.padded_points(P)
+            ws = torch.empty(lib.sdfhip_field_workspace_size(h, P, 0), dtype=torch.uint8, device=dev)
+            sdf = torch.empty(NP, device=dev)
+            feat = torch.empty(NP, self.config.geo_feat_dim, device=dev) if want_feat else None
+            _lib.check(lib.sdfhip_field_forward(h, _lib.ptr(packed), _lib.ptr(self.encoding.params.detach()),
+                                                _lib.ptr(self._mask(dev)), _lib.ptr(origins), _lib.ptr(dirs), _lib.ptr(starts),
+                                                n, s, None, mode, 0, ctypes.c_void_p(ws.data_ptr()), _lib.ptr(sdf), None, None,
+                                                _lib.ptr(feat), _lib.stream()), "field_forward")
+        return sdf[:P], (None if feat is None else feat[:P])
+
+    def forward_geonetwork(self, inputs: torch.Tensor) -> torch.Tensor:
+        """sdf_field.py:380-410: [P,3] -> [P, 1 + geo_feat_dim] (column 0 = sdf).  Inference form (no autograd graph):
+        the differentiable path is ``forward`` / ``get_outputs``."""
+        x = inputs.reshape(-1, 3).contiguous().float()
+        sdf, feat = self._run_inference(_lib.MODE_GEO, x, None, None, x.shape[0], 1, True)
+        return torch.cat([sdf[:, None], feat], dim=-1)
+
+    def get_sdf(self, ray_samples):
+        """sdf_field.py:412-418: sdf at the frustum START positions, NO scene contraction (sampler callback, no grad)."""
+        o, d, st, _ = unpack_ray_samples(ray_samples)
+        n, s = st.shape
+        sdf, _ = self._run_inference(_lib.MODE_SDF, o, d, st, n, s, False)
+        return sdf.view(n, s, 1)
+
+    def get_alpha(self, ray_samples, sdf=None, gradients=None):
+        """sdf_field.py:476-525 (elementwise; the fused model path uses renderers.neus_render instead)."""
+        if sdf is None or gradients is None:
+            out = self.get_outputs(ray_samples)
+            sdf, gradients = out[FieldHeadNames.SDF], out[FieldHeadNames.GRADIENT]
+        inv_s = self.deviation_network.get_variance()
+        true_cos = (ray_samples.frustums.directions * gradients).sum(-1, keepdim=True)
+        ca = self._cos_anneal_ratio
+        iter_cos = -(F.relu(-true_cos * 0.5 + 0.5) * (1.0 - ca) + F.relu(-true_cos) * ca)
+        est_next = sdf + iter_cos * ray_samples.deltas * 0.5
+        est_prev = sdf - iter_cos * ray_samples.deltas * 0.5
+        prev_cdf, next_cdf = torch.sigmoid(est_prev * inv_s), torch.sigmoid(est_next * inv_s)
+        return ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).clip(0.0, 1.0)
+
+    def get_occupancy(self, sdf):
+        """sdf_field.py:527-530."""
+        return torch.sigmoid(-10.0 * sdf)
+
+    def get_outputs(self, ray_samples, return_alphas=False, return_occupancy=False) -> Dict:
+        """sdf_field.py:614-689."""
+        if ray_samples.camera_indices is None:
+            raise AttributeError("Camera indices are not provided.")
+        o, d, st, _ = unpack_ray_samples(ray_samples)
+        n, s = st.shape
+        dev = o.device
+        emb = None
+        if self.config.use_appearance_embedding:
+            cam = ray_samples.camera_indices.reshape(n, -1)[:, 0]
+            if self.training:
+                emb = self.embedding_appearance(cam)
+            elif self.use_average_appearance_embedding:
+                emb = self.embedding_appearance.mean(dim=0)[None, :].expand(n, -1)
+        theta = self._theta()
+        sdf, grad, rgb, x = _FieldFunction.apply(theta, self.encoding.params, emb, self, o, d, st, self._mask(dev))
+        sdf3 = sdf[..., None]
+        outputs = {
+            FieldHeadNames.RGB: rgb,
+            FieldHeadNames.DENSITY: self.laplace_density(sdf3),
+            FieldHeadNames.SDF: sdf3,
+            FieldHeadNames.NORMAL: F.normalize(grad, p=2, dim=-1),
+            FieldHeadNames.GRADIENT: grad,
+            "points_norm": x.norm(dim=-1, keepdim=True),
+            "sampled_sdf": None,
+        }
+        if return_alphas:
+            outputs[FieldHeadNames.ALPHA] = self.get_alpha(ray_samples, sdf3, grad)
+        if return_occupancy:
+            outputs[FieldHeadNames.OCCUPANCY] = self.get_occupancy(sdf3)
+        return outputs
+
+    def forward(self, ray_samples, return_alphas=False, return_occupancy=False):
+        """sdf_field.py:691-698."""
+        return self.get_outputs(ray_samples, return_alphas=return_alphas, return_occupancy=return_occupancy)
+
+    # fused entry used by the models (skips the per-head PyTorch elementwise ops)
+    def forward_fused(self, ray_samples):
+        """(sdf [N,S], d sdf/dx [N,S,3], rgb [N,S,3], contracted positions [N,S,3]) in one native call."""
+        if ray_samples.camera_indices is None:
+            raise AttributeError("Camera indices are not provided.")
+        o, d, st, _ = unpack_ray_samples(ray_samples)
+        n = st.shape[0]
+        emb = None
+        if self.config.use_appearance_embedding and self.training:
+            emb = self.embedding_appearance(ray_samples.camera_indices.reshape(n, -1)[:, 0])
+        return _FieldFunction.apply(self._theta(), self.encoding.params, emb, self, o, d, st, self._mask(o.device))

@@ -1,0 +1,169 @@
+"""Ray samplers mirroring nerfstudio/model_components/ray_samplers.py (Sampler :32, SpacedSampler :55,
+UniformLinDispPiecewiseSampler :221, PDFSampler :250, ProposalNetworkSampler :497).
+
+Each sampler is one HIP kernel launch (the reference issues 10-25 small PyTorch kernels each).  Sampler outputs
+carry no gradient (bins.detach(), ray_samplers.py:358).  Stratified jitter uses a single draw per ray
+(``single_jitter=True``, the neus-facto setting, neus_facto.py:145); tests inject the draw to compare with the oracle.
+"""
+from typing import Callable, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from sdfstudio_amd import _lib
+from sdfstudio_amd.cameras.rays import RayBundle, RaySamples
+
+
+def _piecewise_to_euclidean(nears: torch.Tensor, fars: torch.Tensor) -> Callable:
+    """spacing_to_euclidean_fn of UniformLinDispPiecewiseSampler (ray_samplers.py:115-117, 240-241)."""
+
+    def fn(x):
+        sp = lambda v: torch.where(v < 1, v / 2, 1 - 1 / (2 * v))
+        inv = lambda v: torch.where(v < 0.5, 2 * v, 1 / (2 - 2 * v))
+        s_near, s_far = sp(nears), sp(fars)
+        return inv(x * s_far + (1 - x) * s_near)
+
+    return fn
+
+
+class Sampler(nn.Module):
+    """ray_samplers.py:32-52."""
+
+    def __init__(self, num_samples: Optional[int] = None) -> None:
+        super().__init__()
+        self.num_samples = num_samples
+
+    def forward(self, *args, **kwargs):
+        return self.generate_ray_samples(*args, **kwargs)
+
+
+def _make_samples(ray_bundle: RayBundle, bins, starts, ends) -> RaySamples:
+    return ray_bundle.get_ray_samples(
+        bin_starts=starts[..., None], bin_ends=ends[..., None], spacing_starts=bins[:, :-1, None],
+        spacing_ends=bins[:, 1:, None], spacing_to_euclidean_fn=_piecewise_to_euclidean(ray_bundle.nears, ray_bundle.fars),
+        flat_bins=bins,
+    )
+
+
+class UniformLinDispPiecewiseSampler(Sampler):
+    """ray_samplers.py:221-247: first half uniform, second half linear in disparity."""
+
+    def __init__(self, num_samples: Optional[int] = None, train_stratified=True, single_jitter=True) -> None:
+        super().__init__(num_samples=num_samples)
+        if not single_jitter:
+            raise NotImplementedError("per-sample jitter is not built; neus-facto uses single_jitter=True")
+        self.train_stratified = train_stratified
+        self.jitter_override: Optional[torch.Tensor] = None  # tests inject the draw here
+
+    def generate_ray_samples(self, ray_bundle: RayBundle, num_samples: Optional[int] = None) -> RaySamples:
+        lib = _lib.load()
+        s = num_samples or self.num_samples
+        n = len(ray_bundle)
+        dev = ray_bundle.origins.device
+        nears = ray_bundle.nears.reshape(-1).contiguous()
+        fars = ray_bundle.fars.reshape(-1).contiguous()
+        jitter = None
+        if self.train_stratified and self.training:
+            jitter = self.jitter_override if self.jitter_override is not None else torch.rand(n, device=dev)
+            jitter = jitter.reshape(-1).contiguous()
+        bins = torch.empty(n, s + 1, device=dev)
+        starts = torch.empty(n, s, device=dev)
+        ends = torch.empty(n, s, device=dev)
+        _lib.check(lib.sdfhip_sample_spaced(_lib.ptr(nears), _lib.ptr(fars), _lib.ptr(jitter), n, s, _lib.ptr(bins),
+                                            _lib.ptr(starts), _lib.ptr(ends), _lib.stream()), "sample_spaced")
+        return _make_samples(ray_bundle, bins, starts, ends)
+
+
+class PDFSampler(Sampler):
+    """ray_samplers.py:250-370 with include_original=False (the ProposalNetworkSampler setting, :525)."""
+
+    def __init__(self, num_samples: Optional[int] = None, train_stratified: bool = True, single_jitter: bool = True,
+                 include_original: bool = False, histogram_padding: float = 0.01) -> None:
+        super().__init__(num_samples=num_samples)
+        if include_original or not single_jitter:
+            raise NotImplementedError("only include_original=False, single_jitter=True is built")
+        self.train_stratified = train_stratified
+        self.histogram_padding = histogram_padding
+        self.jitter_override: Optional[torch.Tensor] = None
+
+    def generate_ray_samples(self, ray_bundle: RayBundle, ray_samples: RaySamples, weights: torch.Tensor,
+                             num_samples: Optional[int] = None, anneal: float = 1.0) -> RaySamples:
+        lib = _lib.load()
+        s_out = num_samples or self.num_samples
+        w = weights[..., 0] if weights.dim() == 3 else weights
+        w = w.detach().contiguous()
+        n, s_in = w.shape
+        dev = w.device
+        bins_in = ray_samples.flat_bins
+        if bins_in is None:
+            bins_in = torch.cat([ray_samples.spacing_starts[..., 0], ray_samples.spacing_ends[..., -1:, 0]], dim=-1)
+        bins_in = bins_in.contiguous()
+        nears = ray_bundle.nears.reshape(-1).contiguous()
+        fars = ray_bundle.fars.reshape(-1).contiguous()
+        jitter = None
+        if self.train_stratified and self.training:
+            jitter = self.jitter_override if self.jitter_override is not None else torch.rand(n, device=dev)
+            jitter = jitter.reshape(-1).contiguous()
+        bins = torch.empty(n, s_out + 1, device=dev)
+        starts = torch.empty(n, s_out, device=dev)
+        ends = torch.empty(n, s_out, device=dev)
+        _lib.check(lib.sdfhip_sample_pdf(_lib.ptr(w), _lib.ptr(bins_in), _lib.ptr(nears), _lib.ptr(fars), _lib.ptr(jitter),
+                                         n, s_in, s_out, float(anneal), float(self.histogram_padding), _lib.ptr(bins),
+                                         _lib.ptr(starts), _lib.ptr(ends), _lib.stream()), "sample_pdf")
+        return _make_samples(ray_bundle, bins, starts, ends)
+
+
+class ProposalNetworkSampler(Sampler):
+    """ray_samplers.py:497-578.  density_fns take a RaySamples (fused midpoint + contraction + grid + MLP kernel)."""
+
+    def __init__(self, num_proposal_samples_per_ray: Tuple[int, ...] = (64,), num_nerf_samples_per_ray: int = 32,
+                 num_proposal_network_iterations: int = 2, use_uniform_sampler: bool = False, single_jitter: bool = True,
+                 update_sched: Callable = lambda x: 1) -> None:
+        super().__init__()
+        if use_uniform_sampler:
+            raise NotImplementedError("neus-facto uses the piecewise initial sampler (neus_facto.py:140-147)")
+        if num_proposal_network_iterations < 1:
+            raise ValueError("num_proposal_network_iterations must be >= 1")
+        self.num_proposal_samples_per_ray = num_proposal_samples_per_ray
+        self.num_nerf_samples_per_ray = num_nerf_samples_per_ray
+        self.num_proposal_network_iterations = num_proposal_network_iterations
+        self.update_sched = update_sched
+        self.initial_sampler = UniformLinDispPiecewiseSampler(single_jitter=single_jitter)
+        self.pdf_sampler = PDFSampler(include_original=False, single_jitter=single_jitter)
+        self._anneal = 1.0
+        self._steps_since_update = 0
+        self._step = 0
+
+    def set_anneal(self, anneal: float) -> None:
+        self._anneal = anneal
+
+    def step_cb(self, step):
+        self._step = step
+        self._steps_since_update += 1
+
+    def generate_ray_samples(self, ray_bundle: RayBundle, density_fns: List[Callable]):
+        weights_list, ray_samples_list = [], []
+        n = self.num_proposal_network_iterations
+        weights, ray_samples = None, None
+        updated = self._steps_since_update > self.update_sched(self._step) or self._step < 10
+        for i_level in range(n + 1):
+            is_prop = i_level < n
+            num_samples = self.num_proposal_samples_per_ray[i_level] if is_prop else self.num_nerf_samples_per_ray
+            if i_level == 0:
+                ray_samples = self.initial_sampler(ray_bundle, num_samples=num_samples)
+            else:
+                # torch.pow(weights, anneal) (ray_samplers.py:562) is folded into the PDF kernel
+                ray_samples = self.pdf_sampler(ray_bundle, ray_samples, weights, num_samples=num_samples,
+                                               anneal=self._anneal)
+            if is_prop:
+                if updated:
+                    density = density_fns[i_level](ray_samples)
+                else:
+                    with torch.no_grad():
+                        density = density_fns[i_level](ray_samples)
+                weights = ray_samples.get_weights(density)
+                weights_list.append(weights)
+                ray_samples_list.append(ray_samples)
+        if updated:
+            self._steps_since_update = 0
+        return ray_samples, weights_list, ray_samples_list

@@ -1,0 +1,151 @@
+"""Weights + renderers, mirroring nerfstudio/cameras/rays.py:131-230 and nerfstudio/model_components/renderers.py.
+
+The reference composes get_alpha -> get_weights_from_alphas -> RGBRenderer / DepthRenderer / SemanticRenderer /
+AccumulationRenderer out of ~40 small PyTorch kernels; here the whole chain is one HIP kernel per direction
+(one 64-lane wavefront per ray, DPP scans): ``neus_render``.  ``density_to_weights`` is RaySamples.get_weights.
+The thin nn.Module wrappers keep the reference's class names / call signatures.
+"""
+from typing import Optional
+
+import torch
+from torch import nn
+
+from sdfstudio_amd import _lib
+
+
+class _DensityWeights(torch.autograd.Function):
+    """RaySamples.get_weights (rays.py:146-167): w_i = (1 - exp(-d_i s_i)) exp(-sum_{j<i} d_j s_j)."""
+
+    @staticmethod
+    def forward(ctx, density, starts, ends):
+        lib = _lib.load()
+        density = density.contiguous()
+        n, s = density.shape
+        weights = torch.empty_like(density)
+        _lib.check(lib.sdfhip_density_weights_forward(_lib.ptr(density), _lib.ptr(starts), _lib.ptr(ends), n, s,
+                                                      _lib.ptr(weights), _lib.stream()), "density_weights_forward")
+        ctx.save_for_backward(density, starts, ends)
+        return weights
+
+    @staticmethod
+    def backward(ctx, wbar):
+        density, starts, ends = ctx.saved_tensors
+        lib = _lib.load()
+        n, s = density.shape
+        dbar = torch.empty_like(density)
+        _lib.check(lib.sdfhip_density_weights_backward(_lib.ptr(density), _lib.ptr(starts), _lib.ptr(ends), n, s,
+                                                       _lib.ptr(wbar.contiguous()), _lib.ptr(dbar), _lib.stream()),
+                   "density_weights_backward")
+        return dbar, None, None
+
+
+def density_to_weights(density: torch.Tensor, starts: torch.Tensor, ends: torch.Tensor) -> torch.Tensor:
+    """density, starts, ends: [N,S] -> weights [N,S]."""
+    return _DensityWeights.apply(density, starts.contiguous(), ends.contiguous())
+
+
+class _NeusRender(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sdf, grad, rgb, variance, dirs, starts, ends, background, cos_anneal):
+        lib = _lib.load()
+        n, s = starts.shape
+        dev = starts.device
+        sdf, grad, rgb = sdf.contiguous(), grad.contiguous(), rgb.contiguous()
+        alpha = torch.empty(n, s, device=dev)
+        weights = torch.empty(n, s, device=dev)
+        out_rgb = torch.empty(n, 3, device=dev)
+        depth_raw = torch.empty(n, device=dev)
+        depth = torch.empty(n, device=dev)
+        normal = torch.empty(n, 3, device=dev)
+        acc = torch.empty(n, device=dev)
+        minmax = torch.empty(2, device=dev)
+        _lib.check(lib.sdfhip_neus_render_forward(
+            _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(rgb), _lib.ptr(dirs), _lib.ptr(starts), _lib.ptr(ends),
+            _lib.ptr(variance), _lib.ptr(background), float(cos_anneal), n, s, _lib.ptr(alpha), _lib.ptr(weights),
+            _lib.ptr(out_rgb), _lib.ptr(depth_raw), _lib.ptr(depth), _lib.ptr(normal), _lib.ptr(acc), _lib.ptr(minmax),
+            _lib.stream()), "neus_render_forward")
+        ctx.save_for_backward(sdf, grad, rgb, variance, dirs, starts, ends, alpha, weights, depth_raw, acc, minmax)
+        ctx.background = background
+        ctx.cos_anneal = float(cos_anneal)
+        ctx.mark_non_differentiable(alpha)
+        return out_rgb, depth, normal, acc, weights, alpha
+
+    @staticmethod
+    def backward(ctx, rgb_bar, depth_bar, normal_bar, acc_bar, weights_bar, _alpha_bar):
+        sdf, grad, rgb, variance, dirs, starts, ends, alpha, weights, depth_raw, acc, minmax = ctx.saved_tensors
+        lib = _lib.load()
+        n, s = starts.shape
+        sdf_bar = torch.empty_like(sdf)
+        grad_bar = torch.empty_like(grad)
+        rgbs_bar = torch.empty_like(rgb)
+        var_bar = torch.zeros_like(variance)
+
+        def c(t):
+            return None if t is None else t.contiguous()
+
+        _lib.check(lib.sdfhip_neus_render_backward(
+            _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(rgb), _lib.ptr(dirs), _lib.ptr(starts), _lib.ptr(ends),
+            _lib.ptr(variance), _lib.ptr(ctx.background), ctx.cos_anneal, n, s, _lib.ptr(alpha), _lib.ptr(weights),
+            _lib.ptr(depth_raw), _lib.ptr(acc), _lib.ptr(minmax), _lib.ptr(c(rgb_bar)), _lib.ptr(c(depth_bar)),
+            _lib.ptr(c(normal_bar)), _lib.ptr(c(acc_bar)), _lib.ptr(c(weights_bar)), _lib.ptr(sdf_bar), _lib.ptr(grad_bar),
+            _lib.ptr(rgbs_bar), _lib.ptr(var_bar), _lib.stream()), "neus_render_backward")
+        return sdf_bar, grad_bar, rgbs_bar, var_bar, None, None, None, None, None
+
+
+def neus_render(sdf, gradients, rgb, variance, directions, starts, ends, cos_anneal_ratio: float,
+                background: Optional[torch.Tensor] = None):
+    """Fused SDFField.get_alpha (sdf_field.py:476-525) + get_weights_from_alphas (rays.py:194-208) + renderers.
+
+    sdf [N,S], gradients [N,S,3], rgb [N,S,3], variance [1] (deviation_network.variance), directions [N,3],
+    starts/ends [N,S].  Returns rgb [N,3], depth [N] (expected, clipped as renderers.py:257), normal [N,3]
+    (sum of w * normalize(grad)), accumulation [N], weights [N,S], alpha [N,S].
+    """
+    return _NeusRender.apply(sdf, gradients, rgb, variance, directions.contiguous(), starts.contiguous(),
+                             ends.contiguous(), background, cos_anneal_ratio)
+
+
+class RGBRenderer(nn.Module):
+    """renderers.py:42-118 for dense [N,S] samples: sum_s w rgb + bg (1 - sum_s w); clamp to [0,1] in eval."""
+
+    def __init__(self, background_color=None) -> None:
+        super().__init__()
+        self.background_color = background_color
+
+    def forward(self, rgb: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
+        comp = torch.sum(weights * rgb, dim=-2)
+        acc = torch.sum(weights, dim=-2)
+        bg = self.background_color
+        if isinstance(bg, torch.Tensor):
+            comp = comp + bg.to(comp) * (1.0 - acc)
+        if not self.training:
+            comp = comp.clamp(0.0, 1.0)
+        return comp
+
+
+class AccumulationRenderer(nn.Module):
+    """renderers.py:171-197."""
+
+    def forward(self, weights: torch.Tensor) -> torch.Tensor:
+        return torch.sum(weights, dim=-2)
+
+
+class DepthRenderer(nn.Module):
+    """renderers.py:200-261, method='expected'."""
+
+    def __init__(self, method: str = "expected") -> None:
+        super().__init__()
+        if method != "expected":
+            raise NotImplementedError("only the 'expected' depth method is on the SDF path")
+        self.method = method
+
+    def forward(self, weights: torch.Tensor, ray_samples) -> torch.Tensor:
+        steps = (ray_samples.frustums.starts + ray_samples.frustums.ends) / 2
+        depth = torch.sum(weights * steps, dim=-2) / (torch.sum(weights, -2) + 1e-10)
+        return torch.clip(depth, steps.min(), steps.max())
+
+
+class SemanticRenderer(nn.Module):
+    """renderers.py:284-295 (used for normals by SurfaceModel)."""
+
+    def forward(self, semantics: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
+        return torch.sum(weights * semantics, dim=-2)

@@ -1,0 +1,228 @@
+"""NeuS-facto model, mirroring nerfstudio/models/neus_facto.py (+ the parts of base_surface_model.py and neus.py it
+inherits) as the CALLER of the native hot path: sample -> field -> alpha/weights/render -> losses.
+
+Host glue only; every heavy stage is one native call:
+  ProposalNetworkSampler (sample_spaced / proposal_forward / density_weights / sample_pdf kernels)
+  SDFField.forward_fused (encode + geometry MLP + analytic gradient + colour MLP kernels)
+  renderers.neus_render  (alpha + transmittance scan + rgb/depth/normal/accumulation, one wavefront per ray)
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Tuple, Type
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from sdfstudio_amd.cameras.rays import RayBundle
+from sdfstudio_amd.fields.density_fields import HashMLPDensityField
+from sdfstudio_amd.fields.field_heads import FieldHeadNames
+from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
+from sdfstudio_amd.model_components.losses import interlevel_loss_zip
+from sdfstudio_amd.model_components.ray_samplers import ProposalNetworkSampler
+from sdfstudio_amd.model_components.renderers import neus_render
+
+
+class SceneContraction(nn.Module):
+    """field_components/spatial_distortions.py:42-92 (order = inf); a marker for the kernels, callable for host code."""
+
+    def __init__(self, order=float("inf")) -> None:
+        super().__init__()
+        self.order = order
+
+    def forward(self, positions: torch.Tensor) -> torch.Tensor:
+        mag = torch.linalg.norm(positions, ord=self.order, dim=-1, keepdim=True)
+        safe = torch.where(mag >= 1, mag, torch.ones_like(mag))
+        return torch.where(mag >= 1, (2 - 1 / safe) * (positions / safe), positions)
+
+
+@dataclass
+class NeuSFactoModelConfig:
+    """models/neus_facto.py:43-97 + base_surface_model.py:69-134 (the knobs on the path; same names)."""
+
+    _target: Type = field(default_factory=lambda: NeuSFactoModel)
+    near_plane: float = 0.05
+    far_plane: float = 4.0
+    background_color: str = "black"
+    eikonal_loss_mult: float = 0.1
+    fg_mask_loss_mult: float = 0.01
+    mono_normal_loss_mult: float = 0.0
+    mono_depth_loss_mult: float = 0.0
+    sdf_field: SDFFieldConfig = field(default_factory=SDFFieldConfig)
+    background_model: str = "none"
+    num_proposal_samples_per_ray: Tuple[int, ...] = (256, 96)
+    num_neus_samples_per_ray: int = 48
+    num_proposal_iterations: int = 2
+    use_same_proposal_network: bool = False
+    proposal_net_args_list: List[Dict] = field(
+        default_factory=lambda: [
+            {"hidden_dim": 16, "log2_hashmap_size": 17, "num_levels": 5, "max_res": 64},
+            {"hidden_dim": 16, "log2_hashmap_size": 17, "num_levels": 5, "max_res": 256},
+        ]
+    )
+    interlevel_loss_mult: float = 1.0
+    use_proposal_weight_anneal: bool = True
+    proposal_weights_anneal_slope: float = 10.0
+    proposal_weights_anneal_max_num_iters: int = 1000
+    use_single_jitter: bool = True
+    scene_contraction_norm: str = "inf"
+    anneal_end: int = 50000
+
+    def setup(self, **kwargs):
+        return self._target(self, **kwargs)
+
+
+@dataclass
+class SceneBox:
+    """data/scene_box.py: the fields SurfaceModel reads (aabb, near, far, collider_type)."""
+
+    aabb: torch.Tensor
+    near: float = 0.5
+    far: float = 4.5
+    radius: float = 1.0
+    collider_type: str = "near_far"
+
+
+class NeuSFactoModel(nn.Module):
+    """models/neus_facto.py:100-352 on top of models/neus.py and models/base_surface_model.py."""
+
+    def __init__(self, config: NeuSFactoModelConfig, scene_box: SceneBox, num_train_data: int, **kwargs) -> None:
+        super().__init__()
+        self.config = config
+        self.scene_box = scene_box
+        self.num_train_data = num_train_data
+        self.populate_modules()
+
+    def populate_modules(self):
+        """base_surface_model.py:144-233, neus_facto.py:110-147."""
+        c = self.config
+        if c.background_model != "none":
+            raise NotImplementedError("background models are outside this round's scope (SURVEY.md section 8, row f4)")
+        if c.scene_contraction_norm != "inf":
+            raise NotImplementedError("only the L-inf scene contraction is built")
+        if self.scene_box.collider_type != "near_far":
+            raise NotImplementedError("only the near/far collider is on the path this round")
+        self.scene_contraction = SceneContraction(order=float("inf"))
+        self.field = c.sdf_field.setup(aabb=self.scene_box.aabb, spatial_distortion=self.scene_contraction,
+                                       num_images=self.num_train_data, use_average_appearance_embedding=False)
+        self.proposal_networks = nn.ModuleList()
+        n_prop = c.num_proposal_iterations
+        if c.use_same_proposal_network:
+            net = HashMLPDensityField(self.scene_box.aabb, spatial_distortion=self.scene_contraction, **c.proposal_net_args_list[0])
+            self.proposal_networks.append(net)
+            self.density_fns = [net.density_fn for _ in range(n_prop)]
+        else:
+            for i in range(n_prop):
+                args = c.proposal_net_args_list[min(i, len(c.proposal_net_args_list) - 1)]
+                self.proposal_networks.append(
+                    HashMLPDensityField(self.scene_box.aabb, spatial_distortion=self.scene_contraction, **args))
+            self.density_fns = [net.density_fn for net in self.proposal_networks]
+        self.proposal_sampler = ProposalNetworkSampler(
+            num_nerf_samples_per_ray=c.num_neus_samples_per_ray, num_proposal_samples_per_ray=c.num_proposal_samples_per_ray,
+            num_proposal_network_iterations=c.num_proposal_iterations, single_jitter=c.use_single_jitter,
+            update_sched=lambda step: -1,
+        )
+        bg = {"black": torch.zeros(3), "white": torch.ones(3)}.get(c.background_color)
+        if bg is None:
+            raise NotImplementedError("background_color must be black or white on the fused path")
+        self.register_buffer("background", bg, persistent=False)
+
+    def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:
+        """base_surface_model.py:238-245, neus_facto.py:149-152."""
+        return {
+            "fields": list(self.field.parameters()),
+            "field_background": [],
+            "proposal_networks": list(self.proposal_networks.parameters()),
+        }
+
+    # ---- training callbacks (neus.py:82-92, neus_facto.py:163-176), exposed as plain methods
+    def before_train_iteration(self, step: int):
+        if self.config.anneal_end > 0:
+            self.field.set_cos_anneal_ratio(min(1.0, step / self.config.anneal_end))
+        if self.config.use_proposal_weight_anneal:
+            n = self.config.proposal_weights_anneal_max_num_iters
+            frac = float(np.clip(step / n, 0, 1))
+            b = self.config.proposal_weights_anneal_slope
+            self.proposal_sampler.set_anneal((b * frac) / ((b - 1) * frac + 1))
+
+    def after_train_iteration(self, step: int):
+        self.proposal_sampler.step_cb(step)
+
+    def collide(self, ray_bundle: RayBundle) -> RayBundle:
+        """scene_colliders.py:111-129 NearFarCollider."""
+        ones = torch.ones_like(ray_bundle.origins[..., 0:1])
+        ray_bundle.nears = ones * self.scene_box.near
+        ray_bundle.fars = ones * self.scene_box.far
+        return ray_bundle
+
+    def sample_and_forward_field(self, ray_bundle: RayBundle) -> Dict:
+        """neus_facto.py:282-302 (+ get_weights_from_alphas and the renderers, fused)."""
+        ray_samples, weights_list, ray_samples_list = self.proposal_sampler(ray_bundle, density_fns=self.density_fns)
+        sdf, grad, rgb, x = self.field.forward_fused(ray_samples)
+        bg = None if self.config.background_color == "black" else self.background
+        out_rgb, depth, normal, acc, weights, alpha = neus_render(
+            sdf, grad, rgb, self.field.deviation_network.variance, ray_samples.flat_directions, ray_samples.flat_starts,
+            ray_samples.flat_ends, self.field._cos_anneal_ratio, bg)
+        field_outputs = {
+            FieldHeadNames.RGB: rgb, FieldHeadNames.SDF: sdf[..., None], FieldHeadNames.GRADIENT: grad,
+            FieldHeadNames.ALPHA: alpha[..., None], "points_norm": x.norm(dim=-1, keepdim=True), "sampled_sdf": None,
+        }
+        weights_list.append(weights[..., None])
+        ray_samples_list.append(ray_samples)
+        return {
+            "ray_samples": ray_samples, "field_outputs": field_outputs, "weights": weights[..., None],
+            "weights_list": weights_list, "ray_samples_list": ray_samples_list,
+            "rendered": (out_rgb, depth, normal, acc),
+        }
+
+    def get_outputs(self, ray_bundle: RayBundle) -> Dict:
+        """base_surface_model.py:292-365."""
+        so = self.sample_and_forward_field(ray_bundle)
+        rgb, depth, normal, acc = so["rendered"]
+        if not self.training:
+            rgb = rgb.clamp(0.0, 1.0)  # renderers.py:116-117
+        depth = depth[:, None]
+        if ray_bundle.directions_norm is not None:
+            depth = depth / ray_bundle.directions_norm  # base_surface_model.py:303
+        outputs = {
+            "rgb": rgb, "accumulation": acc[:, None], "depth": depth, "normal": normal, "weights": so["weights"],
+            "directions_norm": ray_bundle.directions_norm,
+        }
+        if self.training:
+            outputs.update({"eik_grad": so["field_outputs"][FieldHeadNames.GRADIENT],
+                            "points_norm": so["field_outputs"]["points_norm"]})
+            outputs.update(so)
+        outputs["normal_vis"] = (normal + 1.0) / 2.0
+        return outputs
+
+    def forward(self, ray_bundle: RayBundle) -> Dict:
+        """models/base_model.py:131-142."""
+        return self.get_outputs(self.collide(ray_bundle))
+
+    def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, torch.Tensor]:
+        """base_surface_model.py:399-437 (rgb, eikonal, fg mask, mono normal) + neus_facto.py:304-310 (interlevel)."""
+        c = self.config
+        image = batch["image"].to(outputs["rgb"].device)
+        loss = {"rgb_loss": F.l1_loss(image, outputs["rgb"])}
+        if self.training:
+            g = outputs["eik_grad"]
+            loss["eikonal_loss"] = ((g.norm(2, dim=-1) - 1) ** 2).mean() * c.eikonal_loss_mult
+            if "fg_mask" in batch and c.fg_mask_loss_mult > 0.0:
+                fg = batch["fg_mask"].float().to(image.device)
+                wsum = outputs["weights"].sum(dim=1).clip(1e-3, 1.0 - 1e-3)
+                loss["fg_mask_loss"] = F.binary_cross_entropy(wsum, fg) * c.fg_mask_loss_mult
+            if "normal" in batch and c.mono_normal_loss_mult > 0.0:
+                n_gt = F.normalize(batch["normal"].to(image.device), p=2, dim=-1)  # losses.py:264-275
+                n_pr = F.normalize(outputs["normal"], p=2, dim=-1)
+                l1 = torch.abs(n_pr - n_gt).sum(dim=-1).mean()
+                cos = (1.0 - torch.sum(n_pr * n_gt, dim=-1)).mean()
+                loss["normal_loss"] = (l1 + cos) * c.mono_normal_loss_mult
+            weights = [w[..., 0] for w in outputs["weights_list"]]
+            bins = [rs.flat_bins for rs in outputs["ray_samples_list"]]
+            loss["interlevel_loss"] = c.interlevel_loss_mult * interlevel_loss_zip(weights, bins)
+        return loss
+
+    def get_metrics_dict(self, outputs, batch) -> Dict[str, torch.Tensor]:
+        image = batch["image"].to(outputs["rgb"].device)
+        mse = F.mse_loss(outputs["rgb"], image)
+        return {"psnr": -10.0 * torch.log10(mse)}

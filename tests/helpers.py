@@ -1,0 +1,114 @@
+"""Shared test plumbing: golden loading, oracle <-> product parameter mapping, error reporting."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+from oracle import sdf_path as O  # noqa: E402
+
+
+def load_golden(mode: str):
+    z = np.load(os.path.join(GOLDEN, f"neus_facto_small_{mode}.npz"))
+    out = {"in": {}, "param": {}, "out": {}, "loss": {}, "grad": {}}
+    for k in z.files:
+        head, name = k.split("/", 1)
+        out[head][name] = torch.from_numpy(z[k])
+    return out
+
+
+def small_oracle_cfg() -> O.ModelCfg:
+    f = O.FieldCfg(
+        num_layers=8, hidden_dim=64, geo_feat_dim=64, num_layers_color=4, hidden_dim_color=64, bias=0.5,
+        inside_outside=False, use_grid_feature=True, beta_init=0.3, num_levels=8, max_res=128, base_res=4,
+        log2_hashmap_size=11, hash_features_per_level=2, hash_smoothstep=True,
+    )
+    props = (
+        O.ProposalCfg(hidden_dim=16, num_levels=5, max_res=32, base_res=4, log2_hashmap_size=9),
+        O.ProposalCfg(hidden_dim=16, num_levels=5, max_res=64, base_res=4, log2_hashmap_size=9),
+    )
+    return O.ModelCfg(field=f, proposals=props, num_proposal_samples=(32, 24), num_neus_samples=16)
+
+
+def report(name, got, ref, rtol, atol):
+    """Returns (ok, message) comparing got with ref under |d| <= atol + rtol * max|ref|."""
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    assert got.shape == ref.shape, f"{name}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
+    if got.numel() == 0:
+        return True, f"{name}: empty"
+    d = (got - ref).abs()
+    scale = ref.abs().max().item()
+    err = d.max().item()
+    idx = int(d.argmax())
+    ok = bool(torch.isfinite(got).all()) and err <= atol + rtol * scale
+    return ok, (f"{name}: max|d|={err:.3e} (scale {scale:.3e}, rel {err / (scale + 1e-30):.2e}) at flat {idx}: "
+                f"got {got.reshape(-1)[idx].item():.8g} ref {ref.reshape(-1)[idx].item():.8g}; tol {atol + rtol * scale:.2e}")
+
+
+def assert_close(name, got, ref, rtol=1e-4, atol=1e-6):
+    ok, msg = report(name, got, ref, rtol, atol)
+    print(("PASS " if ok else "FAIL ") + msg)
+    assert ok, msg
+
+
+def product_model_from_params(params, cfg: O.ModelCfg, device, field_kwargs=None):
+    """Build sdfstudio_amd's NeuSFactoModel with the given (oracle-named) parameters."""
+    from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
+    from sdfstudio_amd.models.neus_facto import NeuSFactoModel, NeuSFactoModelConfig, SceneBox
+
+    fc = cfg.field
+    fcfg = SDFFieldConfig(
+        num_layers=fc.num_layers, hidden_dim=fc.hidden_dim, geo_feat_dim=fc.geo_feat_dim,
+        num_layers_color=fc.num_layers_color, hidden_dim_color=fc.hidden_dim_color, bias=fc.bias,
+        inside_outside=fc.inside_outside, use_grid_feature=True, beta_init=fc.beta_init, num_levels=fc.num_levels,
+        max_res=fc.max_res, base_res=fc.base_res, log2_hashmap_size=fc.log2_hashmap_size,
+        hash_features_per_level=fc.hash_features_per_level, hash_smoothstep=fc.hash_smoothstep,
+        use_appearance_embedding=fc.use_appearance_embedding, **(field_kwargs or {}),
+    )
+    mcfg = NeuSFactoModelConfig(
+        sdf_field=fcfg, num_proposal_samples_per_ray=tuple(cfg.num_proposal_samples),
+        num_neus_samples_per_ray=cfg.num_neus_samples, num_proposal_iterations=len(cfg.proposals),
+        proposal_net_args_list=[
+            {"hidden_dim": p.hidden_dim, "log2_hashmap_size": p.log2_hashmap_size, "num_levels": p.num_levels,
+             "max_res": p.max_res, "base_res": p.base_res} for p in cfg.proposals
+        ],
+        eikonal_loss_mult=cfg.eikonal_loss_mult, interlevel_loss_mult=cfg.interlevel_loss_mult,
+    )
+    box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=cfg.near, far=cfg.far)
+    model = NeuSFactoModel(mcfg, box, num_train_data=49)
+    load_params(model, params)
+    return model.to(device)
+
+
+def load_params(model, params):
+    sd = model.state_dict()
+    for k, v in params.items():
+        if k.startswith("proposal_networks."):
+            i, name = k.split(".")[1:3]
+            key = f"proposal_networks.{i}.mlp_base.{name}"
+        else:
+            key = f"field.{k}"
+        assert key in sd, f"{key} missing from the product model"
+        assert tuple(sd[key].shape) == tuple(v.shape), (key, tuple(sd[key].shape), tuple(v.shape))
+        sd[key] = v.clone()
+    model.load_state_dict(sd)
+
+
+def product_grads(model):
+    """Gradients keyed by oracle names."""
+    out = {}
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        if k.startswith("field."):
+            out[k[len("field."):]] = p.grad.detach()
+        elif k.startswith("proposal_networks."):
+            i = k.split(".")[1]
+            out[f"proposal_networks.{i}.{k.split('.')[-1]}"] = p.grad.detach()
+    return out

@@ -1,0 +1,181 @@
+"""CPU suite (-m "not gpu"): the oracle against the committed golden vectors (minted from the reference's own Python),
+the C-ABI library (loads, exports every declared symbol, host-only entry points), and host-side logic."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROOT, assert_close, load_golden, small_oracle_cfg
+from oracle import hashgrid, sdf_path as O
+
+OUT_KEYS = ["starts", "ends", "bins", "sdf", "gradient", "field_rgb", "alpha", "density", "field_normal", "points_norm",
+            "weights", "rgb", "normal", "accumulation", "prop_weights0", "prop_weights1"]
+
+
+def _oracle_run(g, training):
+    cfg = small_oracle_cfg()
+    p = {k: v.clone().requires_grad_(v.is_floating_point() and k != "laplace_density.beta_min") for k, v in g["param"].items()}
+    rand = [g["in"][f"rand{i}"] for i in range(3)] if training else None
+    o = O.neus_facto_forward(g["in"]["origins"], g["in"]["dirs"], g["in"]["cam"], p, cfg, anneal=float(g["in"]["anneal"]),
+                             cos_anneal_ratio=float(g["in"]["cos_anneal"]), rand=rand, training=training)
+    return cfg, p, o
+
+
+def _omap(o):
+    f = o["field"]
+    return {"starts": o["starts"], "ends": o["ends"], "bins": o["bins"], "sdf": f["sdf"], "gradient": f["gradient"],
+            "field_rgb": f["rgb"], "alpha": f["alpha"], "density": f["density"], "field_normal": f["normal"],
+            "points_norm": f["points_norm"], "weights": o["weights"], "rgb": o["rgb"], "depth": o["depth"],
+            "normal": o["normal"], "accumulation": o["accumulation"], "prop_weights0": o["weights_list"][0],
+            "prop_weights1": o["weights_list"][1]}
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_oracle_reproduces_reference_golden_outputs(mode):
+    g = load_golden(mode)
+    _, _, o = _oracle_run(g, mode == "train")
+    m = _omap(o)
+    if mode == "eval":
+        m["rgb"] = m["rgb"].clamp(0, 1)
+    for k in OUT_KEYS:
+        assert_close(k, m[k], g["out"][k], rtol=2e-5, atol=1e-6)
+    assert_close("depth", m["depth"], g["out"]["depth"], rtol=1e-4, atol=1e-6)  # / accumulation: ill-conditioned on empty rays
+
+
+def test_oracle_reproduces_reference_golden_gradients():
+    g = load_golden("train")
+    cfg, p, o = _oracle_run(g, True)
+    losses = O.neus_facto_loss(o, g["in"]["image"], cfg)
+    for k, v in g["loss"].items():
+        assert abs(losses[k].item() - v.item()) <= 1e-5 * abs(v.item()) + 1e-8, k
+    sum(losses.values()).backward()
+    assert len(g["grad"]) >= 30
+    for k, ref in g["grad"].items():
+        assert_close(f"grad {k}", p[k].grad, ref, rtol=1e-3, atol=1e-9)
+
+
+def test_oracle_known_answers_from_reference_tests():
+    # reference tests/cameras/test_rays.py:11-30: frustum position = origin + dir * (start+end)/2 -> [0, 3.5, 2]... restated
+    o, d = torch.tensor([[0.0, 1.0, 2.0]]), torch.tensor([[0.0, 1.0, 0.0]])
+    mid = o + d * ((torch.tensor([2.0]) + torch.tensor([3.0])) / 2)
+    assert torch.allclose(mid, torch.tensor([[0.0, 3.5, 2.0]]))
+    # reference tests/model_components/test_renderers.py:10-25: uniform weights, ones -> ~1, zeros -> ~0
+    w = torch.full((4, 10), 0.1)
+    rgb, _, _, acc = O.render(w, torch.ones(4, 10, 3), torch.zeros(4, 10, 3), torch.zeros(4, 10), torch.ones(4, 10))
+    assert rgb.max() > 0.9 and torch.allclose(acc, torch.ones(4))
+    rgb0, _, _, _ = O.render(w, torch.zeros(4, 10, 3), torch.zeros(4, 10, 3), torch.zeros(4, 10), torch.ones(4, 10))
+    assert rgb0.abs().max() < 1e-6
+    # reference tests/field_components/test_encodings.py:28-50: NeRFEncoding out dim and range
+    enc = O.nerf_encoding(torch.rand(5, 3), 6, include_input=False)
+    assert enc.shape == (5, 36) and enc.max() <= 1 and enc.min() >= -1
+
+
+def test_oracle_properties():
+    torch.manual_seed(0)
+    a = torch.rand(16, 32)
+    w, T = O.weights_from_alphas(a)
+    assert (w >= 0).all() and (w.sum(1) <= 1 + 1e-5).all() and torch.allclose(T[:, 0], torch.ones(16))
+    sd = torch.linspace(-1, 1, 101)
+    dens = O.laplace_density(sd, torch.tensor(0.1))
+    assert (dens[1:] <= dens[:-1] + 1e-6).all()  # monotone in -sdf
+    bins = O.pdf_sample(torch.rand(8, 20), torch.linspace(0, 1, 21)[None].expand(8, -1).contiguous(), 12, None)
+    assert (bins[:, 1:] >= bins[:, :-1]).all() and bins.min() >= 0 and bins.max() <= 1
+    # eikonal ~ 1 at geometric init (sphere of radius bias)
+    cfg = O.FieldCfg(num_layers=8, hidden_dim=256, geo_feat_dim=32, num_levels=4, log2_hashmap_size=8, base_res=4, max_res=16)
+    p = O.init_field_params(cfg)
+    x = (torch.rand(256, 3) * 2 - 1) * 0.8
+    sdf, _, g = O.sdf_and_gradient(x, p, cfg, create_graph=False)
+    assert (g.norm(dim=-1) - 1).abs().mean() < 0.2
+    assert (sdf - (x.norm(dim=-1) - cfg.bias)).abs().mean() < 0.2
+
+
+# ---------------------------------------------------------------------------------------------- C ABI
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "sdfhip.h")).read()
+    return sorted(set(re.findall(r"\b(sdfhip_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_abi_library_exports_every_declared_symbol():
+    from sdfstudio_amd import _lib
+
+    assert os.path.exists(_lib.LIB_PATH), "libsdfhip.so has not been built (python -m sdfstudio_amd.build)"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in include/sdfhip.h but not exported"
+    assert set(_lib.exported_symbols()) == set(declared), "the ctypes binding and the header disagree"
+    assert _lib.load().sdfhip_version() >= 100
+
+
+def test_abi_grid_levels_match_oracle():
+    from sdfstudio_amd import _lib
+
+    for (L, F, T, base, mx, smooth) in [(16, 2, 19, 16, 2048, True), (8, 2, 11, 4, 128, True), (5, 2, 17, 16, 64, False),
+                                        (5, 2, 17, 16, 256, False), (5, 2, 9, 4, 32, False)]:
+        growth = float(np.exp((np.log(mx) - np.log(base)) / (L - 1)))
+        lv = hashgrid.make_levels(L, F, T, base, growth, smooth)
+        levels, n = _lib.grid_levels(_lib.GridCfg(L, F, T, base, growth, int(smooth)))
+        assert n == lv.n_entries
+        for i, l in enumerate(levels):
+            assert l.resolution == lv.resolution[i] and l.size == lv.size[i] and l.offset == lv.offset[i]
+            assert bool(l.hashed) == bool(lv.hashed[i])
+            assert abs(l.scale - float(lv.scale[i])) <= 1e-6 * abs(float(lv.scale[i]))
+    # BASELINE config 2/3: 5 dense + 11 hashed levels, 12.2 M parameters
+    growth = float(np.exp((np.log(2048) - np.log(16)) / 15))
+    levels, n = _lib.grid_levels(_lib.GridCfg(16, 2, 19, 16, growth, 1))
+    assert sum(1 for l in levels if not l.hashed) == 5 and n * 2 == 12196240
+
+
+def test_abi_rejects_bad_arguments_loudly():
+    from sdfstudio_amd import _lib
+
+    lib = _lib.load()
+    bad = _lib.GridCfg(40, 2, 19, 16, 1.38, 1)
+    rc = lib.sdfhip_grid_levels(ctypes.byref(bad), None, None)
+    assert rc != 0 and b"n_levels" in lib.sdfhip_last_error()
+    with pytest.raises(_lib.SdfHipError):
+        _lib.ptr(torch.zeros(4))  # CPU tensor: there is no CPU fallback
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "sdfstudio_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+
+
+def test_host_model_structure_matches_reference_parameter_names():
+    from helpers import product_model_from_params
+
+    g = load_golden("train")
+    model = product_model_from_params(g["param"], small_oracle_cfg(), torch.device("cpu"))
+    names = dict(model.named_parameters())
+    for k in g["grad"]:
+        if k.startswith("proposal_networks."):
+            continue
+        assert f"field.{k}" in names, k
+    groups = model.get_param_groups()
+    assert set(groups) == {"fields", "field_background", "proposal_networks"}
+    # the weight-norm fold used for the flat effective parameter vector == torch's weight_norm
+    lin = model.field.glin3
+    w = torch._weight_norm(lin.weight_v, lin.weight_g, 0)
+    assert torch.allclose(w, O.fold_weight_norm(lin.weight_v, lin.weight_g), atol=1e-7)
+    assert model.field._theta().numel() == sum(
+        getattr(model.field, n).weight_v.numel() + getattr(model.field, n).bias.numel() for n in model.field._lin_names)
+
+
+def test_interlevel_loss_host_matches_oracle():
+    from sdfstudio_amd.model_components.losses import interlevel_loss_zip
+
+    torch.manual_seed(1)
+    bins = [torch.sort(torch.rand(6, s + 1), dim=-1)[0] for s in (32, 24, 16)]
+    ws = [torch.rand(6, s).requires_grad_(True) for s in (32, 24, 16)]
+    a = interlevel_loss_zip(ws, bins)
+    b = O.interlevel_loss_zip(ws, bins)
+    assert abs(a.item() - b.item()) <= 1e-6 * abs(b.item())
