@@ -1,0 +1,244 @@
+"""bench.py — NeuS-facto training throughput of the sdfhip hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one full training iteration of BASELINE config 2 on every rank: draw 4096 rays, proposal sampling
+(256 + 96 proposal samples, two proposal fields), 128 SDF-field samples per ray through hash grid + 8x256 geometry MLP
+(+ analytic normal) + 4x256 colour MLP, NeuS alpha compositing, L1 + eikonal + interlevel losses, full backward
+(including the second-order terms), one RCCL all-reduce of the flat gradient buffer when N > 1, Adam step.
+Inputs are synthetic (DTU-scan65-like cameras) and already resident in HBM.
+
+Rank 0 prints ONE JSON line.  `value` = whole-job field ray-samples per second (N * 4096 * 128 / step time).
+`roofline` is for the dominant kernel (geo_bwd_kernel: tangent + data backward of the geometry MLP), with its launch
+time measured live by HIP events recorded on the launch stream inside the timed region (sdfhip_profile_*).
+`cpu_baseline` times the CPU oracle (a port of the reference's PyTorch path) on this host for a bounded sample.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_RAYS = 4096
+N_SAMPLES = 128
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, f32 in / f32 accumulate
+PEAK_HBM_GBS = 8000.0
+
+
+def synthetic_cameras(device):
+    """49 pinhole cameras, 384x384, fx=925.5 fy=922.6 cx=199.4 cy=198.1, centres on a sphere of radius 2.73 looking at
+    the origin (docs/sdfstudio-data.md:26-88 scan65 meta)."""
+    k = torch.arange(49, dtype=torch.float64)
+    phi = k * 2.399963229728653
+    z = 0.15 + 0.7 * (k + 0.5) / 49
+    r = torch.sqrt(1 - z * z)
+    centers = torch.stack([r * torch.cos(phi), r * torch.sin(phi), z], dim=-1) * 2.73
+    fwd = -centers / centers.norm(dim=-1, keepdim=True)
+    up = torch.tensor([0.0, 0.0, 1.0], dtype=torch.float64).expand_as(fwd)
+    right = torch.cross(fwd, up, dim=-1)
+    right = right / right.norm(dim=-1, keepdim=True)
+    down = torch.cross(fwd, right, dim=-1)
+    rot = torch.stack([right, down, fwd], dim=-1)  # camera-to-world columns (x right, y down, z forward)
+    return centers.float().to(device), rot.float().to(device)
+
+
+def draw_rays(centers, rot, n, gen):
+    """Uniform random (camera, y, x) as pixel_samplers.py:47-50, then pinhole ray directions."""
+    dev = centers.device
+    u = torch.rand(n, 3, device=dev, generator=gen)
+    cam = (u[:, 0] * 49).long().clamp_(max=48)
+    y = (u[:, 1] * 384).floor() + 0.5
+    x = (u[:, 2] * 384).floor() + 0.5
+    d_cam = torch.stack([(x - 199.4) / 925.5, (y - 198.1) / 922.6, torch.ones_like(x)], dim=-1)
+    d = torch.einsum("nij,nj->ni", rot[cam], d_cam)
+    norm = d.norm(dim=-1, keepdim=True)
+    return centers[cam].contiguous(), (d / norm).contiguous(), norm, cam
+
+
+def build_model(device):
+    from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
+    from sdfstudio_amd.models.neus_facto import NeuSFactoModel, NeuSFactoModelConfig, SceneBox
+
+    torch.manual_seed(0)
+    fcfg = SDFFieldConfig(num_layers=8, hidden_dim=256, geo_feat_dim=256, num_layers_color=4, hidden_dim_color=256, bias=0.5,
+                          inside_outside=False, use_grid_feature=True, beta_init=0.3, num_levels=16, max_res=2048, base_res=16,
+                          log2_hashmap_size=19, hash_features_per_level=2, hash_smoothstep=True)
+    mcfg = NeuSFactoModelConfig(sdf_field=fcfg, num_proposal_samples_per_ray=(256, 96), num_neus_samples_per_ray=N_SAMPLES,
+                                background_model="none")
+    box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=0.5, far=4.5)
+    return NeuSFactoModel(mcfg, box, num_train_data=49).to(device).train()
+
+
+def flops_per_sample():
+    """SURVEY.md section 8 FLOP bookkeeping (2 x MACs): geometry MLP G, colour MLP C; training step = 6G + 3C."""
+    g = 2 * (71 * 256 + 2 * 256 * 256 + 256 * 185 + 4 * 256 * 256 + 256 * 257)
+    c = 2 * (321 * 256 + 3 * 256 * 256 + 256 * 3)
+    return g, c
+
+
+def cpu_baseline():
+    """The CPU oracle (oracle/sdf_path.py: PyTorch port of the reference path, pinned against the reference's own Python)
+    timed on this host: same network / sampler configuration, a bounded batch of rays, full training step with Adam."""
+    from oracle import sdf_path as O
+
+    torch.set_float32_matmul_precision("highest")
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.ModelCfg(field=O.FieldCfg(bias=0.5, inside_outside=False, beta_init=0.3), num_neus_samples=N_SAMPLES)
+    p = O.init_field_params(cfg.field, seed=0)
+    p.update(O.init_proposal_params(cfg.proposals))
+    for k, v in p.items():
+        if v.is_floating_point() and k != "laplace_density.beta_min":
+            v.requires_grad_(True)
+    opt = torch.optim.Adam([v for v in p.values() if v.requires_grad], lr=5e-4, eps=1e-15)
+    n = 256
+    o, d, cam = O.synthetic_rays(n, seed=1)
+    image = torch.rand(n, 3)
+
+    def step():
+        rand = [torch.rand(n, 1) for _ in range(3)]
+        out = O.neus_facto_forward(o, d, cam, p, cfg, anneal=1.0, cos_anneal_ratio=1.0, rand=rand, training=True)
+        loss = sum(O.neus_facto_loss(out, image, cfg).values())
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+
+    step()
+    t0 = time.perf_counter()
+    iters = 0
+    while iters < 3 or (time.perf_counter() - t0 < 10.0 and iters < 50):
+        step()
+        iters += 1
+    dt = (time.perf_counter() - t0) / iters
+    return {"value": n * N_SAMPLES / dt, "unit": "ray-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{iters} training iterations of {n} rays x {N_SAMPLES} samples (same networks, samplers, losses, Adam); "
+                      f"{dt * 1e3:.0f} ms/iter"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the sdfhip path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+
+    from sdfstudio_amd import _lib
+    from sdfstudio_amd.cameras.rays import RayBundle
+    from sdfstudio_amd.distributed import FlatGradients, broadcast_parameters
+
+    model = build_model(device)
+    broadcast_parameters(model)
+    groups = model.get_param_groups()
+    flat = FlatGradients([p for g in groups.values() for p in g])
+    # optimizers as method_configs.py:483-500 (neus-facto): Adam lr 5e-4 (fields) / 1e-2 (proposal networks), eps 1e-15
+    opts = [torch.optim.Adam(groups["fields"], lr=5e-4, eps=1e-15, fused=True),
+            torch.optim.Adam(groups["proposal_networks"], lr=1e-2, eps=1e-15, fused=True)]
+    centers, rot = synthetic_cameras(device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(42 + rank)  # base_config.py:74 + scripts/train.py:86: seed + global rank
+
+    def step(i):
+        model.before_train_iteration(i)
+        o, d, norm, cam = draw_rays(centers, rot, N_RAYS, gen)
+        image = torch.rand(N_RAYS, 3, device=device, generator=gen)
+        rb = RayBundle(origins=o, directions=d, directions_norm=norm, camera_indices=cam[:, None])
+        out = model(rb)
+        loss = sum(model.get_loss_dict(out, {"image": image}).values())
+        flat.zero()
+        loss.backward()
+        flat.all_reduce_mean()
+        for opt in opts:
+            opt.step()
+        model.after_train_iteration(i)
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    _lib.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    prof = _lib.profile_collect()
+    _lib.profile_enable(False)
+    assert math.isfinite(float(loss)), "training diverged"
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        samples = world * N_RAYS * N_SAMPLES
+        value = samples / (dt / args.steps)
+        g, c = flops_per_sample()
+        P = N_RAYS * N_SAMPLES
+        # dominant kernel: geo_bwd_kernel = tangent pass (G) + data backward (G): 2G flop per sample, one launch per step
+        kt_ms, kn = prof.get("geo_bwd_kernel", (0.0, 0))
+        roof = None
+        if kn > 0:
+            avg_s = kt_ms / kn * 1e-3
+            achieved = 2 * g * P / avg_s / 1e12
+            roof = {"kernel": "geo_bwd_kernel", "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "avg_launch_ms": round(kt_ms / kn, 4), "launches": kn,
+                    "algorithmic": f"2G = {2 * g} flop per ray-sample x {P} ray-samples per launch"}
+        kernels = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] / args.steps} for k, v in prof.items()}
+        mfma_ms = sum(prof.get(k, (0.0, 0))[0] for k in ("geo_fwd_kernel", "geo_bwd_kernel", "col_fwd_kernel", "col_bwd_kernel",
+                                                         "wgrad_kernel")) / args.steps
+        line = {
+            "metric": "ray-samples/sec (NeuS-facto train step, 4096 rays x 128 samples per GPU)",
+            "value": round(value, 1), "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "iters_per_sec": round(1e3 / ms, 3), "per_gpu": round(value / world, 1),
+            "config": {"workload": "BASELINE config 2: NeuS-facto hash-grid 16x2x2^19 smoothstep + 8x256 geo MLP + 4x256 colour MLP, "
+                                   "4096 rays x 128 samples (+256/96 proposal samples) per GPU per step, full train step incl. Adam",
+                       "rays_per_gpu": N_RAYS, "samples_per_ray": N_SAMPLES,
+                       "parallelism": f"dp{world} (flat-gradient RCCL all-reduce)" if world > 1 else "single GPU"},
+            "roofline": roof,
+            "model_tflops": round((6 * g + 3 * c) * P / (ms * 1e-3) / 1e12, 2),
+            "mfma_kernels_ms_per_step": round(mfma_ms, 3),
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -77,6 +77,9 @@ _SIGNATURES = {
                                                 ctypes.c_void_p]),
     "sdfhip_neus_render_forward": (c_i32, [c_float_p] * 8 + [c_f32, c_i64, c_i32] + [c_float_p] * 8 + [ctypes.c_void_p]),
     "sdfhip_neus_render_backward": (c_i32, [c_float_p] * 8 + [c_f32, c_i64, c_i32] + [c_float_p] * 14 + [ctypes.c_void_p]),
+    "sdfhip_profile_enable": (c_i32, [c_i32]),
+    "sdfhip_profile_name": (ctypes.c_char_p, [c_i32]),
+    "sdfhip_profile_read": (c_i32, [c_i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
 }
 
 _lib: Optional[ctypes.CDLL] = None
@@ -141,3 +144,20 @@ def grid_levels(cfg: GridCfg):
     n = c_i64(0)
     check(lib.sdfhip_grid_levels(ctypes.byref(cfg), levels, ctypes.byref(n)), "sdfhip_grid_levels")
     return list(levels), int(n.value)
+
+
+def profile_enable(on: bool) -> int:
+    return load().sdfhip_profile_enable(1 if on else 0)
+
+
+def profile_collect():
+    lib = load()
+    out = {}
+    n_slots = 17
+    for slot in range(n_slots):
+        ms = ctypes.c_double(0.0)
+        cnt = c_i64(0)
+        check(lib.sdfhip_profile_read(slot, ctypes.byref(ms), ctypes.byref(cnt)), "profile_read")
+        if cnt.value > 0:
+            out[lib.sdfhip_profile_name(slot).decode()] = (ms.value, int(cnt.value))
+    return out

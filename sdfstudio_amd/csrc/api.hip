@@ -25,6 +25,65 @@ extern "C" int sdfhip_version(void) { return 100; }
 extern "C" const char* sdfhip_last_error(void) { return g_err; }
 extern "C" int64_t sdfhip_padded_points(int64_t n) { return (n + 127) / 128 * 128; }
 
+
+// ------------------------------------------------------------------------------------------------ kernel timing (bench)
+// HIP events around selected launches, on the stream the kernel is launched on.  Disabled by default.
+enum ProfSlot {
+  PS_PACK = 0, PS_ENCODE, PS_GEO_FWD, PS_ASSEMBLE, PS_COL_FWD, PS_COL_BWD, PS_BWD_PREP, PS_GEO_BWD, PS_GRID_BWD, PS_WGRAD,
+  PS_WREDUCE, PS_PROP_FWD, PS_PROP_BWD, PS_RENDER_FWD, PS_RENDER_BWD, PS_DENSITY_W, PS_SAMPLERS, PS_COUNT
+};
+static const char* kProfNames[PS_COUNT] = {
+    "pack_kernel", "geo_encode_kernel", "geo_fwd_kernel", "grad_assemble_kernel", "col_fwd_kernel", "col_bwd_kernel",
+    "bwd_prep_kernel", "geo_bwd_kernel", "grid_bwd_kernel", "wgrad_kernel", "wreduce_kernel", "prop_fwd_kernel",
+    "prop_bwd_kernel", "neus_render_fwd_kernel", "neus_render_bwd_kernel", "density_weights_kernels", "sampler_kernels"};
+struct ProfState {
+  bool enabled = false;
+  std::vector<hipEvent_t> start[PS_COUNT], stop[PS_COUNT];
+  size_t used[PS_COUNT] = {};
+};
+static ProfState g_prof;
+struct ProfScope {
+  int slot;
+  hipStream_t s;
+  bool on;
+  ProfScope(int slot_, hipStream_t s_) : slot(slot_), s(s_), on(g_prof.enabled) {
+    if (!on) return;
+    if (g_prof.used[slot] == g_prof.start[slot].size()) {
+      hipEvent_t a, b;
+      (void)hipEventCreate(&a);
+      (void)hipEventCreate(&b);
+      g_prof.start[slot].push_back(a);
+      g_prof.stop[slot].push_back(b);
+    }
+    (void)hipEventRecord(g_prof.start[slot][g_prof.used[slot]], s);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(g_prof.stop[slot][g_prof.used[slot]], s);
+    g_prof.used[slot]++;
+  }
+};
+extern "C" int sdfhip_profile_enable(int enable) {
+  g_prof.enabled = enable != 0;
+  for (int i = 0; i < PS_COUNT; ++i) g_prof.used[i] = 0;
+  return PS_COUNT;
+}
+extern "C" const char* sdfhip_profile_name(int slot) { return (slot >= 0 && slot < PS_COUNT) ? kProfNames[slot] : ""; }
+// total milliseconds and number of timed launches (scopes) recorded for a slot since the last enable; waits for them.
+extern "C" int sdfhip_profile_read(int slot, double* total_ms, int64_t* count) {
+  SDFHIP_REQUIRE(slot >= 0 && slot < PS_COUNT && total_ms && count, "profile_read: bad argument");
+  double t = 0.0;
+  for (size_t i = 0; i < g_prof.used[slot]; ++i) {
+    float ms = 0.0f;
+    SDFHIP_CHECK_HIP(hipEventSynchronize(g_prof.stop[slot][i]));
+    SDFHIP_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.start[slot][i], g_prof.stop[slot][i]));
+    t += ms;
+  }
+  *total_ms = t;
+  *count = (int64_t)g_prof.used[slot];
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ grid descriptor
 extern "C" int sdfhip_grid_levels(const SdfHipGridCfg* cfg, SdfHipGridLevel* levels, int64_t* n_entries) {
   SDFHIP_REQUIRE(cfg != nullptr, "grid cfg is null");
@@ -385,9 +444,9 @@ extern "C" int64_t sdfhip_field_workspace_size(const SdfHipField* f, int64_t n_p
 extern "C" int sdfhip_field_pack(const SdfHipField* f, const float* theta, float* packed, sdfhip_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   dim3 g1((f->max_pack_elems + 255) / 256, (unsigned)f->pack.size());
-  pack_kernel<<<g1, 256, 0, s>>>(theta, f->d_pack, f->d_maps, packed);
+  { ProfScope ps_(PS_PACK, s); pack_kernel<<<g1, 256, 0, s>>>(theta, f->d_pack, f->d_maps, packed);
   dim3 g2((f->max_vec_n + 255) / 256, (unsigned)f->vec.size());
-  packvec_kernel<<<g2, 256, 0, s>>>(theta, f->d_vec, f->d_maps, packed);
+  packvec_kernel<<<g2, 256, 0, s>>>(theta, f->d_vec, f->d_maps, packed); }
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -458,7 +517,7 @@ extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, c
   ea.x_out = w.x;
   ea.in0_tp = w.in0;
   ea.dydp = full ? w.dydp : nullptr;
-  geo_encode_kernel<<<dim3((unsigned)(NP / 256 + (NP % 256 != 0)), f->grid.n_levels + 1), 256, 0, s>>>(ea);
+  { ProfScope ps_(PS_ENCODE, s); geo_encode_kernel<<<dim3((unsigned)(NP / 256 + (NP % 256 != 0)), f->grid.n_levels + 1), 256, 0, s>>>(ea); }
 
   GeoFwdArgs ga;
   memset(&ga, 0, sizeof(ga));
@@ -472,7 +531,7 @@ extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, c
   ga.sdf = sdf;
   ga.e_tp = w.e;
   const unsigned grid = (unsigned)(NP / 128);
-  k->geo_fwd(full ? 0 : (mode == SDFHIP_MODE_GEO ? 1 : 2), ga, grid, s);
+  { ProfScope ps_(PS_GEO_FWD, s); k->geo_fwd(full ? 0 : (mode == SDFHIP_MODE_GEO ? 1 : 2), ga, grid, s); }
 
   if (full) {
     AssembleArgs aa;
@@ -494,7 +553,7 @@ extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, c
     aa.emb_dim = f->cfg.appearance_dim;
     aa.grad = grad;
     aa.csmall_tp = w.csmall;
-    grad_assemble_kernel<<<(unsigned)(NP / 256 + (NP % 256 != 0)), 256, 0, s>>>(aa);
+    { ProfScope ps_(PS_ASSEMBLE, s); grad_assemble_kernel<<<(unsigned)(NP / 256 + (NP % 256 != 0)), 256, 0, s>>>(aa); }
 
     ColFwdArgs ca;
     memset(&ca, 0, sizeof(ca));
@@ -503,7 +562,7 @@ extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, c
     ca.csmall_tp = w.csmall;
     for (int l = 0; l < k->nlc; ++l) ca.h_tp[l] = w.h[l];
     ca.rgb = w.rgb;  // kept for the backward's sigmoid derivative; the caller gets a copy
-    k->col_fwd(ca, grid, s);
+    { ProfScope ps_(PS_COL_FWD, s); k->col_fwd(ca, grid, s); }
     SDFHIP_CHECK_HIP(hipMemcpyAsync(rgb, w.rgb, (size_t)NP * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
   if (feat != nullptr && mode != SDFHIP_MODE_SDF) {
@@ -532,7 +591,7 @@ static void run_wgrad(const SdfHipField* f, const FieldWs& w, const WgradArgs& b
   a.tiles_per_split = (int)((a.n_tiles + w.n_split - 1) / w.n_split);
   a.partial = w.partial;
   a.bpartial = b_off >= 0 ? w.bpartial : nullptr;
-  wgrad_kernel<<<dim3((unsigned)w.n_split, (unsigned)(n_obg * a.n_ib_groups)), 64, 0, s>>>(a);
+  { ProfScope ps_(PS_WGRAD, s); wgrad_kernel<<<dim3((unsigned)w.n_split, (unsigned)(n_obg * a.n_ib_groups)), 64, 0, s>>>(a); }
   WreduceArgs r;
   memset(&r, 0, sizeof(r));
   r.partial = w.partial;
@@ -549,7 +608,7 @@ static void run_wgrad(const SdfHipField* f, const FieldWs& w, const WgradArgs& b
   r.b_off = b_off;
   r.accumulate = 0;
   const int total = r.rows * r.cols;
-  wreduce_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(r);
+  { ProfScope ps_(PS_WREDUCE, s); wreduce_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(r); }
 }
 
 extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
@@ -581,7 +640,7 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
   cb.dout_tp = w.dout;
   cb.featbar_tp = w.featbar;
   cb.csmallbar_tp = w.csmallbar;
-  k->col_bwd(cb, grid, s);
+  { ProfScope ps_(PS_COL_BWD, s); k->col_bwd(cb, grid, s); }
 
   // 2. total d L / d grad, tangent seed, padded sdfbar
   BwdPrepArgs pa;
@@ -605,7 +664,7 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
   pa.ebar_tp = w.ebar;
   pa.sdfbar = w.sdfbar;
   pa.embbar = emb_bar;
-  bwd_prep_kernel<<<pgrid, 256, 0, s>>>(pa);
+  { ProfScope ps_(PS_BWD_PREP, s); bwd_prep_kernel<<<pgrid, 256, 0, s>>>(pa); }
 
   // 3. geometry network: tangent pass + data backward
   GeoBwdArgs gb;
@@ -621,7 +680,7 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
   }
   for (int l = 1; l <= k->nl; ++l) gb.qb_tp[l] = w.qb[l];
   gb.in0bar_tp = w.in0bar;
-  k->geo_bwd(gb, grid, s);
+  { ProfScope ps_(PS_GEO_BWD, s); k->geo_bwd(gb, grid, s); }
 
   // 4. hash table gradient (first-order through the features + second-order through d feature / d x)
   GridBwdArgs ga;
@@ -636,7 +695,7 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
   ga.pe_degree = f->cfg.pe_degree;
   ga.nb0 = k->nb0;
   ga.tablebar = table_bar;
-  grid_bwd_kernel<<<dim3((unsigned)((P + 255) / 256), f->grid.n_levels), 256, 0, s>>>(ga);
+  { ProfScope ps_(PS_GRID_BWD, s); grid_bwd_kernel<<<dim3((unsigned)((P + 255) / 256), f->grid.n_levels), 256, 0, s>>>(ga); }
 
   // 5. weight gradients: split-K GEMMs over points
   const int64_t n_tiles = NP / 32;
@@ -694,7 +753,7 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
     a.B[0] = seg1(w.z[k->nl - 1], k->nbh, 1);
     run_wgrad(f, w, a, f->g_rowmap[k->nl], f->g_colmap[k->nl], li.w_off, li.in_dim, 1.0f, li.b_off, theta_bar, s);
     const int tps = (int)((n_tiles + w.n_split - 1) / w.n_split);
-    k->sdfrow(w.z[k->nl - 1], w.qb[k->nl], w.sdfbar, n_tiles, tps, w.partial, (unsigned)w.n_split, s);
+    { ProfScope ps_(PS_WGRAD, s); k->sdfrow(w.z[k->nl - 1], w.qb[k->nl], w.sdfbar, n_tiles, tps, w.partial, (unsigned)w.n_split, s); }
     const int stride = k->nbh * 32 + 32;
     sdfrow_reduce_kernel<<<(stride + 255) / 256, 256, 0, s>>>(w.partial, w.n_split, stride, f->cfg.hidden_dim, theta_bar + li.w_off,
                                                               theta_bar + li.b_off);
@@ -756,7 +815,7 @@ extern "C" int sdfhip_proposal_forward(const SdfHipGridCfg* grid, const float* t
   a.w2 = w2;
   a.density = density;
   if (a.n_points == 0) return 0;
-  prop_fwd_kernel<<<(unsigned)((a.n_points + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
+  { ProfScope ps_(PS_PROP_FWD, (hipStream_t)stream); prop_fwd_kernel<<<(unsigned)((a.n_points + 255) / 256), 256, 0, (hipStream_t)stream>>>(a); }
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -784,9 +843,9 @@ extern "C" int sdfhip_proposal_backward(const SdfHipGridCfg* grid, const float* 
   a.densbar = density_bar;
   a.tablebar = table_bar;
   a.wpartial = (float*)workspace;
-  prop_bwd_kernel<<<kPropBwdBlocks, 256, 0, s>>>(a);
-  colsum_kernel<<<1, 256, 0, s>>>(a.wpartial, kPropBwdBlocks, 160, w1_bar, 0);
-  colsum_kernel<<<1, 64, 0, s>>>(a.wpartial + 160, kPropBwdBlocks, 16, w2_bar, 0);
+  { ProfScope ps_(PS_PROP_BWD, s); prop_bwd_kernel<<<kPropBwdBlocks, 256, 0, s>>>(a); }
+  colsum_kernel<<<1, 256, 0, s>>>(a.wpartial, kPropBwdBlocks, 160, 176, w1_bar, 0);
+  colsum_kernel<<<1, 64, 0, s>>>(a.wpartial + 160, kPropBwdBlocks, 16, 176, w2_bar, 0);
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -806,7 +865,7 @@ extern "C" int sdfhip_sample_spaced(const float* nears, const float* fars, const
   a.ends = ends;
   const int64_t total = n_rays * (n_samples + 1);
   if (total == 0) return 0;
-  spaced_bins_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
+  { ProfScope ps_(PS_SAMPLERS, (hipStream_t)stream); spaced_bins_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(a); }
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -845,7 +904,7 @@ extern "C" int sdfhip_sample_pdf(const float* weights, const float* bins_in, con
   a.ends = ends;
   if (n_rays == 0) return 0;
   const unsigned grid = (unsigned)((n_rays + 3) / 4);
-  SDFHIP_DISPATCH_C(s_in, (pdf_sample_kernel<C><<<grid, 256, 0, (hipStream_t)stream>>>(a)));
+  { ProfScope ps_(PS_SAMPLERS, (hipStream_t)stream); SDFHIP_DISPATCH_C(s_in, (pdf_sample_kernel<C><<<grid, 256, 0, (hipStream_t)stream>>>(a))); }
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -865,7 +924,7 @@ extern "C" int sdfhip_density_weights_forward(const float* density, const float*
   a.weights = weights;
   if (n_rays == 0) return 0;
   const unsigned grid = (unsigned)((n_rays + 3) / 4);
-  SDFHIP_DISPATCH_C(n_samples, (density_weights_fwd_kernel<C><<<grid, 256, 0, (hipStream_t)stream>>>(a)));
+  { ProfScope ps_(PS_DENSITY_W, (hipStream_t)stream); SDFHIP_DISPATCH_C(n_samples, (density_weights_fwd_kernel<C><<<grid, 256, 0, (hipStream_t)stream>>>(a))); }
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -886,7 +945,7 @@ extern "C" int sdfhip_density_weights_backward(const float* density, const float
   a.densitybar = density_bar;
   if (n_rays == 0) return 0;
   const unsigned grid = (unsigned)((n_rays + 3) / 4);
-  SDFHIP_DISPATCH_C(n_samples, (density_weights_bwd_kernel<C><<<grid, 256, 0, (hipStream_t)stream>>>(a)));
+  { ProfScope ps_(PS_DENSITY_W, (hipStream_t)stream); SDFHIP_DISPATCH_C(n_samples, (density_weights_bwd_kernel<C><<<grid, 256, 0, (hipStream_t)stream>>>(a))); }
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -929,7 +988,7 @@ extern "C" int sdfhip_neus_render_forward(const float* sdf, const float* grad, c
   if (n_rays == 0) return 0;
   minmax_init_kernel<<<1, 1, 0, s>>>(steps_minmax);
   const unsigned grid = (unsigned)((n_rays + 3) / 4);
-  SDFHIP_DISPATCH_C(n_samples, (neus_render_fwd_kernel<C><<<grid, 256, 0, s>>>(a)));
+  { ProfScope ps_(PS_RENDER_FWD, s); SDFHIP_DISPATCH_C(n_samples, (neus_render_fwd_kernel<C><<<grid, 256, 0, s>>>(a))); }
   depth_clip_kernel<<<(unsigned)((n_rays + 255) / 256), 256, 0, s>>>(out_depth_raw, steps_minmax, (int)n_rays, out_depth);
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
@@ -975,7 +1034,7 @@ extern "C" int sdfhip_neus_render_backward(const float* sdf, const float* grad, 
   a.variancebar = variance_bar;
   if (n_rays == 0) return 0;
   const unsigned grid = (unsigned)((n_rays + 3) / 4);
-  SDFHIP_DISPATCH_C(n_samples, (neus_render_bwd_kernel<C><<<grid, 256, 0, (hipStream_t)stream>>>(a)));
+  { ProfScope ps_(PS_RENDER_BWD, (hipStream_t)stream); SDFHIP_DISPATCH_C(n_samples, (neus_render_bwd_kernel<C><<<grid, 256, 0, (hipStream_t)stream>>>(a))); }
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }

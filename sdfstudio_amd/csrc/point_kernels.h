@@ -42,7 +42,9 @@ SDFHIP_D void grid_cell(const GridLevelDev& L, const bool smooth, const float p[
   uint32_t g[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    const float pos = fmaf(L.scale, p[d], 0.5f);
+    // un-fused multiply-add on purpose: the parity oracle (oracle/hashgrid.py) evaluates x * scale + 0.5 with two fp32
+    // roundings; at scale ~2e3 a fused fma moves the interpolation weight by up to 1e-4
+    const float pos = __fadd_rn(__fmul_rn(L.scale, p[d]), 0.5f);
     const float fl = floorf(pos);
     const float f = pos - fl;
     g[d] = (uint32_t)(int)fl;
@@ -483,11 +485,11 @@ __global__ __launch_bounds__(256) void prop_bwd_kernel(const PropArgs a) {
 }
 
 // out[i] (+)= sum_k partial[k][i]
-__global__ void colsum_kernel(const float* __restrict__ partial, const int n_rows, const int n_cols, float* __restrict__ out,
-                              const int accumulate) {
+__global__ void colsum_kernel(const float* __restrict__ partial, const int n_rows, const int n_cols, const int row_stride,
+                              float* __restrict__ out, const int accumulate) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_cols) return;
   float s = 0.0f;
-  for (int k = 0; k < n_rows; ++k) s += partial[(size_t)k * n_cols + i];
+  for (int k = 0; k < n_rows; ++k) s += partial[(size_t)k * row_stride + i];
   out[i] = (accumulate ? out[i] : 0.0f) + s;
 }
