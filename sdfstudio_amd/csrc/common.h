@@ -41,24 +41,33 @@ SDFHIP_D void static_for(F&& f) {
   }
 }
 
-// ---- softplus(beta=100, threshold=20) and its derivatives, matching torch's CPU kernels
-// (aten softplus / softplus_backward / softplus_double_backward) used at sdf_field.py:365,409.
+// ---- softplus(beta=100, threshold=20) and its derivatives (aten softplus / softplus_backward / softplus_double_backward,
+// used at sdf_field.py:365,409) on the hardware transcendental unit: v_exp_f32 / v_log_f32 (base 2, 1 ulp) and v_rcp_f32.
+//   t = 100 z ; e = exp(t) ; h = log(1 + e) / 100 ; s'(z) = e / (1 + e) ; s''(z) = 100 s' (1 - s')
+// log(1 + e) is formed as log2(1 + e) ln2: for tiny e the rounding of 1 + e bounds the ABSOLUTE error of h by 6e-10, far
+// below the fp32 resolution of the next layer's accumulation.  A libm expf + log1pf + IEEE division here costs ~150 VALU
+// instructions per element and made the fused kernels instruction-fetch bound (profiles/r1_notes.md).
 SDFHIP_D void softplus100(float z, float& h, float& d1) {
   const float t = 100.0f * z;
-  if (t > 20.0f) {
-    h = z;
-    d1 = 1.0f;
-  } else {
-    const float e = expf(t);
-    h = log1pf(e) * 0.01f;
-    d1 = e / (e + 1.0f);
-  }
+  const float e = __builtin_amdgcn_exp2f(fminf(t, 20.0f) * 1.44269504088896340736f);
+  const float u = 1.0f + e;
+  const float hs = __builtin_amdgcn_logf(u) * (0.69314718055994530942f * 0.01f);
+  const float ds = e * __builtin_amdgcn_rcpf(u);
+  const bool lin = t > 20.0f;
+  h = lin ? z : hs;
+  d1 = lin ? 1.0f : ds;
 }
 SDFHIP_D float softplus100_d1(float z) {
   const float t = 100.0f * z;
-  if (t > 20.0f) return 1.0f;
-  const float e = expf(t);
-  return e / (e + 1.0f);
+  const float e = __builtin_amdgcn_exp2f(fminf(t, 20.0f) * 1.44269504088896340736f);
+  const float ds = e * __builtin_amdgcn_rcpf(1.0f + e);
+  return t > 20.0f ? 1.0f : ds;
+}
+SDFHIP_D float softplus100_h(float z) {
+  const float t = 100.0f * z;
+  const float e = __builtin_amdgcn_exp2f(fminf(t, 20.0f) * 1.44269504088896340736f);
+  const float hs = __builtin_amdgcn_logf(1.0f + e) * (0.69314718055994530942f * 0.01f);
+  return t > 20.0f ? z : hs;
 }
 
 // thread-local last-error string (extern "C" API returns 0 or a negative code)

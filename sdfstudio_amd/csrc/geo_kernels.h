@@ -84,9 +84,7 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
       if constexpr (SAVE || GRAD) tp_store_blk(acc[b], a.z_tp[l], tile, NBO, b, lane);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float h, d1;
-        softplus100(acc[b][r], h, d1);
-        H[b][r] = h;
+        H[b][r] = softplus100_h(acc[b][r]);
       }
     }
   });

@@ -85,9 +85,7 @@ SDFHIP_D f32x4 wg_load(const TpOperand& op, const int blk, const int64_t tile, c
   if (op.xf[seg] == 1) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float h, d1;
-      softplus100(v[i], h, d1);
-      v[i] = h;
+      v[i] = softplus100_h(v[i]);
     }
   }
   return v;
@@ -227,9 +225,7 @@ __global__ __launch_bounds__(64, 1) void sdfrow_grad_kernel(const float* __restr
       const float* qp = qb_last + ((size_t)tile * NBH + b) * 1024 + lane;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        float h, d1;
-        softplus100(zp[r * 64], h, d1);
-        acc[b][r] += fmaf(sb, h, qp[r * 64]);
+        acc[b][r] += fmaf(sb, softplus100_h(zp[r * 64]), qp[r * 64]);
       }
     }
   }
