@@ -586,12 +586,20 @@ __global__ void sdfrow_reduce_kernel(const float* __restrict__ partial, const in
 static void run_wgrad(const SdfHipField* f, const FieldWs& w, const WgradArgs& base, int rowmap, int colmap, int64_t w_off, int ld,
                       float scale, int64_t b_off, float* theta_bar, hipStream_t s) {
   WgradArgs a = base;
-  a.n_ib_groups = (a.nbb + 3) / 4;
-  const int n_obg = (a.nba + 3) / 4;
+  a.n_col_macros = (a.nbb + 7) / 8;
+  const int n_row_macros = (a.nba + 7) / 8;
   a.tiles_per_split = (int)((a.n_tiles + w.n_split - 1) / w.n_split);
   a.partial = w.partial;
   a.bpartial = b_off >= 0 ? w.bpartial : nullptr;
-  { ProfScope ps_(PS_WGRAD, s); wgrad_kernel<<<dim3((unsigned)w.n_split, (unsigned)(n_obg * a.n_ib_groups)), 64, 0, s>>>(a); }
+  {
+    ProfScope ps_(PS_WGRAD, s);
+    static bool lds_attr_set = false;
+    if (!lds_attr_set) {
+      (void)hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWgLdsBytes);
+      lds_attr_set = true;
+    }
+    wgrad_kernel<<<dim3((unsigned)w.n_split, (unsigned)(n_row_macros * a.n_col_macros)), 256, kWgLdsBytes, s>>>(a);
+  }
   WreduceArgs r;
   memset(&r, 0, sizeof(r));
   r.partial = w.partial;

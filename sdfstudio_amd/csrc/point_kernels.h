@@ -99,6 +99,33 @@ SDFHIP_D void start_position(const float* __restrict__ origins, const float* __r
   }
 }
 
+
+// ---- wave-level run reduction in front of the table-gradient atomics
+// Lanes of a wavefront hold consecutive samples of a ray, so neighbouring lanes often fall into the same grid cell (always
+// on the coarse levels, and more so once the sampler has concentrated the samples at the surface).  Device-scope fp32
+// atomics execute memory-side on MI355X (~20 G/s chip-wide, measured; same-address updates serialise), so every run of
+// equal indices is summed in registers first (segmented Hillis-Steele scan, 6 shuffle steps) and only the run's last lane
+// issues the atomic.  Returns true for the lane that must issue; v0 / v1 then hold the run totals.
+SDFHIP_D bool wave_run_reduce(const uint32_t idx, const bool active, float& v0, float& v1) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t key = active ? idx : 0xffffffffu;  // inactive lanes never join a run of active ones
+  const uint32_t prev = __shfl_up(key, 1);
+  const uint32_t next = __shfl_down(key, 1);
+  int head = (lane == 0) || (prev != key);
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float u0 = __shfl_up(v0, d);
+    const float u1 = __shfl_up(v1, d);
+    const int uh = __shfl_up(head, d);
+    if (lane >= d && !head) {
+      v0 += u0;
+      v1 += u1;
+      head |= uh;
+    }
+  }
+  return active && ((lane == 63) || (next != key));
+}
+
 struct EncodeArgs {
   GridDev grid;
   const float* origins;  // [N,3] (or [P,3] positions when dirs == null)
@@ -329,22 +356,25 @@ struct GridBwdArgs {
 // grid = (ceil(P/256), n_levels)
 __global__ __launch_bounds__(256) void grid_bwd_kernel(const GridBwdArgs a) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= a.n_points) return;
+  const bool live = p < a.n_points;
   const int level = blockIdx.y;
   const float m0 = a.mask[level * 2 + 0], m1 = a.mask[level * 2 + 1];
-  if (m0 == 0.0f && m1 == 0.0f) return;
+  if (m0 == 0.0f && m1 == 0.0f) return;  // block-uniform
   const int feat0 = 3 + 6 * a.pe_degree;
-  const float yb0 = a.in0bar_tp[tp_index(p, feat0 + level * 2 + 0, a.nb0)] * m0;
-  const float yb1 = a.in0bar_tp[tp_index(p, feat0 + level * 2 + 1, a.nb0)] * m1;
-  float e0 = 0.f, e1 = 0.f, gb[3] = {0.f, 0.f, 0.f};
+  float yb0 = 0.f, yb1 = 0.f, e0 = 0.f, e1 = 0.f, gb[3] = {0.f, 0.f, 0.f}, pp[3] = {0.5f, 0.5f, 0.5f};
   const bool second = a.e_tp != nullptr && a.gtot != nullptr;
-  if (second) {
-    e0 = a.e_tp[tp_index(p, feat0 + level * 2 + 0, a.nb0)] * m0 * 0.25f;
-    e1 = a.e_tp[tp_index(p, feat0 + level * 2 + 1, a.nb0)] * m1 * 0.25f;
+  if (live) {
+    yb0 = a.in0bar_tp[tp_index(p, feat0 + level * 2 + 0, a.nb0)] * m0;
+    yb1 = a.in0bar_tp[tp_index(p, feat0 + level * 2 + 1, a.nb0)] * m1;
+    if (second) {
+      e0 = a.e_tp[tp_index(p, feat0 + level * 2 + 0, a.nb0)] * m0 * 0.25f;
+      e1 = a.e_tp[tp_index(p, feat0 + level * 2 + 1, a.nb0)] * m1 * 0.25f;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) gb[d] = a.gtot[p * 3 + d];
+      for (int d = 0; d < 3; ++d) gb[d] = a.gtot[p * 3 + d];
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) pp[d] = (a.x[p * 3 + d] + 2.0f) * 0.25f;
   }
-  const float pp[3] = {(a.x[p * 3 + 0] + 2.0f) * 0.25f, (a.x[p * 3 + 1] + 2.0f) * 0.25f, (a.x[p * 3 + 2] + 2.0f) * 0.25f};
   GridCell c;
   grid_cell(a.grid.lv[level], a.grid.smoothstep != 0, pp, c);
 #pragma unroll
@@ -358,9 +388,11 @@ __global__ __launch_bounds__(256) void grid_bwd_kernel(const GridBwdArgs a) {
       t0 = fmaf(s, e0, t0);
       t1 = fmaf(s, e1, t1);
     }
-    float* dst = a.tablebar + (size_t)c.idx[k] * 2;
-    atomicAdd(dst, t0);
-    atomicAdd(dst + 1, t1);
+    if (wave_run_reduce(c.idx[k], live, t0, t1)) {
+      float* dst = a.tablebar + (size_t)c.idx[k] * 2;
+      atomicAdd(dst, t0);
+      atomicAdd(dst + 1, t1);
+    }
   }
 }
 
@@ -383,30 +415,39 @@ struct PropArgs {
   float* wpartial;       // [n_blocks][176]  (backward)
 };
 
-SDFHIP_D float prop_point(const PropArgs& a, const int64_t p, float feat[kPropIn], float hid[kPropHidden], GridCell cells[kPropLevels]) {
+// position of point p in the grid's [0,1] domain: frustum MIDPOINT (rays.py:46-55) or explicit position, L-inf contraction, (x+2)/4
+SDFHIP_D void prop_position(const PropArgs& a, const int64_t p, float pp[3]) {
   float x[3];
   if (a.dirs == nullptr) {  // explicit positions [P,3] (Field.density_fn, base_field.py:48-65)
 #pragma unroll
     for (int d = 0; d < 3; ++d) x[d] = a.origins[p * 3 + d];
   } else {
     const int64_t ray = p / a.S;
-    const float t = 0.5f * (a.starts[p] + a.ends[p]);  // rays.py:46-55: frustum MIDPOINT
+    const float t = 0.5f * (a.starts[p] + a.ends[p]);
 #pragma unroll
     for (int d = 0; d < 3; ++d) x[d] = a.origins[ray * 3 + d] + a.dirs[ray * 3 + d] * t;
   }
   if (a.contract) contract_inf(x);
-  const float pp[3] = {(x[0] + 2.0f) * 0.25f, (x[1] + 2.0f) * 0.25f, (x[2] + 2.0f) * 0.25f};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) pp[d] = (x[d] + 2.0f) * 0.25f;
+}
+
+// grid features (5 levels x 2) and the 16 hidden pre-activations; returns the output pre-activation
+SDFHIP_D float prop_mlp(const PropArgs& a, const float pp[3], float feat[kPropIn], float hid[kPropHidden]) {
   const float2* tab = reinterpret_cast<const float2*>(a.table);
 #pragma unroll
   for (int l = 0; l < kPropLevels; ++l) {
-    grid_cell(a.grid.lv[l], a.grid.smoothstep != 0, pp, cells[l]);
+    GridCell c;
+    grid_cell(a.grid.lv[l], a.grid.smoothstep != 0, pp, c);
+    float2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = tab[c.idx[k]];
     float y0 = 0.f, y1 = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float2 v = tab[cells[l].idx[k]];
-      const float w = corner_w(cells[l], k);
-      y0 = fmaf(w, v.x, y0);
-      y1 = fmaf(w, v.y, y1);
+      const float w = corner_w(c, k);
+      y0 = fmaf(w, v[k].x, y0);
+      y1 = fmaf(w, v[k].y, y1);
     }
     feat[2 * l] = y0;
     feat[2 * l + 1] = y1;
@@ -426,57 +467,95 @@ SDFHIP_D float prop_point(const PropArgs& a, const int64_t p, float feat[kPropIn
 __global__ __launch_bounds__(256) void prop_fwd_kernel(const PropArgs a) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= a.n_points) return;
-  float feat[kPropIn], hid[kPropHidden];
-  GridCell cells[kPropLevels];
-  const float pre = prop_point(a, p, feat, hid, cells);
+  float pp[3], feat[kPropIn], hid[kPropHidden];
+  prop_position(a, p, pp);
+  const float pre = prop_mlp(a, pp, feat, hid);
   a.density[p] = expf(pre);
 }
 
-// grid-stride; per-thread register accumulation of the 176 weight gradients, block reduction through LDS
-__global__ __launch_bounds__(256) void prop_bwd_kernel(const PropArgs a) {
+// Backward.  Thread <-> point (grid-stride, block-uniform trip count).  Table gradient: run-reduced fp32 atomics.
+// Weight gradients: w1_bar[j][i] = sum_p hb_j[p] feat_i[p] and w2_bar[j] = sum_p relu(hid_j[p]) pb[p] are 16 x 16 products
+// contracted over the points, accumulated on the matrix core (v_mfma_f32_16x16x4_f32, 8 accumulator registers per
+// lane instead of 176): each wave transposes its 64 points through a private LDS slab ([row][64 points + 4 pad]).
+constexpr int kPropT = 64;     // LDS row stride (floats)
+constexpr int kPropRows = 27;  // rows 0..15: relu(hid_j)^T ; 16..25: feat_i^T ; 26: pb
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void prop_bwd_kernel(const PropArgs a) {
+  __shared__ __attribute__((aligned(16))) float slab[4][kPropRows][kPropT];
   __shared__ float red[4][176];
-  float w1b[kPropHidden * kPropIn], w2b[kPropHidden];
-#pragma unroll
-  for (int i = 0; i < kPropHidden * kPropIn; ++i) w1b[i] = 0.0f;
-#pragma unroll
-  for (int i = 0; i < kPropHidden; ++i) w2b[i] = 0.0f;
-  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < a.n_points; p += (int64_t)gridDim.x * 256) {
-    const float db = a.densbar[p];
-    if (db == 0.0f) continue;
-    float feat[kPropIn], hid[kPropHidden];
-    GridCell cells[kPropLevels];
-    const float pre = prop_point(a, p, feat, hid, cells);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float (*sh)[kPropT] = slab[wave];
+  f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t base = (int64_t)blockIdx.x * 256; base < a.n_points; base += (int64_t)gridDim.x * 256) {
+    // compiler barrier: keeps the 176 (wave-uniform, scalar-cache resident) MLP weights from being hoisted out of the loop
+    // into vector registers, which costs the kernel its occupancy
+    asm volatile("" ::: "memory");
+    const int64_t p = base + threadIdx.x;
+    const bool live = p < a.n_points;
+    const int64_t pc = live ? p : a.n_points - 1;
+    const float db = live ? a.densbar[pc] : 0.0f;
+    float pp[3], feat[kPropIn], hid[kPropHidden];
+    prop_position(a, pc, pp);
+    const float pre = prop_mlp(a, pp, feat, hid);
     const float pb = db * expf(fminf(fmaxf(pre, -15.0f), 15.0f));  // activations.py:36-39
     float fb[kPropIn];
 #pragma unroll
     for (int i = 0; i < kPropIn; ++i) fb[i] = 0.0f;
 #pragma unroll
     for (int j = 0; j < kPropHidden; ++j) {
-      w2b[j] = fmaf(pb, fmaxf(hid[j], 0.0f), w2b[j]);
       const float hb = hid[j] > 0.0f ? pb * a.w2[j] : 0.0f;
+      sh[j][lane] = fmaxf(hid[j], 0.0f);
 #pragma unroll
-      for (int i = 0; i < kPropIn; ++i) {
-        w1b[j * kPropIn + i] = fmaf(hb, feat[i], w1b[j * kPropIn + i]);
-        fb[i] = fmaf(a.w1[j * kPropIn + i], hb, fb[i]);
-      }
+      for (int i = 0; i < kPropIn; ++i) fb[i] = fmaf(a.w1[j * kPropIn + i], hb, fb[i]);
     }
 #pragma unroll
-    for (int l = 0; l < kPropLevels; ++l)
+    for (int i = 0; i < kPropIn; ++i) sh[16 + i][lane] = feat[i];
+    sh[26][lane] = pb;
+    // ---- table gradient
+    const bool contributes = live && db != 0.0f;
+#pragma unroll
+    for (int l = 0; l < kPropLevels; ++l) {
+      GridCell c;
+      grid_cell(a.grid.lv[l], a.grid.smoothstep != 0, pp, c);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        const float w = corner_w(cells[l], k);
-        float* dst = a.tablebar + (size_t)cells[l].idx[k] * 2;
-        atomicAdd(dst, w * fb[2 * l]);
-        atomicAdd(dst + 1, w * fb[2 * l + 1]);
+        const float w = corner_w(c, k);
+        float t0 = w * fb[2 * l], t1 = w * fb[2 * l + 1];
+        if (wave_run_reduce(c.idx[k], contributes, t0, t1)) {
+          float* dst = a.tablebar + (size_t)c.idx[k] * 2;
+          atomicAdd(dst, t0);
+          atomicAdd(dst + 1, t1);
+        }
       }
+    }
+    // ---- weight gradients on the matrix core: lane (m = lane & 15, k = lane >> 4) takes points 16 u + 4 k + e
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's slab writes have landed (wave-private slab)
+    __builtin_amdgcn_wave_barrier();
+    // A rows: j = m.  B columns: n = m < 10 -> feat_n, n >= 10 -> pb (only column 10 of acc2 is used, columns >= 10 of acc1 ignored)
+    const int m = lane & 15, kq = lane >> 4;
+    const float w2m = a.w2[m];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const f32x4 ar = *reinterpret_cast<const f32x4*>(&sh[m][16 * u + 4 * kq]);
+      const f32x4 bf = *reinterpret_cast<const f32x4*>(&sh[16 + (m < 10 ? m : 10)][16 * u + 4 * kq]);
+      const f32x4 pbv = *reinterpret_cast<const f32x4*>(&sh[26][16 * u + 4 * kq]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float ah = ar[e] > 0.0f ? pbv[e] * w2m : 0.0f;                           // hb_j of this point
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ah, bf[e], acc1, 0, 0, 0);     // [j][i]  += hb_j feat_i
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[e], bf[e], acc2, 0, 0, 0);  // [j][10] += relu(hid_j) pb
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // slab reads done before the next iteration overwrites it
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // C layout of 16x16x4: col n = lane & 15, row m = 4 (lane >> 4) + reg
+  {
+    const int n = lane & 15;
 #pragma unroll
-  for (int i = 0; i < 176; ++i) {
-    float v = i < 160 ? w1b[i < 160 ? i : 0] : w2b[i >= 160 ? i - 160 : 0];
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
-    if (lane == 0) red[wave][i] = v;
+    for (int r = 0; r < 4; ++r) {
+      const int j = 4 * (lane >> 4) + r;
+      if (n < kPropIn) red[wave][j * kPropIn + n] = acc1[r];
+      if (n == 10) red[wave][160 + j] = acc2[r];
+    }
   }
   __syncthreads();
   if (threadIdx.x < 176)

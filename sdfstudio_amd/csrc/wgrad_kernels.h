@@ -3,8 +3,8 @@
 //  pack_kernel    natural [out][in] fp32 weights -> MFMA A-operand order  Wp[kb][ob][reg][lane]
 //                 (and the transposed pack used by the chain / data-backward passes)
 //  wgrad_kernel   split-K GEMM over points:  C[o][i] = sum_p A[p][o] * B[p][i]  with A, B tile-packed in HBM,
-//                 one wave per (point-split, 4x4 block macro tile); fp32 MFMA 32x32x2, contraction over points.
-//                 Column sums of A (bias gradients) fall out of the same loads.
+//                 one workgroup per (point-split, 8x8 block macro tile), tiles transposed through LDS; fp32 MFMA 32x32x2.
+//                 Column sums of A (bias gradients) fall out of the same reads.
 //  wreduce_kernel sums the split partials and scatters them into the natural-layout gradient vector.
 #pragma once
 #include "common.h"
@@ -60,6 +60,16 @@ static __global__ void packvec_kernel(const float* __restrict__ theta, const Vec
 }
 
 // ------------------------------------------------------------------------------------------------ wgrad
+// C[o][i] = sum over points of A[p][o] * B[p][i]: a GEMM whose contraction runs over the 524 288 points, with both
+// operands stored tile-packed (lane <-> point).  The MFMA wants lane <-> feature, so every 32-point tile is transposed
+// through LDS: the workgroup (4 waves) loads the <= 8 A blocks and <= 8 B blocks of one tile with coalesced 1 KiB
+// dwordx4 wave loads (each HBM byte is read once per macro tile, softplus applied once where the operand is a saved
+// pre-activation), writes them as [block][feature 0..31][point 0..31] rows of 36 floats (ds_write_b128, conflict free),
+// and each wave reads its 4 + 4 blocks back with ds_read_b128 (4 consecutive points of "its" feature; the 36-float row
+// stride spreads a 16-lane read group over all 64 banks).  Each wave owns a 4x4-block (128 x 128) quadrant of the
+// 256 x 256 macro tile: 256 accumulator registers, 256 MFMAs per tile against 32 LDS reads.  The next tile's global loads
+// are in flight in registers while the current one is multiplied.  Split over points; partials are reduced by
+// wreduce_kernel.  Column sums of pair 0's A (bias gradients) fall out of the A reads.
 struct TpOperand {
   const float* ptr[2];  // up to two concatenated TP arrays
   int32_t nb[2];        // blocks in each
@@ -69,36 +79,25 @@ struct WgradArgs {
   TpOperand A[2], B[2];  // up to two (A, B) pairs accumulated into the same C
   int32_t n_pairs;
   int32_t nba, nbb;      // total blocks of A (rows of C / 32) and B (cols of C / 32)
-  int32_t n_ib_groups;   // ceil(nbb / 4)
+  int32_t n_col_macros;  // ceil(nbb / 8)
   int64_t n_tiles;       // point tiles
   int32_t tiles_per_split;
   float* partial;        // [n_split][nba*32][nbb*32]
   float* bpartial;       // [n_split][nba*32]   column sums of pair 0's A   (may be null)
 };
 
-SDFHIP_D f32x4 wg_load(const TpOperand& op, const int blk, const int64_t tile, const int nb_total, const int rowoff) {
-  // rowoff = reg_of_row*64 + 32*hf_of_row + 4*(lane>>5)   (+ 8*g added by the caller)
-  const int seg = blk >= op.nb[0];
-  const int lb = blk - (seg ? op.nb[0] : 0);
-  const float* p = op.ptr[seg] + ((size_t)tile * op.nb[seg] + lb) * 1024 + rowoff;
-  f32x4 v = *reinterpret_cast<const f32x4*>(p);
-  if (op.xf[seg] == 1) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      v[i] = softplus100_h(v[i]);
-    }
-  }
-  return v;
-}
+constexpr int kWgRow = 36;              // floats per LDS row (32 points + 4 pad: 16-byte aligned, bank-spreading)
+constexpr int kWgBlk = 32 * kWgRow;     // floats per staged block
+constexpr int kWgLdsBytes = 16 * kWgBlk * 4;
 
-// grid = (n_split, n_ob_groups * n_ib_groups), block = 64 (one wave)
-static __global__ __launch_bounds__(64, 1) void wgrad_kernel(const WgradArgs a) {
-  const int lane = threadIdx.x;
+// grid = (n_split, n_row_macros * n_col_macros), block = 256
+static __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [16 slots][32][36]: slots 0..7 = A blocks, 8..15 = B blocks
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qi = wave >> 1, qj = wave & 1;
   const int split = blockIdx.x;
-  const int ibg = blockIdx.y % a.n_ib_groups, obg = blockIdx.y / a.n_ib_groups;
-  const int ob0 = obg * 4, ib0 = ibg * 4;
-  const int row = lane & 31;
-  const int rowoff = tp_reg_of_row(row) * 64 + 32 * tp_hf_of_row(row) + 4 * (lane >> 5);
+  const int mrow = blockIdx.y / a.n_col_macros, mcol = blockIdx.y % a.n_col_macros;
+  const int ob_base = mrow * 8, ib_base = mcol * 8;
 
   f32x16 acc[4][4];
 #pragma unroll
@@ -112,33 +111,96 @@ static __global__ __launch_bounds__(64, 1) void wgrad_kernel(const WgradArgs a) 
   const int64_t t0 = (int64_t)split * a.tiles_per_split;
   int64_t t1 = t0 + a.tiles_per_split;
   if (t1 > a.n_tiles) t1 = a.n_tiles;
+  const int n_t = t1 > t0 ? (int)(t1 - t0) : 0;
+  const int n_stage = n_t * a.n_pairs;
 
-  for (int pr = 0; pr < a.n_pairs; ++pr) {
-    const TpOperand& A = a.A[pr];
-    const TpOperand& B = a.B[pr];
-    for (int64_t tile = t0; tile < t1; ++tile) {
-#pragma unroll 2
-      for (int g = 0; g < 4; ++g) {
-        f32x4 av[4], bv[4];
+  // staging role of this wave: slots {wave, wave + 4} (A) and {8 + wave, 12 + wave} (B)
+  int slot[4] = {wave, wave + 4, 8 + wave, 12 + wave};
+  bool valid[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          av[i] = (ob0 + i < a.nba) ? wg_load(A, ob0 + i, tile, a.nba, rowoff + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-          bv[i] = (ib0 + i < a.nbb) ? wg_load(B, ib0 + i, tile, a.nbb, rowoff + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int q = 0; q < 4; ++q) valid[q] = slot[q] < 8 ? (ob_base + slot[q] < a.nba) : (ib_base + slot[q] - 8 < a.nbb);
+  // wave-uniform validity of the quadrant's blocks
+  bool av[4], bv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    av[i] = ob_base + qi * 4 + i < a.nba;
+    bv[i] = ib_base + qj * 4 + i < a.nbb;
+  }
+
+  f32x4 pre[4][4];
+  auto load_stage = [&](const int st) {
+    const int pr = st / n_t;
+    const int64_t tile = t0 + (st - pr * n_t);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!valid[q]) continue;
+      const TpOperand& op = slot[q] < 8 ? a.A[pr] : a.B[pr];
+      const int blk = slot[q] < 8 ? ob_base + slot[q] : ib_base + slot[q] - 8;
+      const int seg = blk >= op.nb[0];
+      const int lb = blk - (seg ? op.nb[0] : 0);
+      const f32x4* src = reinterpret_cast<const f32x4*>(op.ptr[seg] + ((size_t)tile * op.nb[seg] + lb) * 1024) + lane;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pre[q][i] = src[i * 64];
+    }
+  };
+  auto store_stage = [&](const int st) {
+    const int pr = st / n_t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!valid[q]) continue;
+      const TpOperand& op = slot[q] < 8 ? a.A[pr] : a.B[pr];
+      const int blk = slot[q] < 8 ? ob_base + slot[q] : ib_base + slot[q] - 8;
+      const bool xf = op.xf[blk >= op.nb[0]] == 1;
+      // lane holds, for i = 0..3, TP row r = 4 i + (lane >> 4), half (lane >> 3) & 1, points 4 (lane & 7) .. + 3
+      float* dst = lds + slot[q] * kWgBlk + (lane & 7) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v = pre[q][i];
+        if (xf) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = softplus100_h(v[e]);
         }
-        if (pr == 0) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) colsum[i] += (av[i][0] + av[i][1]) + (av[i][2] + av[i][3]);
-        }
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s], bv[j][s], acc[i][j], 0, 0, 0);
+        const int f = tp_row(i * 4 + (lane >> 4), (lane >> 3) & 1);
+        *reinterpret_cast<f32x4*>(dst + f * kWgRow) = v;
       }
     }
+  };
+
+  if (n_stage > 0) load_stage(0);
+  for (int st = 0; st < n_stage; ++st) {
+    __syncthreads();  // every wave is done reading the previous stage
+    store_stage(st);
+    __syncthreads();
+    if (st + 1 < n_stage) load_stage(st + 1);
+    const bool first_pair = st < n_t;
+    const float* la = lds + (qi * 4) * kWgBlk + (lane & 31) * kWgRow + 4 * (lane >> 5);
+    const float* lb = lds + (8 + qj * 4) * kWgBlk + (lane & 31) * kWgRow + 4 * (lane >> 5);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 a4[4], b4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a4[i] = av[i] ? *reinterpret_cast<const f32x4*>(la + i * kWgBlk + g * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+        b4[i] = bv[i] ? *reinterpret_cast<const f32x4*>(lb + i * kWgBlk + g * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (first_pair) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) colsum[i] += (a4[i][0] + a4[i][1]) + (a4[i][2] + a4[i][3]);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (!av[i]) continue;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (!bv[j]) continue;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][s], b4[j][s], acc[i][j], 0, 0, 0);
+          }
+        }
+    }
   }
+
   const int ldc = a.nbb * 32;
   float* C = a.partial + (size_t)split * a.nba * 32 * ldc;
   const int hf = lane >> 5;
@@ -146,17 +208,18 @@ static __global__ __launch_bounds__(64, 1) void wgrad_kernel(const WgradArgs a) 
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      if (ob0 + i < a.nba && ib0 + j < a.nbb) {
+      const int ob = ob_base + qi * 4 + i, ib = ib_base + qj * 4 + j;
+      if (ob < a.nba && ib < a.nbb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          C[(size_t)((ob0 + i) * 32 + tp_row(r, hf)) * ldc + (ib0 + j) * 32 + (lane & 31)] = acc[i][j][r];
+        for (int r = 0; r < 16; ++r) C[(size_t)(ob * 32 + tp_row(r, hf)) * ldc + ib * 32 + (lane & 31)] = acc[i][j][r];
       }
     }
-  if (a.bpartial != nullptr && ibg == 0) {
+  if (a.bpartial != nullptr && mcol == 0 && qj == 0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const float t = colsum[i] + __shfl_xor(colsum[i], 32);
-      if (hf == 0 && ob0 + i < a.nba) a.bpartial[(size_t)split * a.nba * 32 + (ob0 + i) * 32 + lane] = t;
+      const int ob = ob_base + qi * 4 + i;
+      if (hf == 0 && ob < a.nba) a.bpartial[(size_t)split * a.nba * 32 + ob * 32 + lane] = t;
     }
   }
 }
