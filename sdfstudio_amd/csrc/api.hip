@@ -586,19 +586,20 @@ __global__ void sdfrow_reduce_kernel(const float* __restrict__ partial, const in
 static void run_wgrad(const SdfHipField* f, const FieldWs& w, const WgradArgs& base, int rowmap, int colmap, int64_t w_off, int ld,
                       float scale, int64_t b_off, float* theta_bar, hipStream_t s) {
   WgradArgs a = base;
-  a.n_col_macros = (a.nbb + 7) / 8;
-  const int n_row_macros = (a.nba + 7) / 8;
   a.tiles_per_split = (int)((a.n_tiles + w.n_split - 1) / w.n_split);
   a.partial = w.partial;
   a.bpartial = b_off >= 0 ? w.bpartial : nullptr;
   {
     ProfScope ps_(PS_WGRAD, s);
-    static bool lds_attr_set = false;
-    if (!lds_attr_set) {
-      (void)hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWgLdsBytes);
-      lds_attr_set = true;
-    }
-    wgrad_kernel<<<dim3((unsigned)w.n_split, (unsigned)(n_row_macros * a.n_col_macros)), 256, kWgLdsBytes, s>>>(a);
+    for (int ob = 0; ob < a.nba; ob += 8)
+      for (int ib = 0; ib < a.nbb; ib += 8) {
+        a.ob_base = ob;
+        a.ib_base = ib;
+        const int na = (std::min(8, a.nba - ob) + 1) / 2, nb = (std::min(8, a.nbb - ib) + 1) / 2;
+        WgradKernelFn fn = wgrad_pick(na, nb);
+        (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, kWgLdsBytes);
+        hipLaunchKernelGGL(fn, dim3((unsigned)w.n_split), dim3(256), kWgLdsBytes, s, a);
+      }
   }
   WreduceArgs r;
   memset(&r, 0, sizeof(r));

@@ -79,7 +79,7 @@ struct WgradArgs {
   TpOperand A[2], B[2];  // up to two (A, B) pairs accumulated into the same C
   int32_t n_pairs;
   int32_t nba, nbb;      // total blocks of A (rows of C / 32) and B (cols of C / 32)
-  int32_t n_col_macros;  // ceil(nbb / 8)
+  int32_t ob_base, ib_base;  // first row / column block of the macro tile this launch computes
   int64_t n_tiles;       // point tiles
   int32_t tiles_per_split;
   float* partial;        // [n_split][nba*32][nbb*32]
@@ -90,23 +90,29 @@ constexpr int kWgRow = 36;              // floats per LDS row (32 points + 4 pad
 constexpr int kWgBlk = 32 * kWgRow;     // floats per staged block
 constexpr int kWgLdsBytes = 16 * kWgBlk * 4;
 
-// grid = (n_split, n_row_macros * n_col_macros), block = 256
-static __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
+// grid = n_split, block = 256.  One macro tile (<= 8 x 8 blocks at ob_base / ib_base) per launch.  Wave (qi, qj) owns row
+// blocks ob_base + qi + 2 i (i < NA) and column blocks ib_base + qj + 2 j (j < NB): the interleaved assignment keeps the four
+// waves balanced for 6- or 3-block operands, and NA / NB are compile-time so the 16 NA NB MFMAs of each 8-point group form
+// one straight-line block.  Slots beyond the operand's extent stay zero in LDS (multiplied but never written back).
+template <int NA, int NB>
+__global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [16 slots][32][36]: slots 0..7 = A blocks, 8..15 = B blocks
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keeps the staging predicates scalar
   const int qi = wave >> 1, qj = wave & 1;
   const int split = blockIdx.x;
-  const int mrow = blockIdx.y / a.n_col_macros, mcol = blockIdx.y % a.n_col_macros;
-  const int ob_base = mrow * 8, ib_base = mcol * 8;
+  const int ob_base = a.ob_base, ib_base = a.ib_base;
 
-  f32x16 acc[4][4];
+  f32x16 acc[NA][NB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NA; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NB; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  float colsum[4] = {0.f, 0.f, 0.f, 0.f};
+  float colsum[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) colsum[i] = 0.0f;
 
   const int64_t t0 = (int64_t)split * a.tiles_per_split;
   int64_t t1 = t0 + a.tiles_per_split;
@@ -114,43 +120,62 @@ static __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a)
   const int n_t = t1 > t0 ? (int)(t1 - t0) : 0;
   const int n_stage = n_t * a.n_pairs;
 
+  for (int i = tid; i < 16 * kWgBlk / 4; i += 256) reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
   // staging role of this wave: slots {wave, wave + 4} (A) and {8 + wave, 12 + wave} (B)
-  int slot[4] = {wave, wave + 4, 8 + wave, 12 + wave};
+  const int slot[4] = {wave, wave + 4, 8 + wave, 12 + wave};
   bool valid[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) valid[q] = slot[q] < 8 ? (ob_base + slot[q] < a.nba) : (ib_base + slot[q] - 8 < a.nbb);
-  // wave-uniform validity of the quadrant's blocks
-  bool av[4], bv[4];
+
+  // per-slot source description, resolved once (wave-uniform -> scalar registers): base pointer, floats per tile, softplus flag
+  const float* src0[4];
+  const float* src1[4];
+  int stride0[4], stride1[4];
+  bool xf0[4], xf1[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    av[i] = ob_base + qi * 4 + i < a.nba;
-    bv[i] = ib_base + qj * 4 + i < a.nbb;
+  for (int q = 0; q < 4; ++q) {
+    const int blk = slot[q] < 8 ? ob_base + slot[q] : ib_base + slot[q] - 8;
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const TpOperand& op = slot[q] < 8 ? a.A[pr] : a.B[pr];
+      const int seg = blk >= op.nb[0];
+      const int lb = blk - (seg ? op.nb[0] : 0);
+      const float* base = op.ptr[seg] + (size_t)lb * 1024;
+      const int stride = op.nb[seg] * 1024;
+      const bool xf = op.xf[seg] == 1;
+      if (pr == 0) {
+        src0[q] = base;
+        stride0[q] = stride;
+        xf0[q] = xf;
+      } else {
+        src1[q] = base;
+        stride1[q] = stride;
+        xf1[q] = xf;
+      }
+    }
   }
 
   f32x4 pre[4][4];
   auto load_stage = [&](const int st) {
-    const int pr = st / n_t;
-    const int64_t tile = t0 + (st - pr * n_t);
+    const bool p1 = st >= n_t;
+    const int64_t tile = t0 + (p1 ? st - n_t : st);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (!valid[q]) continue;
-      const TpOperand& op = slot[q] < 8 ? a.A[pr] : a.B[pr];
-      const int blk = slot[q] < 8 ? ob_base + slot[q] : ib_base + slot[q] - 8;
-      const int seg = blk >= op.nb[0];
-      const int lb = blk - (seg ? op.nb[0] : 0);
-      const f32x4* src = reinterpret_cast<const f32x4*>(op.ptr[seg] + ((size_t)tile * op.nb[seg] + lb) * 1024) + lane;
+      const float* base = p1 ? src1[q] : src0[q];
+      const int stride = p1 ? stride1[q] : stride0[q];
+      const f32x4* src = reinterpret_cast<const f32x4*>(base + (size_t)tile * stride) + lane;
 #pragma unroll
       for (int i = 0; i < 4; ++i) pre[q][i] = src[i * 64];
     }
   };
   auto store_stage = [&](const int st) {
-    const int pr = st / n_t;
+    const bool p1 = st >= n_t;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (!valid[q]) continue;
-      const TpOperand& op = slot[q] < 8 ? a.A[pr] : a.B[pr];
-      const int blk = slot[q] < 8 ? ob_base + slot[q] : ib_base + slot[q] - 8;
-      const bool xf = op.xf[blk >= op.nb[0]] == 1;
+      const bool xf = p1 ? xf1[q] : xf0[q];
       // lane holds, for i = 0..3, TP row r = 4 i + (lane >> 4), half (lane >> 3) & 1, points 4 (lane & 7) .. + 3
       float* dst = lds + slot[q] * kWgBlk + (lane & 7) * 4;
 #pragma unroll
@@ -167,37 +192,31 @@ static __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a)
   };
 
   if (n_stage > 0) load_stage(0);
+  const float* la = lds + qi * kWgBlk + (lane & 31) * kWgRow + 4 * (lane >> 5);
+  const float* lb = lds + (8 + qj) * kWgBlk + (lane & 31) * kWgRow + 4 * (lane >> 5);
   for (int st = 0; st < n_stage; ++st) {
-    __syncthreads();  // every wave is done reading the previous stage
+    __syncthreads();  // every wave is done reading the previous stage (and, first time round, the zero fill has landed)
     store_stage(st);
     __syncthreads();
     if (st + 1 < n_stage) load_stage(st + 1);
     const bool first_pair = st < n_t;
-    const float* la = lds + (qi * 4) * kWgBlk + (lane & 31) * kWgRow + 4 * (lane >> 5);
-    const float* lb = lds + (8 + qj * 4) * kWgBlk + (lane & 31) * kWgRow + 4 * (lane >> 5);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      f32x4 a4[4], b4[4];
+      f32x4 a4[NA], b4[NB];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        a4[i] = av[i] ? *reinterpret_cast<const f32x4*>(la + i * kWgBlk + g * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
-        b4[i] = bv[i] ? *reinterpret_cast<const f32x4*>(lb + i * kWgBlk + g * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      for (int i = 0; i < NA; ++i) a4[i] = *reinterpret_cast<const f32x4*>(la + 2 * i * kWgBlk + g * 8);
+#pragma unroll
+      for (int j = 0; j < NB; ++j) b4[j] = *reinterpret_cast<const f32x4*>(lb + 2 * j * kWgBlk + g * 8);
       if (first_pair) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) colsum[i] += (a4[i][0] + a4[i][1]) + (a4[i][2] + a4[i][3]);
+        for (int i = 0; i < NA; ++i) colsum[i] += (a4[i][0] + a4[i][1]) + (a4[i][2] + a4[i][3]);
       }
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (!av[i]) continue;
+        for (int i = 0; i < NA; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (!bv[j]) continue;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][s], b4[j][s], acc[i][j], 0, 0, 0);
-          }
-        }
+          for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i][s], b4[j][s], acc[i][j], 0, 0, 0);
     }
   }
 
@@ -205,22 +224,41 @@ static __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a)
   float* C = a.partial + (size_t)split * a.nba * 32 * ldc;
   const int hf = lane >> 5;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NA; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int ob = ob_base + qi * 4 + i, ib = ib_base + qj * 4 + j;
-      if (ob < a.nba && ib < a.nbb) {
+    for (int j = 0; j < NB; ++j) {
+      const int ob = ob_base + qi + 2 * i, ib = ib_base + qj + 2 * j;
+      if (qi + 2 * i < 8 && qj + 2 * j < 8 && ob < a.nba && ib < a.nbb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) C[(size_t)(ob * 32 + tp_row(r, hf)) * ldc + ib * 32 + (lane & 31)] = acc[i][j][r];
       }
     }
-  if (a.bpartial != nullptr && mcol == 0 && qj == 0) {
+  if (a.bpartial != nullptr && ib_base == 0 && qj == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NA; ++i) {
       const float t = colsum[i] + __shfl_xor(colsum[i], 32);
-      const int ob = ob_base + qi * 4 + i;
-      if (hf == 0 && ob < a.nba) a.bpartial[(size_t)split * a.nba * 32 + ob * 32 + lane] = t;
+      const int ob = ob_base + qi + 2 * i;
+      if (hf == 0 && qi + 2 * i < 8 && ob < a.nba) a.bpartial[(size_t)split * a.nba * 32 + ob * 32 + lane] = t;
     }
+  }
+}
+
+typedef void (*WgradKernelFn)(const WgradArgs);
+template <int NA>
+static WgradKernelFn wgrad_pick_nb(const int nb) {
+  switch (nb) {
+    case 1: return wgrad_kernel<NA, 1>;
+    case 2: return wgrad_kernel<NA, 2>;
+    case 3: return wgrad_kernel<NA, 3>;
+    default: return wgrad_kernel<NA, 4>;
+  }
+}
+static WgradKernelFn wgrad_pick(const int na, const int nb) {
+  switch (na) {
+    case 1: return wgrad_pick_nb<1>(nb);
+    case 2: return wgrad_pick_nb<2>(nb);
+    case 3: return wgrad_pick_nb<3>(nb);
+    default: return wgrad_pick_nb<4>(nb);
   }
 }
 
