@@ -10,7 +10,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdfhip.so")
+LIB_PATH = os.environ.get("SDFHIP_LIB", os.path.join(_HERE, "libsdfhip.so"))  # override: A/B runs of two builds in one process tree
 
 c_float_p = ctypes.c_void_p  # device pointers travel as raw addresses
 c_i64 = ctypes.c_int64

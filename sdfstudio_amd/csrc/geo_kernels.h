@@ -10,6 +10,10 @@
 //             v_l = W_l qb_l ; qb_{l+1} = s'(z_l) v_l ; zc_l = v_l * r_l * 100 (1 - s'(z_l))
 //   backward  ub_NL = W_f^T featbar + w_s sdfbar ; zb_l = ub_{l+1} s'(z_l) + zc_l ; ub_l = W_l^T zb_l
 //   weight gradients are separate split-K GEMMs (wgrad_kernel): Wb_l = Zb_l^T U_l + R_l^T Qb_l.
+//
+// Every line above is one tp_gemm (mlp_core.h) whose input blocks are produced just in time from the previous gemm's
+// accumulators; the elementwise work (softplus, its derivatives, loads / stores of the saved tensors) rides in the
+// producer, interleaved with the MFMAs of the previous block.
 #pragma once
 #include "mlp_core.h"
 
@@ -24,12 +28,15 @@ struct GeoDims {
   static constexpr int nbo(int l) { return l == NL ? NBF : ((l + 1 == SKIP) ? NB3 : NBH); }
   static constexpr int cmax(int a, int b) { return a > b ? a : b; }
   static constexpr int MAXB = cmax(cmax(NBH, NBF), cmax(NB0, SKIP >= 0 ? NB3 + NB0 : 0));
-  static constexpr int LDS_FLOATS = 2 * MAXB * 1024;
+  static constexpr int BUF_FLOATS = MAXB * 1024;                        // one weight chunk buffer
+  static constexpr int CW = cmax(NBH, NBF) * 32;                         // stride of the constant-vector area
+  static constexpr int CVEC_FLOATS = (NL + 2) * CW;                      // biases of layers 0..NL, then w_sdf
+  static constexpr int LDS_FLOATS = 2 * BUF_FLOATS + CVEC_FLOATS;
 };
 
 struct GeoPtrs {
-  const float* wp[kMaxLayers];    // packed W_l      [kb][nbo][16][64]
-  const float* wpT[kMaxLayers];   // packed W_l^T    [nbo][kb][16][64]
+  const float* wp[kMaxLayers];    // packed W_l      [kb][nbo][4][64][4]
+  const float* wpT[kMaxLayers];   // packed W_l^T    [nbo][kb][4][64][4]
   const float* bias[kMaxLayers];  // natural order, padded to nbo*32
   const float* w_sdf;             // [NBH*32]  row of the output layer that produces sdf
   const float* b_sdf;             // [1]
@@ -45,87 +52,140 @@ struct GeoFwdArgs {
   float* e_tp;              // [T][NB0]   d sdf / d in0
 };
 
-// one TP block (16 registers) load / store
-SDFHIP_D f32x16 tp_load_blk(const float* __restrict__ base, const int64_t tile, const int nb, const int b, const int lane) {
-  const float* p = base + ((size_t)tile * nb + b) * 1024 + lane;
-  f32x16 v;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) v[r] = p[r * 64];
-  return v;
-}
-SDFHIP_D void tp_store_blk(const f32x16 v, float* __restrict__ base, const int64_t tile, const int nb, const int b, const int lane) {
-  float* p = base + ((size_t)tile * nb + b) * 1024 + lane;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) p[r * 64] = v[r];
+// biases (layers 0..NL) and w_sdf into the constant area of LDS: cvec[l * CW + i], w_sdf at l = NL + 1
+template <class D>
+SDFHIP_D void geo_stage_cvec(float* cvec, const GeoPtrs& p, const int tid) {
+  static_for<0, D::NL + 1>([&](auto lc) __attribute__((always_inline)) {
+    constexpr int l = decltype(lc)::value;
+    if (tid < D::nbo(l) * 32) cvec[l * D::CW + tid] = p.bias[l][tid];
+  });
+  if (tid < D::NBH * 32) cvec[(D::NL + 1) * D::CW + tid] = p.w_sdf[tid];
 }
 
 template <class D, bool GRAD, bool SAVE, bool FEAT>
 __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, hf = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-  constexpr int MAXB = D::MAXB;
+  constexpr int MAXB = D::MAXB, W = D::CW;
+  float* cvec = lds + 2 * D::BUF_FLOATS;
 
-  f32x16 H[MAXB];
-  tp_load<D::NB0>(H, a.in0_tp, tile, lane);
+  WStream ws{lds, D::BUF_FLOATS, 0, wave, lane};
+  ws.issue(a.p.wp[0], D::nbo(0), true);
+  geo_stage_cvec<D>(cvec, a.p, tid);
+  __syncthreads();
 
+  f32x16 accA[MAXB], accB[MAXB];
+  Raw carry;
+
+  // HBM operands of input block kb of forward layer l (only in0 blocks come from memory)
+  auto fwd_fetch = [&](auto lc, auto kbc) __attribute__((always_inline)) {
+    constexpr int l = decltype(lc)::value, kb = decltype(kbc)::value;
+    Raw raw;
+    if constexpr (l == 0) raw.a = tp_load_blk(a.in0_tp, tile, D::NB0, kb, lane);
+    else if constexpr (l == D::SKIP && kb >= D::NB3) raw.a = tp_load_blk(a.in0_tp, tile, D::NB0, kb - D::NB3, lane);
+    return raw;
+  };
+  // HBM operands of block b of the chain step through layer l
+  auto chain_fetch = [&](auto lc, auto bc) __attribute__((always_inline)) {
+    constexpr int l = decltype(lc)::value, b = decltype(bc)::value;
+    Raw raw;
+    raw.a = tp_load_blk(a.z_tp[l], tile, D::nbo(l), b, lane);
+    return raw;
+  };
+
+  // ---- forward layers 0 .. NL-1: out_l = b_l + W_l u_l
+  carry = fwd_fetch(IC<0>{}, IC<0>{});
   static_for<0, D::NL>([&](auto lc) __attribute__((always_inline)) {
     constexpr int l = decltype(lc)::value;
     constexpr int KB = D::kb(l), NBO = D::nbo(l);
-    if constexpr (l == D::SKIP) {
+    auto& in = pick<(l % 2) == 0>(accA, accB);   // accumulators of layer l - 1 (l >= 1)
+    auto& out = pick<(l % 2) == 0>(accB, accA);
 #pragma unroll
-      for (int b = 0; b < D::NB0; ++b) H[D::NB3 + b] = tp_load_blk(a.in0_tp, tile, D::NB0, b, lane);
-    }
-    f32x16 acc[MAXB];
-    tp_load_rowvec<NBO>(acc, a.p.bias[l], hf);
-    tp_gemm<KB, NBO>(acc, H, a.p.wp[l], lds, tid, lane);
-#pragma unroll
-    for (int b = 0; b < NBO; ++b) {
-      if constexpr (SAVE || GRAD) tp_store_blk(acc[b], a.z_tp[l], tile, NBO, b, lane);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        H[b][r] = softplus100_h(acc[b][r]);
+    for (int b = 0; b < NBO; ++b) out[b] = tp_rowvec_blk(cvec + l * W, b, hf);
+    auto fetch = [&](auto kbc) __attribute__((always_inline)) { return fwd_fetch(lc, kbc); };
+    auto make = [&](auto kbc, const Raw& raw, auto ec) __attribute__((always_inline)) {
+      constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
+      if constexpr (l == 0 || (l == D::SKIP && kb >= D::NB3)) {
+        return raw.a[e];
+      } else {
+        const float z = in[kb][e];
+        if constexpr (SAVE || GRAD) *tp_elem(a.z_tp[l > 0 ? l - 1 : 0], tile, D::nbo(l > 0 ? l - 1 : 0), kb, e, lane) = z;
+        return softplus100_h(z);
       }
-    }
+    };
+    constexpr bool last = l + 1 == D::NL;
+    const float* next = last ? (FEAT ? a.p.wp[D::NL] : (GRAD ? a.p.wpT[D::NL - 1] : nullptr)) : a.p.wp[l + 1];
+    constexpr int next_nbo = last ? (FEAT ? D::NBF : D::kb(D::NL - 1)) : D::nbo(l + 1);
+    auto next_fetch = [&]() __attribute__((always_inline)) {
+      if constexpr (!last) return fwd_fetch(IC<(last ? l : l + 1)>{}, IC<0>{});
+      else return Raw{};
+    };
+    constexpr int ZS = (SAVE || GRAD) ? 16 : 0;  // z stores per produced block
+    using ST = Stores<(l == 0 ? 0 : ZS), (l == 0 ? 0 : (l == D::SKIP ? 0 : ZS)), (l == D::SKIP ? D::NB3 : (1 << 30))>;
+    tp_gemm<KB, NBO, ST>(out, carry, fetch, make, next_fetch, ws, a.p.wp[l], next, next_nbo);
   });
 
-  // output layer: feature rows through the MFMA path, the sdf row as a lane-local dot product
+  // ---- output layer: the sdf row as a lane-local dot product riding in the producer, feature rows on the MFMA path
   {
+    auto& in = pick<(D::NL % 2) == 0>(accA, accB);
+    auto& out = pick<(D::NL % 2) == 0>(accB, accA);
     float part = 0.0f;
+    auto make = [&](auto kbc, const Raw&, auto ec) __attribute__((always_inline)) {
+      constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
+      const float z = in[kb][e];
+      if constexpr (SAVE || GRAD) *tp_elem(a.z_tp[D::NL - 1], tile, D::NBH, kb, e, lane) = z;
+      const float h = softplus100_h(z);
+      part = fmaf(cvec[(D::NL + 1) * W + kb * 32 + tp_row(e, hf)], h, part);
+      return h;
+    };
+    if constexpr (FEAT) {
 #pragma unroll
-    for (int b = 0; b < D::NBH; ++b)
+      for (int b = 0; b < D::NBF; ++b) out[b] = tp_rowvec_blk(cvec + D::NL * W, b, hf);
+      auto next_fetch = [&]() __attribute__((always_inline)) {
+        if constexpr (GRAD) return chain_fetch(IC<D::NL - 1>{}, IC<0>{});
+        else return Raw{};
+      };
+      tp_gemm<D::NBH, D::NBF, Stores<((SAVE || GRAD) ? 16 : 0)>>(out, carry, NoFetch{}, make, next_fetch, ws, a.p.wp[D::NL], GRAD ? a.p.wpT[D::NL - 1] : nullptr,
+                              D::kb(D::NL - 1));
 #pragma unroll
-      for (int r = 0; r < 16; ++r) part = fmaf(a.p.w_sdf[b * 32 + tp_row(r, hf)], H[b][r], part);
+      for (int b = 0; b < D::NBF; ++b) tp_store_blk(out[b], a.feat_tp, tile, D::NBF, b, lane);
+    } else {
+      static_for<0, D::NBH>([&](auto kbc) __attribute__((always_inline)) {
+        static_for<0, 16>([&](auto ec) __attribute__((always_inline)) { (void)make(kbc, carry, ec); });
+      });
+      if constexpr (GRAD) carry = chain_fetch(IC<D::NL - 1>{}, IC<0>{});
+    }
     part += __shfl_xor(part, 32);
     if (hf == 0) a.sdf[tile * 32 + lane] = part + a.p.b_sdf[0];
   }
-  if constexpr (FEAT) {
-    f32x16 acc[MAXB];
-    tp_load_rowvec<D::NBF>(acc, a.p.bias[D::NL], hf);
-    tp_gemm<D::NBH, D::NBF>(acc, H, a.p.wp[D::NL], lds, tid, lane);
-    tp_store<D::NBF>(acc, a.feat_tp, tile, lane);
-  }
 
+  // ---- chain: q_l = W_l^T (q_{l+1} * s'(z_l)),  q_NL = w_sdf
   if constexpr (GRAD) {
-    f32x16 q[MAXB];
-    tp_load_rowvec<D::NBH>(q, a.p.w_sdf, hf);
-    static_for<0, D::NL>([&](auto lc) __attribute__((always_inline)) {
-      constexpr int l = D::NL - 1 - decltype(lc)::value;
+#pragma unroll
+    for (int b = 0; b < D::NBH; ++b) accA[b] = tp_rowvec_blk(cvec + (D::NL + 1) * W, b, hf);
+    static_for<0, D::NL>([&](auto sc) __attribute__((always_inline)) {
+      constexpr int step = decltype(sc)::value;
+      constexpr int l = D::NL - 1 - step;
       constexpr int KB = D::kb(l), NBO = D::nbo(l);
-      // r_l = q * s'(z_l)   (in place in q)
+      auto& q = pick<(step % 2) == 0>(accA, accB);
+      auto& qn = pick<(step % 2) == 0>(accB, accA);
 #pragma unroll
-      for (int b = 0; b < NBO; ++b) {
-        const f32x16 z = tp_load_blk(a.z_tp[l], tile, NBO, b, lane);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) q[b][r] *= softplus100_d1(z[r]);
-        if constexpr (SAVE) tp_store_blk(q[b], a.r_tp[l], tile, NBO, b, lane);
-      }
-      f32x16 qn[MAXB];
-#pragma unroll
-      for (int b = 0; b < KB; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) qn[b][r] = 0.0f;
-      tp_gemm<NBO, KB>(qn, q, a.p.wpT[l], lds, tid, lane);
+      for (int b = 0; b < KB; ++b) qn[b] = f32x16_zero();
+      auto fetch = [&](auto bc) __attribute__((always_inline)) { return chain_fetch(IC<l>{}, bc); };
+      auto make = [&](auto bc, const Raw& raw, auto ec) __attribute__((always_inline)) {
+        constexpr int b = decltype(bc)::value, e = decltype(ec)::value;
+        const float r = q[b][e] * softplus100_d1(raw.a[e]);
+        if constexpr (SAVE) *tp_elem(a.r_tp[l], tile, NBO, b, e, lane) = r;
+        return r;
+      };
+      auto next_fetch = [&]() __attribute__((always_inline)) {
+        if constexpr (l > 0) return chain_fetch(IC<(l > 0 ? l - 1 : 0)>{}, IC<0>{});
+        else return Raw{};
+      };
+      tp_gemm<NBO, KB, Stores<(SAVE ? 16 : 0)>>(qn, carry, fetch, make, next_fetch, ws, a.p.wpT[l], l > 0 ? a.p.wpT[l > 0 ? l - 1 : 0] : nullptr,
+                       l > 0 ? D::kb(l > 0 ? l - 1 : 0) : 0);
       if constexpr (l == D::SKIP) {
         // the part of d sdf / d (layer input) that goes straight to in0: park it in e_tp, layer 0 adds to it
 #pragma unroll
@@ -137,10 +197,6 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
           if constexpr (D::SKIP > 0) qn[b] += tp_load_blk(a.e_tp, tile, D::NB0, b, lane);
           tp_store_blk(qn[b], a.e_tp, tile, D::NB0, b, lane);
         }
-      } else {
-        constexpr int NC = D::nbo(l - 1);
-#pragma unroll
-        for (int b = 0; b < NC; ++b) q[b] = qn[b];
       }
     });
   }
@@ -161,76 +217,138 @@ struct GeoBwdArgs {
 template <class D>
 __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hf = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, hf = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
   constexpr int MAXB = D::MAXB;
+  float* cvec = lds + 2 * D::BUF_FLOATS;
 
-  // ---- tangent pass (second-order terms)
+  WStream ws{lds, D::BUF_FLOATS, 0, wave, lane};
+  ws.issue(a.p.wp[0], D::nbo(0), true);
+  if (tid < D::NBH * 32) cvec[tid] = a.p.w_sdf[tid];
+  __syncthreads();
+
+  f32x16 accA[MAXB], accB[MAXB];
+  Raw carry;
+
+  // HBM operands of input block kb of tangent layer l: the seed blocks, or (z, r) of the layer below
+  auto tan_fetch = [&](auto lc, auto kbc) __attribute__((always_inline)) {
+    constexpr int l = decltype(lc)::value, kb = decltype(kbc)::value;
+    Raw raw;
+    if constexpr (l == 0) {
+      raw.a = tp_load_blk(a.ebar_tp, tile, D::NB0, kb, lane);  // qb_0 == ebar (already in HBM)
+    } else if constexpr (l == D::SKIP && kb >= D::NB3) {
+      raw.a = tp_load_blk(a.ebar_tp, tile, D::NB0, kb - D::NB3, lane);
+    } else {
+      raw.a = tp_load_blk(a.z_tp[l > 0 ? l - 1 : 0], tile, D::nbo(l > 0 ? l - 1 : 0), kb, lane);
+      raw.b = tp_load_blk(a.r_tp[l > 0 ? l - 1 : 0], tile, D::nbo(l > 0 ? l - 1 : 0), kb, lane);
+    }
+    return raw;
+  };
+  // tangent epilogue of layer l on element e of block b:  qb_{l+1} = s'(z_l) v ;  zc_l = v r_l 100 (1 - s'(z_l))  (-> zb_tp[l])
+  auto tangent_elem = [&](auto lc, auto bc, auto ec, const float v, const Raw& raw) __attribute__((always_inline)) {
+    constexpr int l = decltype(lc)::value, b = decltype(bc)::value, e = decltype(ec)::value;
+    const float d1 = softplus100_d1(raw.a[e]);
+    *tp_elem(a.zb_tp[l], tile, D::nbo(l), b, e, lane) = v * raw.b[e] * (100.0f * (1.0f - d1));
+    return d1 * v;
+  };
+  auto bwd_fetch = [&](auto lc, auto bc) __attribute__((always_inline)) {
+    constexpr int l = decltype(lc)::value, b = decltype(bc)::value;
+    Raw raw;
+    raw.a = tp_load_blk(a.z_tp[l], tile, D::nbo(l), b, lane);
+    raw.b = tp_load_blk(a.zb_tp[l], tile, D::nbo(l), b, lane);
+    return raw;
+  };
+
+  // ---- tangent pass (second-order terms): v_l = W_l qb_l
+  carry = tan_fetch(IC<0>{}, IC<0>{});
+  static_for<0, D::NL>([&](auto lc) __attribute__((always_inline)) {
+    constexpr int l = decltype(lc)::value;
+    constexpr int KB = D::kb(l), NBO = D::nbo(l);
+    auto& in = pick<(l % 2) == 0>(accA, accB);  // v_{l-1}
+    auto& out = pick<(l % 2) == 0>(accB, accA);
+#pragma unroll
+    for (int b = 0; b < NBO; ++b) out[b] = f32x16_zero();
+    auto fetch = [&](auto kbc) __attribute__((always_inline)) { return tan_fetch(lc, kbc); };
+    auto make = [&](auto kbc, const Raw& raw, auto ec) __attribute__((always_inline)) {
+      constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
+      if constexpr (l == 0) {
+        return raw.a[e];
+      } else if constexpr (l == D::SKIP && kb >= D::NB3) {
+        *tp_elem(a.qb_tp[l], tile, KB, kb, e, lane) = raw.a[e];
+        return raw.a[e];
+      } else {
+        const float qn = tangent_elem(IC<(l > 0 ? l - 1 : 0)>{}, kbc, ec, in[kb][e], raw);
+        *tp_elem(a.qb_tp[l], tile, KB, kb, e, lane) = qn;
+        return qn;
+      }
+    };
+    constexpr bool last = l + 1 == D::NL;
+    auto next_fetch = [&]() __attribute__((always_inline)) {
+      if constexpr (!last) return tan_fetch(IC<(last ? l : l + 1)>{}, IC<0>{});
+      else return Raw{};
+    };
+    // stores per produced block: zc + qb (32) for blocks computed from the layer below, qb only (16) for the seed blocks of
+    // the skip layer, none for layer 0
+    using ST = Stores<(l == 0 ? 0 : 32), (l == 0 ? 0 : (l == D::SKIP ? 16 : 32)), (l == D::SKIP ? D::NB3 : (1 << 30))>;
+    tp_gemm<KB, NBO, ST>(out, carry, fetch, make, next_fetch, ws, a.p.wp[l], last ? a.p.wpT[D::NL] : a.p.wp[last ? l : l + 1],
+                     last ? D::NBH : D::nbo(last ? l : l + 1));
+  });
   {
-    f32x16 qb[MAXB];
-    tp_load<D::NB0>(qb, a.ebar_tp, tile, lane);
-    static_for<0, D::NL>([&](auto lc) __attribute__((always_inline)) {
-      constexpr int l = decltype(lc)::value;
-      constexpr int KB = D::kb(l), NBO = D::nbo(l);
-      if constexpr (l == D::SKIP) {
-#pragma unroll
-        for (int b = 0; b < D::NB0; ++b) qb[D::NB3 + b] = tp_load_blk(a.ebar_tp, tile, D::NB0, b, lane);
-      }
-      if constexpr (l > 0) tp_store<KB>(qb, a.qb_tp[l], tile, lane);  // (l == 0: qb_0 == ebar, already in HBM)
-      f32x16 v[MAXB];
-#pragma unroll
-      for (int b = 0; b < NBO; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[b][r] = 0.0f;
-      tp_gemm<KB, NBO>(v, qb, a.p.wp[l], lds, tid, lane);
-#pragma unroll
-      for (int b = 0; b < NBO; ++b) {
-        const f32x16 z = tp_load_blk(a.z_tp[l], tile, NBO, b, lane);
-        const f32x16 rr = tp_load_blk(a.r_tp[l], tile, NBO, b, lane);
-        f32x16 zc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float d1 = softplus100_d1(z[r]);
-          const float vv = v[b][r];
-          qb[b][r] = d1 * vv;
-          zc[r] = vv * rr[r] * (100.0f * (1.0f - d1));
-        }
-        tp_store_blk(zc, a.zb_tp[l], tile, NBO, b, lane);
-      }
+    // epilogue of the last hidden layer: qb_NL (tangent reaching the sdf row; only the weight gradient needs it) and zc_{NL-1}
+    auto& v = pick<(D::NL % 2) == 0>(accA, accB);
+    static_for<0, D::NBH>([&](auto bc) __attribute__((always_inline)) {
+      constexpr int b = decltype(bc)::value;
+      const Raw raw = tan_fetch(IC<D::NL>{}, bc);
+      static_for<0, 16>([&](auto ec) __attribute__((always_inline)) {
+        constexpr int e = decltype(ec)::value;
+        *tp_elem(a.qb_tp[D::NL], tile, D::NBH, b, e, lane) = tangent_elem(IC<D::NL - 1>{}, bc, ec, v[b][e], raw);
+      });
     });
-    tp_store<D::NBH>(qb, a.qb_tp[D::NL], tile, lane);
   }
 
-  // ---- backward pass
-  f32x16 ub[MAXB];
+  // ---- backward pass: ub_NL = w_s sdfbar + W_f^T featbar
   {
-    f32x16 fb[MAXB];
-    tp_load<D::NBF>(fb, a.featbar_tp, tile, lane);
     const float sb = a.sdfbar[tile * 32 + (lane & 31)];
 #pragma unroll
-    for (int b = 0; b < D::NBH; ++b)
+    for (int b = 0; b < D::NBH; ++b) {
+      const f32x16 w = tp_rowvec_blk(cvec, b, hf);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) ub[b][r] = a.p.w_sdf[b * 32 + tp_row(r, hf)] * sb;
-    tp_gemm<D::NBF, D::NBH>(ub, fb, a.p.wpT[D::NL], lds, tid, lane);
-  }
-  static_for<0, D::NL>([&](auto lc) __attribute__((always_inline)) {
-    constexpr int l = D::NL - 1 - decltype(lc)::value;
-    constexpr int KB = D::kb(l), NBO = D::nbo(l);
-    // zb_l = ub * s'(z_l) + zc_l   (in place in ub)
-#pragma unroll
-    for (int b = 0; b < NBO; ++b) {
-      const f32x16 z = tp_load_blk(a.z_tp[l], tile, NBO, b, lane);
-      const f32x16 zc = tp_load_blk(a.zb_tp[l], tile, NBO, b, lane);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) ub[b][r] = fmaf(ub[b][r], softplus100_d1(z[r]), zc[r]);
-      tp_store_blk(ub[b], a.zb_tp[l], tile, NBO, b, lane);
+      for (int i = 0; i < 16; ++i) accA[b][i] = w[i] * sb;
     }
-    f32x16 un[MAXB];
+    auto fetch = [&](auto bc) __attribute__((always_inline)) {
+      constexpr int b = decltype(bc)::value;
+      Raw raw;
+      raw.a = tp_load_blk(a.featbar_tp, tile, D::NBF, b, lane);
+      return raw;
+    };
+    auto make = [&](auto, const Raw& raw, auto ec) __attribute__((always_inline)) { return raw.a[decltype(ec)::value]; };
+    auto next_fetch = [&]() __attribute__((always_inline)) { return bwd_fetch(IC<D::NL - 1>{}, IC<0>{}); };
+    carry = fetch(IC<0>{});
+    tp_gemm<D::NBF, D::NBH, Stores<0>>(accA, carry, fetch, make, next_fetch, ws, a.p.wpT[D::NL], a.p.wpT[D::NL - 1], D::kb(D::NL - 1));
+  }
+  static_for<0, D::NL>([&](auto sc) __attribute__((always_inline)) {
+    constexpr int step = decltype(sc)::value;
+    constexpr int l = D::NL - 1 - step;
+    constexpr int KB = D::kb(l), NBO = D::nbo(l);
+    auto& ub = pick<(step % 2) == 0>(accA, accB);
+    auto& un = pick<(step % 2) == 0>(accB, accA);
 #pragma unroll
-    for (int b = 0; b < KB; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) un[b][r] = 0.0f;
-    tp_gemm<NBO, KB>(un, ub, a.p.wpT[l], lds, tid, lane);
+    for (int b = 0; b < KB; ++b) un[b] = f32x16_zero();
+    // zb_l = ub * s'(z_l) + zc_l
+    auto fetch = [&](auto bc) __attribute__((always_inline)) { return bwd_fetch(IC<l>{}, bc); };
+    auto make = [&](auto bc, const Raw& raw, auto ec) __attribute__((always_inline)) {
+      constexpr int b = decltype(bc)::value, e = decltype(ec)::value;
+      const float zb = fmaf(ub[b][e], softplus100_d1(raw.a[e]), raw.b[e]);
+      *tp_elem(a.zb_tp[l], tile, NBO, b, e, lane) = zb;
+      return zb;
+    };
+    auto next_fetch = [&]() __attribute__((always_inline)) {
+      if constexpr (l > 0) return bwd_fetch(IC<(l > 0 ? l - 1 : 0)>{}, IC<0>{});
+      else return Raw{};
+    };
+    tp_gemm<NBO, KB, Stores<16>>(un, carry, fetch, make, next_fetch, ws, a.p.wpT[l], l > 0 ? a.p.wpT[l > 0 ? l - 1 : 0] : nullptr,
+                     l > 0 ? D::kb(l > 0 ? l - 1 : 0) : 0);
     if constexpr (l == D::SKIP) {
 #pragma unroll
       for (int b = 0; b < D::NB0; ++b) tp_store_blk(un[D::NB3 + b], a.in0bar_tp, tile, D::NB0, b, lane);
@@ -241,10 +359,6 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
         if constexpr (D::SKIP > 0) un[b] += tp_load_blk(a.in0bar_tp, tile, D::NB0, b, lane);
         tp_store_blk(un[b], a.in0bar_tp, tile, D::NB0, b, lane);
       }
-    } else {
-      constexpr int NC = D::nbo(l - 1);
-#pragma unroll
-      for (int b = 0; b < NC; ++b) ub[b] = un[b];
     }
   });
 }

@@ -1,94 +1,184 @@
 // sdfhip — MFMA core shared by the fused geometry / colour network kernels (gfx950).
 //
-// One workgroup = 4 waves = 128 points; one wave per SIMD, each wave owns a 32-point tile whose
-// activations stay in VGPRs in tile-packed (TP) order across all layers.  Per layer the effective
-// (weight-norm folded) weight matrix streams L2 -> LDS in 16-k-step chunks shared by the 4 waves
-// (double buffered, one barrier per chunk) and is consumed as the MFMA A operand:
+// One workgroup = 4 waves = 128 points; one wave per SIMD, each wave owns a 32-point tile.  A fused network is a
+// sequence of "gemms"   acc_out[0..NBO) (+)= W (NBO x KB blocks) * B[0..KB)   where the k-th 32-wide input block B[kb]
+// is PRODUCED just in time from the previous layer's accumulators by a small functor (activation, derivative scaling,
+// loads of saved tensors, stores of tensors the backward needs):
 //
-//   acc[ob] (+)= v_mfma_f32_32x32x2_f32( A = Wp[kb][ob][r][lane],  B = H[kb][r] (own register) )
+//   for kb in 0..KB (fully unrolled, every register index a compile-time constant):
+//       wait for weight chunk kb in LDS (s_waitcnt vmcnt(0) ; s_barrier)
+//       start the LDS-DMA of the next chunk (possibly the first chunk of the NEXT gemm: the stream never drains)
+//       issue the global loads the producer of block kb + 1 needs
+//       16 x NBO  v_mfma_f32_32x32x2_f32  with A = weight fragment from LDS (ds_read_b128: 4 k-steps per read),
+//                                               B = blk[r] (own register, accumulator layout of the previous gemm)
+//       ... with the 16 elements of block kb + 1 produced between the MFMA groups of the second half of the step
 //
-// fp32 in / fp32 accumulate: exact-f32 numerics (the reference trains in fp32, parity target 1e-5 on SDF).
+// So activations never leave the register file between layers, never exist as a full 128-register copy (the previous
+// accumulators ARE the activations, converted 16 registers at a time) and the weights move HBM/L2 -> LDS by DMA
+// (global_load_lds_dwordx4) without passing through registers.  fp32 in / fp32 accumulate: exact-f32 numerics
+// (the reference trains in fp32; parity target 1e-5 on SDF).
+//
+// Weight chunk layout (pack_kernel):  Wp[kb][ob][r4][lane][j]  holds  W[out = 32 ob + (lane & 31)][k = 32 kb + tp_row(4 r4 + j, lane >> 5)]
 #pragma once
 #include "common.h"
 
-// floats in one weight chunk (all NBO output blocks of one 32-wide k block)
-template <int NBO>
-struct Chunk {
-  static constexpr int kFloats = NBO * 1024;
+template <int N>
+using IC = std::integral_constant<int, N>;
+
+constexpr int kChunkBlockFloats = 1024;  // one (k block, out block) pair: 32 x 32 weights
+
+struct WStream {
+  float* lds;        // two chunk buffers of buf_floats each
+  int buf_floats;
+  int cur;           // buffer holding the chunk that the next mfma step consumes
+  int wave, lane;
+
+  // Start the DMA of `nbo` KiB-blocks from gsrc into the buffer that is NOT current.  Every wave copies a quarter.
+  SDFHIP_D void issue(const float* __restrict__ gsrc, const int nbo, const bool into_current = false) {
+    float* dst = lds + ((into_current ? cur : cur ^ 1) * buf_floats);
+    for (int i = 0; i < nbo; ++i) {
+      const int piece = i * 4 + wave;  // 1 KiB per wave instruction: lane l supplies bytes [16 l, 16 l + 16)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + piece * 256 + lane * 4),
+                                       (__attribute__((address_space(3))) void*)(dst + piece * 256), 16, 0, 0);
+    }
+  }
+  // The weight chunk about to be consumed has landed in LDS for every wave, and every wave is done reading the other
+  // buffer.  NEWER = number of vector-memory operations this wave issued AFTER the chunk's DMA (the producer's stores):
+  // vmcnt retires in issue order, so waiting for "at most NEWER outstanding" covers the DMA without draining those stores.
+  // A bare s_barrier (no workgroup release fence) keeps the compiler from adding its own vmcnt(0) in front of it.
+  template <int NEWER>
+  SDFHIP_D void wait_sync() {
+    static_assert(NEWER >= 0 && NEWER < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEWER) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  SDFHIP_D const float* current() const { return lds + cur * buf_floats + lane * 4; }
+  SDFHIP_D void flip() { cur ^= 1; }
 };
 
-// acc[0..NBO) += W (packed at wp) * H[0..KB)    — all 4 waves of the workgroup must call this together.
-// The k-block loop is a real loop: after block H[0] is consumed the register tile is rotated by one block
-// (KB v_mov groups, hidden under the 16*NBO MFMAs) so that every register index stays a compile-time constant;
-// after KB iterations H is back in its original order.
-template <int KB, int NBO, int MAXA, int MAXH>
-SDFHIP_D void tp_gemm(f32x16 (&acc)[MAXA], f32x16 (&H)[MAXH], const float* __restrict__ wp, float* lds,
-                      const int tid, const int lane) {
-  static_assert(KB <= MAXH && NBO <= MAXA, "register tile too small");
-  constexpr int CH = NBO * 1024;
-  f32x4 st[NBO];
-  {
-    const f32x4* src = reinterpret_cast<const f32x4*>(wp);
-#pragma unroll
-    for (int i = 0; i < NBO; ++i) st[i] = src[i * 256 + tid];
-    f32x4* dst = reinterpret_cast<f32x4*>(lds);
-#pragma unroll
-    for (int i = 0; i < NBO; ++i) dst[i * 256 + tid] = st[i];
+// What a producer fetched from HBM for one input block (up to two TP blocks, e.g. z_l and zc_l); unused members cost nothing.
+struct Raw {
+  f32x16 a, b;
+};
+struct NoFetch {  // producer without an HBM fetch
+  template <class... K>
+  SDFHIP_D Raw operator()(K...) const {
+    return Raw{};
   }
-  __syncthreads();
-#pragma unroll 1
-  for (int kb = 0; kb < KB; ++kb) {
-    const float* cur = lds + (kb & 1) * CH + lane;
-    const bool more = kb + 1 < KB;
-    if (more) {
-      const f32x4* src = reinterpret_cast<const f32x4*>(wp + (size_t)(kb + 1) * CH);
+};
+
+// acc[0..NBO) += W * B with B[kb] produced just in time.  The producer of a block is split so that neither HBM latency nor
+// its VALU work ever sits in front of the matrix pipe (one wave per SIMD: nothing else would cover it):
+//   fetch(IC<kb>) -> Raw               global loads block kb needs; issued at the head of step kb - 1, pinned there
+//   make(IC<kb>, Raw, IC<e>) -> float  element e of the block (VALU + the element's stores); the 16 elements of block
+//                                      kb + 1 are written, two at a time, between the MFMA groups of the SECOND half of
+//                                      step kb: their operands were fetched half a step (~4000 cycles) earlier
+//   next_fetch() -> Raw                fetch of block 0 of the FOLLOWING gemm, issued at the head of this gemm's last step;
+//                                      it travels in `carry`, which on entry holds this gemm's own block-0 operands
+//   ST::at(kb)                         number of global stores make(IC<kb>, ..) issues (see WStream::wait_sync)
+// wp: this gemm's packed weights (first chunk already in flight / landed in the current buffer).
+// next_wp / next_nbo: first chunk of the gemm that follows (nullptr: none).
+// global stores make(IC<kb>, ..) issues for one block: A for blocks kb < FROM, B for the rest
+template <int A, int B = A, int FROM = 1 << 30>
+struct Stores {
+  static constexpr int at(int kb) { return kb < FROM ? A : B; }
+};
+
+template <int KB, int NBO, class ST, int MAXA, class Fetch, class Make, class NextFetch>
+SDFHIP_D void tp_gemm(f32x16 (&acc)[MAXA], Raw& carry, Fetch&& fetch, Make&& make, NextFetch&& next_fetch, WStream& ws,
+                      const float* __restrict__ wp, const float* __restrict__ next_wp, const int next_nbo) {
+  static_assert(NBO <= MAXA, "accumulator tile too small");
+  // r1: operands of the block made during the current step; r2: operands of the block after that (in flight)
+  Raw r1 = carry, r2;
+  if constexpr (KB > 1) r2 = fetch(IC<(KB > 1 ? 1 : 0)>{});
+  f32x16 blk;
+  static_for<0, 16>([&](auto ec) __attribute__((always_inline)) { blk[decltype(ec)::value] = make(IC<0>{}, r1, ec); });
+  static_for<0, KB>([&](auto kbc) __attribute__((always_inline)) {
+    constexpr int kb = decltype(kbc)::value;
+    constexpr bool more = kb + 1 < KB;
+    ws.template wait_sync<ST::at(kb)>();
+    if constexpr (more) ws.issue(wp + (size_t)(kb + 1) * NBO * kChunkBlockFloats, NBO);
+    else if (next_wp != nullptr) ws.issue(next_wp, next_nbo);
+    r1 = r2;
+    if constexpr (kb + 2 < KB) r2 = fetch(IC<(kb + 2 < KB ? kb + 2 : 0)>{});
+    else if constexpr (!more) carry = next_fetch();
+    __builtin_amdgcn_sched_barrier(0);  // DMA + loads stay at the head of the step
+    const float* cur = ws.current();
+    f32x16 nxt;
+    if constexpr (more)
+      static_for<0, 16>([&](auto ec) __attribute__((always_inline)) {
+        nxt[decltype(ec)::value] = make(IC<(more ? kb + 1 : 0)>{}, r1, ec);
+      });
 #pragma unroll
-      for (int i = 0; i < NBO; ++i) st[i] = src[i * 256 + tid];
+    for (int r4 = 0; r4 < 4; ++r4) {
+      f32x4 a[NBO];
+#pragma unroll
+      for (int ob = 0; ob < NBO; ++ob) a[ob] = *reinterpret_cast<const f32x4*>(cur + (ob * 4 + r4) * 256);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ob = 0; ob < NBO; ++ob)
+          acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ob][j], blk[r4 * 4 + j], acc[ob], 0, 0, 0);
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float b = H[0][r];
-#pragma unroll
-      for (int ob = 0; ob < NBO; ++ob) {
-        const float a = cur[(ob * 16 + r) * 64];
-        acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[ob], 0, 0, 0);
-      }
-    }
-    if (more) {
-      f32x4* dst = reinterpret_cast<f32x4*>(lds + ((kb + 1) & 1) * CH);
-#pragma unroll
-      for (int i = 0; i < NBO; ++i) dst[i * 256 + tid] = st[i];
-    }
-    __syncthreads();
-    const f32x16 h0 = H[0];
-#pragma unroll
-    for (int i = 0; i + 1 < KB; ++i) H[i] = H[i + 1];
-    H[KB - 1] = h0;
-  }
+    ws.flip();
+    if constexpr (more) blk = nxt;
+  });
+  if constexpr (KB == 1) carry = next_fetch();
 }
 
-// TP load / store of NB blocks for one tile
-template <int NB, int MAXH>
-SDFHIP_D void tp_load(f32x16 (&H)[MAXH], const float* __restrict__ base, const int64_t tile, const int lane) {
-  const float* p = base + (size_t)tile * NB * 1024 + lane;
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) H[b][r] = p[(b * 16 + r) * 64];
+// Wave-uniform GLOBAL pointer: pins a pointer the compiler cannot prove uniform into scalar registers, so that the global
+// loads / stores below use the SGPR-base + 32-bit VGPR offset + immediate form.  One shared offset register (lane * 4) then
+// serves every tensor and every element; 64-bit per-element addresses in VGPRs cost the fused kernels their register budget.
+// The result is typed address_space(1): after the integer round trip the compiler could no longer infer "global" and
+// would fall back to flat_load / flat_store, which also tick lgkmcnt and so stall the LDS -> MFMA stream.
+typedef __attribute__((address_space(1))) float gfloat;
+typedef __attribute__((address_space(1))) const float gcfloat;
+SDFHIP_D gfloat* uniform_gptr(const float* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return reinterpret_cast<gfloat*>(((uint64_t)hi << 32) | lo);
 }
-template <int NB, int MAXH>
-SDFHIP_D void tp_store(const f32x16 (&H)[MAXH], float* __restrict__ base, const int64_t tile, const int lane) {
-  float* p = base + (size_t)tile * NB * 1024 + lane;
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) p[(b * 16 + r) * 64] = H[b][r];
+// first element of TP block b of the wave's tile:  A[tile][nb blocks][16][64]
+SDFHIP_D gfloat* tp_block_ptr(const float* __restrict__ base, const int64_t tile, const int nb, const int b) {
+  return uniform_gptr(base + ((size_t)tile * nb + b) * 1024);
 }
-// per-feature vector (natural order, padded to NB*32) broadcast into TP registers
-template <int NB, int MAXH>
-SDFHIP_D void tp_load_rowvec(f32x16 (&H)[MAXH], const float* __restrict__ v, const int hf) {
+// element e of TP block b: address of (tile, nb, b, e, lane)
+SDFHIP_D gfloat* tp_elem(float* __restrict__ base, const int64_t tile, const int nb, const int b, const int e, const int lane) {
+  return tp_block_ptr(base, tile, nb, b) + ((unsigned)lane + (unsigned)e * 64u);
+}
+
+// one TP block (16 registers) load / store
+SDFHIP_D f32x16 tp_load_blk(const float* __restrict__ base, const int64_t tile, const int nb, const int b, const int lane) {
+  const gfloat* p = tp_block_ptr(base, tile, nb, b);
+  f32x16 v;
 #pragma unroll
-  for (int b = 0; b < NB; ++b)
+  for (int r = 0; r < 16; ++r) v[r] = p[(unsigned)lane + (unsigned)r * 64u];
+  return v;
+}
+SDFHIP_D void tp_store_blk(const f32x16 v, float* __restrict__ base, const int64_t tile, const int nb, const int b, const int lane) {
+  gfloat* p = tp_block_ptr(base, tile, nb, b);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) H[b][r] = v[b * 32 + tp_row(r, hf)];
+  for (int r = 0; r < 16; ++r) p[(unsigned)lane + (unsigned)r * 64u] = v[r];
+}
+// per-feature vector (natural order, in LDS) broadcast into one TP block: element r <-> feature 32 b + tp_row(r, hf)
+SDFHIP_D f32x16 tp_rowvec_blk(const float* v, const int b, const int hf) {
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = v[b * 32 + tp_row(r, hf)];
+  return o;
+}
+SDFHIP_D f32x16 f32x16_zero() {
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+  return o;
+}
+
+// compile-time ping-pong selection
+template <bool FIRST, class T>
+SDFHIP_D T& pick(T& a, T& b) {
+  if constexpr (FIRST) return a;
+  else return b;
 }

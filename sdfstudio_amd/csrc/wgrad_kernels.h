@@ -1,6 +1,6 @@
 // sdfhip — weight packing and weight-gradient kernels for the fused networks.
 //
-//  pack_kernel    natural [out][in] fp32 weights -> MFMA A-operand order  Wp[kb][ob][reg][lane]
+//  pack_kernel    natural [out][in] fp32 weights -> MFMA A-operand order  Wp[kb][ob][r4][lane][j]
 //                 (and the transposed pack used by the chain / data-backward passes)
 //  wgrad_kernel   split-K GEMM over points:  C[o][i] = sum_p A[p][o] * B[p][i]  with A, B tile-packed in HBM,
 //                 one workgroup per (point-split, 8x8 block macro tile), tiles transposed through LDS; fp32 MFMA 32x32x2.
@@ -29,7 +29,9 @@ static __global__ void pack_kernel(const float* __restrict__ theta, const PackDe
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int total = d.kb * d.nbo * 1024;
   if (idx >= total) return;
-  const int lane = idx & 63, reg = (idx >> 6) & 15, ob = (idx >> 10) % d.nbo, kb = (idx >> 10) / d.nbo;
+  // chunk layout [kb][ob][r4][lane][j] (mlp_core.h): one ds_read_b128 per lane yields the A operands of 4 consecutive k steps
+  const int j = idx & 3, lane = (idx >> 2) & 63, r4 = (idx >> 8) & 3, ob = (idx >> 10) % d.nbo, kb = (idx >> 10) / d.nbo;
+  const int reg = r4 * 4 + j;
   const int o = ob * 32 + (lane & 31);             // MFMA A-operand row  (output feature)
   const int k = kb * 32 + tp_row(reg, lane >> 5);  // contraction index in TP order
   const int32_t* rowmap = maps + d.rowmap_off;
