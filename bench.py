@@ -211,8 +211,14 @@ def main():
         if kn > 0:
             avg_s = kt_ms / kn * 1e-3
             achieved = 2 * g * P / avg_s / 1e12
+            traffic = None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the bench)
+            tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as fh:
+                    tj = json.load(fh)
+                traffic = {"hbm_bytes_per_launch": tj["hbm_read_bytes"] + tj["hbm_write_bytes"], "source": tj["source"]}
             roof = {"kernel": "geo_bwd_kernel", "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "avg_launch_ms": round(kt_ms / kn, 4), "launches": kn,
                     "algorithmic": f"2G = {2 * g} flop per ray-sample x {P} ray-samples per launch"}
         kernels = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] / args.steps} for k, v in prof.items()}

@@ -1,8 +1,8 @@
 #!/bin/bash
-# A/B two builds of libsdfhip on the SAME GPU box (timings are not comparable across boxes): tools/ab.sh <libA> <libB> [steps]
-A=$1; B=$2; STEPS=${3:-8}
+# A/B builds of libsdfhip on the SAME GPU box (timings are not comparable across boxes): tools/ab.sh <steps> <libA> <libB> ...
+STEPS=$1; shift
 for rep in 1 2; do
-  for L in "$A" "$B"; do
+  for L in "$@"; do
     SDFHIP_LIB=$L python bench.py --steps $STEPS --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); k=d['kernels']
 print('$L'.split('/')[-1], 'ms/step', d['ms_per_step'], {n:round(k[n]['ms_per_step'],2) for n in ('geo_fwd_kernel','geo_bwd_kernel','col_fwd_kernel','col_bwd_kernel','wgrad_kernel')})"
