@@ -127,11 +127,28 @@ int sdfhip_proposal_backward(const SdfHipGridCfg* grid, const float* table, cons
  * jitter: [n_rays] single-jitter draw (training) or NULL (eval).  bins: [n_rays, S+1]; starts/ends [n_rays, S]. */
 int sdfhip_sample_spaced(const float* nears, const float* fars, const float* jitter, int64_t n_rays, int32_t n_samples,
                          float* bins, float* starts, float* ends, sdfhip_stream_t stream);
+/* UniformSampler (ray_samplers.py:130-151): identity spacing, euclidean = x far + (1 - x) near.  Same arguments. */
+int sdfhip_sample_uniform(const float* nears, const float* fars, const float* jitter, int64_t n_rays, int32_t n_samples,
+                          float* bins, float* starts, float* ends, sdfhip_stream_t stream);
 /* PDFSampler(include_original=False, single_jitter) (ray_samplers.py:275-370) applied to weights^anneal
  * (ProposalNetworkSampler :562).  Outputs are constants w.r.t. autograd (bins.detach(), :358). */
 int sdfhip_sample_pdf(const float* weights, const float* bins_in, const float* nears, const float* fars,
                       const float* jitter, int64_t n_rays, int32_t s_in, int32_t s_out, float anneal,
                       float histogram_padding, float* bins_out, float* starts, float* ends, sdfhip_stream_t stream);
+
+/* One up-sampling step of NeuSSampler.generate_ray_samples (ray_samplers.py:851-886), UniformSampler spacing:
+ *   sdf = gather(cat(sdf_a, sdf_b), index) (:864-868; index == NULL, s_b == 0 on the first step)
+ *   alpha = rendering_sdf_with_fixed_inv_s(bins_in, sdf, inv_s) (:899-944) -> weights (rays.py:194-208) with a trailing 0 (:873)
+ *   new samples = PDFSampler(histogram_padding = 1e-5, include_original = False)(weights, n_new) (:875-880, :303-358)
+ *   merged = merge_ray_samples(current, new) (:757-786): sorted bins + the index into cat(starts_current, starts_new)
+ * bins_in [N,S+1] (S = s_a + s_b), jitter [N] or NULL.  Outputs: sdf_merged [N,S]; new_bins [N,n_new+1]; new_starts /
+ * new_ends [N,n_new] euclidean (the caller evaluates get_sdf there and passes the result as the next step's sdf_b);
+ * merged_bins [N,S+n_new+1]; merged_index [N,S+n_new] (int32); merged_starts / merged_ends [N,S+n_new] euclidean.
+ * All outputs are constants w.r.t. autograd (bins.detach(), :771). */
+int sdfhip_neus_upsample(const float* bins_in, const float* sdf_a, const float* sdf_b, const int32_t* index, const float* nears,
+                         const float* fars, const float* jitter, int64_t n_rays, int32_t s_a, int32_t s_b, int32_t n_new,
+                         float inv_s, float* sdf_merged, float* new_bins, float* new_starts, float* new_ends, float* merged_bins,
+                         int32_t* merged_index, float* merged_starts, float* merged_ends, sdfhip_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------- weights + renderers
  * RaySamples.get_weights (cameras/rays.py:146-167) and its backward. */

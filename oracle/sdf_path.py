@@ -384,6 +384,92 @@ def proposal_sampler(origins, dirs, nears, fars, p: Params, cfg: ModelCfg, annea
     return bins, starts, ends, weights_list, bins_list
 
 
+# ----------------------------------------------------------------------------- NeuS hierarchical sampler
+def uniform_to_euclidean(bins: torch.Tensor, nears: torch.Tensor, fars: torch.Tensor) -> torch.Tensor:
+    """ray_samplers.py:115-117 with UniformSampler's identity spacing_fn (:130-151)."""
+    return bins * fars[:, None] + (1 - bins) * nears[:, None]
+
+
+def neus_upsample_alpha(sdf: torch.Tensor, deltas: torch.Tensor, inv_s: float) -> torch.Tensor:
+    """ray_samplers.py:899-944 rendering_sdf_with_fixed_inv_s.  sdf [N,S], deltas [N,S] -> alpha [N,S-1]."""
+    prev_sdf, next_sdf = sdf[:, :-1], sdf[:, 1:]
+    d = deltas[:, :-1]
+    mid_sdf = (prev_sdf + next_sdf) * 0.5
+    cos_val = (next_sdf - prev_sdf) / (d + 1e-5)
+    prev_cos = torch.cat([torch.zeros_like(cos_val[:, :1]), cos_val[:, :-1]], dim=-1)
+    cos_val = torch.minimum(prev_cos, cos_val).clip(-1e3, 0.0)
+    prev_esti = mid_sdf - cos_val * d * 0.5
+    next_esti = mid_sdf + cos_val * d * 0.5
+    prev_cdf = torch.sigmoid(prev_esti * inv_s)
+    next_cdf = torch.sigmoid(next_esti * inv_s)
+    return (prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)
+
+
+def merge_bins(bins_1: torch.Tensor, bins_2: torch.Tensor):
+    """ray_samplers.py:757-786 merge_ray_samples on spacing bins [N,S1+1], [N,S2+1] -> merged bins [N,S1+S2+1] and the
+    sorted index into cat(starts_1, starts_2)."""
+    ends = torch.maximum(bins_1[:, -1:], bins_2[:, -1:])
+    merged, index = torch.sort(torch.cat([bins_1[:, :-1], bins_2[:, :-1]], -1), -1)
+    return torch.cat([merged, ends], dim=-1), index
+
+
+def neus_sampler(origins, dirs, nears, fars, sdf_fn, num_samples: int = 64, num_samples_importance: int = 64,
+                 num_upsample_steps: int = 4, base_variance: float = 64.0, rand: Optional[List[torch.Tensor]] = None):
+    """ray_samplers.py:815-897 NeuSSampler.generate_ray_samples.
+
+    sdf_fn(starts [N,S]) -> sdf [N,S] evaluates the field at the frustum START positions (sdf_field.py:412-418).
+    rand: [t_rand0, u_rand1, ..., u_rand_steps] single-jitter draws [N,1] (training) or None (eval).
+    Returns the final spacing bins [N, num_samples + num_samples_importance + 1] and their euclidean starts / ends.
+    """
+    n = origins.shape[0]
+    bins = initial_bins(n, num_samples, None if rand is None else rand[0], origins.dtype)
+    n_new = num_samples_importance // num_upsample_steps
+    sdf = None
+    new_bins, index = bins, None
+    for it in range(num_upsample_steps):
+        eu_new = uniform_to_euclidean(new_bins, nears, fars)
+        with torch.no_grad():
+            new_sdf = sdf_fn(eu_new[:, :-1])
+        if index is not None:
+            sdf = torch.gather(torch.cat([sdf, new_sdf], -1), 1, index)
+        else:
+            sdf = new_sdf
+        eu = uniform_to_euclidean(bins, nears, fars)
+        alphas = neus_upsample_alpha(sdf, eu[:, 1:] - eu[:, :-1], base_variance * 2**it)
+        weights, _ = weights_from_alphas(alphas)
+        weights = torch.cat([weights, torch.zeros_like(weights[:, :1])], dim=1)
+        new_bins = pdf_sample(weights, bins, n_new, None if rand is None else rand[1 + it], histogram_padding=1e-5)
+        bins, index = merge_bins(bins, new_bins)
+    eu = uniform_to_euclidean(bins, nears, fars)
+    return bins, eu[:, :-1], eu[:, 1:]
+
+
+def neus_forward(origins, dirs, cam_idx, p: Params, cfg: "ModelCfg", cos_anneal_ratio: float = 1.0, rand=None, mask=None,
+                 training=True, num_samples: int = 64, num_samples_importance: int = 64, num_upsample_steps: int = 4,
+                 base_variance: float = 64.0, samples=None):
+    """models/neus.py:94-104 + base_surface_model.py:292-365 (background_model == 'none', black background).
+    samples = (bins, starts, ends) bypasses the sampler (parity of the field / renderer on identical samples: four rounds of
+    inverse-CDF resampling with histogram_padding 1e-5 are ill-conditioned in fp32, see tests)."""
+    n = origins.shape[0]
+    nears = torch.full((n,), cfg.near, dtype=origins.dtype)
+    fars = torch.full((n,), cfg.far, dtype=origins.dtype)
+
+    def sdf_fn(starts):
+        pos = origins[:, None, :] + dirs[:, None, :] * starts[..., None]  # NOT contracted (sdf_field.py:412-418)
+        return geo_network(pos.reshape(-1, 3), p, cfg.field, mask)[:, 0].view(starts.shape)
+
+    if samples is None:
+        bins, starts, ends = neus_sampler(origins, dirs, nears, fars, sdf_fn, num_samples, num_samples_importance,
+                                          num_upsample_steps, base_variance, rand)
+    else:
+        bins, starts, ends = samples
+    fo = field_outputs(origins, dirs, starts, ends - starts, cam_idx, p, cfg.field, mask, cos_anneal_ratio, training)
+    weights, trans = weights_from_alphas(fo["alpha"])
+    rgb, depth, normal, acc = render(weights, fo["rgb"], fo["normal"], starts, ends)
+    return {"rgb": rgb, "depth": depth, "normal": normal, "accumulation": acc, "weights": weights, "field": fo,
+            "starts": starts, "ends": ends, "bins": bins}
+
+
 # ----------------------------------------------------------------------------- losses
 def _blur_stepfun(x, y, r):
     """model_components/losses.py:116-128."""

@@ -70,6 +70,11 @@ _SIGNATURES = {
                                          c_float_p, c_float_p, ctypes.c_void_p]),
     "sdfhip_sample_spaced": (c_i32, [c_float_p, c_float_p, c_float_p, c_i64, c_i32, c_float_p, c_float_p, c_float_p,
                                      ctypes.c_void_p]),
+    "sdfhip_sample_uniform": (c_i32, [c_float_p, c_float_p, c_float_p, c_i64, c_i32, c_float_p, c_float_p, c_float_p,
+                                      ctypes.c_void_p]),
+    "sdfhip_neus_upsample": (c_i32, [c_float_p, c_float_p, c_float_p, ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_i64, c_i32,
+                                     c_i32, c_i32, c_f32, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_void_p,
+                                     c_float_p, c_float_p, ctypes.c_void_p]),
     "sdfhip_sample_pdf": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_i64, c_i32, c_i32, c_f32, c_f32,
                                   c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
     "sdfhip_density_weights_forward": (c_i32, [c_float_p, c_float_p, c_float_p, c_i64, c_i32, c_float_p, ctypes.c_void_p]),

@@ -617,7 +617,7 @@ static void run_wgrad(const SdfHipField* f, const FieldWs& w, const WgradArgs& b
   r.b_off = b_off;
   r.accumulate = 0;
   const int total = r.rows * r.cols;
-  { ProfScope ps_(PS_WREDUCE, s); wreduce_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(r); }
+  { ProfScope ps_(PS_WREDUCE, s); wreduce_kernel<<<(unsigned)((total + 63) / 64), 256, 0, s>>>(r); }
 }
 
 extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
@@ -860,8 +860,8 @@ extern "C" int sdfhip_proposal_backward(const SdfHipGridCfg* grid, const float* 
 }
 
 // ------------------------------------------------------------------------------------------------ samplers
-extern "C" int sdfhip_sample_spaced(const float* nears, const float* fars, const float* jitter, int64_t n_rays, int32_t n_samples,
-                                    float* bins, float* starts, float* ends, sdfhip_stream_t stream) {
+static int sample_spaced_impl(const float* nears, const float* fars, const float* jitter, int64_t n_rays, int32_t n_samples, int uniform,
+                              float* bins, float* starts, float* ends, sdfhip_stream_t stream) {
   SDFHIP_REQUIRE(nears && fars && bins && starts && ends && n_samples >= 1, "sample_spaced: bad argument");
   BinsArgs a;
   a.nears = nears;
@@ -869,6 +869,7 @@ extern "C" int sdfhip_sample_spaced(const float* nears, const float* fars, const
   a.jitter = jitter;
   a.N = (int)n_rays;
   a.S = n_samples;
+  a.uniform = uniform;
   a.bins = bins;
   a.starts = starts;
   a.ends = ends;
@@ -877,6 +878,14 @@ extern "C" int sdfhip_sample_spaced(const float* nears, const float* fars, const
   { ProfScope ps_(PS_SAMPLERS, (hipStream_t)stream); spaced_bins_kernel<<<(unsigned)((total + 255) / 256), 256, 0, (hipStream_t)stream>>>(a); }
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
+}
+extern "C" int sdfhip_sample_spaced(const float* nears, const float* fars, const float* jitter, int64_t n_rays, int32_t n_samples,
+                                    float* bins, float* starts, float* ends, sdfhip_stream_t stream) {
+  return sample_spaced_impl(nears, fars, jitter, n_rays, n_samples, 0, bins, starts, ends, stream);
+}
+extern "C" int sdfhip_sample_uniform(const float* nears, const float* fars, const float* jitter, int64_t n_rays, int32_t n_samples,
+                                     float* bins, float* starts, float* ends, sdfhip_stream_t stream) {
+  return sample_spaced_impl(nears, fars, jitter, n_rays, n_samples, 1, bins, starts, ends, stream);
 }
 
 #define SDFHIP_DISPATCH_C(S, CALL)                                      \
@@ -914,6 +923,51 @@ extern "C" int sdfhip_sample_pdf(const float* weights, const float* bins_in, con
   if (n_rays == 0) return 0;
   const unsigned grid = (unsigned)((n_rays + 3) / 4);
   { ProfScope ps_(PS_SAMPLERS, (hipStream_t)stream); SDFHIP_DISPATCH_C(s_in, (pdf_sample_kernel<C><<<grid, 256, 0, (hipStream_t)stream>>>(a))); }
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfhip_neus_upsample(const float* bins_in, const float* sdf_a, const float* sdf_b, const int32_t* index, const float* nears,
+                                    const float* fars, const float* jitter, int64_t n_rays, int32_t s_a, int32_t s_b, int32_t n_new,
+                                    float inv_s, float* sdf_merged, float* new_bins, float* new_starts, float* new_ends,
+                                    float* merged_bins, int32_t* merged_index, float* merged_starts, float* merged_ends,
+                                    sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(bins_in && sdf_a && nears && fars && sdf_merged && new_bins && new_starts && new_ends && merged_bins && merged_index &&
+                     merged_starts && merged_ends,
+                 "neus_upsample: null argument");
+  SDFHIP_REQUIRE((s_b == 0) == (index == nullptr) && (s_b == 0 || sdf_b != nullptr), "neus_upsample: sdf_b / index must come together");
+  const int S = s_a + s_b;
+  SDFHIP_REQUIRE(S >= 2 && n_new >= 1 && n_new <= kNeusUpMaxNew && S + n_new + 1 <= 64 * kMaxPerLane,
+                 "neus_upsample: %d + %d samples unsupported (new <= %d, total <= %d)", S, n_new, kNeusUpMaxNew, 64 * kMaxPerLane - 1);
+  NeusUpArgs a;
+  a.bins_in = bins_in;
+  a.sdf_a = sdf_a;
+  a.sdf_b = sdf_b;
+  a.index = index;
+  a.nears = nears;
+  a.fars = fars;
+  a.jitter = jitter;
+  a.N = (int)n_rays;
+  a.Sa = s_a;
+  a.Sb = s_b;
+  a.n_new = n_new;
+  a.inv_s = inv_s;
+  a.histogram_padding = 1e-5f;  // NeuSSampler's PDFSampler (ray_samplers.py:843-847)
+  a.eps = 1e-5f;
+  const int nbins = n_new + 1;
+  a.u_end = (float)(1.0 - 1.0 / (double)nbins);
+  a.u_center = (float)(1.0 / (2.0 * (double)nbins));
+  a.sdf_merged = sdf_merged;
+  a.new_bins = new_bins;
+  a.new_starts = new_starts;
+  a.new_ends = new_ends;
+  a.merged_bins = merged_bins;
+  a.merged_index = merged_index;
+  a.merged_starts = merged_starts;
+  a.merged_ends = merged_ends;
+  if (n_rays == 0) return 0;
+  const unsigned grid = (unsigned)((n_rays + 3) / 4);
+  { ProfScope ps_(PS_SAMPLERS, (hipStream_t)stream); SDFHIP_DISPATCH_C(S + n_new + 1, (neus_upsample_kernel<C><<<grid, 256, 0, (hipStream_t)stream>>>(a))); }
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }

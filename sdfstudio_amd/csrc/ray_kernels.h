@@ -410,6 +410,7 @@ struct BinsArgs {
   const float* fars;   // [N]
   const float* jitter; // [N] single-jitter draw in [0,1) or null (deterministic)
   int32_t N, S;        // S samples -> S+1 bins
+  int32_t uniform;     // 0: UniformLinDispPiecewiseSampler spacing (ray_samplers.py:240-241), 1: UniformSampler (identity, :130-151)
   float* bins;         // [N,S+1] spacing-domain bins
   float* starts;       // [N,S] euclidean
   float* ends;         // [N,S]
@@ -431,8 +432,13 @@ __global__ void spaced_bins_kernel(const BinsArgs a) {
     b = lo + (hi - lo) * a.jitter[ray];
   }
   a.bins[idx] = b;
-  const float sn = piecewise_fn(a.nears[ray]), sf = piecewise_fn(a.fars[ray]);
-  const float e = piecewise_inv(b * sf + (1.0f - b) * sn);
+  float e;
+  if (a.uniform) {
+    e = b * a.fars[ray] + (1.0f - b) * a.nears[ray];
+  } else {
+    const float sn = piecewise_fn(a.nears[ray]), sf = piecewise_fn(a.fars[ray]);
+    e = piecewise_inv(b * sf + (1.0f - b) * sn);
+  }
   if (j < a.S) a.starts[(int64_t)ray * a.S + j] = e;
   if (j > 0) a.ends[(int64_t)ray * a.S + j - 1] = e;
 }
@@ -524,5 +530,180 @@ __global__ __launch_bounds__(256) void pdf_sample_kernel(const PdfArgs a) {
     const float e = piecewise_inv(b * sf + (1.0f - b) * sn);
     if (j < a.S_out) a.starts[(int64_t)ray * a.S_out + j] = e;
     if (j > 0) a.ends[(int64_t)ray * a.S_out + j - 1] = e;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ NeuS hierarchical sampler
+// One up-sampling step of NeuSSampler (ray_samplers.py:851-886): merge the sdf of the samples added by the previous step
+// (:864-868), alpha with a fixed inverse variance (:899-944), weights (rays.py:194-208), PDFSampler with
+// histogram_padding 1e-5 / include_original = False (:303-358), merge_ray_samples (:757-786).  One wavefront per ray, the
+// ray's working set (<= 512 samples) staged in LDS; UniformSampler spacing (euclid = x far + (1 - x) near).
+struct NeusUpArgs {
+  const float* bins_in;   // [N,S+1]
+  const float* sdf_a;     // [N,Sa]
+  const float* sdf_b;     // [N,Sb] or null
+  const int32_t* index;   // [N,S] into cat(sdf_a, sdf_b) or null (identity)
+  const float* nears;
+  const float* fars;
+  const float* jitter;    // [N] or null
+  int32_t N, Sa, Sb, n_new;
+  float inv_s, histogram_padding, eps, u_end, u_center;
+  float* sdf_merged;      // [N,S]
+  float* new_bins;        // [N,n_new+1]
+  float* new_starts;      // [N,n_new]  euclidean starts of the new samples (where the field is evaluated next)
+  float* new_ends;        // [N,n_new]
+  float* merged_bins;     // [N,S+n_new+1]
+  int32_t* merged_index;  // [N,S+n_new]
+  float* merged_starts;   // [N,S+n_new]
+  float* merged_ends;     // [N,S+n_new]
+};
+
+constexpr int kNeusUpMaxNew = 64;
+template <int C>
+__global__ __launch_bounds__(256) void neus_upsample_kernel(const NeusUpArgs a) {
+  __shared__ float sdf_s[4][64 * C], bin_s[4][64 * C + 1], cdf_s[4][64 * C + 1], new_s[4][kNeusUpMaxNew + 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ray = blockIdx.x * 4 + wv;
+  if (ray >= a.N) return;
+  const int S = a.Sa + a.Sb, Sn = a.n_new;
+  float* sdf = sdf_s[wv];
+  float* bin = bin_s[wv];
+  float* cdf = cdf_s[wv];
+  float* nb = new_s[wv];
+  const float near = a.nears[ray], far = a.fars[ray];
+  auto euclid = [&](const float x) { return x * far + (1.0f - x) * near; };
+  auto lds_sync = [&]() {
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's LDS traffic is complete (wave-private arrays)
+    __builtin_amdgcn_wave_barrier();
+  };
+  for (int s = lane; s <= S; s += 64) {
+    bin[s] = a.bins_in[(int64_t)ray * (S + 1) + s];
+    if (s < S) {
+      const int src = a.index != nullptr ? a.index[(int64_t)ray * S + s] : s;
+      const float v = src < a.Sa ? a.sdf_a[(int64_t)ray * a.Sa + src] : a.sdf_b[(int64_t)ray * a.Sb + (src - a.Sa)];
+      sdf[s] = v;
+      a.sdf_merged[(int64_t)ray * S + s] = v;
+    }
+  }
+  lds_sync();
+  // alpha_i, i < S - 1 (the last sample gets weight 0, :873)
+  float al[C], one_m[C];
+  float local = 1.0f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int i = lane * C + c;
+    al[c] = 0.0f;
+    one_m[c] = 1.0f;
+    if (i < S - 1) {
+      const float e0 = euclid(bin[i]), e1 = euclid(bin[i + 1]);
+      const float d = e1 - e0;
+      const float s0 = sdf[i], s1 = sdf[i + 1];
+      float cosv = (s1 - s0) / (d + 1e-5f);
+      float prev = 0.0f;
+      if (i > 0) prev = (s0 - sdf[i - 1]) / ((e0 - euclid(bin[i - 1])) + 1e-5f);
+      cosv = fminf(fmaxf(fminf(prev, cosv), -1e3f), 0.0f);
+      const float mid = (s0 + s1) * 0.5f;
+      const float pc = sigmoidf_((mid - cosv * d * 0.5f) * a.inv_s), nc = sigmoidf_((mid + cosv * d * 0.5f) * a.inv_s);
+      al[c] = (pc - nc + 1e-5f) / (pc + 1e-5f);
+      one_m[c] = 1.0f - al[c] + 1e-7f;
+    }
+    local *= one_m[c];
+  }
+  float T = __shfl_up(wave_incl_scan_mul(local, lane), 1);
+  if (lane == 0) T = 1.0f;
+  // PDF over the S weights
+  float w[C];
+  float wsum_l = 0.0f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int i = lane * C + c;
+    w[c] = 0.0f;
+    if (i < S) {
+      w[c] = (i < S - 1 ? al[c] * T : 0.0f) + a.histogram_padding;
+      wsum_l += w[c];
+    }
+    T *= one_m[c];
+  }
+  float wsum = wave_sum(wsum_l);
+  const float padding = fmaxf(a.eps - wsum, 0.0f);
+  const float add = padding / (float)S;
+  wsum += padding;
+  float pl = 0.0f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int i = lane * C + c;
+    w[c] = i < S ? (w[c] + add) / wsum : 0.0f;
+    pl += w[c];
+  }
+  float cum = wave_incl_scan_add(pl, lane) - pl;
+  if (lane == 0) cdf[0] = 0.0f;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int i = lane * C + c;
+    if (i < S) {
+      cum += w[c];
+      cdf[i + 1] = fminf(1.0f, cum);
+    }
+  }
+  lds_sync();
+  const int nbins = Sn + 1;
+  for (int j = lane; j < nbins; j += 64) {
+    const float end = a.u_end;
+    const float step = end / (float)(nbins - 1);
+    float u = j < nbins / 2 ? step * (float)j : end - step * (float)(nbins - 1 - j);  // torch.linspace
+    u += a.jitter != nullptr ? a.jitter[ray] / (float)nbins : a.u_center;
+    int lo = 0, hi = S + 1;
+    while (lo < hi) {  // searchsorted(side = "right")
+      const int m = (lo + hi) >> 1;
+      if (cdf[m] > u) hi = m; else lo = m + 1;
+    }
+    const int below = min(max(lo - 1, 0), S), above = min(max(lo, 0), S);
+    const float c0 = cdf[below], c1 = cdf[above];
+    float t = (u - c0) / (c1 - c0);
+    if (t != t) t = 0.0f;
+    t = fminf(fmaxf(t, 0.0f), 1.0f);
+    const float b = bin[below] + t * (bin[above] - bin[below]);
+    nb[j] = b;
+    a.new_bins[(int64_t)ray * nbins + j] = b;
+    const float e = euclid(b);
+    if (j < Sn) a.new_starts[(int64_t)ray * Sn + j] = e;
+    if (j > 0) a.new_ends[(int64_t)ray * Sn + j - 1] = e;
+  }
+  lds_sync();
+  // merge: both start lists are sorted; rank by counting (list 1 first on ties, as a stable sort of cat(starts_1, starts_2))
+  const int M = S + Sn;
+  float* mb = a.merged_bins + (int64_t)ray * (M + 1);
+  int32_t* mi = a.merged_index + (int64_t)ray * M;
+  // cdf is dead: reuse it as the merged-bin scratch (the kernel is instantiated for C >= ceil((S + n_new + 1) / 64))
+  float* merged = cdf;
+  for (int i = lane; i < S; i += 64) {
+    const float v = bin[i];
+    int lo = 0, hi = Sn;
+    while (lo < hi) {  // number of new starts strictly below v
+      const int m = (lo + hi) >> 1;
+      if (nb[m] < v) lo = m + 1; else hi = m;
+    }
+    mi[i + lo] = i;
+    merged[i + lo] = v;
+  }
+  for (int j = lane; j < Sn; j += 64) {
+    const float v = nb[j];
+    int lo = 0, hi = S;
+    while (lo < hi) {  // number of old starts <= v
+      const int m = (lo + hi) >> 1;
+      if (bin[m] <= v) lo = m + 1; else hi = m;
+    }
+    mi[j + lo] = S + j;
+    merged[j + lo] = v;
+  }
+  if (lane == 0) merged[M] = fmaxf(bin[S], nb[Sn]);
+  lds_sync();
+  for (int i = lane; i <= M; i += 64) {
+    const float b0 = merged[i];
+    mb[i] = b0;
+    if (i < M) {
+      a.merged_starts[(int64_t)ray * M + i] = euclid(b0);
+      a.merged_ends[(int64_t)ray * M + i] = euclid(merged[i + 1]);
+    }
   }
 }

@@ -278,26 +278,51 @@ struct WreduceArgs {
   int64_t b_off;   // bias gradient destination (index by natural row), or -1
   int32_t accumulate;
 };
-static __global__ void wreduce_kernel(const WreduceArgs a) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// block = 256 threads = 64 consecutive elements x 4 interleaved split groups (each thread sums n_split / 4 partials, 8 loads
+// in flight), combined through LDS; grid = ceil(rows * cols / 64)
+static __global__ __launch_bounds__(256) void wreduce_kernel(const WreduceArgs a) {
+  __shared__ float red[4][64];
+  const int ix = threadIdx.x & 63, sg = threadIdx.x >> 6;
   const int total = a.rows * a.cols;
+  const int idx = blockIdx.x * 64 + ix;
+  float s = 0.0f;
   if (idx < total) {
+    const float* p = a.partial + idx;
+    int k = sg;
+    for (; k + 28 < a.n_split; k += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + 4 * u) * total];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < a.n_split; k += 4) s += p[(size_t)k * total];
+  }
+  red[sg][ix] = s;
+  __syncthreads();
+  if (sg == 0 && idx < total) {
+    s = (red[0][ix] + red[1][ix]) + (red[2][ix] + red[3][ix]);
     const int o = idx / a.cols, i = idx % a.cols;
     const int nr = a.rowmap[o], nc = a.colmap[i];
     if (nr >= 0 && nc >= 0) {
-      float s = 0.0f;
-      for (int k = 0; k < a.n_split; ++k) s += a.partial[(size_t)k * total + idx];
       float* dst = a.theta_bar + a.w_off + (int64_t)nr * a.ld + nc;
       *dst = (a.accumulate ? *dst : 0.0f) + s * a.scale;
     }
   }
-  if (a.bpartial != nullptr && a.b_off >= 0 && idx < a.rows) {
-    const int nr = a.rowmap[idx];
-    if (nr >= 0) {
-      float s = 0.0f;
-      for (int k = 0; k < a.n_split; ++k) s += a.bpartial[(size_t)k * a.rows + idx];
-      float* dst = a.theta_bar + a.b_off + nr;
-      *dst = (a.accumulate ? *dst : 0.0f) + s;
+  // bias gradients: rows elements, handled by the first ceil(rows / 64) blocks
+  if (a.bpartial != nullptr && a.b_off >= 0 && blockIdx.x * 64 < a.rows) {  // block-uniform condition (barriers inside)
+    float t = 0.0f;
+    if (idx < a.rows)
+      for (int k = sg; k < a.n_split; k += 4) t += a.bpartial[(size_t)k * a.rows + idx];
+    __syncthreads();
+    red[sg][ix] = t;
+    __syncthreads();
+    if (sg == 0 && idx < a.rows) {
+      const int nr = a.rowmap[idx];
+      if (nr >= 0) {
+        float* dst = a.theta_bar + a.b_off + nr;
+        *dst = (a.accumulate ? *dst : 0.0f) + ((red[0][ix] + red[1][ix]) + (red[2][ix] + red[3][ix]));
+      }
     }
   }
 }

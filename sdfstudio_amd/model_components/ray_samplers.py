@@ -74,6 +74,117 @@ class UniformLinDispPiecewiseSampler(Sampler):
         return _make_samples(ray_bundle, bins, starts, ends)
 
 
+class UniformSampler(Sampler):
+    """ray_samplers.py:130-151: uniform spacing (identity spacing_fn); euclidean = x far + (1 - x) near."""
+
+    def __init__(self, num_samples: Optional[int] = None, train_stratified=True, single_jitter=True) -> None:
+        super().__init__(num_samples=num_samples)
+        if not single_jitter:
+            raise NotImplementedError("per-sample jitter is not built (NeuSSampler uses single_jitter=True, ray_samplers.py:826)")
+        self.train_stratified = train_stratified
+        self.jitter_override: Optional[torch.Tensor] = None
+
+    def generate_ray_samples(self, ray_bundle: RayBundle, num_samples: Optional[int] = None) -> RaySamples:
+        lib = _lib.load()
+        s = num_samples or self.num_samples
+        n = len(ray_bundle)
+        dev = ray_bundle.origins.device
+        nears = ray_bundle.nears.reshape(-1).contiguous()
+        fars = ray_bundle.fars.reshape(-1).contiguous()
+        jitter = None
+        if self.train_stratified and self.training:
+            jitter = self.jitter_override if self.jitter_override is not None else torch.rand(n, device=dev)
+            jitter = jitter.reshape(-1).contiguous()
+        bins = torch.empty(n, s + 1, device=dev)
+        starts = torch.empty(n, s, device=dev)
+        ends = torch.empty(n, s, device=dev)
+        _lib.check(lib.sdfhip_sample_uniform(_lib.ptr(nears), _lib.ptr(fars), _lib.ptr(jitter), n, s, _lib.ptr(bins),
+                                             _lib.ptr(starts), _lib.ptr(ends), _lib.stream()), "sample_uniform")
+        return _make_uniform_samples(ray_bundle, bins, starts, ends)
+
+
+def _make_uniform_samples(ray_bundle: RayBundle, bins, starts, ends) -> RaySamples:
+    nears, fars = ray_bundle.nears, ray_bundle.fars
+    return ray_bundle.get_ray_samples(
+        bin_starts=starts[..., None], bin_ends=ends[..., None], spacing_starts=bins[:, :-1, None], spacing_ends=bins[:, 1:, None],
+        spacing_to_euclidean_fn=lambda x: x * fars + (1 - x) * nears, flat_bins=bins,
+    )
+
+
+class NeuSSampler(Sampler):
+    """ray_samplers.py:815-944.  Each up-sampling step (merge of the new sdf values, alpha with a fixed inverse variance,
+    weights, PDF resampling, sorted merge) is ONE kernel launch (sdfhip_neus_upsample) plus the field's no-grad sdf
+    evaluation at the new samples; the reference issues ~60 small PyTorch kernels per step."""
+
+    def __init__(self, num_samples: int = 64, num_samples_importance: int = 64, num_samples_outside: int = 32,
+                 num_upsample_steps: int = 4, base_variance: float = 64, single_jitter: bool = True) -> None:
+        super().__init__()
+        if not single_jitter:
+            raise NotImplementedError("only single_jitter=True is built")
+        self.num_samples = num_samples
+        self.num_samples_importance = num_samples_importance
+        self.num_samples_outside = num_samples_outside  # unused by the reference as well (ray_samplers.py:888-893)
+        self.num_upsample_steps = num_upsample_steps
+        self.base_variance = base_variance
+        self.uniform_sampler = UniformSampler(single_jitter=single_jitter)
+        self.jitter_overrides: Optional[List[torch.Tensor]] = None  # tests: one draw per up-sampling step
+
+    def upsample_step(self, ray_bundle: RayBundle, bins, sdf_a, sdf_b, index, n_new: int, inv_s: float, jitter):
+        """One reference loop iteration; returns (sdf_merged, new_bins, new_starts, new_ends, merged_bins, merged_index,
+        merged_starts, merged_ends)."""
+        lib = _lib.load()
+        n, s1 = bins.shape
+        s = s1 - 1
+        dev = bins.device
+        s_a = sdf_a.shape[1]
+        s_b = 0 if sdf_b is None else sdf_b.shape[1]
+        assert s_a + s_b == s
+        nears = ray_bundle.nears.reshape(-1).contiguous()
+        fars = ray_bundle.fars.reshape(-1).contiguous()
+        sdf_m = torch.empty(n, s, device=dev)
+        new_bins = torch.empty(n, n_new + 1, device=dev)
+        new_starts = torch.empty(n, n_new, device=dev)
+        new_ends = torch.empty(n, n_new, device=dev)
+        m_bins = torch.empty(n, s + n_new + 1, device=dev)
+        m_index = torch.empty(n, s + n_new, device=dev, dtype=torch.int32)
+        m_starts = torch.empty(n, s + n_new, device=dev)
+        m_ends = torch.empty(n, s + n_new, device=dev)
+        _lib.check(lib.sdfhip_neus_upsample(
+            _lib.ptr(bins.contiguous()), _lib.ptr(sdf_a.contiguous()), _lib.ptr(None if sdf_b is None else sdf_b.contiguous()),
+            None if index is None else index.data_ptr(), _lib.ptr(nears), _lib.ptr(fars), _lib.ptr(jitter), n, s_a, s_b, n_new,
+            float(inv_s), _lib.ptr(sdf_m), _lib.ptr(new_bins), _lib.ptr(new_starts), _lib.ptr(new_ends), _lib.ptr(m_bins),
+            m_index.data_ptr(), _lib.ptr(m_starts), _lib.ptr(m_ends), _lib.stream()), "neus_upsample")
+        return sdf_m, new_bins, new_starts, new_ends, m_bins, m_index, m_starts, m_ends
+
+    def generate_ray_samples(self, ray_bundle: Optional[RayBundle] = None, sdf_fn: Optional[Callable] = None,
+                             ray_samples: Optional[RaySamples] = None) -> RaySamples:
+        assert ray_bundle is not None and sdf_fn is not None
+        if ray_samples is None:
+            ray_samples = self.uniform_sampler(ray_bundle, num_samples=self.num_samples)
+        n = len(ray_bundle)
+        dev = ray_bundle.origins.device
+        bins = ray_samples.flat_bins
+        n_new = self.num_samples_importance // self.num_upsample_steps
+        new_samples = ray_samples
+        sdf, index = None, None
+        m_starts, m_ends = ray_samples.flat_starts, ray_samples.flat_ends
+        for it in range(self.num_upsample_steps):
+            with torch.no_grad():
+                new_sdf = sdf_fn(new_samples)[..., 0]
+            jitter = None
+            if self.training:
+                jitter = (self.jitter_overrides[it] if self.jitter_overrides is not None else torch.rand(n, device=dev))
+                jitter = jitter.reshape(-1).contiguous()
+            if sdf is None:
+                sdf_a, sdf_b = new_sdf, None
+            else:
+                sdf_a, sdf_b = sdf, new_sdf
+            sdf, new_bins, new_starts, new_ends, bins, index, m_starts, m_ends = self.upsample_step(
+                ray_bundle, bins, sdf_a, sdf_b, index, n_new, self.base_variance * 2 ** it, jitter)
+            new_samples = _make_uniform_samples(ray_bundle, new_bins, new_starts, new_ends)
+        return _make_uniform_samples(ray_bundle, bins, m_starts, m_ends)
+
+
 class PDFSampler(Sampler):
     """ray_samplers.py:250-370 with include_original=False (the ProposalNetworkSampler setting, :525)."""
 

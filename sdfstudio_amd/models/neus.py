@@ -1,0 +1,97 @@
+"""NeuS model, mirroring nerfstudio/models/neus.py (NeuSModelConfig :34-47, NeuSModel :50-113) on top of
+models/base_surface_model.py: NeuSSampler (hierarchical up-sampling driven by SDFField.get_sdf) -> SDFField -> NeuS alpha
+compositing.  Host glue only; every stage is a native call (see models/neus_facto.py for the shared parts)."""
+from dataclasses import dataclass, field
+from typing import Dict, List, Type
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from sdfstudio_amd.cameras.rays import RayBundle
+from sdfstudio_amd.fields.field_heads import FieldHeadNames
+from sdfstudio_amd.model_components.ray_samplers import NeuSSampler
+from sdfstudio_amd.model_components.renderers import neus_render
+from sdfstudio_amd.models.neus_facto import NeuSFactoModel, NeuSFactoModelConfig, SceneContraction
+
+
+@dataclass
+class NeuSModelConfig(NeuSFactoModelConfig):
+    """models/neus.py:34-47 (+ the SurfaceModelConfig knobs inherited through NeuSFactoModelConfig)."""
+
+    _target: Type = field(default_factory=lambda: NeuSModel)
+    num_samples: int = 64
+    num_samples_importance: int = 64
+    num_samples_outside: int = 32
+    num_up_sample_steps: int = 4
+    base_variance: float = 64.0
+    perturb: bool = True
+
+
+class NeuSModel(NeuSFactoModel):
+    """models/neus.py:50-113."""
+
+    def populate_modules(self):
+        """base_surface_model.py:144-233 + neus.py:61-73."""
+        c = self.config
+        if c.background_model != "none":
+            raise NotImplementedError("background models are outside this round's scope (SURVEY.md section 8, row f4)")
+        if self.scene_box.collider_type != "near_far":
+            raise NotImplementedError("only the near/far collider is on the path this round")
+        self.scene_contraction = SceneContraction(order=float("inf"))
+        self.field = c.sdf_field.setup(aabb=self.scene_box.aabb, spatial_distortion=self.scene_contraction,
+                                       num_images=self.num_train_data, use_average_appearance_embedding=False)
+        self.sampler = NeuSSampler(num_samples=c.num_samples, num_samples_importance=c.num_samples_importance,
+                                   num_samples_outside=c.num_samples_outside, num_upsample_steps=c.num_up_sample_steps,
+                                   base_variance=c.base_variance)
+        bg = {"black": torch.zeros(3), "white": torch.ones(3)}.get(c.background_color)
+        if bg is None:
+            raise NotImplementedError("background_color must be black or white on the fused path")
+        self.register_buffer("background", bg, persistent=False)
+        self.anneal_end = 50000
+
+    def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:
+        return {"fields": list(self.field.parameters()), "field_background": []}
+
+    def before_train_iteration(self, step: int):
+        if self.anneal_end > 0:
+            self.field.set_cos_anneal_ratio(min(1.0, step / self.anneal_end))  # neus.py:80-84
+
+    def after_train_iteration(self, step: int):
+        pass
+
+    def sample_and_forward_field(self, ray_bundle: RayBundle) -> Dict:
+        """neus.py:94-104."""
+        ray_samples = self.sampler(ray_bundle, sdf_fn=self.field.get_sdf)
+        sdf, grad, rgb, x = self.field.forward_fused(ray_samples)
+        bg = None if self.config.background_color == "black" else self.background
+        out_rgb, depth, normal, acc, weights, alpha = neus_render(
+            sdf, grad, rgb, self.field.deviation_network.variance, ray_samples.flat_directions, ray_samples.flat_starts,
+            ray_samples.flat_ends, self.field._cos_anneal_ratio, bg)
+        field_outputs = {
+            FieldHeadNames.RGB: rgb, FieldHeadNames.SDF: sdf[..., None], FieldHeadNames.GRADIENT: grad,
+            FieldHeadNames.ALPHA: alpha[..., None], "points_norm": x.norm(dim=-1, keepdim=True), "sampled_sdf": None,
+        }
+        return {"ray_samples": ray_samples, "field_outputs": field_outputs, "weights": weights[..., None],
+                "rendered": (out_rgb, depth, normal, acc)}
+
+    def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, torch.Tensor]:
+        """base_surface_model.py:399-416 (rgb, eikonal, fg mask)."""
+        c = self.config
+        image = batch["image"].to(outputs["rgb"].device)
+        loss = {"rgb_loss": F.l1_loss(image, outputs["rgb"])}
+        if self.training:
+            g = outputs["eik_grad"]
+            loss["eikonal_loss"] = ((g.norm(2, dim=-1) - 1) ** 2).mean() * c.eikonal_loss_mult
+            if "fg_mask" in batch and c.fg_mask_loss_mult > 0.0:
+                fg = batch["fg_mask"].float().to(image.device)
+                wsum = outputs["weights"].sum(dim=1).clip(1e-3, 1.0 - 1e-3)
+                loss["fg_mask_loss"] = F.binary_cross_entropy(wsum, fg) * c.fg_mask_loss_mult
+        return loss
+
+    def get_metrics_dict(self, outputs, batch) -> Dict[str, torch.Tensor]:
+        m = super().get_metrics_dict(outputs, batch)
+        if self.training:  # neus.py:106-113
+            m["s_val"] = self.field.deviation_network.get_variance().detach()
+            m["inv_s"] = 1.0 / self.field.deviation_network.get_variance().detach()
+        return m

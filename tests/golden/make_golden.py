@@ -89,10 +89,12 @@ def build_reference(ns, cfg: O.ModelCfg, p):
             net.mlp_base.w1.copy_(p[f"proposal_networks.{i}.w1"])
             net.mlp_base.w2.copy_(p[f"proposal_networks.{i}.w2"])
         nets.append(net)
-    sampler = ns.rs.ProposalNetworkSampler(
-        num_nerf_samples_per_ray=cfg.num_neus_samples, num_proposal_samples_per_ray=cfg.num_proposal_samples,
-        num_proposal_network_iterations=len(cfg.proposals), single_jitter=True, update_sched=lambda step: -1,
-    )
+    sampler = None
+    if len(cfg.proposals) > 0:
+        sampler = ns.rs.ProposalNetworkSampler(
+            num_nerf_samples_per_ray=cfg.num_neus_samples, num_proposal_samples_per_ray=cfg.num_proposal_samples,
+            num_proposal_network_iterations=len(cfg.proposals), single_jitter=True, update_sched=lambda step: -1,
+        )
     return field, nets, sampler
 
 
@@ -239,5 +241,158 @@ def main():
         print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def main_neus():
+    """NeuS (models/neus.py): NeuSSampler (ray_samplers.py:815) driving SDFField.get_sdf, then the same field / renderer path.
+    Small sampler (16 + 4 x 4 samples) so the vectors stay small; writes tests/golden/neus_small_{train,eval}.npz."""
+    ns = ref_harness.import_reference()
+    cfg = small_cfg()
+    p = {k: v for k, v in perturbed_params(cfg).items() if not k.startswith("proposal_networks.")}
+    n = 48
+    origins, dirs, cam = O.synthetic_rays(n, seed=43)
+    g = torch.Generator().manual_seed(9)
+    image = torch.rand(n, 3, generator=g)
+    num_samples, num_importance, steps, base_var = 16, 16, 4, 64.0
+    rand = [torch.rand(n, 1, generator=g) for _ in range(1 + steps)]
+    cos_anneal = 0.3
+    field, _, _ = build_reference(ns, O.ModelCfg(field=cfg.field, proposals=()), p)
+    sampler = ns.rs.NeuSSampler(num_samples=num_samples, num_samples_importance=num_importance, num_samples_outside=0,
+                                num_upsample_steps=steps, base_variance=base_var)
+    H = ns.FieldHeadNames
+    for mode in ("train", "eval"):
+        training = mode == "train"
+        for m in [field, sampler]:
+            m.train(training)
+        field.set_cos_anneal_ratio(cos_anneal)
+        rb = ns.rays.RayBundle(
+            origins=origins, directions=dirs, pixel_area=torch.ones(n, 1), directions_norm=torch.ones(n, 1),
+            camera_indices=cam[:, None], nears=torch.full((n, 1), cfg.near), fars=torch.full((n, 1), cfg.far),
+        )
+        with _RandQueue(rand if training else []):
+            ray_samples = sampler(rb, sdf_fn=field.get_sdf)
+        # the same loop once more, step by step with the reference's own methods (ray_samplers.py:851-886), to record every
+        # upsampling step's inputs and outputs: single steps are well conditioned and are compared tightly
+        steps_blob = {}
+        with _RandQueue(rand if training else []), torch.no_grad():
+            sb = lambda r: torch.cat([r.spacing_starts[..., 0], r.spacing_ends[..., -1:, 0]], -1)
+            rs_k = sampler.uniform_sampler(rb, num_samples=num_samples)
+            new_k, sdf_k, idx_k = rs_k, None, None
+            for it in range(steps):
+                new_sdf = field.get_sdf(new_k)
+                sdf_k = new_sdf if idx_k is None else torch.gather(torch.cat([sdf_k.squeeze(-1), new_sdf.squeeze(-1)], -1), 1,
+                                                                     idx_k).unsqueeze(-1)
+                al = sampler.rendering_sdf_with_fixed_inv_s(rs_k, sdf_k.reshape(rs_k.shape), inv_s=base_var * 2**it)
+                w = rs_k.get_weights_from_alphas(al[..., None])
+                w = torch.cat((w, torch.zeros_like(w[:, :1])), dim=1)
+                new_k = sampler.pdf_sampler(rb, rs_k, w, num_samples=num_importance // steps)
+                steps_blob[f"step{it}/bins_in"] = sb(rs_k)
+                steps_blob[f"step{it}/sdf_in"] = sdf_k.reshape(rs_k.shape)
+                steps_blob[f"step{it}/alpha"] = al
+                steps_blob[f"step{it}/new_bins"] = sb(new_k)
+                rs_k, idx_k = sampler.error_bounded_sampler.merge_ray_samples(rb, rs_k, new_k)
+                steps_blob[f"step{it}/merged_bins"] = sb(rs_k)
+                steps_blob[f"step{it}/index"] = idx_k
+            assert torch.equal(sb(rs_k), sb(ray_samples)), "step-by-step replay differs from NeuSSampler.generate_ray_samples"
+        fo = field(ray_samples, return_alphas=True)
+        weights, trans = ray_samples.get_weights_and_transmittance_from_alphas(fo[H.ALPHA])
+        rgb_r = ns.rd.RGBRenderer(background_color=torch.zeros(3))
+        rgb_r.train(training)
+        rgb = rgb_r(rgb=fo[H.RGB], weights=weights)
+        depth = ns.rd.DepthRenderer(method="expected")(weights=weights, ray_samples=ray_samples)
+        normal = ns.rd.SemanticRenderer()(semantics=fo[H.NORMAL], weights=weights)
+        acc = ns.rd.AccumulationRenderer()(weights=weights)
+        out = {
+            "starts": ray_samples.frustums.starts[..., 0], "ends": ray_samples.frustums.ends[..., 0],
+            "bins": torch.cat([ray_samples.spacing_starts[..., 0], ray_samples.spacing_ends[..., -1:, 0]], -1),
+            "sdf": fo[H.SDF][..., 0], "gradient": fo[H.GRADIENT], "field_rgb": fo[H.RGB], "alpha": fo[H.ALPHA][..., 0],
+            "weights": weights[..., 0], "rgb": rgb, "depth": depth[..., 0], "normal": normal, "accumulation": acc[..., 0],
+        }
+        # single upsampling steps of the oracle on the reference's inputs
+        nears_t, fars_t = torch.full((n,), cfg.near), torch.full((n,), cfg.far)
+        for it in range(steps):
+            b_in, s_in = steps_blob[f"step{it}/bins_in"], steps_blob[f"step{it}/sdf_in"]
+            eu = O.uniform_to_euclidean(b_in, nears_t, fars_t)
+            al = O.neus_upsample_alpha(s_in, eu[:, 1:] - eu[:, :-1], base_var * 2**it)
+            assert (al - steps_blob[f"step{it}/alpha"]).abs().max().item() <= 2e-6, f"step {it} alpha"
+            wo, _ = O.weights_from_alphas(al)
+            wo = torch.cat([wo, torch.zeros_like(wo[:, :1])], 1)
+            nb = O.pdf_sample(wo, b_in, num_importance // steps, rand[1 + it] if training else None, histogram_padding=1e-5)
+            mb, ix = O.merge_bins(b_in, nb)
+            e1 = (nb - steps_blob[f"step{it}/new_bins"]).abs().max().item()
+            assert e1 <= 2e-5, f"step {it} new bins {e1:.2e}"
+            same = torch.equal(ix, steps_blob[f"step{it}/index"])
+            print(f"[neus {mode}] step {it}: |d new bins| {e1:.1e}, merge index identical: {same}")
+        losses, ref_grads = {}, {}
+        if training:
+            losses["rgb_loss"] = torch.nn.L1Loss()(image, rgb)
+            losses["eikonal_loss"] = ((fo[H.GRADIENT].norm(2, dim=-1) - 1) ** 2).mean() * cfg.eikonal_loss_mult
+            field.zero_grad()
+            sum(losses.values()).backward()
+            for k, v in field.named_parameters():
+                if v.grad is not None:
+                    ref_grads[k] = v.grad.clone()
+        # ---- oracle on the same inputs
+        po = {k: v.clone().requires_grad_(v.is_floating_point() and k != "laplace_density.beta_min") for k, v in p.items()}
+        # (1) the sampler restatement: four rounds of inverse-CDF resampling with histogram_padding = 1e-5 divide by cdf
+        # increments of ~1e-6, so fp32 round-off (1e-6 on the sdf) moves individual samples by up to a few 1e-3 after the
+        # fourth round; the restatement must agree on the bulk of the samples and stay sorted / in range
+        with torch.no_grad():
+            o_s = O.neus_forward(origins, dirs, cam, p, cfg, cos_anneal_ratio=cos_anneal, rand=rand if training else None,
+                                 training=training, num_samples=num_samples, num_samples_importance=num_importance,
+                                 num_upsample_steps=steps, base_variance=base_var)
+        d_bins = (o_s["bins"] - out["bins"]).abs()
+        assert d_bins.median().item() <= 2e-6 and d_bins.max().item() <= 5e-3, (d_bins.median().item(), d_bins.max().item())
+        print(f"[neus {mode}] sampler: median |d bins| {d_bins.median().item():.1e}, max {d_bins.max().item():.1e}")
+        # (2) field + renderer + losses + gradients on IDENTICAL samples (the reference's)
+        o = O.neus_forward(origins, dirs, cam, po, cfg, cos_anneal_ratio=cos_anneal, training=training,
+                           samples=(out["bins"], out["starts"], out["ends"]))
+        if not training:
+            o["rgb"] = o["rgb"].clamp(0.0, 1.0)
+        omap = {"starts": o["starts"], "ends": o["ends"], "bins": o["bins"], "sdf": o["field"]["sdf"],
+                "gradient": o["field"]["gradient"], "field_rgb": o["field"]["rgb"], "alpha": o["field"]["alpha"],
+                "weights": o["weights"], "rgb": o["rgb"], "depth": o["depth"], "normal": o["normal"],
+                "accumulation": o["accumulation"]}
+        worst = 0.0
+        for k, v in out.items():
+            err = (omap[k].detach() - v.detach()).abs().max().item()
+            scale = v.detach().abs().max().item() + 1e-12
+            worst = max(worst, err / scale)
+            tol = 1e-4 if k == "depth" else 2e-5
+            assert err <= tol * scale + 1e-6, f"[neus] oracle != reference on {k}: abs {err:.3e} (scale {scale:.3e})"
+        if training:
+            g_o = o["field"]["gradient"]
+            ol = {"rgb_loss": torch.nn.functional.l1_loss(o["rgb"], image),
+                  "eikonal_loss": ((g_o.norm(2, dim=-1) - 1) ** 2).mean() * cfg.eikonal_loss_mult}
+            for k in losses:
+                assert abs(ol[k].item() - losses[k].item()) <= 1e-5 * abs(losses[k].item()) + 1e-8, k
+            sum(ol.values()).backward()
+            for k, gref in ref_grads.items():
+                err = (po[k].grad - gref).abs().max().item()
+                scale = gref.abs().max().item() + 1e-12
+                worst = max(worst, err / scale)
+                assert err <= 1e-3 * scale + 1e-9, f"[neus] oracle grad != reference on {k}: {err:.3e} / {scale:.3e}"
+        print(f"[neus {mode}] oracle reproduces the reference; worst rel err {worst:.2e}")
+        blob = {"in/origins": origins, "in/dirs": dirs, "in/cam": cam, "in/image": image, "in/cos_anneal": torch.tensor(cos_anneal),
+                "in/num_samples": torch.tensor(num_samples), "in/num_importance": torch.tensor(num_importance),
+                "in/steps": torch.tensor(steps), "in/base_variance": torch.tensor(base_var)}
+        for i, r in enumerate(rand):
+            blob[f"in/rand{i}"] = r
+        for k, v in p.items():
+            blob[f"param/{k}"] = v
+        for k, v in out.items():
+            blob[f"out/{k}"] = v.detach()
+        for k, v in losses.items():
+            blob[f"loss/{k}"] = v.detach()
+        for k, v in ref_grads.items():
+            blob[f"grad/{k}"] = v
+        blob.update(steps_blob)
+        path = os.path.join(HERE, f"neus_small_{mode}.npz")
+        np.savez_compressed(path, **{k: v.numpy() for k, v in blob.items()})
+        print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "neus":
+        main_neus()
+    else:
+        main()
+        main_neus()

@@ -13,13 +13,17 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 from oracle import sdf_path as O  # noqa: E402
 
 
-def load_golden(mode: str):
-    z = np.load(os.path.join(GOLDEN, f"neus_facto_small_{mode}.npz"))
+def load_golden_file(name: str):
+    z = np.load(os.path.join(GOLDEN, name))
     out = {"in": {}, "param": {}, "out": {}, "loss": {}, "grad": {}}
     for k in z.files:
-        head, name = k.split("/", 1)
-        out[head][name] = torch.from_numpy(z[k])
+        head, key = k.split("/", 1)
+        out.setdefault(head, {})[key] = torch.from_numpy(z[k])
     return out
+
+
+def load_golden(mode: str):
+    return load_golden_file(f"neus_facto_small_{mode}.npz")
 
 
 def small_oracle_cfg() -> O.ModelCfg:

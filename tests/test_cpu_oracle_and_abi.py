@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import ROOT, assert_close, load_golden, small_oracle_cfg
+from helpers import ROOT, assert_close, load_golden, load_golden_file, small_oracle_cfg
 from oracle import hashgrid, sdf_path as O
 
 OUT_KEYS = ["starts", "ends", "bins", "sdf", "gradient", "field_rgb", "alpha", "density", "field_normal", "points_norm",
@@ -55,6 +55,51 @@ def test_oracle_reproduces_reference_golden_gradients():
     assert len(g["grad"]) >= 30
     for k, ref in g["grad"].items():
         assert_close(f"grad {k}", p[k].grad, ref, rtol=1e-3, atol=1e-9)
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_oracle_neus_sampler_and_model_against_reference_golden(mode):
+    """NeuS (models/neus.py): every up-sampling step on the reference's own inputs (bit-tight), the four-step sampler end to
+    end (ill-conditioned: bulk agreement), field + renderer + gradients on the reference's samples."""
+    g = load_golden_file(f"neus_small_{mode}.npz")
+    cfg = small_oracle_cfg()
+    n = g["in"]["origins"].shape[0]
+    training = mode == "train"
+    steps, n_imp, base = int(g["in"]["steps"]), int(g["in"]["num_importance"]), float(g["in"]["base_variance"])
+    nears, fars = torch.full((n,), cfg.near), torch.full((n,), cfg.far)
+    for it in range(steps):
+        st = g[f"step{it}"]
+        eu = O.uniform_to_euclidean(st["bins_in"], nears, fars)
+        al = O.neus_upsample_alpha(st["sdf_in"], eu[:, 1:] - eu[:, :-1], base * 2 ** it)
+        assert_close(f"step {it} alpha", al, st["alpha"], rtol=0, atol=2e-6)
+        w, _ = O.weights_from_alphas(al)
+        w = torch.cat([w, torch.zeros_like(w[:, :1])], 1)
+        nb = O.pdf_sample(w, st["bins_in"], n_imp // steps, g["in"][f"rand{1 + it}"] if training else None, histogram_padding=1e-5)
+        assert_close(f"step {it} new bins", nb, st["new_bins"], rtol=0, atol=2e-5)
+        mb, ix = O.merge_bins(st["bins_in"], st["new_bins"])
+        assert torch.equal(mb, st["merged_bins"]) and torch.equal(ix, st["index"])
+    p = {k: v.clone().requires_grad_(v.is_floating_point() and k != "laplace_density.beta_min") for k, v in g["param"].items()}
+    kw = dict(cos_anneal_ratio=float(g["in"]["cos_anneal"]), training=training)
+    with torch.no_grad():
+        o_s = O.neus_forward(g["in"]["origins"], g["in"]["dirs"], g["in"]["cam"], p, cfg,
+                             rand=[g["in"][f"rand{i}"] for i in range(1 + steps)] if training else None,
+                             num_samples=int(g["in"]["num_samples"]), num_samples_importance=n_imp, num_upsample_steps=steps,
+                             base_variance=base, **kw)
+    d = (o_s["bins"] - g["out"]["bins"]).abs()
+    assert d.median().item() <= 2e-6 and d.max().item() <= 5e-3
+    o = O.neus_forward(g["in"]["origins"], g["in"]["dirs"], g["in"]["cam"], p, cfg,
+                       samples=(g["out"]["bins"], g["out"]["starts"], g["out"]["ends"]), **kw)
+    rgb = o["rgb"] if training else o["rgb"].clamp(0, 1)
+    for k, v in {"sdf": o["field"]["sdf"], "gradient": o["field"]["gradient"], "alpha": o["field"]["alpha"], "weights": o["weights"],
+                 "rgb": rgb, "normal": o["normal"], "accumulation": o["accumulation"]}.items():
+        assert_close(k, v, g["out"][k], rtol=2e-5, atol=1e-6)
+    if training:
+        loss = torch.nn.functional.l1_loss(o["rgb"], g["in"]["image"]) + (
+            (o["field"]["gradient"].norm(2, dim=-1) - 1) ** 2).mean() * cfg.eikonal_loss_mult
+        loss.backward()
+        assert len(g["grad"]) >= 30
+        for k, ref in g["grad"].items():
+            assert_close(f"grad {k}", p[k].grad, ref, rtol=1e-3, atol=1e-9)
 
 
 def test_oracle_known_answers_from_reference_tests():

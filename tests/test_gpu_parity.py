@@ -8,8 +8,9 @@ import math
 
 import pytest
 import torch
+import torch.nn.functional as F
 
-from helpers import (assert_close, assert_fp32_class, load_golden, product_grads, product_model_from_params, small_oracle_cfg,
+from helpers import (assert_close, assert_fp32_class, load_golden, load_golden_file, product_grads, product_model_from_params, small_oracle_cfg,
                      to_double)
 from oracle import sdf_path as O
 
@@ -78,6 +79,137 @@ def test_pdf_sampler(device, training, shape):
     eu = O.spacing_to_euclidean(b.cpu(), torch.full((n,), 0.5), torch.full((n,), 4.5))
     assert_close("pdf starts", rs.flat_starts, eu[:, :-1], rtol=2e-6, atol=2e-6)
     assert_close("pdf ends", rs.flat_ends, eu[:, 1:], rtol=2e-6, atol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------------ NeuS sampler
+@pytest.mark.parametrize("training", [True, False])
+def test_uniform_sampler(device, training):
+    from sdfstudio_amd.model_components.ray_samplers import UniformSampler
+
+    n, S = 77, 64
+    o, d, cam = O.synthetic_rays(n)
+    rb = _bundle(o, d, cam, 0.5, 4.5, device)
+    jit = torch.rand(n, 1)
+    smp = UniformSampler().train(training)
+    smp.jitter_override = jit.to(device)
+    rs = smp(rb, num_samples=S)
+    bins = O.initial_bins(n, S, jit if training else None)
+    eu = O.uniform_to_euclidean(bins, torch.full((n,), 0.5), torch.full((n,), 4.5))
+    assert_close("bins", rs.flat_bins, bins, rtol=0, atol=2e-7)
+    assert_close("starts", rs.flat_starts, eu[:, :-1], rtol=1e-6, atol=1e-6)
+    assert_close("ends", rs.flat_ends, eu[:, 1:], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_neus_upsample_steps_against_reference(device, mode):
+    """Every up-sampling step of the reference's NeuSSampler run (golden: its own inputs and outputs per step): merged sdf,
+    new bins (PDF resampling), merged bins and the merge index, on identical inputs."""
+    from sdfstudio_amd.model_components.ray_samplers import NeuSSampler
+
+    g = load_golden_file(f"neus_small_{mode}.npz")
+    cfg = small_oracle_cfg()
+    n = g["in"]["origins"].shape[0]
+    steps, n_imp, base = int(g["in"]["steps"]), int(g["in"]["num_importance"]), float(g["in"]["base_variance"])
+    smp = NeuSSampler(num_samples=int(g["in"]["num_samples"]), num_samples_importance=n_imp, num_upsample_steps=steps,
+                      base_variance=base).train(mode == "train")
+    rb = _bundle(g["in"]["origins"], g["in"]["dirs"], g["in"]["cam"], cfg.near, cfg.far, device)
+    for it in range(steps):
+        st = g[f"step{it}"]
+        bins_in, sdf_in = st["bins_in"].to(device), st["sdf_in"].to(device)
+        jit = g["in"][f"rand{1 + it}"].to(device).reshape(-1) if mode == "train" else None
+        sdf_m, new_bins, new_starts, new_ends, m_bins, m_index, m_starts, m_ends = smp.upsample_step(
+            rb, bins_in, sdf_in, None, None, n_imp // steps, base * 2 ** it, jit)
+        assert_close(f"step {it} merged sdf (identity)", sdf_m, st["sdf_in"], rtol=0, atol=0)
+        # inverse-CDF with histogram_padding 1e-5: cdf increments down to ~1e-6, one fp32 ulp of the cdf moves an edge by 1e-4 of a bin
+        assert_close(f"step {it} new bins", new_bins, st["new_bins"], rtol=0, atol=3e-5)
+        ref_m, ref_i = O.merge_bins(bins_in.cpu(), new_bins.cpu())  # merge is exact given the kernel's own new bins
+        assert_close(f"step {it} merged bins", m_bins, ref_m, rtol=0, atol=0)
+        assert torch.equal(m_index.cpu().long(), ref_i), f"step {it}: merge index"
+        eu = O.uniform_to_euclidean(ref_m, torch.full((n,), cfg.near), torch.full((n,), cfg.far))
+        assert_close(f"step {it} merged starts", m_starts, eu[:, :-1], rtol=1e-6, atol=1e-6)
+        assert_close(f"step {it} merged ends", m_ends, eu[:, 1:], rtol=1e-6, atol=1e-6)
+        # and the sdf gather with a real index: feed (sdf_a, sdf_b, index) of the NEXT reference step
+        if it + 1 < steps:
+            nxt = g[f"step{it + 1}"]
+            idx = st["index"].to(device).int().contiguous()
+            cat_ref = torch.gather(torch.cat([st["sdf_in"], torch.zeros(n, n_imp // steps)], -1), 1, st["index"])
+            known = st["index"] < st["sdf_in"].shape[1]
+            sdf_b = torch.zeros(n, n_imp // steps)
+            # sdf of the new samples = the entries of the next step's merged sdf that came from list 2
+            sdf_b[torch.arange(n)[:, None].expand_as(st["index"])[~known], (st["index"] - st["sdf_in"].shape[1])[~known]] = \
+                nxt["sdf_in"][~known]
+            out = smp.upsample_step(rb, nxt["bins_in"].to(device), sdf_in, sdf_b.to(device), idx, n_imp // steps,
+                                    base * 2 ** (it + 1), None if jit is None else g["in"][f"rand{2 + it}"].to(device).reshape(-1))
+            assert_close(f"step {it + 1} merged sdf (gather)", out[0], nxt["sdf_in"], rtol=0, atol=0)
+            assert cat_ref.shape == nxt["sdf_in"].shape
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_neus_model_against_reference_golden(device, mode):
+    """models/neus.py end to end.  Sampler: four rounds of ill-conditioned inverse-CDF resampling -> the bulk of the samples
+    must agree to fp32 round-off, none may be off by more than a few 1e-3 (the oracle's own spread against the reference);
+    field + renderer + losses + gradients: on the reference's samples, 1e-5 on SDF / 1e-4 relative on the rest."""
+    from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
+    from sdfstudio_amd.model_components.renderers import neus_render
+    from sdfstudio_amd.models.neus import NeuSModel, NeuSModelConfig
+    from sdfstudio_amd.models.neus_facto import SceneBox
+    from helpers import load_params
+
+    g = load_golden_file(f"neus_small_{mode}.npz")
+    cfg = small_oracle_cfg()
+    fc = cfg.field
+    fcfg = SDFFieldConfig(num_layers=fc.num_layers, hidden_dim=fc.hidden_dim, geo_feat_dim=fc.geo_feat_dim,
+                          num_layers_color=fc.num_layers_color, hidden_dim_color=fc.hidden_dim_color, bias=fc.bias,
+                          inside_outside=fc.inside_outside, use_grid_feature=True, beta_init=fc.beta_init, num_levels=fc.num_levels,
+                          max_res=fc.max_res, base_res=fc.base_res, log2_hashmap_size=fc.log2_hashmap_size,
+                          hash_features_per_level=fc.hash_features_per_level, hash_smoothstep=fc.hash_smoothstep)
+    steps = int(g["in"]["steps"])
+    mcfg = NeuSModelConfig(sdf_field=fcfg, num_samples=int(g["in"]["num_samples"]),
+                           num_samples_importance=int(g["in"]["num_importance"]), num_up_sample_steps=steps,
+                           base_variance=float(g["in"]["base_variance"]), eikonal_loss_mult=cfg.eikonal_loss_mult)
+    box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=cfg.near, far=cfg.far)
+    model = NeuSModel(mcfg, box, num_train_data=49)
+    load_params(model, g["param"])
+    training = mode == "train"
+    model = model.to(device).train(training)
+    ca = float(g["in"]["cos_anneal"])
+    model.field.set_cos_anneal_ratio(ca)
+    model.sampler.uniform_sampler.jitter_override = g["in"]["rand0"].to(device)
+    model.sampler.jitter_overrides = [g["in"][f"rand{1 + i}"].to(device) for i in range(steps)]
+    rb = _bundle(g["in"]["origins"], g["in"]["dirs"], g["in"]["cam"], cfg.near, cfg.far, device)
+    ref = g["out"]
+    out = model(rb)
+    d_bins = (out["ray_samples"].flat_bins.cpu() - ref["bins"]).abs() if training else None
+    if training:
+        assert d_bins.median().item() <= 1e-5 and d_bins.max().item() <= 5e-3, (d_bins.median().item(), d_bins.max().item())
+        b = out["ray_samples"].flat_bins
+        assert (b[:, 1:] >= b[:, :-1]).all() and b.min() >= 0 and b.max() <= 1
+    assert_close("rgb (own samples)", out["rgb"], ref["rgb"], rtol=5e-3, atol=5e-3)
+    # identical samples
+    rs = rb.get_ray_samples(ref["starts"].to(device), ref["ends"].to(device))
+    sdf, grad, rgb, x = model.field.forward_fused(rs)
+    out_rgb, depth, normal, acc, weights, alpha = neus_render(
+        sdf, grad, rgb, model.field.deviation_network.variance, rs.flat_directions, rs.flat_starts, rs.flat_ends, ca, None)
+    assert_close("sdf", sdf, ref["sdf"], rtol=0, atol=1e-5)
+    assert_close("gradient", grad, ref["gradient"], rtol=1e-4, atol=1e-6)
+    assert_close("alpha", alpha, ref["alpha"], rtol=1e-4, atol=1e-6)
+    assert_close("weights", weights, ref["weights"], rtol=1e-4, atol=1e-6)
+    assert_close("rendered rgb", out_rgb.clamp(0, 1) if not training else out_rgb, ref["rgb"], rtol=1e-4, atol=1e-6)
+    hit = ref["accumulation"] > 0.05
+    assert_close("rendered depth", depth[hit.to(device)], ref["depth"][hit], rtol=1e-4, atol=1e-6)
+    assert_close("rendered normal", normal, ref["normal"], rtol=1e-4, atol=1e-6)
+    if training:
+        loss = F.l1_loss(g["in"]["image"].to(device), out_rgb) + ((grad.norm(2, dim=-1) - 1) ** 2).mean() * cfg.eikonal_loss_mult
+        assert_close("loss", loss, g["loss"]["rgb_loss"] + g["loss"]["eikonal_loss"], rtol=1e-4, atol=1e-7)
+        model.zero_grad()
+        loss.backward()
+        got = product_grads(model)
+        n_checked = 0
+        for k, rg in g["grad"].items():
+            assert k in got, f"no gradient for {k}"
+            assert_close(f"grad {k}", got[k], rg, rtol=5e-3, atol=1e-8)
+            n_checked += 1
+        assert n_checked >= 40
 
 
 # ------------------------------------------------------------------------------------------------ density weights
