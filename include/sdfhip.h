@@ -127,14 +127,36 @@ int sdfhip_proposal_backward(const SdfHipGridCfg* grid, const float* table, cons
  * jitter: [n_rays] single-jitter draw (training) or NULL (eval).  bins: [n_rays, S+1]; starts/ends [n_rays, S]. */
 int sdfhip_sample_spaced(const float* nears, const float* fars, const float* jitter, int64_t n_rays, int32_t n_samples,
                          float* bins, float* starts, float* ends, sdfhip_stream_t stream);
-/* UniformSampler (ray_samplers.py:130-151): identity spacing, euclidean = x far + (1 - x) near.  Same arguments. */
-int sdfhip_sample_uniform(const float* nears, const float* fars, const float* jitter, int64_t n_rays, int32_t n_samples,
-                          float* bins, float* starts, float* ends, sdfhip_stream_t stream);
+/* UniformSampler (ray_samplers.py:130-151): identity spacing, euclidean = x far + (1 - x) near.
+ * jitter: [n_rays] (single_jitter) or, with jitter_per_sample != 0, [n_rays, n_samples+1] (ray_samplers.py:107-110), or NULL. */
+int sdfhip_sample_uniform(const float* nears, const float* fars, const float* jitter, int32_t jitter_per_sample, int64_t n_rays,
+                          int32_t n_samples, float* bins, float* starts, float* ends, sdfhip_stream_t stream);
 /* PDFSampler(include_original=False, single_jitter) (ray_samplers.py:275-370) applied to weights^anneal
  * (ProposalNetworkSampler :562).  Outputs are constants w.r.t. autograd (bins.detach(), :358). */
 int sdfhip_sample_pdf(const float* weights, const float* bins_in, const float* nears, const float* fars,
                       const float* jitter, int64_t n_rays, int32_t s_in, int32_t s_out, float anneal,
                       float histogram_padding, float* bins_out, float* starts, float* ends, sdfhip_stream_t stream);
+
+/* PDFSampler in UniformSampler spacing (the samplers NeuSSampler / ErrorBoundedSampler own, ray_samplers.py:607-611, 843-847);
+ * jitter [n_rays] or [n_rays, s_out+1] (jitter_per_sample) or NULL. */
+int sdfhip_sample_pdf_uniform(const float* weights, const float* bins_in, const float* nears, const float* fars, const float* jitter,
+                              int32_t jitter_per_sample, int64_t n_rays, int32_t s_in, int32_t s_out, float histogram_padding,
+                              float* bins_out, float* starts, float* ends, sdfhip_stream_t stream);
+/* ErrorBoundedSampler.merge_ray_samples (ray_samplers.py:757-786), UniformSampler spacing: bins_1 [N,s1+1], bins_2 [N,s2+1] ->
+ * merged_bins [N,s1+s2+1], merged_index [N,s1+s2] (int32, into cat(starts_1, starts_2)), euclidean merged_starts / merged_ends. */
+int sdfhip_merge_uniform(const float* bins_1, const float* bins_2, const float* nears, const float* fars, int64_t n_rays, int32_t s1,
+                         int32_t s2, float* merged_bins, int32_t* merged_index, float* merged_starts, float* merged_ends,
+                         sdfhip_stream_t stream);
+/* One outer iteration of VolSDF Algorithm 1 (ErrorBoundedSampler.generate_ray_samples, ray_samplers.py:650-683) up to the
+ * resampling weights: sdf = gather(cat(sdf_a, sdf_b), index) ; d* (get_dstar :704-726) ; beta by bisection on the error bound
+ * (get_updated_beta / get_error_bound :728-755) ; weights = get_weights_and_transmittance(laplace_density(sdf, beta)) ;
+ * err_weights = (clamp(exp(cumsum(error per section)), 1e6) - 1) * transmittance (:676-683).
+ * beta_in / beta_out [N]; beta0 [1] = density_fn.get_beta(); not_converged [1]: OR over rays of (beta_out > beta0), accumulated
+ * (the caller zeroes it; it is the reference's `beta.max() > beta0` host decision, :671). */
+int sdfhip_volsdf_bound_step(const float* bins_in, const float* sdf_a, const float* sdf_b, const int32_t* index, const float* nears,
+                             const float* fars, const float* beta_in, const float* beta0, int64_t n_rays, int32_t s_a, int32_t s_b,
+                             float eps, int32_t beta_iters, float* sdf_merged, float* beta_out, float* weights, float* err_weights,
+                             int32_t* not_converged, sdfhip_stream_t stream);
 
 /* One up-sampling step of NeuSSampler.generate_ray_samples (ray_samplers.py:851-886), UniformSampler spacing:
  *   sdf = gather(cat(sdf_a, sdf_b), index) (:864-868; index == NULL, s_b == 0 on the first step)

@@ -470,6 +470,125 @@ def neus_forward(origins, dirs, cam_idx, p: Params, cfg: "ModelCfg", cos_anneal_
             "starts": starts, "ends": ends, "bins": bins}
 
 
+# ----------------------------------------------------------------------------- VolSDF error-bounded sampler
+def volsdf_dstar(sdf: torch.Tensor, deltas: torch.Tensor) -> torch.Tensor:
+    """ray_samplers.py:704-726 get_dstar (Theorem 1 of VolSDF).  sdf, deltas [N,S] -> d* [N,S] (last column repeated)."""
+    a, b, c = deltas[:, :-1], sdf[:, :-1].abs(), sdf[:, 1:].abs()
+    first = a.pow(2) + b.pow(2) <= c.pow(2)
+    second = a.pow(2) + c.pow(2) <= b.pow(2)
+    d_star = torch.zeros_like(a)
+    d_star = torch.where(first, b, d_star)
+    d_star = torch.where(second, c, d_star)
+    s = (a + b + c) / 2.0
+    area = s * (s - a) * (s - b) * (s - c)
+    mask = ~first & ~second & (b + c - a > 0)
+    d_star = torch.where(mask, (2.0 * torch.sqrt(area)) / a, d_star)
+    d_star = (sdf[:, 1:].sign() * sdf[:, :-1].sign() == 1) * d_star
+    return torch.cat((d_star, d_star[:, -1:]), dim=-1)
+
+
+def volsdf_error_bound(beta: torch.Tensor, sdf: torch.Tensor, d_star: torch.Tensor, deltas: torch.Tensor) -> torch.Tensor:
+    """ray_samplers.py:740-755 get_error_bound.  beta [N,1] (or [1]); returns [N]."""
+    dd = deltas * laplace_density(sdf, beta)
+    integral = torch.cat([torch.zeros_like(dd[:, :1]), torch.cumsum(dd[:, :-1], dim=-1)], dim=-1)
+    per_section = torch.exp(-d_star / beta) * (deltas ** 2.0) / (4 * beta ** 2)
+    err_int = torch.cumsum(per_section, dim=-1)
+    bound = (torch.clamp(torch.exp(err_int), max=1.0e6) - 1.0) * torch.exp(-integral)
+    return bound.max(-1)[0]
+
+
+def volsdf_update_beta(beta0: torch.Tensor, beta: torch.Tensor, sdf, d_star, deltas, eps: float = 0.1, iters: int = 10):
+    """ray_samplers.py:728-738 get_updated_beta (bisection; the reference's in-place aliasing written functionally)."""
+    curr = volsdf_error_bound(beta0, sdf, d_star, deltas)
+    beta_max = torch.where(curr <= eps, beta0.expand_as(beta), beta)
+    beta_min = beta0.expand_as(beta).clone()
+    for _ in range(iters):
+        mid = (beta_min + beta_max) / 2.0
+        e = volsdf_error_bound(mid[:, None], sdf, d_star, deltas)
+        beta_max = torch.where(e <= eps, mid, beta_max)
+        beta_min = torch.where(e > eps, mid, beta_min)
+    return beta_max
+
+
+def weights_and_transmittance_from_density(density: torch.Tensor, deltas: torch.Tensor):
+    """cameras/rays.py:169-192: weights [N,S] and transmittance [N,S] (T_i BEFORE sample i)."""
+    dd = deltas * density
+    trans = torch.exp(-torch.cat([torch.zeros_like(dd[:, :1]), torch.cumsum(dd[:, :-1], dim=-1)], dim=-1))
+    return (1 - torch.exp(-dd)) * trans, trans
+
+
+def error_bounded_sampler(nears, fars, sdf_fn, beta0: torch.Tensor, num_samples: int = 64, num_samples_eval: int = 128,
+                          num_samples_extra: int = 32, eps: float = 0.1, beta_iters: int = 10, max_total_iters: int = 5,
+                          rand: Optional[List[torch.Tensor]] = None, trace: Optional[list] = None):
+    """ray_samplers.py:611-702 ErrorBoundedSampler.generate_ray_samples (VolSDF Algorithm 1), UniformSampler spacing.
+
+    sdf_fn(starts [N,S]) -> sdf [N,S].  beta0 = density_fn.get_beta() (shape [1]).  rand: the torch.rand draws in call order
+    (initial uniform [N,S_eval+1], one [N,n+1] per PDF call, extra uniform [N,extra+1]) or None (eval).
+    Returns final spacing bins and euclidean starts / ends ([N, num_samples + num_samples_extra])."""
+    n = nears.shape[0]
+    rq = list(rand) if rand is not None else None
+    draw = (lambda: rq.pop(0)) if rq is not None else (lambda: None)
+    bins = initial_bins(n, num_samples_eval, draw(), nears.dtype)
+    eu = uniform_to_euclidean(bins, nears, fars)
+    deltas = eu[:, 1:] - eu[:, :-1]
+    beta = torch.sqrt((1.0 / (4.0 * math.log(eps + 1.0))) * (deltas ** 2.0).sum(-1))
+    total, not_converge, index, sdf, new_bins = 0, True, None, None, bins
+    while not_converge and total < max_total_iters:
+        with torch.no_grad():
+            new_sdf = sdf_fn(uniform_to_euclidean(new_bins, nears, fars)[:, :-1])
+        sdf = new_sdf if index is None else torch.gather(torch.cat([sdf, new_sdf], -1), 1, index)
+        eu = uniform_to_euclidean(bins, nears, fars)
+        deltas = eu[:, 1:] - eu[:, :-1]
+        d_star = volsdf_dstar(sdf, deltas)
+        rec = {"bins_in": bins, "sdf_in": sdf, "beta_in": beta}
+        beta = volsdf_update_beta(beta0, beta, sdf, d_star, deltas, eps, beta_iters)
+        weights, trans = weights_and_transmittance_from_density(laplace_density(sdf, beta[:, None]), deltas)
+        total += 1
+        not_converge = bool(beta.max() > beta0)
+        rec.update({"beta_out": beta, "weights": weights})
+        if not_converge and total < max_total_iters:
+            per_section = torch.exp(-d_star / beta[:, None]) * (deltas ** 2.0) / (4 * beta[:, None] ** 2)
+            w = (torch.clamp(torch.exp(torch.cumsum(per_section, dim=-1)), max=1.0e6) - 1.0) * trans
+            new_bins = pdf_sample(w, bins, num_samples_eval, draw(), histogram_padding=1e-5)
+            rec.update({"err_weights": w, "new_bins": new_bins})
+            bins, index = merge_bins(bins, new_bins)
+            rec.update({"merged_bins": bins, "index": index})
+        else:
+            bins = pdf_sample(weights, bins, num_samples, draw(), histogram_padding=1e-5)
+            rec.update({"final_bins": bins})
+        if trace is not None:
+            trace.append(rec)
+    if num_samples_extra > 0:
+        bins, _ = merge_bins(bins, initial_bins(n, num_samples_extra, draw(), nears.dtype))
+    eu = uniform_to_euclidean(bins, nears, fars)
+    return bins, eu[:, :-1], eu[:, 1:]
+
+
+def volsdf_forward(origins, dirs, cam_idx, p: Params, cfg: "ModelCfg", rand=None, mask=None, training=True,
+                   num_samples: int = 64, num_samples_eval: int = 128, num_samples_extra: int = 32, samples=None, trace=None):
+    """models/volsdf.py:62-79 + base_surface_model.py:292-365 (background_model == 'none', black background): density from the
+    Laplace CDF of the sdf (sdf_field.py:49-71), weights from density (rays.py:146-167)."""
+    n = origins.shape[0]
+    nears = torch.full((n,), cfg.near, dtype=origins.dtype)
+    fars = torch.full((n,), cfg.far, dtype=origins.dtype)
+
+    def sdf_fn(starts):
+        pos = origins[:, None, :] + dirs[:, None, :] * starts[..., None]  # NOT contracted (sdf_field.py:412-418)
+        return geo_network(pos.reshape(-1, 3), p, cfg.field, mask)[:, 0].view(starts.shape)
+
+    if samples is None:
+        beta0 = (p["laplace_density.beta"].abs() + p["laplace_density.beta_min"]).detach()
+        bins, starts, ends = error_bounded_sampler(nears, fars, sdf_fn, beta0, num_samples, num_samples_eval, num_samples_extra,
+                                                   rand=rand, trace=trace)
+    else:
+        bins, starts, ends = samples
+    fo = field_outputs(origins, dirs, starts, ends - starts, cam_idx, p, cfg.field, mask, 1.0, training)
+    weights, trans = weights_and_transmittance_from_density(fo["density"], ends - starts)
+    rgb, depth, normal, acc = render(weights, fo["rgb"], fo["normal"], starts, ends)
+    return {"rgb": rgb, "depth": depth, "normal": normal, "accumulation": acc, "weights": weights, "field": fo,
+            "starts": starts, "ends": ends, "bins": bins}
+
+
 # ----------------------------------------------------------------------------- losses
 def _blur_stepfun(x, y, r):
     """model_components/losses.py:116-128."""

@@ -70,8 +70,15 @@ _SIGNATURES = {
                                          c_float_p, c_float_p, ctypes.c_void_p]),
     "sdfhip_sample_spaced": (c_i32, [c_float_p, c_float_p, c_float_p, c_i64, c_i32, c_float_p, c_float_p, c_float_p,
                                      ctypes.c_void_p]),
-    "sdfhip_sample_uniform": (c_i32, [c_float_p, c_float_p, c_float_p, c_i64, c_i32, c_float_p, c_float_p, c_float_p,
+    "sdfhip_sample_uniform": (c_i32, [c_float_p, c_float_p, c_float_p, c_i32, c_i64, c_i32, c_float_p, c_float_p, c_float_p,
                                       ctypes.c_void_p]),
+    "sdfhip_sample_pdf_uniform": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_i32, c_i64, c_i32, c_i32, c_f32,
+                                          c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
+    "sdfhip_merge_uniform": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, c_i64, c_i32, c_i32, c_float_p, ctypes.c_void_p,
+                                     c_float_p, c_float_p, ctypes.c_void_p]),
+    "sdfhip_volsdf_bound_step": (c_i32, [c_float_p, c_float_p, c_float_p, ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p,
+                                         c_i64, c_i32, c_i32, c_f32, c_i32, c_float_p, c_float_p, c_float_p, c_float_p,
+                                         ctypes.c_void_p, ctypes.c_void_p]),
     "sdfhip_neus_upsample": (c_i32, [c_float_p, c_float_p, c_float_p, ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_i64, c_i32,
                                      c_i32, c_i32, c_f32, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_void_p,
                                      c_float_p, c_float_p, ctypes.c_void_p]),

@@ -860,13 +860,14 @@ extern "C" int sdfhip_proposal_backward(const SdfHipGridCfg* grid, const float* 
 }
 
 // ------------------------------------------------------------------------------------------------ samplers
-static int sample_spaced_impl(const float* nears, const float* fars, const float* jitter, int64_t n_rays, int32_t n_samples, int uniform,
-                              float* bins, float* starts, float* ends, sdfhip_stream_t stream) {
+static int sample_spaced_impl(const float* nears, const float* fars, const float* jitter, int jitter_per_sample, int64_t n_rays,
+                              int32_t n_samples, int uniform, float* bins, float* starts, float* ends, sdfhip_stream_t stream) {
   SDFHIP_REQUIRE(nears && fars && bins && starts && ends && n_samples >= 1, "sample_spaced: bad argument");
   BinsArgs a;
   a.nears = nears;
   a.fars = fars;
   a.jitter = jitter;
+  a.jitter_stride = (jitter != nullptr && jitter_per_sample) ? n_samples + 1 : 0;
   a.N = (int)n_rays;
   a.S = n_samples;
   a.uniform = uniform;
@@ -881,11 +882,12 @@ static int sample_spaced_impl(const float* nears, const float* fars, const float
 }
 extern "C" int sdfhip_sample_spaced(const float* nears, const float* fars, const float* jitter, int64_t n_rays, int32_t n_samples,
                                     float* bins, float* starts, float* ends, sdfhip_stream_t stream) {
-  return sample_spaced_impl(nears, fars, jitter, n_rays, n_samples, 0, bins, starts, ends, stream);
+  return sample_spaced_impl(nears, fars, jitter, 0, n_rays, n_samples, 0, bins, starts, ends, stream);
 }
-extern "C" int sdfhip_sample_uniform(const float* nears, const float* fars, const float* jitter, int64_t n_rays, int32_t n_samples,
-                                     float* bins, float* starts, float* ends, sdfhip_stream_t stream) {
-  return sample_spaced_impl(nears, fars, jitter, n_rays, n_samples, 1, bins, starts, ends, stream);
+extern "C" int sdfhip_sample_uniform(const float* nears, const float* fars, const float* jitter, int32_t jitter_per_sample,
+                                     int64_t n_rays, int32_t n_samples, float* bins, float* starts, float* ends,
+                                     sdfhip_stream_t stream) {
+  return sample_spaced_impl(nears, fars, jitter, jitter_per_sample, n_rays, n_samples, 1, bins, starts, ends, stream);
 }
 
 #define SDFHIP_DISPATCH_C(S, CALL)                                      \
@@ -894,20 +896,23 @@ extern "C" int sdfhip_sample_uniform(const float* nears, const float* fars, cons
     if (c_ <= 1) { constexpr int C = 1; CALL; }                         \
     else if (c_ <= 2) { constexpr int C = 2; CALL; }                    \
     else if (c_ <= 4) { constexpr int C = 4; CALL; }                    \
-    else { constexpr int C = 8; CALL; }                                 \
+    else if (c_ <= 8) { constexpr int C = 8; CALL; }                    \
+    else { constexpr int C = 16; CALL; }                                \
   } while (0)
 
-extern "C" int sdfhip_sample_pdf(const float* weights, const float* bins_in, const float* nears, const float* fars, const float* jitter,
-                                 int64_t n_rays, int32_t s_in, int32_t s_out, float anneal, float histogram_padding, float* bins_out,
-                                 float* starts, float* ends, sdfhip_stream_t stream) {
+static int sample_pdf_impl(const float* weights, const float* bins_in, const float* nears, const float* fars, const float* jitter,
+                           int jitter_per_sample, int uniform, int64_t n_rays, int32_t s_in, int32_t s_out, float anneal,
+                           float histogram_padding, float* bins_out, float* starts, float* ends, sdfhip_stream_t stream) {
   SDFHIP_REQUIRE(weights && bins_in && nears && fars && bins_out && starts && ends, "sample_pdf: null argument");
-  SDFHIP_REQUIRE(s_in >= 1 && s_in <= 64 * kMaxPerLane && s_out >= 1, "sample_pdf: s_in %d / s_out %d unsupported", s_in, s_out);
+  SDFHIP_REQUIRE(s_in >= 1 && s_in <= 64 * kMaxPerLane && s_out >= 1, "sample_pdf: unsupported sample counts (%d -> %d)", s_in, s_out);
   PdfArgs a;
   a.weights = weights;
   a.bins_in = bins_in;
   a.nears = nears;
   a.fars = fars;
   a.jitter = jitter;
+  a.jitter_stride = (jitter != nullptr && jitter_per_sample) ? s_out + 1 : 0;
+  a.uniform = uniform;
   a.N = (int)n_rays;
   a.S_in = s_in;
   a.S_out = s_out;
@@ -915,14 +920,87 @@ extern "C" int sdfhip_sample_pdf(const float* weights, const float* bins_in, con
   a.histogram_padding = histogram_padding;
   a.eps = 1e-5f;
   const int nbins = s_out + 1;
-  a.u_end = (float)(1.0 - 1.0 / (double)nbins);
-  a.u_center = (float)(1.0 / (double)(2 * nbins));
+  a.u_end = (float)(1.0 - 1.0 / (double)nbins);     // python float arithmetic, then cast (torch.linspace end)
+  a.u_center = (float)(1.0 / (2.0 * (double)nbins));
   a.bins_out = bins_out;
   a.starts = starts;
   a.ends = ends;
   if (n_rays == 0) return 0;
   const unsigned grid = (unsigned)((n_rays + 3) / 4);
   { ProfScope ps_(PS_SAMPLERS, (hipStream_t)stream); SDFHIP_DISPATCH_C(s_in, (pdf_sample_kernel<C><<<grid, 256, 0, (hipStream_t)stream>>>(a))); }
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int sdfhip_sample_pdf(const float* weights, const float* bins_in, const float* nears, const float* fars, const float* jitter,
+                                 int64_t n_rays, int32_t s_in, int32_t s_out, float anneal, float histogram_padding, float* bins_out,
+                                 float* starts, float* ends, sdfhip_stream_t stream) {
+  return sample_pdf_impl(weights, bins_in, nears, fars, jitter, 0, 0, n_rays, s_in, s_out, anneal, histogram_padding, bins_out, starts, ends,
+                         stream);
+}
+extern "C" int sdfhip_sample_pdf_uniform(const float* weights, const float* bins_in, const float* nears, const float* fars,
+                                         const float* jitter, int32_t jitter_per_sample, int64_t n_rays, int32_t s_in, int32_t s_out,
+                                         float histogram_padding, float* bins_out, float* starts, float* ends, sdfhip_stream_t stream) {
+  return sample_pdf_impl(weights, bins_in, nears, fars, jitter, jitter_per_sample, 1, n_rays, s_in, s_out, 1.0f, histogram_padding, bins_out,
+                         starts, ends, stream);
+}
+
+extern "C" int sdfhip_merge_uniform(const float* bins_1, const float* bins_2, const float* nears, const float* fars, int64_t n_rays,
+                                    int32_t s1, int32_t s2, float* merged_bins, int32_t* merged_index, float* merged_starts,
+                                    float* merged_ends, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(bins_1 && bins_2 && nears && fars && merged_bins && merged_index && merged_starts && merged_ends && s1 >= 1 && s2 >= 1,
+                 "merge_uniform: bad argument");
+  if (n_rays == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  MergeArgs a;
+  a.bins_1 = bins_1;
+  a.bins_2 = bins_2;
+  a.nears = nears;
+  a.fars = fars;
+  a.N = (int)n_rays;
+  a.S1 = s1;
+  a.S2 = s2;
+  a.merged_bins = merged_bins;
+  a.merged_index = merged_index;
+  const int M = s1 + s2;
+  const int64_t total = n_rays * (M + 1);
+  ProfScope ps_(PS_SAMPLERS, s);
+  merge_bins_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(a);
+  uniform_euclid_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(merged_bins, nears, fars, (int)n_rays, M, merged_starts, merged_ends);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfhip_volsdf_bound_step(const float* bins_in, const float* sdf_a, const float* sdf_b, const int32_t* index,
+                                        const float* nears, const float* fars, const float* beta_in, const float* beta0, int64_t n_rays,
+                                        int32_t s_a, int32_t s_b, float eps, int32_t beta_iters, float* sdf_merged, float* beta_out,
+                                        float* weights, float* err_weights, int32_t* not_converged, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(bins_in && sdf_a && nears && fars && beta_in && beta0 && sdf_merged && beta_out && weights && err_weights && not_converged,
+                 "volsdf_bound_step: null argument");
+  SDFHIP_REQUIRE((s_b == 0) == (index == nullptr) && (s_b == 0 || sdf_b != nullptr), "volsdf_bound_step: sdf_b / index must come together");
+  const int S = s_a + s_b;
+  SDFHIP_REQUIRE(S >= 2 && S <= 64 * kMaxPerLane, "volsdf_bound_step: %d samples unsupported (2..%d)", S, 64 * kMaxPerLane);
+  VolsdfStepArgs a;
+  a.bins_in = bins_in;
+  a.sdf_a = sdf_a;
+  a.sdf_b = sdf_b;
+  a.index = index;
+  a.nears = nears;
+  a.fars = fars;
+  a.beta_in = beta_in;
+  a.beta0 = beta0;
+  a.N = (int)n_rays;
+  a.Sa = s_a;
+  a.Sb = s_b;
+  a.beta_iters = beta_iters;
+  a.eps = eps;
+  a.sdf_merged = sdf_merged;
+  a.beta_out = beta_out;
+  a.weights = weights;
+  a.err_weights = err_weights;
+  a.not_converged = not_converged;
+  if (n_rays == 0) return 0;
+  const unsigned grid = (unsigned)((n_rays + 3) / 4);
+  { ProfScope ps_(PS_SAMPLERS, (hipStream_t)stream); SDFHIP_DISPATCH_C(S, (volsdf_step_kernel<C><<<grid, 256, 0, (hipStream_t)stream>>>(a))); }
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }

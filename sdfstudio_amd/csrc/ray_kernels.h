@@ -8,7 +8,7 @@
 #pragma once
 #include "common.h"
 
-constexpr int kMaxPerLane = 8;  // S <= 512
+constexpr int kMaxPerLane = 16;  // S <= 1024
 
 SDFHIP_D float wave_incl_scan_add(float v, const int lane) {
 #pragma unroll
@@ -408,7 +408,8 @@ SDFHIP_D float piecewise_inv(const float x) { return x < 0.5f ? 2.0f * x : 1.0f 
 struct BinsArgs {
   const float* nears;  // [N]
   const float* fars;   // [N]
-  const float* jitter; // [N] single-jitter draw in [0,1) or null (deterministic)
+  const float* jitter; // [N] single-jitter draw in [0,1), [N,S+1] per-sample draws (jitter_stride = S+1), or null (deterministic)
+  int32_t jitter_stride;
   int32_t N, S;        // S samples -> S+1 bins
   int32_t uniform;     // 0: UniformLinDispPiecewiseSampler spacing (ray_samplers.py:240-241), 1: UniformSampler (identity, :130-151)
   float* bins;         // [N,S+1] spacing-domain bins
@@ -429,7 +430,7 @@ __global__ void spaced_bins_kernel(const BinsArgs a) {
   if (a.jitter != nullptr) {
     const float lo = j == 0 ? lin(0) : (lin(j) + lin(j - 1)) * 0.5f;
     const float hi = j == a.S ? lin(a.S) : (lin(j + 1) + lin(j)) * 0.5f;
-    b = lo + (hi - lo) * a.jitter[ray];
+    b = lo + (hi - lo) * a.jitter[a.jitter_stride ? (int64_t)ray * a.jitter_stride + j : ray];
   }
   a.bins[idx] = b;
   float e;
@@ -448,7 +449,8 @@ struct PdfArgs {
   const float* bins_in;   // [N,S_in+1]
   const float* nears;
   const float* fars;
-  const float* jitter;    // [N] or null
+  const float* jitter;    // [N], [N,S_out+1] (jitter_stride = S_out+1) or null
+  int32_t jitter_stride, uniform;  // uniform: UniformSampler spacing (euclid = x far + (1 - x) near) instead of the piecewise one
   int32_t N, S_in, S_out;
   float anneal, histogram_padding, eps;
   float u_end;      // float(1 - 1/(S_out+1))            (ray_samplers.py:323)
@@ -473,7 +475,10 @@ __global__ __launch_bounds__(256) void pdf_sample_kernel(const PdfArgs a) {
   for (int c = 0; c < C; ++c) {
     const int s = lane * C + c;
     w[c] = 0.0f;
-    if (s < Si) w[c] = powf(a.weights[(int64_t)ray * Si + s], a.anneal) + a.histogram_padding;
+    if (s < Si) {
+      const float wv = a.weights[(int64_t)ray * Si + s];
+      w[c] = (a.anneal == 1.0f ? wv : powf(wv, a.anneal)) + a.histogram_padding;
+    }
     local += w[c];
   }
   float wsum = wave_sum(local);
@@ -505,14 +510,15 @@ __global__ __launch_bounds__(256) void pdf_sample_kernel(const PdfArgs a) {
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave are done (single-wave producer/consumer)
   __builtin_amdgcn_wave_barrier();
   const int nbins = a.S_out + 1;
-  const float sn = piecewise_fn(a.nears[ray]), sf = piecewise_fn(a.fars[ray]);
+  const float near_ = a.nears[ray], far_ = a.fars[ray];
+  const float sn = piecewise_fn(near_), sf = piecewise_fn(far_);
   const float* bin = a.bins_in + (int64_t)ray * (Si + 1);
   for (int j = lane; j < nbins; j += 64) {
     // u = linspace(0, 1 - 1/nbins, nbins)[j] + (jitter / nbins | 1/(2 nbins))      (ray_samplers.py:321-334)
     const float end = a.u_end;
     const float step = end / (float)(nbins - 1);
     float u = j < nbins / 2 ? step * (float)j : end - step * (float)(nbins - 1 - j);
-    u += a.jitter != nullptr ? a.jitter[ray] / (float)nbins : a.u_center;
+    u += a.jitter != nullptr ? a.jitter[a.jitter_stride ? (int64_t)ray * a.jitter_stride + j : ray] / (float)nbins : a.u_center;
     // searchsorted(cdf, u, side="right"): first index with cdf[idx] > u
     int lo = 0, hi = Si + 1;
     while (lo < hi) {
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(256) void pdf_sample_kernel(const PdfArgs a) {
     t = fminf(fmaxf(t, 0.0f), 1.0f); // +-inf clip like torch.clip after nan_to_num
     const float b = b0 + t * (b1 - b0);
     a.bins_out[(int64_t)ray * nbins + j] = b;
-    const float e = piecewise_inv(b * sf + (1.0f - b) * sn);
+    const float e = a.uniform ? b * far_ + (1.0f - b) * near_ : piecewise_inv(b * sf + (1.0f - b) * sn);
     if (j < a.S_out) a.starts[(int64_t)ray * a.S_out + j] = e;
     if (j > 0) a.ends[(int64_t)ray * a.S_out + j - 1] = e;
   }
@@ -705,5 +711,223 @@ __global__ __launch_bounds__(256) void neus_upsample_kernel(const NeusUpArgs a) 
       a.merged_starts[(int64_t)ray * M + i] = euclid(b0);
       a.merged_ends[(int64_t)ray * M + i] = euclid(merged[i + 1]);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ VolSDF error-bounded sampler
+// merge_ray_samples (ray_samplers.py:757-786) for two sorted bin sets in UniformSampler spacing: thread per element, rank by
+// binary search in the other list (list 1 first on ties, as a stable sort of cat(starts_1, starts_2)).
+struct MergeArgs {
+  const float* bins_1;  // [N,S1+1]
+  const float* bins_2;  // [N,S2+1]
+  const float* nears;
+  const float* fars;
+  int32_t N, S1, S2;
+  float* merged_bins;     // [N,S1+S2+1]
+  int32_t* merged_index;  // [N,S1+S2]
+};
+__global__ void merge_bins_kernel(const MergeArgs a) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int M = a.S1 + a.S2;
+  if (idx >= (int64_t)a.N * (M + 1)) return;
+  const int ray = (int)(idx / (M + 1)), e = (int)(idx % (M + 1));
+  const float* b1 = a.bins_1 + (int64_t)ray * (a.S1 + 1);
+  const float* b2 = a.bins_2 + (int64_t)ray * (a.S2 + 1);
+  float* mb = a.merged_bins + (int64_t)ray * (M + 1);
+  int32_t* mi = a.merged_index + (int64_t)ray * M;
+  if (e == M) {
+    mb[M] = fmaxf(b1[a.S1], b2[a.S2]);
+  } else if (e < a.S1) {
+    const float v = b1[e];
+    int lo = 0, hi = a.S2;
+    while (lo < hi) {
+      const int m = (lo + hi) >> 1;
+      if (b2[m] < v) lo = m + 1; else hi = m;
+    }
+    mb[e + lo] = v;
+    mi[e + lo] = e;
+  } else {
+    const int j = e - a.S1;
+    const float v = b2[j];
+    int lo = 0, hi = a.S1;
+    while (lo < hi) {
+      const int m = (lo + hi) >> 1;
+      if (b1[m] <= v) lo = m + 1; else hi = m;
+    }
+    mb[j + lo] = v;
+    mi[j + lo] = a.S1 + j;
+  }
+}
+// euclidean starts / ends of uniform-spacing bins [N,S+1]
+__global__ void uniform_euclid_kernel(const float* __restrict__ bins, const float* __restrict__ nears, const float* __restrict__ fars,
+                                      const int N, const int S, float* __restrict__ starts, float* __restrict__ ends) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * (S + 1)) return;
+  const int ray = (int)(idx / (S + 1)), j = (int)(idx % (S + 1));
+  const float b = bins[idx];
+  const float e = b * fars[ray] + (1.0f - b) * nears[ray];
+  if (j < S) starts[(int64_t)ray * S + j] = e;
+  if (j > 0) ends[(int64_t)ray * S + j - 1] = e;
+}
+
+// One outer iteration of VolSDF Algorithm 1 up to the resampling weights (ray_samplers.py:650-674): merge the new sdf values
+// (:654-658), d* (Theorem 1, :704-726), beta by bisection on the error bound (:728-755: 1 + beta_iters bound evaluations, each two
+// wave scans and a max), density -> weights / transmittance (rays.py:169-192), and the error-proportional weights (:676-683).
+// One wavefront per ray, C consecutive samples per lane, everything in registers between the scans.
+struct VolsdfStepArgs {
+  const float* bins_in;   // [N,S+1]
+  const float* sdf_a;     // [N,Sa]
+  const float* sdf_b;     // [N,Sb] or null
+  const int32_t* index;   // [N,S] or null
+  const float* nears;
+  const float* fars;
+  const float* beta_in;   // [N]
+  const float* beta0;     // [1]  density_fn.get_beta()
+  int32_t N, Sa, Sb, beta_iters;
+  float eps;
+  float* sdf_merged;      // [N,S]
+  float* beta_out;        // [N]
+  float* weights;         // [N,S]
+  float* err_weights;     // [N,S]
+  int32_t* not_converged; // [1]  max over rays of (beta_out > beta0); caller zeroes
+};
+
+SDFHIP_D float laplace_density_f(const float sdf, const float beta) {  // sdf_field.py:49-71
+  const float sg = sdf > 0.0f ? 1.0f : (sdf < 0.0f ? -1.0f : 0.0f);
+  return (1.0f / beta) * (0.5f + 0.5f * sg * expm1f(-fabsf(sdf) / beta));
+}
+SDFHIP_D float wave_max(float v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v = fmaxf(v, __shfl_xor(v, m));
+  return v;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void volsdf_step_kernel(const VolsdfStepArgs a) {
+  __shared__ float sdf_s[4][64 * C + 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ray = blockIdx.x * 4 + wv;
+  if (ray >= a.N) return;
+  const int S = a.Sa + a.Sb;
+  float* sl = sdf_s[wv];
+  const float near = a.nears[ray], far = a.fars[ray];
+  const float* bin = a.bins_in + (int64_t)ray * (S + 1);
+  for (int s = lane; s < S; s += 64) {
+    const int src = a.index != nullptr ? a.index[(int64_t)ray * S + s] : s;
+    const float v = src < a.Sa ? a.sdf_a[(int64_t)ray * a.Sa + src] : a.sdf_b[(int64_t)ray * a.Sb + (src - a.Sa)];
+    sl[s] = v;
+    a.sdf_merged[(int64_t)ray * S + s] = v;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  float sd[C], dl[C], ds[C];
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int i = lane * C + c;
+    sd[c] = 0.0f;
+    dl[c] = 0.0f;
+    ds[c] = 0.0f;
+    if (i < S) {
+      sd[c] = sl[i];
+      const float b0 = bin[i], b1 = bin[i + 1];
+      dl[c] = (b1 * far + (1.0f - b1) * near) - (b0 * far + (1.0f - b0) * near);
+    }
+  }
+  // d*: interval i uses samples i and i + 1; the last sample repeats the previous interval's value
+  auto dstar_of = [&](const int i, const float dist) {
+    const float s0 = sl[i], s1 = sl[i + 1];
+    const float A = dist, B = fabsf(s0), Cc = fabsf(s1);
+    const bool first = A * A + B * B <= Cc * Cc, second = A * A + Cc * Cc <= B * B;
+    float d = 0.0f;
+    if (first) d = B;
+    if (second) d = Cc;
+    const float sh = (A + B + Cc) * 0.5f;
+    const float area = sh * (sh - A) * (sh - B) * (sh - Cc);
+    if (!first && !second && (B + Cc - A > 0.0f)) d = (2.0f * sqrtf(area)) / A;
+    const float sg0 = s0 > 0.0f ? 1.0f : (s0 < 0.0f ? -1.0f : 0.0f), sg1 = s1 > 0.0f ? 1.0f : (s1 < 0.0f ? -1.0f : 0.0f);
+    return (sg0 * sg1 == 1.0f) ? d : 0.0f;
+  };
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int i = lane * C + c;
+    if (i < S - 1) {
+      ds[c] = dstar_of(i, dl[c]);
+    } else if (i == S - 1 && S >= 2) {
+      const float b0 = bin[S - 2], b1 = bin[S - 1];
+      ds[c] = dstar_of(S - 2, (b1 * far + (1.0f - b1) * near) - (b0 * far + (1.0f - b0) * near));
+    }
+  }
+  // error bound for a given beta (get_error_bound); optionally returns per-sample transmittance and error integral
+  auto error_bound = [&](const float beta) {
+    float dd[C], es[C];
+    float ldd = 0.0f, les = 0.0f;
+    const float inv4b2 = 1.0f / (4.0f * beta * beta);
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int i = lane * C + c;
+      dd[c] = i < S ? dl[c] * laplace_density_f(sd[c], beta) : 0.0f;
+      es[c] = i < S ? expf(-ds[c] / beta) * (dl[c] * dl[c]) * inv4b2 : 0.0f;
+      ldd += dd[c];
+      les += es[c];
+    }
+    float integral = wave_incl_scan_add(ldd, lane) - ldd;  // exclusive over lanes
+    float err = wave_incl_scan_add(les, lane) - les;
+    float mx = 0.0f;
+    bool any = false;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const int i = lane * C + c;
+      if (i < S) {
+        err += es[c];
+        const float bnd = (fminf(expf(err), 1.0e6f) - 1.0f) * expf(-integral);
+        mx = any ? fmaxf(mx, bnd) : bnd;
+        any = true;
+        integral += dd[c];
+      }
+    }
+    // max over the S samples (all bounds are >= 0; lanes without samples contribute 0, which cannot exceed a real maximum >= 0)
+    return wave_max(any ? mx : 0.0f);
+  };
+  const float beta0 = a.beta0[0];
+  float beta = a.beta_in[ray];
+  {
+    const float curr = error_bound(beta0);
+    if (curr <= a.eps) beta = beta0;
+    float bmin = beta0, bmax = beta;
+    for (int j = 0; j < a.beta_iters; ++j) {
+      const float mid = (bmin + bmax) * 0.5f;
+      const float e = error_bound(mid);
+      if (e <= a.eps) bmax = mid; else bmin = mid;
+    }
+    beta = bmax;
+  }
+  // density -> weights, transmittance; error-proportional weights
+  float dd[C], es[C];
+  float ldd = 0.0f, les = 0.0f;
+  const float inv4b2 = 1.0f / (4.0f * beta * beta);
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int i = lane * C + c;
+    dd[c] = i < S ? dl[c] * laplace_density_f(sd[c], beta) : 0.0f;
+    es[c] = i < S ? expf(-ds[c] / beta) * (dl[c] * dl[c]) * inv4b2 : 0.0f;
+    ldd += dd[c];
+    les += es[c];
+  }
+  float integral = wave_incl_scan_add(ldd, lane) - ldd;
+  float err = wave_incl_scan_add(les, lane) - les;
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    const int i = lane * C + c;
+    if (i < S) {
+      const float T = expf(-integral);
+      err += es[c];
+      a.weights[(int64_t)ray * S + i] = (1.0f - expf(-dd[c])) * T;
+      a.err_weights[(int64_t)ray * S + i] = (fminf(expf(err), 1.0e6f) - 1.0f) * T;
+      integral += dd[c];
+    }
+  }
+  if (lane == 0) {
+    a.beta_out[ray] = beta;
+    if (beta > beta0) atomicMax(a.not_converged, 1);
   }
 }

@@ -185,8 +185,6 @@ class SDFField(nn.Module):
         unsupported = []
         if c.encoding_type != "hash":
             unsupported.append(f"encoding_type={c.encoding_type!r}")
-        if not c.use_grid_feature:
-            unsupported.append("use_grid_feature=False")
         if c.use_diffuse_color or c.use_specular_tint or c.use_reflections or c.use_n_dot_v:
             unsupported.append("ref-nerf colour options")
         if c.off_axis:
@@ -324,6 +322,10 @@ class SDFField(nn.Module):
     def _mask(self, device):
         if self.hash_encoding_mask.device != device:
             self.hash_encoding_mask = self.hash_encoding_mask.to(device)
+        if not self.use_grid_feature:
+            # sdf_field.py:389-390: without grid features the geometry network still has its 71 inputs, the feature columns are
+            # zeros (BASELINE config 1, "pure MLP"); an all-zero level mask makes the kernels skip the table entirely
+            return torch.zeros_like(self.hash_encoding_mask)
         return self.hash_encoding_mask
 
     def _run_inference(self, mode, origins, dirs, starts, n, s, want_feat):

@@ -77,12 +77,11 @@ class UniformLinDispPiecewiseSampler(Sampler):
 class UniformSampler(Sampler):
     """ray_samplers.py:130-151: uniform spacing (identity spacing_fn); euclidean = x far + (1 - x) near."""
 
-    def __init__(self, num_samples: Optional[int] = None, train_stratified=True, single_jitter=True) -> None:
+    def __init__(self, num_samples: Optional[int] = None, train_stratified=True, single_jitter=False) -> None:
         super().__init__(num_samples=num_samples)
-        if not single_jitter:
-            raise NotImplementedError("per-sample jitter is not built (NeuSSampler uses single_jitter=True, ray_samplers.py:826)")
         self.train_stratified = train_stratified
-        self.jitter_override: Optional[torch.Tensor] = None
+        self.single_jitter = single_jitter
+        self.jitter_override: Optional[torch.Tensor] = None  # tests: [N,1] (single) or [N,S+1] (per sample)
 
     def generate_ray_samples(self, ray_bundle: RayBundle, num_samples: Optional[int] = None) -> RaySamples:
         lib = _lib.load()
@@ -93,13 +92,14 @@ class UniformSampler(Sampler):
         fars = ray_bundle.fars.reshape(-1).contiguous()
         jitter = None
         if self.train_stratified and self.training:
-            jitter = self.jitter_override if self.jitter_override is not None else torch.rand(n, device=dev)
-            jitter = jitter.reshape(-1).contiguous()
+            shape = (n,) if self.single_jitter else (n, s + 1)
+            jitter = self.jitter_override if self.jitter_override is not None else torch.rand(shape, device=dev)
+            jitter = jitter.reshape(shape).contiguous()
         bins = torch.empty(n, s + 1, device=dev)
         starts = torch.empty(n, s, device=dev)
         ends = torch.empty(n, s, device=dev)
-        _lib.check(lib.sdfhip_sample_uniform(_lib.ptr(nears), _lib.ptr(fars), _lib.ptr(jitter), n, s, _lib.ptr(bins),
-                                             _lib.ptr(starts), _lib.ptr(ends), _lib.stream()), "sample_uniform")
+        _lib.check(lib.sdfhip_sample_uniform(_lib.ptr(nears), _lib.ptr(fars), _lib.ptr(jitter), 0 if self.single_jitter else 1, n, s,
+                                             _lib.ptr(bins), _lib.ptr(starts), _lib.ptr(ends), _lib.stream()), "sample_uniform")
         return _make_uniform_samples(ray_bundle, bins, starts, ends)
 
 
@@ -126,7 +126,7 @@ class NeuSSampler(Sampler):
         self.num_samples_outside = num_samples_outside  # unused by the reference as well (ray_samplers.py:888-893)
         self.num_upsample_steps = num_upsample_steps
         self.base_variance = base_variance
-        self.uniform_sampler = UniformSampler(single_jitter=single_jitter)
+        self.uniform_sampler = UniformSampler(single_jitter=True)
         self.jitter_overrides: Optional[List[torch.Tensor]] = None  # tests: one draw per up-sampling step
 
     def upsample_step(self, ray_bundle: RayBundle, bins, sdf_a, sdf_b, index, n_new: int, inv_s: float, jitter):
@@ -183,6 +183,123 @@ class NeuSSampler(Sampler):
                 ray_bundle, bins, sdf_a, sdf_b, index, n_new, self.base_variance * 2 ** it, jitter)
             new_samples = _make_uniform_samples(ray_bundle, new_bins, new_starts, new_ends)
         return _make_uniform_samples(ray_bundle, bins, m_starts, m_ends)
+
+
+class ErrorBoundedSampler(Sampler):
+    """ray_samplers.py:581-788 (VolSDF Algorithm 1).  Per outer iteration: the field's no-grad sdf at the new samples, ONE kernel
+    for merge + d* + the beta bisection (11 error-bound evaluations) + weights (sdfhip_volsdf_bound_step), then one PDF kernel and
+    one merge kernel; the reference issues several hundred small PyTorch kernels per iteration.  The loop-exit decision
+    (`beta.max() > beta0`, :671) is a host read of one int, as in the reference."""
+
+    def __init__(self, num_samples: int = 64, num_samples_eval: int = 128, num_samples_extra: int = 32, eps: float = 0.1,
+                 beta_iters: int = 10, max_total_iters: int = 5, add_tiny: float = 1e-6, single_jitter: bool = False) -> None:
+        super().__init__()
+        self.num_samples, self.num_samples_eval, self.num_samples_extra = num_samples, num_samples_eval, num_samples_extra
+        self.eps, self.beta_iters, self.max_total_iters, self.add_tiny = eps, beta_iters, max_total_iters, add_tiny
+        self.single_jitter = single_jitter
+        self.uniform_sampler = UniformSampler(single_jitter=single_jitter)
+        self.jitter_queue: Optional[List[torch.Tensor]] = None  # tests: the torch.rand draws in call order
+
+    def _draw(self, n, m, dev):
+        if not self.training:
+            return None
+        shape = (n,) if self.single_jitter else (n, m + 1)
+        if self.jitter_queue is not None:
+            return self.jitter_queue.pop(0).to(dev).reshape(shape).contiguous()
+        return torch.rand(shape, device=dev)
+
+    def _pdf(self, ray_bundle, weights, bins, s_out):
+        lib = _lib.load()
+        n, s_in = weights.shape
+        dev = weights.device
+        nears, fars = ray_bundle.nears.reshape(-1).contiguous(), ray_bundle.fars.reshape(-1).contiguous()
+        jitter = self._draw(n, s_out, dev)
+        out_bins = torch.empty(n, s_out + 1, device=dev)
+        starts = torch.empty(n, s_out, device=dev)
+        ends = torch.empty(n, s_out, device=dev)
+        _lib.check(lib.sdfhip_sample_pdf_uniform(_lib.ptr(weights.contiguous()), _lib.ptr(bins.contiguous()), _lib.ptr(nears),
+                                                 _lib.ptr(fars), _lib.ptr(jitter), 0 if self.single_jitter else 1, n, s_in, s_out,
+                                                 1e-5, _lib.ptr(out_bins), _lib.ptr(starts), _lib.ptr(ends), _lib.stream()),
+                   "sample_pdf_uniform")
+        return out_bins, starts, ends
+
+    def merge(self, ray_bundle, bins_1, bins_2):
+        """merge_ray_samples (:757-786) on spacing bins -> (bins, index, starts, ends)."""
+        lib = _lib.load()
+        n, s1, s2 = bins_1.shape[0], bins_1.shape[1] - 1, bins_2.shape[1] - 1
+        dev = bins_1.device
+        nears, fars = ray_bundle.nears.reshape(-1).contiguous(), ray_bundle.fars.reshape(-1).contiguous()
+        m_bins = torch.empty(n, s1 + s2 + 1, device=dev)
+        m_index = torch.empty(n, s1 + s2, device=dev, dtype=torch.int32)
+        m_starts = torch.empty(n, s1 + s2, device=dev)
+        m_ends = torch.empty(n, s1 + s2, device=dev)
+        _lib.check(lib.sdfhip_merge_uniform(_lib.ptr(bins_1.contiguous()), _lib.ptr(bins_2.contiguous()), _lib.ptr(nears), _lib.ptr(fars),
+                                            n, s1, s2, _lib.ptr(m_bins), m_index.data_ptr(), _lib.ptr(m_starts), _lib.ptr(m_ends),
+                                            _lib.stream()), "merge_uniform")
+        return m_bins, m_index, m_starts, m_ends
+
+    def bound_step(self, ray_bundle, bins, sdf_a, sdf_b, index, beta, beta0):
+        """One Algorithm-1 iteration up to the weights: (sdf_merged, beta_out, weights, err_weights, not_converged)."""
+        lib = _lib.load()
+        n, s = bins.shape[0], bins.shape[1] - 1
+        dev = bins.device
+        s_a = sdf_a.shape[1]
+        s_b = 0 if sdf_b is None else sdf_b.shape[1]
+        assert s_a + s_b == s
+        nears, fars = ray_bundle.nears.reshape(-1).contiguous(), ray_bundle.fars.reshape(-1).contiguous()
+        sdf_m = torch.empty(n, s, device=dev)
+        beta_out = torch.empty(n, device=dev)
+        weights = torch.empty(n, s, device=dev)
+        err_w = torch.empty(n, s, device=dev)
+        flag = torch.zeros(1, device=dev, dtype=torch.int32)
+        _lib.check(lib.sdfhip_volsdf_bound_step(
+            _lib.ptr(bins.contiguous()), _lib.ptr(sdf_a.contiguous()), _lib.ptr(None if sdf_b is None else sdf_b.contiguous()),
+            None if index is None else index.data_ptr(), _lib.ptr(nears), _lib.ptr(fars), _lib.ptr(beta.contiguous()),
+            _lib.ptr(beta0.reshape(1).contiguous()), n, s_a, s_b, float(self.eps), int(self.beta_iters), _lib.ptr(sdf_m),
+            _lib.ptr(beta_out), _lib.ptr(weights), _lib.ptr(err_w), flag.data_ptr(), _lib.stream()), "volsdf_bound_step")
+        return sdf_m, beta_out, weights, err_w, flag
+
+    def generate_ray_samples(self, ray_bundle: Optional[RayBundle] = None, density_fn: Optional[Callable] = None,
+                             sdf_fn: Optional[Callable] = None, return_eikonal_points: bool = True):
+        assert ray_bundle is not None and density_fn is not None and sdf_fn is not None
+        import math
+
+        n = len(ray_bundle)
+        dev = ray_bundle.origins.device
+        beta0 = density_fn.get_beta().detach().float()
+        self.uniform_sampler.train(self.training)
+        self.uniform_sampler.jitter_override = self._draw(n, self.num_samples_eval, dev)
+        ray_samples = self.uniform_sampler(ray_bundle, num_samples=self.num_samples_eval)
+        bins = ray_samples.flat_bins
+        deltas = ray_samples.flat_ends - ray_samples.flat_starts
+        beta = torch.sqrt((1.0 / (4.0 * math.log(self.eps + 1.0))) * (deltas ** 2.0).sum(-1))  # Lemma 2 (:625-626)
+        total, not_converge = 0, True
+        sdf, index, new_samples = None, None, ray_samples
+        while not_converge and total < self.max_total_iters:
+            with torch.no_grad():
+                new_sdf = sdf_fn(new_samples)[..., 0]
+            sdf_a, sdf_b = (new_sdf, None) if sdf is None else (sdf, new_sdf)
+            sdf, beta, weights, err_w, flag = self.bound_step(ray_bundle, bins, sdf_a, sdf_b, index, beta, beta0)
+            total += 1
+            not_converge = bool(flag.item())  # `beta.max() > beta0` (:671): the reference's host decision
+            if not_converge and total < self.max_total_iters:
+                new_bins, new_starts, new_ends = self._pdf(ray_bundle, err_w, bins, self.num_samples_eval)
+                new_samples = _make_uniform_samples(ray_bundle, new_bins, new_starts, new_ends)
+                bins, index, _, _ = self.merge(ray_bundle, bins, new_bins)
+            else:
+                bins, f_starts, f_ends = self._pdf(ray_bundle, weights, bins, self.num_samples)
+        out = _make_uniform_samples(ray_bundle, bins, f_starts, f_ends)
+        points = None
+        if return_eikonal_points:
+            # :685-689: random near-surface points (unused by the models: base_surface_model.py:343-345)
+            mid = out.frustums.get_positions().reshape(-1, 3)
+            points = mid[torch.randint(mid.shape[0], (n * 10,), device=dev)]
+        if self.num_samples_extra > 0:
+            self.uniform_sampler.jitter_override = self._draw(n, self.num_samples_extra, dev)
+            extra = self.uniform_sampler(ray_bundle, num_samples=self.num_samples_extra)
+            bins, _, m_starts, m_ends = self.merge(ray_bundle, bins, extra.flat_bins)
+            out = _make_uniform_samples(ray_bundle, bins, m_starts, m_ends)
+        return (out, points) if return_eikonal_points else out
 
 
 class PDFSampler(Sampler):

@@ -390,9 +390,212 @@ def main_neus():
         print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
+class _RandByShape:
+    """torch.rand replacement that serves preset tensors per requested shape and records the order they were used in."""
+
+    def __init__(self, pools):
+        self.pools = {k: list(v) for k, v in pools.items()}
+        self.used = []
+        self._orig = torch.rand
+
+    def __enter__(self):
+        def fake(*size, **kw):
+            shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else tuple(size)
+            t = self.pools[shape].pop(0)
+            self.used.append(t)
+            return t.clone()
+
+        torch.rand = fake
+        return self
+
+    def __exit__(self, *a):
+        torch.rand = self._orig
+
+
+def main_volsdf():
+    """VolSDF (models/volsdf.py), BASELINE config 1 flavour: pure-MLP SDF field (use_grid_feature=False: zero grid features,
+    sdf_field.py:389-390), ErrorBoundedSampler (ray_samplers.py:581), density rendering.  Nothing of tiny-cuda-nn is involved,
+    so this golden pins the oracle against the reference with no shim in the loop.  Writes tests/golden/volsdf_small_{train,eval}.npz."""
+    ns = ref_harness.import_reference()
+    cfg = small_cfg()
+    cfg.field.use_grid_feature = False
+    p = {k: v for k, v in perturbed_params(cfg).items() if not k.startswith("proposal_networks.")}
+    p["laplace_density.beta"] = torch.full((1,), 0.02)
+    n = 40
+    origins, dirs, cam = O.synthetic_rays(n, seed=44)
+    g = torch.Generator().manual_seed(11)
+    image = torch.rand(n, 3, generator=g)
+    ns_final, ns_eval, ns_extra = 16, 32, 8
+    pools = {(n, ns_eval + 1): [torch.rand(n, ns_eval + 1, generator=g) for _ in range(8)],
+             (n, ns_final + 1): [torch.rand(n, ns_final + 1, generator=g) for _ in range(2)],
+             (n, ns_extra + 1): [torch.rand(n, ns_extra + 1, generator=g) for _ in range(2)]}
+    fc = cfg.field
+    rcfg = ns.sf.SDFFieldConfig(
+        num_layers=fc.num_layers, hidden_dim=fc.hidden_dim, geo_feat_dim=fc.geo_feat_dim, num_layers_color=fc.num_layers_color,
+        hidden_dim_color=fc.hidden_dim_color, bias=fc.bias, inside_outside=fc.inside_outside, use_grid_feature=False,
+        beta_init=fc.beta_init, num_levels=fc.num_levels, max_res=fc.max_res, base_res=fc.base_res,
+        log2_hashmap_size=fc.log2_hashmap_size, hash_features_per_level=fc.hash_features_per_level, hash_smoothstep=fc.hash_smoothstep)
+    field = ns.sf.SDFField(rcfg, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_images=49,
+                           spatial_distortion=ns.sd.SceneContraction(order=float("inf")))
+    sd = field.state_dict()
+    for k in sd:
+        if k in p:
+            sd[k] = p[k].clone()
+    field.load_state_dict(sd)
+    sampler = ns.rs.ErrorBoundedSampler(num_samples=ns_final, num_samples_eval=ns_eval, num_samples_extra=ns_extra)
+    H = ns.FieldHeadNames
+    for mode in ("train", "eval"):
+        training = mode == "train"
+        for m in [field, sampler]:
+            m.train(training)
+        rb = ns.rays.RayBundle(
+            origins=origins, directions=dirs, pixel_area=torch.ones(n, 1), directions_norm=torch.ones(n, 1),
+            camera_indices=cam[:, None], nears=torch.full((n, 1), cfg.near), fars=torch.full((n, 1), cfg.far))
+        with _RandByShape(pools) as rq:
+            ray_samples, _eik = sampler(rb, density_fn=field.laplace_density, sdf_fn=field.get_sdf)
+        rand = list(rq.used) if training else None
+        fo = field(ray_samples)
+        weights, trans = ray_samples.get_weights_and_transmittance(fo[H.DENSITY])
+        rgb_r = ns.rd.RGBRenderer(background_color=torch.zeros(3))
+        rgb_r.train(training)
+        rgb = rgb_r(rgb=fo[H.RGB], weights=weights)
+        depth = ns.rd.DepthRenderer(method="expected")(weights=weights, ray_samples=ray_samples)
+        normal = ns.rd.SemanticRenderer()(semantics=fo[H.NORMAL], weights=weights)
+        acc = ns.rd.AccumulationRenderer()(weights=weights)
+        out = {
+            "starts": ray_samples.frustums.starts[..., 0], "ends": ray_samples.frustums.ends[..., 0],
+            "bins": torch.cat([ray_samples.spacing_starts[..., 0], ray_samples.spacing_ends[..., -1:, 0]], -1),
+            "sdf": fo[H.SDF][..., 0], "gradient": fo[H.GRADIENT], "field_rgb": fo[H.RGB], "density": fo[H.DENSITY][..., 0],
+            "weights": weights[..., 0], "rgb": rgb, "depth": depth[..., 0], "normal": normal, "accumulation": acc[..., 0],
+        }
+        # ---- step-by-step replay with the reference's own methods (ray_samplers.py:633-682), recording every iteration
+        steps_blob = {}
+        sb = lambda r: torch.cat([r.spacing_starts[..., 0], r.spacing_ends[..., -1:, 0]], -1)
+        with _RandQueue([t.clone() for t in rand] if training else []), torch.no_grad():
+            beta0 = field.laplace_density.get_beta().detach()
+            rs_k = sampler.uniform_sampler(rb, num_samples=ns_eval)
+            deltas = rs_k.deltas.squeeze(-1)
+            beta = torch.sqrt((1.0 / (4.0 * torch.log(torch.tensor(sampler.eps + 1.0)))) * (deltas ** 2.0).sum(-1))
+            total, not_conv, idx_k, new_k, sdf_k = 0, True, None, rs_k, None
+            while not_conv and total < sampler.max_total_iters:
+                new_sdf = field.get_sdf(new_k)
+                sdf_k = new_sdf if idx_k is None else torch.gather(torch.cat([sdf_k.squeeze(-1), new_sdf.squeeze(-1)], -1), 1,
+                                                                     idx_k).unsqueeze(-1)
+                pre = f"step{total}/"
+                steps_blob[pre + "bins_in"] = sb(rs_k)
+                steps_blob[pre + "sdf_in"] = sdf_k.reshape(rs_k.shape).clone()
+                steps_blob[pre + "beta_in"] = beta.clone()
+                d_star = sampler.get_dstar(sdf_k, rs_k)
+                beta = sampler.get_updated_beta(beta0, beta, field.laplace_density, sdf_k, d_star, rs_k)
+                density = field.laplace_density(sdf_k.reshape(rs_k.shape), beta=beta.unsqueeze(-1))
+                w, tr = rs_k.get_weights_and_transmittance(density.unsqueeze(-1))
+                steps_blob[pre + "d_star"] = d_star.clone()
+                steps_blob[pre + "beta_out"] = beta.clone()
+                steps_blob[pre + "weights"] = w[..., 0].clone()
+                total += 1
+                not_conv = bool(beta.max() > beta0)
+                if not_conv and total < sampler.max_total_iters:
+                    deltas = rs_k.deltas.squeeze(-1)
+                    eps_sec = torch.exp(-d_star / beta.unsqueeze(-1)) * (deltas ** 2.0) / (4 * beta.unsqueeze(-1) ** 2)
+                    ew = (torch.clamp(torch.exp(torch.cumsum(eps_sec, dim=-1)), max=1.0e6) - 1.0) * tr[..., 0]
+                    new_k = sampler.pdf_sampler(rb, rs_k, ew.unsqueeze(-1), num_samples=ns_eval)
+                    steps_blob[pre + "err_weights"] = ew.clone()
+                    steps_blob[pre + "new_bins"] = sb(new_k)
+                    rs_k, idx_k = sampler.merge_ray_samples(rb, rs_k, new_k)
+                    steps_blob[pre + "merged_bins"] = sb(rs_k)
+                    steps_blob[pre + "index"] = idx_k.clone()
+                else:
+                    rs_k = sampler.pdf_sampler(rb, rs_k, w, num_samples=ns_final)
+                    steps_blob[pre + "final_bins"] = sb(rs_k)
+            n_iters = total
+            uni = sampler.uniform_sampler(rb, num_samples=ns_extra)
+            steps_blob["extra_bins"] = sb(uni)
+            rs_k, _ = sampler.merge_ray_samples(rb, rs_k, uni)
+            assert torch.equal(sb(rs_k), out["bins"]), "step-by-step replay differs from ErrorBoundedSampler.generate_ray_samples"
+        print(f"[volsdf {mode}] reference sampler: {n_iters} outer iterations, beta0 {float(beta0):.3f}, final beta max "
+              f"{float(steps_blob[f'step{n_iters - 1}/beta_out'].max()):.3f}")
+        # ---- oracle: (1) whole sampler, (2) every iteration on the reference's inputs, (3) field + render on identical samples
+        po = {k: v.clone().requires_grad_(v.is_floating_point() and k != "laplace_density.beta_min") for k, v in p.items()}
+        tr_o = []
+        with torch.no_grad():
+            o_s = O.volsdf_forward(origins, dirs, cam, p, cfg, rand=[t.clone() for t in rand] if training else None,
+                                   training=training, num_samples=ns_final, num_samples_eval=ns_eval, num_samples_extra=ns_extra,
+                                   trace=tr_o)
+        d_bins = (o_s["bins"] - out["bins"]).abs()
+        print(f"[volsdf {mode}] oracle sampler: {len(tr_o)} iterations, median |d bins| {d_bins.median().item():.1e}, max {d_bins.max().item():.1e}")
+        assert len(tr_o) == n_iters and d_bins.median().item() <= 2e-6 and d_bins.max().item() <= 5e-3
+        nears_t, fars_t = torch.full((n,), cfg.near), torch.full((n,), cfg.far)
+        beta0_o = (p["laplace_density.beta"].abs() + p["laplace_density.beta_min"])
+        for it in range(n_iters):
+            pre = f"step{it}/"
+            b_in, s_in, be_in = steps_blob[pre + "bins_in"], steps_blob[pre + "sdf_in"], steps_blob[pre + "beta_in"]
+            eu = O.uniform_to_euclidean(b_in, nears_t, fars_t)
+            dl = eu[:, 1:] - eu[:, :-1]
+            ds = O.volsdf_dstar(s_in, dl)
+            assert (ds - steps_blob[pre + "d_star"]).abs().max().item() <= 1e-6, f"step {it} d_star"
+            be = O.volsdf_update_beta(beta0_o, be_in, s_in, ds, dl)
+            assert (be - steps_blob[pre + "beta_out"]).abs().max().item() <= 1e-6 * float(be.max()), f"step {it} beta"
+            w_o, t_o = O.weights_and_transmittance_from_density(O.laplace_density(s_in, be[:, None]), dl)
+            assert (w_o - steps_blob[pre + "weights"]).abs().max().item() <= 2e-6, f"step {it} weights"
+        losses, ref_grads = {}, {}
+        if training:
+            losses["rgb_loss"] = torch.nn.L1Loss()(image, rgb)
+            losses["eikonal_loss"] = ((fo[H.GRADIENT].norm(2, dim=-1) - 1) ** 2).mean() * cfg.eikonal_loss_mult
+            field.zero_grad()
+            sum(losses.values()).backward()
+            for k, v in field.named_parameters():
+                if v.grad is not None:
+                    ref_grads[k] = v.grad.clone()
+        o = O.volsdf_forward(origins, dirs, cam, po, cfg, training=training, samples=(out["bins"], out["starts"], out["ends"]))
+        if not training:
+            o["rgb"] = o["rgb"].clamp(0.0, 1.0)
+        omap = {"sdf": o["field"]["sdf"], "gradient": o["field"]["gradient"], "field_rgb": o["field"]["rgb"],
+                "density": o["field"]["density"], "weights": o["weights"], "rgb": o["rgb"], "depth": o["depth"],
+                "normal": o["normal"], "accumulation": o["accumulation"]}
+        worst = 0.0
+        for k, v in omap.items():
+            err = (v.detach() - out[k].detach()).abs().max().item()
+            scale = out[k].detach().abs().max().item() + 1e-12
+            worst = max(worst, err / scale)
+            tol = 1e-4 if k == "depth" else 2e-5
+            assert err <= tol * scale + 1e-6, f"[volsdf] oracle != reference on {k}: abs {err:.3e} (scale {scale:.3e})"
+        if training:
+            g_o = o["field"]["gradient"]
+            ol = {"rgb_loss": torch.nn.functional.l1_loss(o["rgb"], image),
+                  "eikonal_loss": ((g_o.norm(2, dim=-1) - 1) ** 2).mean() * cfg.eikonal_loss_mult}
+            for k in losses:
+                assert abs(ol[k].item() - losses[k].item()) <= 1e-5 * abs(losses[k].item()) + 1e-8, k
+            sum(ol.values()).backward()
+            for k, gref in ref_grads.items():
+                err = (po[k].grad - gref).abs().max().item()
+                scale = gref.abs().max().item() + 1e-12
+                worst = max(worst, err / scale)
+                assert err <= 1e-3 * scale + 1e-9, f"[volsdf] oracle grad != reference on {k}: {err:.3e} / {scale:.3e}"
+        print(f"[volsdf {mode}] oracle reproduces the reference; worst rel err {worst:.2e}")
+        blob = {"in/origins": origins, "in/dirs": dirs, "in/cam": cam, "in/image": image, "in/n_iters": torch.tensor(n_iters),
+                "in/num_samples": torch.tensor(ns_final), "in/num_samples_eval": torch.tensor(ns_eval),
+                "in/num_samples_extra": torch.tensor(ns_extra)}
+        for i, r in enumerate(rand or []):
+            blob[f"in/rand{i}"] = r
+        for k, v in p.items():
+            blob[f"param/{k}"] = v
+        for k, v in out.items():
+            blob[f"out/{k}"] = v.detach()
+        for k, v in losses.items():
+            blob[f"loss/{k}"] = v.detach()
+        for k, v in ref_grads.items():
+            blob[f"grad/{k}"] = v
+        blob.update(steps_blob)
+        path = os.path.join(HERE, f"volsdf_small_{mode}.npz")
+        np.savez_compressed(path, **{k: v.numpy() for k, v in blob.items()})
+        print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "neus":
-        main_neus()
-    else:
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "facto"):
         main()
+    if which in ("all", "neus"):
         main_neus()
+    if which in ("all", "volsdf"):
+        main_volsdf()

@@ -17,7 +17,7 @@ def load_golden_file(name: str):
     z = np.load(os.path.join(GOLDEN, name))
     out = {"in": {}, "param": {}, "out": {}, "loss": {}, "grad": {}}
     for k in z.files:
-        head, key = k.split("/", 1)
+        head, key = k.split("/", 1) if "/" in k else ("misc", k)
         out.setdefault(head, {})[key] = torch.from_numpy(z[k])
     return out
 

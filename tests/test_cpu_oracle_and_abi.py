@@ -102,6 +102,55 @@ def test_oracle_neus_sampler_and_model_against_reference_golden(mode):
             assert_close(f"grad {k}", p[k].grad, ref, rtol=1e-3, atol=1e-9)
 
 
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_oracle_volsdf_against_reference_golden(mode):
+    """VolSDF with the pure-MLP field (BASELINE config 1 flavour; no tiny-cuda-nn anywhere in this golden): every outer
+    iteration of ErrorBoundedSampler on the reference's own inputs, the sampler end to end, field + density rendering +
+    gradients on the reference's samples."""
+    g = load_golden_file(f"volsdf_small_{mode}.npz")
+    cfg = small_oracle_cfg()
+    cfg.field.use_grid_feature = False
+    n = g["in"]["origins"].shape[0]
+    training = mode == "train"
+    n_iters = int(g["in"]["n_iters"])
+    ns, ns_eval, ns_extra = int(g["in"]["num_samples"]), int(g["in"]["num_samples_eval"]), int(g["in"]["num_samples_extra"])
+    nears, fars = torch.full((n,), cfg.near), torch.full((n,), cfg.far)
+    beta0 = g["param"]["laplace_density.beta"].abs() + g["param"]["laplace_density.beta_min"]
+    for it in range(n_iters):
+        st = g[f"step{it}"]
+        eu = O.uniform_to_euclidean(st["bins_in"], nears, fars)
+        dl = eu[:, 1:] - eu[:, :-1]
+        ds = O.volsdf_dstar(st["sdf_in"], dl)
+        assert_close(f"it {it} d*", ds, st["d_star"], rtol=0, atol=1e-6)
+        be = O.volsdf_update_beta(beta0, st["beta_in"], st["sdf_in"], ds, dl)
+        assert_close(f"it {it} beta", be, st["beta_out"], rtol=1e-6, atol=0)
+        w, _ = O.weights_and_transmittance_from_density(O.laplace_density(st["sdf_in"], be[:, None]), dl)
+        assert_close(f"it {it} weights", w, st["weights"], rtol=0, atol=2e-6)
+        if "index" in st:
+            mb, ix = O.merge_bins(st["bins_in"], st["new_bins"])
+            assert torch.equal(mb, st["merged_bins"]) and torch.equal(ix, st["index"])
+    p = {k: v.clone().requires_grad_(v.is_floating_point() and k != "laplace_density.beta_min") for k, v in g["param"].items()}
+    rand = [g["in"][f"rand{i}"] for i in range(len([k for k in g["in"] if k.startswith("rand")]))]
+    with torch.no_grad():
+        o_s = O.volsdf_forward(g["in"]["origins"], g["in"]["dirs"], g["in"]["cam"], p, cfg, rand=rand if training else None,
+                               training=training, num_samples=ns, num_samples_eval=ns_eval, num_samples_extra=ns_extra)
+    d = (o_s["bins"] - g["out"]["bins"]).abs()
+    assert d.median().item() <= 2e-6 and d.max().item() <= 5e-3
+    o = O.volsdf_forward(g["in"]["origins"], g["in"]["dirs"], g["in"]["cam"], p, cfg, training=training,
+                         samples=(g["out"]["bins"], g["out"]["starts"], g["out"]["ends"]))
+    rgb = o["rgb"] if training else o["rgb"].clamp(0, 1)
+    for k, v in {"sdf": o["field"]["sdf"], "gradient": o["field"]["gradient"], "density": o["field"]["density"],
+                 "weights": o["weights"], "rgb": rgb, "normal": o["normal"], "accumulation": o["accumulation"]}.items():
+        assert_close(k, v, g["out"][k], rtol=2e-5, atol=1e-6)
+    if training:
+        loss = torch.nn.functional.l1_loss(o["rgb"], g["in"]["image"]) + (
+            (o["field"]["gradient"].norm(2, dim=-1) - 1) ** 2).mean() * cfg.eikonal_loss_mult
+        loss.backward()
+        assert len(g["grad"]) >= 30
+        for k, ref in g["grad"].items():
+            assert_close(f"grad {k}", p[k].grad, ref, rtol=1e-3, atol=1e-9)
+
+
 def test_oracle_known_answers_from_reference_tests():
     # reference tests/cameras/test_rays.py:11-30: frustum position = origin + dir * (start+end)/2 -> [0, 3.5, 2]... restated
     o, d = torch.tensor([[0.0, 1.0, 2.0]]), torch.tensor([[0.0, 1.0, 0.0]])
