@@ -596,9 +596,13 @@ static void run_wgrad(const SdfHipField* f, const FieldWs& w, const WgradArgs& b
         a.ob_base = ob;
         a.ib_base = ib;
         const int na = (std::min(8, a.nba - ob) + 1) / 2, nb = (std::min(8, a.nbb - ib) + 1) / 2;
-        WgradKernelFn fn = wgrad_pick(na, nb);
-        (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, kWgLdsBytes);
-        hipLaunchKernelGGL(fn, dim3((unsigned)w.n_split), dim3(256), kWgLdsBytes, s, a);
+        // weight-gradient products: split-bf16 (3 bf16 MFMAs per product, fp32 accumulate) by default; SDFHIP_WGRAD_FP32=1
+        // selects the exact-fp32 MFMA kernel (A/B and strict-fp32 runs)
+        static const bool fp32 = getenv("SDFHIP_WGRAD_FP32") != nullptr && getenv("SDFHIP_WGRAD_FP32")[0] == '1';
+        WgradKernelFn fn = wgrad_pick(na, nb, fp32);
+        const int lds_bytes = fp32 ? kWgLdsBytes : kWbLdsBytes;
+        (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        hipLaunchKernelGGL(fn, dim3((unsigned)w.n_split), dim3(256), lds_bytes, s, a);
       }
   }
   WreduceArgs r;

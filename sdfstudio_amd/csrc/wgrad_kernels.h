@@ -245,22 +245,208 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
   }
 }
 
-typedef void (*WgradKernelFn)(const WgradArgs);
-template <int NA>
-static WgradKernelFn wgrad_pick_nb(const int nb) {
-  switch (nb) {
-    case 1: return wgrad_kernel<NA, 1>;
-    case 2: return wgrad_kernel<NA, 2>;
-    case 3: return wgrad_kernel<NA, 3>;
-    default: return wgrad_kernel<NA, 4>;
+// ------------------------------------------------------------------------------------------------ wgrad, split-bf16 products
+// Same GEMM, same data flow, but every fp32 operand x is split as x = hi + lo + O(2^-17 |x|) into two bf16 values when the tile is
+// written to LDS, and a product a b is formed as a_hi b_hi + a_hi b_lo + a_lo b_hi on v_mfma_f32_32x32x16_bf16 with fp32
+// accumulation: 6 MFMAs of 32 cycles per 32 x 32 x 32 block product instead of 16 fp32 MFMAs of 64 cycles (5.3x less matrix-pipe
+// time).  The dropped a_lo b_lo term and the split residual are ~2^-16 relative per product, below the fp32 round-off of the
+// 524 288-term sums these gradients are (sqrt(N) 2^-24 ~ 4e-5); parameter-gradient parity (1e-3) is unaffected.  With the
+// matrix pipe out of the way the kernel is bound by streaming the operand tiles from HBM.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int kWbRow = 40;                  // bf16 per LDS row: 32 points + 8 pad (80 B: spreads a 16-lane b128 group over all banks)
+constexpr int kWbTile = 32 * kWbRow;        // one hi or lo tile
+constexpr int kWbSlot = 2 * kWbTile;        // [hi | lo]
+constexpr int kWbLdsBytes = 16 * kWbSlot * 2;
+
+template <int NA, int NB>
+__global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 ldsb[];  // [16 slots][hi|lo][32][40]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qi = wave >> 1, qj = wave & 1;
+  const int split = blockIdx.x;
+  const int ob_base = a.ob_base, ib_base = a.ib_base;
+
+  f32x16 acc[NA][NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  // column sums of pair 0's A blocks this wave stages (slots wave, wave + 4): per lane 4 TP rows per slot
+  float colsum[2][4];
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) colsum[q][i] = 0.0f;
+
+  const int64_t t0 = (int64_t)split * a.tiles_per_split;
+  int64_t t1 = t0 + a.tiles_per_split;
+  if (t1 > a.n_tiles) t1 = a.n_tiles;
+  const int n_t = t1 > t0 ? (int)(t1 - t0) : 0;
+  const int n_stage = n_t * a.n_pairs;
+
+  for (int i = tid; i < kWbLdsBytes / 16; i += 256) reinterpret_cast<f32x4*>(ldsb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int slot[4] = {wave, wave + 4, 8 + wave, 12 + wave};
+  bool valid[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) valid[q] = slot[q] < 8 ? (ob_base + slot[q] < a.nba) : (ib_base + slot[q] - 8 < a.nbb);
+  const float* src0[4];
+  const float* src1[4];
+  int stride0[4], stride1[4];
+  bool xf0[4], xf1[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int blk = slot[q] < 8 ? ob_base + slot[q] : ib_base + slot[q] - 8;
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const TpOperand& op = slot[q] < 8 ? a.A[pr] : a.B[pr];
+      const int seg = blk >= op.nb[0];
+      const int lb = blk - (seg ? op.nb[0] : 0);
+      const float* base = op.ptr[seg] + (size_t)lb * 1024;
+      const int stride = op.nb[seg] * 1024;
+      const bool xf = op.xf[seg] == 1;
+      if (pr == 0) {
+        src0[q] = base;
+        stride0[q] = stride;
+        xf0[q] = xf;
+      } else {
+        src1[q] = base;
+        stride1[q] = stride;
+        xf1[q] = xf;
+      }
+    }
+  }
+
+  f32x4 pre[4][4];
+  auto load_stage = [&](const int st) {
+    const bool p1 = st >= n_t;
+    const int64_t tile = t0 + (p1 ? st - n_t : st);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!valid[q]) continue;
+      const float* base = p1 ? src1[q] : src0[q];
+      const int stride = p1 ? stride1[q] : stride0[q];
+      const f32x4* src = reinterpret_cast<const f32x4*>(base + (size_t)tile * stride) + lane;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pre[q][i] = src[i * 64];
+    }
+  };
+  auto store_stage = [&](const int st) {
+    const bool p1 = st >= n_t;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (!valid[q]) continue;
+      const bool xf = p1 ? xf1[q] : xf0[q];
+      // lane holds, for i = 0..3, TP row r = 4 i + (lane >> 4), half (lane >> 3) & 1, points 4 (lane & 7) .. + 3
+      __bf16* dst = ldsb + slot[q] * kWbSlot + (lane & 7) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        f32x4 v = pre[q][i];
+        if (xf) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = softplus100_h(v[e]);
+        }
+        if (q < 2 && !p1) colsum[q][i] += (v[0] + v[1]) + (v[2] + v[3]);
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          hi[e] = (__bf16)v[e];
+          lo[e] = (__bf16)(v[e] - (float)hi[e]);
+        }
+        const int f = tp_row(i * 4 + (lane >> 4), (lane >> 3) & 1);
+        *reinterpret_cast<bf16x4*>(dst + f * kWbRow) = hi;
+        *reinterpret_cast<bf16x4*>(dst + kWbTile + f * kWbRow) = lo;
+      }
+    }
+  };
+
+  if (n_stage > 0) load_stage(0);
+  // lane (row = lane & 31, k half = lane >> 5) reads 8 consecutive points of "its" feature row
+  const __bf16* la = ldsb + qi * kWbSlot + (lane & 31) * kWbRow + 8 * (lane >> 5);
+  const __bf16* lb = ldsb + (8 + qj) * kWbSlot + (lane & 31) * kWbRow + 8 * (lane >> 5);
+  for (int st = 0; st < n_stage; ++st) {
+    __syncthreads();
+    store_stage(st);
+    __syncthreads();
+    if (st + 1 < n_stage) load_stage(st + 1);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 ah[NA], al[NA], bh[NB], bl[NB];
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        ah[i] = *reinterpret_cast<const bf16x8*>(la + 2 * i * kWbSlot + kk * 16);
+        al[i] = *reinterpret_cast<const bf16x8*>(la + 2 * i * kWbSlot + kWbTile + kk * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        bh[j] = *reinterpret_cast<const bf16x8*>(lb + 2 * j * kWbSlot + kk * 16);
+        bl[j] = *reinterpret_cast<const bf16x8*>(lb + 2 * j * kWbSlot + kWbTile + kk * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  const int ldc = a.nbb * 32;
+  float* C = a.partial + (size_t)split * a.nba * 32 * ldc;
+  const int hf = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int ob = ob_base + qi + 2 * i, ib = ib_base + qj + 2 * j;
+      if (qi + 2 * i < 8 && qj + 2 * j < 8 && ob < a.nba && ib < a.nbb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) C[(size_t)(ob * 32 + tp_row(r, hf)) * ldc + ib * 32 + (lane & 31)] = acc[i][j][r];
+      }
+    }
+  if (a.bpartial != nullptr && ib_base == 0) {
+    // each staged A row was summed over this lane's 4 points: finish over the 8 lanes that share the row
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float t = colsum[q][i];
+        t += __shfl_xor(t, 1);
+        t += __shfl_xor(t, 2);
+        t += __shfl_xor(t, 4);
+        const int ob = ob_base + slot[q];
+        if (valid[q] && (lane & 7) == 0 && ob < a.nba)
+          a.bpartial[(size_t)split * a.nba * 32 + ob * 32 + tp_row(i * 4 + (lane >> 4), (lane >> 3) & 1)] = t;
+      }
   }
 }
-static WgradKernelFn wgrad_pick(const int na, const int nb) {
+
+typedef void (*WgradKernelFn)(const WgradArgs);
+template <int NA>
+static WgradKernelFn wgrad_pick_nb(const int nb, const bool fp32) {
+  switch (nb) {
+    case 1: return fp32 ? wgrad_kernel<NA, 1> : wgrad_bf16_kernel<NA, 1>;
+    case 2: return fp32 ? wgrad_kernel<NA, 2> : wgrad_bf16_kernel<NA, 2>;
+    case 3: return fp32 ? wgrad_kernel<NA, 3> : wgrad_bf16_kernel<NA, 3>;
+    default: return fp32 ? wgrad_kernel<NA, 4> : wgrad_bf16_kernel<NA, 4>;
+  }
+}
+static WgradKernelFn wgrad_pick(const int na, const int nb, const bool fp32) {
   switch (na) {
-    case 1: return wgrad_pick_nb<1>(nb);
-    case 2: return wgrad_pick_nb<2>(nb);
-    case 3: return wgrad_pick_nb<3>(nb);
-    default: return wgrad_pick_nb<4>(nb);
+    case 1: return wgrad_pick_nb<1>(nb, fp32);
+    case 2: return wgrad_pick_nb<2>(nb, fp32);
+    case 3: return wgrad_pick_nb<3>(nb, fp32);
+    default: return wgrad_pick_nb<4>(nb, fp32);
   }
 }
 

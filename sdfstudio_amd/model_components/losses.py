@@ -41,3 +41,55 @@ def interlevel_loss_zip(weights_list: List[torch.Tensor], bins_list: List[torch.
         w_target = cum[:, 1:] - cum[:, :-1]
         total = total + torch.mean(torch.clip(w_target - wp, min=0) ** 2 / (wp + 1e-5))
     return total
+
+
+def monosdf_normal_loss(normal_pred: torch.Tensor, normal_gt: torch.Tensor) -> torch.Tensor:
+    """losses.py:264-275: L1 + cosine between the rendered normal and the monocular normal prior."""
+    n_gt = torch.nn.functional.normalize(normal_gt, p=2, dim=-1)
+    n_pr = torch.nn.functional.normalize(normal_pred, p=2, dim=-1)
+    return torch.abs(n_pr - n_gt).sum(dim=-1).mean() + (1.0 - torch.sum(n_pr * n_gt, dim=-1)).mean()
+
+
+def scale_and_shift_invariant_loss(prediction: torch.Tensor, target: torch.Tensor, mask: torch.Tensor, alpha: float = 0.5,
+                                   scales: int = 1) -> torch.Tensor:
+    """losses.py:278-409 ScaleAndShiftInvariantLoss (MiDaS), batch-based reduction, as used for the MonoSDF depth prior
+    (base_surface_model.py:227,427-437).  prediction / target / mask: [B,H,W].
+
+    Per image: least-squares scale s and shift t of the prediction against the target (closed form 2x2 system, zero when the
+    system is singular), then MSE(s p + t, target) / 2 + alpha * sum over `scales` of the masked gradient-matching term."""
+    m = mask.to(prediction.dtype)
+    a00 = (m * prediction * prediction).sum((1, 2))
+    a01 = (m * prediction).sum((1, 2))
+    a11 = m.sum((1, 2))
+    b0 = (m * prediction * target).sum((1, 2))
+    b1 = (m * target).sum((1, 2))
+    det = a00 * a11 - a01 * a01
+    ok = det != 0
+    safe = torch.where(ok, det, torch.ones_like(det))
+    scale = torch.where(ok, (a11 * b0 - a01 * b1) / safe, torch.zeros_like(det))
+    shift = torch.where(ok, (-a01 * b0 + a00 * b1) / safe, torch.zeros_like(det))
+    ssi = scale.view(-1, 1, 1) * prediction + shift.view(-1, 1, 1)
+
+    def batch_mean(image_loss, count):
+        total = count.sum()
+        return image_loss.sum() / total if total != 0 else image_loss.sum() * 0.0
+
+    res = ssi - target
+    total = batch_mean((m * res * res).sum((1, 2)), 2 * a11)
+    if alpha > 0:
+        reg = 0.0
+        for k in range(scales):
+            st = 2 ** k
+            p_, t_, m_ = ssi[:, ::st, ::st], target[:, ::st, ::st], m[:, ::st, ::st]
+            diff = m_ * (p_ - t_)
+            gx = (m_[:, :, 1:] * m_[:, :, :-1]) * torch.abs(diff[:, :, 1:] - diff[:, :, :-1])
+            gy = (m_[:, 1:, :] * m_[:, :-1, :]) * torch.abs(diff[:, 1:, :] - diff[:, :-1, :])
+            reg = reg + batch_mean(gx.sum((1, 2)) + gy.sum((1, 2)), m_.sum((1, 2)))
+        total = total + alpha * reg
+    return total
+
+
+def monosdf_depth_loss(depth_pred: torch.Tensor, depth_gt: torch.Tensor) -> torch.Tensor:
+    """base_surface_model.py:427-437: the ray batch is viewed as a 32 x (N/32) patch, the prior is rescaled (x 50 + 0.5)."""
+    mask = torch.ones_like(depth_gt).reshape(1, 32, -1).bool()
+    return scale_and_shift_invariant_loss(depth_pred.reshape(1, 32, -1), (depth_gt * 50 + 0.5).reshape(1, 32, -1), mask, 0.5, 1)

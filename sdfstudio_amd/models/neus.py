@@ -10,6 +10,7 @@ from torch import nn
 
 from sdfstudio_amd.cameras.rays import RayBundle
 from sdfstudio_amd.fields.field_heads import FieldHeadNames
+from sdfstudio_amd.model_components.losses import monosdf_depth_loss, monosdf_normal_loss
 from sdfstudio_amd.model_components.ray_samplers import NeuSSampler
 from sdfstudio_amd.model_components.renderers import neus_render
 from sdfstudio_amd.models.neus_facto import NeuSFactoModel, NeuSFactoModelConfig, SceneContraction
@@ -87,6 +88,10 @@ class NeuSModel(NeuSFactoModel):
                 fg = batch["fg_mask"].float().to(image.device)
                 wsum = outputs["weights"].sum(dim=1).clip(1e-3, 1.0 - 1e-3)
                 loss["fg_mask_loss"] = F.binary_cross_entropy(wsum, fg) * c.fg_mask_loss_mult
+            if "normal" in batch and c.mono_normal_loss_mult > 0.0:  # base_surface_model.py:419-424 (mono-neus / monosdf presets)
+                loss["normal_loss"] = monosdf_normal_loss(outputs["normal"], batch["normal"].to(image.device)) * c.mono_normal_loss_mult
+            if "depth" in batch and c.mono_depth_loss_mult > 0.0:  # base_surface_model.py:427-437
+                loss["depth_loss"] = monosdf_depth_loss(outputs["depth"], batch["depth"].to(image.device)[..., None]) * c.mono_depth_loss_mult
         return loss
 
     def get_metrics_dict(self, outputs, batch) -> Dict[str, torch.Tensor]:

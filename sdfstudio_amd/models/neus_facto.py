@@ -18,7 +18,7 @@ from sdfstudio_amd.cameras.rays import RayBundle
 from sdfstudio_amd.fields.density_fields import HashMLPDensityField
 from sdfstudio_amd.fields.field_heads import FieldHeadNames
 from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
-from sdfstudio_amd.model_components.losses import interlevel_loss_zip
+from sdfstudio_amd.model_components.losses import interlevel_loss_zip, monosdf_depth_loss, monosdf_normal_loss
 from sdfstudio_amd.model_components.ray_samplers import ProposalNetworkSampler
 from sdfstudio_amd.model_components.renderers import neus_render
 
@@ -211,12 +211,10 @@ class NeuSFactoModel(nn.Module):
                 fg = batch["fg_mask"].float().to(image.device)
                 wsum = outputs["weights"].sum(dim=1).clip(1e-3, 1.0 - 1e-3)
                 loss["fg_mask_loss"] = F.binary_cross_entropy(wsum, fg) * c.fg_mask_loss_mult
-            if "normal" in batch and c.mono_normal_loss_mult > 0.0:
-                n_gt = F.normalize(batch["normal"].to(image.device), p=2, dim=-1)  # losses.py:264-275
-                n_pr = F.normalize(outputs["normal"], p=2, dim=-1)
-                l1 = torch.abs(n_pr - n_gt).sum(dim=-1).mean()
-                cos = (1.0 - torch.sum(n_pr * n_gt, dim=-1)).mean()
-                loss["normal_loss"] = (l1 + cos) * c.mono_normal_loss_mult
+            if "normal" in batch and c.mono_normal_loss_mult > 0.0:  # base_surface_model.py:419-424
+                loss["normal_loss"] = monosdf_normal_loss(outputs["normal"], batch["normal"].to(image.device)) * c.mono_normal_loss_mult
+            if "depth" in batch and c.mono_depth_loss_mult > 0.0:  # base_surface_model.py:427-437
+                loss["depth_loss"] = monosdf_depth_loss(outputs["depth"], batch["depth"].to(image.device)[..., None]) * c.mono_depth_loss_mult
             weights = [w[..., 0] for w in outputs["weights_list"]]
             bins = [rs.flat_bins for rs in outputs["ray_samples_list"]]
             loss["interlevel_loss"] = c.interlevel_loss_mult * interlevel_loss_zip(weights, bins)

@@ -273,3 +273,28 @@ def test_interlevel_loss_host_matches_oracle():
     a = interlevel_loss_zip(ws, bins)
     b = O.interlevel_loss_zip(ws, bins)
     assert abs(a.item() - b.item()) <= 1e-6 * abs(b.item())
+
+
+def test_mono_prior_losses_against_reference():
+    """MonoSDF depth / normal prior losses (config 4): the host restatement against the reference's own functions when
+    /root/reference is present (build container), and against known answers minted from them (GPU box)."""
+    from sdfstudio_amd.model_components.losses import monosdf_depth_loss, monosdf_normal_loss
+
+    g = torch.Generator().manual_seed(3)
+    n = 256
+    depth_pred = torch.rand(n, 1, generator=g) * 3 + 0.5
+    depth_gt = torch.rand(n, 1, generator=g)
+    n_pred = torch.randn(n, 3, generator=g)
+    n_gt = torch.randn(n, 3, generator=g)
+    ld, ln = monosdf_depth_loss(depth_pred, depth_gt), monosdf_normal_loss(n_pred, n_gt)
+    assert abs(ld.item() - 109.58025360107422) <= 2e-3 and abs(ln.item() - 3.061246156692505) <= 1e-5, (ld.item(), ln.item())
+    if os.path.isdir("/root/reference/nerfstudio"):
+        from oracle import ref_harness
+
+        ref_harness.import_reference()
+        from nerfstudio.model_components import losses as RL
+
+        ref_d = RL.ScaleAndShiftInvariantLoss(alpha=0.5, scales=1)(
+            depth_pred.reshape(1, 32, -1), (depth_gt * 50 + 0.5).reshape(1, 32, -1), torch.ones(1, 32, n // 32).bool())
+        assert abs(ld.item() - ref_d.item()) <= 1e-5 * abs(ref_d.item())
+        assert abs(ln.item() - RL.monosdf_normal_loss(n_pred, n_gt).item()) <= 1e-6
