@@ -182,6 +182,28 @@ def sdf_and_gradient(x: torch.Tensor, p: Params, cfg: FieldCfg, mask=None, creat
     return sdf[:, 0], h[:, 1:], grad
 
 
+# Test instrumentation for the one non-smooth spot of the field: d relu(z) / dz jumps at z = 0, so two correct fp32
+# implementations whose pre-activations differ by round-off can legitimately disagree on the gradient contribution of a
+# (point, unit) pair with |z| ~ 1e-7.  relu_hook(record={}) captures the colour network's pre-activations; relu_hook(flip=
+# {layer: bool mask}) evaluates the other branch at the flagged pairs (tests/helpers.py: assert_grads_close_mod_relu_flips).
+RELU_HOOK = None
+
+
+class relu_hook:
+    def __init__(self, record=None, flip=None):
+        self.cfg = {"record": record, "flip": flip}
+
+    def __enter__(self):
+        global RELU_HOOK
+        self.prev, RELU_HOOK = RELU_HOOK, self.cfg
+        return self
+
+    def __exit__(self, *exc):
+        global RELU_HOOK
+        RELU_HOOK = self.prev
+        return False
+
+
 def color_network(x, dirs, grad, feat, emb, p: Params, cfg: FieldCfg) -> torch.Tensor:
     """fields/sdf_field.py:532-612 get_colors with the ref-nerf options off. Note the RAW gradient enters (572-578)."""
     d = nerf_encoding(dirs, 4, include_input=True)
@@ -190,7 +212,14 @@ def color_network(x, dirs, grad, feat, emb, p: Params, cfg: FieldCfg) -> torch.T
     for l in range(n_lin):
         h = linear_wn(p, f"clin{l}", h)
         if l < n_lin - 1:
-            h = torch.relu(h)
+            z = h
+            h = torch.relu(z)
+            if RELU_HOOK is not None:  # test instrumentation, see relu_hook()
+                if RELU_HOOK.get("record") is not None:
+                    RELU_HOOK["record"][l] = z.detach()
+                flip = (RELU_HOOK.get("flip") or {}).get(l)
+                if flip is not None:  # the OTHER branch of the ReLU at the flagged (point, unit) pairs
+                    h = torch.where(flip, z - h, h)
     rgb = torch.sigmoid(h)
     return rgb * (1 + 2 * cfg.rgb_padding) - cfg.rgb_padding
 

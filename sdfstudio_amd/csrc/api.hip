@@ -254,7 +254,7 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
     d.scale = scale;
     f->pack.push_back(d);
     const int64_t at = poff;
-    poff += (int64_t)kb * nbo * 1024;
+    poff += (int64_t)kb * nbo * kChunkBlockFloats;
     f->max_pack_elems = std::max(f->max_pack_elems, kb * nbo * 1024);
     return at;
   };
@@ -336,7 +336,7 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
     const int m3 = add_map(maps, ident(3, 3));
     f->c_bout = add_vec(li.b_off, 3, m3, 1);
   }
-  f->packed_size = poff;
+  f->packed_size = poff + 1024;  // the chunk DMA moves whole 4 KiB rounds: slack behind the last chunk
   // largest split-K partial
   auto upd = [&](int rows_blocks, int col_blocks) {
     f->max_partial_elems = std::max<int64_t>(f->max_partial_elems, (int64_t)rows_blocks * 32 * col_blocks * 32);

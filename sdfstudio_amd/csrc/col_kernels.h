@@ -12,15 +12,16 @@ struct ColDims {
   static constexpr int NBF = NBF_, NBS = NBS_, NBC = NBC_, NLC = NLC_;
   static constexpr int kb(int l) { return l == 0 ? NBF + NBS : NBC; }
   static constexpr int MAXB = (NBF + NBS) > NBC ? (NBF + NBS) : NBC;
-  static constexpr int BUF_FLOATS = MAXB * 1024;
+  static constexpr int buf_floats(int ns) { return chunk_pieces(MAXB, ns) * 256; }
   static constexpr int CW = NBC * 32;
   static constexpr int CVEC_FLOATS = (NLC + 3) * CW;  // biases of the NLC hidden layers, then the 3 output rows
-  static constexpr int LDS_FLOATS = 2 * BUF_FLOATS + CVEC_FLOATS;
+  static constexpr int lds_floats(int ns) { return 2 * buf_floats(ns) + CVEC_FLOATS; }
 };
+constexpr int kNsCol = kNsFwd;  // forward: 6-term products (a 3-term forward flips ReLU branches at |z| ~ 1e-5)
 
 struct ColPtrs {
-  const float* wp[kMaxLayers];    // packed W_l   [kb][NBC][4][64][4]
-  const float* wpT[kMaxLayers];   // packed W_l^T [NBC][kb][4][64][4]
+  const float* wp[kMaxLayers];    // packed W_l   [kb][3][NBC][2][64] x 8 bf16
+  const float* wpT[kMaxLayers];   // packed W_l^T [NBC][3][kb][2][64] x 8 bf16
   const float* bias[kMaxLayers];  // padded natural order
   const float* w_out;             // [3][NBC*32]
   const float* b_out;             // [3]
@@ -42,10 +43,11 @@ __global__ __launch_bounds__(256, 1) void col_fwd_kernel(const ColFwdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
   constexpr int MAXB = D::MAXB, W = D::CW;
-  float* cvec = lds + 2 * D::BUF_FLOATS;
+  constexpr int NS = kNsCol;
+  float* cvec = lds + 2 * D::buf_floats(NS);
 
-  WStream ws{lds, D::BUF_FLOATS, 0, wave, lane};
-  ws.issue(a.p.wp[0], D::NBC, true);
+  WStream ws{lds, D::buf_floats(NS), 0, wave, lane};
+  ws.issue(a.p.wp[0], chunk_pieces(D::NBC, NS), true);
   static_for<0, D::NLC>([&](auto lc) __attribute__((always_inline)) {
     constexpr int l = decltype(lc)::value;
     if (tid < W) cvec[l * W + tid] = a.p.bias[l][tid];
@@ -84,8 +86,8 @@ __global__ __launch_bounds__(256, 1) void col_fwd_kernel(const ColFwdArgs a) {
         return h;
       }
     };
-    tp_gemm<KB, D::NBC, Stores<((l > 0 && SAVE) ? 16 : 0)>>(out, carry, fetch, make, NoFetch{}, ws, a.p.wp[l], l + 1 < D::NLC ? a.p.wp[l + 1 < D::NLC ? l + 1 : l] : nullptr,
-                        D::NBC);
+    tp_gemm<KB, D::NBC, Stores<((l > 0 && SAVE) ? 16 : 0)>, NS>(out, carry, fetch, make, NoFetch{}, ws, a.p.wp[l],
+                                                                l + 1 < D::NLC ? a.p.wp[l + 1 < D::NLC ? l + 1 : l] : nullptr, chunk_pieces(D::NBC, NS));
   });
 
   // last hidden activation + the 3-row output layer
@@ -136,10 +138,11 @@ __global__ __launch_bounds__(256, 1) void col_bwd_kernel(const ColBwdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
   constexpr int MAXB = D::MAXB, W = D::CW;
-  float* cvec = lds + 2 * D::BUF_FLOATS;
+  constexpr int NS = kNsGrad;
+  float* cvec = lds + 2 * D::buf_floats(NS);
 
-  WStream ws{lds, D::BUF_FLOATS, 0, wave, lane};
-  ws.issue(a.p.wpT[D::NLC - 1], D::kb(D::NLC - 1), true);
+  WStream ws{lds, D::buf_floats(NS), 0, wave, lane};
+  ws.issue(a.p.wpT[D::NLC - 1], chunk_pieces(D::kb(D::NLC - 1), NS), true);
   for (int i = tid; i < 3 * W; i += 256) cvec[i] = a.p.w_out[i];
   __syncthreads();
 
@@ -196,8 +199,8 @@ __global__ __launch_bounds__(256, 1) void col_bwd_kernel(const ColBwdArgs a) {
       if constexpr (l > 0) return h_fetch(IC<(l > 0 ? l - 1 : 0)>{}, IC<0>{});
       else return Raw{};
     };
-    tp_gemm<D::NBC, KB, Stores<16>>(un, carry, fetch, make, next_fetch, ws, a.p.wpT[l], l > 0 ? a.p.wpT[l > 0 ? l - 1 : 0] : nullptr,
-                        l > 0 ? D::kb(l > 0 ? l - 1 : 0) : 0);
+    tp_gemm<D::NBC, KB, Stores<16>, NS>(un, carry, fetch, make, next_fetch, ws, a.p.wpT[l], l > 0 ? a.p.wpT[l > 0 ? l - 1 : 0] : nullptr,
+                                        l > 0 ? chunk_pieces(D::kb(l > 0 ? l - 1 : 0), NS) : 0);
     if constexpr (l == 0) {
 #pragma unroll
       for (int b = 0; b < D::NBF; ++b) tp_store_blk(un[b], a.featbar_tp, tile, D::NBF, b, lane);

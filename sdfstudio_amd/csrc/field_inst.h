@@ -28,19 +28,19 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
   using GD = GeoDims<NBH, NB0, NB3, NL, SKIP, NBF>;                                                                  \
   using CD = ColDims<NBF, NBS, NBC, NLC>;                                                                            \
   static void geo_fwd(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s) {                                 \
-    const size_t lds = GD::LDS_FLOATS * sizeof(float);                                                               \
-    if (mode == 0) launch_lds(geo_fwd_kernel<GD, true, true, true>, a, grid, 256, lds, s);                                   \
-    else if (mode == 1) launch_lds(geo_fwd_kernel<GD, false, false, true>, a, grid, 256, lds, s);                            \
-    else launch_lds(geo_fwd_kernel<GD, false, false, false>, a, grid, 256, lds, s);                                     \
+    const size_t lds = GD::lds_floats(kNsFwd) * sizeof(float);                                                        \
+    if (mode == 0) launch_lds(geo_fwd_kernel<GD, true, true, true>, a, grid, 256, lds, s);                            \
+    else if (mode == 1) launch_lds(geo_fwd_kernel<GD, false, false, true>, a, grid, 256, lds, s);                     \
+    else launch_lds(geo_fwd_kernel<GD, false, false, false>, a, grid, 256, lds, s);                                   \
   }                                                                                                                  \
   static void geo_bwd(const GeoBwdArgs& a, unsigned grid, hipStream_t s) {                                           \
-    launch_lds(geo_bwd_kernel<GD>, a, grid, 256, GD::LDS_FLOATS * sizeof(float), s);                                         \
+    launch_lds(geo_bwd_kernel<GD>, a, grid, 256, GD::lds_floats(kNsGrad) * sizeof(float), s);                         \
   }                                                                                                                  \
   static void col_fwd(const ColFwdArgs& a, unsigned grid, hipStream_t s) {                                           \
-    launch_lds(col_fwd_kernel<CD, true>, a, grid, 256, CD::LDS_FLOATS * sizeof(float), s);                                   \
+    launch_lds(col_fwd_kernel<CD, true>, a, grid, 256, CD::lds_floats(kNsCol) * sizeof(float), s);                    \
   }                                                                                                                  \
   static void col_bwd(const ColBwdArgs& a, unsigned grid, hipStream_t s) {                                           \
-    launch_lds(col_bwd_kernel<CD>, a, grid, 256, CD::LDS_FLOATS * sizeof(float), s);                                         \
+    launch_lds(col_bwd_kernel<CD>, a, grid, 256, CD::lds_floats(kNsGrad) * sizeof(float), s);                         \
   }                                                                                                                  \
   static void sdfrow(const float* z, const float* q, const float* sb, int64_t nt, int tps, float* part,             \
                      unsigned grid, hipStream_t s) {                                                                 \
@@ -49,7 +49,7 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
   }                                                                                                                  \
   const FieldKernels* sdfhip_kernels_##NAME() {                                                                      \
     static const FieldKernels k = {NBH, NB0, NB3, NL, SKIP, NBF, NBS, NBC, NLC,                                      \
-                                   NAME##_ns::GD::LDS_FLOATS * sizeof(float), NAME##_ns::CD::LDS_FLOATS * sizeof(float), \
+                                   NAME##_ns::GD::lds_floats(kNsMax) * sizeof(float), NAME##_ns::CD::lds_floats(kNsMax) * sizeof(float), \
                                    NAME##_ns::geo_fwd, NAME##_ns::geo_bwd, NAME##_ns::col_fwd, NAME##_ns::col_bwd,   \
                                    NAME##_ns::sdfrow};                                                               \
     return &k;                                                                                                       \

@@ -18,6 +18,17 @@
 #include "mlp_core.h"
 
 constexpr int kMaxLayers = 10;
+// bf16 parts per operand (mlp_core.h).  Everything the forward call returns (sdf, geo feature, d sdf / dx, rgb) is computed
+// with 6-term products (fp32-class: these carry the parity targets, and the raw d sdf / dx feeds the colour network's
+// ReLUs); the backward kernels (tangent pass, data backward, colour backward) use 3-term products.
+#ifndef SDFHIP_NS_FWD
+#define SDFHIP_NS_FWD 3
+#endif
+#ifndef SDFHIP_NS_GRAD
+#define SDFHIP_NS_GRAD 2
+#endif
+constexpr int kNsFwd = SDFHIP_NS_FWD, kNsGrad = SDFHIP_NS_GRAD;
+constexpr int kNsMax = kNsFwd > kNsGrad ? kNsFwd : kNsGrad;
 
 template <int NBH_, int NB0_, int NB3_, int NL_, int SKIP_, int NBF_>
 struct GeoDims {
@@ -28,15 +39,15 @@ struct GeoDims {
   static constexpr int nbo(int l) { return l == NL ? NBF : ((l + 1 == SKIP) ? NB3 : NBH); }
   static constexpr int cmax(int a, int b) { return a > b ? a : b; }
   static constexpr int MAXB = cmax(cmax(NBH, NBF), cmax(NB0, SKIP >= 0 ? NB3 + NB0 : 0));
-  static constexpr int BUF_FLOATS = MAXB * 1024;                        // one weight chunk buffer
+  static constexpr int buf_floats(int ns) { return chunk_pieces(MAXB, ns) * 256; }  // one weight chunk buffer
   static constexpr int CW = cmax(NBH, NBF) * 32;                         // stride of the constant-vector area
   static constexpr int CVEC_FLOATS = (NL + 2) * CW;                      // biases of layers 0..NL, then w_sdf
-  static constexpr int LDS_FLOATS = 2 * BUF_FLOATS + CVEC_FLOATS;
+  static constexpr int lds_floats(int ns) { return 2 * buf_floats(ns) + CVEC_FLOATS; }
 };
 
 struct GeoPtrs {
-  const float* wp[kMaxLayers];    // packed W_l      [kb][nbo][4][64][4]
-  const float* wpT[kMaxLayers];   // packed W_l^T    [nbo][kb][4][64][4]
+  const float* wp[kMaxLayers];    // packed W_l      [kb][3][nbo][2][64] x 8 bf16
+  const float* wpT[kMaxLayers];   // packed W_l^T    [nbo][3][kb][2][64] x 8 bf16
   const float* bias[kMaxLayers];  // natural order, padded to nbo*32
   const float* w_sdf;             // [NBH*32]  row of the output layer that produces sdf
   const float* b_sdf;             // [1]
@@ -69,10 +80,11 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
   constexpr int MAXB = D::MAXB, W = D::CW;
-  float* cvec = lds + 2 * D::BUF_FLOATS;
+  constexpr int NSF = kNsFwd, NSC = kNsFwd, NSB = kNsFwd;
+  float* cvec = lds + 2 * D::buf_floats(NSB);
 
-  WStream ws{lds, D::BUF_FLOATS, 0, wave, lane};
-  ws.issue(a.p.wp[0], D::nbo(0), true);
+  WStream ws{lds, D::buf_floats(NSB), 0, wave, lane};
+  ws.issue(a.p.wp[0], chunk_pieces(D::nbo(0), NSF), true);
   geo_stage_cvec<D>(cvec, a.p, tid);
   __syncthreads();
 
@@ -117,14 +129,14 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
     };
     constexpr bool last = l + 1 == D::NL;
     const float* next = last ? (FEAT ? a.p.wp[D::NL] : (GRAD ? a.p.wpT[D::NL - 1] : nullptr)) : a.p.wp[l + 1];
-    constexpr int next_nbo = last ? (FEAT ? D::NBF : D::kb(D::NL - 1)) : D::nbo(l + 1);
+    constexpr int next_pieces = last ? (FEAT ? chunk_pieces(D::NBF, NSF) : chunk_pieces(D::kb(D::NL - 1), NSC)) : chunk_pieces(D::nbo(l + 1), NSF);
     auto next_fetch = [&]() __attribute__((always_inline)) {
       if constexpr (!last) return fwd_fetch(IC<(last ? l : l + 1)>{}, IC<0>{});
       else return Raw{};
     };
     constexpr int ZS = (SAVE || GRAD) ? 16 : 0;  // z stores per produced block
     using ST = Stores<(l == 0 ? 0 : ZS), (l == 0 ? 0 : (l == D::SKIP ? 0 : ZS)), (l == D::SKIP ? D::NB3 : (1 << 30))>;
-    tp_gemm<KB, NBO, ST>(out, carry, fetch, make, next_fetch, ws, a.p.wp[l], next, next_nbo);
+    tp_gemm<KB, NBO, ST, NSF>(out, carry, fetch, make, next_fetch, ws, a.p.wp[l], next, next_pieces);
   });
 
   // ---- output layer: the sdf row as a lane-local dot product riding in the producer, feature rows on the MFMA path
@@ -147,8 +159,8 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
         if constexpr (GRAD) return chain_fetch(IC<D::NL - 1>{}, IC<0>{});
         else return Raw{};
       };
-      tp_gemm<D::NBH, D::NBF, Stores<((SAVE || GRAD) ? 16 : 0)>>(out, carry, NoFetch{}, make, next_fetch, ws, a.p.wp[D::NL], GRAD ? a.p.wpT[D::NL - 1] : nullptr,
-                              D::kb(D::NL - 1));
+      tp_gemm<D::NBH, D::NBF, Stores<((SAVE || GRAD) ? 16 : 0)>, NSF>(out, carry, NoFetch{}, make, next_fetch, ws, a.p.wp[D::NL],
+                                                                       GRAD ? a.p.wpT[D::NL - 1] : nullptr, chunk_pieces(D::kb(D::NL - 1), NSC));
 #pragma unroll
       for (int b = 0; b < D::NBF; ++b) tp_store_blk(out[b], a.feat_tp, tile, D::NBF, b, lane);
     } else {
@@ -184,8 +196,8 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
         if constexpr (l > 0) return chain_fetch(IC<(l > 0 ? l - 1 : 0)>{}, IC<0>{});
         else return Raw{};
       };
-      tp_gemm<NBO, KB, Stores<(SAVE ? 16 : 0)>>(qn, carry, fetch, make, next_fetch, ws, a.p.wpT[l], l > 0 ? a.p.wpT[l > 0 ? l - 1 : 0] : nullptr,
-                       l > 0 ? D::kb(l > 0 ? l - 1 : 0) : 0);
+      tp_gemm<NBO, KB, Stores<(SAVE ? 16 : 0)>, NSC>(qn, carry, fetch, make, next_fetch, ws, a.p.wpT[l], l > 0 ? a.p.wpT[l > 0 ? l - 1 : 0] : nullptr,
+                                                     l > 0 ? chunk_pieces(D::kb(l > 0 ? l - 1 : 0), NSC) : 0);
       if constexpr (l == D::SKIP) {
         // the part of d sdf / d (layer input) that goes straight to in0: park it in e_tp, layer 0 adds to it
 #pragma unroll
@@ -221,10 +233,11 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
   constexpr int MAXB = D::MAXB;
-  float* cvec = lds + 2 * D::BUF_FLOATS;
+  constexpr int NS = kNsGrad;
+  float* cvec = lds + 2 * D::buf_floats(NS);
 
-  WStream ws{lds, D::BUF_FLOATS, 0, wave, lane};
-  ws.issue(a.p.wp[0], D::nbo(0), true);
+  WStream ws{lds, D::buf_floats(NS), 0, wave, lane};
+  ws.issue(a.p.wp[0], chunk_pieces(D::nbo(0), NS), true);
   if (tid < D::NBH * 32) cvec[tid] = a.p.w_sdf[tid];
   __syncthreads();
 
@@ -291,8 +304,8 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
     // stores per produced block: zc + qb (32) for blocks computed from the layer below, qb only (16) for the seed blocks of
     // the skip layer, none for layer 0
     using ST = Stores<(l == 0 ? 0 : 32), (l == 0 ? 0 : (l == D::SKIP ? 16 : 32)), (l == D::SKIP ? D::NB3 : (1 << 30))>;
-    tp_gemm<KB, NBO, ST>(out, carry, fetch, make, next_fetch, ws, a.p.wp[l], last ? a.p.wpT[D::NL] : a.p.wp[last ? l : l + 1],
-                     last ? D::NBH : D::nbo(last ? l : l + 1));
+    tp_gemm<KB, NBO, ST, NS>(out, carry, fetch, make, next_fetch, ws, a.p.wp[l], last ? a.p.wpT[D::NL] : a.p.wp[last ? l : l + 1],
+                             chunk_pieces(last ? D::NBH : D::nbo(last ? l : l + 1), NS));
   });
   {
     // epilogue of the last hidden layer: qb_NL (tangent reaching the sdf row; only the weight gradient needs it) and zc_{NL-1}
@@ -325,7 +338,8 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
     auto make = [&](auto, const Raw& raw, auto ec) __attribute__((always_inline)) { return raw.a[decltype(ec)::value]; };
     auto next_fetch = [&]() __attribute__((always_inline)) { return bwd_fetch(IC<D::NL - 1>{}, IC<0>{}); };
     carry = fetch(IC<0>{});
-    tp_gemm<D::NBF, D::NBH, Stores<0>>(accA, carry, fetch, make, next_fetch, ws, a.p.wpT[D::NL], a.p.wpT[D::NL - 1], D::kb(D::NL - 1));
+    tp_gemm<D::NBF, D::NBH, Stores<0>, NS>(accA, carry, fetch, make, next_fetch, ws, a.p.wpT[D::NL], a.p.wpT[D::NL - 1],
+                                           chunk_pieces(D::kb(D::NL - 1), NS));
   }
   static_for<0, D::NL>([&](auto sc) __attribute__((always_inline)) {
     constexpr int step = decltype(sc)::value;
@@ -347,8 +361,8 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
       if constexpr (l > 0) return bwd_fetch(IC<(l > 0 ? l - 1 : 0)>{}, IC<0>{});
       else return Raw{};
     };
-    tp_gemm<NBO, KB, Stores<16>>(un, carry, fetch, make, next_fetch, ws, a.p.wpT[l], l > 0 ? a.p.wpT[l > 0 ? l - 1 : 0] : nullptr,
-                     l > 0 ? D::kb(l > 0 ? l - 1 : 0) : 0);
+    tp_gemm<NBO, KB, Stores<16>, NS>(un, carry, fetch, make, next_fetch, ws, a.p.wpT[l], l > 0 ? a.p.wpT[l > 0 ? l - 1 : 0] : nullptr,
+                                     l > 0 ? chunk_pieces(D::kb(l > 0 ? l - 1 : 0), NS) : 0);
     if constexpr (l == D::SKIP) {
 #pragma unroll
       for (int b = 0; b < D::NB0; ++b) tp_store_blk(un[D::NB3 + b], a.in0bar_tp, tile, D::NB0, b, lane);

@@ -6,26 +6,36 @@
 // loads of saved tensors, stores of tensors the backward needs):
 //
 //   for kb in 0..KB (fully unrolled, every register index a compile-time constant):
-//       wait for weight chunk kb in LDS (s_waitcnt vmcnt(0) ; s_barrier)
+//       wait for weight chunk kb in LDS (counted s_waitcnt vmcnt ; s_barrier)
 //       start the LDS-DMA of the next chunk (possibly the first chunk of the NEXT gemm: the stream never drains)
-//       issue the global loads the producer of block kb + 1 needs
-//       16 x NBO  v_mfma_f32_32x32x2_f32  with A = weight fragment from LDS (ds_read_b128: 4 k-steps per read),
-//                                               B = blk[r] (own register, accumulator layout of the previous gemm)
-//       ... with the 16 elements of block kb + 1 produced between the MFMA groups of the second half of the step
+//       issue the global loads the producer of block kb + 2 needs
+//       produce block kb + 1 (VALU) and split it into bf16 parts, interleaved with
+//       2 x NBO x {3 | 6}  v_mfma_f32_32x32x16_bf16  with A = weight fragments from LDS (ds_read_b128: 8 k per read),
+//                                                        B = the parts of block kb (own registers)
 //
-// So activations never leave the register file between layers, never exist as a full 128-register copy (the previous
-// accumulators ARE the activations, converted 16 registers at a time) and the weights move HBM/L2 -> LDS by DMA
-// (global_load_lds_dwordx4) without passing through registers.  fp32 in / fp32 accumulate: exact-f32 numerics
-// (the reference trains in fp32; parity target 1e-5 on SDF).
+// Numerics: fp32 in, fp32 accumulate, products by SPLIT bf16.  x = x0 + x1 (+ x2) with x0 = bf16(x), x1 = bf16(x - x0), ...
+// (each part carries 8 more mantissa bits; a product of two bf16 is exact in fp32), and
+//   NS = 2:  w x ~ w1 x0 + w0 x1 + w0 x0                                 (3 MFMAs, relative product error ~2^-16)
+//   NS = 3:  w x ~ w1 x1 + w2 x0 + w0 x2 + w1 x0 + w0 x1 + w0 x0        (6 MFMAs, all 24 mantissa bits: fp32-class)
+// The matrix pipe runs bf16 16x faster than fp32 (MI355X: 2.5 PFLOP/s vs 157 TFLOP/s), so even the 6-term form is
+// ~2.7x cheaper than v_mfma_f32_32x32x2_f32.  The forward layers (whose outputs have parity targets: 1e-5 on SDF) use
+// NS = 3; the derivative / gradient passes use NS = 2.  Activations never leave the register file between layers and
+// the weights move L2 -> LDS by DMA (global_load_lds_dwordx4) without passing through registers.
 //
-// Weight chunk layout (pack_kernel):  Wp[kb][ob][r4][lane][j]  holds  W[out = 32 ob + (lane & 31)][k = 32 kb + tp_row(4 r4 + j, lane >> 5)]
+// Weight chunk layout (pack_kernel), bf16:  Wp[kb][part 0..2][ob][kk 0..1][lane][j 0..7]
+//   = part of  W[out = 32 ob + (lane & 31)][k = 32 kb + tp_row(8 kk + j, lane >> 5)]
+// One ds_read_b128 is the A operand of one MFMA; a gemm that runs NS = 2 streams only parts 0, 1 of every chunk.
 #pragma once
 #include "common.h"
 
 template <int N>
 using IC = std::integral_constant<int, N>;
 
-constexpr int kChunkBlockFloats = 1024;  // one (k block, out block) pair: 32 x 32 weights
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kChunkBlockFloats = 1536;  // HBM: one (k block, out block) pair = 3 bf16 parts x 32 x 32 weights
+// KiB pieces the DMA moves for one chunk of nbo out-blocks and ns parts (4 waves x 1 KiB per instruction round)
+SDFHIP_HD constexpr int chunk_pieces(const int nbo, const int ns) { return (nbo * ns * 2 + 3) / 4 * 4; }
 
 struct WStream {
   float* lds;        // two chunk buffers of buf_floats each
@@ -33,11 +43,12 @@ struct WStream {
   int cur;           // buffer holding the chunk that the next mfma step consumes
   int wave, lane;
 
-  // Start the DMA of `nbo` KiB-blocks from gsrc into the buffer that is NOT current.  Every wave copies a quarter.
-  SDFHIP_D void issue(const float* __restrict__ gsrc, const int nbo, const bool into_current = false) {
+  // Start the DMA of `pieces` KiB (a multiple of 4: every wave issues the same count, so vmcnt bookkeeping is uniform)
+  // from gsrc into the buffer that is NOT current.
+  SDFHIP_D void issue(const float* __restrict__ gsrc, const int pieces, const bool into_current = false) {
     float* dst = lds + ((into_current ? cur : cur ^ 1) * buf_floats);
-    for (int i = 0; i < nbo; ++i) {
-      const int piece = i * 4 + wave;  // 1 KiB per wave instruction: lane l supplies bytes [16 l, 16 l + 16)
+    for (int i = 0; i < pieces; i += 4) {
+      const int piece = i + wave;  // 1 KiB per wave instruction: lane l supplies bytes [16 l, 16 l + 16)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + piece * 256 + lane * 4),
                                        (__attribute__((address_space(3))) void*)(dst + piece * 256), 16, 0, 0);
     }
@@ -57,6 +68,29 @@ struct WStream {
   SDFHIP_D void flip() { cur ^= 1; }
 };
 
+// One 32-feature activation block split into NS bf16 parts; p[q][kk] is the B operand of the MFMAs of k half kk.
+template <int NS>
+struct SplitBlk {
+  bf16x8 p[NS][2];
+};
+template <int NS>
+SDFHIP_D SplitBlk<NS> split_block(const f32x16& v) {
+  SplitBlk<NS> s;
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float r = v[kk * 8 + j];
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        const __bf16 h = (__bf16)r;
+        s.p[q][kk][j] = h;
+        if (q + 1 < NS) r -= (float)h;
+      }
+    }
+  return s;
+}
+
 // What a producer fetched from HBM for one input block (up to two TP blocks, e.g. z_l and zc_l); unused members cost nothing.
 struct Raw {
   f32x16 a, b;
@@ -70,57 +104,76 @@ struct NoFetch {  // producer without an HBM fetch
 
 // acc[0..NBO) += W * B with B[kb] produced just in time.  The producer of a block is split so that neither HBM latency nor
 // its VALU work ever sits in front of the matrix pipe (one wave per SIMD: nothing else would cover it):
-//   fetch(IC<kb>) -> Raw               global loads block kb needs; issued at the head of step kb - 1, pinned there
-//   make(IC<kb>, Raw, IC<e>) -> float  element e of the block (VALU + the element's stores); the 16 elements of block
-//                                      kb + 1 are written, two at a time, between the MFMA groups of the SECOND half of
-//                                      step kb: their operands were fetched half a step (~4000 cycles) earlier
+//   fetch(IC<kb>) -> Raw               global loads block kb needs; issued at the head of step kb - 2, pinned there
+//   make(IC<kb>, Raw, IC<e>) -> float  element e of the block (VALU + the element's stores); block kb + 1 is produced
+//                                      during step kb, the compiler interleaves it with the step's MFMAs
 //   next_fetch() -> Raw                fetch of block 0 of the FOLLOWING gemm, issued at the head of this gemm's last step;
 //                                      it travels in `carry`, which on entry holds this gemm's own block-0 operands
 //   ST::at(kb)                         number of global stores make(IC<kb>, ..) issues (see WStream::wait_sync)
+//   NS                                 bf16 parts per operand (2: 3-term products, 3: 6-term, fp32-class)
 // wp: this gemm's packed weights (first chunk already in flight / landed in the current buffer).
-// next_wp / next_nbo: first chunk of the gemm that follows (nullptr: none).
+// next_wp / next_pieces: first chunk of the gemm that follows (nullptr: none), chunk_pieces(its NBO, its NS).
 // global stores make(IC<kb>, ..) issues for one block: A for blocks kb < FROM, B for the rest
 template <int A, int B = A, int FROM = 1 << 30>
 struct Stores {
   static constexpr int at(int kb) { return kb < FROM ? A : B; }
 };
 
-template <int KB, int NBO, class ST, int MAXA, class Fetch, class Make, class NextFetch>
+template <int KB, int NBO, class ST, int NS, int MAXA, class Fetch, class Make, class NextFetch>
 SDFHIP_D void tp_gemm(f32x16 (&acc)[MAXA], Raw& carry, Fetch&& fetch, Make&& make, NextFetch&& next_fetch, WStream& ws,
-                      const float* __restrict__ wp, const float* __restrict__ next_wp, const int next_nbo) {
+                      const float* __restrict__ wp, const float* __restrict__ next_wp, const int next_pieces) {
   static_assert(NBO <= MAXA, "accumulator tile too small");
+  static_assert(NS == 2 || NS == 3, "2 or 3 bf16 parts");
+  // (weight part, activation part) of every product term, smallest magnitude first
+  constexpr int NT = NS == 2 ? 3 : 6;
+  constexpr int ta[6] = {1, NS == 2 ? 0 : 2, 0, 1, 0, 0};
+  constexpr int tb[6] = {NS == 2 ? 0 : 1, NS == 2 ? 1 : 0, NS == 2 ? 0 : 2, 0, 1, 0};
+  constexpr int G = NBO <= 4 ? NBO : 4;  // out-blocks per operand-read group (bounds the live weight fragments)
   // r1: operands of the block made during the current step; r2: operands of the block after that (in flight)
   Raw r1 = carry, r2;
   if constexpr (KB > 1) r2 = fetch(IC<(KB > 1 ? 1 : 0)>{});
-  f32x16 blk;
-  static_for<0, 16>([&](auto ec) __attribute__((always_inline)) { blk[decltype(ec)::value] = make(IC<0>{}, r1, ec); });
+  SplitBlk<NS> blk;
+  {
+    f32x16 first;
+    static_for<0, 16>([&](auto ec) __attribute__((always_inline)) { first[decltype(ec)::value] = make(IC<0>{}, r1, ec); });
+    blk = split_block<NS>(first);
+  }
   static_for<0, KB>([&](auto kbc) __attribute__((always_inline)) {
     constexpr int kb = decltype(kbc)::value;
     constexpr bool more = kb + 1 < KB;
     ws.template wait_sync<ST::at(kb)>();
-    if constexpr (more) ws.issue(wp + (size_t)(kb + 1) * NBO * kChunkBlockFloats, NBO);
-    else if (next_wp != nullptr) ws.issue(next_wp, next_nbo);
+    if constexpr (more) ws.issue(wp + (size_t)(kb + 1) * NBO * kChunkBlockFloats, chunk_pieces(NBO, NS));
+    else if (next_wp != nullptr) ws.issue(next_wp, next_pieces);
     r1 = r2;
     if constexpr (kb + 2 < KB) r2 = fetch(IC<(kb + 2 < KB ? kb + 2 : 0)>{});
     else if constexpr (!more) carry = next_fetch();
     __builtin_amdgcn_sched_barrier(0);  // DMA + loads stay at the head of the step
     const float* cur = ws.current();
-    f32x16 nxt;
-    if constexpr (more)
+    SplitBlk<NS> nxt;
+    if constexpr (more) {
+      f32x16 v;
       static_for<0, 16>([&](auto ec) __attribute__((always_inline)) {
-        nxt[decltype(ec)::value] = make(IC<(more ? kb + 1 : 0)>{}, r1, ec);
+        v[decltype(ec)::value] = make(IC<(more ? kb + 1 : 0)>{}, r1, ec);
       });
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      f32x4 a[NBO];
-#pragma unroll
-      for (int ob = 0; ob < NBO; ++ob) a[ob] = *reinterpret_cast<const f32x4*>(cur + (ob * 4 + r4) * 256);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int ob = 0; ob < NBO; ++ob)
-          acc[ob] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ob][j], blk[r4 * 4 + j], acc[ob], 0, 0, 0);
+      nxt = split_block<NS>(v);
     }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int g0 = 0; g0 < NBO; g0 += G) {
+        bf16x8 a[NS][G];
+#pragma unroll
+        for (int q = 0; q < NS; ++q)
+#pragma unroll
+          for (int i = 0; i < G; ++i)
+            if (g0 + i < NBO) a[q][i] = *reinterpret_cast<const bf16x8*>(cur + ((q * NBO + g0 + i) * 2 + kk) * 256);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int i = 0; i < G; ++i)
+            if (g0 + i < NBO)
+              acc[g0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ta[t]][i], blk.p[tb[t]][kk], acc[g0 + i], 0, 0, 0);
+      }
     ws.flip();
     if constexpr (more) blk = nxt;
   });

@@ -1,6 +1,6 @@
 // sdfhip — weight packing and weight-gradient kernels for the fused networks.
 //
-//  pack_kernel    natural [out][in] fp32 weights -> MFMA A-operand order  Wp[kb][ob][r4][lane][j]
+//  pack_kernel    natural [out][in] fp32 weights -> split-bf16 MFMA A-operand order  Wp[kb][part][ob][kk][lane][j]
 //                 (and the transposed pack used by the chain / data-backward passes)
 //  wgrad_kernel   split-K GEMM over points:  C[o][i] = sum_p A[p][o] * B[p][i]  with A, B tile-packed in HBM,
 //                 one workgroup per (point-split, 8x8 block macro tile), tiles transposed through LDS; fp32 MFMA 32x32x2.
@@ -22,18 +22,18 @@ struct PackDesc {
   int32_t pad_;
 };
 
-// grid = (ceil(kb*nbo*1024 / 256), n_desc)
+// grid = (ceil(kb*nbo*1024 / 256), n_desc).  One thread per weight: writes its three bf16 parts (w = w0 + w1 + w2, each part the
+// bf16 rounding of what the previous parts left) into the chunk layout of mlp_core.h:
+//   Wp[kb][part][ob][kk][lane][j]  <-  W[out = 32 ob + (lane & 31)][k = 32 kb + tp_row(8 kk + j, lane >> 5)]
 static __global__ void pack_kernel(const float* __restrict__ theta, const PackDesc* __restrict__ descs,
                             const int32_t* __restrict__ maps, float* __restrict__ packed) {
   const PackDesc d = descs[blockIdx.y];
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int total = d.kb * d.nbo * 1024;
   if (idx >= total) return;
-  // chunk layout [kb][ob][r4][lane][j] (mlp_core.h): one ds_read_b128 per lane yields the A operands of 4 consecutive k steps
-  const int j = idx & 3, lane = (idx >> 2) & 63, r4 = (idx >> 8) & 3, ob = (idx >> 10) % d.nbo, kb = (idx >> 10) / d.nbo;
-  const int reg = r4 * 4 + j;
-  const int o = ob * 32 + (lane & 31);             // MFMA A-operand row  (output feature)
-  const int k = kb * 32 + tp_row(reg, lane >> 5);  // contraction index in TP order
+  const int j = idx & 7, lane = (idx >> 3) & 63, kk = (idx >> 9) & 1, ob = (idx >> 10) % d.nbo, kb = (idx >> 10) / d.nbo;
+  const int o = ob * 32 + (lane & 31);                     // MFMA A-operand row  (output feature)
+  const int k = kb * 32 + tp_row(kk * 8 + j, lane >> 5);   // contraction index in TP order
   const int32_t* rowmap = maps + d.rowmap_off;
   const int32_t* colmap = maps + d.colmap_off;
   float v = 0.0f;
@@ -44,7 +44,13 @@ static __global__ void pack_kernel(const float* __restrict__ theta, const PackDe
     const int nr = rowmap[k], nc = colmap[o];
     if (nr >= 0 && nc >= 0) v = theta[d.src_off + (int64_t)nr * d.ld + nc] * d.scale;
   }
-  packed[d.dst_off + idx] = v;
+  __bf16* chunk = reinterpret_cast<__bf16*>(packed + d.dst_off) + (size_t)kb * d.nbo * 3072;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const __bf16 h = (__bf16)v;
+    chunk[(((q * d.nbo + ob) * 2 + kk) * 64 + lane) * 8 + j] = h;
+    v -= (float)h;
+  }
 }
 
 // padded natural-order vectors (biases, output rows): dst[i] = map[i] >= 0 ? theta[src_off + map[i]*stride] : 0

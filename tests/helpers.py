@@ -58,6 +58,8 @@ def report(name, got, ref, rtol, atol):
 def assert_close(name, got, ref, rtol=1e-4, atol=1e-6):
     ok, msg = report(name, got, ref, rtol, atol)
     print(("PASS " if ok else "FAIL ") + msg)
+    if os.environ.get("SDFHIP_TEST_KEEP_GOING"):  # debugging aid: print every comparison of a failing test
+        return
     assert ok, msg
 
 
@@ -76,6 +78,54 @@ def assert_fp32_class(name, got, ref32, truth64, factor=3.0, atol=1e-6):
            f"bound {factor * e_ref + atol:.3e}")
     print(("PASS " if ok else "FAIL ") + msg)
     assert ok, msg
+
+
+def relu_flip_basis(run_backward, margin=2e-6, max_flips=48):
+    """Gradient changes caused by taking the other ReLU branch at every knife-edge pre-activation of the colour network.
+
+    run_backward() -> {name: grad} evaluates the ORACLE (any dtype) on the test's inputs.  Pre-activations with |z| < margin
+    are the (point, unit) pairs where fp32 implementations with different summation order may pick different branches;
+    for each of them the oracle is re-run with that single branch flipped.  Returns (base grads, [delta grads per flip])."""
+    rec = {}
+    with O.relu_hook(record=rec):
+        base = {k: v.detach().clone() for k, v in run_backward().items()}
+    edges = [(l, i) for l, z in sorted(rec.items()) for i in torch.nonzero(z.abs() < margin).tolist()]
+    assert len(edges) <= max_flips, f"{len(edges)} knife-edge ReLU pre-activations: shrink the case or the margin"
+    basis = []
+    for l, (row, col) in edges:
+        m = torch.zeros_like(rec[l], dtype=torch.bool)
+        m[row, col] = True
+        with O.relu_hook(flip={l: m}):
+            g = run_backward()
+        basis.append({k: g[k].detach() - base[k] for k in base})
+        print(f"knife-edge ReLU: colour layer {l}, point {row}, unit {col}, z = {rec[l][row, col].item():+.2e}")
+    return base, basis
+
+
+def assert_grads_close_mod_relu_flips(got, ref, basis, rtol, atol=1e-8):
+    """Every gradient tensor must match `ref` within rtol * max|ref| once the ReLU branch choices at the knife-edge
+    pre-activations (relu_flip_basis) are allowed to differ: got - ref = sum_k c_k basis_k with c_k in {-1, 0, 1}."""
+    keys = [k for k in ref if k in got]
+    scale = {k: ref[k].abs().max().item() + 1e-30 for k in keys}
+    diff = torch.cat([((got[k].detach().cpu().double() - ref[k].double()) / scale[k]).flatten() for k in keys])
+    coef = []
+    if basis:
+        B = torch.stack([torch.cat([(b[k].double() / scale[k]).flatten() for k in keys]) for b in basis], dim=1)
+        c = torch.linalg.lstsq(B, diff[:, None]).solution[:, 0]
+        coef = c.round().clamp(-1, 1)
+        diff = diff - B @ coef
+        print("ReLU branch differences absorbed:", [int(v) for v in coef.tolist()])
+    off, bad = 0, []
+    for k in keys:
+        n = ref[k].numel()
+        err = diff[off:off + n].abs().max().item()
+        off += n
+        ok = err <= rtol + atol / scale[k]
+        print(("PASS " if ok else "FAIL ") + f"grad {k}: max|d| / max|ref| = {err:.3e} (tol {rtol:.1e})")
+        if not ok:
+            bad.append(k)
+    assert not bad, f"gradients differ beyond ReLU branch ambiguity: {bad}"
+    return coef
 
 
 def to_double(params):

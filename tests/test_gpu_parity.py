@@ -10,8 +10,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import (assert_close, assert_fp32_class, load_golden, load_golden_file, product_grads, product_model_from_params, small_oracle_cfg,
-                     to_double)
+from helpers import (assert_close, assert_fp32_class, assert_grads_close_mod_relu_flips, load_golden, load_golden_file, product_grads,
+                     product_model_from_params, relu_flip_basis, small_oracle_cfg, to_double)
 from oracle import sdf_path as O
 
 pytestmark = pytest.mark.gpu
@@ -204,12 +204,23 @@ def test_neus_model_against_reference_golden(device, mode):
         model.zero_grad()
         loss.backward()
         got = product_grads(model)
-        n_checked = 0
-        for k, rg in g["grad"].items():
+        for k in g["grad"]:
             assert k in got, f"no gradient for {k}"
-            assert_close(f"grad {k}", got[k], rg, rtol=5e-3, atol=1e-8)
-            n_checked += 1
-        assert n_checked >= 40
+        assert len(g["grad"]) >= 40
+
+        # The colour network's ReLUs: pre-activations within round-off of zero may take either branch (helpers.py).  Its raw
+        # d sdf / dx input carries ~1e-4 of fp32 noise here (finest hash levels: scale 2e3 x one ulp of the position; the
+        # "gradient" line above), which reaches the pre-activations as ~1e-5: that is the knife-edge margin.
+        def oracle_backward():
+            po = {k: v.clone().requires_grad_(v.is_floating_point() and k != "laplace_density.beta_min") for k, v in g["param"].items()}
+            o = O.neus_forward(g["in"]["origins"], g["in"]["dirs"], g["in"]["cam"], po, cfg, cos_anneal_ratio=ca, training=True,
+                               samples=(ref["bins"], ref["starts"], ref["ends"]))
+            lo = F.l1_loss(o["rgb"], g["in"]["image"]) + ((o["field"]["gradient"].norm(2, dim=-1) - 1) ** 2).mean() * cfg.eikonal_loss_mult
+            lo.backward()
+            return {k: po[k].grad for k in g["grad"]}
+
+        _, basis = relu_flip_basis(oracle_backward, margin=3e-5)
+        assert_grads_close_mod_relu_flips(got, g["grad"], basis, rtol=5e-3)
 
 
 # ------------------------------------------------------------------------------------------------ VolSDF sampler

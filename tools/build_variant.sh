@@ -1,0 +1,15 @@
+#!/bin/bash
+# Build a libsdfhip variant with extra compiler flags for same-box A/B runs: tools/build_variant.sh <name> [-DFOO=1 ...]
+# -> tools/_bin/libsdfhip_<name>.so
+set -e
+NAME=$1; shift
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=$ROOT/tools/_bin; OBJ=$OUT/obj_$NAME; mkdir -p $OBJ
+for f in api inst_a inst_b; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-unused-function "$@" -I $ROOT/sdfstudio_amd/csrc \
+    -c $ROOT/sdfstudio_amd/csrc/$f.hip -o $OBJ/$f.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJ/api.o $OBJ/inst_a.o $OBJ/inst_b.o -o $OUT/libsdfhip_$NAME.so
+rm -rf $OBJ
+echo built $OUT/libsdfhip_$NAME.so

@@ -1,0 +1,115 @@
+// Dev probe: per-box characterisation (boxes in the pool differ): pure MFMA rates, L2 -> LDS DMA stream rate, LDS read rate.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256, 1) void mfma_bf16(float* out, int iters) {
+  f32x16 acc[8];
+  for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0;
+  bf16x8 a, b;
+  for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(threadIdx.x * 0.001f + j); b[j] = (__bf16)(j * 0.5f); }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0;
+  for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+__global__ __launch_bounds__(256, 1) void mfma_f32(float* out, int iters) {
+  f32x16 acc[8];
+  for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0;
+  float a = threadIdx.x * 0.001f, b = 0.5f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0;
+  for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+// every WG streams the same `bytes` (L2 resident) into LDS, chunk by chunk, `reps` times
+__global__ __launch_bounds__(256, 1) void dma_stream(const float* src, size_t floats, int reps, float* out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const size_t chunks = floats / 8192;  // 32 KiB chunks
+  int buf = 0;
+  for (int r = 0; r < reps; ++r)
+    for (size_t c = 0; c < chunks; ++c) {
+      const float* g = src + c * 8192;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int piece = i * 4 + wave;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(g + piece * 256 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(lds + buf * 8192 + piece * 256), 16, 0, 0);
+      }
+      buf = (buf + 1) & 3;
+      asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  out[blockIdx.x * 256 + threadIdx.x] = lds[threadIdx.x];
+}
+__global__ __launch_bounds__(256, 1) void lds_read(float* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  for (int i = threadIdx.x; i < 16384; i += 256) lds[i] = i;
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  f32x4 s = {0, 0, 0, 0};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      f32x4 v = *reinterpret_cast<volatile f32x4*>(lds + ((u * 256 + it * 64) & 16383 & ~255) + lane * 4);
+      s += v;
+    }
+  }
+  out[blockIdx.x * 256 + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+
+template <class F>
+static float timeit(F&& f) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  f(); f();
+  hipEventRecord(e0);
+  for (int i = 0; i < 5; ++i) f();
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  return ms / 5;
+}
+int main() {
+  hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
+  printf("%s  CUs %d  clock %d MHz  mem clock %d MHz  bus %d  L2 %d KiB  total %.1f GiB  gcn %s\n", p.name, p.multiProcessorCount, p.clockRate / 1000,
+         p.memoryClockRate / 1000, p.memoryBusWidth, p.l2CacheSize / 1024, p.totalGlobalMem / 1073741824.0, p.gcnArchName);
+  float* out; hipMalloc(&out, 4096 * 256 * 4);
+  float* src; hipMalloc(&src, 4 << 20); hipMemset(src, 0, 4 << 20);
+  const int G = 4096;
+  {
+    const int iters = 400;
+    float ms = timeit([&] { mfma_bf16<<<G, 256>>>(out, iters); });
+    printf("mfma bf16 32x32x16 : %7.3f ms  %7.1f TFLOP/s\n", ms, (double)G * 4 * iters * 32 * 32768.0 / ms / 1e9);
+    ms = timeit([&] { mfma_f32<<<G, 256>>>(out, iters); });
+    printf("mfma f32 32x32x2   : %7.3f ms  %7.1f TFLOP/s\n", ms, (double)G * 4 * iters * 32 * 4096.0 / ms / 1e9);
+  }
+  hipFuncSetAttribute((const void*)dma_stream, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+  for (size_t mb : {1, 2, 4}) {
+    const int reps = 2;
+    float ms = timeit([&] { dma_stream<<<G, 256, 131072>>>(src, (mb << 20) / 4, reps, out); });
+    printf("L2->LDS DMA stream, %zu MiB working set: %7.3f ms  %6.2f TB/s\n", mb, ms, (double)G * reps * (mb << 20) / ms / 1e9);
+  }
+  {
+    const int iters = 200;
+    hipFuncSetAttribute((const void*)lds_read, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    float ms = timeit([&] { lds_read<<<G, 256, 65536>>>(out, iters); });
+    const double bytes = (double)G * 256 * iters * 32 * 16;
+    printf("LDS ds_read_b128   : %7.3f ms  %6.2f TB/s  = %.1f B/clk/CU at %d MHz\n", ms, bytes / ms / 1e9, bytes / ms / 1e3 / p.multiProcessorCount / p.clockRate * 1e0, p.clockRate / 1000);
+  }
+  return 0;
+}
