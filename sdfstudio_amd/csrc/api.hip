@@ -156,6 +156,10 @@ struct SdfHipField {
   int32_t* d_maps = nullptr;
   int max_pack_elems = 0, max_vec_n = 0;
   int64_t max_partial_elems = 0, max_partial_rows = 0;
+  // Side stream for work that is independent of the caller's stream for a while (the atomics-bound hash-table scatter runs
+  // beside the weight-gradient GEMMs).  Always forked from / joined back into the caller's stream with events, so the
+  // caller still sees plain stream order.
+  hipStream_t side = nullptr;
 
   int kb_geo(int l) const { return l == 0 ? k->nb0 : (l == k->skip ? k->nb3 + k->nb0 : k->nbh); }
   int nbo_geo(int l) const { return l == k->nl ? k->nbf : ((l + 1 == k->skip) ? k->nb3 : k->nbh); }
@@ -347,6 +351,7 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
   upd(1, k->nbc);
   f->max_partial_elems = std::max<int64_t>(f->max_partial_elems, k->nbh * 32 + 32);
 
+  if (getenv("SDFHIP_NO_OVERLAP") == nullptr) (void)hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking);
   hipError_t e = hipMalloc((void**)&f->d_pack, f->pack.size() * sizeof(PackDesc));
   if (e == hipSuccess) e = hipMalloc((void**)&f->d_vec, f->vec.size() * sizeof(VecDesc));
   if (e == hipSuccess) e = hipMalloc((void**)&f->d_maps, maps.size() * sizeof(int32_t));
@@ -367,6 +372,7 @@ extern "C" void sdfhip_field_destroy(SdfHipField* f) {
   if (f->d_pack) (void)hipFree(f->d_pack);
   if (f->d_vec) (void)hipFree(f->d_vec);
   if (f->d_maps) (void)hipFree(f->d_maps);
+  if (f->side) (void)hipStreamDestroy(f->side);
   delete f;
 }
 
@@ -708,7 +714,22 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
   ga.pe_degree = f->cfg.pe_degree;
   ga.nb0 = k->nb0;
   ga.tablebar = table_bar;
-  { ProfScope ps_(PS_GRID_BWD, s); grid_bwd_kernel<<<dim3((unsigned)((P + 255) / 256), f->grid.n_levels), 256, 0, s>>>(ga); }
+  // forked: nothing below reads table_bar, and the scatter is bound by memory-side atomics, not by CUs
+  hipEvent_t ev_join = nullptr;
+  {
+    hipStream_t gs = s;
+    if (f->side != nullptr) {
+      hipEvent_t ev_fork = nullptr;
+      SDFHIP_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+      SDFHIP_CHECK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+      SDFHIP_CHECK_HIP(hipEventRecord(ev_fork, s));
+      SDFHIP_CHECK_HIP(hipStreamWaitEvent(f->side, ev_fork, 0));
+      (void)hipEventDestroy(ev_fork);  // released once the wait has consumed it
+      gs = f->side;
+    }
+    { ProfScope ps_(PS_GRID_BWD, gs); grid_bwd_kernel<<<dim3((unsigned)((P + 255) / 256), f->grid.n_levels), 256, 0, gs>>>(ga); }
+    if (ev_join != nullptr) SDFHIP_CHECK_HIP(hipEventRecord(ev_join, gs));
+  }
 
   // 5. weight gradients: split-K GEMMs over points
   const int64_t n_tiles = NP / 32;
@@ -794,6 +815,10 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
     a.A[0] = seg1(w.dout, 1, 0);
     a.B[0] = seg1(w.h[k->nlc - 1], k->nbc, 0);
     run_wgrad(f, w, a, f->c_rowmap[k->nlc], f->c_colmap[k->nlc], li.w_off, li.in_dim, 1.0f, li.b_off, theta_bar, s);
+  }
+  if (ev_join != nullptr) {
+    SDFHIP_CHECK_HIP(hipStreamWaitEvent(s, ev_join, 0));
+    (void)hipEventDestroy(ev_join);
   }
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;

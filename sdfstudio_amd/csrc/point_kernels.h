@@ -353,8 +353,44 @@ struct GridBwdArgs {
   float* tablebar;         // [entries][F]  (accumulated)
 };
 
+// ---- line-coalesced issue of the table-gradient atomics
+// The memory-side atomic unit is priced per (instruction, 64-byte line) pair: ~21 G line-updates/s chip-wide whether the
+// lanes of one instruction touch 64 lines or 16 (tools/probe_atomic.hip: 21 / 42 / 84 / 334 G adds/s with 1 / 2 / 4 / 16
+// lanes per line).  One point's contributions to an entry pair (x, x + 1) x (feature 0, 1) are 16 contiguous bytes on the
+// dense levels (and on the hashed levels whenever x is even: the hash multiplies x by 1), so the 16 adds of a point are
+// transposed through LDS: instruction (c, q) carries, in lanes 4 i .. 4 i + 3, the x-pair of corner pair c of point
+// 16 q + i  ->  16 lines per instruction instead of 64.
+struct ScatterStage {
+  float v[64][17];     // [point of the wave][corner * 2 + feature], row padded against bank conflicts
+  uint32_t e[64][9];   // [point][corner] table entry, or kNoEntry when the run reduction gave the add to another lane
+};
+constexpr uint32_t kNoEntry = 0xffffffffu;
+SDFHIP_D void scatter_stage_put(ScatterStage& st, const int lane, const int k, const bool issue, const uint32_t entry, const float t0,
+                                const float t1) {
+  st.v[lane][2 * k] = t0;
+  st.v[lane][2 * k + 1] = t1;
+  st.e[lane][k] = issue ? entry : kNoEntry;
+}
+SDFHIP_D void scatter_stage_flush(const ScatterStage& st, const int lane, float* __restrict__ tablebar) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // this wave's LDS writes are ordered before its reads below
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int pt = q * 16 + (lane >> 2), k = c * 2 + ((lane >> 1) & 1), f = lane & 1;
+      const uint32_t entry = st.e[pt][k];
+      const float v = st.v[pt][2 * k + f];
+      if (entry != kNoEntry) atomicAdd(tablebar + (size_t)entry * 2 + f, v);
+    }
+  __builtin_amdgcn_wave_barrier();
+}
+
 // grid = (ceil(P/256), n_levels)
 __global__ __launch_bounds__(256) void grid_bwd_kernel(const GridBwdArgs a) {
+  __shared__ ScatterStage stage[4];
+  const int lane = threadIdx.x & 63;
+  ScatterStage& st = stage[threadIdx.x >> 6];
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool live = p < a.n_points;
   const int level = blockIdx.y;
@@ -388,12 +424,10 @@ __global__ __launch_bounds__(256) void grid_bwd_kernel(const GridBwdArgs a) {
       t0 = fmaf(s, e0, t0);
       t1 = fmaf(s, e1, t1);
     }
-    if (wave_run_reduce(c.idx[k], live, t0, t1)) {
-      float* dst = a.tablebar + (size_t)c.idx[k] * 2;
-      atomicAdd(dst, t0);
-      atomicAdd(dst + 1, t1);
-    }
+    const bool issue = wave_run_reduce(c.idx[k], live, t0, t1);
+    scatter_stage_put(st, lane, k, issue, c.idx[k], t0, t1);
   }
+  scatter_stage_flush(st, lane, a.tablebar);
 }
 
 // ------------------------------------------------------------------------------------------------ proposal field
