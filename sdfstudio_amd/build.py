@@ -7,6 +7,7 @@ sources so rebuilding after an edit only recompiles what changed.  The shared ob
 import concurrent.futures
 import hashlib
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -26,15 +27,26 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the sdfhip extension cannot be built")
 
 
+def _closure(name: str, seen: set) -> None:
+    """Local headers a source pulls in (transitively), so an edit only rebuilds the translation units that see it."""
+    if name in seen:
+        return
+    seen.add(name)
+    with open(os.path.join(CSRC, name), "r") as fh:
+        for line in fh:
+            m = re.match(r'\s*#\s*include\s+"([^"]+)"', line)
+            if m and os.path.exists(os.path.join(CSRC, m.group(1))):
+                _closure(m.group(1), seen)
+
+
 def _digest(src: str) -> str:
     h = hashlib.sha256()
     h.update(" ".join(FLAGS).encode())
-    with open(os.path.join(CSRC, src), "rb") as fh:
-        h.update(fh.read())
-    for name in sorted(os.listdir(CSRC)):
-        if name.endswith(".h"):
-            with open(os.path.join(CSRC, name), "rb") as fh:
-                h.update(fh.read())
+    deps: set = set()
+    _closure(src, deps)
+    for name in sorted(deps):
+        with open(os.path.join(CSRC, name), "rb") as fh:
+            h.update(fh.read())
     with open(os.path.join(HERE, "..", "include", "sdfhip.h"), "rb") as fh:
         h.update(fh.read())
     return h.hexdigest()[:16]

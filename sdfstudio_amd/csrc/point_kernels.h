@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void prop_fwd_kernel(const PropArgs a) {
   a.density[p] = expf(pre);
 }
 
-// Backward.  Thread <-> point (grid-stride, block-uniform trip count).  Table gradient: run-reduced fp32 atomics.
+// Backward.  Thread <-> point (grid-stride, block-uniform trip count).  Table gradient: run-reduced, line-coalesced fp32 atomics.
 // Weight gradients: w1_bar[j][i] = sum_p hb_j[p] feat_i[p] and w2_bar[j] = sum_p relu(hid_j[p]) pb[p] are 16 x 16 products
 // contracted over the points, accumulated on the matrix core (v_mfma_f32_16x16x4_f32, 8 accumulator registers per
 // lane instead of 176): each wave transposes its 64 points through a private LDS slab ([row][64 points + 4 pad]).
@@ -516,8 +516,10 @@ constexpr int kPropRows = 27;  // rows 0..15: relu(hid_j)^T ; 16..25: feat_i^T ;
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void prop_bwd_kernel(const PropArgs a) {
   __shared__ __attribute__((aligned(16))) float slab[4][kPropRows][kPropT];
   __shared__ float red[4][176];
+  __shared__ ScatterStage stage[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float (*sh)[kPropT] = slab[wave];
+  ScatterStage& st = stage[wave];
   f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
   for (int64_t base = (int64_t)blockIdx.x * 256; base < a.n_points; base += (int64_t)gridDim.x * 256) {
     // compiler barrier: keeps the 176 (wave-uniform, scalar-cache resident) MLP weights from being hoisted out of the loop
@@ -554,12 +556,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
       for (int k = 0; k < 8; ++k) {
         const float w = corner_w(c, k);
         float t0 = w * fb[2 * l], t1 = w * fb[2 * l + 1];
-        if (wave_run_reduce(c.idx[k], contributes, t0, t1)) {
-          float* dst = a.tablebar + (size_t)c.idx[k] * 2;
-          atomicAdd(dst, t0);
-          atomicAdd(dst + 1, t1);
-        }
+        const bool issue = wave_run_reduce(c.idx[k], contributes, t0, t1);
+        scatter_stage_put(st, lane, k, issue, c.idx[k], t0, t1);
       }
+      scatter_stage_flush(st, lane, a.tablebar);
     }
     // ---- weight gradients on the matrix core: lane (m = lane & 15, k = lane >> 4) takes points 16 u + 4 k + e
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): this wave's slab writes have landed (wave-private slab)

@@ -73,6 +73,9 @@ __global__ __launch_bounds__(256, 1) void lds_read(float* out, int iters) {
   out[blockIdx.x * 256 + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
+__global__ __launch_bounds__(256) void hbm_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
 template <class F>
 static float timeit(F&& f) {
   hipEvent_t e0, e1;
@@ -89,7 +92,7 @@ int main() {
   printf("%s  CUs %d  clock %d MHz  mem clock %d MHz  bus %d  L2 %d KiB  total %.1f GiB  gcn %s\n", p.name, p.multiProcessorCount, p.clockRate / 1000,
          p.memoryClockRate / 1000, p.memoryBusWidth, p.l2CacheSize / 1024, p.totalGlobalMem / 1073741824.0, p.gcnArchName);
   float* out; hipMalloc(&out, 4096 * 256 * 4);
-  float* src; hipMalloc(&src, 4 << 20); hipMemset(src, 0, 4 << 20);
+  float* src; hipMalloc(&src, 16 << 20); hipMemset(src, 0, 16 << 20);
   const int G = 4096;
   {
     const int iters = 400;
@@ -98,8 +101,15 @@ int main() {
     ms = timeit([&] { mfma_f32<<<G, 256>>>(out, iters); });
     printf("mfma f32 32x32x2   : %7.3f ms  %7.1f TFLOP/s\n", ms, (double)G * 4 * iters * 32 * 4096.0 / ms / 1e9);
   }
+  {
+    float4 *a, *b; const size_t n = (1ull << 30) / 16;
+    hipMalloc(&a, n * 16); hipMalloc(&b, n * 16); hipMemset(a, 1, n * 16);
+    float ms = timeit([&] { hbm_copy<<<256 * 16, 256>>>(a, b, n); });
+    printf("HBM copy 1 GiB     : %7.3f ms  %6.2f TB/s (read + write)\n", ms, 2.0 * n * 16 / ms / 1e9);
+    hipFree(a); hipFree(b);
+  }
   hipFuncSetAttribute((const void*)dma_stream, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
-  for (size_t mb : {1, 2, 4}) {
+  for (size_t mb : {1, 2, 4, 16}) {
     const int reps = 2;
     float ms = timeit([&] { dma_stream<<<G, 256, 131072>>>(src, (mb << 20) / 4, reps, out); });
     printf("L2->LDS DMA stream, %zu MiB working set: %7.3f ms  %6.2f TB/s\n", mb, ms, (double)G * reps * (mb << 20) / ms / 1e9);
