@@ -11,7 +11,9 @@ Inputs are synthetic (DTU-scan65-like cameras) and already
 
 Rank 0 prints ONE JSON line.  `value` = whole-job field ray-samples per second (N * 4096 * 128 / step time).
 `roofline` is for the dominant kernel (geo_bwd_kernel: tangent + data backward of the geometry MLP), with its launch
-time measured live by HIP events recorded on the launch stream inside the timed region (sdfhip_profile_*).
+time measured live by HIP events recorded on the launch stream inside the timed region (sdfhip_profile_*).  With the
+matrix products on the bf16 pipe (split-bf16, fp32 accumulate) that kernel is bound by the HBM traffic of the saved
+per-layer tensors it must read and write (DESIGN.md section 4 derives the 58.9 KB per ray-sample), not by MFMA.
 `cpu_baseline` times the CPU oracle (a port of the reference's PyTorch path) on this host for a bounded sample.
 """
 import argparse
@@ -29,8 +31,21 @@ if ROOT not in sys.path:
 
 N_RAYS = 4096
 N_SAMPLES = 128
-PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, f32 in / f32 accumulate
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA, f32 accumulate
 PEAK_HBM_GBS = 8000.0
+
+
+def geo_bwd_algorithmic_bytes(nbh=8, nb0=3, nb3=6, nl=8, skip=4, nbf=8):
+    """HBM bytes per ray-sample that geo_bwd_kernel's algorithm moves: every tensor is tile-packed in
+    blocks of 32 features x 4 B = 128 B per point.  Tangent pass: reads the seed, z_l and r_l; writes the tangent qb_l
+    entering every layer and zc_l.  Data backward: reads featbar, z_l and zc_l; writes zbar_l and d L / d in0."""
+    kb = lambda l: nb0 if l == 0 else (nb3 + nb0 if l == skip else nbh)
+    nbo = lambda l: nbf if l == nl else (nb3 if l + 1 == skip else nbh)
+    rd = nb0 + sum(2 * nbo(l - 1) for l in range(1, nl)) + (nb0 if 0 < skip < nl else 0) + 2 * nbo(nl - 1)
+    wr = sum(kb(l) + nbo(l - 1) for l in range(1, nl)) + 2 * nbh
+    rd += nbf + sum(2 * nbo(l) for l in range(nl)) + (nb0 if skip > 0 else 0)
+    wr += sum(nbo(l) for l in range(nl)) + nb0 * (2 if skip > 0 else 1)
+    return 128 * (rd + wr)
 
 
 def synthetic_cameras(device):
@@ -211,22 +226,29 @@ def main():
         value = samples / (dt / args.steps)
         g, c = flops_per_sample()
         P = N_RAYS * N_SAMPLES
-        # dominant kernel: geo_bwd_kernel = tangent pass (G) + data backward (G): 2G flop per sample, one launch per step
+        # dominant kernel: geo_bwd_kernel = tangent pass (G) + data backward (G), one launch per step
         kt_ms, kn = prof.get("geo_bwd_kernel", (0.0, 0))
         roof = None
         if kn > 0:
             avg_s = kt_ms / kn * 1e-3
-            achieved = 2 * g * P / avg_s / 1e12
+            alg_bytes = geo_bwd_algorithmic_bytes() * P
+            achieved = alg_bytes / avg_s / 1e9
             traffic = None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the bench)
-            tpath = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-            if os.path.exists(tpath):
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
+            tpath = os.path.join(ROOT, "profiles", cands[-1]) if cands else ""  # newest committed PMC pass (r1 < r1c < r2 ...)
+            if cands:
                 with open(tpath) as fh:
                     tj = json.load(fh)
                 traffic = {"hbm_bytes_per_launch": tj["hbm_read_bytes"] + tj["hbm_write_bytes"], "source": tj["source"]}
-            roof = {"kernel": "geo_bwd_kernel", "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+            flops = 2 * g * P
+            roof = {"kernel": "geo_bwd_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": traffic,
                     "avg_launch_ms": round(kt_ms / kn, 4), "launches": kn,
-                    "algorithmic": f"2G = {2 * g} flop per ray-sample x {P} ray-samples per launch"}
+                    "algorithmic": f"{geo_bwd_algorithmic_bytes()} B per ray-sample (saved per-layer tensors read + written, DESIGN.md "
+                                   f"section 4) x {P} ray-samples per launch",
+                    # the matrix side of the same kernel: 2G algorithmic flop per sample, each product issued as 3 bf16 MFMA terms
+                    "mfma": {"algorithmic_tflops": round(flops / avg_s / 1e12, 1), "issued_bf16_tflops": round(3 * flops / avg_s / 1e12, 1),
+                             "peak_bf16_tflops": PEAK_BF16_MFMA_TFLOPS, "frac_issued": round(3 * flops / avg_s / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}}
         kernels = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] / args.steps} for k, v in prof.items()}
         mfma_ms = sum(prof.get(k, (0.0, 0))[0] for k in ("geo_fwd_kernel", "geo_bwd_kernel", "col_fwd_kernel", "col_bwd_kernel",
                                                          "wgrad_kernel")) / args.steps
@@ -234,6 +256,8 @@ def main():
             "metric": "ray-samples/sec (NeuS-facto train step, 4096 rays x 128 samples per GPU)",
             "value": round(value, 1), "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "dtype_note": "fp32 tensors and accumulators; matrix products as split-bf16 terms on the bf16 MFMA pipe (6 terms = fp32-class "
+                          "for everything the forward returns, 3 terms in the backward kernels and weight-gradient GEMMs)",
             "data": "synthetic", "iters_per_sec": round(1e3 / ms, 3), "per_gpu": round(value / world, 1),
             "config": {"workload": "BASELINE config 2: NeuS-facto hash-grid 16x2x2^19 smoothstep + 8x256 geo MLP + 4x256 colour MLP, "
                                    "4096 rays x 128 samples (+256/96 proposal samples) per GPU per step, full train step incl. Adam",

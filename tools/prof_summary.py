@@ -1,0 +1,64 @@
+"""Reduce the rocprofv3 CSVs of tools/profile_round.sh to the summaries committed under profiles/.
+
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (verbatim)
+  profiles/<tag>_pmc_summary.csv    per kernel (average per launch): FETCH_SIZE / WRITE_SIZE [KB], HBM read GB (FETCH_SIZE x 2: gfx950's
+                                    counter reports half of a coalesced stream, MI355X_MICROARCH.md), HBM write GB, SQ ratios
+  profiles/<tag>_pmc_traffic.json   the dominant kernel's HBM bytes per launch (read by bench.py -> roofline.traffic)
+"""
+import csv, json, os, shutil, sys
+from collections import defaultdict
+
+tag = sys.argv[1]
+root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+src = os.path.join(root, "gpurun_out", tag)
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "")
+
+
+def counters(sub):
+    acc = defaultdict(lambda: defaultdict(list))
+    path = os.path.join(src, sub, "p_counter_collection.csv")
+    if not os.path.exists(path):
+        return acc
+    with open(path) as fh:
+        for r in csv.DictReader(fh):
+            acc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+ks = os.path.join(src, "kt", "kt_kernel_stats.csv")
+if os.path.exists(ks):
+    shutil.copy(ks, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+fetch, write, sq = counters("pmc_fetch"), counters("pmc_write"), counters("pmc_sq")
+mean = lambda v: sum(v) / len(v) if v else float("nan")
+rows = []
+for k in sorted(fetch, key=lambda n: -mean(fetch[n]["FETCH_SIZE"]) - mean(write.get(n, {}).get("WRITE_SIZE", [0.0]))):
+    if "rocclr" in k or k.startswith("at::") or "elementwise" in k:
+        continue
+    f_kb, w_kb = mean(fetch[k]["FETCH_SIZE"]), mean(write[k]["WRITE_SIZE"]) if k in write else float("nan")
+    s = sq.get(k, {})
+    wave = mean(s.get("SQ_WAVE_CYCLES", []))
+    ratio = lambda c: round(mean(s.get(c, [])) / wave, 3) if s and wave == wave and wave > 0 else ""
+    rows.append({"kernel": k, "launches_sampled": len(fetch[k]["FETCH_SIZE"]), "FETCH_SIZE_KB": round(f_kb), "WRITE_SIZE_KB": round(w_kb),
+                 "hbm_read_GB_corrected_x2": round(2 * f_kb * 1024 / 1e9, 3), "hbm_write_GB": round(w_kb * 1024 / 1e9, 3),
+                 # matrix-pipe busy cycles over (cycles x 1024 SIMDs): GRBM_GUI_ACTIVE is summed over the 8 XCDs
+                 "mfma_busy_frac": round(mean(s["SQ_VALU_MFMA_BUSY_CYCLES"]) / (mean(s["GRBM_GUI_ACTIVE"]) * 128), 3) if s else "",
+                 "wait_any_frac": ratio("SQ_WAIT_ANY"),
+                 "wait_inst_frac": ratio("SQ_WAIT_INST_ANY"), "valu_frac": ratio("SQ_ACTIVE_INST_VALU")})
+if rows:
+    with open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w", newline="") as fh:
+        w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+        w.writeheader()
+        w.writerows(rows[:24])
+    for r in rows:
+        if r["kernel"].startswith("geo_bwd_kernel"):
+            json.dump({"kernel": "geo_bwd_kernel", "hbm_read_bytes": r["hbm_read_GB_corrected_x2"] * 1e9, "hbm_write_bytes": r["hbm_write_GB"] * 1e9,
+                       "source": f"profiles/{tag}_pmc_summary.csv: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), FETCH_SIZE "
+                                 "doubled per MI355X_MICROARCH.md (gfx950 reports half of a coalesced stream)"},
+                      open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+for r in rows[:12]:
+    print(r)
