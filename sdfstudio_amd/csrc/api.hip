@@ -882,8 +882,7 @@ extern "C" int sdfhip_proposal_backward(const SdfHipGridCfg* grid, const float* 
   a.tablebar = table_bar;
   a.wpartial = (float*)workspace;
   { ProfScope ps_(PS_PROP_BWD, s); prop_bwd_kernel<<<kPropBwdBlocks, 256, 0, s>>>(a); }
-  colsum_kernel<<<1, 256, 0, s>>>(a.wpartial, kPropBwdBlocks, 160, 176, w1_bar, 0);
-  colsum_kernel<<<1, 64, 0, s>>>(a.wpartial + 160, kPropBwdBlocks, 16, 176, w2_bar, 0);
+  colsum_kernel<<<(176 + 31) / 32, 256, 0, s>>>(a.wpartial, kPropBwdBlocks, 176, 176, w1_bar, 160, w2_bar);
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, 1) void col_fwd_kernel(const ColFwdArgs a) {
         return h;
       }
     };
-    tp_gemm<KB, D::NBC, Stores<((l > 0 && SAVE) ? 16 : 0)>, NS>(out, carry, fetch, make, NoFetch{}, ws, a.p.wp[l],
+    tp_gemm<KB, D::NBC, Stores<((l > 0 && SAVE) ? 16 : 0), ((l > 0 && SAVE) ? 16 : 0), 1 << 30, (l == 0 ? 16 : 0)>, NS>(out, carry, fetch, make, NoFetch{}, ws, a.p.wp[l],
                                                                 l + 1 < D::NLC ? a.p.wp[l + 1 < D::NLC ? l + 1 : l] : nullptr, chunk_pieces(D::NBC, NS));
   });
 
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void col_bwd_kernel(const ColBwdArgs a) {
       if constexpr (l > 0) return h_fetch(IC<(l > 0 ? l - 1 : 0)>{}, IC<0>{});
       else return Raw{};
     };
-    tp_gemm<D::NBC, KB, Stores<16>, NS>(un, carry, fetch, make, next_fetch, ws, a.p.wpT[l], l > 0 ? a.p.wpT[l > 0 ? l - 1 : 0] : nullptr,
+    tp_gemm<D::NBC, KB, Stores<16, 16, 1 << 30, 16>, NS>(un, carry, fetch, make, next_fetch, ws, a.p.wpT[l], l > 0 ? a.p.wpT[l > 0 ? l - 1 : 0] : nullptr,
                                         l > 0 ? chunk_pieces(D::kb(l > 0 ? l - 1 : 0), NS) : 0);
     if constexpr (l == 0) {
 #pragma unroll

@@ -44,7 +44,7 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
   }                                                                                                                  \
   static void sdfrow(const float* z, const float* q, const float* sb, int64_t nt, int tps, float* part,             \
                      unsigned grid, hipStream_t s) {                                                                 \
-    sdfrow_grad_kernel<NBH><<<grid, 64, 0, s>>>(z, q, sb, nt, tps, part);                                            \
+    sdfrow_grad_kernel<NBH><<<grid, 256, 0, s>>>(z, q, sb, nt, tps, part);                                            \
   }                                                                                                                  \
   }                                                                                                                  \
   const FieldKernels* sdfhip_kernels_##NAME() {                                                                      \

@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
       else return Raw{};
     };
     constexpr int ZS = (SAVE || GRAD) ? 16 : 0;  // z stores per produced block
-    using ST = Stores<(l == 0 ? 0 : ZS), (l == 0 ? 0 : (l == D::SKIP ? 0 : ZS)), (l == D::SKIP ? D::NB3 : (1 << 30))>;
+    using ST = Stores<(l == 0 ? 0 : ZS), (l == 0 ? 0 : (l == D::SKIP ? 0 : ZS)), (l == D::SKIP ? D::NB3 : (1 << 30)),
+                      (l == 0 ? 16 : 0), (l == 0 || l == D::SKIP ? 16 : 0)>;
     tp_gemm<KB, NBO, ST, NSF>(out, carry, fetch, make, next_fetch, ws, a.p.wp[l], next, next_pieces);
   });
 
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
         if constexpr (l > 0) return chain_fetch(IC<(l > 0 ? l - 1 : 0)>{}, IC<0>{});
         else return Raw{};
       };
-      tp_gemm<NBO, KB, Stores<(SAVE ? 16 : 0)>, NSC>(qn, carry, fetch, make, next_fetch, ws, a.p.wpT[l], l > 0 ? a.p.wpT[l > 0 ? l - 1 : 0] : nullptr,
+      tp_gemm<NBO, KB, Stores<(SAVE ? 16 : 0), (SAVE ? 16 : 0), 1 << 30, 16>, NSC>(qn, carry, fetch, make, next_fetch, ws, a.p.wpT[l], l > 0 ? a.p.wpT[l > 0 ? l - 1 : 0] : nullptr,
                                                      l > 0 ? chunk_pieces(D::kb(l > 0 ? l - 1 : 0), NSC) : 0);
       if constexpr (l == D::SKIP) {
         // the part of d sdf / d (layer input) that goes straight to in0: park it in e_tp, layer 0 adds to it
@@ -303,7 +304,8 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
     };
     // stores per produced block: zc + qb (32) for blocks computed from the layer below, qb only (16) for the seed blocks of
     // the skip layer, none for layer 0
-    using ST = Stores<(l == 0 ? 0 : 32), (l == 0 ? 0 : (l == D::SKIP ? 16 : 32)), (l == D::SKIP ? D::NB3 : (1 << 30))>;
+    using ST = Stores<(l == 0 ? 0 : 32), (l == 0 ? 0 : (l == D::SKIP ? 16 : 32)), (l == D::SKIP ? D::NB3 : (1 << 30)),
+                      (l == 0 ? 16 : 32), (l == 0 || l == D::SKIP ? 16 : 32)>;
     tp_gemm<KB, NBO, ST, NS>(out, carry, fetch, make, next_fetch, ws, a.p.wp[l], last ? a.p.wpT[D::NL] : a.p.wp[last ? l : l + 1],
                              chunk_pieces(last ? D::NBH : D::nbo(last ? l : l + 1), NS));
   });
@@ -338,7 +340,7 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
     auto make = [&](auto, const Raw& raw, auto ec) __attribute__((always_inline)) { return raw.a[decltype(ec)::value]; };
     auto next_fetch = [&]() __attribute__((always_inline)) { return bwd_fetch(IC<D::NL - 1>{}, IC<0>{}); };
     carry = fetch(IC<0>{});
-    tp_gemm<D::NBF, D::NBH, Stores<0>, NS>(accA, carry, fetch, make, next_fetch, ws, a.p.wpT[D::NL], a.p.wpT[D::NL - 1],
+    tp_gemm<D::NBF, D::NBH, Stores<0, 0, 1 << 30, 16>, NS>(accA, carry, fetch, make, next_fetch, ws, a.p.wpT[D::NL], a.p.wpT[D::NL - 1],
                                            chunk_pieces(D::kb(D::NL - 1), NS));
   }
   static_for<0, D::NL>([&](auto sc) __attribute__((always_inline)) {
@@ -361,8 +363,8 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
       if constexpr (l > 0) return bwd_fetch(IC<(l > 0 ? l - 1 : 0)>{}, IC<0>{});
       else return Raw{};
     };
-    tp_gemm<NBO, KB, Stores<16>, NS>(un, carry, fetch, make, next_fetch, ws, a.p.wpT[l], l > 0 ? a.p.wpT[l > 0 ? l - 1 : 0] : nullptr,
-                                     l > 0 ? chunk_pieces(D::kb(l > 0 ? l - 1 : 0), NS) : 0);
+    tp_gemm<NBO, KB, Stores<16, 16, 1 << 30, 32>, NS>(un, carry, fetch, make, next_fetch, ws, a.p.wpT[l], l > 0 ? a.p.wpT[l > 0 ? l - 1 : 0] : nullptr,
+                                                      l > 0 ? chunk_pieces(D::kb(l > 0 ? l - 1 : 0), NS) : 0);
     if constexpr (l == D::SKIP) {
 #pragma unroll
       for (int b = 0; b < D::NB0; ++b) tp_store_blk(un[D::NB3 + b], a.in0bar_tp, tile, D::NB0, b, lane);

@@ -109,15 +109,38 @@ struct NoFetch {  // producer without an HBM fetch
 //                                      during step kb, the compiler interleaves it with the step's MFMAs
 //   next_fetch() -> Raw                fetch of block 0 of the FOLLOWING gemm, issued at the head of this gemm's last step;
 //                                      it travels in `carry`, which on entry holds this gemm's own block-0 operands
-//   ST::at(kb)                         number of global stores make(IC<kb>, ..) issues (see WStream::wait_sync)
+//   ST::at(kb), ST::ld(kb)             number of global stores make(IC<kb>, ..) / global loads fetch(IC<kb>) issue: both are
+//                                      issued AFTER the DMA of chunk kb, so the wait for that chunk may leave them in flight
+//                                      (WStream::wait_sync); under-counting is safe, over-counting is not
 //   NS                                 bf16 parts per operand (2: 3-term products, 3: 6-term, fp32-class)
 // wp: this gemm's packed weights (first chunk already in flight / landed in the current buffer).
 // next_wp / next_pieces: first chunk of the gemm that follows (nullptr: none), chunk_pieces(its NBO, its NS).
 // global stores make(IC<kb>, ..) issues for one block: A for blocks kb < FROM, B for the rest
-template <int A, int B = A, int FROM = 1 << 30>
+template <int A, int B = A, int FROM = 1 << 30, int LA = 0, int LB = LA>
 struct Stores {
-  static constexpr int at(int kb) { return kb < FROM ? A : B; }
+  static constexpr int at(int kb) { return kb < FROM ? A : B; }    // global stores make(IC<kb>, ..) issues
+  static constexpr int ld(int kb) { return kb < FROM ? LA : LB; }  // global loads fetch(IC<kb>) issues
 };
+
+// out-blocks per operand-read group: a divisor of NBO, small enough that two groups of weight fragments (the one being
+// multiplied and the one in flight from LDS) fit the register budget next to 256 accumulator registers
+constexpr int gemm_group(const int nbo, const int ns) {
+  const int gmax = ns == 3 ? 2 : 4;
+  for (int g = gmax; g > 1; --g)
+    if (nbo % g == 0) return g;
+  return nbo <= 5 ? nbo : 1;
+}
+
+// element e (TP register index) of a block under construction -> its slot in the split operand
+template <int NS, int E>
+SDFHIP_D void split_put(SplitBlk<NS>& s, float r) {
+#pragma unroll
+  for (int q = 0; q < NS; ++q) {
+    const __bf16 h = (__bf16)r;
+    s.p[q][E >> 3][E & 7] = h;
+    if (q + 1 < NS) r -= (float)h;
+  }
+}
 
 template <int KB, int NBO, class ST, int NS, int MAXA, class Fetch, class Make, class NextFetch>
 SDFHIP_D void tp_gemm(f32x16 (&acc)[MAXA], Raw& carry, Fetch&& fetch, Make&& make, NextFetch&& next_fetch, WStream& ws,
@@ -128,52 +151,65 @@ SDFHIP_D void tp_gemm(f32x16 (&acc)[MAXA], Raw& carry, Fetch&& fetch, Make&& mak
   constexpr int NT = NS == 2 ? 3 : 6;
   constexpr int ta[6] = {1, NS == 2 ? 0 : 2, 0, 1, 0, 0};
   constexpr int tb[6] = {NS == 2 ? 0 : 1, NS == 2 ? 1 : 0, NS == 2 ? 0 : 2, 0, 1, 0};
-  constexpr int G = NBO <= 4 ? NBO : 4;  // out-blocks per operand-read group (bounds the live weight fragments)
+  constexpr int G = gemm_group(NBO, NS), NG = NBO / G;  // groups per k half
+  static_assert(NBO % G == 0, "operand groups must tile the out-blocks");
+  constexpr int NGRP = 2 * NG, MPG = NT * G, NM = NGRP * MPG;  // groups, MFMAs per group, MFMAs per step
   // r1: operands of the block made during the current step; r2: operands of the block after that (in flight)
   Raw r1 = carry, r2;
   if constexpr (KB > 1) r2 = fetch(IC<(KB > 1 ? 1 : 0)>{});
   SplitBlk<NS> blk;
-  {
-    f32x16 first;
-    static_for<0, 16>([&](auto ec) __attribute__((always_inline)) { first[decltype(ec)::value] = make(IC<0>{}, r1, ec); });
-    blk = split_block<NS>(first);
-  }
+  static_for<0, 16>([&](auto ec) __attribute__((always_inline)) { split_put<NS, decltype(ec)::value>(blk, make(IC<0>{}, r1, ec)); });
   static_for<0, KB>([&](auto kbc) __attribute__((always_inline)) {
     constexpr int kb = decltype(kbc)::value;
     constexpr bool more = kb + 1 < KB;
-    ws.template wait_sync<ST::at(kb)>();
+    {
+      // vector-memory operations issued after the DMA of chunk kb: the loads of fetch(kb + 1), then the stores of make(kb)
+      constexpr int newer = ST::at(kb) + (more ? ST::ld(more ? kb + 1 : 0) : 0);
+      ws.template wait_sync<(newer < 63 ? newer : 63)>();
+    }
     if constexpr (more) ws.issue(wp + (size_t)(kb + 1) * NBO * kChunkBlockFloats, chunk_pieces(NBO, NS));
     else if (next_wp != nullptr) ws.issue(next_wp, next_pieces);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);  // the producer's loads are counted as newer than the DMA: keep them behind it
     r1 = r2;
     if constexpr (kb + 2 < KB) r2 = fetch(IC<(kb + 2 < KB ? kb + 2 : 0)>{});
     else if constexpr (!more) carry = next_fetch();
-    __builtin_amdgcn_sched_barrier(0);  // DMA + loads stay at the head of the step
     const float* cur = ws.current();
+    // Software pipeline, pinned with scheduling fences (one wave per SIMD: nothing else hides LDS latency or VALU time):
+    //   the weight fragments of group g + 1 are read from LDS while group g multiplies, and the 16 elements of the NEXT
+    //   input block are produced one at a time between MFMAs, spread evenly over the step, so their VALU work and stores
+    //   run in the shadow of the matrix pipe (an MFMA occupies it for 8 passes after a 1-pass issue).
+    bf16x8 a[2][NS][G];
+    auto load_group = [&](auto gc) __attribute__((always_inline)) {
+      constexpr int gi = decltype(gc)::value, kk = gi / NG, g0 = (gi % NG) * G;
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int i = 0; i < G; ++i) a[gi & 1][q][i] = *reinterpret_cast<const bf16x8*>(cur + ((q * NBO + g0 + i) * 2 + kk) * 256);
+    };
+    load_group(IC<0>{});
     SplitBlk<NS> nxt;
-    if constexpr (more) {
-      f32x16 v;
-      static_for<0, 16>([&](auto ec) __attribute__((always_inline)) {
-        v[decltype(ec)::value] = make(IC<(more ? kb + 1 : 0)>{}, r1, ec);
+    static_for<0, NGRP>([&](auto gc) __attribute__((always_inline)) {
+      constexpr int gi = decltype(gc)::value, kk = gi / NG, g0 = (gi % NG) * G;
+      if constexpr (gi + 1 < NGRP) load_group(IC<(gi + 1 < NGRP ? gi + 1 : 0)>{});
+      __builtin_amdgcn_sched_barrier(0);  // DMA, global loads and the LDS reads of the next group stay ahead of this group's MFMAs
+      static_for<0, MPG>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int mi = decltype(mc)::value, t = mi / G, i = mi % G, m = gi * MPG + mi;
+        acc[g0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[gi & 1][ta[t]][i], blk.p[tb[t]][kk], acc[g0 + i], 0, 0, 0);
+        if constexpr (more) {
+          // the first quarter of the step is left to the loads this block's operands arrive by; element e is then due
+          // after MFMA number S0 + floor(e W / 16), W = NM - S0: elements [ceil(16 (m - S0) / W), ceil(16 (m + 1 - S0) / W))
+          constexpr int S0 = NM / 4, W = NM - S0, mm = m - S0;
+          constexpr int lo = mm < 0 ? 0 : (16 * mm + W - 1) / W, hi_ = mm < 0 ? 0 : (16 * (mm + 1) + W - 1) / W, hi = hi_ < 16 ? hi_ : 16;
+          if constexpr (lo < hi) {
+            static_for<lo, hi>([&](auto ec) __attribute__((always_inline)) {
+              split_put<NS, decltype(ec)::value>(nxt, make(IC<(more ? kb + 1 : 0)>{}, r1, ec));
+            });
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
       });
-      nxt = split_block<NS>(v);
-    }
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int g0 = 0; g0 < NBO; g0 += G) {
-        bf16x8 a[NS][G];
-#pragma unroll
-        for (int q = 0; q < NS; ++q)
-#pragma unroll
-          for (int i = 0; i < G; ++i)
-            if (g0 + i < NBO) a[q][i] = *reinterpret_cast<const bf16x8*>(cur + ((q * NBO + g0 + i) * 2 + kk) * 256);
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int i = 0; i < G; ++i)
-            if (g0 + i < NBO)
-              acc[g0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ta[t]][i], blk.p[tb[t]][kk], acc[g0 + i], 0, 0, 0);
-      }
+    });
     ws.flip();
     if constexpr (more) blk = nxt;
   });

@@ -597,12 +597,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-// out[i] (+)= sum_k partial[k][i]
-__global__ void colsum_kernel(const float* __restrict__ partial, const int n_rows, const int n_cols, const int row_stride,
-                              float* __restrict__ out, const int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_cols) return;
+// Column sums of the per-block partials: out1[i] = sum_k partial[k][i] (i < n1), out2[i - n1] = sum_k partial[k][i] (i >= n1).
+// Block = 32 columns x 8 row lanes (coalesced 128-byte row segments), rows strided by 8, LDS tree over the row lanes.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ partial, const int n_rows, const int n_cols, const int row_stride,
+                                                     float* __restrict__ out1, const int n1, float* __restrict__ out2) {
+  __shared__ float red[8][33];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), r0 = threadIdx.x >> 5;
   float s = 0.0f;
-  for (int k = 0; k < n_rows; ++k) s += partial[(size_t)k * row_stride + i];
-  out[i] = (accumulate ? out[i] : 0.0f) + s;
+  if (c < n_cols)
+    for (int k = r0; k < n_rows; k += 8) s += partial[(size_t)k * row_stride + c];
+  red[r0][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (r0 == 0 && c < n_cols) {
+#pragma unroll
+    for (int r = 1; r < 8; ++r) s += red[r][threadIdx.x & 31];
+    if (c < n1) out1[c] = s;
+    else out2[c - n1] = s;
+  }
 }

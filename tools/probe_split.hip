@@ -32,7 +32,7 @@ __device__ __forceinline__ Split<NS> split_block(const f32x16& v) {
   return s;
 }
 
-template <int NS, int ACT, int NBUF>
+template <int NS, int ACT, int NBUF, bool LOOPED>
 __global__ __launch_bounds__(256, 1) void split_kernel(const float* __restrict__ in_tp, const __bf16* __restrict__ wp,
                                                        float* __restrict__ out_tp, unsigned long long* __restrict__ clk) {
   extern __shared__ __attribute__((aligned(16))) __bf16 ldsb[];
@@ -60,10 +60,7 @@ __global__ __launch_bounds__(256, 1) void split_kernel(const float* __restrict__
       for (int r = 0; r < 16; ++r) accA[b][r] = p[(b * 16 + r) * 64];
   }
   int chunk = 0;
-  static_for<0, L>([&](auto lc) __attribute__((always_inline)) {
-    constexpr int l = decltype(lc)::value;
-    auto& in = (l % 2) == 0 ? accA : accB;
-    auto& out = (l % 2) == 0 ? accB : accA;
+  auto layer = [&](f32x16 (&in)[NB], f32x16 (&out)[NB]) __attribute__((always_inline)) {
 #pragma unroll
     for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -88,7 +85,6 @@ __global__ __launch_bounds__(256, 1) void split_kernel(const float* __restrict__
       Split<NS> nxt;
       if constexpr (kb + 1 < NB) nxt = make(kb + 1, in[kb + 1 < NB ? kb + 1 : 0]);
       const __bf16* base = ldsb + cur * CH + lane * 8;
-      // terms (a part, b part), small ones first
       constexpr int NT = NS == 2 ? 3 : 6;
       constexpr int ta[6] = {NS == 2 ? 1 : 1, NS == 2 ? 0 : 2, NS == 2 ? 0 : 0, 1, 0, 0};
       constexpr int tb[6] = {NS == 2 ? 0 : 1, NS == 2 ? 1 : 0, NS == 2 ? 0 : 2, 0, 1, 0};
@@ -108,7 +104,21 @@ __global__ __launch_bounds__(256, 1) void split_kernel(const float* __restrict__
       cur = (cur + 1) % NBUF;
       if constexpr (kb + 1 < NB) blk = nxt;
     });
-  });
+  };
+  if constexpr (LOOPED) {
+    static_assert(NBUF == 2 && L % 2 == 0, "looped variant: two chunk buffers, layer pairs");
+#pragma unroll 1
+    for (int lp = 0; lp < L / 2; ++lp) {
+      layer(accA, accB);
+      layer(accB, accA);
+    }
+  } else {
+    static_for<0, L>([&](auto lc) __attribute__((always_inline)) {
+      constexpr int l = decltype(lc)::value;
+      if constexpr ((l % 2) == 0) layer(accA, accB);
+      else layer(accB, accA);
+    });
+  }
   auto& fin = (L % 2) == 0 ? accA : accB;
   {
     float* p = out_tp + (size_t)tile * NB * 1024 + lane;
@@ -126,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void split_kernel(const float* __restrict__
 static float act_ref(double z, int act) { return act == 0 ? (z > 0 ? z : 0) : (z > 20 ? z : log1p(exp(z))); }
 static __bf16 to_bf16(float x) { return (__bf16)x; }
 
-template <int NS, int ACT, int NBUF>
+template <int NS, int ACT, int NBUF, bool LOOPED = false>
 static void run(const char* name, int64_t P, const float* d_in, float* d_out, unsigned long long* d_clk, const std::vector<float>& W,
                 const std::vector<float>& X) {
   constexpr int CH = NS * NB * 2 * 64 * 8;
@@ -150,14 +160,14 @@ static void run(const char* name, int64_t P, const float* d_in, float* d_out, un
   hipMemcpy(d_wp, Wp.data(), Wp.size() * 2, hipMemcpyHostToDevice);
   const unsigned grid = (unsigned)(P / 128);
   const size_t lds = (size_t)NBUF * CH * 2;
-  hipFuncSetAttribute((const void*)split_kernel<NS, ACT, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute((const void*)split_kernel<NS, ACT, NBUF, LOOPED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  for (int i = 0; i < 2; ++i) split_kernel<NS, ACT, NBUF><<<grid, 256, lds>>>(d_in, d_wp, d_out, d_clk);
+  for (int i = 0; i < 2; ++i) split_kernel<NS, ACT, NBUF, LOOPED><<<grid, 256, lds>>>(d_in, d_wp, d_out, d_clk);
   hipEventRecord(e0);
   const int reps = 5;
-  for (int i = 0; i < reps; ++i) split_kernel<NS, ACT, NBUF><<<grid, 256, lds>>>(d_in, d_wp, d_out, d_clk);
+  for (int i = 0; i < reps; ++i) split_kernel<NS, ACT, NBUF, LOOPED><<<grid, 256, lds>>>(d_in, d_wp, d_out, d_clk);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
@@ -205,12 +215,11 @@ int main() {
   hipMalloc(&d_out, X.size() * 4);
   hipMalloc(&d_clk, 2048 * 8);
   hipMemcpy(d_in, X.data(), X.size() * 4, hipMemcpyHostToDevice);
-  run<2, 0, 2>("3-term relu 2buf", P, d_in, d_out, d_clk, W, X);
-  run<2, 0, 3>("3-term relu 3buf", P, d_in, d_out, d_clk, W, X);
-  run<2, 0, 4>("3-term relu 4buf", P, d_in, d_out, d_clk, W, X);
-  run<2, 1, 4>("3-term softplus 4buf", P, d_in, d_out, d_clk, W, X);
-  run<3, 0, 2>("6-term relu 2buf", P, d_in, d_out, d_clk, W, X);
-  run<3, 0, 3>("6-term relu 3buf", P, d_in, d_out, d_clk, W, X);
-  run<3, 1, 3>("6-term softplus 3buf", P, d_in, d_out, d_clk, W, X);
+  run<2, 0, 2>("3-term relu unrolled", P, d_in, d_out, d_clk, W, X);
+  run<2, 0, 2, true>("3-term relu looped", P, d_in, d_out, d_clk, W, X);
+  run<2, 1, 2>("3-term softplus unrolled", P, d_in, d_out, d_clk, W, X);
+  run<2, 1, 2, true>("3-term softplus looped", P, d_in, d_out, d_clk, W, X);
+  run<3, 1, 2>("6-term softplus unrolled", P, d_in, d_out, d_clk, W, X);
+  run<3, 1, 2, true>("6-term softplus looped", P, d_in, d_out, d_clk, W, X);
   return 0;
 }
