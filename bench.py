@@ -215,6 +215,19 @@ def main():
     prof = _lib.profile_collect()
     _lib.profile_enable(False)
     assert math.isfinite(float(loss.detach())), "training diverged"
+    # forward-only leg (eval-mode render, reported separately; outside the timed training region)
+    model.eval()
+    o, d, norm, cam = draw_rays(centers, rot, N_RAYS, gen)
+    rb_eval = RayBundle(origins=o, directions=d, directions_norm=norm, camera_indices=cam[:, None])
+    with torch.no_grad():
+        model(rb_eval)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            model(rb_eval)
+        torch.cuda.synchronize()
+    fwd_ms = (time.perf_counter() - t1) / 5 * 1e3
+    model.train()
     t = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -264,6 +277,8 @@ def main():
                        "rays_per_gpu": N_RAYS, "samples_per_ray": N_SAMPLES,
                        "parallelism": f"dp{world} (flat-gradient RCCL all-reduce)" if world > 1 else "single GPU"},
             "roofline": roof,
+            "forward_only": {"value": round(N_RAYS * N_SAMPLES / (fwd_ms * 1e-3), 1), "unit": "ray-samples/s per GPU (eval-mode render, no grad)",
+                             "ms_per_batch": round(fwd_ms, 3)},
             "model_tflops": round((6 * g + 3 * c) * P / (ms * 1e-3) / 1e12, 2),
             "mfma_kernels_ms_per_step": round(mfma_ms, 3),
             "kernels": kernels,
