@@ -361,6 +361,14 @@ class SDFField(nn.Module):
         sdf, _ = self._run_inference(_lib.MODE_SDF, o, d, st, n, s, False)
         return sdf.view(n, s, 1)
 
+    def get_density(self, ray_samples):
+        """sdf_field.py:469-475: Laplace density and geometry feature at the frustum START positions (no contraction, no grad)."""
+        o, d, st, _ = unpack_ray_samples(ray_samples)
+        n, s = st.shape
+        pos = (o[:, None, :] + d[:, None, :] * st[..., None]).reshape(-1, 3)
+        h = self.forward_geonetwork(pos).view(n, s, -1)
+        return self.laplace_density(h[..., :1]), h[..., 1:]
+
     def get_alpha(self, ray_samples, sdf=None, gradients=None):
         """sdf_field.py:476-525 (elementwise; the fused model path uses renderers.neus_render instead)."""
         if sdf is None or gradients is None:

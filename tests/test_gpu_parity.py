@@ -578,6 +578,10 @@ def test_field_small_get_sdf_and_geonetwork(device):
     out = model.field.forward_geonetwork(pos.to(device))
     assert_close("forward_geonetwork sdf", out[:, 0], h[:, 0], rtol=0, atol=1e-5)
     assert_close("forward_geonetwork feat", out[:, 1:], h[:, 1:], rtol=1e-4, atol=1e-5)
+    dens, feat = model.field.get_density(rs)  # sdf_field.py:469-475
+    beta = g["param"]["laplace_density.beta"].abs() + g["param"]["laplace_density.beta_min"]
+    assert_close("get_density", dens[..., 0], O.laplace_density(h[:, 0], beta).view(n, s), rtol=1e-4, atol=1e-4)
+    assert_close("get_density feature", feat.reshape(n * s, -1), h[:, 1:], rtol=1e-4, atol=1e-5)
 
 
 def test_field_appearance_embedding(device):
@@ -774,4 +778,37 @@ def test_config1_volsdf_pure_mlp_full_size(device):
     sum(losses.values()).backward()
     for k, prm in model.named_parameters():
         if prm.requires_grad and "embedding" not in k and "encoding" not in k and "deviation" not in k:
+            assert prm.grad is not None and torch.isfinite(prm.grad).all(), k
+
+
+def test_config4_inside_out_mono_priors(device):
+    """BASELINE config 4 shape: NeuS-facto in an inside-out (room) scene, `inside_outside=True` (sign-flipped geometric init,
+    sdf_field.py:294-299), cameras INSIDE the box, monocular depth + normal priors (README.md:74: mono-depth-loss-mult 0.1,
+    mono-normal-loss-mult 0.05).  Same kernels as config 2; size-independent properties of the step."""
+    cfg = O.ModelCfg(field=O.FieldCfg(bias=0.8, inside_outside=True, beta_init=0.3))
+    p = O.init_field_params(cfg.field, seed=0)
+    p.update(O.init_proposal_params(cfg.proposals))
+    model = product_model_from_params(p, cfg, device).train()
+    model.config.mono_depth_loss_mult, model.config.mono_normal_loss_mult = 0.1, 0.05
+    n = 1024  # N = 0 mod 32: the depth loss reshapes to (1, 32, -1) (base_surface_model.py:427-437)
+    gen = torch.Generator().manual_seed(4)
+    o = (torch.rand(n, 3, generator=gen) - 0.5) * 0.6  # camera centres inside the room
+    d = F.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+    cam = torch.randint(0, 49, (n,), generator=gen)
+    out = model(_bundle(o, d, cam, 0.05, 4.0, device))
+    w = out["weights"][..., 0]
+    assert (w >= 0).all() and (w.sum(1) <= 1 + 1e-4).all()
+    # inside-out init: sdf = bias - |x| is positive at the cameras, every ray leaves the sphere of radius `bias` -> it hits
+    assert (out["accumulation"][:, 0] > 0.9).float().mean() > 0.9
+    depth = out["depth"][:, 0]
+    assert torch.isfinite(depth).all() and (depth > 0.05).all() and (depth < 1.5).all()
+    batch = {"image": torch.rand(n, 3, generator=gen), "depth": torch.rand(n, generator=gen),
+             "normal": F.normalize(torch.randn(n, 3, generator=gen), dim=-1)}
+    losses = model.get_loss_dict(out, batch)
+    assert {"rgb_loss", "eikonal_loss", "depth_loss", "normal_loss", "interlevel_loss"} <= set(losses), sorted(losses)
+    for k, v in losses.items():
+        assert torch.isfinite(v), k
+    sum(losses.values()).backward()
+    for k, prm in model.named_parameters():
+        if prm.requires_grad and "embedding" not in k and "laplace_density" not in k:
             assert prm.grad is not None and torch.isfinite(prm.grad).all(), k
