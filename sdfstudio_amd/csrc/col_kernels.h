@@ -59,12 +59,10 @@ __global__ __launch_bounds__(256, 1) void col_fwd_kernel(const ColFwdArgs a) {
   Raw carry;
   auto in_fetch = [&](auto kbc) __attribute__((always_inline)) {
     constexpr int kb = decltype(kbc)::value;
-    Raw raw;
-    if constexpr (kb < D::NBF) raw.a = tp_load_blk(a.feat_tp, tile, D::NBF, kb, lane);
-    else raw.a = tp_load_blk(a.csmall_tp, tile, D::NBS, kb - D::NBF, lane);
-    return raw;
+    if constexpr (kb < D::NBF) return BlkSrc<1>{{tp_block_ptr(a.feat_tp, tile, D::NBF, kb)}};
+    else return BlkSrc<1>{{tp_block_ptr(a.csmall_tp, tile, D::NBS, kb - D::NBF)}};
   };
-  carry = in_fetch(IC<0>{});
+  carry = load_src(in_fetch(IC<0>{}), lane);
   static_for<0, D::NLC>([&](auto lc) __attribute__((always_inline)) {
     constexpr int l = decltype(lc)::value;
     constexpr int KB = D::kb(l);
@@ -74,7 +72,7 @@ __global__ __launch_bounds__(256, 1) void col_fwd_kernel(const ColFwdArgs a) {
     for (int b = 0; b < D::NBC; ++b) out[b] = tp_rowvec_blk(cvec + l * W, b, hf);
     auto fetch = [&](auto kbc) __attribute__((always_inline)) {
       if constexpr (l == 0) return in_fetch(kbc);
-      else return Raw{};
+      else return BlkSrc<0>{};
     };
     auto make = [&](auto kbc, const Raw& raw, auto ec) __attribute__((always_inline)) {
       constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
@@ -86,8 +84,8 @@ __global__ __launch_bounds__(256, 1) void col_fwd_kernel(const ColFwdArgs a) {
         return h;
       }
     };
-    tp_gemm<KB, D::NBC, Stores<((l > 0 && SAVE) ? 16 : 0), ((l > 0 && SAVE) ? 16 : 0), 1 << 30, (l == 0 ? 16 : 0)>, NS>(out, carry, fetch, make, NoFetch{}, ws, a.p.wp[l],
-                                                                l + 1 < D::NLC ? a.p.wp[l + 1 < D::NLC ? l + 1 : l] : nullptr, chunk_pieces(D::NBC, NS));
+    tp_gemm<KB, D::NBC, Stores<((l > 0 && SAVE) ? 16 : 0)>, NS, (l + 1 < D::NLC ? chunk_pieces(D::NBC, NS) : 0)>(
+        out, carry, fetch, make, NoFetch{}, ws, a.p.wp[l], l + 1 < D::NLC ? a.p.wp[l + 1 < D::NLC ? l + 1 : l] : nullptr);
   });
 
   // last hidden activation + the 3-row output layer
@@ -174,11 +172,9 @@ __global__ __launch_bounds__(256, 1) void col_bwd_kernel(const ColBwdArgs a) {
   Raw carry;
   auto h_fetch = [&](auto lc, auto bc) __attribute__((always_inline)) {
     constexpr int l = decltype(lc)::value, b = decltype(bc)::value;
-    Raw raw;
-    raw.a = tp_load_blk(a.h_tp[l], tile, D::NBC, b, lane);
-    return raw;
+    return BlkSrc<1>{{tp_block_ptr(a.h_tp[l], tile, D::NBC, b)}};
   };
-  carry = h_fetch(IC<D::NLC - 1>{}, IC<0>{});
+  carry = load_src(h_fetch(IC<D::NLC - 1>{}, IC<0>{}), lane);
   static_for<0, D::NLC>([&](auto sc) __attribute__((always_inline)) {
     constexpr int step = decltype(sc)::value;
     constexpr int l = D::NLC - 1 - step;
@@ -197,10 +193,10 @@ __global__ __launch_bounds__(256, 1) void col_bwd_kernel(const ColBwdArgs a) {
     };
     auto next_fetch = [&]() __attribute__((always_inline)) {
       if constexpr (l > 0) return h_fetch(IC<(l > 0 ? l - 1 : 0)>{}, IC<0>{});
-      else return Raw{};
+      else return BlkSrc<0>{};
     };
-    tp_gemm<D::NBC, KB, Stores<16, 16, 1 << 30, 16>, NS>(un, carry, fetch, make, next_fetch, ws, a.p.wpT[l], l > 0 ? a.p.wpT[l > 0 ? l - 1 : 0] : nullptr,
-                                        l > 0 ? chunk_pieces(D::kb(l > 0 ? l - 1 : 0), NS) : 0);
+    tp_gemm<D::NBC, KB, Stores<16>, NS, (l > 0 ? chunk_pieces(D::kb(l > 0 ? l - 1 : 0), NS) : 0)>(
+        un, carry, fetch, make, next_fetch, ws, a.p.wpT[l], l > 0 ? a.p.wpT[l > 0 ? l - 1 : 0] : nullptr);
     if constexpr (l == 0) {
 #pragma unroll
       for (int b = 0; b < D::NBF; ++b) tp_store_blk(un[b], a.featbar_tp, tile, D::NBF, b, lane);

@@ -94,21 +94,18 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
   // HBM operands of input block kb of forward layer l (only in0 blocks come from memory)
   auto fwd_fetch = [&](auto lc, auto kbc) __attribute__((always_inline)) {
     constexpr int l = decltype(lc)::value, kb = decltype(kbc)::value;
-    Raw raw;
-    if constexpr (l == 0) raw.a = tp_load_blk(a.in0_tp, tile, D::NB0, kb, lane);
-    else if constexpr (l == D::SKIP && kb >= D::NB3) raw.a = tp_load_blk(a.in0_tp, tile, D::NB0, kb - D::NB3, lane);
-    return raw;
+    if constexpr (l == 0) return BlkSrc<1>{{tp_block_ptr(a.in0_tp, tile, D::NB0, kb)}};
+    else if constexpr (l == D::SKIP && kb >= D::NB3) return BlkSrc<1>{{tp_block_ptr(a.in0_tp, tile, D::NB0, kb - D::NB3)}};
+    else return BlkSrc<0>{};
   };
   // HBM operands of block b of the chain step through layer l
   auto chain_fetch = [&](auto lc, auto bc) __attribute__((always_inline)) {
     constexpr int l = decltype(lc)::value, b = decltype(bc)::value;
-    Raw raw;
-    raw.a = tp_load_blk(a.z_tp[l], tile, D::nbo(l), b, lane);
-    return raw;
+    return BlkSrc<1>{{tp_block_ptr(a.z_tp[l], tile, D::nbo(l), b)}};
   };
 
   // ---- forward layers 0 .. NL-1: out_l = b_l + W_l u_l
-  carry = fwd_fetch(IC<0>{}, IC<0>{});
+  carry = load_src(fwd_fetch(IC<0>{}, IC<0>{}), lane);
   static_for<0, D::NL>([&](auto lc) __attribute__((always_inline)) {
     constexpr int l = decltype(lc)::value;
     constexpr int KB = D::kb(l), NBO = D::nbo(l);
@@ -129,15 +126,14 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
     };
     constexpr bool last = l + 1 == D::NL;
     const float* next = last ? (FEAT ? a.p.wp[D::NL] : (GRAD ? a.p.wpT[D::NL - 1] : nullptr)) : a.p.wp[l + 1];
-    constexpr int next_pieces = last ? (FEAT ? chunk_pieces(D::NBF, NSF) : chunk_pieces(D::kb(D::NL - 1), NSC)) : chunk_pieces(D::nbo(l + 1), NSF);
+    constexpr int next_pieces = last ? (FEAT ? chunk_pieces(D::NBF, NSF) : (GRAD ? chunk_pieces(D::kb(D::NL - 1), NSC) : 0)) : chunk_pieces(D::nbo(l + 1), NSF);
     auto next_fetch = [&]() __attribute__((always_inline)) {
       if constexpr (!last) return fwd_fetch(IC<(last ? l : l + 1)>{}, IC<0>{});
-      else return Raw{};
+      else return BlkSrc<0>{};
     };
     constexpr int ZS = (SAVE || GRAD) ? 16 : 0;  // z stores per produced block
-    using ST = Stores<(l == 0 ? 0 : ZS), (l == 0 ? 0 : (l == D::SKIP ? 0 : ZS)), (l == D::SKIP ? D::NB3 : (1 << 30)),
-                      (l == 0 ? 16 : 0), (l == 0 || l == D::SKIP ? 16 : 0)>;
-    tp_gemm<KB, NBO, ST, NSF>(out, carry, fetch, make, next_fetch, ws, a.p.wp[l], next, next_pieces);
+    using ST = Stores<(l == 0 ? 0 : ZS), (l == 0 ? 0 : (l == D::SKIP ? 0 : ZS)), (l == D::SKIP ? D::NB3 : (1 << 30))>;
+    tp_gemm<KB, NBO, ST, NSF, next_pieces>(out, carry, fetch, make, next_fetch, ws, a.p.wp[l], next);
   });
 
   // ---- output layer: the sdf row as a lane-local dot product riding in the producer, feature rows on the MFMA path
@@ -158,17 +154,17 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
       for (int b = 0; b < D::NBF; ++b) out[b] = tp_rowvec_blk(cvec + D::NL * W, b, hf);
       auto next_fetch = [&]() __attribute__((always_inline)) {
         if constexpr (GRAD) return chain_fetch(IC<D::NL - 1>{}, IC<0>{});
-        else return Raw{};
+        else return BlkSrc<0>{};
       };
-      tp_gemm<D::NBH, D::NBF, Stores<((SAVE || GRAD) ? 16 : 0)>, NSF>(out, carry, NoFetch{}, make, next_fetch, ws, a.p.wp[D::NL],
-                                                                       GRAD ? a.p.wpT[D::NL - 1] : nullptr, chunk_pieces(D::kb(D::NL - 1), NSC));
+      tp_gemm<D::NBH, D::NBF, Stores<((SAVE || GRAD) ? 16 : 0)>, NSF, (GRAD ? chunk_pieces(D::kb(D::NL - 1), NSC) : 0)>(
+          out, carry, NoFetch{}, make, next_fetch, ws, a.p.wp[D::NL], GRAD ? a.p.wpT[D::NL - 1] : nullptr);
 #pragma unroll
       for (int b = 0; b < D::NBF; ++b) tp_store_blk(out[b], a.feat_tp, tile, D::NBF, b, lane);
     } else {
       static_for<0, D::NBH>([&](auto kbc) __attribute__((always_inline)) {
         static_for<0, 16>([&](auto ec) __attribute__((always_inline)) { (void)make(kbc, carry, ec); });
       });
-      if constexpr (GRAD) carry = chain_fetch(IC<D::NL - 1>{}, IC<0>{});
+      if constexpr (GRAD) carry = load_src(chain_fetch(IC<D::NL - 1>{}, IC<0>{}), lane);
     }
     part += __shfl_xor(part, 32);
     if (hf == 0) a.sdf[tile * 32 + lane] = part + a.p.b_sdf[0];
@@ -195,10 +191,10 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
       };
       auto next_fetch = [&]() __attribute__((always_inline)) {
         if constexpr (l > 0) return chain_fetch(IC<(l > 0 ? l - 1 : 0)>{}, IC<0>{});
-        else return Raw{};
+        else return BlkSrc<0>{};
       };
-      tp_gemm<NBO, KB, Stores<(SAVE ? 16 : 0), (SAVE ? 16 : 0), 1 << 30, 16>, NSC>(qn, carry, fetch, make, next_fetch, ws, a.p.wpT[l], l > 0 ? a.p.wpT[l > 0 ? l - 1 : 0] : nullptr,
-                                                     l > 0 ? chunk_pieces(D::kb(l > 0 ? l - 1 : 0), NSC) : 0);
+      tp_gemm<NBO, KB, Stores<(SAVE ? 16 : 0)>, NSC, (l > 0 ? chunk_pieces(D::kb(l > 0 ? l - 1 : 0), NSC) : 0)>(
+          qn, carry, fetch, make, next_fetch, ws, a.p.wpT[l], l > 0 ? a.p.wpT[l > 0 ? l - 1 : 0] : nullptr);
       if constexpr (l == D::SKIP) {
         // the part of d sdf / d (layer input) that goes straight to in0: park it in e_tp, layer 0 adds to it
 #pragma unroll
@@ -248,16 +244,14 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
   // HBM operands of input block kb of tangent layer l: the seed blocks, or (z, r) of the layer below
   auto tan_fetch = [&](auto lc, auto kbc) __attribute__((always_inline)) {
     constexpr int l = decltype(lc)::value, kb = decltype(kbc)::value;
-    Raw raw;
     if constexpr (l == 0) {
-      raw.a = tp_load_blk(a.ebar_tp, tile, D::NB0, kb, lane);  // qb_0 == ebar (already in HBM)
+      return BlkSrc<1>{{tp_block_ptr(a.ebar_tp, tile, D::NB0, kb)}};  // qb_0 == ebar (already in HBM)
     } else if constexpr (l == D::SKIP && kb >= D::NB3) {
-      raw.a = tp_load_blk(a.ebar_tp, tile, D::NB0, kb - D::NB3, lane);
+      return BlkSrc<1>{{tp_block_ptr(a.ebar_tp, tile, D::NB0, kb - D::NB3)}};
     } else {
-      raw.a = tp_load_blk(a.z_tp[l > 0 ? l - 1 : 0], tile, D::nbo(l > 0 ? l - 1 : 0), kb, lane);
-      raw.b = tp_load_blk(a.r_tp[l > 0 ? l - 1 : 0], tile, D::nbo(l > 0 ? l - 1 : 0), kb, lane);
+      return BlkSrc<2>{{tp_block_ptr(a.z_tp[l > 0 ? l - 1 : 0], tile, D::nbo(l > 0 ? l - 1 : 0), kb),
+                        tp_block_ptr(a.r_tp[l > 0 ? l - 1 : 0], tile, D::nbo(l > 0 ? l - 1 : 0), kb)}};
     }
-    return raw;
   };
   // tangent epilogue of layer l on element e of block b:  qb_{l+1} = s'(z_l) v ;  zc_l = v r_l 100 (1 - s'(z_l))  (-> zb_tp[l])
   auto tangent_elem = [&](auto lc, auto bc, auto ec, const float v, const Raw& raw) __attribute__((always_inline)) {
@@ -268,14 +262,11 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
   };
   auto bwd_fetch = [&](auto lc, auto bc) __attribute__((always_inline)) {
     constexpr int l = decltype(lc)::value, b = decltype(bc)::value;
-    Raw raw;
-    raw.a = tp_load_blk(a.z_tp[l], tile, D::nbo(l), b, lane);
-    raw.b = tp_load_blk(a.zb_tp[l], tile, D::nbo(l), b, lane);
-    return raw;
+    return BlkSrc<2>{{tp_block_ptr(a.z_tp[l], tile, D::nbo(l), b), tp_block_ptr(a.zb_tp[l], tile, D::nbo(l), b)}};
   };
 
   // ---- tangent pass (second-order terms): v_l = W_l qb_l
-  carry = tan_fetch(IC<0>{}, IC<0>{});
+  carry = load_src(tan_fetch(IC<0>{}, IC<0>{}), lane);
   static_for<0, D::NL>([&](auto lc) __attribute__((always_inline)) {
     constexpr int l = decltype(lc)::value;
     constexpr int KB = D::kb(l), NBO = D::nbo(l);
@@ -300,21 +291,20 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
     constexpr bool last = l + 1 == D::NL;
     auto next_fetch = [&]() __attribute__((always_inline)) {
       if constexpr (!last) return tan_fetch(IC<(last ? l : l + 1)>{}, IC<0>{});
-      else return Raw{};
+      else return BlkSrc<0>{};
     };
     // stores per produced block: zc + qb (32) for blocks computed from the layer below, qb only (16) for the seed blocks of
     // the skip layer, none for layer 0
-    using ST = Stores<(l == 0 ? 0 : 32), (l == 0 ? 0 : (l == D::SKIP ? 16 : 32)), (l == D::SKIP ? D::NB3 : (1 << 30)),
-                      (l == 0 ? 16 : 32), (l == 0 || l == D::SKIP ? 16 : 32)>;
-    tp_gemm<KB, NBO, ST, NS>(out, carry, fetch, make, next_fetch, ws, a.p.wp[l], last ? a.p.wpT[D::NL] : a.p.wp[last ? l : l + 1],
-                             chunk_pieces(last ? D::NBH : D::nbo(last ? l : l + 1), NS));
+    using ST = Stores<(l == 0 ? 0 : 32), (l == 0 ? 0 : (l == D::SKIP ? 16 : 32)), (l == D::SKIP ? D::NB3 : (1 << 30))>;
+    tp_gemm<KB, NBO, ST, NS, chunk_pieces(last ? D::NBH : D::nbo(last ? l : l + 1), NS)>(
+        out, carry, fetch, make, next_fetch, ws, a.p.wp[l], last ? a.p.wpT[D::NL] : a.p.wp[last ? l : l + 1]);
   });
   {
     // epilogue of the last hidden layer: qb_NL (tangent reaching the sdf row; only the weight gradient needs it) and zc_{NL-1}
     auto& v = pick<(D::NL % 2) == 0>(accA, accB);
     static_for<0, D::NBH>([&](auto bc) __attribute__((always_inline)) {
       constexpr int b = decltype(bc)::value;
-      const Raw raw = tan_fetch(IC<D::NL>{}, bc);
+      const Raw raw = load_src(tan_fetch(IC<D::NL>{}, bc), lane);
       static_for<0, 16>([&](auto ec) __attribute__((always_inline)) {
         constexpr int e = decltype(ec)::value;
         *tp_elem(a.qb_tp[D::NL], tile, D::NBH, b, e, lane) = tangent_elem(IC<D::NL - 1>{}, bc, ec, v[b][e], raw);
@@ -333,15 +323,13 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
     }
     auto fetch = [&](auto bc) __attribute__((always_inline)) {
       constexpr int b = decltype(bc)::value;
-      Raw raw;
-      raw.a = tp_load_blk(a.featbar_tp, tile, D::NBF, b, lane);
-      return raw;
+      return BlkSrc<1>{{tp_block_ptr(a.featbar_tp, tile, D::NBF, b)}};
     };
     auto make = [&](auto, const Raw& raw, auto ec) __attribute__((always_inline)) { return raw.a[decltype(ec)::value]; };
     auto next_fetch = [&]() __attribute__((always_inline)) { return bwd_fetch(IC<D::NL - 1>{}, IC<0>{}); };
-    carry = fetch(IC<0>{});
-    tp_gemm<D::NBF, D::NBH, Stores<0, 0, 1 << 30, 16>, NS>(accA, carry, fetch, make, next_fetch, ws, a.p.wpT[D::NL], a.p.wpT[D::NL - 1],
-                                           chunk_pieces(D::kb(D::NL - 1), NS));
+    carry = load_src(fetch(IC<0>{}), lane);
+    tp_gemm<D::NBF, D::NBH, Stores<0>, NS, chunk_pieces(D::kb(D::NL - 1), NS)>(accA, carry, fetch, make, next_fetch, ws, a.p.wpT[D::NL],
+                                                                               a.p.wpT[D::NL - 1]);
   }
   static_for<0, D::NL>([&](auto sc) __attribute__((always_inline)) {
     constexpr int step = decltype(sc)::value;
@@ -361,10 +349,10 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
     };
     auto next_fetch = [&]() __attribute__((always_inline)) {
       if constexpr (l > 0) return bwd_fetch(IC<(l > 0 ? l - 1 : 0)>{}, IC<0>{});
-      else return Raw{};
+      else return BlkSrc<0>{};
     };
-    tp_gemm<NBO, KB, Stores<16, 16, 1 << 30, 32>, NS>(un, carry, fetch, make, next_fetch, ws, a.p.wpT[l], l > 0 ? a.p.wpT[l > 0 ? l - 1 : 0] : nullptr,
-                                                      l > 0 ? chunk_pieces(D::kb(l > 0 ? l - 1 : 0), NS) : 0);
+    tp_gemm<NBO, KB, Stores<16>, NS, (l > 0 ? chunk_pieces(D::kb(l > 0 ? l - 1 : 0), NS) : 0)>(
+        un, carry, fetch, make, next_fetch, ws, a.p.wpT[l], l > 0 ? a.p.wpT[l > 0 ? l - 1 : 0] : nullptr);
     if constexpr (l == D::SKIP) {
 #pragma unroll
       for (int b = 0; b < D::NB0; ++b) tp_store_blk(un[D::NB3 + b], a.in0bar_tp, tile, D::NB0, b, lane);

@@ -53,6 +53,13 @@ struct WStream {
                                        (__attribute__((address_space(3))) void*)(dst + piece * 256), 16, 0, 0);
     }
   }
+  // one DMA instruction of the chunk going into the buffer that is NOT current: piece 4 j + wave
+  SDFHIP_D void issue_piece(const float* __restrict__ gsrc, const int j) {
+    float* dst = lds + (cur ^ 1) * buf_floats;
+    const int piece = 4 * j + wave;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + piece * 256 + lane * 4),
+                                     (__attribute__((address_space(3))) void*)(dst + piece * 256), 16, 0, 0);
+  }
   // The weight chunk about to be consumed has landed in LDS for every wave, and every wave is done reading the other
   // buffer.  NEWER = number of vector-memory operations this wave issued AFTER the chunk's DMA (the producer's stores):
   // vmcnt retires in issue order, so waiting for "at most NEWER outstanding" covers the DMA without draining those stores.
@@ -91,35 +98,55 @@ SDFHIP_D SplitBlk<NS> split_block(const f32x16& v) {
   return s;
 }
 
-// What a producer fetched from HBM for one input block (up to two TP blocks, e.g. z_l and zc_l); unused members cost nothing.
+// What a producer reads from HBM for one input block: up to two TP blocks (e.g. z_l and zc_l); unused members cost nothing.
 struct Raw {
   f32x16 a, b;
 };
-struct NoFetch {  // producer without an HBM fetch
+typedef __attribute__((address_space(1))) float gfloat;
+typedef __attribute__((address_space(1))) const float gcfloat;
+// Where those blocks live: N wave-uniform pointers to the first element of the wave's TP block (tp_block_ptr).  The fused
+// kernels hand these to tp_gemm, which spreads the 16 N element loads over the MFMAs of a step.
+template <int N>
+struct BlkSrc {
+  static constexpr int n = N;
+  const gfloat* p[N > 0 ? N : 1];
+};
+struct NoFetch {  // producer without HBM operands
   template <class... K>
-  SDFHIP_D Raw operator()(K...) const {
-    return Raw{};
+  SDFHIP_D BlkSrc<0> operator()(K...) const {
+    return BlkSrc<0>{};
   }
 };
+template <int E, int N>
+SDFHIP_D void load_src_elem(const BlkSrc<N>& src, Raw& r, const int lane) {
+  if constexpr (N >= 1) r.a[E] = src.p[0][(unsigned)lane + (unsigned)E * 64u];
+  if constexpr (N >= 2) r.b[E] = src.p[1][(unsigned)lane + (unsigned)E * 64u];
+}
+template <int N>
+SDFHIP_D Raw load_src(const BlkSrc<N>& src, const int lane) {
+  Raw r;
+  static_for<0, 16>([&](auto ec) __attribute__((always_inline)) { load_src_elem<decltype(ec)::value>(src, r, lane); });
+  return r;
+}
 
 // acc[0..NBO) += W * B with B[kb] produced just in time.  The producer of a block is split so that neither HBM latency nor
 // its VALU work ever sits in front of the matrix pipe (one wave per SIMD: nothing else would cover it):
-//   fetch(IC<kb>) -> Raw               global loads block kb needs; issued at the head of step kb - 2, pinned there
+//   fetch(IC<kb>) -> BlkSrc<N>         where the HBM operands of block kb live; their 16 N element loads are issued during
+//                                      step kb - 2, one or two per MFMA gap
 //   make(IC<kb>, Raw, IC<e>) -> float  element e of the block (VALU + the element's stores); block kb + 1 is produced
 //                                      during step kb, the compiler interleaves it with the step's MFMAs
-//   next_fetch() -> Raw                fetch of block 0 of the FOLLOWING gemm, issued at the head of this gemm's last step;
-//                                      it travels in `carry`, which on entry holds this gemm's own block-0 operands
-//   ST::at(kb), ST::ld(kb)             number of global stores make(IC<kb>, ..) / global loads fetch(IC<kb>) issue: both are
-//                                      issued AFTER the DMA of chunk kb, so the wait for that chunk may leave them in flight
-//                                      (WStream::wait_sync); under-counting is safe, over-counting is not
+//   next_fetch() -> BlkSrc<N>          operands of block 0 of the FOLLOWING gemm, loaded during this gemm's last step;
+//                                      they travel in `carry`, which on entry holds this gemm's own block-0 operands
+//   ST::at(kb)                         number of global stores make(IC<kb>, ..) issues.  Those stores and the 16 N loads of
+//                                      fetch(kb + 1) are issued AFTER the DMA of chunk kb, so the wait for that chunk may
+//                                      leave them in flight (WStream::wait_sync)
 //   NS                                 bf16 parts per operand (2: 3-term products, 3: 6-term, fp32-class)
 // wp: this gemm's packed weights (first chunk already in flight / landed in the current buffer).
-// next_wp / next_pieces: first chunk of the gemm that follows (nullptr: none), chunk_pieces(its NBO, its NS).
+// next_wp / NEXTP: first chunk of the gemm that follows, chunk_pieces(its NBO, its NS) (0: none).
 // global stores make(IC<kb>, ..) issues for one block: A for blocks kb < FROM, B for the rest
-template <int A, int B = A, int FROM = 1 << 30, int LA = 0, int LB = LA>
+template <int A, int B = A, int FROM = 1 << 30>
 struct Stores {
-  static constexpr int at(int kb) { return kb < FROM ? A : B; }    // global stores make(IC<kb>, ..) issues
-  static constexpr int ld(int kb) { return kb < FROM ? LA : LB; }  // global loads fetch(IC<kb>) issues
+  static constexpr int at(int kb) { return kb < FROM ? A : B; }  // global stores make(IC<kb>, ..) issues
 };
 
 // out-blocks per operand-read group: a divisor of NBO, small enough that two groups of weight fragments (the one being
@@ -142,11 +169,12 @@ SDFHIP_D void split_put(SplitBlk<NS>& s, float r) {
   }
 }
 
-template <int KB, int NBO, class ST, int NS, int MAXA, class Fetch, class Make, class NextFetch>
+template <int KB, int NBO, class ST, int NS, int NEXTP, int MAXA, class Fetch, class Make, class NextFetch>
 SDFHIP_D void tp_gemm(f32x16 (&acc)[MAXA], Raw& carry, Fetch&& fetch, Make&& make, NextFetch&& next_fetch, WStream& ws,
-                      const float* __restrict__ wp, const float* __restrict__ next_wp, const int next_pieces) {
+                      const float* __restrict__ wp, const float* __restrict__ next_wp) {
   static_assert(NBO <= MAXA, "accumulator tile too small");
   static_assert(NS == 2 || NS == 3, "2 or 3 bf16 parts");
+  static_assert(NEXTP % 4 == 0, "whole DMA rounds");
   // (weight part, activation part) of every product term, smallest magnitude first
   constexpr int NT = NS == 2 ? 3 : 6;
   constexpr int ta[6] = {1, NS == 2 ? 0 : 2, 0, 1, 0, 0};
@@ -154,9 +182,10 @@ SDFHIP_D void tp_gemm(f32x16 (&acc)[MAXA], Raw& carry, Fetch&& fetch, Make&& mak
   constexpr int G = gemm_group(NBO, NS), NG = NBO / G;  // groups per k half
   static_assert(NBO % G == 0, "operand groups must tile the out-blocks");
   constexpr int NGRP = 2 * NG, MPG = NT * G, NM = NGRP * MPG;  // groups, MFMAs per group, MFMAs per step
+  const int lane = ws.lane;
   // r1: operands of the block made during the current step; r2: operands of the block after that (in flight)
   Raw r1 = carry, r2;
-  if constexpr (KB > 1) r2 = fetch(IC<(KB > 1 ? 1 : 0)>{});
+  if constexpr (KB > 1) r2 = load_src(fetch(IC<(KB > 1 ? 1 : 0)>{}), lane);
   SplitBlk<NS> blk;
   static_for<0, 16>([&](auto ec) __attribute__((always_inline)) { split_put<NS, decltype(ec)::value>(blk, make(IC<0>{}, r1, ec)); });
   static_for<0, KB>([&](auto kbc) __attribute__((always_inline)) {
@@ -164,21 +193,28 @@ SDFHIP_D void tp_gemm(f32x16 (&acc)[MAXA], Raw& carry, Fetch&& fetch, Make&& mak
     constexpr bool more = kb + 1 < KB;
     {
       // vector-memory operations issued after the DMA of chunk kb: the loads of fetch(kb + 1), then the stores of make(kb)
-      constexpr int newer = ST::at(kb) + (more ? ST::ld(more ? kb + 1 : 0) : 0);
+      constexpr int newer = ST::at(kb) + (more ? 16 * decltype(fetch(IC<(more ? kb + 1 : 0)>{}))::n : 0);
       ws.template wait_sync<(newer < 63 ? newer : 63)>();
     }
-    if constexpr (more) ws.issue(wp + (size_t)(kb + 1) * NBO * kChunkBlockFloats, chunk_pieces(NBO, NS));
-    else if (next_wp != nullptr) ws.issue(next_wp, next_pieces);
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);  // the producer's loads are counted as newer than the DMA: keep them behind it
     r1 = r2;
-    if constexpr (kb + 2 < KB) r2 = fetch(IC<(kb + 2 < KB ? kb + 2 : 0)>{});
-    else if constexpr (!more) carry = next_fetch();
+    // This step's vector-memory work, in issue order: the DMA pieces of the next weight chunk, then the element loads of
+    // the block after next (the last step: of block 0 of the next gemm), then - from MFMA S0 on - the stores of the block
+    // being produced.  Everything is spread over the MFMA gaps: an LDS-DMA piece or a global load costs the wave tens of
+    // issue cycles, and issued in one burst at the head of the step they would leave the matrix pipe idle.
+    const auto src = [&]() __attribute__((always_inline)) {
+      if constexpr (kb + 2 < KB) return fetch(IC<(kb + 2 < KB ? kb + 2 : 0)>{});
+      else if constexpr (!more) return next_fetch();
+      else return BlkSrc<0>{};
+    }();
+    constexpr int NSRC = std::remove_cv_t<std::remove_reference_t<decltype(src)>>::n;
+    constexpr int ND = (more ? chunk_pieces(NBO, NS) : NEXTP) / 4;
+    const float* dsrc = more ? wp + (size_t)(kb + 1) * NBO * kChunkBlockFloats : next_wp;
+    constexpr int NOPS = ND + (NSRC > 0 ? 16 : 0);
+    constexpr int P1 = NM / 2 > 0 ? NM / 2 : 1;
+    constexpr int PER = NOPS == 0 ? 1 : (NOPS + P1 - 1) / P1;          // memory operations per MFMA gap
+    constexpr int S0 = NOPS == 0 ? NM / 4 : (NOPS + PER - 1) / PER;     // first gap that produces an element
+    constexpr int W = NM - S0 > 0 ? NM - S0 : 1;
     const float* cur = ws.current();
-    // Software pipeline, pinned with scheduling fences (one wave per SIMD: nothing else hides LDS latency or VALU time):
-    //   the weight fragments of group g + 1 are read from LDS while group g multiplies, and the 16 elements of the NEXT
-    //   input block are produced one at a time between MFMAs, spread evenly over the step, so their VALU work and stores
-    //   run in the shadow of the matrix pipe (an MFMA occupies it for 8 passes after a 1-pass issue).
     bf16x8 a[2][NS][G];
     auto load_group = [&](auto gc) __attribute__((always_inline)) {
       constexpr int gi = decltype(gc)::value, kk = gi / NG, g0 = (gi % NG) * G;
@@ -192,28 +228,37 @@ SDFHIP_D void tp_gemm(f32x16 (&acc)[MAXA], Raw& carry, Fetch&& fetch, Make&& mak
     static_for<0, NGRP>([&](auto gc) __attribute__((always_inline)) {
       constexpr int gi = decltype(gc)::value, kk = gi / NG, g0 = (gi % NG) * G;
       if constexpr (gi + 1 < NGRP) load_group(IC<(gi + 1 < NGRP ? gi + 1 : 0)>{});
-      __builtin_amdgcn_sched_barrier(0);  // DMA, global loads and the LDS reads of the next group stay ahead of this group's MFMAs
+      __builtin_amdgcn_sched_barrier(0);  // the LDS reads of the next group stay ahead of this group's MFMAs
       static_for<0, MPG>([&](auto mc) __attribute__((always_inline)) {
         constexpr int mi = decltype(mc)::value, t = mi / G, i = mi % G, m = gi * MPG + mi;
         acc[g0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[gi & 1][ta[t]][i], blk.p[tb[t]][kk], acc[g0 + i], 0, 0, 0);
-        if constexpr (more) {
-          // the first quarter of the step is left to the loads this block's operands arrive by; element e is then due
-          // after MFMA number S0 + floor(e W / 16), W = NM - S0: elements [ceil(16 (m - S0) / W), ceil(16 (m + 1 - S0) / W))
-          constexpr int S0 = NM / 4, W = NM - S0, mm = m - S0;
-          constexpr int lo = mm < 0 ? 0 : (16 * mm + W - 1) / W, hi_ = mm < 0 ? 0 : (16 * (mm + 1) + W - 1) / W, hi = hi_ < 16 ? hi_ : 16;
-          if constexpr (lo < hi) {
-            static_for<lo, hi>([&](auto ec) __attribute__((always_inline)) {
-              split_put<NS, decltype(ec)::value>(nxt, make(IC<(more ? kb + 1 : 0)>{}, r1, ec));
-            });
-            __builtin_amdgcn_sched_barrier(0);
-          }
+        constexpr int olo = m * PER < NOPS ? m * PER : NOPS, ohi = (m + 1) * PER < NOPS ? (m + 1) * PER : NOPS;
+        if constexpr (olo < ohi) {
+          static_for<olo, ohi>([&](auto jc) __attribute__((always_inline)) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j < ND) {
+              ws.issue_piece(dsrc, j);
+            } else {
+              if constexpr (kb + 2 < KB) load_src_elem<j - ND>(src, r2, lane);
+              else load_src_elem<j - ND>(src, carry, lane);
+            }
+          });
         }
+        // element e of the next input block is due after MFMA number S0 + floor(e W / 16)
+        constexpr int mm = m - S0;
+        constexpr int elo = (!more || mm < 0) ? 0 : (16 * mm + W - 1) / W, ehi_ = (!more || mm < 0) ? 0 : (16 * (mm + 1) + W - 1) / W;
+        constexpr int ehi = m + 1 == NM && more ? 16 : (ehi_ < 16 ? ehi_ : 16);
+        if constexpr (elo < ehi) {
+          static_for<elo, ehi>([&](auto ec) __attribute__((always_inline)) {
+            split_put<NS, decltype(ec)::value>(nxt, make(IC<(more ? kb + 1 : 0)>{}, r1, ec));
+          });
+        }
+        if constexpr (olo < ohi || elo < ehi) __builtin_amdgcn_sched_barrier(0);
       });
     });
     ws.flip();
     if constexpr (more) blk = nxt;
   });
-  if constexpr (KB == 1) carry = next_fetch();
 }
 
 // Wave-uniform GLOBAL pointer: pins a pointer the compiler cannot prove uniform into scalar registers, so that the global
@@ -221,8 +266,6 @@ SDFHIP_D void tp_gemm(f32x16 (&acc)[MAXA], Raw& carry, Fetch&& fetch, Make&& mak
 // serves every tensor and every element; 64-bit per-element addresses in VGPRs cost the fused kernels their register budget.
 // The result is typed address_space(1): after the integer round trip the compiler could no longer infer "global" and
 // would fall back to flat_load / flat_store, which also tick lgkmcnt and so stall the LDS -> MFMA stream.
-typedef __attribute__((address_space(1))) float gfloat;
-typedef __attribute__((address_space(1))) const float gcfloat;
 SDFHIP_D gfloat* uniform_gptr(const float* p) {
   const uint64_t v = reinterpret_cast<uint64_t>(p);
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);

@@ -108,6 +108,19 @@ int main() {
     printf("HBM copy 1 GiB     : %7.3f ms  %6.2f TB/s (read + write)\n", ms, 2.0 * n * 16 / ms / 1e9);
     hipFree(a); hipFree(b);
   }
+  {
+    // sustained matrix load: bf16 MFMA back to back for ~1.5 s, rate per ~150 ms window (power / current limiters show up here)
+    printf("sustained bf16 mfma:");
+    for (int w = 0; w < 10; ++w) {
+      hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+      hipEventRecord(e0);
+      for (int i = 0; i < 50; ++i) mfma_bf16<<<G, 256>>>(out, 400);
+      hipEventRecord(e1); hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      printf(" %.0f", (double)G * 4 * 400 * 32 * 32768.0 * 50 / ms / 1e9);
+    }
+    printf(" TFLOP/s\n");
+  }
   hipFuncSetAttribute((const void*)dma_stream, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
   for (size_t mb : {1, 2, 4, 16}) {
     const int reps = 2;
