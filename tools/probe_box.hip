@@ -63,16 +63,48 @@ __global__ __launch_bounds__(256, 1) void lds_read(float* out, int iters) {
   __syncthreads();
   const int lane = threadIdx.x & 63;
   f32x4 s = {0, 0, 0, 0};
+  const unsigned base = (unsigned)(size_t)(lds) + lane * 16;  // LDS byte address (address space 3 pointers are 32-bit offsets)
   for (int it = 0; it < iters; ++it) {
+    f32x4 v[16];
 #pragma unroll
-    for (int u = 0; u < 32; ++u) {
-      f32x4 v = *reinterpret_cast<volatile f32x4*>(lds + ((u * 256 + it * 64) & 16383 & ~255) + lane * 4);
-      s += v;
-    }
+    for (int u = 0; u < 16; ++u) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v[u]) : "v"(base + ((it & 3) << 14) * 0), "n"(u * 1024));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s += v[u];
   }
   out[blockIdx.x * 256 + threadIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
-
+// dependent chain of ds_read_b32 (each address comes from the previous read): LDS latency per read in shader cycles,
+// alone (MFMA = 0) or with independent bf16 MFMAs issued between the reads (MFMA = 1)
+template <int MFMA>
+__global__ __launch_bounds__(256, 1) void lds_latency(unsigned long long* cyc, float* out) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  unsigned* li = reinterpret_cast<unsigned*>(lds);
+  for (int i = threadIdx.x; i < 16384; i += 256) li[i] = ((i + 64 * 7) & 16383) * 4;  // byte offset of the next element
+  __syncthreads();
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0;
+  bf16x8 a, b;
+  for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(threadIdx.x * 0.001f + j); b[j] = (__bf16)(j * 0.5f); }
+  unsigned addr = (unsigned)(size_t)(lds) + threadIdx.x * 4;
+  const unsigned base = (unsigned)(size_t)(lds);
+  const unsigned long long t0 = __builtin_readcyclecounter();
+  for (int it = 0; it < 512; ++it) {
+    unsigned nxt;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(nxt) : "v"(addr));
+    if constexpr (MFMA) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    addr = base + nxt;
+  }
+  const unsigned long long t1 = __builtin_readcyclecounter();
+  if (threadIdx.x == 0 && blockIdx.x < 64) cyc[blockIdx.x] = t1 - t0;
+  float s = addr;
+  for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
 __global__ __launch_bounds__(256) void hbm_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
@@ -128,11 +160,23 @@ int main() {
     printf("L2->LDS DMA stream, %zu MiB working set: %7.3f ms  %6.2f TB/s\n", mb, ms, (double)G * reps * (mb << 20) / ms / 1e9);
   }
   {
-    const int iters = 200;
+    const int iters = 2000;
     hipFuncSetAttribute((const void*)lds_read, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
     float ms = timeit([&] { lds_read<<<G, 256, 65536>>>(out, iters); });
-    const double bytes = (double)G * 256 * iters * 32 * 16;
-    printf("LDS ds_read_b128   : %7.3f ms  %6.2f TB/s  = %.1f B/clk/CU at %d MHz\n", ms, bytes / ms / 1e9, bytes / ms / 1e3 / p.multiProcessorCount / p.clockRate * 1e0, p.clockRate / 1000);
+    const double bytes = (double)G * 256 * iters * 16 * 16;
+    printf("LDS ds_read_b128   : %7.3f ms  %6.2f TB/s  = %.0f B/clk/CU at the nominal %d MHz (4 waves per CU, 16 reads per wait)\n", ms, bytes / ms / 1e9,
+           bytes / (ms * 1e-3) / p.multiProcessorCount / (p.clockRate * 1e3), p.clockRate / 1000);
+  }
+  {
+    unsigned long long* cyc; hipMalloc(&cyc, 64 * 8);
+    hipFuncSetAttribute((const void*)lds_latency<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipFuncSetAttribute((const void*)lds_latency<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    std::vector<unsigned long long> h(64);
+    lds_latency<0><<<256, 256, 65536>>>(cyc, out); hipMemcpy(h.data(), cyc, 64 * 8, hipMemcpyDeviceToHost);
+    double a0 = 0; for (auto v : h) a0 += (double)v; a0 /= 64 * 512;
+    lds_latency<1><<<256, 256, 65536>>>(cyc, out); hipMemcpy(h.data(), cyc, 64 * 8, hipMemcpyDeviceToHost);
+    double a1 = 0; for (auto v : h) a1 += (double)v; a1 /= 64 * 512;
+    printf("LDS dependent ds_read_b32 : %.0f cycles per read alone, %.0f with 4 bf16 MFMAs (128 cycles of matrix pipe) per read\n", a0, a1);
   }
   return 0;
 }
