@@ -24,15 +24,20 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
 
 // mode: 0 = train/full (GRAD, SAVE, FEAT), 1 = geonetwork (FEAT only), 2 = sdf only
 // The three heavy kernel families of one network shape can live in separate translation units (the fully unrolled fused
-// kernels take minutes each to compile): GEO_FWD / GEO_BWD define plain functions, COL defines the rest and the table.
+// kernels take minutes each to compile): GEO_FWD_TRAIN / GEO_FWD_INFER / GEO_BWD define plain functions, COL defines the rest and the table.
 #define SDFHIP_GEO_DIMS(NBH, NB0, NB3, NL, SKIP, NBF) GeoDims<NBH, NB0, NB3, NL, SKIP, NBF>
 
-#define SDFHIP_DEFINE_GEO_FWD(NAME, NBH, NB0, NB3, NL, SKIP, NBF)                                                    \
-  void sdfhip_geo_fwd_##NAME(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s) {                          \
+#define SDFHIP_DEFINE_GEO_FWD_TRAIN(NAME, NBH, NB0, NB3, NL, SKIP, NBF)                                              \
+  void sdfhip_geo_fwd_train_##NAME(const GeoFwdArgs& a, unsigned grid, hipStream_t s) {                              \
+    using GD = SDFHIP_GEO_DIMS(NBH, NB0, NB3, NL, SKIP, NBF);                                                        \
+    launch_lds(geo_fwd_kernel<GD, true, true, true>, a, grid, 256, GD::lds_floats(kNsFwd) * sizeof(float), s);       \
+  }
+
+#define SDFHIP_DEFINE_GEO_FWD_INFER(NAME, NBH, NB0, NB3, NL, SKIP, NBF)                                              \
+  void sdfhip_geo_fwd_infer_##NAME(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s) {                    \
     using GD = SDFHIP_GEO_DIMS(NBH, NB0, NB3, NL, SKIP, NBF);                                                        \
     const size_t lds = GD::lds_floats(kNsFwd) * sizeof(float);                                                       \
-    if (mode == 0) launch_lds(geo_fwd_kernel<GD, true, true, true>, a, grid, 256, lds, s);                           \
-    else if (mode == 1) launch_lds(geo_fwd_kernel<GD, false, false, true>, a, grid, 256, lds, s);                    \
+    if (mode == 1) launch_lds(geo_fwd_kernel<GD, false, false, true>, a, grid, 256, lds, s);                         \
     else launch_lds(geo_fwd_kernel<GD, false, false, false>, a, grid, 256, lds, s);                                  \
   }
 
@@ -43,9 +48,14 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
   }
 
 #define SDFHIP_DEFINE_COL_AND_TABLE(NAME, NBH, NB0, NB3, NL, SKIP, NBF, NBS, NBC, NLC)                               \
-  void sdfhip_geo_fwd_##NAME(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s);                           \
+  void sdfhip_geo_fwd_train_##NAME(const GeoFwdArgs& a, unsigned grid, hipStream_t s);                              \
+  void sdfhip_geo_fwd_infer_##NAME(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s);                     \
   void sdfhip_geo_bwd_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s);                                     \
   namespace NAME##_ns {                                                                                              \
+  static void geo_fwd(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s) {                                 \
+    if (mode == 0) sdfhip_geo_fwd_train_##NAME(a, grid, s);                                                          \
+    else sdfhip_geo_fwd_infer_##NAME(mode, a, grid, s);                                                              \
+  }                                                                                                                  \
   using GD = SDFHIP_GEO_DIMS(NBH, NB0, NB3, NL, SKIP, NBF);                                                          \
   using CD = ColDims<NBF, NBS, NBC, NLC>;                                                                            \
   static void col_fwd(const ColFwdArgs& a, unsigned grid, hipStream_t s) {                                           \
@@ -62,13 +72,14 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
   const FieldKernels* sdfhip_kernels_##NAME() {                                                                      \
     static const FieldKernels k = {NBH, NB0, NB3, NL, SKIP, NBF, NBS, NBC, NLC,                                      \
                                    NAME##_ns::GD::lds_floats(kNsMax) * sizeof(float), NAME##_ns::CD::lds_floats(kNsMax) * sizeof(float), \
-                                   sdfhip_geo_fwd_##NAME, sdfhip_geo_bwd_##NAME, NAME##_ns::col_fwd, NAME##_ns::col_bwd, \
+                                   NAME##_ns::geo_fwd, sdfhip_geo_bwd_##NAME, NAME##_ns::col_fwd, NAME##_ns::col_bwd,       \
                                    NAME##_ns::sdfrow};                                                               \
     return &k;                                                                                                       \
   }
 
 // everything of one shape in one translation unit
 #define SDFHIP_DEFINE_FIELD_KERNELS(NAME, NBH, NB0, NB3, NL, SKIP, NBF, NBS, NBC, NLC) \
-  SDFHIP_DEFINE_GEO_FWD(NAME, NBH, NB0, NB3, NL, SKIP, NBF)                             \
+  SDFHIP_DEFINE_GEO_FWD_TRAIN(NAME, NBH, NB0, NB3, NL, SKIP, NBF)                       \
+  SDFHIP_DEFINE_GEO_FWD_INFER(NAME, NBH, NB0, NB3, NL, SKIP, NBF)                       \
   SDFHIP_DEFINE_GEO_BWD(NAME, NBH, NB0, NB3, NL, SKIP, NBF)                             \
   SDFHIP_DEFINE_COL_AND_TABLE(NAME, NBH, NB0, NB3, NL, SKIP, NBF, NBS, NBC, NLC)

@@ -218,6 +218,9 @@ SDFHIP_D void tp_gemm(f32x16 (&acc)[MAXA], Raw& carry, Fetch&& fetch, Make&& mak
     bf16x8 a[2][NS][G];
     auto load_group = [&](auto gc) __attribute__((always_inline)) {
       constexpr int gi = decltype(gc)::value, kk = gi / NG, g0 = (gi % NG) * G;
+#ifdef SDFHIP_ABLATE_LDS_READS  // timing experiment only (wrong numerics): weight fragments read for the first two groups of a step
+      if constexpr (gi >= 2) return;
+#endif
 #pragma unroll
       for (int q = 0; q < NS; ++q)
 #pragma unroll
