@@ -81,7 +81,8 @@ int64_t sdfhip_field_table_size(const SdfHipField* f);    /* floats in the hash 
 int64_t sdfhip_field_packed_size(const SdfHipField* f);   /* floats in the MFMA-packed weight blob */
 int64_t sdfhip_field_workspace_size(const SdfHipField* f, int64_t n_points, int32_t training); /* bytes */
 
-/* theta -> MFMA operand order (once per optimiser step). */
+/* theta -> split-bf16 MFMA operand order: every weight as three bf16 parts w0 + w1 + w2 (all 24 mantissa bits), W and W^T
+ * chunked per 32-wide k block (once per optimiser step). */
 int sdfhip_field_pack(const SdfHipField* f, const float* theta, float* packed, sdfhip_stream_t stream);
 
 enum {
@@ -107,6 +108,19 @@ int sdfhip_field_backward(const SdfHipField* f, const float* packed, const float
                           int64_t n_rays, int32_t n_samples, void* workspace,
                           const float* sdf_bar, const float* grad_bar, const float* rgb_bar,
                           float* theta_bar, float* table_bar, float* emb_bar, sdfhip_stream_t stream);
+
+/* Differentiable geometry network on explicit positions: SDFField.forward_geonetwork (sdf_field.py:380-410) under autograd -
+ * what the reference differentiates through in the sparse-SfM loss (base_surface_model.py:463) and, six more times per sample,
+ * in the numerical-gradient path (sdf_field.py:433-453).  First order only (no d sdf / dx, no second-order terms).
+ * positions [P,3] are used as given (no contraction).  sdf [rows], feat [P, geo_feat_dim] or NULL; rows = sdfhip_padded_points(P).
+ * workspace: sdfhip_geo_workspace_size(f, P) bytes, kept by the caller until the backward. */
+int64_t sdfhip_geo_workspace_size(const SdfHipField* f, int64_t n_points);
+int sdfhip_geo_forward(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
+                       const float* positions, int64_t n_points, void* workspace, float* sdf, float* feat, sdfhip_stream_t stream);
+/* sdf_bar [P] and feat_bar [P, geo_feat_dim] (either may be NULL = zero).  The geometry-network entries of theta_bar [theta_size]
+ * are overwritten (the colour-network entries are left untouched: the caller zeroes the vector); table_bar is accumulated into. */
+int sdfhip_geo_backward(const SdfHipField* f, const float* packed, const float* level_mask, int64_t n_points, void* workspace,
+                        const float* sdf_bar, const float* feat_bar, float* theta_bar, float* table_bar, sdfhip_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------- proposal density field
  * Replaces nerfstudio.fields.density_fields.HashMLPDensityField.get_density / density_fn (:99-118; base_field.py:48-65):

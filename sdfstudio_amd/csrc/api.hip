@@ -630,6 +630,207 @@ static void run_wgrad(const SdfHipField* f, const FieldWs& w, const WgradArgs& b
   { ProfScope ps_(PS_WREDUCE, s); wreduce_kernel<<<(unsigned)((total + 63) / 64), 256, 0, s>>>(r); }
 }
 
+static TpOperand seg1(const float* p, int nb, int xf) {
+  TpOperand o;
+  memset(&o, 0, sizeof(o));
+  o.ptr[0] = p;
+  o.nb[0] = nb;
+  o.xf[0] = xf;
+  return o;
+}
+static TpOperand seg2(const float* p0, int nb0, int xf0, const float* p1, int nb1, int xf1) {
+  TpOperand o;
+  memset(&o, 0, sizeof(o));
+  o.ptr[0] = p0;
+  o.nb[0] = nb0;
+  o.xf[0] = xf0;
+  o.ptr[1] = p1;
+  o.nb[1] = nb1;
+  o.xf[1] = xf1;
+  return o;
+}
+
+// Weight gradients of the geometry network: split-K GEMMs over the points.  tangent = the second-order pair (R_l^T Qb_l) rides along.
+static void run_geo_wgrads(const SdfHipField* f, const FieldWs& w, const bool tangent, const int64_t n_tiles, float* theta_bar,
+                           hipStream_t s) {
+  const FieldKernels* k = f->k;
+  for (int l = 0; l < k->nl; ++l) {
+    const LinearInfo& li = f->lin[l];
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_pairs = tangent ? 2 : 1;
+    a.nba = f->nbo_geo(l);
+    a.nbb = f->kb_geo(l);
+    a.n_tiles = n_tiles;
+    a.A[0] = seg1(w.zb[l], a.nba, 0);
+    a.A[1] = seg1(w.r[l], a.nba, 0);
+    if (l == 0) {
+      a.B[0] = seg1(w.in0, k->nb0, 0);
+      a.B[1] = seg1(w.ebar, k->nb0, 0);
+    } else if (l == k->skip) {
+      a.B[0] = seg2(w.z[l - 1], k->nb3, 1, w.in0, k->nb0, 0);
+      a.B[1] = seg1(w.qb[l], a.nbb, 0);
+    } else {
+      a.B[0] = seg1(w.z[l - 1], a.nbb, 1);
+      a.B[1] = seg1(w.qb[l], a.nbb, 0);
+    }
+    run_wgrad(f, w, a, f->g_rowmap[l], f->g_colmap[l], li.w_off, li.in_dim, f->g_scale[l], li.b_off, theta_bar, s);
+  }
+  {
+    // output layer: feature rows through the GEMM, sdf row through its own reduction
+    const LinearInfo& li = f->lin[k->nl];
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_pairs = 1;
+    a.nba = k->nbf;
+    a.nbb = k->nbh;
+    a.n_tiles = n_tiles;
+    a.A[0] = seg1(w.featbar, k->nbf, 0);
+    a.B[0] = seg1(w.z[k->nl - 1], k->nbh, 1);
+    run_wgrad(f, w, a, f->g_rowmap[k->nl], f->g_colmap[k->nl], li.w_off, li.in_dim, 1.0f, li.b_off, theta_bar, s);
+    const int tps = (int)((n_tiles + w.n_split - 1) / w.n_split);
+    { ProfScope ps_(PS_WGRAD, s); k->sdfrow(w.z[k->nl - 1], tangent ? w.qb[k->nl] : nullptr, w.sdfbar, n_tiles, tps, w.partial, (unsigned)w.n_split, s); }
+    const int stride = k->nbh * 32 + 32;
+    sdfrow_reduce_kernel<<<(stride + 255) / 256, 256, 0, s>>>(w.partial, w.n_split, stride, f->cfg.hidden_dim, theta_bar + li.w_off,
+                                                              theta_bar + li.b_off);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ differentiable geometry network
+// forward_geonetwork (sdf_field.py:380-410) as a first-order differentiable operator on explicit positions: what the reference
+// differentiates through in the sparse-SfM loss (base_surface_model.py:463), and the building block of the numerical-gradient
+// path (sdf_field.py:433-453: six more evaluations of the same network).
+static void carve_geo(const SdfHipField* f, int64_t n_points, void* base, FieldWs* w) {
+  const FieldKernels* k = f->k;
+  const int64_t np = sdfhip_padded_points(n_points);
+  size_t off = 0;
+  auto take = [&](int64_t floats) {
+    float* p = base ? reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off) : nullptr;
+    off += ((size_t)floats * sizeof(float) + 255) / 256 * 256;
+    return p;
+  };
+  memset(w, 0, sizeof(*w));
+  w->x = take(np * 3);
+  w->in0 = take(np * k->nb0 * 32);
+  w->feat = take(np * k->nbf * 32);
+  for (int l = 0; l < k->nl; ++l) w->z[l] = take(np * f->nbo_geo(l) * 32);
+  w->sdfbar = take(np);
+  for (int l = 0; l < k->nl; ++l) w->zb[l] = take(np * f->nbo_geo(l) * 32);
+  w->in0bar = take(np * k->nb0 * 32);
+  w->featbar = take(np * k->nbf * 32);
+  const int64_t n_tiles = np / 32;
+  w->n_split = (int)std::min<int64_t>(256, n_tiles);
+  w->partial = take((int64_t)w->n_split * f->max_partial_elems);
+  w->bpartial = take((int64_t)w->n_split * f->max_partial_rows);
+  w->bytes = off;
+}
+
+extern "C" int64_t sdfhip_geo_workspace_size(const SdfHipField* f, int64_t n_points) {
+  FieldWs w;
+  carve_geo(f, n_points, nullptr, &w);
+  return (int64_t)w.bytes;
+}
+
+// natural [n_rows][n_feat] (or null: zeros) -> tile-packed [T][nb], rows >= n_rows and features >= n_feat zero
+__global__ void totp_kernel(const float* __restrict__ in, const int nb, const int n_feat, const int64_t n_rows, const int64_t n_padded,
+                            float* __restrict__ tp) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int width = nb * 32;
+  if (idx >= n_padded * width) return;
+  const int64_t p = idx / width;
+  const int c = (int)(idx % width);
+  tp[tp_index(p, c, nb)] = (in != nullptr && p < n_rows && c < n_feat) ? in[p * n_feat + c] : 0.0f;
+}
+__global__ void pad_copy_kernel(const float* __restrict__ in, const int64_t n, const int64_t n_padded, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_padded) out[i] = (in != nullptr && i < n) ? in[i] : 0.0f;
+}
+
+extern "C" int sdfhip_geo_forward(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
+                                  const float* positions, int64_t n_points, void* workspace, float* sdf, float* feat,
+                                  sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(f && packed && table && level_mask && positions && workspace && sdf, "geo_forward: null argument");
+  if (n_points == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const FieldKernels* k = f->k;
+  const int64_t P = n_points, NP = sdfhip_padded_points(P);
+  FieldWs w;
+  carve_geo(f, P, workspace, &w);
+  EncodeArgs ea;
+  memset(&ea, 0, sizeof(ea));
+  ea.grid = f->grid;
+  ea.origins = positions;  // explicit positions, used as given (forward_geonetwork does not contract)
+  ea.n_points = P;
+  ea.n_padded = NP;
+  ea.S = 1;
+  ea.pe_degree = f->cfg.pe_degree;
+  ea.use_pe = f->cfg.use_position_encoding;
+  ea.nb0 = k->nb0;
+  ea.table = table;
+  ea.mask = level_mask;
+  ea.x_out = w.x;
+  ea.in0_tp = w.in0;
+  { ProfScope ps_(PS_ENCODE, s); geo_encode_kernel<<<dim3((unsigned)(NP / 256 + (NP % 256 != 0)), f->grid.n_levels + 1), 256, 0, s>>>(ea); }
+  GeoFwdArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  fill_geo_ptrs(f, packed, &ga.p);
+  ga.in0_tp = w.in0;
+  for (int l = 0; l < k->nl; ++l) ga.z_tp[l] = w.z[l];
+  ga.feat_tp = w.feat;
+  ga.sdf = sdf;
+  { ProfScope ps_(PS_GEO_FWD, s); k->geo_fwd(3, ga, (unsigned)(NP / 128), s); }
+  if (feat != nullptr) {
+    const int64_t total = P * f->cfg.geo_feat_dim;
+    untp_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(w.feat, k->nbf, f->cfg.geo_feat_dim, P, feat);
+  }
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfhip_geo_backward(const SdfHipField* f, const float* packed, const float* level_mask, int64_t n_points, void* workspace,
+                                   const float* sdf_bar, const float* feat_bar, float* theta_bar, float* table_bar,
+                                   sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(f && packed && level_mask && workspace && theta_bar && table_bar, "geo_backward: null argument");
+  if (n_points == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const FieldKernels* k = f->k;
+  const int64_t P = n_points, NP = sdfhip_padded_points(P);
+  FieldWs w;
+  carve_geo(f, P, workspace, &w);
+  const unsigned pg = (unsigned)((NP + 255) / 256);
+  pad_copy_kernel<<<pg, 256, 0, s>>>(sdf_bar, P, NP, w.sdfbar);
+  const int64_t fw = NP * k->nbf * 32;
+  totp_kernel<<<(unsigned)((fw + 255) / 256), 256, 0, s>>>(feat_bar, k->nbf, f->cfg.geo_feat_dim, P, NP, w.featbar);
+
+  GeoBwdArgs gb;
+  memset(&gb, 0, sizeof(gb));
+  fill_geo_ptrs(f, packed, &gb.p);
+  gb.featbar_tp = w.featbar;
+  gb.sdfbar = w.sdfbar;
+  for (int l = 0; l < k->nl; ++l) {
+    gb.z_tp[l] = w.z[l];
+    gb.zb_tp[l] = w.zb[l];
+  }
+  gb.in0bar_tp = w.in0bar;
+  { ProfScope ps_(PS_GEO_BWD, s); k->geo_bwd1(gb, (unsigned)(NP / 128), s); }
+
+  GridBwdArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  ga.grid = f->grid;
+  ga.x = w.x;
+  ga.in0bar_tp = w.in0bar;
+  ga.mask = level_mask;
+  ga.n_points = P;
+  ga.pe_degree = f->cfg.pe_degree;
+  ga.nb0 = k->nb0;
+  ga.tablebar = table_bar;
+  { ProfScope ps_(PS_GRID_BWD, s); grid_bwd_kernel<<<dim3((unsigned)((P + 255) / 256), f->grid.n_levels), 256, 0, s>>>(ga); }
+
+  run_geo_wgrads(f, w, false, NP / 32, theta_bar, s);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
                                      int64_t n_rays, int32_t n_samples, void* workspace, const float* sdf_bar, const float* grad_bar,
                                      const float* rgb_bar, float* theta_bar, float* table_bar, float* emb_bar,
@@ -733,65 +934,7 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
 
   // 5. weight gradients: split-K GEMMs over points
   const int64_t n_tiles = NP / 32;
-  auto seg1 = [](const float* p, int nb, int xf) {
-    TpOperand o;
-    memset(&o, 0, sizeof(o));
-    o.ptr[0] = p;
-    o.nb[0] = nb;
-    o.xf[0] = xf;
-    return o;
-  };
-  auto seg2 = [](const float* p0, int nb0, int xf0, const float* p1, int nb1, int xf1) {
-    TpOperand o;
-    memset(&o, 0, sizeof(o));
-    o.ptr[0] = p0;
-    o.nb[0] = nb0;
-    o.xf[0] = xf0;
-    o.ptr[1] = p1;
-    o.nb[1] = nb1;
-    o.xf[1] = xf1;
-    return o;
-  };
-  for (int l = 0; l < k->nl; ++l) {
-    const LinearInfo& li = f->lin[l];
-    WgradArgs a;
-    memset(&a, 0, sizeof(a));
-    a.n_pairs = 2;
-    a.nba = f->nbo_geo(l);
-    a.nbb = f->kb_geo(l);
-    a.n_tiles = n_tiles;
-    a.A[0] = seg1(w.zb[l], a.nba, 0);
-    a.A[1] = seg1(w.r[l], a.nba, 0);
-    if (l == 0) {
-      a.B[0] = seg1(w.in0, k->nb0, 0);
-      a.B[1] = seg1(w.ebar, k->nb0, 0);
-    } else if (l == k->skip) {
-      a.B[0] = seg2(w.z[l - 1], k->nb3, 1, w.in0, k->nb0, 0);
-      a.B[1] = seg1(w.qb[l], a.nbb, 0);
-    } else {
-      a.B[0] = seg1(w.z[l - 1], a.nbb, 1);
-      a.B[1] = seg1(w.qb[l], a.nbb, 0);
-    }
-    run_wgrad(f, w, a, f->g_rowmap[l], f->g_colmap[l], li.w_off, li.in_dim, f->g_scale[l], li.b_off, theta_bar, s);
-  }
-  {
-    // output layer: feature rows through the GEMM, sdf row through its own reduction
-    const LinearInfo& li = f->lin[k->nl];
-    WgradArgs a;
-    memset(&a, 0, sizeof(a));
-    a.n_pairs = 1;
-    a.nba = k->nbf;
-    a.nbb = k->nbh;
-    a.n_tiles = n_tiles;
-    a.A[0] = seg1(w.featbar, k->nbf, 0);
-    a.B[0] = seg1(w.z[k->nl - 1], k->nbh, 1);
-    run_wgrad(f, w, a, f->g_rowmap[k->nl], f->g_colmap[k->nl], li.w_off, li.in_dim, 1.0f, li.b_off, theta_bar, s);
-    const int tps = (int)((n_tiles + w.n_split - 1) / w.n_split);
-    { ProfScope ps_(PS_WGRAD, s); k->sdfrow(w.z[k->nl - 1], w.qb[k->nl], w.sdfbar, n_tiles, tps, w.partial, (unsigned)w.n_split, s); }
-    const int stride = k->nbh * 32 + 32;
-    sdfrow_reduce_kernel<<<(stride + 255) / 256, 256, 0, s>>>(w.partial, w.n_split, stride, f->cfg.hidden_dim, theta_bar + li.w_off,
-                                                              theta_bar + li.b_off);
-  }
+  run_geo_wgrads(f, w, true, n_tiles, theta_bar, s);
   for (int l = 0; l < k->nlc; ++l) {
     const LinearInfo& li = f->lin[f->n_geo + l];
     WgradArgs a;

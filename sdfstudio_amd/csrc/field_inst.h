@@ -8,7 +8,8 @@ struct FieldKernels {
   int nbh, nb0, nb3, nl, skip, nbf, nbs, nbc, nlc;
   size_t geo_lds, col_lds;
   void (*geo_fwd)(int mode_train_geo_sdf, const GeoFwdArgs&, unsigned grid, hipStream_t);
-  void (*geo_bwd)(const GeoBwdArgs&, unsigned grid, hipStream_t);
+  void (*geo_bwd)(const GeoBwdArgs&, unsigned grid, hipStream_t);   // tangent pass + data backward (after MODE_FULL)
+  void (*geo_bwd1)(const GeoBwdArgs&, unsigned grid, hipStream_t);  // first-order data backward only (after sdfhip_geo_forward)
   void (*col_fwd)(const ColFwdArgs&, unsigned grid, hipStream_t);
   void (*col_bwd)(const ColBwdArgs&, unsigned grid, hipStream_t);
   void (*sdfrow)(const float* z_last, const float* qb_last, const float* sdfbar, int64_t n_tiles, int tiles_per_split,
@@ -22,7 +23,7 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, s, a);
 }
 
-// mode: 0 = train/full (GRAD, SAVE, FEAT), 1 = geonetwork (FEAT only), 2 = sdf only
+// mode: 0 = train/full (GRAD, SAVE, FEAT), 1 = geonetwork (FEAT only), 2 = sdf only, 3 = geonetwork saving z_l (differentiable)
 // The three heavy kernel families of one network shape can live in separate translation units (the fully unrolled fused
 // kernels take minutes each to compile): GEO_FWD_TRAIN / GEO_FWD_INFER / GEO_BWD define plain functions, COL defines the rest and the table.
 #define SDFHIP_GEO_DIMS(NBH, NB0, NB3, NL, SKIP, NBF) GeoDims<NBH, NB0, NB3, NL, SKIP, NBF>
@@ -38,6 +39,7 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
     using GD = SDFHIP_GEO_DIMS(NBH, NB0, NB3, NL, SKIP, NBF);                                                        \
     const size_t lds = GD::lds_floats(kNsFwd) * sizeof(float);                                                       \
     if (mode == 1) launch_lds(geo_fwd_kernel<GD, false, false, true>, a, grid, 256, lds, s);                         \
+    else if (mode == 3) launch_lds(geo_fwd_kernel<GD, false, true, true>, a, grid, 256, lds, s);                     \
     else launch_lds(geo_fwd_kernel<GD, false, false, false>, a, grid, 256, lds, s);                                  \
   }
 
@@ -45,12 +47,17 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
   void sdfhip_geo_bwd_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s) {                                    \
     using GD = SDFHIP_GEO_DIMS(NBH, NB0, NB3, NL, SKIP, NBF);                                                        \
     launch_lds(geo_bwd_kernel<GD>, a, grid, 256, GD::lds_floats(kNsGrad) * sizeof(float), s);                        \
+  }                                                                                                                  \
+  void sdfhip_geo_bwd1_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s) {                                   \
+    using GD = SDFHIP_GEO_DIMS(NBH, NB0, NB3, NL, SKIP, NBF);                                                        \
+    launch_lds(geo_bwd_kernel<GD, false>, a, grid, 256, GD::lds_floats(kNsGrad) * sizeof(float), s);                 \
   }
 
 #define SDFHIP_DEFINE_COL_AND_TABLE(NAME, NBH, NB0, NB3, NL, SKIP, NBF, NBS, NBC, NLC)                               \
   void sdfhip_geo_fwd_train_##NAME(const GeoFwdArgs& a, unsigned grid, hipStream_t s);                              \
   void sdfhip_geo_fwd_infer_##NAME(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s);                     \
   void sdfhip_geo_bwd_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s);                                     \
+  void sdfhip_geo_bwd1_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s);                                    \
   namespace NAME##_ns {                                                                                              \
   static void geo_fwd(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s) {                                 \
     if (mode == 0) sdfhip_geo_fwd_train_##NAME(a, grid, s);                                                          \
@@ -72,7 +79,8 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
   const FieldKernels* sdfhip_kernels_##NAME() {                                                                      \
     static const FieldKernels k = {NBH, NB0, NB3, NL, SKIP, NBF, NBS, NBC, NLC,                                      \
                                    NAME##_ns::GD::lds_floats(kNsMax) * sizeof(float), NAME##_ns::CD::lds_floats(kNsMax) * sizeof(float), \
-                                   NAME##_ns::geo_fwd, sdfhip_geo_bwd_##NAME, NAME##_ns::col_fwd, NAME##_ns::col_bwd,       \
+                                   NAME##_ns::geo_fwd, sdfhip_geo_bwd_##NAME, sdfhip_geo_bwd1_##NAME, NAME##_ns::col_fwd,   \
+                                   NAME##_ns::col_bwd,                                                               \
                                    NAME##_ns::sdfrow};                                                               \
     return &k;                                                                                                       \
   }

@@ -223,7 +223,8 @@ struct GeoBwdArgs {
   float* in0bar_tp;              // [T][NB0]
 };
 
-template <class D>
+// TANGENT = false: first-order backward only (no second-order terms: the caller differentiated sdf / feature, not d sdf / dx).
+template <class D, bool TANGENT = true>
 __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, hf = lane >> 5;
@@ -234,7 +235,8 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
   float* cvec = lds + 2 * D::buf_floats(NS);
 
   WStream ws{lds, D::buf_floats(NS), 0, wave, lane};
-  ws.issue(a.p.wp[0], chunk_pieces(D::nbo(0), NS), true);
+  if constexpr (TANGENT) ws.issue(a.p.wp[0], chunk_pieces(D::nbo(0), NS), true);
+  else ws.issue(a.p.wpT[D::NL], chunk_pieces(D::NBH, NS), true);
   if (tid < D::NBH * 32) cvec[tid] = a.p.w_sdf[tid];
   __syncthreads();
 
@@ -262,9 +264,11 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
   };
   auto bwd_fetch = [&](auto lc, auto bc) __attribute__((always_inline)) {
     constexpr int l = decltype(lc)::value, b = decltype(bc)::value;
-    return BlkSrc<2>{{tp_block_ptr(a.z_tp[l], tile, D::nbo(l), b), tp_block_ptr(a.zb_tp[l], tile, D::nbo(l), b)}};
+    if constexpr (TANGENT) return BlkSrc<2>{{tp_block_ptr(a.z_tp[l], tile, D::nbo(l), b), tp_block_ptr(a.zb_tp[l], tile, D::nbo(l), b)}};
+    else return BlkSrc<1>{{tp_block_ptr(a.z_tp[l], tile, D::nbo(l), b)}};
   };
 
+  if constexpr (TANGENT) {
   // ---- tangent pass (second-order terms): v_l = W_l qb_l
   carry = load_src(tan_fetch(IC<0>{}, IC<0>{}), lane);
   static_for<0, D::NL>([&](auto lc) __attribute__((always_inline)) {
@@ -312,6 +316,8 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
     });
   }
 
+  }
+
   // ---- backward pass: ub_NL = w_s sdfbar + W_f^T featbar
   {
     const float sb = a.sdfbar[tile * 32 + (lane & 31)];
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
     auto fetch = [&](auto bc) __attribute__((always_inline)) { return bwd_fetch(IC<l>{}, bc); };
     auto make = [&](auto bc, const Raw& raw, auto ec) __attribute__((always_inline)) {
       constexpr int b = decltype(bc)::value, e = decltype(ec)::value;
-      const float zb = fmaf(ub[b][e], softplus100_d1(raw.a[e]), raw.b[e]);
+      const float zb = TANGENT ? fmaf(ub[b][e], softplus100_d1(raw.a[e]), raw.b[e]) : ub[b][e] * softplus100_d1(raw.a[e]);
       *tp_elem(a.zb_tp[l], tile, NBO, b, e, lane) = zb;
       return zb;
     };

@@ -521,6 +521,7 @@ static __global__ __launch_bounds__(256) void wreduce_kernel(const WreduceArgs a
 
 // Gradient of the sdf output row (lane-local dot product in geo_fwd_kernel):
 //   w_sdf_bar[k] = sum_p ( sdfbar_p * softplus(z_last[p][k]) + qb_last[p][k] ),   b_sdf_bar = sum_p sdfbar_p
+// (qb_last == nullptr: first-order backward, no tangent term)
 // grid = n_split, block = 256 (the 4 waves interleave over the split's tiles, then sum through LDS).
 // partial: [n_split][NBH*32 + 32]  (last 32-slot holds b_sdf_bar in [0])
 template <int NBH>
@@ -547,7 +548,7 @@ __global__ __launch_bounds__(256) void sdfrow_grad_kernel(const float* __restric
       const float* qp = qb_last + ((size_t)tile * NBH + b) * 1024 + lane;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        acc[b][r] += fmaf(sb, softplus100_h(zp[r * 64]), qp[r * 64]);
+        acc[b][r] += fmaf(sb, softplus100_h(zp[r * 64]), qb_last != nullptr ? qp[r * 64] : 0.0f);
       }
     }
   }

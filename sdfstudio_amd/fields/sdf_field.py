@@ -173,6 +173,44 @@ class _FieldFunction(torch.autograd.Function):
         return theta_bar, table_bar, emb_bar, None, None, None, None, None
 
 
+class _GeoNetFunction(torch.autograd.Function):
+    """forward_geonetwork under autograd (first order): (theta, table) -> (sdf [P], geometry feature [P, F]) at explicit positions."""
+
+    @staticmethod
+    def forward(ctx, theta, table, fld, positions, mask):
+        lib = _lib.load()
+        dev = theta.device
+        P = positions.shape[0]
+        NP = _lib.padded_points(P)
+        h = fld._handle
+        packed = torch.empty(lib.sdfhip_field_packed_size(h), device=dev)
+        _lib.check(lib.sdfhip_field_pack(h, _lib.ptr(theta.contiguous()), _lib.ptr(packed), _lib.stream()), "field_pack")
+        ws = torch.empty(lib.sdfhip_geo_workspace_size(h, P), dtype=torch.uint8, device=dev)
+        sdf = torch.empty(NP, device=dev)
+        feat = torch.empty(P, fld.config.geo_feat_dim, device=dev)
+        _lib.check(lib.sdfhip_geo_forward(h, _lib.ptr(packed), _lib.ptr(table), _lib.ptr(mask), _lib.ptr(positions), P,
+                                          ctypes.c_void_p(ws.data_ptr()), _lib.ptr(sdf), _lib.ptr(feat), _lib.stream()), "geo_forward")
+        ctx.save_for_backward(packed, table, mask, ws)
+        ctx.fld, ctx.P = fld, P
+        return sdf[:P], feat
+
+    @staticmethod
+    def backward(ctx, sdf_bar, feat_bar):
+        packed, table, mask, ws = ctx.saved_tensors
+        lib = _lib.load()
+        h = ctx.fld._handle
+        theta_bar = torch.zeros(lib.sdfhip_field_theta_size(h), device=packed.device)  # colour entries stay zero
+        table_bar = torch.zeros_like(table)
+
+        def c(t):
+            return None if t is None else t.contiguous()
+
+        _lib.check(lib.sdfhip_geo_backward(h, _lib.ptr(packed), _lib.ptr(mask), ctx.P, ctypes.c_void_p(ws.data_ptr()),
+                                           _lib.ptr(c(sdf_bar)), _lib.ptr(c(feat_bar)), _lib.ptr(theta_bar), _lib.ptr(table_bar),
+                                           _lib.stream()), "geo_backward")
+        return theta_bar, table_bar, None, None, None
+
+
 class SDFField(nn.Module):
     """fields/sdf_field.py:188-698."""
 
@@ -348,10 +386,14 @@ class SDFField(nn.Module):
         return sdf[:P], (None if feat is None else feat[:P])
 
     def forward_geonetwork(self, inputs: torch.Tensor) -> torch.Tensor:
-        """sdf_field.py:380-410: [P,3] -> [P, 1 + geo_feat_dim] (column 0 = sdf).  Inference form (no autograd graph):
-        the differentiable path is ``forward`` / ``get_outputs``."""
-        x = inputs.reshape(-1, 3).contiguous().float()
-        sdf, feat = self._run_inference(_lib.MODE_GEO, x, None, None, x.shape[0], 1, True)
+        """sdf_field.py:380-410: [P,3] -> [P, 1 + geo_feat_dim] (column 0 = sdf).  Under autograd the result is differentiable
+        w.r.t. the network weights and the hash table (first order; the positions are treated as constants), e.g. for the
+        sparse-SfM loss (base_surface_model.py:463); with grad disabled a lighter kernel variant that saves nothing runs."""
+        x = inputs.detach().reshape(-1, 3).contiguous().float()
+        if torch.is_grad_enabled() and x.shape[0] > 0:
+            sdf, feat = _GeoNetFunction.apply(self._theta(), self.encoding.params, self, x, self._mask(x.device))
+        else:
+            sdf, feat = self._run_inference(_lib.MODE_GEO, x, None, None, x.shape[0], 1, True)
         return torch.cat([sdf[:, None], feat], dim=-1)
 
     def get_sdf(self, ray_samples):

@@ -584,6 +584,43 @@ def test_field_small_get_sdf_and_geonetwork(device):
     assert_close("get_density feature", feat.reshape(n * s, -1), h[:, 1:], rtol=1e-4, atol=1e-5)
 
 
+def test_forward_geonetwork_is_differentiable(device):
+    """SDFField.forward_geonetwork under autograd (sdf_field.py:380-410; first-order backward kernel, no tangent pass) against the
+    oracle's geo_network: outputs and the gradients of every geometry-network weight and of the hash table; the colour network
+    must receive exactly zero."""
+    g = load_golden("train")
+    cfg = small_oracle_cfg()
+    model = product_model_from_params(g["param"], cfg, device).train()
+    torch.manual_seed(21)
+    n = 333  # ragged: 2 full workgroups + a tail
+    pos = (torch.rand(n, 3) * 2 - 1) * 0.9
+    c_sdf, c_feat = torch.randn(n), torch.randn(n, cfg.field.geo_feat_dim) * 0.1
+    po = {k: v.clone().requires_grad_(v.is_floating_point() and k != "laplace_density.beta_min") for k, v in g["param"].items()}
+    h = O.geo_network(pos, po, cfg.field)
+    ((h[:, 0] * c_sdf).sum() + (h[:, 1:] * c_feat).sum()).backward()
+    out = model.field.forward_geonetwork(pos.to(device))
+    assert out.requires_grad
+    assert_close("sdf", out[:, 0], h[:, 0], rtol=0, atol=1e-5)
+    assert_close("feature", out[:, 1:], h[:, 1:], rtol=1e-4, atol=1e-5)
+    model.zero_grad()
+    ((out[:, 0] * c_sdf.to(device)).sum() + (out[:, 1:] * c_feat.to(device)).sum()).backward()
+    got = product_grads(model)
+    checked = 0
+    for k, ref in po.items():
+        if ref.grad is None:
+            if k.startswith("clin") and k in got:
+                assert got[k].abs().max().item() == 0.0, k
+            continue
+        if k.startswith("glin") or k == "encoding.params":
+            assert_close(f"grad {k}", got[k], ref.grad, rtol=1e-3, atol=1e-9)
+            checked += 1
+    assert checked >= 9 * 3 + 1
+    with torch.no_grad():
+        lite = model.field.forward_geonetwork(pos.to(device))
+    assert not lite.requires_grad
+    assert_close("no-grad variant", lite, out, rtol=0, atol=0)
+
+
 def test_field_appearance_embedding(device):
     g = load_golden("train")
     cfg = small_oracle_cfg()
