@@ -122,6 +122,22 @@ int sdfhip_geo_forward(const SdfHipField* f, const float* packed, const float* t
 int sdfhip_geo_backward(const SdfHipField* f, const float* packed, const float* level_mask, int64_t n_points, void* workspace,
                         const float* sdf_bar, const float* feat_bar, float* theta_bar, float* table_bar, sdfhip_stream_t stream);
 
+/* Colour network as its own operator: SDFField.get_colors (sdf_field.py:532-612, ref-nerf options off) with every input supplied
+ * by the caller - the numerical-gradient path (sdf_field.py:639-644) feeds it the finite-difference d sdf / dx.
+ * feat [P, geo_feat_dim], x [P,3] (contracted positions), dirs [n_rays,3], grad [P,3] (RAW gradient, :572-578),
+ * emb [n_rays, appearance_dim] or NULL (zeros, :554-564); rgb [rows,3], rows = sdfhip_padded_points(P), P = n_rays * n_samples.
+ * workspace: sdfhip_color_workspace_size(f, P) bytes, kept until the backward. */
+int64_t sdfhip_color_workspace_size(const SdfHipField* f, int64_t n_points);
+int sdfhip_color_forward(const SdfHipField* f, const float* packed, const float* feat, const float* x, const float* dirs,
+                         const float* grad, const float* emb, int64_t n_rays, int32_t n_samples, void* workspace, float* rgb,
+                         sdfhip_stream_t stream);
+/* rgb_bar [P,3].  The colour-network entries of theta_bar are overwritten (geometry entries untouched: the caller zeroes the
+ * vector); feat_bar [P, geo_feat_dim] and grad_bar [P,3] (either may be NULL) are overwritten; emb_bar [n_rays, appearance_dim]
+ * (may be NULL) is accumulated into. */
+int sdfhip_color_backward(const SdfHipField* f, const float* packed, int64_t n_rays, int32_t n_samples, void* workspace,
+                          const float* rgb_bar, float* theta_bar, float* feat_bar, float* grad_bar, float* emb_bar,
+                          sdfhip_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------- proposal density field
  * Replaces nerfstudio.fields.density_fields.HashMLPDensityField.get_density / density_fn (:99-118; base_field.py:48-65):
  * L-inf contraction of the frustum MIDPOINT, (x+2)/4, tcnn HashGrid(5 levels, F=2, linear) + FullyFusedMLP(16, ReLU,

@@ -204,6 +204,17 @@ class relu_hook:
         return False
 
 
+def numerical_gradient(x: torch.Tensor, p: Params, cfg: FieldCfg, delta: float, mask=None):
+    """fields/sdf_field.py:431-453 (use_numerical_gradients): central differences of the sdf at x +- delta e_k, in the (contracted)
+    space x lives in.  Returns (gradients [P,3], the six tap values [6,P])."""
+    offs = torch.tensor([[delta, 0.0, 0.0], [-delta, 0.0, 0.0], [0.0, delta, 0.0], [0.0, -delta, 0.0], [0.0, 0.0, delta],
+                         [0.0, 0.0, -delta]], dtype=x.dtype)
+    pts = (x[None, :, :] + offs[:, None, :]).reshape(-1, 3)
+    taps = geo_network(pts, p, cfg, mask)[:, 0].view(6, x.shape[0])
+    grad = torch.stack([0.5 * (taps[0] - taps[1]) / delta, 0.5 * (taps[2] - taps[3]) / delta, 0.5 * (taps[4] - taps[5]) / delta], dim=-1)
+    return grad, taps
+
+
 def color_network(x, dirs, grad, feat, emb, p: Params, cfg: FieldCfg) -> torch.Tensor:
     """fields/sdf_field.py:532-612 get_colors with the ref-nerf options off. Note the RAW gradient enters (572-578)."""
     d = nerf_encoding(dirs, 4, include_input=True)
@@ -246,13 +257,21 @@ def neus_alpha(sdf, grad, dirs, deltas, inv_s, cos_anneal_ratio: float) -> torch
 
 
 def field_outputs(origins, dirs, starts, deltas, cam_idx, p: Params, cfg: FieldCfg, mask=None,
-                  cos_anneal_ratio: float = 1.0, training: bool = True) -> Dict[str, torch.Tensor]:
-    """fields/sdf_field.py:614-689 get_outputs(return_alphas=True) for a dense [N,S] sample set."""
+                  cos_anneal_ratio: float = 1.0, training: bool = True, numerical_delta: Optional[float] = None) -> Dict[str, torch.Tensor]:
+    """fields/sdf_field.py:614-689 get_outputs(return_alphas=True) for a dense [N,S] sample set.  numerical_delta: the
+    use_numerical_gradients branch (:638-644) with numerical_gradients_delta = that value."""
     n, s = starts.shape
     pos = origins[:, None, :] + dirs[:, None, :] * starts[..., None]  # cameras/rays.py:61-73 (START positions)
     x = contract_inf(pos.reshape(-1, 3))  # sdf_field.py:629
     points_norm = x.norm(dim=-1)
-    sdf, feat, grad = sdf_and_gradient(x, p, cfg, mask)
+    sampled_sdf = None
+    if numerical_delta is None:
+        sdf, feat, grad = sdf_and_gradient(x, p, cfg, mask)
+    else:
+        h = geo_network(x, p, cfg, mask)
+        sdf, feat = h[:, 0], h[:, 1:]
+        grad, taps = numerical_gradient(x, p, cfg, numerical_delta, mask)
+        sampled_sdf = taps.view(6, n, s).permute(1, 2, 0).contiguous()  # :644
     dirs_flat = dirs[:, None, :].expand(n, s, 3).reshape(-1, 3)
     if training and cfg.use_appearance_embedding:
         emb = p["embedding_appearance.embedding.weight"][cam_idx][:, None, :].expand(n, s, -1).reshape(n * s, -1)
@@ -266,7 +285,7 @@ def field_outputs(origins, dirs, starts, deltas, cam_idx, p: Params, cfg: FieldC
     return {
         "rgb": rgb.view(n, s, 3), "density": density.view(n, s), "sdf": sdf.view(n, s),
         "gradient": grad.view(n, s, 3), "normal": F.normalize(grad, p=2, dim=-1).view(n, s, 3),
-        "points_norm": points_norm.view(n, s), "alpha": alpha, "geo_feature": feat.view(n, s, -1),
+        "points_norm": points_norm.view(n, s), "alpha": alpha, "geo_feature": feat.view(n, s, -1), "sampled_sdf": sampled_sdf,
     }
 
 

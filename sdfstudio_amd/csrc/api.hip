@@ -696,6 +696,35 @@ static void run_geo_wgrads(const SdfHipField* f, const FieldWs& w, const bool ta
   }
 }
 
+// Weight gradients of the colour network (first order only).
+static void run_col_wgrads(const SdfHipField* f, const FieldWs& w, const int64_t n_tiles, float* theta_bar, hipStream_t s) {
+  const FieldKernels* k = f->k;
+  for (int l = 0; l < k->nlc; ++l) {
+    const LinearInfo& li = f->lin[f->n_geo + l];
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_pairs = 1;
+    a.nba = k->nbc;
+    a.nbb = f->kb_col(l);
+    a.n_tiles = n_tiles;
+    a.A[0] = seg1(w.d[l], k->nbc, 0);
+    a.B[0] = l == 0 ? seg2(w.feat, k->nbf, 0, w.csmall, k->nbs, 0) : seg1(w.h[l - 1], k->nbc, 0);
+    run_wgrad(f, w, a, f->c_rowmap[l], f->c_colmap[l], li.w_off, li.in_dim, 1.0f, li.b_off, theta_bar, s);
+  }
+  {
+    const LinearInfo& li = f->lin[f->n_geo + k->nlc];
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_pairs = 1;
+    a.nba = 1;
+    a.nbb = k->nbc;
+    a.n_tiles = n_tiles;
+    a.A[0] = seg1(w.dout, 1, 0);
+    a.B[0] = seg1(w.h[k->nlc - 1], k->nbc, 0);
+    run_wgrad(f, w, a, f->c_rowmap[k->nlc], f->c_colmap[k->nlc], li.w_off, li.in_dim, 1.0f, li.b_off, theta_bar, s);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ differentiable geometry network
 // forward_geonetwork (sdf_field.py:380-410) as a first-order differentiable operator on explicit positions: what the reference
 // differentiates through in the sparse-SfM loss (base_surface_model.py:463), and the building block of the numerical-gradient
@@ -831,6 +860,131 @@ extern "C" int sdfhip_geo_backward(const SdfHipField* f, const float* packed, co
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ colour network as its own operator
+// SDFField.get_colors (sdf_field.py:532-612) with every input supplied by the caller: the numerical-gradient path feeds it the
+// finite-difference normal instead of the analytic one (sdf_field.py:639-644, 655).
+static void carve_col(const SdfHipField* f, int64_t n_points, void* base, FieldWs* w) {
+  const FieldKernels* k = f->k;
+  const int64_t np = sdfhip_padded_points(n_points);
+  size_t off = 0;
+  auto take = [&](int64_t floats) {
+    float* p = base ? reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off) : nullptr;
+    off += ((size_t)floats * sizeof(float) + 255) / 256 * 256;
+    return p;
+  };
+  memset(w, 0, sizeof(*w));
+  w->feat = take(np * k->nbf * 32);
+  w->csmall = take(np * k->nbs * 32);
+  for (int l = 0; l < k->nlc; ++l) w->h[l] = take(np * k->nbc * 32);
+  w->rgb = take(np * 3);
+  for (int l = 0; l < k->nlc; ++l) w->d[l] = take(np * k->nbc * 32);
+  w->dout = take(np * 32);
+  w->featbar = take(np * k->nbf * 32);
+  w->csmallbar = take(np * k->nbs * 32);
+  const int64_t n_tiles = np / 32;
+  w->n_split = (int)std::min<int64_t>(256, n_tiles);
+  w->partial = take((int64_t)w->n_split * f->max_partial_elems);
+  w->bpartial = take((int64_t)w->n_split * f->max_partial_rows);
+  w->bytes = off;
+}
+
+extern "C" int64_t sdfhip_color_workspace_size(const SdfHipField* f, int64_t n_points) {
+  FieldWs w;
+  carve_col(f, n_points, nullptr, &w);
+  return (int64_t)w.bytes;
+}
+
+extern "C" int sdfhip_color_forward(const SdfHipField* f, const float* packed, const float* feat, const float* x, const float* dirs,
+                                    const float* grad, const float* emb, int64_t n_rays, int32_t n_samples, void* workspace,
+                                    float* rgb, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(f && packed && feat && x && dirs && grad && workspace && rgb, "color_forward: null argument");
+  SDFHIP_REQUIRE(n_samples >= 1 && n_rays >= 0, "color_forward: bad shape");
+  if (n_rays == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const FieldKernels* k = f->k;
+  const int64_t P = n_rays * n_samples, NP = sdfhip_padded_points(P);
+  FieldWs w;
+  carve_col(f, P, workspace, &w);
+  const int64_t fw = NP * k->nbf * 32;
+  totp_kernel<<<(unsigned)((fw + 255) / 256), 256, 0, s>>>(feat, k->nbf, f->cfg.geo_feat_dim, P, NP, w.feat);
+  AssembleArgs aa;
+  memset(&aa, 0, sizeof(aa));
+  aa.x = x;
+  aa.dirs = dirs;
+  aa.emb = emb;
+  aa.grad_in = grad;
+  aa.n_points = P;
+  aa.n_padded = NP;
+  aa.S = n_samples;
+  aa.pe_degree = f->cfg.pe_degree;
+  aa.use_pe = f->cfg.use_position_encoding;
+  aa.n_feat = f->n_feat;
+  aa.nb0 = k->nb0;
+  aa.nbs = k->nbs;
+  aa.emb_dim = f->cfg.appearance_dim;
+  aa.csmall_tp = w.csmall;
+  { ProfScope ps_(PS_ASSEMBLE, s); grad_assemble_kernel<<<(unsigned)(NP / 256 + (NP % 256 != 0)), 256, 0, s>>>(aa); }
+  ColFwdArgs ca;
+  memset(&ca, 0, sizeof(ca));
+  fill_col_ptrs(f, packed, &ca.p);
+  ca.feat_tp = w.feat;
+  ca.csmall_tp = w.csmall;
+  for (int l = 0; l < k->nlc; ++l) ca.h_tp[l] = w.h[l];
+  ca.rgb = w.rgb;
+  { ProfScope ps_(PS_COL_FWD, s); k->col_fwd(ca, (unsigned)(NP / 128), s); }
+  SDFHIP_CHECK_HIP(hipMemcpyAsync(rgb, w.rgb, (size_t)NP * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// d L / d (normal input) [P,3] and d L / d (appearance embedding) [N, emb_dim] out of the colour backward's small-input block
+__global__ void color_unpack_kernel(const float* __restrict__ csmallbar_tp, const int nbs, const int64_t n_points, const int S,
+                                    const int emb_dim, float* __restrict__ grad_bar, float* __restrict__ emb_bar) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_points) return;
+  if (grad_bar != nullptr) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) grad_bar[p * 3 + d] = csmallbar_tp[tp_index(p, 30 + d, nbs)];
+  }
+  if (emb_bar != nullptr)
+    for (int j = 0; j < emb_dim; ++j) atomicAdd(emb_bar + (p / S) * emb_dim + j, csmallbar_tp[tp_index(p, 33 + j, nbs)]);
+}
+
+extern "C" int sdfhip_color_backward(const SdfHipField* f, const float* packed, int64_t n_rays, int32_t n_samples, void* workspace,
+                                     const float* rgb_bar, float* theta_bar, float* feat_bar, float* grad_bar, float* emb_bar,
+                                     sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(f && packed && workspace && rgb_bar && theta_bar, "color_backward: null argument");
+  if (n_rays == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const FieldKernels* k = f->k;
+  const int64_t P = n_rays * n_samples, NP = sdfhip_padded_points(P);
+  FieldWs w;
+  carve_col(f, P, workspace, &w);
+  ColBwdArgs cb;
+  memset(&cb, 0, sizeof(cb));
+  fill_col_ptrs(f, packed, &cb.p);
+  cb.rgb = w.rgb;
+  cb.rgbbar = rgb_bar;
+  cb.n_points = P;
+  for (int l = 0; l < k->nlc; ++l) {
+    cb.h_tp[l] = w.h[l];
+    cb.d_tp[l] = w.d[l];
+  }
+  cb.dout_tp = w.dout;
+  cb.featbar_tp = w.featbar;
+  cb.csmallbar_tp = w.csmallbar;
+  { ProfScope ps_(PS_COL_BWD, s); k->col_bwd(cb, (unsigned)(NP / 128), s); }
+  if (feat_bar != nullptr) {
+    const int64_t total = P * f->cfg.geo_feat_dim;
+    untp_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(w.featbar, k->nbf, f->cfg.geo_feat_dim, P, feat_bar);
+  }
+  color_unpack_kernel<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(w.csmallbar, k->nbs, P, n_samples, f->cfg.appearance_dim, grad_bar,
+                                                                  emb_bar);
+  run_col_wgrads(f, w, NP / 32, theta_bar, s);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
                                      int64_t n_rays, int32_t n_samples, void* workspace, const float* sdf_bar, const float* grad_bar,
                                      const float* rgb_bar, float* theta_bar, float* table_bar, float* emb_bar,
@@ -935,30 +1089,7 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
   // 5. weight gradients: split-K GEMMs over points
   const int64_t n_tiles = NP / 32;
   run_geo_wgrads(f, w, true, n_tiles, theta_bar, s);
-  for (int l = 0; l < k->nlc; ++l) {
-    const LinearInfo& li = f->lin[f->n_geo + l];
-    WgradArgs a;
-    memset(&a, 0, sizeof(a));
-    a.n_pairs = 1;
-    a.nba = k->nbc;
-    a.nbb = f->kb_col(l);
-    a.n_tiles = n_tiles;
-    a.A[0] = seg1(w.d[l], k->nbc, 0);
-    a.B[0] = l == 0 ? seg2(w.feat, k->nbf, 0, w.csmall, k->nbs, 0) : seg1(w.h[l - 1], k->nbc, 0);
-    run_wgrad(f, w, a, f->c_rowmap[l], f->c_colmap[l], li.w_off, li.in_dim, 1.0f, li.b_off, theta_bar, s);
-  }
-  {
-    const LinearInfo& li = f->lin[f->n_geo + k->nlc];
-    WgradArgs a;
-    memset(&a, 0, sizeof(a));
-    a.n_pairs = 1;
-    a.nba = 1;
-    a.nbb = k->nbc;
-    a.n_tiles = n_tiles;
-    a.A[0] = seg1(w.dout, 1, 0);
-    a.B[0] = seg1(w.h[k->nlc - 1], k->nbc, 0);
-    run_wgrad(f, w, a, f->c_rowmap[k->nlc], f->c_colmap[k->nlc], li.w_off, li.in_dim, 1.0f, li.b_off, theta_bar, s);
-  }
+  run_col_wgrads(f, w, n_tiles, theta_bar, s);
   if (ev_join != nullptr) {
     SDFHIP_CHECK_HIP(hipStreamWaitEvent(s, ev_join, 0));
     (void)hipEventDestroy(ev_join);

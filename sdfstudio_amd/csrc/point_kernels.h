@@ -220,8 +220,9 @@ struct AssembleArgs {
   const float* emb;     // [N][emb_dim] per-ray appearance embedding or null (zeros)
   int64_t n_points, n_padded;
   int32_t S, pe_degree, use_pe, n_feat, nb0, nbs, emb_dim, pad_;
-  float* grad;          // [n_padded][3]
+  float* grad;          // [n_padded][3]  (null with grad_in)
   float* csmall_tp;     // [T][nbs]
+  const float* grad_in; // [P][3] or null: take d sdf / dx from the caller instead of assembling it from e_tp (numerical gradients)
 };
 
 // block = 256 threads over points
@@ -234,9 +235,9 @@ __global__ __launch_bounds__(256) void grad_assemble_kernel(const AssembleArgs a
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       x[d] = a.x[p * 3 + d];
-      g[d] = a.e_tp[tp_index(p, d, a.nb0)];
+      g[d] = a.grad_in != nullptr ? a.grad_in[p * 3 + d] : a.e_tp[tp_index(p, d, a.nb0)];
     }
-    if (a.use_pe) {
+    if (a.use_pe && a.grad_in == nullptr) {
       for (int d = 0; d < 3; ++d)
         for (int f = 0; f < a.pe_degree; ++f) {
           const float fr = (float)(1 << f);
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(256) void grad_assemble_kernel(const AssembleArgs a
         }
     }
     const int feat0 = 3 + 6 * a.pe_degree;
-    for (int c = 0; c < a.n_feat; ++c) {
+    for (int c = 0; c < (a.grad_in == nullptr ? a.n_feat : 0); ++c) {
       const float ec = a.e_tp[tp_index(p, feat0 + c, a.nb0)] * a.mask[c] * 0.25f;
 #pragma unroll
       for (int d = 0; d < 3; ++d) g[d] = fmaf(ec, a.dydp[(size_t)(c * 3 + d) * a.n_padded + p], g[d]);
@@ -256,8 +257,10 @@ __global__ __launch_bounds__(256) void grad_assemble_kernel(const AssembleArgs a
 #pragma unroll
     for (int d = 0; d < 3; ++d) dir[d] = a.dirs[ray * 3 + d];
   }
+  if (a.grad != nullptr) {
 #pragma unroll
-  for (int d = 0; d < 3; ++d) a.grad[p * 3 + d] = g[d];
+    for (int d = 0; d < 3; ++d) a.grad[p * 3 + d] = g[d];
+  }
   // colour-network small inputs: x(3) | PE(dir): sin(d 2^f) (12), sin(d 2^f + pi/2) (12), d (3) | grad (3) | emb
 #pragma unroll
   for (int d = 0; d < 3; ++d) a.csmall_tp[tp_index(p, d, a.nbs)] = x[d];

@@ -211,6 +211,53 @@ class _GeoNetFunction(torch.autograd.Function):
         return theta_bar, table_bar, None, None, None
 
 
+class _ColorFunction(torch.autograd.Function):
+    """get_colors (sdf_field.py:532-612) as its own autograd node: (theta, feat, grad[, emb]) -> rgb.  Used by the
+    numerical-gradient path, where the normal fed to the colour network is a finite difference of six more sdf evaluations."""
+
+    @staticmethod
+    def forward(ctx, theta, feat, grad, emb, fld, x, dirs, n, s):
+        lib = _lib.load()
+        dev = theta.device
+        P = n * s
+        NP = _lib.padded_points(P)
+        h = fld._handle
+        packed = torch.empty(lib.sdfhip_field_packed_size(h), device=dev)
+        _lib.check(lib.sdfhip_field_pack(h, _lib.ptr(theta.contiguous()), _lib.ptr(packed), _lib.stream()), "field_pack")
+        ws = torch.empty(lib.sdfhip_color_workspace_size(h, P), dtype=torch.uint8, device=dev)
+        rgb = torch.empty(NP, 3, device=dev)
+        emb_c = None if emb is None else emb.contiguous()
+        _lib.check(lib.sdfhip_color_forward(h, _lib.ptr(packed), _lib.ptr(feat.contiguous()), _lib.ptr(x.contiguous()),
+                                            _lib.ptr(dirs.contiguous()), _lib.ptr(grad.contiguous()), _lib.ptr(emb_c), n, s,
+                                            ctypes.c_void_p(ws.data_ptr()), _lib.ptr(rgb), _lib.stream()), "color_forward")
+        ctx.save_for_backward(packed, ws)
+        ctx.fld, ctx.shape, ctx.has_emb = fld, (n, s), emb is not None
+        return rgb[:P]
+
+    @staticmethod
+    def backward(ctx, rgb_bar):
+        packed, ws = ctx.saved_tensors
+        lib = _lib.load()
+        fld = ctx.fld
+        n, s = ctx.shape
+        dev = packed.device
+        h = fld._handle
+        theta_bar = torch.zeros(lib.sdfhip_field_theta_size(h), device=dev)  # geometry entries stay zero
+        feat_bar = torch.empty(n * s, fld.config.geo_feat_dim, device=dev)
+        grad_bar = torch.empty(n * s, 3, device=dev)
+        emb_bar = torch.zeros(n, fld.config.appearance_embedding_dim, device=dev) if ctx.has_emb else None
+        _lib.check(lib.sdfhip_color_backward(h, _lib.ptr(packed), n, s, ctypes.c_void_p(ws.data_ptr()), _lib.ptr(rgb_bar.contiguous()),
+                                             _lib.ptr(theta_bar), _lib.ptr(feat_bar), _lib.ptr(grad_bar), _lib.ptr(emb_bar),
+                                             _lib.stream()), "color_backward")
+        return theta_bar, feat_bar, grad_bar, emb_bar, None, None, None, None, None
+
+
+def _contract_inf(x: torch.Tensor) -> torch.Tensor:
+    """SceneContraction(order=inf), field_components/spatial_distortions.py:66-92."""
+    mag = x.abs().amax(dim=-1, keepdim=True)
+    return torch.where(mag < 1.0, x, (2.0 - 1.0 / mag.clamp_min(1e-30)) * (x / mag.clamp_min(1e-30)))
+
+
 class SDFField(nn.Module):
     """fields/sdf_field.py:188-698."""
 
@@ -227,8 +274,6 @@ class SDFField(nn.Module):
             unsupported.append("ref-nerf colour options")
         if c.off_axis:
             unsupported.append("off_axis")
-        if c.use_numerical_gradients:
-            unsupported.append("use_numerical_gradients (neus-facto-angelo path, next round)")
         if not c.weight_norm:
             unsupported.append("weight_norm=False")
         if unsupported:
@@ -298,6 +343,7 @@ class SDFField(nn.Module):
 
         self._cos_anneal_ratio = 1.0
         self.numerical_gradients_delta = 0.0001
+        self.last_sampled_sdf = None  # [N,S,6] tap values of the latest numerical-gradient forward (curvature loss)
 
         # ---- native descriptor
         skip = 4 if c.num_layers > 4 else -1
@@ -403,6 +449,44 @@ class SDFField(nn.Module):
         sdf, _ = self._run_inference(_lib.MODE_SDF, o, d, st, n, s, False)
         return sdf.view(n, s, 1)
 
+    def _tap_offsets(self, like: torch.Tensor) -> torch.Tensor:
+        d = self.numerical_gradients_delta
+        return torch.tensor([[d, 0, 0], [-d, 0, 0], [0, d, 0], [0, -d, 0], [0, 0, d], [0, 0, -d]], dtype=like.dtype, device=like.device)
+
+    def gradient(self, x, skip_spatial_distortion=False, return_sdf=False):
+        """sdf_field.py:424-467, numerical mode: central differences of six more evaluations of the geometry network at
+        x +- delta e_k (in contracted space), differentiable w.r.t. the parameters."""
+        shape = x.shape[:-1]
+        x = x.reshape(-1, 3).float()
+        if self.spatial_distortion is not None and not skip_spatial_distortion:
+            x = _contract_inf(x)
+        if self.config.use_numerical_gradients:
+            delta = self.numerical_gradients_delta
+            taps = (x[None, :, :] + self._tap_offsets(x)[:, None, :]).reshape(-1, 3)
+            points_sdf = self.forward_geonetwork(taps)[:, 0].view(6, *shape)
+            gradients = torch.stack([0.5 * (points_sdf[0] - points_sdf[1]) / delta, 0.5 * (points_sdf[2] - points_sdf[3]) / delta,
+                                     0.5 * (points_sdf[4] - points_sdf[5]) / delta], dim=-1)
+            return (gradients, points_sdf) if return_sdf else gradients
+        raise NotImplementedError("gradient() is built for use_numerical_gradients=True; the analytic d sdf / dx (with its autograd "
+                                  "graph) comes out of get_outputs / forward_fused")
+
+    def _numerical_outputs(self, ray_samples, o, d, st, emb):
+        """get_outputs with use_numerical_gradients (sdf_field.py:629-655): geometry network at the contracted start positions
+        and at the six taps in ONE differentiable call (7 P points), finite-difference normal, colour network on it."""
+        n, s = st.shape
+        pos = (o[:, None, :] + d[:, None, :] * st[..., None]).reshape(-1, 3)
+        x = _contract_inf(pos) if self.spatial_distortion is not None else pos
+        P = x.shape[0]
+        delta = self.numerical_gradients_delta
+        pts = torch.cat([x[None], x[None, :, :] + self._tap_offsets(x)[:, None, :]], dim=0).reshape(-1, 3)
+        h = self.forward_geonetwork(pts)
+        sdf, feat = h[:P, 0], h[:P, 1:]
+        taps = h[P:, 0].view(6, P)
+        grad = torch.stack([0.5 * (taps[0] - taps[1]) / delta, 0.5 * (taps[2] - taps[3]) / delta, 0.5 * (taps[4] - taps[5]) / delta], dim=-1)
+        rgb = _ColorFunction.apply(self._theta(), feat, grad, emb, self, x.detach(), d, n, s)
+        sampled_sdf = taps.view(6, n, s).permute(1, 2, 0).contiguous()  # :644
+        return sdf.view(n, s), grad.view(n, s, 3), rgb.view(n, s, 3), x.detach().view(n, s, 3), sampled_sdf
+
     def get_density(self, ray_samples):
         """sdf_field.py:469-475: Laplace density and geometry feature at the frustum START positions (no contraction, no grad)."""
         o, d, st, _ = unpack_ray_samples(ray_samples)
@@ -443,8 +527,12 @@ class SDFField(nn.Module):
                 emb = self.embedding_appearance(cam)
             elif self.use_average_appearance_embedding:
                 emb = self.embedding_appearance.mean(dim=0)[None, :].expand(n, -1)
-        theta = self._theta()
-        sdf, grad, rgb, x = _FieldFunction.apply(theta, self.encoding.params, emb, self, o, d, st, self._mask(dev))
+        sampled_sdf = None
+        if self.config.use_numerical_gradients:
+            sdf, grad, rgb, x, sampled_sdf = self._numerical_outputs(ray_samples, o, d, st, emb)
+        else:
+            theta = self._theta()
+            sdf, grad, rgb, x = _FieldFunction.apply(theta, self.encoding.params, emb, self, o, d, st, self._mask(dev))
         sdf3 = sdf[..., None]
         outputs = {
             FieldHeadNames.RGB: rgb,
@@ -453,7 +541,7 @@ class SDFField(nn.Module):
             FieldHeadNames.NORMAL: F.normalize(grad, p=2, dim=-1),
             FieldHeadNames.GRADIENT: grad,
             "points_norm": x.norm(dim=-1, keepdim=True),
-            "sampled_sdf": None,
+            "sampled_sdf": sampled_sdf,
         }
         if return_alphas:
             outputs[FieldHeadNames.ALPHA] = self.get_alpha(ray_samples, sdf3, grad)
@@ -475,4 +563,7 @@ class SDFField(nn.Module):
         emb = None
         if self.config.use_appearance_embedding and self.training:
             emb = self.embedding_appearance(ray_samples.camera_indices.reshape(n, -1)[:, 0])
+        if self.config.use_numerical_gradients:
+            sdf, grad, rgb, x, self.last_sampled_sdf = self._numerical_outputs(ray_samples, o, d, st, emb)
+            return sdf, grad, rgb, x
         return _FieldFunction.apply(self._theta(), self.encoding.params, emb, self, o, d, st, self._mask(o.device))

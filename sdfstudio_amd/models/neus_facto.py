@@ -61,6 +61,7 @@ class NeuSFactoModelConfig:
         ]
     )
     interlevel_loss_mult: float = 1.0
+    curvature_loss_multi: float = 0.0
     use_proposal_weight_anneal: bool = True
     proposal_weights_anneal_slope: float = 10.0
     proposal_weights_anneal_max_num_iters: int = 1000
@@ -165,7 +166,8 @@ class NeuSFactoModel(nn.Module):
             ray_samples.flat_ends, self.field._cos_anneal_ratio, bg)
         field_outputs = {
             FieldHeadNames.RGB: rgb, FieldHeadNames.SDF: sdf[..., None], FieldHeadNames.GRADIENT: grad,
-            FieldHeadNames.ALPHA: alpha[..., None], "points_norm": x.norm(dim=-1, keepdim=True), "sampled_sdf": None,
+            FieldHeadNames.ALPHA: alpha[..., None], "points_norm": x.norm(dim=-1, keepdim=True),
+            "sampled_sdf": self.field.last_sampled_sdf if self.field.config.use_numerical_gradients else None,
         }
         weights_list.append(weights[..., None])
         ray_samples_list.append(ray_samples)
@@ -218,6 +220,15 @@ class NeuSFactoModel(nn.Module):
             weights = [w[..., 0] for w in outputs["weights_list"]]
             bins = [rs.flat_bins for rs in outputs["ray_samples_list"]]
             loss["interlevel_loss"] = c.interlevel_loss_mult * interlevel_loss_zip(weights, bins)
+            if c.curvature_loss_multi > 0.0:  # neus_facto.py:312-325 (numerical-gradient field: the six tap values are on hand)
+                fo = outputs["field_outputs"]
+                if fo["sampled_sdf"] is None:
+                    raise ValueError("curvature_loss_multi > 0 needs sdf_field.use_numerical_gradients=True")
+                delta = self.field.numerical_gradients_delta
+                centered = fo[FieldHeadNames.SDF]
+                surrounding = fo["sampled_sdf"].reshape(centered.shape[:2] + (3, 2))
+                curvature = (surrounding.sum(dim=-1) - 2 * centered) / (delta * delta)
+                loss["curvature_loss"] = curvature.abs().mean() * c.curvature_loss_multi * getattr(self, "curvature_loss_multi_factor", 1.0)
         return loss
 
     def get_metrics_dict(self, outputs, batch) -> Dict[str, torch.Tensor]:

@@ -591,6 +591,80 @@ def main_volsdf():
         print("wrote", path, f"{os.path.getsize(path) / 1024:.0f} KiB")
 
 
+def main_numgrad():
+    """use_numerical_gradients (the neus-facto-angelo field mode, sdf_field.py:431-453,638-644) on the small configuration:
+    the reference SDFField evaluated on fixed ray samples, its finite-difference normals, `sampled_sdf`, the colour network
+    on those normals, and the gradients of rgb-L1 + eikonal + curvature (neus_facto.py:312-325) w.r.t. every field parameter.
+    Writes tests/golden/numgrad_small_train.npz."""
+    ns = ref_harness.import_reference()
+    cfg = small_cfg()
+    p = {k: v for k, v in perturbed_params(cfg).items() if not k.startswith("proposal_networks.")}
+    n, s = 40, 24
+    delta = 1.0 / 128.0  # a coarse-level step as the delta schedule sets it early in training (neus_facto.py:209-225)
+    origins, dirs, cam = O.synthetic_rays(n, seed=44)
+    g = torch.Generator().manual_seed(11)
+    starts = torch.sort(torch.rand(n, s, generator=g) * (cfg.far - cfg.near) + cfg.near, dim=-1).values
+    ends = torch.cat([starts[:, 1:], torch.full((n, 1), cfg.far)], dim=-1)
+    image = torch.rand(n, s, 3, generator=g)
+    curv_mult = 5e-4
+    field, _, _ = build_reference(ns, O.ModelCfg(field=cfg.field, proposals=()), p)
+    field.config.use_numerical_gradients = True
+    field.set_numerical_gradients_delta(delta)
+    field.train(True)
+    H = ns.FieldHeadNames
+    rb = ns.rays.RayBundle(origins=origins, directions=dirs, pixel_area=torch.ones(n, 1), directions_norm=torch.ones(n, 1),
+                           camera_indices=cam[:, None], nears=torch.full((n, 1), cfg.near), fars=torch.full((n, 1), cfg.far))
+    rs = rb.get_ray_samples(bin_starts=starts[..., None], bin_ends=ends[..., None])
+    fo = field(rs)
+    sur = fo["sampled_sdf"].reshape(n, s, 3, 2)
+    curvature = (sur.sum(dim=-1) - 2 * fo[H.SDF]) / (delta * delta)
+    losses = {"rgb_loss": torch.nn.L1Loss()(image, fo[H.RGB]),
+              "eikonal_loss": ((fo[H.GRADIENT].norm(2, dim=-1) - 1) ** 2).mean() * cfg.eikonal_loss_mult,
+              "curvature_loss": torch.abs(curvature).mean() * curv_mult}
+    field.zero_grad()
+    sum(losses.values()).backward()
+    ref_grads = {k: v.grad.clone() for k, v in field.named_parameters() if v.grad is not None}
+    out = {"sdf": fo[H.SDF][..., 0], "gradient": fo[H.GRADIENT], "field_rgb": fo[H.RGB], "sampled_sdf": fo["sampled_sdf"],
+           "normal": fo[H.NORMAL]}
+    # ---- oracle on the same inputs
+    po = {k: v.clone().requires_grad_(v.is_floating_point() and k != "laplace_density.beta_min") for k, v in p.items()}
+    o = O.field_outputs(origins, dirs, starts, ends - starts, cam, po, cfg.field, None, 1.0, True, numerical_delta=delta)
+    omap = {"sdf": o["sdf"], "gradient": o["gradient"], "field_rgb": o["rgb"], "sampled_sdf": o["sampled_sdf"], "normal": o["normal"]}
+    worst = 0.0
+    for k, v in out.items():
+        err = (omap[k].detach() - v.detach()).abs().max().item()
+        scale = v.detach().abs().max().item() + 1e-12
+        worst = max(worst, err / scale)
+        # the finite difference divides fp32 round-off of the sdf (1e-7) by 2 delta
+        tol = 1e-4 if k in ("gradient", "normal") else 2e-5
+        assert err <= tol * scale + 1e-6, f"[numgrad] oracle != reference on {k}: abs {err:.3e} (scale {scale:.3e})"
+    ol = {"rgb_loss": torch.nn.functional.l1_loss(o["rgb"], image),
+          "eikonal_loss": ((o["gradient"].norm(2, dim=-1) - 1) ** 2).mean() * cfg.eikonal_loss_mult,
+          "curvature_loss": ((o["sampled_sdf"].reshape(n, s, 3, 2).sum(-1) - 2 * o["sdf"][..., None]) / (delta * delta)).abs().mean() * curv_mult}
+    for k in losses:
+        assert abs(ol[k].item() - losses[k].item()) <= 2e-4 * abs(losses[k].item()) + 1e-8, (k, ol[k].item(), losses[k].item())
+    sum(ol.values()).backward()
+    for k, gref in ref_grads.items():
+        err = (po[k].grad - gref).abs().max().item()
+        scale = gref.abs().max().item() + 1e-12
+        worst = max(worst, err / scale)
+        assert err <= 2e-3 * scale + 1e-9, f"[numgrad] oracle grad != reference on {k}: {err:.3e} / {scale:.3e}"
+    print(f"[numgrad] oracle reproduces the reference; worst rel err {worst:.2e}")
+    blob = {"in/origins": origins, "in/dirs": dirs, "in/cam": cam, "in/starts": starts, "in/ends": ends, "in/image": image,
+            "in/delta": torch.tensor(delta), "in/curv_mult": torch.tensor(curv_mult)}
+    for k, v in p.items():
+        blob[f"param/{k}"] = v
+    for k, v in out.items():
+        blob[f"out/{k}"] = v.detach()
+    for k, v in losses.items():
+        blob[f"loss/{k}"] = v.detach()
+    for k, v in ref_grads.items():
+        blob[f"grad/{k}"] = v
+    path = os.path.join(HERE, "numgrad_small_train.npz")
+    np.savez_compressed(path, **{k: v.detach().numpy() for k, v in blob.items()})
+    print("wrote", path, f"{os.path.getsize(path) / 1e6:.2f} MB")
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "all"
     if which in ("all", "facto"):
@@ -599,3 +673,5 @@ if __name__ == "__main__":
         main_neus()
     if which in ("all", "volsdf"):
         main_volsdf()
+    if which in ("all", "numgrad"):
+        main_numgrad()

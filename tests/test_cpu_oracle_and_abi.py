@@ -324,3 +324,27 @@ def test_bench_algorithmic_bytes_of_geo_bwd():
     blocks += 3 + 3 + 3
     assert blocks == 460
     assert bench.geo_bwd_algorithmic_bytes() == 128 * blocks == 58880
+
+
+def test_oracle_numerical_gradients_against_reference_golden():
+    """use_numerical_gradients branch (sdf_field.py:431-453,638-644) + curvature loss (neus_facto.py:312-325): the oracle on the
+    golden inputs reproduces the reference's outputs, losses and parameter gradients (tests/golden/make_golden.py numgrad)."""
+    from helpers import load_golden_file, small_oracle_cfg
+
+    g = load_golden_file("numgrad_small_train.npz")
+    cfg = small_oracle_cfg()
+    i, ref = g["in"], g["out"]
+    delta, n, s = float(i["delta"]), i["starts"].shape[0], i["starts"].shape[1]
+    po = {k: v.clone().requires_grad_(v.is_floating_point() and k != "laplace_density.beta_min") for k, v in g["param"].items()}
+    o = O.field_outputs(i["origins"], i["dirs"], i["starts"], i["ends"] - i["starts"], i["cam"], po, cfg.field, None, 1.0, True,
+                        numerical_delta=delta)
+    assert (o["sdf"] - ref["sdf"]).abs().max().item() <= 2e-6
+    assert (o["sampled_sdf"] - ref["sampled_sdf"]).abs().max().item() <= 2e-6
+    assert (o["gradient"] - ref["gradient"]).abs().max().item() <= 1e-4 * ref["gradient"].abs().max().item()
+    assert (o["rgb"] - ref["field_rgb"]).abs().max().item() <= 2e-5
+    curv = ((o["sampled_sdf"].reshape(n, s, 3, 2).sum(-1) - 2 * o["sdf"][..., None]) / (delta * delta)).abs().mean() * float(i["curv_mult"])
+    loss = torch.nn.functional.l1_loss(o["rgb"], i["image"]) + ((o["gradient"].norm(2, dim=-1) - 1) ** 2).mean() * cfg.eikonal_loss_mult + curv
+    assert abs(curv.item() - g["loss"]["curvature_loss"].item()) <= 2e-4 * g["loss"]["curvature_loss"].item()
+    loss.backward()
+    for k, gref in g["grad"].items():
+        assert (po[k].grad - gref).abs().max().item() <= 2e-3 * gref.abs().max().item() + 1e-9, k
