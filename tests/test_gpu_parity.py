@@ -903,3 +903,43 @@ def test_numerical_gradient_field_against_reference_golden(device):
     assert len(g["grad"]) >= 40
     _, basis = relu_flip_basis(oracle_backward, margin=3e-5)  # the finite-difference normal carries ~1e-4 of noise into the colour net
     assert_grads_close_mod_relu_flips(got, g["grad"], basis, rtol=5e-3)
+
+
+def test_numerical_gradient_model_step_properties(device):
+    """neus-facto-angelo flavour of the step at BASELINE config 2's network shape: numerical gradients with the delta of the
+    coarsest active level, progressive level mask, curvature loss on `sampled_sdf` (method_configs.py:381-450,
+    neus_facto.py:209-225,312-325).  Size-independent properties of one training step."""
+    cfg = O.ModelCfg(field=O.FieldCfg(bias=0.5, inside_outside=False, beta_init=0.3))
+    p = O.init_field_params(cfg.field, seed=0)
+    p.update(O.init_proposal_params(cfg.proposals))
+    model = product_model_from_params(p, cfg, device).train()
+    fld = model.field
+    fld.config.use_numerical_gradients = True
+    model.config.curvature_loss_multi = 5e-4
+    level = 8
+    fld.update_mask(level)                                                               # sdf_field.py:376-378
+    fld.set_numerical_gradients_delta(1.0 / (fld.base_res * fld.growth_factor ** (level - 1)))  # neus_facto.py:219-222
+    n = 512
+    o, d, cam = O.synthetic_rays(n)
+    out = model(_bundle(o, d, cam, cfg.near, cfg.far, device))
+    fo = out["field_outputs"]
+    assert fo["sampled_sdf"].shape == (n, 128, 6) and torch.isfinite(fo["sampled_sdf"]).all()
+    w = out["weights"][..., 0]
+    assert (w >= 0).all() and (w.sum(1) <= 1 + 1e-4).all() and torch.isfinite(out["rgb"]).all()
+    g = out["eik_grad"]
+    inside = out["points_norm"][..., 0] < 0.9
+    assert ((g.norm(dim=-1) - 1).abs()[inside]).mean() < 0.3  # finite-difference normal of the sphere init is still ~ unit
+    losses = model.get_loss_dict(out, {"image": torch.rand(n, 3)})
+    assert "curvature_loss" in losses and torch.isfinite(losses["curvature_loss"]) and losses["curvature_loss"] > 0
+    sum(losses.values()).backward()
+    table_grad = None
+    for k, prm in model.named_parameters():
+        if prm.requires_grad and "embedding" not in k and "laplace_density" not in k:
+            assert prm.grad is not None and torch.isfinite(prm.grad).all(), k
+        if k.endswith("encoding.params") and k.startswith("field"):
+            table_grad = prm.grad
+    # masked levels (>= level) receive exactly zero gradient (what lets DDP skip them, SURVEY 8e)
+    first_masked = fld.encoding.levels[level].offset
+    assert table_grad.view(-1, 2)[first_masked:].abs().max().item() == 0.0
+    # (at geometric init the first layer ignores the grid features, sdf_field.py:296-299, so the active levels' gradient is
+    # zero too; the non-trivial table gradients are checked against the reference in the golden test above)
