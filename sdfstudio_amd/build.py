@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libsdfhip.so")
-SOURCES = ["inst_a_fwd.hip", "inst_a_bwd.hip", "inst_a_inf.hip", "api.hip", "inst_a.hip", "inst_b.hip"]  # slowest first
+SOURCES = ["inst_a_fwd.hip", "inst_a_bwd.hip", "inst_a_inf.hip", "api.hip", "inst_a.hip", "inst_b.hip", "inst_c.hip"]  # slowest first
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-function"]
 
 

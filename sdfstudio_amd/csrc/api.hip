@@ -12,6 +12,7 @@
 
 const FieldKernels* sdfhip_kernels_A();
 const FieldKernels* sdfhip_kernels_B();
+const FieldKernels* sdfhip_kernels_C();
 
 static thread_local char g_err[1024] = "";
 void sdfhip_set_error(const char* fmt, ...) {
@@ -88,7 +89,8 @@ extern "C" int sdfhip_profile_read(int slot, double* total_ms, int64_t* count) {
 extern "C" int sdfhip_grid_levels(const SdfHipGridCfg* cfg, SdfHipGridLevel* levels, int64_t* n_entries) {
   SDFHIP_REQUIRE(cfg != nullptr, "grid cfg is null");
   SDFHIP_REQUIRE(cfg->n_levels >= 1 && cfg->n_levels <= kMaxLevels, "n_levels %d out of range [1,%d]", cfg->n_levels, kMaxLevels);
-  SDFHIP_REQUIRE(cfg->n_features == 2, "only n_features_per_level == 2 is built (got %d)", cfg->n_features);
+  SDFHIP_REQUIRE(cfg->n_features >= 2 && cfg->n_features <= 8 && cfg->n_features % 2 == 0,
+                 "n_features_per_level must be 2, 4, 6 or 8 (got %d)", cfg->n_features);
   SDFHIP_REQUIRE(cfg->log2_hashmap_size >= 4 && cfg->log2_hashmap_size <= 24, "log2_hashmap_size %d unsupported", cfg->log2_hashmap_size);
   // tiny-cuda-nn GridEncoding constructor arithmetic, in fp32 (see oracle/hashgrid.py for the statement)
   const float l2 = log2f(cfg->per_level_scale);
@@ -200,7 +202,7 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
   if (skip >= 0 && (skip < 1 || skip >= NL || H - D0 <= 0)) return fail("bad skip layer");
   if (NL + 1 > kMaxLayers || NLC + 1 > kMaxLayers) return fail("too many layers");
   const int nb0 = (D0 + 31) / 32, nb3 = skip >= 0 ? (H - D0 + 31) / 32 : 0, nbs = (33 + E + 31) / 32;
-  const FieldKernels* cands[] = {sdfhip_kernels_A(), sdfhip_kernels_B()};
+  const FieldKernels* cands[] = {sdfhip_kernels_A(), sdfhip_kernels_B(), sdfhip_kernels_C()};
   f->k = nullptr;
   for (const FieldKernels* k : cands) {
     if (k->nbh == H / 32 && k->nb0 == nb0 && k->nb3 == nb3 && k->nl == NL && k->skip == skip && k->nbf == GF / 32 && k->nbs == nbs &&
@@ -523,7 +525,7 @@ extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, c
   ea.x_out = w.x;
   ea.in0_tp = w.in0;
   ea.dydp = full ? w.dydp : nullptr;
-  { ProfScope ps_(PS_ENCODE, s); geo_encode_kernel<<<dim3((unsigned)(NP / 256 + (NP % 256 != 0)), f->grid.n_levels + 1), 256, 0, s>>>(ea); }
+  { ProfScope ps_(PS_ENCODE, s); geo_encode_kernel<<<dim3((unsigned)(NP / 256 + (NP % 256 != 0)), f->grid.n_levels * (f->grid.n_features / 2) + 1), 256, 0, s>>>(ea); }
 
   GeoFwdArgs ga;
   memset(&ga, 0, sizeof(ga));
@@ -799,7 +801,7 @@ extern "C" int sdfhip_geo_forward(const SdfHipField* f, const float* packed, con
   ea.mask = level_mask;
   ea.x_out = w.x;
   ea.in0_tp = w.in0;
-  { ProfScope ps_(PS_ENCODE, s); geo_encode_kernel<<<dim3((unsigned)(NP / 256 + (NP % 256 != 0)), f->grid.n_levels + 1), 256, 0, s>>>(ea); }
+  { ProfScope ps_(PS_ENCODE, s); geo_encode_kernel<<<dim3((unsigned)(NP / 256 + (NP % 256 != 0)), f->grid.n_levels * (f->grid.n_features / 2) + 1), 256, 0, s>>>(ea); }
   GeoFwdArgs ga;
   memset(&ga, 0, sizeof(ga));
   fill_geo_ptrs(f, packed, &ga.p);
@@ -853,7 +855,7 @@ extern "C" int sdfhip_geo_backward(const SdfHipField* f, const float* packed, co
   ga.pe_degree = f->cfg.pe_degree;
   ga.nb0 = k->nb0;
   ga.tablebar = table_bar;
-  { ProfScope ps_(PS_GRID_BWD, s); grid_bwd_kernel<<<dim3((unsigned)((P + 255) / 256), f->grid.n_levels), 256, 0, s>>>(ga); }
+  { ProfScope ps_(PS_GRID_BWD, s); grid_bwd_kernel<<<dim3((unsigned)((P + 255) / 256), f->grid.n_levels * (f->grid.n_features / 2)), 256, 0, s>>>(ga); }
 
   run_geo_wgrads(f, w, false, NP / 32, theta_bar, s);
   SDFHIP_CHECK_HIP(hipGetLastError());
@@ -1082,7 +1084,7 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
       (void)hipEventDestroy(ev_fork);  // released once the wait has consumed it
       gs = f->side;
     }
-    { ProfScope ps_(PS_GRID_BWD, gs); grid_bwd_kernel<<<dim3((unsigned)((P + 255) / 256), f->grid.n_levels), 256, 0, gs>>>(ga); }
+    { ProfScope ps_(PS_GRID_BWD, gs); grid_bwd_kernel<<<dim3((unsigned)((P + 255) / 256), f->grid.n_levels * (f->grid.n_features / 2)), 256, 0, gs>>>(ga); }
     if (ev_join != nullptr) SDFHIP_CHECK_HIP(hipEventRecord(ev_join, gs));
   }
 

@@ -151,11 +151,13 @@ __global__ __launch_bounds__(256) void geo_encode_kernel(const EncodeArgs a) {
     start_position(a.origins, a.dirs, a.starts, p, a.S, x);
     if (a.contract) contract_inf(x);
   }
-  const int L = a.grid.n_levels;
-  const int level = blockIdx.y;
+  // blockIdx.y = level * (F / 2) + feature pair; the last y is the position / positional-encoding block.  An F-feature level is
+  // F / 2 two-feature gathers that share the cell (hash_features_per_level = 8 in the neus-facto-angelo preset).
+  const int L = a.grid.n_levels, F = a.grid.n_features, pairs = F >> 1;
+  const int level = blockIdx.y / pairs, pair = blockIdx.y % pairs;
   const int pe_dims = 6 * a.pe_degree;
   const int feat0 = 3 + pe_dims;
-  if (level == L) {
+  if ((int)blockIdx.y == L * pairs) {
     // position + positional encoding + zero padding  (encodings.py:167-208: sin(cat[x f, x f + pi/2]))
     a.x_out[p * 3 + 0] = x[0];
     a.x_out[p * 3 + 1] = x[1];
@@ -173,8 +175,9 @@ __global__ __launch_bounds__(256) void geo_encode_kernel(const EncodeArgs a) {
     for (int c = feat0 + L * a.grid.n_features; c < a.nb0 * 32; ++c) a.in0_tp[tp_index(p, c, a.nb0)] = 0.0f;
     return;
   }
-  // ---- one grid level (F == 2)
-  const float m0 = a.mask[level * 2 + 0], m1 = a.mask[level * 2 + 1];
+  // ---- one feature pair of one grid level
+  const int c0 = level * F + pair * 2;
+  const float m0 = a.mask[c0 + 0], m1 = a.mask[c0 + 1];
   float y0 = 0.f, y1 = 0.f, d0[3] = {0.f, 0.f, 0.f}, d1[3] = {0.f, 0.f, 0.f};
   if (live && (m0 != 0.0f || m1 != 0.0f)) {
     const float pp[3] = {(x[0] + 2.0f) * 0.25f, (x[1] + 2.0f) * 0.25f, (x[2] + 2.0f) * 0.25f};  // sdf_field.py:384
@@ -183,7 +186,7 @@ __global__ __launch_bounds__(256) void geo_encode_kernel(const EncodeArgs a) {
     const float2* tab = reinterpret_cast<const float2*>(a.table);
     float2 v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = tab[c.idx[k]];
+    for (int k = 0; k < 8; ++k) v[k] = tab[(size_t)c.idx[k] * pairs + pair];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const float w = corner_w(c, k);
@@ -200,13 +203,13 @@ __global__ __launch_bounds__(256) void geo_encode_kernel(const EncodeArgs a) {
       }
     }
   }
-  a.in0_tp[tp_index(p, feat0 + level * 2 + 0, a.nb0)] = y0 * m0;
-  a.in0_tp[tp_index(p, feat0 + level * 2 + 1, a.nb0)] = y1 * m1;
+  a.in0_tp[tp_index(p, feat0 + c0 + 0, a.nb0)] = y0 * m0;
+  a.in0_tp[tp_index(p, feat0 + c0 + 1, a.nb0)] = y1 * m1;
   if (a.dydp != nullptr) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      a.dydp[(size_t)((level * 2 + 0) * 3 + d) * a.n_padded + p] = d0[d];
-      a.dydp[(size_t)((level * 2 + 1) * 3 + d) * a.n_padded + p] = d1[d];
+      a.dydp[(size_t)((c0 + 0) * 3 + d) * a.n_padded + p] = d0[d];
+      a.dydp[(size_t)((c0 + 1) * 3 + d) * a.n_padded + p] = d1[d];
     }
   }
 }
@@ -374,7 +377,9 @@ SDFHIP_D void scatter_stage_put(ScatterStage& st, const int lane, const int k, c
   st.v[lane][2 * k + 1] = t1;
   st.e[lane][k] = issue ? entry : kNoEntry;
 }
-SDFHIP_D void scatter_stage_flush(const ScatterStage& st, const int lane, float* __restrict__ tablebar) {
+// entry_stride = features per table entry, feat_off = first feature of the pair being scattered
+SDFHIP_D void scatter_stage_flush(const ScatterStage& st, const int lane, float* __restrict__ tablebar, const int entry_stride = 2,
+                                  const int feat_off = 0) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // this wave's LDS writes are ordered before its reads below
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -384,30 +389,31 @@ SDFHIP_D void scatter_stage_flush(const ScatterStage& st, const int lane, float*
       const int pt = q * 16 + (lane >> 2), k = c * 2 + ((lane >> 1) & 1), f = lane & 1;
       const uint32_t entry = st.e[pt][k];
       const float v = st.v[pt][2 * k + f];
-      if (entry != kNoEntry) atomicAdd(tablebar + (size_t)entry * 2 + f, v);
+      if (entry != kNoEntry) atomicAdd(tablebar + (size_t)entry * entry_stride + feat_off + f, v);
     }
   __builtin_amdgcn_wave_barrier();
 }
 
-// grid = (ceil(P/256), n_levels)
+// grid = (ceil(P/256), n_levels * F / 2): one feature pair of one level per y
 __global__ __launch_bounds__(256) void grid_bwd_kernel(const GridBwdArgs a) {
   __shared__ ScatterStage stage[4];
   const int lane = threadIdx.x & 63;
   ScatterStage& st = stage[threadIdx.x >> 6];
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool live = p < a.n_points;
-  const int level = blockIdx.y;
-  const float m0 = a.mask[level * 2 + 0], m1 = a.mask[level * 2 + 1];
+  const int F = a.grid.n_features, pairs = F >> 1;
+  const int level = blockIdx.y / pairs, pair = blockIdx.y % pairs, c0 = level * F + pair * 2;
+  const float m0 = a.mask[c0 + 0], m1 = a.mask[c0 + 1];
   if (m0 == 0.0f && m1 == 0.0f) return;  // block-uniform
   const int feat0 = 3 + 6 * a.pe_degree;
   float yb0 = 0.f, yb1 = 0.f, e0 = 0.f, e1 = 0.f, gb[3] = {0.f, 0.f, 0.f}, pp[3] = {0.5f, 0.5f, 0.5f};
   const bool second = a.e_tp != nullptr && a.gtot != nullptr;
   if (live) {
-    yb0 = a.in0bar_tp[tp_index(p, feat0 + level * 2 + 0, a.nb0)] * m0;
-    yb1 = a.in0bar_tp[tp_index(p, feat0 + level * 2 + 1, a.nb0)] * m1;
+    yb0 = a.in0bar_tp[tp_index(p, feat0 + c0 + 0, a.nb0)] * m0;
+    yb1 = a.in0bar_tp[tp_index(p, feat0 + c0 + 1, a.nb0)] * m1;
     if (second) {
-      e0 = a.e_tp[tp_index(p, feat0 + level * 2 + 0, a.nb0)] * m0 * 0.25f;
-      e1 = a.e_tp[tp_index(p, feat0 + level * 2 + 1, a.nb0)] * m1 * 0.25f;
+      e0 = a.e_tp[tp_index(p, feat0 + c0 + 0, a.nb0)] * m0 * 0.25f;
+      e1 = a.e_tp[tp_index(p, feat0 + c0 + 1, a.nb0)] * m1 * 0.25f;
 #pragma unroll
       for (int d = 0; d < 3; ++d) gb[d] = a.gtot[p * 3 + d];
     }
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(256) void grid_bwd_kernel(const GridBwdArgs a) {
     const bool issue = wave_run_reduce(c.idx[k], live, t0, t1);
     scatter_stage_put(st, lane, k, issue, c.idx[k], t0, t1);
   }
-  scatter_stage_flush(st, lane, a.tablebar);
+  scatter_stage_flush(st, lane, a.tablebar, F, pair * 2);
 }
 
 // ------------------------------------------------------------------------------------------------ proposal field

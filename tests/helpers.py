@@ -144,7 +144,8 @@ def product_model_from_params(params, cfg: O.ModelCfg, device, field_kwargs=None
         inside_outside=fc.inside_outside, use_grid_feature=True, beta_init=fc.beta_init, num_levels=fc.num_levels,
         max_res=fc.max_res, base_res=fc.base_res, log2_hashmap_size=fc.log2_hashmap_size,
         hash_features_per_level=fc.hash_features_per_level, hash_smoothstep=fc.hash_smoothstep,
-        use_appearance_embedding=fc.use_appearance_embedding, **(field_kwargs or {}),
+        use_appearance_embedding=fc.use_appearance_embedding, use_position_encoding=fc.use_position_encoding,
+        **(field_kwargs or {}),
     )
     mcfg = NeuSFactoModelConfig(
         sdf_field=fcfg, num_proposal_samples_per_ray=tuple(cfg.num_proposal_samples),
