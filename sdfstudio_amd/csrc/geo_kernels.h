@@ -269,52 +269,52 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
   };
 
   if constexpr (TANGENT) {
-  // ---- tangent pass (second-order terms): v_l = W_l qb_l
-  carry = load_src(tan_fetch(IC<0>{}, IC<0>{}), lane);
-  static_for<0, D::NL>([&](auto lc) __attribute__((always_inline)) {
-    constexpr int l = decltype(lc)::value;
-    constexpr int KB = D::kb(l), NBO = D::nbo(l);
-    auto& in = pick<(l % 2) == 0>(accA, accB);  // v_{l-1}
-    auto& out = pick<(l % 2) == 0>(accB, accA);
+    // ---- tangent pass (second-order terms): v_l = W_l qb_l
+    carry = load_src(tan_fetch(IC<0>{}, IC<0>{}), lane);
+    static_for<0, D::NL>([&](auto lc) __attribute__((always_inline)) {
+      constexpr int l = decltype(lc)::value;
+      constexpr int KB = D::kb(l), NBO = D::nbo(l);
+      auto& in = pick<(l % 2) == 0>(accA, accB);  // v_{l-1}
+      auto& out = pick<(l % 2) == 0>(accB, accA);
 #pragma unroll
-    for (int b = 0; b < NBO; ++b) out[b] = f32x16_zero();
-    auto fetch = [&](auto kbc) __attribute__((always_inline)) { return tan_fetch(lc, kbc); };
-    auto make = [&](auto kbc, const Raw& raw, auto ec) __attribute__((always_inline)) {
-      constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
-      if constexpr (l == 0) {
-        return raw.a[e];
-      } else if constexpr (l == D::SKIP && kb >= D::NB3) {
-        *tp_elem(a.qb_tp[l], tile, KB, kb, e, lane) = raw.a[e];
-        return raw.a[e];
-      } else {
-        const float qn = tangent_elem(IC<(l > 0 ? l - 1 : 0)>{}, kbc, ec, in[kb][e], raw);
-        *tp_elem(a.qb_tp[l], tile, KB, kb, e, lane) = qn;
-        return qn;
-      }
-    };
-    constexpr bool last = l + 1 == D::NL;
-    auto next_fetch = [&]() __attribute__((always_inline)) {
-      if constexpr (!last) return tan_fetch(IC<(last ? l : l + 1)>{}, IC<0>{});
-      else return BlkSrc<0>{};
-    };
-    // stores per produced block: zc + qb (32) for blocks computed from the layer below, qb only (16) for the seed blocks of
-    // the skip layer, none for layer 0
-    using ST = Stores<(l == 0 ? 0 : 32), (l == 0 ? 0 : (l == D::SKIP ? 16 : 32)), (l == D::SKIP ? D::NB3 : (1 << 30))>;
-    tp_gemm<KB, NBO, ST, NS, chunk_pieces(last ? D::NBH : D::nbo(last ? l : l + 1), NS)>(
-        out, carry, fetch, make, next_fetch, ws, a.p.wp[l], last ? a.p.wpT[D::NL] : a.p.wp[last ? l : l + 1]);
-  });
-  {
-    // epilogue of the last hidden layer: qb_NL (tangent reaching the sdf row; only the weight gradient needs it) and zc_{NL-1}
-    auto& v = pick<(D::NL % 2) == 0>(accA, accB);
-    static_for<0, D::NBH>([&](auto bc) __attribute__((always_inline)) {
-      constexpr int b = decltype(bc)::value;
-      const Raw raw = load_src(tan_fetch(IC<D::NL>{}, bc), lane);
-      static_for<0, 16>([&](auto ec) __attribute__((always_inline)) {
-        constexpr int e = decltype(ec)::value;
-        *tp_elem(a.qb_tp[D::NL], tile, D::NBH, b, e, lane) = tangent_elem(IC<D::NL - 1>{}, bc, ec, v[b][e], raw);
-      });
+      for (int b = 0; b < NBO; ++b) out[b] = f32x16_zero();
+      auto fetch = [&](auto kbc) __attribute__((always_inline)) { return tan_fetch(lc, kbc); };
+      auto make = [&](auto kbc, const Raw& raw, auto ec) __attribute__((always_inline)) {
+        constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
+        if constexpr (l == 0) {
+          return raw.a[e];
+        } else if constexpr (l == D::SKIP && kb >= D::NB3) {
+          *tp_elem(a.qb_tp[l], tile, KB, kb, e, lane) = raw.a[e];
+          return raw.a[e];
+        } else {
+          const float qn = tangent_elem(IC<(l > 0 ? l - 1 : 0)>{}, kbc, ec, in[kb][e], raw);
+          *tp_elem(a.qb_tp[l], tile, KB, kb, e, lane) = qn;
+          return qn;
+        }
+      };
+      constexpr bool last = l + 1 == D::NL;
+      auto next_fetch = [&]() __attribute__((always_inline)) {
+        if constexpr (!last) return tan_fetch(IC<(last ? l : l + 1)>{}, IC<0>{});
+        else return BlkSrc<0>{};
+      };
+      // stores per produced block: zc + qb (32) for blocks computed from the layer below, qb only (16) for the seed blocks of
+      // the skip layer, none for layer 0
+      using ST = Stores<(l == 0 ? 0 : 32), (l == 0 ? 0 : (l == D::SKIP ? 16 : 32)), (l == D::SKIP ? D::NB3 : (1 << 30))>;
+      tp_gemm<KB, NBO, ST, NS, chunk_pieces(last ? D::NBH : D::nbo(last ? l : l + 1), NS)>(
+          out, carry, fetch, make, next_fetch, ws, a.p.wp[l], last ? a.p.wpT[D::NL] : a.p.wp[last ? l : l + 1]);
     });
-  }
+    {
+      // epilogue of the last hidden layer: qb_NL (tangent reaching the sdf row; only the weight gradient needs it) and zc_{NL-1}
+      auto& v = pick<(D::NL % 2) == 0>(accA, accB);
+      static_for<0, D::NBH>([&](auto bc) __attribute__((always_inline)) {
+        constexpr int b = decltype(bc)::value;
+        const Raw raw = load_src(tan_fetch(IC<D::NL>{}, bc), lane);
+        static_for<0, 16>([&](auto ec) __attribute__((always_inline)) {
+          constexpr int e = decltype(ec)::value;
+          *tp_elem(a.qb_tp[D::NL], tile, D::NBH, b, e, lane) = tangent_elem(IC<D::NL - 1>{}, bc, ec, v[b][e], raw);
+        });
+      });
+    }
 
   }
 

@@ -105,6 +105,27 @@ __global__ __launch_bounds__(256, 1) void lds_latency(unsigned long long* cyc, f
   for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+// Access pattern of the fused network kernels: every wave reads one 4 KiB block from each of NARR arrays (same tile index) and
+// writes one - ARRAY-MAJOR (NARR separate multi-GiB arrays: NARR distinct pages per wave) versus TILE-MAJOR (the NARR blocks of a
+// tile contiguous: one or two pages per wave).  Same bytes; a gap between the two is address-translation (TLB) cost.
+template <bool TILE_MAJOR>
+__global__ __launch_bounds__(256, 1) void block_stream(const float* __restrict__ src, float* __restrict__ dst, int narr, size_t tiles) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t tile = (size_t)blockIdx.x * 4 + wave;
+  float acc = 0.f;
+  for (int a = 0; a < narr; ++a) {
+    const size_t blk = TILE_MAJOR ? tile * narr + a : (size_t)a * tiles + tile;
+    const float* p = src + blk * 1024 + lane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc += p[r * 64];
+    if ((a & 3) == 0) {
+      float* q = dst + blk * 1024 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) q[r * 64] = acc;
+    }
+  }
+  if (acc == 123.456f) dst[0] = acc;
+}
 __global__ __launch_bounds__(256) void hbm_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
@@ -166,6 +187,16 @@ int main() {
     const double bytes = (double)G * 256 * iters * 16 * 16;
     printf("LDS ds_read_b128   : %7.3f ms  %6.2f TB/s  = %.0f B/clk/CU at the nominal %d MHz (4 waves per CU, 16 reads per wait)\n", ms, bytes / ms / 1e9,
            bytes / (ms * 1e-3) / p.multiProcessorCount / (p.clockRate * 1e3), p.clockRate / 1000);
+  }
+  {
+    const int narr = 40; const size_t tiles = 16384;  // 524288 points: 40 x 64 MiB
+    float *a, *b; hipMalloc(&a, narr * tiles * 4096); hipMalloc(&b, narr * tiles * 4096); hipMemset(a, 0, narr * tiles * 4096);
+    float m0 = timeit([&] { block_stream<false><<<(unsigned)(tiles / 4), 256>>>(a, b, narr, tiles); });
+    float m1 = timeit([&] { block_stream<true><<<(unsigned)(tiles / 4), 256>>>(a, b, narr, tiles); });
+    const double bytes = 1.25 * narr * tiles * 4096.0;
+    printf("4 KiB blocks of 40 arrays per wave: array-major %.3f ms (%.2f TB/s), tile-major %.3f ms (%.2f TB/s)\n", m0, bytes / m0 / 1e9, m1,
+           bytes / m1 / 1e9);
+    hipFree(a); hipFree(b);
   }
   {
     unsigned long long* cyc; hipMalloc(&cyc, 64 * 8);
