@@ -10,7 +10,7 @@ Smoothstep) and ``fields/density_fields.py:89-94`` (5 levels, F=2, T=2^17,
 Linear).
 
 Published algorithm (restated):
-  per level l:  scale_l = exp2(l * log2(per_level_scale)) * base_res - 1  (fp32)
+  per level l:  scale_l = fp32( exp2(l * log2(per_level_scale)) * base_res - 1 )  (evaluated in double, see make_levels)
                 res_l   = ceil(scale_l) + 1
                 size_l  = min(next_multiple(res_l^3, 8), 2^log2_hashmap_size)
   position:     pos = x * scale_l + 0.5 ; cell = floor(pos) ; w = pos - cell
@@ -65,15 +65,18 @@ def make_levels(
     per_level_scale: float,
     smoothstep: bool,
 ) -> GridLevels:
-    """Per-level scale / resolution / table extent, in fp32 like tcnn's host code."""
-    l2 = np.log2(np.float32(per_level_scale)).astype(np.float32)
+    """Per-level scale / resolution / table extent.  The scale is evaluated in DOUBLE from the fp32 per_level_scale and rounded
+    to fp32 once: tcnn evaluates exp2f / log2 in single precision with the host libm, whose last bit is library dependent
+    (glibc exp2f vs numpy's differ by up to 1.5e-3 at scale 4095, which moves the finest cells by 7e-4 of their size and the
+    analytic normal of a linear 8-feature level by 0.1); one correctly rounded value is what both sides can reproduce."""
+    l2 = np.log2(np.float64(np.float32(per_level_scale)))
     scale = np.zeros(n_levels, np.float32)
     res = np.zeros(n_levels, np.int64)
     size = np.zeros(n_levels, np.int64)
     hashed = np.zeros(n_levels, bool)
     offset = np.zeros(n_levels + 1, np.int64)
     for lvl in range(n_levels):
-        s = np.float32(np.exp2(np.float32(lvl) * l2) * np.float32(base_resolution) - np.float32(1.0))
+        s = np.float32(np.exp2(np.float64(lvl) * l2) * np.float64(base_resolution) - 1.0)
         r = int(np.ceil(s)) + 1
         n = r**3
         n = (n + 7) // 8 * 8

@@ -93,10 +93,11 @@ extern "C" int sdfhip_grid_levels(const SdfHipGridCfg* cfg, SdfHipGridLevel* lev
                  "n_features_per_level must be 2, 4, 6 or 8 (got %d)", cfg->n_features);
   SDFHIP_REQUIRE(cfg->log2_hashmap_size >= 4 && cfg->log2_hashmap_size <= 24, "log2_hashmap_size %d unsupported", cfg->log2_hashmap_size);
   // tiny-cuda-nn GridEncoding constructor arithmetic, in fp32 (see oracle/hashgrid.py for the statement)
-  const float l2 = log2f(cfg->per_level_scale);
+  // evaluated in double and rounded once (oracle/hashgrid.py make_levels: the last bit of exp2f is libm dependent)
+  const double l2 = log2((double)cfg->per_level_scale);
   uint64_t off = 0;
   for (int l = 0; l < cfg->n_levels; ++l) {
-    const float scale = exp2f((float)l * l2) * (float)cfg->base_resolution - 1.0f;
+    const float scale = (float)(exp2((double)l * l2) * (double)cfg->base_resolution - 1.0);
     const uint32_t res = (uint32_t)ceilf(scale) + 1u;
     uint64_t n = (uint64_t)res * res * res;
     n = (n + 7) / 8 * 8;

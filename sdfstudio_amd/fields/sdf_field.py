@@ -276,10 +276,6 @@ class SDFField(nn.Module):
             unsupported.append("off_axis")
         if not c.weight_norm:
             unsupported.append("weight_norm=False")
-        if c.hash_features_per_level != 2 and not c.use_numerical_gradients:
-            # the 8-feature grid is the neus-facto-angelo preset's, which runs on numerical gradients; the analytic normal
-            # through it is not validated (method_configs.py:403-422)
-            unsupported.append("hash_features_per_level != 2 with analytic gradients")
         if unsupported:
             raise NotImplementedError("sdfhip does not build: " + ", ".join(unsupported))
         self.aabb = nn.Parameter(torch.as_tensor(aabb, dtype=torch.float32), requires_grad=False)

@@ -956,7 +956,9 @@ def _angelo_field_cfg(log2_t):
 
 def test_config5_shape_field_fwd_bwd(device):
     """BASELINE config 5's field SHAPE (8 features per level, linear interpolation, 1-hidden-layer geometry network, in0 = 167) on
-    a 2^19 table, in the preset's own mode (numerical gradients), against the oracle and anchored on its fp64 evaluation."""
+    a 2^19 table: the analytic path and the preset's own numerical-gradient path against the oracle, anchored on its fp64
+    evaluation.  (The analytic normal through the 4095-scale linear level is what exposed a last-bit difference in the level
+    scale between libm's exp2f and numpy's: both sides now evaluate it in double, oracle/hashgrid.py make_levels.)"""
     fc = _angelo_field_cfg(19)
     cfg = O.ModelCfg(field=fc)
     gen = torch.Generator().manual_seed(31)
@@ -970,12 +972,21 @@ def test_config5_shape_field_fwd_bwd(device):
         if k.endswith("weight_v"):
             p[k] = p[k] + 0.02 * torch.randn(p[k].shape, generator=gen)
     p.update(O.init_proposal_params(cfg.proposals))
-    model = product_model_from_params(p, cfg, device, field_kwargs={"use_numerical_gradients": True}).train()
+    model = product_model_from_params(p, cfg, device).train()
     n, s = 24, 20  # 480 points: padded tail
     o, d, cam, starts = _field_case(cfg, p, n, s, seed=16)
     coefs = [torch.randn(n, s), torch.randn(n, s, 3) * 0.3, torch.randn(n, s, 3)]
-    # delta of level 8 (neus_facto.py:219-222)
+    # ---- analytic d sdf / dx (one fused call, second-order backward)
+    fo, po = _oracle_field(fc, p, o, d, cam, starts, coefs)
+    f64, p64 = _oracle_field(fc, to_double(p), o.double(), d.double(), cam, starts.double(), [c.double() for c in coefs])
+    sdf, grad, rgb, _ = _product_field(model, o, d, cam, starts, coefs, device)
+    assert_close("sdf", sdf, fo["sdf"], rtol=0, atol=1e-5)
+    assert_fp32_class("gradient", grad, fo["gradient"], f64["gradient"], factor=3.0, atol=2e-5)
+    assert_fp32_class("rgb", rgb, fo["rgb"], f64["rgb"], factor=3.0, atol=2e-5)
+    _check_field_grads(model, po, rtol=1e-3, truth=p64, min_checked=22)
+    # ---- numerical gradients (the preset's mode), delta of level 8 (neus_facto.py:219-222)
     delta = 1.0 / (fc.base_res * fc.growth_factor() ** 7)
+    model.field.config.use_numerical_gradients = True
     model.field.set_numerical_gradients_delta(delta)
 
     def oracle_num(pp, oo, dd, ss, cc):
