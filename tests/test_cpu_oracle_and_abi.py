@@ -348,3 +348,36 @@ def test_oracle_numerical_gradients_against_reference_golden():
     loss.backward()
     for k, gref in g["grad"].items():
         assert (po[k].grad - gref).abs().max().item() <= 2e-3 * gref.abs().max().item() + 1e-9, k
+
+
+def test_level_table_of_the_library_equals_the_oracles():
+    """sdfhip_grid_levels (host-only C, what the kernels index with) against oracle/hashgrid.py make_levels: scale bit for bit,
+    resolution, entries, offsets, dense / hashed - for config 2, config 5 (2^22, 8 features), the proposal grids and the small
+    golden grid.  (A one-ulp difference in a level scale moves the finest cells measurably, see make_levels.)"""
+    import math
+
+    from oracle import hashgrid
+    from sdfstudio_amd import _lib
+
+    cases = [(16, 2, 19, 16, 2048, True), (16, 8, 22, 64, 4096, False), (5, 2, 17, 16, 64, False), (5, 2, 17, 16, 256, False),
+             (8, 2, 12, 4, 64, True), (16, 8, 19, 64, 4096, False)]
+    for n_levels, n_feat, log2_t, base, max_res, smooth in cases:
+        growth = math.exp((math.log(max_res) - math.log(base)) / (n_levels - 1))
+        lv = hashgrid.make_levels(n_levels, n_feat, log2_t, base, growth, smooth)
+        levels, n_entries = _lib.grid_levels(_lib.GridCfg(n_levels, n_feat, log2_t, base, float(growth), 1 if smooth else 0))
+        assert n_entries == lv.n_entries
+        for l in range(n_levels):
+            assert np.float32(levels[l].scale) == np.float32(lv.scale[l]), (l, levels[l].scale, float(lv.scale[l]))
+            assert levels[l].resolution == int(lv.resolution[l]) and levels[l].size == int(lv.size[l])
+            assert levels[l].offset == int(lv.offset[l]) and bool(levels[l].hashed) == bool(lv.hashed[l])
+
+
+def test_host_contraction_equals_the_oracles():
+    """The numerical-gradient path contracts positions on the host (SceneContraction(order=inf), spatial_distortions.py:66-92)."""
+    from sdfstudio_amd.fields.sdf_field import _contract_inf
+
+    torch.manual_seed(3)
+    x = torch.randn(4096, 3) * 2.0
+    x[0] = torch.tensor([1.0, -0.5, 0.25])   # on the unit box
+    x[1] = torch.tensor([0.0, 0.0, 0.0])
+    assert torch.equal(_contract_inf(x), O.contract_inf(x))
