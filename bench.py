@@ -246,16 +246,18 @@ def main():
             avg_s = kt_ms / kn * 1e-3
             alg_bytes = geo_bwd_algorithmic_bytes() * P
             achieved = alg_bytes / avg_s / 1e9
-            traffic = None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the bench)
+            traffic, traffic_source = None, None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the bench)
             cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
             tpath = os.path.join(ROOT, "profiles", cands[-1]) if cands else ""  # newest committed PMC pass (r1 < r1c < r2 ...)
             if cands:
                 with open(tpath) as fh:
                     tj = json.load(fh)
-                traffic = {"hbm_bytes_per_launch": tj["hbm_read_bytes"] + tj["hbm_write_bytes"], "source": tj["source"]}
+                traffic = tj["hbm_read_bytes"] + tj["hbm_write_bytes"]  # HBM bytes per launch
+                traffic_source = tj["source"]
             flops = 2 * g * P
             roof = {"kernel": "geo_bwd_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS,
-                    "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": traffic,
+                    "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_unit": "bytes per launch",
+                    "traffic_source": traffic_source, "algorithmic_bytes": alg_bytes,
                     "avg_launch_ms": round(kt_ms / kn, 4), "launches": kn,
                     "algorithmic": f"{geo_bwd_algorithmic_bytes()} B per ray-sample (saved per-layer tensors read + written, DESIGN.md "
                                    f"section 4) x {P} ray-samples per launch",
