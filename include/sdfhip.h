@@ -61,7 +61,7 @@ typedef struct {
   int32_t pe_degree;             /* position_encoding_max_degree */
   int32_t use_position_encoding;
   int32_t appearance_dim;        /* appearance_embedding_dim */
-  int32_t contract;              /* 1: SceneContraction(order=inf) on the sample positions, 0: none */
+  int32_t contract;              /* SceneContraction on the sample positions: 0 none, 1 order = inf, 2 order = None (L2) */
   float rgb_padding;
   SdfHipGridCfg grid;
 } SdfHipFieldCfg;

@@ -129,6 +129,14 @@ def contract_inf(x: torch.Tensor) -> torch.Tensor:
     return torch.where(mag >= 1, (2.0 - 1.0 / safe) * (x / safe), x)
 
 
+def contract_l2(x: torch.Tensor) -> torch.Tensor:
+    """field_components/spatial_distortions.py:66-73 with order=None (torch.linalg.norm's default: the 2-norm) -
+    scene_contraction_norm = "l2" (base_surface_model.py:150-151)."""
+    mag = torch.linalg.norm(x, dim=-1, keepdim=True)
+    safe = torch.where(mag >= 1, mag, torch.ones_like(mag))
+    return torch.where(mag >= 1, (2.0 - 1.0 / safe) * (x / safe), x)
+
+
 def fold_weight_norm(v: torch.Tensor, g: torch.Tensor) -> torch.Tensor:
     """torch.nn.utils.weight_norm(dim=0) as applied at sdf_field.py:312-313: W = g * v / ||v||_row."""
     return g * v / v.norm(dim=1, keepdim=True)
@@ -257,12 +265,13 @@ def neus_alpha(sdf, grad, dirs, deltas, inv_s, cos_anneal_ratio: float) -> torch
 
 
 def field_outputs(origins, dirs, starts, deltas, cam_idx, p: Params, cfg: FieldCfg, mask=None,
-                  cos_anneal_ratio: float = 1.0, training: bool = True, numerical_delta: Optional[float] = None) -> Dict[str, torch.Tensor]:
+                  cos_anneal_ratio: float = 1.0, training: bool = True, numerical_delta: Optional[float] = None,
+                  contraction: str = "inf") -> Dict[str, torch.Tensor]:
     """fields/sdf_field.py:614-689 get_outputs(return_alphas=True) for a dense [N,S] sample set.  numerical_delta: the
     use_numerical_gradients branch (:638-644) with numerical_gradients_delta = that value."""
     n, s = starts.shape
     pos = origins[:, None, :] + dirs[:, None, :] * starts[..., None]  # cameras/rays.py:61-73 (START positions)
-    x = contract_inf(pos.reshape(-1, 3))  # sdf_field.py:629
+    x = (contract_inf if contraction == "inf" else contract_l2)(pos.reshape(-1, 3))  # sdf_field.py:629
     points_norm = x.norm(dim=-1)
     sampled_sdf = None
     if numerical_delta is None:
@@ -290,10 +299,10 @@ def field_outputs(origins, dirs, starts, deltas, cam_idx, p: Params, cfg: FieldC
 
 
 # ----------------------------------------------------------------------------- proposal density
-def proposal_density(positions: torch.Tensor, p: Params, prefix: str, cfg: ProposalCfg) -> torch.Tensor:
+def proposal_density(positions: torch.Tensor, p: Params, prefix: str, cfg: ProposalCfg, contraction: str = "inf") -> torch.Tensor:
     """fields/density_fields.py:99-118 (+ base_field.py:48-65): contraction, (x+2)/4, grid -> ReLU MLP -> exp."""
     shape = positions.shape[:-1]
-    x = (contract_inf(positions.reshape(-1, 3)) + 2.0) / 4.0
+    x = ((contract_inf if contraction == "inf" else contract_l2)(positions.reshape(-1, 3)) + 2.0) / 4.0
     lv = cfg.grid_levels()
     feat = hashgrid.grid_encode(x, p[f"{prefix}.table"].view(lv.n_entries, lv.n_features), lv)
     pre = torch.relu(feat @ p[f"{prefix}.w1"].t()) @ p[f"{prefix}.w2"].t()

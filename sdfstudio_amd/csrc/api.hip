@@ -517,7 +517,7 @@ extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, c
   ea.n_padded = NP;
   ea.S = n_samples;
   // get_outputs contracts the sample positions (sdf_field.py:629); get_sdf / forward_geonetwork do NOT (:412-418, :380)
-  ea.contract = (f->cfg.contract && full) ? 1 : 0;
+  ea.contract = full ? f->cfg.contract : 0;  // 0 none, 1 L-inf, 2 L2
   ea.pe_degree = f->cfg.pe_degree;
   ea.use_pe = f->cfg.use_position_encoding;
   ea.nb0 = k->nb0;

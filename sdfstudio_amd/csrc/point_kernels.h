@@ -23,9 +23,11 @@ struct GridDev {
   GridLevelDev lv[kMaxLevels];
 };
 
-SDFHIP_D void contract_inf(float x[3]) {
-  // spatial_distortions.py:66-73 with ord = inf
-  const float mag = fmaxf(fabsf(x[0]), fmaxf(fabsf(x[1]), fabsf(x[2])));
+// order: 1 = L-inf (surface models' default, base_surface_model.py:148-155), 2 = L2 (SceneContraction(order=None))
+SDFHIP_D void contract_inf(float x[3], const int order = 1) {
+  // spatial_distortions.py:66-73
+  const float mag = order == 2 ? sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(x[0], x[0]), __fmul_rn(x[1], x[1])), __fmul_rn(x[2], x[2])))
+                               : fmaxf(fabsf(x[0]), fmaxf(fabsf(x[1]), fabsf(x[2])));
   if (mag >= 1.0f) {
     const float k = (2.0f - 1.0f / mag);
     x[0] = k * (x[0] / mag);
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void geo_encode_kernel(const EncodeArgs a) {
   float x[3] = {0.f, 0.f, 0.f};
   if (live) {
     start_position(a.origins, a.dirs, a.starts, p, a.S, x);
-    if (a.contract) contract_inf(x);
+    if (a.contract) contract_inf(x, a.contract);
   }
   // blockIdx.y = level * (F / 2) + feature pair; the last y is the position / positional-encoding block.  An F-feature level is
   // F / 2 two-feature gathers that share the cell (hash_features_per_level = 8 in the neus-facto-angelo preset).
@@ -470,7 +472,7 @@ SDFHIP_D void prop_position(const PropArgs& a, const int64_t p, float pp[3]) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) x[d] = a.origins[ray * 3 + d] + a.dirs[ray * 3 + d] * t;
   }
-  if (a.contract) contract_inf(x);
+  if (a.contract) contract_inf(x, a.contract);
 #pragma unroll
   for (int d = 0; d < 3; ++d) pp[d] = (x[d] + 2.0f) * 0.25f;
 }

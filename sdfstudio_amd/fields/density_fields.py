@@ -77,6 +77,10 @@ class HashMLPDensityField(nn.Module):
         self.spatial_distortion = spatial_distortion
         if spatial_distortion is None:
             raise NotImplementedError("the aabb-normalised (no contraction) proposal path is not built")
+        order = getattr(spatial_distortion, "order", None)
+        if order not in (float("inf"), None, 2):
+            raise NotImplementedError("SceneContraction is built for order = inf and order = None / 2")
+        self._contract = 1 if order == float("inf") else 2
         growth = math.exp((math.log(max_res) - math.log(base_res)) / (num_levels - 1))
         self.grid_cfg = _lib.GridCfg(num_levels, features_per_level, log2_hashmap_size, base_res, growth, 0)
         _, n_entries = _lib.grid_levels(self.grid_cfg)
@@ -88,10 +92,10 @@ class HashMLPDensityField(nn.Module):
         if isinstance(positions_or_samples, torch.Tensor):
             pos = positions_or_samples
             flat = pos.reshape(-1, 3).contiguous().float()
-            d = _ProposalDensity.apply(p.table, p.w1, p.w2, self.grid_cfg, 1, flat, None, None, None)
+            d = _ProposalDensity.apply(p.table, p.w1, p.w2, self.grid_cfg, self._contract, flat, None, None, None)
             return d.view(*pos.shape[:-1], 1)
         o, d, st, en = unpack_ray_samples(positions_or_samples)
-        dens = _ProposalDensity.apply(p.table, p.w1, p.w2, self.grid_cfg, 1, o, d, st, en)
+        dens = _ProposalDensity.apply(p.table, p.w1, p.w2, self.grid_cfg, self._contract, o, d, st, en)
         return dens[..., None]
 
     def get_density(self, ray_samples):

@@ -252,9 +252,9 @@ class _ColorFunction(torch.autograd.Function):
         return theta_bar, feat_bar, grad_bar, emb_bar, None, None, None, None, None
 
 
-def _contract_inf(x: torch.Tensor) -> torch.Tensor:
-    """SceneContraction(order=inf), field_components/spatial_distortions.py:66-92."""
-    mag = x.abs().amax(dim=-1, keepdim=True)
+def _contract_inf(x: torch.Tensor, order=float("inf")) -> torch.Tensor:
+    """SceneContraction, field_components/spatial_distortions.py:66-92 (order = inf, or None / 2 for the L2 norm)."""
+    mag = x.abs().amax(dim=-1, keepdim=True) if order == float("inf") else torch.linalg.norm(x, dim=-1, keepdim=True)
     return torch.where(mag < 1.0, x, (2.0 - 1.0 / mag.clamp_min(1e-30)) * (x / mag.clamp_min(1e-30)))
 
 
@@ -283,9 +283,9 @@ class SDFField(nn.Module):
         contract = 0
         if spatial_distortion is not None:
             order = getattr(spatial_distortion, "order", None)
-            if order != float("inf"):
-                raise NotImplementedError("only SceneContraction(order=inf) is built (base_surface_model.py:148-155)")
-            contract = 1
+            if order not in (float("inf"), None, 2):
+                raise NotImplementedError("SceneContraction is built for order = inf and order = None / 2 (base_surface_model.py:148-155)")
+            contract = 1 if order == float("inf") else 2
         self.num_images = num_images
         self.embedding_appearance = _Embedding(num_images, c.appearance_embedding_dim)
         self.use_average_appearance_embedding = use_average_appearance_embedding
@@ -459,7 +459,7 @@ class SDFField(nn.Module):
         shape = x.shape[:-1]
         x = x.reshape(-1, 3).float()
         if self.spatial_distortion is not None and not skip_spatial_distortion:
-            x = _contract_inf(x)
+            x = _contract_inf(x, self.spatial_distortion.order)
         if self.config.use_numerical_gradients:
             delta = self.numerical_gradients_delta
             taps = (x[None, :, :] + self._tap_offsets(x)[:, None, :]).reshape(-1, 3)
@@ -475,7 +475,7 @@ class SDFField(nn.Module):
         and at the six taps in ONE differentiable call (7 P points), finite-difference normal, colour network on it."""
         n, s = st.shape
         pos = (o[:, None, :] + d[:, None, :] * st[..., None]).reshape(-1, 3)
-        x = _contract_inf(pos) if self.spatial_distortion is not None else pos
+        x = _contract_inf(pos, self.spatial_distortion.order) if self.spatial_distortion is not None else pos
         P = x.shape[0]
         delta = self.numerical_gradients_delta
         pts = torch.cat([x[None], x[None, :, :] + self._tap_offsets(x)[:, None, :]], dim=0).reshape(-1, 3)

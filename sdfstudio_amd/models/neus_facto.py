@@ -24,7 +24,7 @@ from sdfstudio_amd.model_components.renderers import neus_render
 
 
 class SceneContraction(nn.Module):
-    """field_components/spatial_distortions.py:42-92 (order = inf); a marker for the kernels, callable for host code."""
+    """field_components/spatial_distortions.py:42-92 (order = inf, or None for L2); a marker for the kernels, callable for host code."""
 
     def __init__(self, order=float("inf")) -> None:
         super().__init__()
@@ -99,11 +99,11 @@ class NeuSFactoModel(nn.Module):
         c = self.config
         if c.background_model != "none":
             raise NotImplementedError("background models are outside this round's scope (SURVEY.md section 8, row f4)")
-        if c.scene_contraction_norm != "inf":
-            raise NotImplementedError("only the L-inf scene contraction is built")
+        if c.scene_contraction_norm not in ("inf", "l2"):
+            raise ValueError("Invalid scene contraction norm")  # base_surface_model.py:148-155
         if self.scene_box.collider_type != "near_far":
             raise NotImplementedError("only the near/far collider is on the path this round")
-        self.scene_contraction = SceneContraction(order=float("inf"))
+        self.scene_contraction = SceneContraction(order=float("inf") if c.scene_contraction_norm == "inf" else None)
         self.field = c.sdf_field.setup(aabb=self.scene_box.aabb, spatial_distortion=self.scene_contraction,
                                        num_images=self.num_train_data, use_average_appearance_embedding=False)
         self.proposal_networks = nn.ModuleList()

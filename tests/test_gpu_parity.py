@@ -1032,3 +1032,61 @@ def test_config5_full_shape_step_properties(device):
             assert prm.grad is not None and torch.isfinite(prm.grad).all(), k
     tg = dict(model.named_parameters())["field.encoding.params"].grad.view(-1, 8)
     assert tg[fld.encoding.levels[8].offset:].abs().max().item() == 0.0  # masked levels: exactly zero (DDP can skip them)
+
+
+def test_l2_scene_contraction(device):
+    """scene_contraction_norm = "l2" (SceneContraction(order=None), base_surface_model.py:150-151, spatial_distortions.py:66-73):
+    SDF field forward + backward and the proposal density on points well outside the unit ball, against the oracle."""
+    from sdfstudio_amd.fields.density_fields import HashMLPDensityField
+    from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
+    from sdfstudio_amd.models.neus_facto import SceneContraction
+
+    g = load_golden("train")
+    cfg = small_oracle_cfg()
+    fc = cfg.field
+    fcfg = SDFFieldConfig(num_layers=fc.num_layers, hidden_dim=fc.hidden_dim, geo_feat_dim=fc.geo_feat_dim,
+                          num_layers_color=fc.num_layers_color, hidden_dim_color=fc.hidden_dim_color, bias=fc.bias,
+                          inside_outside=fc.inside_outside, use_grid_feature=True, beta_init=fc.beta_init, num_levels=fc.num_levels,
+                          max_res=fc.max_res, base_res=fc.base_res, log2_hashmap_size=fc.log2_hashmap_size,
+                          hash_features_per_level=fc.hash_features_per_level, hash_smoothstep=fc.hash_smoothstep)
+    fld = fcfg.setup(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_images=49, spatial_distortion=SceneContraction(order=None))
+    from helpers import load_params
+
+    class _Wrap(torch.nn.Module):
+        def __init__(self, f):
+            super().__init__()
+            self.field = f
+            self.proposal_networks = torch.nn.ModuleList()
+
+    wrap = _Wrap(fld)
+    load_params(wrap, {k: v for k, v in g["param"].items() if not k.startswith("proposal_networks.")})
+    wrap = wrap.to(device).train()
+    n, s = 29, 11
+    o, d, cam = O.synthetic_rays(n, seed=5)
+    starts = torch.sort(torch.rand(n, s) * 6.0 + 0.5, dim=-1).values  # up to |x| ~ 4: most samples are contracted
+    coefs = [torch.randn(n, s), torch.randn(n, s, 3) * 0.3, torch.randn(n, s, 3)]
+    po = {k: v.clone().requires_grad_(v.is_floating_point() and k != "laplace_density.beta_min") for k, v in g["param"].items()}
+    fo = O.field_outputs(o, d, starts, torch.ones(n, s), cam, po, fc, contraction="l2")
+    ((fo["sdf"] * coefs[0]).sum() + (fo["gradient"] * coefs[1]).sum() + (fo["rgb"] * coefs[2]).sum()).backward()
+    sdf, grad, rgb, x = _product_field(wrap, o, d, cam, starts, coefs, device)
+    assert_close("points_norm (L2-contracted)", x.norm(dim=-1), fo["points_norm"], rtol=1e-6, atol=1e-6)
+    assert (x.norm(dim=-1) < 2.0).all() and (x.norm(dim=-1) > 1.0).float().mean() > 0.3
+    assert_close("sdf", sdf, fo["sdf"], rtol=0, atol=1e-5)
+    assert_close("gradient", grad, fo["gradient"], rtol=1e-4, atol=1e-5)
+    assert_close("rgb", rgb, fo["rgb"], rtol=0, atol=2e-5)
+    got = product_grads(wrap)
+    for k in ("glin0.weight_v", "glin4.weight_v", "glin8.weight_v", "clin0.weight_v", "encoding.params"):
+        assert_close(f"grad {k}", got[k], po[k].grad, rtol=1e-3, atol=1e-9)
+    # proposal density with the same contraction
+    pc = cfg.proposals[0]
+    net = HashMLPDensityField(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), spatial_distortion=SceneContraction(order=None),
+                              hidden_dim=pc.hidden_dim, num_levels=pc.num_levels, max_res=pc.max_res, base_res=pc.base_res,
+                              log2_hashmap_size=pc.log2_hashmap_size, features_per_level=pc.features_per_level).to(device)
+    with torch.no_grad():
+        net.mlp_base.table.copy_(g["param"]["proposal_networks.0.table"])
+        net.mlp_base.w1.copy_(g["param"]["proposal_networks.0.w1"])
+        net.mlp_base.w2.copy_(g["param"]["proposal_networks.0.w2"])
+    pos = (o[:, None, :] + d[:, None, :] * starts[..., None])
+    dens = net.density_fn(pos.to(device))
+    ref = O.proposal_density(pos, g["param"], "proposal_networks.0", pc, contraction="l2")
+    assert_close("proposal density (L2)", dens[..., 0], ref, rtol=1e-4, atol=1e-6)
