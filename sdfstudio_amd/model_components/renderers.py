@@ -105,7 +105,9 @@ def neus_render(sdf, gradients, rgb, variance, directions, starts, ends, cos_ann
 
 
 class RGBRenderer(nn.Module):
-    """renderers.py:42-118 for dense [N,S] samples: sum_s w rgb + bg (1 - sum_s w); clamp to [0,1] in eval."""
+    """renderers.py:42-118 for dense [N,S] samples: sum_s w rgb + bg (1 - sum_s w); clamp to [0,1] in eval.
+    background_color: an RGB tensor, "random" (a fresh uniform colour per ray and call, :86-87), "last_sample" (the colour of
+    the ray's last sample, :84-85), or None (black)."""
 
     def __init__(self, background_color=None) -> None:
         super().__init__()
@@ -115,6 +117,13 @@ class RGBRenderer(nn.Module):
         comp = torch.sum(weights * rgb, dim=-2)
         acc = torch.sum(weights, dim=-2)
         bg = self.background_color
+        if isinstance(bg, str):
+            if bg == "last_sample":
+                bg = rgb[..., -1, :]
+            elif bg == "random":
+                bg = torch.rand_like(comp)
+            else:
+                raise ValueError(f"background_color must be an RGB tensor, 'random' or 'last_sample', not {bg!r}")
         if isinstance(bg, torch.Tensor):
             comp = comp + bg.to(comp) * (1.0 - acc)
         if not self.training:

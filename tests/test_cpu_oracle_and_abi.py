@@ -381,3 +381,26 @@ def test_host_contraction_equals_the_oracles():
     x[0] = torch.tensor([1.0, -0.5, 0.25])   # on the unit box
     x[1] = torch.tensor([0.0, 0.0, 0.0])
     assert torch.equal(_contract_inf(x), O.contract_inf(x))
+
+
+def test_rgb_renderer_background_modes():
+    """RGBRenderer mirror (renderers.py:42-118): tensor, 'last_sample' and 'random' backgrounds; the reference's own renderer
+    tests pin uniform weights -> rgb ~ 1 and zero weights -> background (tests/model_components/test_renderers.py:10-25)."""
+    from sdfstudio_amd.model_components.renderers import RGBRenderer
+
+    torch.manual_seed(0)
+    n, s = 6, 11
+    rgb = torch.rand(n, s, 3)
+    w = torch.rand(n, s, 1)
+    w = w / w.sum(1, keepdim=True) * 0.7
+    comp, acc = (w * rgb).sum(1), w.sum(1)
+    white = torch.ones(3)
+    assert torch.allclose(RGBRenderer(white).train()(rgb, w), comp + white * (1 - acc))
+    assert torch.allclose(RGBRenderer("last_sample").train()(rgb, w), comp + rgb[:, -1] * (1 - acc))
+    r = RGBRenderer("random").train()(rgb, w)
+    bg = (r - comp) / (1 - acc)
+    assert (bg >= -1e-6).all() and (bg <= 1 + 1e-6).all() and bg.std() > 0.05
+    assert torch.allclose(RGBRenderer(None).train()(rgb, w), comp)
+    ones = torch.ones(n, s, 3)
+    assert torch.allclose(RGBRenderer(torch.zeros(3)).train()(ones, torch.full((n, s, 1), 1.0 / s)), torch.ones(n, 3), atol=1e-6)
+    assert torch.allclose(RGBRenderer(white).eval()(ones * 2.0, torch.full((n, s, 1), 1.0 / s)), torch.ones(n, 3))  # eval clamps
