@@ -78,11 +78,21 @@ def draw_rays(centers, rot, n, gen):
     return centers[cam].contiguous(), (d / norm).contiguous(), norm, cam
 
 
-def build_model(device):
+def build_model(device, small=False):
+    """BASELINE config 2 (default), or the small parity configuration of tests/golden (8x64 networks, 8x2x2^11 grid, 32/24
+    proposal + 16 field samples): the latter only drives the N > 1 control-flow test, never a reported number."""
     from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
     from sdfstudio_amd.models.neus_facto import NeuSFactoModel, NeuSFactoModelConfig, SceneBox
 
     torch.manual_seed(0)
+    if small:
+        fcfg = SDFFieldConfig(num_layers=8, hidden_dim=64, geo_feat_dim=64, num_layers_color=4, hidden_dim_color=64, bias=0.5,
+                              inside_outside=False, use_grid_feature=True, beta_init=0.3, num_levels=8, max_res=128, base_res=4,
+                              log2_hashmap_size=11, hash_features_per_level=2, hash_smoothstep=True)
+        mcfg = NeuSFactoModelConfig(sdf_field=fcfg, num_proposal_samples_per_ray=(32, 24), num_neus_samples_per_ray=16,
+                                    background_model="none")
+        box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=0.5, far=4.5)
+        return NeuSFactoModel(mcfg, box, num_train_data=49).to(device).train()
     fcfg = SDFFieldConfig(num_layers=8, hidden_dim=256, geo_feat_dim=256, num_layers_color=4, hidden_dim_color=256, bias=0.5,
                           inside_outside=False, use_grid_feature=True, beta_init=0.3, num_levels=16, max_res=2048, base_res=16,
                           log2_hashmap_size=19, hash_features_per_level=2, hash_smoothstep=True)
@@ -138,14 +148,44 @@ def cpu_baseline():
                       f"{dt * 1e3:.0f} ms/iter"}
 
 
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _spawned(local_rank, args, port):
+    os.environ.update({"RANK": str(local_rank), "LOCAL_RANK": str(local_rank), "WORLD_SIZE": str(args.gpus),
+                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    run(args)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--small", action="store_true", help="small parity configuration (control-flow tests only, not a benchmark)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: one process per GPU, spawned here as the reference does (scripts/train.py:190-203);
+        # under torch.distributed.run the ranks already exist and RANK / WORLD_SIZE come from the environment
+        import torch.multiprocessing as mp
 
+        mp.spawn(_spawned, args=(args, _free_port()), nprocs=args.gpus, join=True)
+        return
+    run(args)
+
+
+def run(args):
+    global N_RAYS, N_SAMPLES
+    if args.small:
+        N_RAYS, N_SAMPLES = 512, 16
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -165,16 +205,20 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world > 1:
+        print(f"[bench] rank {rank}/{world}: backend {dist.get_backend()}{' (RCCL)' if dist.get_backend() == 'nccl' else ''}, "
+              f"device {local_rank} {torch.cuda.get_device_name(local_rank)}", file=sys.stderr, flush=True)
 
     from sdfstudio_amd import _lib
     from sdfstudio_amd.cameras.rays import RayBundle
     from sdfstudio_amd.distributed import FlatGradients, broadcast_parameters
 
-    model = build_model(device)
+    model = build_model(device, small=args.small)
     broadcast_parameters(model)
-    groups = model.get_param_groups()
-    flat = FlatGradients([p for g in groups.values() for p in g])
+    groups = {k: v for k, v in model.get_param_groups().items() if v}  # "field_background" is empty with background_model="none"
+    # one flat gradient buffer; one exchange bucket per parameter group, all-reduced (RCCL) as soon as backward has produced it
+    flat = FlatGradients([p for g in groups.values() for p in g], buckets=list(groups.values()))
     # optimizers as method_configs.py:483-500 (neus-facto): Adam lr 5e-4 (fields) / 1e-2 (proposal networks), eps 1e-15
     opts = [torch.optim.Adam(groups["fields"], lr=5e-4, eps=1e-15, fused=True),
             torch.optim.Adam(groups["proposal_networks"], lr=1e-2, eps=1e-15, fused=True)]
@@ -191,7 +235,7 @@ def main():
         loss = sum(model.get_loss_dict(out, {"image": image}).values())
         flat.zero()
         loss.backward()
-        flat.all_reduce_mean()
+        flat.finish()
         for opt in opts:
             opt.step()
         model.after_train_iteration(i)
@@ -274,18 +318,22 @@ def main():
             "dtype_note": "fp32 tensors and accumulators; matrix products as split-bf16 terms on the bf16 MFMA pipe (6 terms = fp32-class "
                           "for everything the forward returns, 3 terms in the backward kernels and weight-gradient GEMMs)",
             "data": "synthetic", "iters_per_sec": round(1e3 / ms, 3), "per_gpu": round(value / world, 1),
-            "config": {"workload": "BASELINE config 2: NeuS-facto hash-grid 16x2x2^19 smoothstep + 8x256 geo MLP + 4x256 colour MLP, "
+            "config": {"workload": "SMALL parity configuration (control-flow test only, NOT a benchmark)" if args.small else
+                                   "BASELINE config 2: NeuS-facto hash-grid 16x2x2^19 smoothstep + 8x256 geo MLP + 4x256 colour MLP, "
                                    "4096 rays x 128 samples (+256/96 proposal samples) per GPU per step, full train step incl. Adam",
                        "rays_per_gpu": N_RAYS, "samples_per_ray": N_SAMPLES,
                        "parallelism": f"dp{world} (flat-gradient RCCL all-reduce)" if world > 1 else "single GPU"},
             "roofline": roof,
+            "collective": None if world == 1 else {"backend": dist.get_backend(), "buckets": len(groups),
+                                                    "bytes_per_step_per_rank": 4 * flat.exchanged_numel(),
+                                                    "overlap": "bucket all-reduce launched from post-accumulate-grad hooks during backward"},
             "forward_only": {"value": round(N_RAYS * N_SAMPLES / (fwd_ms * 1e-3), 1), "unit": "ray-samples/s per GPU (eval-mode render, no grad)",
                              "ms_per_batch": round(fwd_ms, 3)},
             "model_tflops": round((6 * g + 3 * c) * P / (ms * 1e-3) / 1e12, 2),
             "mfma_kernels_ms_per_step": round(mfma_ms, 3),
             "kernels": kernels,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.small:
             print("[bench] GPU leg done: " + json.dumps(line), file=sys.stderr, flush=True)
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -151,6 +151,25 @@ def ptr(t: Optional[torch.Tensor]):
     return ctypes.c_void_p(t.data_ptr())
 
 
+class Keep:
+    """Marshals optional tensors into device pointers for ONE native call and keeps what it hands out alive.
+
+    ``kp = Keep(); lib.fn(kp(a), kp(b), ...); del kp`` - a ``.contiguous()`` copy made for argument i must not be freed
+    before argument i + 1 is evaluated (the caching allocator would hand the same block to the next copy and the two
+    pointers alias); kernels are stream ordered, so keeping the copies until the launch has been issued is enough.
+    """
+
+    def __init__(self):
+        self._refs = []
+
+    def __call__(self, t: Optional[torch.Tensor]):
+        if t is None:
+            return None
+        t = t.contiguous()
+        self._refs.append(t)
+        return ptr(t)
+
+
 def stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 

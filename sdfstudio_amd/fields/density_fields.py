@@ -45,11 +45,13 @@ class _ProposalDensity(torch.autograd.Function):
         table_bar = torch.zeros_like(table)
         w1_bar = torch.empty_like(w1)
         w2_bar = torch.empty_like(w2)
+        kp = _lib.Keep()
         _lib.check(lib.sdfhip_proposal_backward(ctypes.byref(ctx.grid_cfg), _lib.ptr(table), _lib.ptr(w1), _lib.ptr(w2),
                                                 _lib.ptr(origins), _lib.ptr(dirs), _lib.ptr(starts), _lib.ptr(ends), n, s,
-                                                ctx.contract, _lib.ptr(dbar.contiguous()), ctypes.c_void_p(ws.data_ptr()),
+                                                ctx.contract, kp(dbar), ctypes.c_void_p(ws.data_ptr()),
                                                 _lib.ptr(table_bar), _lib.ptr(w1_bar), _lib.ptr(w2_bar), _lib.stream()),
                    "proposal_backward")
+        del kp
         return table_bar, w1_bar, w2_bar, None, None, None, None, None, None
 
 

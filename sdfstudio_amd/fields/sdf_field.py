@@ -123,6 +123,11 @@ class _Embedding(nn.Module):
         return self.embedding(idx)
 
 
+def _contig(t):
+    """Contiguous version of an optional tensor; the CALLER keeps the result in a local until its kernel has been launched."""
+    return None if t is None else t.contiguous()
+
+
 class _FieldFunction(torch.autograd.Function):
     """One autograd node for the whole field: (theta, table[, emb]) -> (sdf, d sdf/dx, rgb, contracted x)."""
 
@@ -135,7 +140,8 @@ class _FieldFunction(torch.autograd.Function):
         NP = _lib.padded_points(P)
         h = fld._handle
         packed = torch.empty(lib.sdfhip_field_packed_size(h), device=dev)
-        _lib.check(lib.sdfhip_field_pack(h, _lib.ptr(theta.contiguous()), _lib.ptr(packed), _lib.stream()), "field_pack")
+        theta_c = theta.contiguous()  # every contiguous() copy stays bound to a local until the launch has been issued
+        _lib.check(lib.sdfhip_field_pack(h, _lib.ptr(theta_c), _lib.ptr(packed), _lib.stream()), "field_pack")
         ws = torch.empty(lib.sdfhip_field_workspace_size(h, P, 1), dtype=torch.uint8, device=dev)
         sdf = torch.empty(NP, device=dev)
         grad = torch.empty(NP, 3, device=dev)
@@ -163,13 +169,14 @@ class _FieldFunction(torch.autograd.Function):
         table_bar = torch.zeros_like(table)
         emb_bar = torch.zeros(n, fld.config.appearance_embedding_dim, device=dev) if ctx.has_emb else None
 
-        def c(t):
-            return None if t is None else t.contiguous()
-
+        # incoming cotangents may be stride-0 expands (e.g. from .sum()): materialise them into locals that outlive the call, a
+        # temporary's storage could be recycled for the next argument's copy before the launch reads it
+        sdf_bar_c, grad_bar_c, rgb_bar_c = _contig(sdf_bar), _contig(grad_bar), _contig(rgb_bar)
         _lib.check(lib.sdfhip_field_backward(h, _lib.ptr(packed), _lib.ptr(table), _lib.ptr(mask), n, s,
-                                             ctypes.c_void_p(ws.data_ptr()), _lib.ptr(c(sdf_bar)), _lib.ptr(c(grad_bar)),
-                                             _lib.ptr(c(rgb_bar)), _lib.ptr(theta_bar), _lib.ptr(table_bar), _lib.ptr(emb_bar),
+                                             ctypes.c_void_p(ws.data_ptr()), _lib.ptr(sdf_bar_c), _lib.ptr(grad_bar_c),
+                                             _lib.ptr(rgb_bar_c), _lib.ptr(theta_bar), _lib.ptr(table_bar), _lib.ptr(emb_bar),
                                              _lib.stream()), "field_backward")
+        del sdf_bar_c, grad_bar_c, rgb_bar_c
         return theta_bar, table_bar, emb_bar, None, None, None, None, None
 
 
@@ -184,7 +191,8 @@ class _GeoNetFunction(torch.autograd.Function):
         NP = _lib.padded_points(P)
         h = fld._handle
         packed = torch.empty(lib.sdfhip_field_packed_size(h), device=dev)
-        _lib.check(lib.sdfhip_field_pack(h, _lib.ptr(theta.contiguous()), _lib.ptr(packed), _lib.stream()), "field_pack")
+        theta_c = theta.contiguous()
+        _lib.check(lib.sdfhip_field_pack(h, _lib.ptr(theta_c), _lib.ptr(packed), _lib.stream()), "field_pack")
         ws = torch.empty(lib.sdfhip_geo_workspace_size(h, P), dtype=torch.uint8, device=dev)
         sdf = torch.empty(NP, device=dev)
         feat = torch.empty(P, fld.config.geo_feat_dim, device=dev)
@@ -202,12 +210,11 @@ class _GeoNetFunction(torch.autograd.Function):
         theta_bar = torch.zeros(lib.sdfhip_field_theta_size(h), device=packed.device)  # colour entries stay zero
         table_bar = torch.zeros_like(table)
 
-        def c(t):
-            return None if t is None else t.contiguous()
-
+        sdf_bar_c, feat_bar_c = _contig(sdf_bar), _contig(feat_bar)
         _lib.check(lib.sdfhip_geo_backward(h, _lib.ptr(packed), _lib.ptr(mask), ctx.P, ctypes.c_void_p(ws.data_ptr()),
-                                           _lib.ptr(c(sdf_bar)), _lib.ptr(c(feat_bar)), _lib.ptr(theta_bar), _lib.ptr(table_bar),
+                                           _lib.ptr(sdf_bar_c), _lib.ptr(feat_bar_c), _lib.ptr(theta_bar), _lib.ptr(table_bar),
                                            _lib.stream()), "geo_backward")
+        del sdf_bar_c, feat_bar_c
         return theta_bar, table_bar, None, None, None
 
 
@@ -223,13 +230,15 @@ class _ColorFunction(torch.autograd.Function):
         NP = _lib.padded_points(P)
         h = fld._handle
         packed = torch.empty(lib.sdfhip_field_packed_size(h), device=dev)
-        _lib.check(lib.sdfhip_field_pack(h, _lib.ptr(theta.contiguous()), _lib.ptr(packed), _lib.stream()), "field_pack")
+        theta_c = theta.contiguous()
+        _lib.check(lib.sdfhip_field_pack(h, _lib.ptr(theta_c), _lib.ptr(packed), _lib.stream()), "field_pack")
         ws = torch.empty(lib.sdfhip_color_workspace_size(h, P), dtype=torch.uint8, device=dev)
         rgb = torch.empty(NP, 3, device=dev)
-        emb_c = None if emb is None else emb.contiguous()
-        _lib.check(lib.sdfhip_color_forward(h, _lib.ptr(packed), _lib.ptr(feat.contiguous()), _lib.ptr(x.contiguous()),
-                                            _lib.ptr(dirs.contiguous()), _lib.ptr(grad.contiguous()), _lib.ptr(emb_c), n, s,
-                                            ctypes.c_void_p(ws.data_ptr()), _lib.ptr(rgb), _lib.stream()), "color_forward")
+        emb_c, feat_c, x_c, dirs_c, grad_c = _contig(emb), _contig(feat), _contig(x), _contig(dirs), _contig(grad)
+        _lib.check(lib.sdfhip_color_forward(h, _lib.ptr(packed), _lib.ptr(feat_c), _lib.ptr(x_c), _lib.ptr(dirs_c), _lib.ptr(grad_c),
+                                            _lib.ptr(emb_c), n, s, ctypes.c_void_p(ws.data_ptr()), _lib.ptr(rgb), _lib.stream()),
+                   "color_forward")
+        del emb_c, feat_c, x_c, dirs_c, grad_c
         ctx.save_for_backward(packed, ws)
         ctx.fld, ctx.shape, ctx.has_emb = fld, (n, s), emb is not None
         return rgb[:P]
@@ -246,9 +255,11 @@ class _ColorFunction(torch.autograd.Function):
         feat_bar = torch.empty(n * s, fld.config.geo_feat_dim, device=dev)
         grad_bar = torch.empty(n * s, 3, device=dev)
         emb_bar = torch.zeros(n, fld.config.appearance_embedding_dim, device=dev) if ctx.has_emb else None
-        _lib.check(lib.sdfhip_color_backward(h, _lib.ptr(packed), n, s, ctypes.c_void_p(ws.data_ptr()), _lib.ptr(rgb_bar.contiguous()),
+        rgb_bar_c = _contig(rgb_bar)
+        _lib.check(lib.sdfhip_color_backward(h, _lib.ptr(packed), n, s, ctypes.c_void_p(ws.data_ptr()), _lib.ptr(rgb_bar_c),
                                              _lib.ptr(theta_bar), _lib.ptr(feat_bar), _lib.ptr(grad_bar), _lib.ptr(emb_bar),
                                              _lib.stream()), "color_backward")
+        del rgb_bar_c
         return theta_bar, feat_bar, grad_bar, emb_bar, None, None, None, None, None
 
 
@@ -513,6 +524,16 @@ class SDFField(nn.Module):
         """sdf_field.py:527-530."""
         return torch.sigmoid(-10.0 * sdf)
 
+    def _appearance_embedding(self, ray_samples, n: int):
+        """sdf_field.py:551-565: per-camera embedding in training, the mean embedding (or zeros = None) in eval."""
+        if not self.config.use_appearance_embedding:
+            return None
+        if self.training:
+            return self.embedding_appearance(ray_samples.camera_indices.reshape(n, -1)[:, 0])
+        if self.use_average_appearance_embedding:
+            return self.embedding_appearance.mean(dim=0)[None, :].expand(n, -1)
+        return None
+
     def get_outputs(self, ray_samples, return_alphas=False, return_occupancy=False) -> Dict:
         """sdf_field.py:614-689."""
         if ray_samples.camera_indices is None:
@@ -520,13 +541,7 @@ class SDFField(nn.Module):
         o, d, st, _ = unpack_ray_samples(ray_samples)
         n, s = st.shape
         dev = o.device
-        emb = None
-        if self.config.use_appearance_embedding:
-            cam = ray_samples.camera_indices.reshape(n, -1)[:, 0]
-            if self.training:
-                emb = self.embedding_appearance(cam)
-            elif self.use_average_appearance_embedding:
-                emb = self.embedding_appearance.mean(dim=0)[None, :].expand(n, -1)
+        emb = self._appearance_embedding(ray_samples, n)
         sampled_sdf = None
         if self.config.use_numerical_gradients:
             sdf, grad, rgb, x, sampled_sdf = self._numerical_outputs(ray_samples, o, d, st, emb)
@@ -560,9 +575,7 @@ class SDFField(nn.Module):
             raise AttributeError("Camera indices are not provided.")
         o, d, st, _ = unpack_ray_samples(ray_samples)
         n = st.shape[0]
-        emb = None
-        if self.config.use_appearance_embedding and self.training:
-            emb = self.embedding_appearance(ray_samples.camera_indices.reshape(n, -1)[:, 0])
+        emb = self._appearance_embedding(ray_samples, n)
         if self.config.use_numerical_gradients:
             sdf, grad, rgb, x, self.last_sampled_sdf = self._numerical_outputs(ray_samples, o, d, st, emb)
             return sdf, grad, rgb, x

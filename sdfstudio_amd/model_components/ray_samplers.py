@@ -149,11 +149,13 @@ class NeuSSampler(Sampler):
         m_index = torch.empty(n, s + n_new, device=dev, dtype=torch.int32)
         m_starts = torch.empty(n, s + n_new, device=dev)
         m_ends = torch.empty(n, s + n_new, device=dev)
+        kp = _lib.Keep()
         _lib.check(lib.sdfhip_neus_upsample(
-            _lib.ptr(bins.contiguous()), _lib.ptr(sdf_a.contiguous()), _lib.ptr(None if sdf_b is None else sdf_b.contiguous()),
+            kp(bins), kp(sdf_a), kp(sdf_b),
             None if index is None else index.data_ptr(), _lib.ptr(nears), _lib.ptr(fars), _lib.ptr(jitter), n, s_a, s_b, n_new,
             float(inv_s), _lib.ptr(sdf_m), _lib.ptr(new_bins), _lib.ptr(new_starts), _lib.ptr(new_ends), _lib.ptr(m_bins),
             m_index.data_ptr(), _lib.ptr(m_starts), _lib.ptr(m_ends), _lib.stream()), "neus_upsample")
+        del kp
         return sdf_m, new_bins, new_starts, new_ends, m_bins, m_index, m_starts, m_ends
 
     def generate_ray_samples(self, ray_bundle: Optional[RayBundle] = None, sdf_fn: Optional[Callable] = None,
@@ -217,10 +219,12 @@ class ErrorBoundedSampler(Sampler):
         out_bins = torch.empty(n, s_out + 1, device=dev)
         starts = torch.empty(n, s_out, device=dev)
         ends = torch.empty(n, s_out, device=dev)
-        _lib.check(lib.sdfhip_sample_pdf_uniform(_lib.ptr(weights.contiguous()), _lib.ptr(bins.contiguous()), _lib.ptr(nears),
+        kp = _lib.Keep()
+        _lib.check(lib.sdfhip_sample_pdf_uniform(kp(weights), kp(bins), _lib.ptr(nears),
                                                  _lib.ptr(fars), _lib.ptr(jitter), 0 if self.single_jitter else 1, n, s_in, s_out,
                                                  1e-5, _lib.ptr(out_bins), _lib.ptr(starts), _lib.ptr(ends), _lib.stream()),
                    "sample_pdf_uniform")
+        del kp
         return out_bins, starts, ends
 
     def merge(self, ray_bundle, bins_1, bins_2):
@@ -233,9 +237,11 @@ class ErrorBoundedSampler(Sampler):
         m_index = torch.empty(n, s1 + s2, device=dev, dtype=torch.int32)
         m_starts = torch.empty(n, s1 + s2, device=dev)
         m_ends = torch.empty(n, s1 + s2, device=dev)
-        _lib.check(lib.sdfhip_merge_uniform(_lib.ptr(bins_1.contiguous()), _lib.ptr(bins_2.contiguous()), _lib.ptr(nears), _lib.ptr(fars),
+        kp = _lib.Keep()
+        _lib.check(lib.sdfhip_merge_uniform(kp(bins_1), kp(bins_2), _lib.ptr(nears), _lib.ptr(fars),
                                             n, s1, s2, _lib.ptr(m_bins), m_index.data_ptr(), _lib.ptr(m_starts), _lib.ptr(m_ends),
                                             _lib.stream()), "merge_uniform")
+        del kp
         return m_bins, m_index, m_starts, m_ends
 
     def bound_step(self, ray_bundle, bins, sdf_a, sdf_b, index, beta, beta0):
@@ -252,11 +258,13 @@ class ErrorBoundedSampler(Sampler):
         weights = torch.empty(n, s, device=dev)
         err_w = torch.empty(n, s, device=dev)
         flag = torch.zeros(1, device=dev, dtype=torch.int32)
+        kp = _lib.Keep()
         _lib.check(lib.sdfhip_volsdf_bound_step(
-            _lib.ptr(bins.contiguous()), _lib.ptr(sdf_a.contiguous()), _lib.ptr(None if sdf_b is None else sdf_b.contiguous()),
-            None if index is None else index.data_ptr(), _lib.ptr(nears), _lib.ptr(fars), _lib.ptr(beta.contiguous()),
-            _lib.ptr(beta0.reshape(1).contiguous()), n, s_a, s_b, float(self.eps), int(self.beta_iters), _lib.ptr(sdf_m),
+            kp(bins), kp(sdf_a), kp(sdf_b),
+            None if index is None else index.data_ptr(), _lib.ptr(nears), _lib.ptr(fars), kp(beta),
+            kp(beta0.reshape(1)), n, s_a, s_b, float(self.eps), int(self.beta_iters), _lib.ptr(sdf_m),
             _lib.ptr(beta_out), _lib.ptr(weights), _lib.ptr(err_w), flag.data_ptr(), _lib.stream()), "volsdf_bound_step")
+        del kp
         return sdf_m, beta_out, weights, err_w, flag
 
     def generate_ray_samples(self, ray_bundle: Optional[RayBundle] = None, density_fn: Optional[Callable] = None,

@@ -33,9 +33,11 @@ class _DensityWeights(torch.autograd.Function):
         lib = _lib.load()
         n, s = density.shape
         dbar = torch.empty_like(density)
+        kp = _lib.Keep()
         _lib.check(lib.sdfhip_density_weights_backward(_lib.ptr(density), _lib.ptr(starts), _lib.ptr(ends), n, s,
-                                                       _lib.ptr(wbar.contiguous()), _lib.ptr(dbar), _lib.stream()),
+                                                       kp(wbar), _lib.ptr(dbar), _lib.stream()),
                    "density_weights_backward")
+        del kp
         return dbar, None, None
 
 
@@ -80,15 +82,14 @@ class _NeusRender(torch.autograd.Function):
         rgbs_bar = torch.empty_like(rgb)
         var_bar = torch.zeros_like(variance)
 
-        def c(t):
-            return None if t is None else t.contiguous()
-
+        kp = _lib.Keep()  # cotangents may be stride-0 expands: their contiguous copies must all outlive the launch
         _lib.check(lib.sdfhip_neus_render_backward(
             _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(rgb), _lib.ptr(dirs), _lib.ptr(starts), _lib.ptr(ends),
             _lib.ptr(variance), _lib.ptr(ctx.background), ctx.cos_anneal, n, s, _lib.ptr(alpha), _lib.ptr(weights),
-            _lib.ptr(depth_raw), _lib.ptr(acc), _lib.ptr(minmax), _lib.ptr(c(rgb_bar)), _lib.ptr(c(depth_bar)),
-            _lib.ptr(c(normal_bar)), _lib.ptr(c(acc_bar)), _lib.ptr(c(weights_bar)), _lib.ptr(sdf_bar), _lib.ptr(grad_bar),
+            _lib.ptr(depth_raw), _lib.ptr(acc), _lib.ptr(minmax), kp(rgb_bar), kp(depth_bar),
+            kp(normal_bar), kp(acc_bar), kp(weights_bar), _lib.ptr(sdf_bar), _lib.ptr(grad_bar),
             _lib.ptr(rgbs_bar), _lib.ptr(var_bar), _lib.stream()), "neus_render_backward")
+        del kp
         return sdf_bar, grad_bar, rgbs_bar, var_bar, None, None, None, None, None
 
 

@@ -52,3 +52,78 @@ def test_flat_gradient_allreduce_world2():
     assert torch.allclose(g0[:15], torch.full((15,), 6.0))
     assert torch.allclose(g0[15:18], torch.full((3,), 4.0))
     assert torch.allclose(g0[18:], torch.full((7,), 1.5))
+
+
+def _bench_worker(rank, world, port, ret):
+    """The parameter set, groups and exchange of bench.py's N > 1 step on the REAL NeuS-facto module tree (built on the CPU: the
+    kernels need a GPU, the gradient exchange does not), with synthetic per-rank gradients pushed through autograd so the
+    post-accumulate hooks, the buckets and the zero_grad recovery run exactly as in training."""
+    import sys
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    from sdfstudio_amd.distributed import FlatGradients, broadcast_parameters
+
+    model = bench.build_model(torch.device("cpu"), small=True)
+    with torch.no_grad():
+        for p in model.parameters():
+            p.add_(0.01 * rank)  # ranks start apart: the broadcast must equalise them
+    broadcast_parameters(model)
+    groups = {k: v for k, v in model.get_param_groups().items() if v}
+    assert set(groups) == {"fields", "proposal_networks"}
+    params = [p for g in groups.values() for p in g if p.requires_grad]
+    flat = FlatGradients(params, buckets=list(groups.values()))
+    launched = []
+    orig = flat._launch
+    flat._launch = lambda bi: (launched.append(bi), orig(bi))[1]
+
+    def backward(scale):
+        loss = sum((p * (scale * (i % 7 + 1))).sum() for i, p in enumerate(params))
+        loss.backward()
+
+    flat.zero()
+    backward(float(rank + 1))
+    assert sorted(set(launched)) == [0, 1], "every bucket must be all-reduced from the autograd hooks, before finish()"
+    flat.finish()
+    g_first = flat.flat.clone()
+    # 2. a stray model.zero_grad() (set_to_none=True) must not leave the flat buffer stale
+    model.zero_grad()
+    assert params[0].grad is None
+    flat.zero()
+    backward(float(rank + 1))
+    flat.finish()
+    assert torch.equal(flat.flat, g_first), "gradients after zero_grad(set_to_none=True) differ"
+    assert params[0].grad.data_ptr() == flat.flat.data_ptr()
+    # 3. active prefix (progressive hash levels): only the first rows of the table travel; the rest stays local
+    table = model.field.encoding.params
+    flat.set_active_numel(table, 1000)
+    n_all = sum(p.numel() for p in params)
+    assert flat.exchanged_numel() == n_all - (table.numel() - 1000)
+    flat.zero()
+    backward(float(rank + 1))
+    flat.finish()
+    off = flat._offset[id(table)]
+    ret[rank] = (torch.cat([p.detach().reshape(-1)[:50] for p in params[:4]]), g_first, flat.flat[off:off + 2000].clone(), flat.exchanged_numel())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_parameter_groups_bucketed_allreduce_world2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_bench_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    p0, g0, t0, n0 = ret[0]
+    p1, g1, t1, n1 = ret[1]
+    assert torch.equal(p0, p1), "parameters were not broadcast"
+    assert torch.equal(g0, g1), "gradients differ after the bucketed all-reduce"
+    # d/dp of sum(p * s * c_i) = s c_i with s = 1, 2 on the two ranks -> mean 1.5 c_i; parameter 0 has c = 1
+    assert torch.allclose(g0[:10], torch.full((10,), 1.5))
+    # active prefix: the first 1000 table entries are means (equal on both ranks), the tail kept the local gradient
+    assert torch.equal(t0[:1000], t1[:1000]) and not torch.equal(t0[1000:], t1[1000:])
+    assert n0 == n1

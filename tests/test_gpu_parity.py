@@ -531,6 +531,25 @@ def test_field_small_fwd_bwd(device, n, s):
     _check_field_grads(model, po)
 
 
+def test_field_small_expanded_cotangents(device):
+    """Cotangents that arrive as stride-0 expands (plain .sum() losses with DIFFERENT scales per head): the binding must keep
+    every contiguous copy it makes alive until the launch, or two of them alias one allocator block."""
+    g = load_golden("train")
+    cfg = small_oracle_cfg()
+    model = product_model_from_params(g["param"], cfg, device).train()
+    n, s = 16, 8
+    o, d, cam, starts = _field_case(cfg, g["param"], n, s, seed=5)
+    scales = (1.0, -0.25, 3.0)
+    coefs = [torch.full((n, s), scales[0]), torch.full((n, s, 3), scales[1]), torch.full((n, s, 3), scales[2])]
+    fo, po = _oracle_field(cfg.field, g["param"], o, d, cam, starts, coefs)
+    rb = _bundle(o, d, cam, 0.5, 4.5, device)
+    st = starts.to(device)
+    sdf, grad, rgb, _ = model.field.forward_fused(rb.get_ray_samples(st, st + 1.0))
+    model.zero_grad()
+    (scales[0] * sdf.sum() + scales[1] * grad.sum() + scales[2] * rgb.sum()).backward()  # all three cotangents are expands
+    _check_field_grads(model, po)
+
+
 def test_field_small_level_mask_and_reference_style_outputs(device):
     from sdfstudio_amd.fields.field_heads import FieldHeadNames as H
 
