@@ -161,6 +161,16 @@ int sdfhip_sample_spaced(const float* nears, const float* fars, const float* jit
  * jitter: [n_rays] (single_jitter) or, with jitter_per_sample != 0, [n_rays, n_samples+1] (ray_samplers.py:107-110), or NULL. */
 int sdfhip_sample_uniform(const float* nears, const float* fars, const float* jitter, int32_t jitter_per_sample, int64_t n_rays,
                           int32_t n_samples, float* bins, float* starts, float* ends, sdfhip_stream_t stream);
+/* Any SpacedSampler subclass (ray_samplers.py:55-247): spacing = SDFHIP_SPACING_* selects spacing_fn / spacing_fn_inv
+ * (piecewise :221-247, uniform :130-151, linear disparity :154-175, sqrt :178-198, log :201-218); jitter as above
+ * (single draw per ray, or per bin edge with jitter_per_sample != 0, ray_samplers.py:105-113). */
+#define SDFHIP_SPACING_PIECEWISE 0
+#define SDFHIP_SPACING_UNIFORM 1
+#define SDFHIP_SPACING_LINDISP 2
+#define SDFHIP_SPACING_SQRT 3
+#define SDFHIP_SPACING_LOG 4
+int sdfhip_sample_spacing(int32_t spacing, const float* nears, const float* fars, const float* jitter, int32_t jitter_per_sample,
+                          int64_t n_rays, int32_t n_samples, float* bins, float* starts, float* ends, sdfhip_stream_t stream);
 /* PDFSampler(include_original=False, single_jitter) (ray_samplers.py:275-370) applied to weights^anneal
  * (ProposalNetworkSampler :562).  Outputs are constants w.r.t. autograd (bins.detach(), :358). */
 int sdfhip_sample_pdf(const float* weights, const float* bins_in, const float* nears, const float* fars,

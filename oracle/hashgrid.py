@@ -13,7 +13,7 @@ Published algorithm (restated):
   per level l:  scale_l = fp32( exp2(l * log2(per_level_scale)) * base_res - 1 )  (evaluated in double, see make_levels)
                 res_l   = ceil(scale_l) + 1
                 size_l  = min(next_multiple(res_l^3, 8), 2^log2_hashmap_size)
-  position:     pos = x * scale_l + 0.5 ; cell = floor(pos) ; w = pos - cell
+  position:     pos = fmaf(scale_l, x, 0.5) (ONE rounding, tcnn grid.h pos_fract) ; cell = floor(pos) ; w = pos - cell
                 Smoothstep: w <- w^2 (3 - 2 w)
   corner index: dense  (res_l^3 <= size_l):  (cx + cy*res + cz*res^2)        mod size_l
                 hashed (otherwise):          (cx*1 ^ cy*2654435761 ^ cz*805459861) mod size_l   (uint32)
@@ -100,13 +100,24 @@ def corner_index(cx: torch.Tensor, cy: torch.Tensor, cz: torch.Tensor, res: int,
     return idx % size
 
 
+def _fma_half(x: torch.Tensor, scale: float) -> torch.Tensor:
+    """fmaf(scale, x, 0.5): tcnn's pos_fract rounds the multiply-add ONCE.  In fp32 the exact product of two fp32 numbers fits
+    a double and so does its sum with 0.5 at these magnitudes (48 significant bits), so rounding the fp64 value to fp32 IS the
+    fused result; the correction is detached, the autograd path stays d pos / d x = scale.  (fp64 inputs: plain arithmetic.)"""
+    pos = x * scale + 0.5
+    if x.dtype == torch.float32:
+        fused = (x.detach().double() * float(np.float32(scale)) + 0.5).float()
+        pos = pos + (fused - pos.detach())
+    return pos
+
+
 def grid_encode(x: torch.Tensor, table: torch.Tensor, lv: GridLevels) -> torch.Tensor:
     """x: [P,3] in [0,1]; table: [n_entries, F]; returns [P, L*F]."""
     outs: List[torch.Tensor] = []
     for lvl in range(lv.n_levels):
         scale = float(lv.scale[lvl])
         res, size, off = int(lv.resolution[lvl]), int(lv.size[lvl]), int(lv.offset[lvl])
-        pos = x * scale + 0.5
+        pos = _fma_half(x, scale)
         cell = torch.floor(pos)
         w = pos - cell
         if lv.smoothstep:

@@ -371,8 +371,26 @@ def spacing_to_euclidean(bins: torch.Tensor, nears: torch.Tensor, fars: torch.Te
     return piecewise_spacing_inv(bins * s_far + (1 - bins) * s_near)
 
 
+SPACINGS = {
+    # spacing_fn / spacing_fn_inv of the SpacedSampler subclasses, ray_samplers.py:130-247
+    "piecewise": (piecewise_spacing, piecewise_spacing_inv),
+    "uniform": (lambda x: x, lambda x: x),
+    "lindisp": (lambda x: 1 / x, lambda x: 1 / x),
+    "sqrt": (torch.sqrt, lambda x: x ** 2),
+    "log": (torch.log, torch.exp),
+}
+
+
+def spaced_to_euclidean(kind: str, bins: torch.Tensor, nears: torch.Tensor, fars: torch.Tensor) -> torch.Tensor:
+    """ray_samplers.py:115-117 for any SpacedSampler subclass: fn_inv(x s_far + (1 - x) s_near)."""
+    fn, inv = SPACINGS[kind]
+    s_near, s_far = fn(nears)[:, None], fn(fars)[:, None]
+    return inv(bins * s_far + (1 - bins) * s_near)
+
+
 def initial_bins(n_rays: int, num_samples: int, t_rand: Optional[torch.Tensor], dtype=torch.float32):
-    """ray_samplers.py:101-113. t_rand: [N,1] single-jitter draw, or None for eval-mode (deterministic) bins."""
+    """ray_samplers.py:101-113. t_rand: [N,1] single-jitter draw, [N,S+1] per-bin-edge draws (single_jitter=False, :107-110), or None
+    for eval-mode (deterministic) bins."""
     bins = torch.linspace(0.0, 1.0, num_samples + 1, dtype=dtype)[None, :].expand(n_rays, -1)
     if t_rand is not None:
         centers = (bins[:, 1:] + bins[:, :-1]) / 2.0

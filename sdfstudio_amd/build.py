@@ -36,7 +36,7 @@ def _closure(name: str, seen: set) -> None:
         for line in fh:
             m = re.match(r'\s*#\s*include\s+"([^"]+)"', line)
             if m and os.path.exists(os.path.join(CSRC, m.group(1))):
-                _closure(m.group(1), seen)
+                _closure(os.path.normpath(m.group(1)), seen)  # also "../../include/sdfhip.h": only the units that see the ABI header
 
 
 def _digest(src: str) -> str:
@@ -47,8 +47,6 @@ def _digest(src: str) -> str:
     for name in sorted(deps):
         with open(os.path.join(CSRC, name), "rb") as fh:
             h.update(fh.read())
-    with open(os.path.join(HERE, "..", "include", "sdfhip.h"), "rb") as fh:
-        h.update(fh.read())
     return h.hexdigest()[:16]
 
 

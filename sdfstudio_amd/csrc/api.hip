@@ -1194,6 +1194,12 @@ extern "C" int sdfhip_sample_uniform(const float* nears, const float* fars, cons
                                      sdfhip_stream_t stream) {
   return sample_spaced_impl(nears, fars, jitter, jitter_per_sample, n_rays, n_samples, 1, bins, starts, ends, stream);
 }
+extern "C" int sdfhip_sample_spacing(int32_t spacing, const float* nears, const float* fars, const float* jitter,
+                                     int32_t jitter_per_sample, int64_t n_rays, int32_t n_samples, float* bins, float* starts,
+                                     float* ends, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(spacing >= SP_PIECEWISE && spacing <= SP_LOG, "sample_spacing: unknown spacing %d", spacing);
+  return sample_spaced_impl(nears, fars, jitter, jitter_per_sample, n_rays, n_samples, spacing, bins, starts, ends, stream);
+}
 
 #define SDFHIP_DISPATCH_C(S, CALL)                                      \
   do {                                                                  \

@@ -44,9 +44,9 @@ SDFHIP_D void grid_cell(const GridLevelDev& L, const bool smooth, const float p[
   uint32_t g[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    // un-fused multiply-add on purpose: the parity oracle (oracle/hashgrid.py) evaluates x * scale + 0.5 with two fp32
-    // roundings; at scale ~2e3 a fused fma moves the interpolation weight by up to 1e-4
-    const float pos = __fadd_rn(__fmul_rn(L.scale, p[d]), 0.5f);
+    // ONE rounding, as tiny-cuda-nn's pos_fract does: fmaf(scale, x, 0.5f) (grid.h); the oracle (oracle/hashgrid.py) forms the
+    // same value through an exact fp64 product.  At scale ~2e3 the un-fused form moves the interpolation weight by up to 1e-4.
+    const float pos = __builtin_fmaf(L.scale, p[d], 0.5f);
     const float fl = floorf(pos);
     const float f = pos - fl;
     g[d] = (uint32_t)(int)fl;

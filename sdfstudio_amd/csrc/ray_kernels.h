@@ -404,6 +404,26 @@ __global__ __launch_bounds__(256) void density_weights_bwd_kernel(const DensityW
 // ------------------------------------------------------------------------------------------------ samplers
 SDFHIP_D float piecewise_fn(const float x) { return x < 1.0f ? x * 0.5f : 1.0f - 1.0f / (2.0f * x); }
 SDFHIP_D float piecewise_inv(const float x) { return x < 0.5f ? 2.0f * x : 1.0f / (2.0f - 2.0f * x); }
+// spacing_fn / spacing_fn_inv of the SpacedSampler subclasses (ray_samplers.py:130-247)
+enum { SP_PIECEWISE = 0, SP_UNIFORM = 1, SP_LINDISP = 2, SP_SQRT = 3, SP_LOG = 4 };
+SDFHIP_D float spacing_fn(const int kind, const float x) {
+  switch (kind) {
+    case SP_UNIFORM: return x;
+    case SP_LINDISP: return 1.0f / x;
+    case SP_SQRT: return sqrtf(x);
+    case SP_LOG: return logf(x);
+    default: return piecewise_fn(x);
+  }
+}
+SDFHIP_D float spacing_inv(const int kind, const float x) {
+  switch (kind) {
+    case SP_UNIFORM: return x;
+    case SP_LINDISP: return 1.0f / x;
+    case SP_SQRT: return x * x;
+    case SP_LOG: return expf(x);
+    default: return piecewise_inv(x);
+  }
+}
 
 struct BinsArgs {
   const float* nears;  // [N]
@@ -411,7 +431,8 @@ struct BinsArgs {
   const float* jitter; // [N] single-jitter draw in [0,1), [N,S+1] per-sample draws (jitter_stride = S+1), or null (deterministic)
   int32_t jitter_stride;
   int32_t N, S;        // S samples -> S+1 bins
-  int32_t uniform;     // 0: UniformLinDispPiecewiseSampler spacing (ray_samplers.py:240-241), 1: UniformSampler (identity, :130-151)
+  int32_t uniform;     // SP_*: 0 UniformLinDispPiecewiseSampler (ray_samplers.py:240-241), 1 UniformSampler (:130-151), 2 LinearDisparity
+                       // (:154-175), 3 Sqrt (:178-198), 4 Log (:201-218)
   float* bins;         // [N,S+1] spacing-domain bins
   float* starts;       // [N,S] euclidean
   float* ends;         // [N,S]
@@ -434,11 +455,11 @@ __global__ void spaced_bins_kernel(const BinsArgs a) {
   }
   a.bins[idx] = b;
   float e;
-  if (a.uniform) {
+  if (a.uniform == SP_UNIFORM) {
     e = b * a.fars[ray] + (1.0f - b) * a.nears[ray];
   } else {
-    const float sn = piecewise_fn(a.nears[ray]), sf = piecewise_fn(a.fars[ray]);
-    e = piecewise_inv(b * sf + (1.0f - b) * sn);
+    const float sn = spacing_fn(a.uniform, a.nears[ray]), sf = spacing_fn(a.uniform, a.fars[ray]);
+    e = spacing_inv(a.uniform, b * sf + (1.0f - b) * sn);
   }
   if (j < a.S) a.starts[(int64_t)ray * a.S + j] = e;
   if (j > 0) a.ends[(int64_t)ray * a.S + j - 1] = e;

@@ -14,16 +14,30 @@ from sdfstudio_amd import _lib
 from sdfstudio_amd.cameras.rays import RayBundle, RaySamples
 
 
+_SPACINGS = {
+    # name: (kernel id (include/sdfhip.h SDFHIP_SPACING_*), spacing_fn, spacing_fn_inv)  -- ray_samplers.py:130-247
+    "piecewise": (0, lambda v: torch.where(v < 1, v / 2, 1 - 1 / (2 * v)), lambda v: torch.where(v < 0.5, 2 * v, 1 / (2 - 2 * v))),
+    "uniform": (1, lambda v: v, lambda v: v),
+    "lindisp": (2, lambda v: 1 / v, lambda v: 1 / v),
+    "sqrt": (3, torch.sqrt, lambda v: v ** 2),
+    "log": (4, torch.log, torch.exp),
+}
+
+
+def _spacing_to_euclidean(kind: str, nears: torch.Tensor, fars: torch.Tensor) -> Callable:
+    """spacing_to_euclidean_fn of a SpacedSampler (ray_samplers.py:115-117): x -> fn_inv(x s_far + (1 - x) s_near)."""
+    _, fn, inv = _SPACINGS[kind]
+    if kind == "uniform":
+        return lambda x: x * fars + (1 - x) * nears
+
+    def to_euclidean(x):
+        return inv(x * fn(fars) + (1 - x) * fn(nears))
+
+    return to_euclidean
+
+
 def _piecewise_to_euclidean(nears: torch.Tensor, fars: torch.Tensor) -> Callable:
-    """spacing_to_euclidean_fn of UniformLinDispPiecewiseSampler (ray_samplers.py:115-117, 240-241)."""
-
-    def fn(x):
-        sp = lambda v: torch.where(v < 1, v / 2, 1 - 1 / (2 * v))
-        inv = lambda v: torch.where(v < 0.5, 2 * v, 1 / (2 - 2 * v))
-        s_near, s_far = sp(nears), sp(fars)
-        return inv(x * s_far + (1 - x) * s_near)
-
-    return fn
+    return _spacing_to_euclidean("piecewise", nears, fars)
 
 
 class Sampler(nn.Module):
@@ -37,78 +51,90 @@ class Sampler(nn.Module):
         return self.generate_ray_samples(*args, **kwargs)
 
 
-def _make_samples(ray_bundle: RayBundle, bins, starts, ends) -> RaySamples:
+def _make_samples(ray_bundle: RayBundle, bins, starts, ends, kind: str = "piecewise") -> RaySamples:
     return ray_bundle.get_ray_samples(
         bin_starts=starts[..., None], bin_ends=ends[..., None], spacing_starts=bins[:, :-1, None],
-        spacing_ends=bins[:, 1:, None], spacing_to_euclidean_fn=_piecewise_to_euclidean(ray_bundle.nears, ray_bundle.fars),
+        spacing_ends=bins[:, 1:, None], spacing_to_euclidean_fn=_spacing_to_euclidean(kind, ray_bundle.nears, ray_bundle.fars),
         flat_bins=bins,
     )
 
 
-class UniformLinDispPiecewiseSampler(Sampler):
-    """ray_samplers.py:221-247: first half uniform, second half linear in disparity."""
+def _make_uniform_samples(ray_bundle: RayBundle, bins, starts, ends) -> RaySamples:
+    return _make_samples(ray_bundle, bins, starts, ends, "uniform")
 
-    def __init__(self, num_samples: Optional[int] = None, train_stratified=True, single_jitter=True) -> None:
+
+class SpacedSampler(Sampler):
+    """ray_samplers.py:55-127: stratified bins in a spacing domain mapped back to euclidean distances, ONE kernel launch
+    (sdfhip_sample_spacing) for the whole family.  `spacing` names the (spacing_fn, spacing_fn_inv) pair; the reference's
+    default is per-bin-edge jitter (single_jitter=False, ray_samplers.py:105-113), neus-facto uses one draw per ray."""
+
+    spacing = "uniform"
+
+    def __init__(self, num_samples: Optional[int] = None, train_stratified=True, single_jitter=False, spacing: Optional[str] = None) -> None:
         super().__init__(num_samples=num_samples)
-        if not single_jitter:
-            raise NotImplementedError("per-sample jitter is not built; neus-facto uses single_jitter=True")
-        self.train_stratified = train_stratified
-        self.jitter_override: Optional[torch.Tensor] = None  # tests inject the draw here
-
-    def generate_ray_samples(self, ray_bundle: RayBundle, num_samples: Optional[int] = None) -> RaySamples:
-        lib = _lib.load()
-        s = num_samples or self.num_samples
-        n = len(ray_bundle)
-        dev = ray_bundle.origins.device
-        nears = ray_bundle.nears.reshape(-1).contiguous()
-        fars = ray_bundle.fars.reshape(-1).contiguous()
-        jitter = None
-        if self.train_stratified and self.training:
-            jitter = self.jitter_override if self.jitter_override is not None else torch.rand(n, device=dev)
-            jitter = jitter.reshape(-1).contiguous()
-        bins = torch.empty(n, s + 1, device=dev)
-        starts = torch.empty(n, s, device=dev)
-        ends = torch.empty(n, s, device=dev)
-        _lib.check(lib.sdfhip_sample_spaced(_lib.ptr(nears), _lib.ptr(fars), _lib.ptr(jitter), n, s, _lib.ptr(bins),
-                                            _lib.ptr(starts), _lib.ptr(ends), _lib.stream()), "sample_spaced")
-        return _make_samples(ray_bundle, bins, starts, ends)
-
-
-class UniformSampler(Sampler):
-    """ray_samplers.py:130-151: uniform spacing (identity spacing_fn); euclidean = x far + (1 - x) near."""
-
-    def __init__(self, num_samples: Optional[int] = None, train_stratified=True, single_jitter=False) -> None:
-        super().__init__(num_samples=num_samples)
+        if spacing is not None:
+            self.spacing = spacing
+        if self.spacing not in _SPACINGS:
+            raise ValueError(f"unknown spacing {self.spacing!r}; built: {sorted(_SPACINGS)}")
         self.train_stratified = train_stratified
         self.single_jitter = single_jitter
-        self.jitter_override: Optional[torch.Tensor] = None  # tests: [N,1] (single) or [N,S+1] (per sample)
+        self.jitter_override: Optional[torch.Tensor] = None  # tests inject the draw: [N] / [N,1] (single) or [N,S+1] (per edge)
 
     def generate_ray_samples(self, ray_bundle: RayBundle, num_samples: Optional[int] = None) -> RaySamples:
         lib = _lib.load()
+        assert ray_bundle is not None and ray_bundle.nears is not None and ray_bundle.fars is not None
         s = num_samples or self.num_samples
+        assert s is not None
         n = len(ray_bundle)
         dev = ray_bundle.origins.device
-        nears = ray_bundle.nears.reshape(-1).contiguous()
-        fars = ray_bundle.fars.reshape(-1).contiguous()
+        kp = _lib.Keep()
         jitter = None
         if self.train_stratified and self.training:
             shape = (n,) if self.single_jitter else (n, s + 1)
             jitter = self.jitter_override if self.jitter_override is not None else torch.rand(shape, device=dev)
-            jitter = jitter.reshape(shape).contiguous()
+            jitter = jitter.reshape(shape)
         bins = torch.empty(n, s + 1, device=dev)
         starts = torch.empty(n, s, device=dev)
         ends = torch.empty(n, s, device=dev)
-        _lib.check(lib.sdfhip_sample_uniform(_lib.ptr(nears), _lib.ptr(fars), _lib.ptr(jitter), 0 if self.single_jitter else 1, n, s,
-                                             _lib.ptr(bins), _lib.ptr(starts), _lib.ptr(ends), _lib.stream()), "sample_uniform")
-        return _make_uniform_samples(ray_bundle, bins, starts, ends)
+        _lib.check(lib.sdfhip_sample_spacing(_SPACINGS[self.spacing][0], kp(ray_bundle.nears.reshape(-1)), kp(ray_bundle.fars.reshape(-1)),
+                                             kp(jitter), 0 if self.single_jitter else 1, n, s, _lib.ptr(bins), _lib.ptr(starts),
+                                             _lib.ptr(ends), _lib.stream()), "sample_spacing")
+        del kp
+        return _make_samples(ray_bundle, bins, starts, ends, self.spacing)
 
 
-def _make_uniform_samples(ray_bundle: RayBundle, bins, starts, ends) -> RaySamples:
-    nears, fars = ray_bundle.nears, ray_bundle.fars
-    return ray_bundle.get_ray_samples(
-        bin_starts=starts[..., None], bin_ends=ends[..., None], spacing_starts=bins[:, :-1, None], spacing_ends=bins[:, 1:, None],
-        spacing_to_euclidean_fn=lambda x: x * fars + (1 - x) * nears, flat_bins=bins,
-    )
+class UniformSampler(SpacedSampler):
+    """ray_samplers.py:130-151."""
+
+    spacing = "uniform"
+
+
+class LinearDisparitySampler(SpacedSampler):
+    """ray_samplers.py:154-175 (the background sampler of the surface models, base_surface_model.py:214)."""
+
+    spacing = "lindisp"
+
+
+class SqrtSampler(SpacedSampler):
+    """ray_samplers.py:178-198."""
+
+    spacing = "sqrt"
+
+
+class LogSampler(SpacedSampler):
+    """ray_samplers.py:201-218."""
+
+    spacing = "log"
+
+
+class UniformLinDispPiecewiseSampler(SpacedSampler):
+    """ray_samplers.py:221-247: first half uniform, second half linear in disparity."""
+
+    spacing = "piecewise"
+
+    def __init__(self, num_samples: Optional[int] = None, train_stratified=True, single_jitter=True) -> None:
+        # (the reference's default is single_jitter=False; every caller on the path passes single_jitter, neus_facto.py:145)
+        super().__init__(num_samples=num_samples, train_stratified=train_stratified, single_jitter=single_jitter)
 
 
 class NeuSSampler(Sampler):

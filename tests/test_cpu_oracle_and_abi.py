@@ -404,3 +404,36 @@ def test_rgb_renderer_background_modes():
     ones = torch.ones(n, s, 3)
     assert torch.allclose(RGBRenderer(torch.zeros(3)).train()(ones, torch.full((n, s, 1), 1.0 / s)), torch.ones(n, 3), atol=1e-6)
     assert torch.allclose(RGBRenderer(white).eval()(ones * 2.0, torch.full((n, s, 1), 1.0 / s)), torch.ones(n, 3))  # eval clamps
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/nerfstudio"), reason="the reference tree only exists in the build container")
+@pytest.mark.parametrize("kind", ["piecewise", "uniform", "lindisp", "sqrt", "log"])
+def test_spaced_sampler_oracle_against_reference(kind):
+    """Pins oracle.spaced_to_euclidean / initial_bins on the reference's own SpacedSampler subclasses (ray_samplers.py:130-247),
+    per-edge and single jitter (torch.rand patched so both sides see the same draw)."""
+    from oracle import ref_harness
+
+    ns = ref_harness.import_reference()
+    RefBundle, ref = ns.rays.RayBundle, ns.rs
+
+    cls = {"piecewise": ref.UniformLinDispPiecewiseSampler, "uniform": ref.UniformSampler, "lindisp": ref.LinearDisparitySampler,
+           "sqrt": ref.SqrtSampler, "log": ref.LogSampler}[kind]
+    torch.manual_seed(1)
+    n, S = 13, 24
+    o, d, _ = O.synthetic_rays(n)
+    nears, fars = 0.05 + torch.rand(n, 1), 2.0 + 100.0 * torch.rand(n, 1)
+    rb = RefBundle(origins=o, directions=d, pixel_area=torch.ones(n, 1), nears=nears, fars=fars)
+    for single in (True, False):
+        jit = torch.rand(n, 1) if single else torch.rand(n, S + 1)
+        smp = cls(num_samples=S, single_jitter=single).train()
+        real_rand = torch.rand
+        torch.rand = lambda *a, **k: jit.clone()
+        try:
+            rs = smp(rb)
+        finally:
+            torch.rand = real_rand
+        bins = O.initial_bins(n, S, jit)
+        eu = O.spaced_to_euclidean(kind, bins, nears[:, 0], fars[:, 0])
+        assert torch.allclose(rs.spacing_starts[..., 0], bins[:, :-1], rtol=0, atol=1e-7)
+        assert torch.allclose(rs.frustums.starts[..., 0], eu[:, :-1], rtol=1e-6, atol=1e-6)
+        assert torch.allclose(rs.frustums.ends[..., 0], eu[:, 1:], rtol=1e-6, atol=1e-6)

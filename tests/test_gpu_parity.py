@@ -82,6 +82,35 @@ def test_pdf_sampler(device, training, shape):
 
 
 # ------------------------------------------------------------------------------------------------ NeuS sampler
+@pytest.mark.parametrize("single_jitter", [True, False])
+@pytest.mark.parametrize("kind", ["piecewise", "uniform", "lindisp", "sqrt", "log"])
+def test_spaced_sampler_family(device, kind, single_jitter):
+    """Every SpacedSampler subclass (ray_samplers.py:130-247), one draw per ray and one per bin edge (:105-113), train + eval."""
+    from sdfstudio_amd.model_components import ray_samplers as RS
+
+    cls = {"piecewise": RS.UniformLinDispPiecewiseSampler, "uniform": RS.UniformSampler, "lindisp": RS.LinearDisparitySampler,
+           "sqrt": RS.SqrtSampler, "log": RS.LogSampler}[kind]
+    torch.manual_seed(3)
+    n, S = 67, 48
+    o, d, cam = O.synthetic_rays(n)
+    nears, fars = 0.05 + torch.rand(n), 2.0 + 100.0 * torch.rand(n)  # the background sampler runs to far = 1000 (base_surface_model.py)
+    rb = _bundle(o, d, cam, 0.5, 4.5, device)
+    rb.nears, rb.fars = nears[:, None].to(device), fars[:, None].to(device)
+    for training in (True, False):
+        jit = torch.rand(n, 1) if single_jitter else torch.rand(n, S + 1)
+        smp = cls(single_jitter=single_jitter).train(training)
+        smp.jitter_override = jit.to(device)
+        rs = smp(rb, num_samples=S)
+        bins = O.initial_bins(n, S, jit if training else None)
+        eu = O.spaced_to_euclidean(kind, bins, nears, fars)
+        assert_close(f"{kind} bins", rs.flat_bins, bins, rtol=0, atol=2e-7)
+        assert_close(f"{kind} starts", rs.flat_starts, eu[:, :-1], rtol=2e-6, atol=1e-6)
+        assert_close(f"{kind} ends", rs.flat_ends, eu[:, 1:], rtol=2e-6, atol=1e-6)
+        x = torch.rand(n, 5)  # applied to [N, bins] tensors, as the PDF sampler does (ray_samplers.py:359)
+        assert_close(f"{kind} spacing_to_euclidean_fn", rs.spacing_to_euclidean_fn(x.to(device)),
+                     O.spaced_to_euclidean(kind, x, nears, fars), rtol=2e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("training", [True, False])
 def test_uniform_sampler(device, training):
     from sdfstudio_amd.model_components.ray_samplers import UniformSampler

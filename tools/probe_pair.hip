@@ -22,6 +22,12 @@ constexpr int NB = 8, L = PROBE_L;
 #ifndef PAIR_NBUF
 #define PAIR_NBUF 2  // weight chunk buffers: 2 = the next chunk streams in during a step, 3 = two chunks ahead
 #endif
+#ifndef PAIR_SB
+#define PAIR_SB 1  // 1: sched_barriers keep the MFMA groups / production batches where they are written; 0: compiler schedule
+#endif
+#ifndef PAIR_BATCH
+#define PAIR_BATCH 4  // elements produced per batch
+#endif
 #ifndef PAIR_BAL
 #define PAIR_BAL 1  // 1: every wave produces HALF a block per step (first half kept in registers); 0: a whole block every other step
 #endif
@@ -124,7 +130,10 @@ __device__ __forceinline__ void pair_body(const float* __restrict__ in_tp, const
       constexpr bool pown1 = ((kb & 1) == ROLE), pown2 = PAIR_BAL && kb + 1 < NB && (((kb + 1) & 1) == ROLE);
       constexpr int pne = (pown1 || pown2) ? (PAIR_BAL ? 8 : 16) : 0;
       constexpr int NMc = 8 * NT;
-      constexpr int zs_prev = pne - ((PPW - 1) * pne + NMc - 1) / NMc;
+      // (batches follow their MFMA group: batch j after group floor((j + 1) 8 / NBATCH) - 1 >= the group holding the last piece
+      // whenever NBATCH <= 4, so every store of the previous step is newer than the chunk's DMA)
+      constexpr int zs_prev = pne;
+      static_assert(PPW <= 2 * NT, "the DMA pieces must sit in the first two MFMA groups");
       constexpr int zs_top = ROLE == 0 ? 16 : (PAIR_BAL ? 8 : 0);
       constexpr int newer = !SAVE ? 0 : (kb == 0 ? zs_top : zs_prev);
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((PAIR_ABL & 1) ? 0 : newer + (PAIR_NBUF - 2) * PPW) : "memory");
@@ -139,34 +148,39 @@ __device__ __forceinline__ void pair_body(const float* __restrict__ in_tp, const
         for (int kk = 0; kk < 2; ++kk) bfr[q][kk] = *reinterpret_cast<const bf16x8*>(rcur + (q * 2 + kk) * 512);
       constexpr int cn = c + PAIR_NBUF - 1;
       const __bf16* gnext = wp + (size_t)(cn < L * NB ? cn : L * NB - 1) * CH;
-      bf16x8 a[2][NS];
+      bf16x8 a[3][NS];  // weight fragments: the group being multiplied and the next two, in flight from LDS
       auto load_a = [&](auto gc) __attribute__((always_inline)) {
         constexpr int g = decltype(gc)::value, kk = g / 4, i = g % 4;
 #pragma unroll
-        for (int q = 0; q < NS; ++q) a[g & 1][q] = *reinterpret_cast<const bf16x8*>(wcur + ((q * NB + 2 * i + ROLE) * 2 + kk) * 512);
+        for (int q = 0; q < NS; ++q) a[g % 3][q] = *reinterpret_cast<const bf16x8*>(wcur + ((q * NB + 2 * i + ROLE) * 2 + kk) * 512);
       };
       load_a(IC<0>{});
-      constexpr int NM = 8 * NT;
+      load_a(IC<1>{});
+      // production: batches of PAIR_BATCH elements (independent dependency chains the compiler interleaves) after every
+      // 8 / nbatch-th MFMA group; the partner wave's MFMAs cover them
+      constexpr int NBATCH = ne / PAIR_BATCH;
       static_for<0, 8>([&](auto gc) __attribute__((always_inline)) {
         constexpr int g = decltype(gc)::value, kk = g / 4, i = g % 4;
-        if constexpr (g + 1 < 8) load_a(IC<(g + 1 < 8 ? g + 1 : 0)>{});
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (g + 2 < 8) load_a(IC<(g + 2 < 8 ? g + 2 : 0)>{});
+        if constexpr (PAIR_SB) __builtin_amdgcn_sched_barrier(0);
         static_for<0, NT>([&](auto tc) __attribute__((always_inline)) {
           constexpr int t = decltype(tc)::value;
-          out[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g & 1][ta[t]], bfr[tb[t]][kk], out[i], 0, 0, 0);
+          out[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[g % 3][ta[t]], bfr[tb[t]][kk], out[i], 0, 0, 0);
           constexpr int m = g * NT + t;
           if constexpr (m < PPW && (PAIR_ABL & 1) == 0) dma_piece(gnext, cn % PAIR_NBUF, m);  // the next chunk's DMA pieces ride in the first gaps
-          // the production work is spread evenly over the MFMA gaps: element j of this step's ne after MFMA floor(j NM / ne)
-          constexpr int jlo = (m * ne + NM - 1) / NM, jhi = ((m + 1) * ne + NM - 1) / NM;
+        });
+        // batch j of NBATCH after group floor((j + 1) 8 / NBATCH) - 1
+        if constexpr (NBATCH > 0) {
+          constexpr int jlo = (g * NBATCH) / 8, jhi = ((g + 1) * NBATCH) / 8;
           if constexpr (jlo < jhi) {
-            static_for<jlo, jhi>([&](auto jc) __attribute__((always_inline)) {
+            if constexpr (PAIR_SB) __builtin_amdgcn_sched_barrier(0);
+            static_for<jlo * PAIR_BATCH, jhi * PAIR_BATCH>([&](auto jc) __attribute__((always_inline)) {
               constexpr int e = e0 + decltype(jc)::value;
               put(np, e, make_elem(l, pb, e, in[pb >> 1][e]));
             });
           }
-          if constexpr (jlo < jhi || m < PPW) __builtin_amdgcn_sched_barrier(0);
-        });
-        __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (PAIR_SB) __builtin_amdgcn_sched_barrier(0);
       });
       if constexpr (own1) publish((kb + 1) & 1, np);
     });
