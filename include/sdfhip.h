@@ -171,6 +171,13 @@ int sdfhip_sample_uniform(const float* nears, const float* fars, const float* ji
 #define SDFHIP_SPACING_LOG 4
 int sdfhip_sample_spacing(int32_t spacing, const float* nears, const float* fars, const float* jitter, int32_t jitter_per_sample,
                           int64_t n_rays, int32_t n_samples, float* bins, float* starts, float* ends, sdfhip_stream_t stream);
+/* interlevel_loss_zip (model_components/losses.py:116-172), the part per proposal level: the field histogram (c [n_rays, s+1]
+ * spacing bins, w [n_rays, s] weights; both constants) blurred with half-width `radius` (0.03 / 0.003 for the two levels, :138)
+ * and resampled at the proposal bins cp [n_rays, s_p+1]; against the proposal weights wp [n_rays, s_p]:
+ *   term = clip(w_gt - wp, 0)^2 / (wp + 1e-5),  dterm = d term / d wp   ([n_rays, s_p] each; w_gt optional, may be NULL).
+ * The loss of the level is mean(term) (:171); only wp carries gradient. */
+int sdfhip_interlevel_terms(const float* c, const float* w, const float* cp, const float* wp, int64_t n_rays, int32_t s, int32_t s_p,
+                            float radius, float* term, float* dterm, float* w_gt, sdfhip_stream_t stream);
 /* PDFSampler(include_original=False, single_jitter) (ray_samplers.py:275-370) applied to weights^anneal
  * (ProposalNetworkSampler :562).  Outputs are constants w.r.t. autograd (bins.detach(), :358). */
 int sdfhip_sample_pdf(const float* weights, const float* bins_in, const float* nears, const float* fars,

@@ -7,6 +7,7 @@
 
 #include "../../include/sdfhip.h"
 #include "field_inst.h"
+#include "wgrad_kernels.h"
 #include "point_kernels.h"
 #include "ray_kernels.h"
 
@@ -135,6 +136,39 @@ static int make_grid_dev(const SdfHipGridCfg* cfg, GridDev* g) {
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ per-thread fork / join state
+// Work that is independent of the caller's stream for a while (the atomics-bound hash-table scatter beside the weight-gradient
+// GEMMs) runs on a side stream, forked from / joined back into the caller's stream with events so the caller still sees
+// plain stream order.  The stream and its two events belong to the CALLING THREAD (created on first use, released at thread
+// exit), not to the field handle: the handle stays immutable and can be shared by the trainer and the viewer thread
+// (SURVEY section 8b), and nothing is created or destroyed on the hot path.
+struct SideLane {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool tried = false;
+  bool ready() {
+    if (!tried) {
+      tried = true;
+      if (getenv("SDFHIP_NO_OVERLAP") != nullptr) return false;
+      if (hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess ||
+          hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) {
+        release();
+      }
+    }
+    return stream != nullptr;
+  }
+  void release() {
+    if (fork) (void)hipEventDestroy(fork);
+    if (join) (void)hipEventDestroy(join);
+    if (stream) (void)hipStreamDestroy(stream);
+    fork = join = nullptr;
+    stream = nullptr;
+  }
+  ~SideLane() { release(); }
+};
+static thread_local SideLane g_side;
+
 // ------------------------------------------------------------------------------------------------ field handle
 struct LinearInfo {
   int out_dim, in_dim;
@@ -159,10 +193,6 @@ struct SdfHipField {
   int32_t* d_maps = nullptr;
   int max_pack_elems = 0, max_vec_n = 0;
   int64_t max_partial_elems = 0, max_partial_rows = 0;
-  // Side stream for work that is independent of the caller's stream for a while (the atomics-bound hash-table scatter runs
-  // beside the weight-gradient GEMMs).  Always forked from / joined back into the caller's stream with events, so the
-  // caller still sees plain stream order.
-  hipStream_t side = nullptr;
 
   int kb_geo(int l) const { return l == 0 ? k->nb0 : (l == k->skip ? k->nb3 + k->nb0 : k->nbh); }
   int nbo_geo(int l) const { return l == k->nl ? k->nbf : ((l + 1 == k->skip) ? k->nb3 : k->nbh); }
@@ -343,7 +373,7 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
     const int m3 = add_map(maps, ident(3, 3));
     f->c_bout = add_vec(li.b_off, 3, m3, 1);
   }
-  f->packed_size = poff + 1024;  // the chunk DMA moves whole 4 KiB rounds: slack behind the last chunk
+  f->packed_size = poff + 2048;  // the chunk DMA moves whole 4 KiB rounds: slack behind the last chunk
   // largest split-K partial
   auto upd = [&](int rows_blocks, int col_blocks) {
     f->max_partial_elems = std::max<int64_t>(f->max_partial_elems, (int64_t)rows_blocks * 32 * col_blocks * 32);
@@ -354,7 +384,6 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
   upd(1, k->nbc);
   f->max_partial_elems = std::max<int64_t>(f->max_partial_elems, k->nbh * 32 + 32);
 
-  if (getenv("SDFHIP_NO_OVERLAP") == nullptr) (void)hipStreamCreateWithFlags(&f->side, hipStreamNonBlocking);
   hipError_t e = hipMalloc((void**)&f->d_pack, f->pack.size() * sizeof(PackDesc));
   if (e == hipSuccess) e = hipMalloc((void**)&f->d_vec, f->vec.size() * sizeof(VecDesc));
   if (e == hipSuccess) e = hipMalloc((void**)&f->d_maps, maps.size() * sizeof(int32_t));
@@ -375,7 +404,6 @@ extern "C" void sdfhip_field_destroy(SdfHipField* f) {
   if (f->d_pack) (void)hipFree(f->d_pack);
   if (f->d_vec) (void)hipFree(f->d_vec);
   if (f->d_maps) (void)hipFree(f->d_maps);
-  if (f->side) (void)hipStreamDestroy(f->side);
   delete f;
 }
 
@@ -460,21 +488,22 @@ extern "C" int sdfhip_field_pack(const SdfHipField* f, const float* theta, float
   return 0;
 }
 
-static void fill_geo_ptrs(const SdfHipField* f, const float* packed, GeoPtrs* p) {
+// ns: the precision mode of the kernel that will read the weights (mlp_core.h): the pointers address the first part it streams
+static void fill_geo_ptrs(const SdfHipField* f, const float* packed, GeoPtrs* p, const int ns) {
   memset(p, 0, sizeof(*p));
   for (int l = 0; l <= f->k->nl; ++l) {
-    p->wp[l] = packed + f->g_wp[l];
-    p->wpT[l] = packed + f->g_wpT[l];
+    p->wp[l] = packed + f->g_wp[l] + chunk_part_offset(f->nbo_geo(l), ns);
+    p->wpT[l] = packed + f->g_wpT[l] + chunk_part_offset(f->kb_geo(l), ns);
     p->bias[l] = packed + f->g_bias[l];
   }
   p->w_sdf = packed + f->g_wsdf;
   p->b_sdf = packed + f->g_bsdf;
 }
-static void fill_col_ptrs(const SdfHipField* f, const float* packed, ColPtrs* p) {
+static void fill_col_ptrs(const SdfHipField* f, const float* packed, ColPtrs* p, const int ns) {
   memset(p, 0, sizeof(*p));
   for (int l = 0; l < f->k->nlc; ++l) {
-    p->wp[l] = packed + f->c_wp[l];
-    p->wpT[l] = packed + f->c_wpT[l];
+    p->wp[l] = packed + f->c_wp[l] + chunk_part_offset(f->k->nbc, ns);
+    p->wpT[l] = packed + f->c_wpT[l] + chunk_part_offset(f->kb_col(l), ns);
     p->bias[l] = packed + f->c_bias[l];
   }
   p->w_out = packed + f->c_wout;
@@ -530,7 +559,7 @@ extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, c
 
   GeoFwdArgs ga;
   memset(&ga, 0, sizeof(ga));
-  fill_geo_ptrs(f, packed, &ga.p);
+  fill_geo_ptrs(f, packed, &ga.p, kNsFwd);
   ga.in0_tp = w.in0;
   for (int l = 0; l < k->nl; ++l) {
     ga.z_tp[l] = w.z[l];
@@ -566,7 +595,7 @@ extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, c
 
     ColFwdArgs ca;
     memset(&ca, 0, sizeof(ca));
-    fill_col_ptrs(f, packed, &ca.p);
+    fill_col_ptrs(f, packed, &ca.p, kNsCol);
     ca.feat_tp = w.feat;
     ca.csmall_tp = w.csmall;
     for (int l = 0; l < k->nlc; ++l) ca.h_tp[l] = w.h[l];
@@ -604,10 +633,18 @@ static void run_wgrad(const SdfHipField* f, const FieldWs& w, const WgradArgs& b
       for (int ib = 0; ib < a.nbb; ib += 8) {
         a.ob_base = ob;
         a.ib_base = ib;
-        const int na = (std::min(8, a.nba - ob) + 1) / 2, nb = (std::min(8, a.nbb - ib) + 1) / 2;
-        // weight-gradient products: split-bf16 (3 bf16 MFMAs per product, fp32 accumulate) by default; SDFHIP_WGRAD_FP32=1
-        // selects the exact-fp32 MFMA kernel (A/B and strict-fp32 runs)
+        const int rows = std::min(8, a.nba - ob), cols = std::min(8, a.nbb - ib);
+        // weight-gradient products: split-bf16 (3 bf16 MFMAs per product, fp32 accumulate).  Default: the 8-wave double-buffered
+        // kernel; SDFHIP_WGRAD_V1=1 the 4-wave one; SDFHIP_WGRAD_FP32=1 the exact-fp32 MFMA kernel (A/B and strict-fp32 runs)
         static const bool fp32 = getenv("SDFHIP_WGRAD_FP32") != nullptr && getenv("SDFHIP_WGRAD_FP32")[0] == '1';
+        static const bool v1 = getenv("SDFHIP_WGRAD_V1") != nullptr && getenv("SDFHIP_WGRAD_V1")[0] == '1';
+        if (!fp32 && !v1) {
+          WgradKernelFn fn = wgrad8_pick((rows + 3) / 4, (cols + 1) / 2);
+          (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, kW8LdsBytes);
+          hipLaunchKernelGGL(fn, dim3((unsigned)w.n_split), dim3(512), kW8LdsBytes, s, a);
+          continue;
+        }
+        const int na = (rows + 1) / 2, nb = (cols + 1) / 2;
         WgradKernelFn fn = wgrad_pick(na, nb, fp32);
         const int lds_bytes = fp32 ? kWgLdsBytes : kWbLdsBytes;
         (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
@@ -805,7 +842,7 @@ extern "C" int sdfhip_geo_forward(const SdfHipField* f, const float* packed, con
   { ProfScope ps_(PS_ENCODE, s); geo_encode_kernel<<<dim3((unsigned)(NP / 256 + (NP % 256 != 0)), f->grid.n_levels * (f->grid.n_features / 2) + 1), 256, 0, s>>>(ea); }
   GeoFwdArgs ga;
   memset(&ga, 0, sizeof(ga));
-  fill_geo_ptrs(f, packed, &ga.p);
+  fill_geo_ptrs(f, packed, &ga.p, kNsFwd);
   ga.in0_tp = w.in0;
   for (int l = 0; l < k->nl; ++l) ga.z_tp[l] = w.z[l];
   ga.feat_tp = w.feat;
@@ -836,7 +873,7 @@ extern "C" int sdfhip_geo_backward(const SdfHipField* f, const float* packed, co
 
   GeoBwdArgs gb;
   memset(&gb, 0, sizeof(gb));
-  fill_geo_ptrs(f, packed, &gb.p);
+  fill_geo_ptrs(f, packed, &gb.p, kNsGrad);
   gb.featbar_tp = w.featbar;
   gb.sdfbar = w.sdfbar;
   for (int l = 0; l < k->nl; ++l) {
@@ -929,7 +966,7 @@ extern "C" int sdfhip_color_forward(const SdfHipField* f, const float* packed, c
   { ProfScope ps_(PS_ASSEMBLE, s); grad_assemble_kernel<<<(unsigned)(NP / 256 + (NP % 256 != 0)), 256, 0, s>>>(aa); }
   ColFwdArgs ca;
   memset(&ca, 0, sizeof(ca));
-  fill_col_ptrs(f, packed, &ca.p);
+  fill_col_ptrs(f, packed, &ca.p, kNsCol);
   ca.feat_tp = w.feat;
   ca.csmall_tp = w.csmall;
   for (int l = 0; l < k->nlc; ++l) ca.h_tp[l] = w.h[l];
@@ -965,7 +1002,7 @@ extern "C" int sdfhip_color_backward(const SdfHipField* f, const float* packed, 
   carve_col(f, P, workspace, &w);
   ColBwdArgs cb;
   memset(&cb, 0, sizeof(cb));
-  fill_col_ptrs(f, packed, &cb.p);
+  fill_col_ptrs(f, packed, &cb.p, kNsGrad);
   cb.rgb = w.rgb;
   cb.rgbbar = rgb_bar;
   cb.n_points = P;
@@ -1006,7 +1043,7 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
   // 1. colour network backward
   ColBwdArgs cb;
   memset(&cb, 0, sizeof(cb));
-  fill_col_ptrs(f, packed, &cb.p);
+  fill_col_ptrs(f, packed, &cb.p, kNsGrad);
   cb.rgb = w.rgb;
   cb.rgbbar = rgb_bar;
   cb.n_points = rgb_bar != nullptr ? P : 0;
@@ -1046,7 +1083,7 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
   // 3. geometry network: tangent pass + data backward
   GeoBwdArgs gb;
   memset(&gb, 0, sizeof(gb));
-  fill_geo_ptrs(f, packed, &gb.p);
+  fill_geo_ptrs(f, packed, &gb.p, kNsGrad);
   gb.ebar_tp = w.ebar;
   gb.featbar_tp = w.featbar;
   gb.sdfbar = w.sdfbar;
@@ -1073,30 +1110,21 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
   ga.nb0 = k->nb0;
   ga.tablebar = table_bar;
   // forked: nothing below reads table_bar, and the scatter is bound by memory-side atomics, not by CUs
-  hipEvent_t ev_join = nullptr;
-  {
-    hipStream_t gs = s;
-    if (f->side != nullptr) {
-      hipEvent_t ev_fork = nullptr;
-      SDFHIP_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-      SDFHIP_CHECK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-      SDFHIP_CHECK_HIP(hipEventRecord(ev_fork, s));
-      SDFHIP_CHECK_HIP(hipStreamWaitEvent(f->side, ev_fork, 0));
-      (void)hipEventDestroy(ev_fork);  // released once the wait has consumed it
-      gs = f->side;
-    }
-    { ProfScope ps_(PS_GRID_BWD, gs); grid_bwd_kernel<<<dim3((unsigned)((P + 255) / 256), f->grid.n_levels * (f->grid.n_features / 2)), 256, 0, gs>>>(ga); }
-    if (ev_join != nullptr) SDFHIP_CHECK_HIP(hipEventRecord(ev_join, gs));
+  const bool forked = g_side.ready();
+  hipStream_t gs = s;
+  if (forked) {
+    SDFHIP_CHECK_HIP(hipEventRecord(g_side.fork, s));
+    SDFHIP_CHECK_HIP(hipStreamWaitEvent(g_side.stream, g_side.fork, 0));
+    gs = g_side.stream;
   }
+  { ProfScope ps_(PS_GRID_BWD, gs); grid_bwd_kernel<<<dim3((unsigned)((P + 255) / 256), f->grid.n_levels * (f->grid.n_features / 2)), 256, 0, gs>>>(ga); }
+  if (forked) SDFHIP_CHECK_HIP(hipEventRecord(g_side.join, gs));
 
   // 5. weight gradients: split-K GEMMs over points
   const int64_t n_tiles = NP / 32;
   run_geo_wgrads(f, w, true, n_tiles, theta_bar, s);
   run_col_wgrads(f, w, n_tiles, theta_bar, s);
-  if (ev_join != nullptr) {
-    SDFHIP_CHECK_HIP(hipStreamWaitEvent(s, ev_join, 0));
-    (void)hipEventDestroy(ev_join);
-  }
+  if (forked) SDFHIP_CHECK_HIP(hipStreamWaitEvent(s, g_side.join, 0));
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1199,6 +1227,30 @@ extern "C" int sdfhip_sample_spacing(int32_t spacing, const float* nears, const 
                                      float* ends, sdfhip_stream_t stream) {
   SDFHIP_REQUIRE(spacing >= SP_PIECEWISE && spacing <= SP_LOG, "sample_spacing: unknown spacing %d", spacing);
   return sample_spaced_impl(nears, fars, jitter, jitter_per_sample, n_rays, n_samples, spacing, bins, starts, ends, stream);
+}
+
+extern "C" int sdfhip_interlevel_terms(const float* c, const float* w, const float* cp, const float* wp, int64_t n_rays, int32_t s,
+                                       int32_t s_p, float radius, float* term, float* dterm, float* w_gt, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(c && w && cp && wp && term && dterm, "interlevel_terms: null argument");
+  SDFHIP_REQUIRE(s >= 1 && s_p >= 1 && 2 * (s + 1) <= 1024 && radius > 0.0f, "interlevel_terms: unsupported shape (S %d, S_p %d)", s, s_p);
+  if (n_rays == 0) return 0;
+  InterlevelArgs a;
+  a.c = c;
+  a.w = w;
+  a.cp = cp;
+  a.wp = wp;
+  a.N = (int)n_rays;
+  a.S = s;
+  a.Sp = s_p;
+  a.r = radius;
+  a.term = term;
+  a.dterm = dterm;
+  a.w_gt = w_gt;
+  const size_t lds = 4 * sizeof(float) * (size_t)(4 * (s + 1) + 4 * (s + 1) + (s_p + 1));
+  SDFHIP_REQUIRE(lds <= 64 * 1024, "interlevel_terms: %d + %d samples do not fit the LDS staging", s, s_p);
+  interlevel_kernel<<<(unsigned)((n_rays + 3) / 4), 256, lds, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
 }
 
 #define SDFHIP_DISPATCH_C(S, CALL)                                      \

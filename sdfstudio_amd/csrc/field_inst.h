@@ -2,7 +2,7 @@
 // compiled in its own translation unit (inst_*.hip) so the build parallelises; the API layer picks the table.
 #pragma once
 #include "col_kernels.h"
-#include "wgrad_kernels.h"
+#include "sdfrow_kernel.h"
 
 struct FieldKernels {
   int nbh, nb0, nb3, nl, skip, nbf, nbs, nbc, nlc;

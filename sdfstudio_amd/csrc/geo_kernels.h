@@ -18,17 +18,18 @@
 #include "mlp_core.h"
 
 constexpr int kMaxLayers = 10;
-// bf16 parts per operand (mlp_core.h).  Everything the forward call returns (sdf, geo feature, d sdf / dx, rgb) is computed
-// with 6-term products (fp32-class: these carry the parity targets, and the raw d sdf / dx feeds the colour network's
-// ReLUs); the backward kernels (tangent pass, data backward, colour backward) use 3-term products.
+// Precision modes (mlp_core.h).  Everything the forward call returns (sdf, geo feature, d sdf / dx, rgb) carries the parity
+// targets and the raw d sdf / dx feeds the colour network's ReLUs: fp32-class products, by default as fp16 hi + lo parts with
+// 3 terms (mode 4; -DSDFHIP_NS_FWD=3 selects the 6-term bf16 form, twice the matrix instructions for the last two mantissa
+// bits); the backward kernels (tangent pass, data backward, colour backward) use 3-term bf16 products (mode 2).
 #ifndef SDFHIP_NS_FWD
-#define SDFHIP_NS_FWD 3
+#define SDFHIP_NS_FWD 4
 #endif
 #ifndef SDFHIP_NS_GRAD
 #define SDFHIP_NS_GRAD 2
 #endif
 constexpr int kNsFwd = SDFHIP_NS_FWD, kNsGrad = SDFHIP_NS_GRAD;
-constexpr int kNsMax = kNsFwd > kNsGrad ? kNsFwd : kNsGrad;
+constexpr int kNsMax = ns_parts(kNsFwd) > ns_parts(kNsGrad) ? kNsFwd : kNsGrad;  // the mode with the larger weight chunks
 
 template <int NBH_, int NB0_, int NB3_, int NL_, int SKIP_, int NBF_>
 struct GeoDims {

@@ -31,11 +31,23 @@
 template <int N>
 using IC = std::integral_constant<int, N>;
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));  // also the raw 16-byte carrier of 8 fp16 (NS == 4)
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kChunkBlockFloats = 1536;  // HBM: one (k block, out block) pair = 3 bf16 parts x 32 x 32 weights
-// KiB pieces the DMA moves for one chunk of nbo out-blocks and ns parts (4 waves x 1 KiB per instruction round)
-SDFHIP_HD constexpr int chunk_pieces(const int nbo, const int ns) { return (nbo * ns * 2 + 3) / 4 * 4; }
+// Precision modes ("NS").  2: bf16 hi + lo, 3-term products.  3: three bf16 parts, 6-term products (all 24 mantissa bits).
+// 4: fp16 hi + lo, 3-term products: 22 mantissa bits (absolute 2^-25 below 0.125), measured on the 8 x 256^2 softplus stack
+// at 5.0e-7 of the result against 4.2e-7 for the 6-term bf16 form and 5.6e-6 for the 3-term bf16 form
+// (tools/probe_split.hip -DPROBE_F16), at HALF the matrix instructions of the 6-term form.  fp16 has no exponent headroom
+// (max 65504, the split saturates there), so it serves the forward passes (activations, d sdf / dx chain: O(1) data); the
+// backward passes carry loss gradients of arbitrary scale and stay on bf16 parts.
+SDFHIP_HD constexpr int ns_parts(const int ns) { return ns == 4 ? 2 : ns; }   // operand parts held / streamed
+SDFHIP_HD constexpr int ns_first(const int ns) { return ns == 4 ? 3 : 0; }    // first part of a packed chunk the mode reads
+constexpr int kChunkParts = 5;  // packed chunk: bf16 parts 0..2, then fp16 parts 0..1
+constexpr int kChunkBlockFloats = kChunkParts * 512;  // HBM: one (k block, out block) pair = 5 parts x 32 x 32 16-bit weights
+// KiB pieces the DMA moves for one chunk of nbo out-blocks in mode ns (4 waves x 1 KiB per instruction round)
+SDFHIP_HD constexpr int chunk_pieces(const int nbo, const int ns) { return (nbo * ns_parts(ns) * 2 + 3) / 4 * 4; }
+// offset (floats) of the parts mode ns streams inside a packed chunk of nbo out-blocks: the host adds it to the weight pointers
+SDFHIP_HD constexpr int chunk_part_offset(const int nbo, const int ns) { return ns_first(ns) * nbo * 512; }
 
 struct WStream {
   float* lds;        // two chunk buffers of buf_floats each
@@ -75,27 +87,16 @@ struct WStream {
   SDFHIP_D void flip() { cur ^= 1; }
 };
 
-// One 32-feature activation block split into NS bf16 parts; p[q][kk] is the B operand of the MFMAs of k half kk.
+// One 32-feature activation block split into the parts of mode NS; p[q][kk] is the B operand of the MFMAs of k half kk.
 template <int NS>
 struct SplitBlk {
-  bf16x8 p[NS][2];
+  bf16x8 p[ns_parts(NS)][2];
 };
+// one product term of mode NS: acc += A * B
 template <int NS>
-SDFHIP_D SplitBlk<NS> split_block(const f32x16& v) {
-  SplitBlk<NS> s;
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float r = v[kk * 8 + j];
-#pragma unroll
-      for (int q = 0; q < NS; ++q) {
-        const __bf16 h = (__bf16)r;
-        s.p[q][kk][j] = h;
-        if (q + 1 < NS) r -= (float)h;
-      }
-    }
-  return s;
+SDFHIP_D f32x16 mfma_term(const bf16x8 a, const bf16x8 b, const f32x16 acc) {
+  if constexpr (NS == 4) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
 }
 
 // What a producer reads from HBM for one input block: up to two TP blocks (e.g. z_l and zc_l); unused members cost nothing.
@@ -152,7 +153,7 @@ struct Stores {
 // out-blocks per operand-read group: a divisor of NBO, small enough that two groups of weight fragments (the one being
 // multiplied and the one in flight from LDS) fit the register budget next to 256 accumulator registers
 constexpr int gemm_group(const int nbo, const int ns) {
-  const int gmax = ns == 3 ? 2 : 4;
+  const int gmax = ns_parts(ns) == 3 ? 2 : 4;
   for (int g = gmax; g > 1; --g)
     if (nbo % g == 0) return g;
   return nbo <= 5 ? nbo : 1;
@@ -161,11 +162,18 @@ constexpr int gemm_group(const int nbo, const int ns) {
 // element e (TP register index) of a block under construction -> its slot in the split operand
 template <int NS, int E>
 SDFHIP_D void split_put(SplitBlk<NS>& s, float r) {
+  if constexpr (NS == 4) {
+    r = __builtin_amdgcn_fmed3f(r, -65504.0f, 65504.0f);  // fp16 has no exponent headroom: saturate instead of inf
+    const _Float16 h = (_Float16)r;
+    s.p[0][E >> 3][E & 7] = __builtin_bit_cast(__bf16, h);
+    s.p[1][E >> 3][E & 7] = __builtin_bit_cast(__bf16, (_Float16)(r - (float)h));
+  } else {
 #pragma unroll
-  for (int q = 0; q < NS; ++q) {
-    const __bf16 h = (__bf16)r;
-    s.p[q][E >> 3][E & 7] = h;
-    if (q + 1 < NS) r -= (float)h;
+    for (int q = 0; q < NS; ++q) {
+      const __bf16 h = (__bf16)r;
+      s.p[q][E >> 3][E & 7] = h;
+      if (q + 1 < NS) r -= (float)h;
+    }
   }
 }
 
@@ -173,12 +181,13 @@ template <int KB, int NBO, class ST, int NS, int NEXTP, int MAXA, class Fetch, c
 SDFHIP_D void tp_gemm(f32x16 (&acc)[MAXA], Raw& carry, Fetch&& fetch, Make&& make, NextFetch&& next_fetch, WStream& ws,
                       const float* __restrict__ wp, const float* __restrict__ next_wp) {
   static_assert(NBO <= MAXA, "accumulator tile too small");
-  static_assert(NS == 2 || NS == 3, "2 or 3 bf16 parts");
+  static_assert(NS == 2 || NS == 3 || NS == 4, "bf16 x 2, bf16 x 3 or fp16 x 2 parts");
   static_assert(NEXTP % 4 == 0, "whole DMA rounds");
   // (weight part, activation part) of every product term, smallest magnitude first
-  constexpr int NT = NS == 2 ? 3 : 6;
-  constexpr int ta[6] = {1, NS == 2 ? 0 : 2, 0, 1, 0, 0};
-  constexpr int tb[6] = {NS == 2 ? 0 : 1, NS == 2 ? 1 : 0, NS == 2 ? 0 : 2, 0, 1, 0};
+  constexpr int NP = ns_parts(NS);
+  constexpr int NT = NP == 2 ? 3 : 6;
+  constexpr int ta[6] = {1, NP == 2 ? 0 : 2, 0, 1, 0, 0};
+  constexpr int tb[6] = {NP == 2 ? 0 : 1, NP == 2 ? 1 : 0, NP == 2 ? 0 : 2, 0, 1, 0};
   constexpr int G = gemm_group(NBO, NS), NG = NBO / G;  // groups per k half
   static_assert(NBO % G == 0, "operand groups must tile the out-blocks");
   constexpr int NGRP = 2 * NG, MPG = NT * G, NM = NGRP * MPG;  // groups, MFMAs per group, MFMAs per step
@@ -215,14 +224,14 @@ SDFHIP_D void tp_gemm(f32x16 (&acc)[MAXA], Raw& carry, Fetch&& fetch, Make&& mak
     constexpr int S0 = NOPS == 0 ? NM / 4 : (NOPS + PER - 1) / PER;     // first gap that produces an element
     constexpr int W = NM - S0 > 0 ? NM - S0 : 1;
     const float* cur = ws.current();
-    bf16x8 a[2][NS][G];
+    bf16x8 a[2][NP][G];
     auto load_group = [&](auto gc) __attribute__((always_inline)) {
       constexpr int gi = decltype(gc)::value, kk = gi / NG, g0 = (gi % NG) * G;
 #ifdef SDFHIP_ABLATE_LDS_READS  // timing experiment only (wrong numerics): weight fragments read for the first two groups of a step
       if constexpr (gi >= 2) return;
 #endif
 #pragma unroll
-      for (int q = 0; q < NS; ++q)
+      for (int q = 0; q < NP; ++q)
 #pragma unroll
         for (int i = 0; i < G; ++i) a[gi & 1][q][i] = *reinterpret_cast<const bf16x8*>(cur + ((q * NBO + g0 + i) * 2 + kk) * 256);
     };
@@ -234,7 +243,7 @@ SDFHIP_D void tp_gemm(f32x16 (&acc)[MAXA], Raw& carry, Fetch&& fetch, Make&& mak
       __builtin_amdgcn_sched_barrier(0);  // the LDS reads of the next group stay ahead of this group's MFMAs
       static_for<0, MPG>([&](auto mc) __attribute__((always_inline)) {
         constexpr int mi = decltype(mc)::value, t = mi / G, i = mi % G, m = gi * MPG + mi;
-        acc[g0 + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[gi & 1][ta[t]][i], blk.p[tb[t]][kk], acc[g0 + i], 0, 0, 0);
+        acc[g0 + i] = mfma_term<NS>(a[gi & 1][ta[t]][i], blk.p[tb[t]][kk], acc[g0 + i]);
         constexpr int olo = m * PER < NOPS ? m * PER : NOPS, ohi = (m + 1) * PER < NOPS ? (m + 1) * PER : NOPS;
         if constexpr (olo < ohi) {
           static_for<olo, ohi>([&](auto jc) __attribute__((always_inline)) {

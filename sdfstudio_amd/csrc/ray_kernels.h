@@ -952,3 +952,145 @@ __global__ __launch_bounds__(256) void volsdf_step_kernel(const VolsdfStepArgs a
     if (beta > beta0) atomicMax(a.not_converged, 1);
   }
 }
+
+// ------------------------------------------------------------------------------------------------ interlevel loss (Zip-NeRF)
+// interlevel_loss_zip (model_components/losses.py:116-172), one proposal level per launch, one wavefront per ray, no sort:
+// the blurred step function's 2 (S + 1) knots {c_i - r} U {c_i + r} are two sorted sequences, so the rank of a knot in the
+// merged order is its own index plus a binary search in the other sequence (on the COMPUTED fp32 knot values, so ties fall
+// exactly as a sort of those values would put them); the reference's sort + 2 gathers + 3 cumsums + searchsorted +
+// 4 gathers (~40 launches, a radix sort among them) become LDS traffic of one wave.
+//   y1_i   = (wn_i - wn_{i-1}) / (2 r),  wn = w / diff(c), wn_{-1} = wn_S = 0           (:120-121)
+//   slope  = cumsum of (+y1 at a left knot, -y1 at a right knot) over the merged knots   (:122-126)
+//   y_r    = max(0, [0, cumsum(diff(x_r) * slope)])                                       (:127-128, :143)
+//   y_cum  = [0, cumsum(trapezoids of y_r)]                                               (:147-148)
+//   bins_k = y_cum interpolated at the proposal bin edge cp_k (searchsorted right)        (:156-166)
+//   w_gt   = diff(bins) ; loss terms clip(w_gt - wp, 0)^2 / (wp + 1e-5)                   (:168-171)
+// Outputs per sample the loss term and its derivative w.r.t. wp (only the proposal weights carry gradient: c, w and cp are
+// detached, :133-134 and the sampler's bins.detach()); the mean over N S_p and the chain rule are one torch op each.
+struct InterlevelArgs {
+  const float* c;    // [N,S+1]  field spacing bins
+  const float* w;    // [N,S]    field weights
+  const float* cp;   // [N,Sp+1] proposal spacing bins
+  const float* wp;   // [N,Sp]   proposal weights
+  int32_t N, S, Sp;
+  float r;
+  float* term;       // [N,Sp]  clip(w_gt - wp, 0)^2 / (wp + 1e-5)
+  float* dterm;      // [N,Sp]  d term / d wp
+  float* w_gt;       // [N,Sp]  (diagnostics / tests) or null
+};
+
+// inclusive scan of n fp32 values in LDS (blocked over the 64 lanes: lane l owns [l m, (l + 1) m)), in place, ACCUMULATED IN
+// DOUBLE and rounded once per output - what torch.cumsum does on the CPU (at::acc_type<float, false> is double), i.e. what the
+// reference's CPU path computes; a plain fp32 scan is ~16x further from the exact sums (the slopes are differences of
+// normalised weights divided by 2 r = 0.006 that cancel to zero over the ray)
+SDFHIP_D void wave_lds_scan_add(float* v, const int n, const int lane) {
+  const int m = (n + 63) / 64;
+  const int b = lane * m, e = b + m < n ? b + m : n;
+  double s = 0.0;
+  for (int k = b; k < e; ++k) s += (double)v[k];
+  double incl = s;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double t = __shfl_up(incl, d);
+    if (lane >= d) incl += t;
+  }
+  double run = incl - s;  // exclusive prefix of this lane's chunk
+  for (int k = b; k < e; ++k) {
+    run += (double)v[k];
+    v[k] = (float)run;
+  }
+}
+
+__global__ __launch_bounds__(256) void interlevel_kernel(const InterlevelArgs a) {
+  extern __shared__ float ilds[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ray = blockIdx.x * 4 + wv;
+  if (ray >= a.N) return;  // whole waves leave together; only wave-level primitives and wave-private LDS below
+  const int S = a.S, Sp = a.Sp, nk = 2 * (S + 1);
+  float* base = ilds + (size_t)wv * (4 * (S + 1) + 2 * nk + (Sp + 1));
+  float* cl = base;               // [S+1] left knots  c_i - r
+  float* cr = cl + (S + 1);       // [S+1] right knots c_i + r
+  float* y1 = cr + (S + 1);       // [S+1]
+  float* cc = y1 + (S + 1);       // [S+1] c
+  float* xr = cc + (S + 1);       // [nk]  merged knots
+  float* yy = xr + nk;            // [nk]  slope increments -> slopes -> y_r -> y_cum
+  float* bb = yy + nk;            // [Sp+1] interpolated cumulative mass at the proposal bin edges
+  const float* c = a.c + (size_t)ray * (S + 1);
+  const float* w = a.w + (size_t)ray * S;
+  const float r = a.r;
+  for (int i = lane; i <= S; i += 64) {
+    const float ci = c[i];
+    cc[i] = ci;
+    cl[i] = ci - r;
+    cr[i] = ci + r;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int i = lane; i <= S; i += 64) {
+    const float wn = i < S ? w[i] / (cc[i + 1] - cc[i]) : 0.0f;
+    const float wm = i > 0 ? w[i - 1] / (cc[i] - cc[i - 1]) : 0.0f;
+    y1[i] = (wn - wm) / (2.0f * r);
+  }
+  __builtin_amdgcn_wave_barrier();
+  // merge: a left knot precedes an equal right knot (concatenation order [left | right] under a stable sort)
+  for (int i = lane; i <= S; i += 64) {
+    const float key = cl[i];
+    int lo = 0, hi = S + 1;  // number of right knots strictly below the key
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cr[mid] < key) lo = mid + 1;
+      else hi = mid;
+    }
+    xr[i + lo] = key;
+    yy[i + lo] = y1[i];
+    const float key2 = cr[i];
+    lo = 0, hi = S + 1;      // number of left knots at or below the key
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cl[mid] <= key2) lo = mid + 1;
+      else hi = mid;
+    }
+    xr[i + lo] = key2;
+    yy[i + lo] = -y1[i];
+  }
+  __builtin_amdgcn_wave_barrier();
+  wave_lds_scan_add(yy, nk - 1, lane);  // slopes on the nk - 1 intervals (the last knot's increment is not used, :124)
+  __builtin_amdgcn_wave_barrier();
+  // seg_k = (x_k - x_{k-1}) slope_{k-1} (seg_0 = 0) into the staging area of the knots, which is free now (cl .. cc = 2 nk floats)
+  float* tmp = cl;
+  for (int k = lane; k < nk; k += 64) tmp[k] = k >= 1 ? (xr[k] - xr[k - 1]) * yy[k - 1] : 0.0f;
+  __builtin_amdgcn_wave_barrier();
+  wave_lds_scan_add(tmp, nk, lane);     // y_r (before the clip)
+  __builtin_amdgcn_wave_barrier();
+  for (int k = lane; k < nk; k += 64)
+    yy[k] = k >= 1 ? (fmaxf(tmp[k], 0.0f) + fmaxf(tmp[k - 1], 0.0f)) * 0.5f * (xr[k] - xr[k - 1]) : 0.0f;
+  __builtin_amdgcn_wave_barrier();
+  wave_lds_scan_add(yy, nk, lane);      // y_cum
+  __builtin_amdgcn_wave_barrier();
+  const float* cp = a.cp + (size_t)ray * (Sp + 1);
+  for (int k = lane; k <= Sp; k += 64) {
+    const float x = cp[k];
+    int lo = 0, hi = nk;  // searchsorted(side="right"): number of knots <= x
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (xr[mid] <= x) lo = mid + 1;
+      else hi = mid;
+    }
+    const int below = min(max(lo - 1, 0), nk - 1), above = min(max(lo, 0), nk - 1);
+    const float x0 = xr[below], x1 = xr[above], b0 = yy[below], b1 = yy[above];
+    float t = (x - x0) / (x1 - x0);
+    t = (t != t) ? 0.0f : t;                       // nan_to_num(.., 0): 0 / 0 when below == above
+    t = fminf(fmaxf(t, 0.0f), 1.0f);               // +-inf clip to the ends
+    bb[k] = b0 + t * (b1 - b0);
+  }
+  __builtin_amdgcn_wave_barrier();
+  const float* wp = a.wp + (size_t)ray * Sp;
+  for (int k = lane; k < Sp; k += 64) {
+    const float wg = bb[k + 1] - bb[k];
+    const float p = wp[k], q = p + 1e-5f;
+    const float d = fmaxf(wg - p, 0.0f);
+    const size_t o = (size_t)ray * Sp + k;
+    a.term[o] = d * d / q;
+    a.dterm[o] = -2.0f * d / q - d * d / (q * q);
+    if (a.w_gt != nullptr) a.w_gt[o] = wg;
+  }
+}

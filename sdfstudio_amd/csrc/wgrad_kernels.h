@@ -7,7 +7,7 @@
 //                 Column sums of A (bias gradients) fall out of the same reads.
 //  wreduce_kernel sums the split partials and scatters them into the natural-layout gradient vector.
 #pragma once
-#include "common.h"
+#include "mlp_core.h"  // chunk layout constants of the packed weights
 
 // One descriptor per packed matrix. All offsets are in floats / ints relative to the base pointers.
 struct PackDesc {
@@ -23,8 +23,8 @@ struct PackDesc {
 };
 
 // grid = (ceil(kb*nbo*1024 / 256), n_desc).  One thread per weight: writes its three bf16 parts (w = w0 + w1 + w2, each part the
-// bf16 rounding of what the previous parts left) into the chunk layout of mlp_core.h:
-//   Wp[kb][part][ob][kk][lane][j]  <-  W[out = 32 ob + (lane & 31)][k = 32 kb + tp_row(8 kk + j, lane >> 5)]
+// bf16 rounding of what the previous parts left) and its two fp16 parts into the chunk layout of mlp_core.h:
+//   Wp[kb][part 0..4][ob][kk][lane][j]  <-  W[out = 32 ob + (lane & 31)][k = 32 kb + tp_row(8 kk + j, lane >> 5)]
 static __global__ void pack_kernel(const float* __restrict__ theta, const PackDesc* __restrict__ descs,
                             const int32_t* __restrict__ maps, float* __restrict__ packed) {
   const PackDesc d = descs[blockIdx.y];
@@ -44,12 +44,21 @@ static __global__ void pack_kernel(const float* __restrict__ theta, const PackDe
     const int nr = rowmap[k], nc = colmap[o];
     if (nr >= 0 && nc >= 0) v = theta[d.src_off + (int64_t)nr * d.ld + nc] * d.scale;
   }
-  __bf16* chunk = reinterpret_cast<__bf16*>(packed + d.dst_off) + (size_t)kb * d.nbo * 3072;
+  __bf16* chunk = reinterpret_cast<__bf16*>(packed + d.dst_off) + (size_t)kb * d.nbo * (2 * kChunkBlockFloats);
+  const size_t at = ((size_t)(ob * 2 + kk) * 64 + lane) * 8 + j, part = (size_t)d.nbo * 1024;  // 16-bit elements per part
+  float r = v;
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const __bf16 h = (__bf16)v;
-    chunk[(((q * d.nbo + ob) * 2 + kk) * 64 + lane) * 8 + j] = h;
-    v -= (float)h;
+  for (int q = 0; q < 3; ++q) {  // parts 0..2: bf16 (modes 2 and 3 of mlp_core.h)
+    const __bf16 h = (__bf16)r;
+    chunk[q * part + at] = h;
+    r -= (float)h;
+  }
+  {  // parts 3, 4: fp16 hi + lo (mode 4), saturating like the activation split
+    const float c = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+    const _Float16 h = (_Float16)c;
+    _Float16* c16 = reinterpret_cast<_Float16*>(chunk);
+    c16[3 * part + at] = h;
+    c16[4 * part + at] = (_Float16)(c - (float)h);
   }
 }
 
@@ -437,6 +446,198 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
   }
 }
 
+// ---- 8-wave version (default).  The 4-wave kernel above is bound by the VALU work of the staging pass (bf16 split of 256 values
+// per wave and tile, softplus where the operand is a saved pre-activation: ~1500 VALU instructions against 96 MFMAs, with the
+// matrix pipe idle meanwhile and two barriers per tile).  Here the macro tile is shared by 8 waves (two per SIMD: their VALU
+// streams issue side by side), each wave stages two blocks instead of four and owns a 2 x 4 block patch (128 accumulator
+// registers), and LDS is double buffered so that tile t + 1 is split and written while tile t is multiplied: one barrier
+// per tile.  LDS: 2 x 80 KiB = all of it.
+constexpr int kW8LdsBytes = 2 * kWbLdsBytes;
+constexpr int kWbBuf = 16 * kWbSlot;  // bf16 elements per stage buffer
+
+template <int NA, int NB>
+__global__ __launch_bounds__(512, 2) void wgrad_bf16x8_kernel(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 ldsb[];  // [2 buffers][16 slots][hi|lo][32][40]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qi = wave >> 1, qj = wave & 1;  // row blocks qi + 4 i (i < NA), column blocks qj + 2 j (j < NB)
+  const int split = blockIdx.x;
+  const int ob_base = a.ob_base, ib_base = a.ib_base;
+
+  f32x16 acc[NA][NB];
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  float colsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // column sums of pair 0's A block this wave stages (slot `wave`): 4 TP rows per lane
+
+  const int64_t t0 = (int64_t)split * a.tiles_per_split;
+  int64_t t1 = t0 + a.tiles_per_split;
+  if (t1 > a.n_tiles) t1 = a.n_tiles;
+  const int n_t = t1 > t0 ? (int)(t1 - t0) : 0;
+  const int n_stage = n_t * a.n_pairs;
+
+  for (int i = tid; i < kW8LdsBytes / 16; i += 512) reinterpret_cast<f32x4*>(ldsb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // staging role: slot `wave` (A block ob_base + wave) and slot 8 + wave (B block ib_base + wave)
+  const int slot[2] = {wave, 8 + wave};
+  const bool valid[2] = {ob_base + wave < a.nba, ib_base + wave < a.nbb};
+  const float* src0[2];
+  const float* src1[2];
+  int stride0[2], stride1[2];
+  bool xf0[2], xf1[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int blk = q == 0 ? ob_base + wave : ib_base + wave;
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const TpOperand& op = q == 0 ? a.A[pr] : a.B[pr];
+      const int seg = blk >= op.nb[0];
+      const int lb = blk - (seg ? op.nb[0] : 0);
+      const float* base = op.ptr[seg] + (size_t)lb * 1024;
+      const int stride = op.nb[seg] * 1024;
+      const bool xf = op.xf[seg] == 1;
+      if (pr == 0) {
+        src0[q] = base;
+        stride0[q] = stride;
+        xf0[q] = xf;
+      } else {
+        src1[q] = base;
+        stride1[q] = stride;
+        xf1[q] = xf;
+      }
+    }
+  }
+
+  // operand tile in flight from HBM, one stage ahead of its split (a second stage in flight measured no faster and its 32
+  // registers push the 2 x 4 patch kernel into spills)
+  f32x4 pre[2][4];
+  auto load_stage = [&](const int st) __attribute__((always_inline)) {
+    const bool p1 = st >= n_t;
+    const int64_t tile = t0 + (p1 ? st - n_t : st);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (!valid[q]) continue;
+      const float* base = p1 ? src1[q] : src0[q];
+      const int stride = p1 ? stride1[q] : stride0[q];
+      const f32x4* src = reinterpret_cast<const f32x4*>(base + (size_t)tile * stride) + lane;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pre[q][i] = src[i * 64];
+    }
+  };
+  // one staging unit = one f32x4 (4 consecutive points of one TP row) of slot q: softplus where the operand is a saved
+  // pre-activation, bias column sums, bf16 hi / lo split, two 8-byte LDS writes
+  auto store_unit = [&](const int st, auto qc, auto ic) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::value, i = decltype(ic)::value;
+    if (!valid[q]) return;
+    const bool p1 = st >= n_t;
+    const bool xf = p1 ? xf1[q] : xf0[q];
+    // lane holds, for i = 0..3, TP row r = 4 i + (lane >> 4), half (lane >> 3) & 1, points 4 (lane & 7) .. + 3
+    __bf16* dst = ldsb + (st & 1) * kWbBuf + slot[q] * kWbSlot + (lane & 7) * 4;
+    f32x4 v = pre[q][i];
+    if (xf) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = softplus100_h(v[e]);
+    }
+    if (q == 0 && !p1) colsum[i] += (v[0] + v[1]) + (v[2] + v[3]);
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hi[e] = (__bf16)v[e];
+      lo[e] = (__bf16)(v[e] - (float)hi[e]);
+    }
+    const int f = tp_row(i * 4 + (lane >> 4), (lane >> 3) & 1);
+    *reinterpret_cast<bf16x4*>(dst + f * kWbRow) = hi;
+    *reinterpret_cast<bf16x4*>(dst + kWbTile + f * kWbRow) = lo;
+  };
+  auto store_stage = [&](const int st) __attribute__((always_inline)) {
+    static_for<0, 8>([&](auto uc) __attribute__((always_inline)) {
+      constexpr int u = decltype(uc)::value;
+      store_unit(st, std::integral_constant<int, (u >> 2)>{}, std::integral_constant<int, (u & 3)>{});
+    });
+  };
+
+  if (n_stage > 0) load_stage(0);
+  __syncthreads();  // the zero fill has landed (slots without a block stay zero)
+  if (n_stage > 0) {
+    store_stage(0);
+    if (n_stage > 1) load_stage(1);
+  }
+  // lane (row = lane & 31, k half = lane >> 5) reads 8 consecutive points of "its" feature row
+  const int frag = (lane & 31) * kWbRow + 8 * (lane >> 5);
+  // One stage: 6 NA NB MFMAs on buffer st & 1 with the eight staging units of stage st + 1 (VALU + ds_write into the other
+  // buffer) placed between them at equal distances and pinned there.  The two waves of a SIMD share its matrix pipe: whichever
+  // loses the arbitration for a run of MFMAs falls behind by that run and from then on does its VALU unit while the partner
+  // multiplies - the pattern settles into complementary phases instead of both waves sitting in their VALU part together.
+  constexpr int M = 6 * NA * NB;
+  for (int st = 0; st < n_stage; ++st) {
+    __syncthreads();  // stage st is complete in buffer st & 1; everybody is done reading the other buffer (stage st - 1)
+    const bool more = st + 1 < n_stage;
+    const __bf16* la = ldsb + (st & 1) * kWbBuf + qi * kWbSlot + frag;
+    const __bf16* lb = ldsb + (st & 1) * kWbBuf + (8 + qj) * kWbSlot + frag;
+    static_for<0, 2>([&](auto kc) __attribute__((always_inline)) {
+      constexpr int kk = decltype(kc)::value;
+      bf16x8 ah[NA], al[NA], bh[NB], bl[NB];
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        ah[i] = *reinterpret_cast<const bf16x8*>(la + 4 * i * kWbSlot + kk * 16);
+        al[i] = *reinterpret_cast<const bf16x8*>(la + 4 * i * kWbSlot + kWbTile + kk * 16);
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        bh[j] = *reinterpret_cast<const bf16x8*>(lb + 2 * j * kWbSlot + kk * 16);
+        bl[j] = *reinterpret_cast<const bf16x8*>(lb + 2 * j * kWbSlot + kWbTile + kk * 16);
+      }
+      static_for<0, 3 * NA * NB>([&](auto mc) __attribute__((always_inline)) {
+        constexpr int mi = decltype(mc)::value, t = mi / (NA * NB), i = (mi / NB) % NA, j = mi % NB;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t == 2 ? al[i] : ah[i], t == 1 ? bl[j] : bh[j], acc[i][j], 0, 0, 0);
+        constexpr int m = kk * 3 * NA * NB + mi;                      // MFMA index within the stage
+        constexpr int ulo = (m * 8) / M, uhi = ((m + 1) * 8) / M;      // staging units due after this MFMA
+        if constexpr (ulo < uhi) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (more) {
+            static_for<ulo, uhi>([&](auto uc) __attribute__((always_inline)) {
+              constexpr int u = decltype(uc)::value;
+              store_unit(st + 1, std::integral_constant<int, (u >> 2)>{}, std::integral_constant<int, (u & 3)>{});
+            });
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+    });
+    if (st + 2 < n_stage) load_stage(st + 2);
+  }
+
+  const int ldc = a.nbb * 32;
+  float* C = a.partial + (size_t)split * a.nba * 32 * ldc;
+  const int hf = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int ob = ob_base + qi + 4 * i, ib = ib_base + qj + 2 * j;
+      if (qi + 4 * i < 8 && qj + 2 * j < 8 && ob < a.nba && ib < a.nbb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) C[(size_t)(ob * 32 + tp_row(r, hf)) * ldc + ib * 32 + (lane & 31)] = acc[i][j][r];
+      }
+    }
+  if (a.bpartial != nullptr && ib_base == 0) {
+    // each staged A row was summed over this lane's 4 points: finish over the 8 lanes that share the row
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float t = colsum[i];
+      t += __shfl_xor(t, 1);
+      t += __shfl_xor(t, 2);
+      t += __shfl_xor(t, 4);
+      const int ob = ob_base + wave;
+      if (valid[0] && (lane & 7) == 0 && ob < a.nba)
+        a.bpartial[(size_t)split * a.nba * 32 + ob * 32 + tp_row(i * 4 + (lane >> 4), (lane >> 3) & 1)] = t;
+    }
+  }
+}
+
 typedef void (*WgradKernelFn)(const WgradArgs);
 template <int NA>
 static WgradKernelFn wgrad_pick_nb(const int nb, const bool fp32) {
@@ -445,6 +646,23 @@ static WgradKernelFn wgrad_pick_nb(const int nb, const bool fp32) {
     case 2: return fp32 ? wgrad_kernel<NA, 2> : wgrad_bf16_kernel<NA, 2>;
     case 3: return fp32 ? wgrad_kernel<NA, 3> : wgrad_bf16_kernel<NA, 3>;
     default: return fp32 ? wgrad_kernel<NA, 4> : wgrad_bf16_kernel<NA, 4>;
+  }
+}
+// 8-wave kernel: na = ceil(row blocks / 4) in {1, 2}, nb = ceil(column blocks / 2) in {1..4}
+static WgradKernelFn wgrad8_pick(const int na, const int nb) {
+  if (na <= 1) {
+    switch (nb) {
+      case 1: return wgrad_bf16x8_kernel<1, 1>;
+      case 2: return wgrad_bf16x8_kernel<1, 2>;
+      case 3: return wgrad_bf16x8_kernel<1, 3>;
+      default: return wgrad_bf16x8_kernel<1, 4>;
+    }
+  }
+  switch (nb) {
+    case 1: return wgrad_bf16x8_kernel<2, 1>;
+    case 2: return wgrad_bf16x8_kernel<2, 2>;
+    case 3: return wgrad_bf16x8_kernel<2, 3>;
+    default: return wgrad_bf16x8_kernel<2, 4>;
   }
 }
 static WgradKernelFn wgrad_pick(const int na, const int nb, const bool fp32) {
@@ -519,56 +737,3 @@ static __global__ __launch_bounds__(256) void wreduce_kernel(const WreduceArgs a
   }
 }
 
-// Gradient of the sdf output row (lane-local dot product in geo_fwd_kernel):
-//   w_sdf_bar[k] = sum_p ( sdfbar_p * softplus(z_last[p][k]) + qb_last[p][k] ),   b_sdf_bar = sum_p sdfbar_p
-// (qb_last == nullptr: first-order backward, no tangent term)
-// grid = n_split, block = 256 (the 4 waves interleave over the split's tiles, then sum through LDS).
-// partial: [n_split][NBH*32 + 32]  (last 32-slot holds b_sdf_bar in [0])
-template <int NBH>
-__global__ __launch_bounds__(256) void sdfrow_grad_kernel(const float* __restrict__ z_last, const float* __restrict__ qb_last,
-                                                            const float* __restrict__ sdfbar, const int64_t n_tiles,
-                                                            const int tiles_per_split, float* __restrict__ partial) {
-  __shared__ float red[4][NBH * 32 + 32];
-  const int lane = threadIdx.x & 63, hf = lane >> 5, wave = threadIdx.x >> 6;
-  const int64_t t0 = (int64_t)blockIdx.x * tiles_per_split;
-  int64_t t1 = t0 + tiles_per_split;
-  if (t1 > n_tiles) t1 = n_tiles;
-  f32x16 acc[NBH];
-#pragma unroll
-  for (int b = 0; b < NBH; ++b)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
-  float bsum = 0.0f;
-  for (int64_t tile = t0 + wave; tile < t1; tile += 4) {
-    const float sb = sdfbar[tile * 32 + (lane & 31)];
-    bsum += sb;
-#pragma unroll
-    for (int b = 0; b < NBH; ++b) {
-      const float* zp = z_last + ((size_t)tile * NBH + b) * 1024 + lane;
-      const float* qp = qb_last + ((size_t)tile * NBH + b) * 1024 + lane;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        acc[b][r] += fmaf(sb, softplus100_h(zp[r * 64]), qb_last != nullptr ? qp[r * 64] : 0.0f);
-      }
-    }
-  }
-  // reduce over the 32 points of a half-wave
-#pragma unroll
-  for (int m = 1; m < 32; m <<= 1) {
-    bsum += __shfl_xor(bsum, m);
-#pragma unroll
-    for (int b = 0; b < NBH; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[b][r] += __shfl_xor(acc[b][r], m);
-  }
-  if ((lane & 31) == 0) {
-#pragma unroll
-    for (int b = 0; b < NBH; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) red[wave][b * 32 + tp_row(r, hf)] = acc[b][r];
-    if (hf == 0) red[wave][NBH * 32] = bsum;
-  }
-  __syncthreads();
-  float* dst = partial + (size_t)blockIdx.x * (NBH * 32 + 32);
-  for (int i = threadIdx.x; i <= NBH * 32; i += 256) dst[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
-}

@@ -1,11 +1,17 @@
-"""Losses that close the NeuS-facto training step (kept as PyTorch device ops this round).
+"""Losses that close the NeuS-facto training step.
 
 interlevel_loss_zip restates nerfstudio/model_components/losses.py:116-172 (Zip-NeRF proposal loss) on flat
 ``[N,S+1]`` spacing-domain bins.  Only the proposal weights carry gradient (the field's weights are detached, :134).
+On a HIP device each proposal level is ONE kernel launch (sdfhip_interlevel_terms: one wavefront per ray, the blurred
+histogram built by merging the two sorted knot sequences instead of sorting them) plus a mean; the torch formulation below
+(``interlevel_loss_zip_torch``: sort, gathers, cumsums, searchsorted - ~40 launches) remains as the host-side statement
+the CPU tests compare with the oracle.  The mono-prior losses are small torch reductions over rendered per-ray outputs.
 """
 from typing import List
 
 import torch
+
+from sdfstudio_amd import _lib
 
 
 def _blurred_step(bins: torch.Tensor, heights: torch.Tensor, radius: float):
@@ -19,8 +25,43 @@ def _blurred_step(bins: torch.Tensor, heights: torch.Tensor, radius: float):
     return knots_sorted, torch.cat([zero, values], dim=-1)
 
 
+class _InterlevelLevel(torch.autograd.Function):
+    """mean over rays and samples of clip(w_gt - wp, 0)^2 / (wp + 1e-5) for one proposal level (losses.py:156-171)."""
+
+    @staticmethod
+    def forward(ctx, wp, c, w, cp, radius):
+        lib = _lib.load()
+        n, s_p = wp.shape
+        s = w.shape[1]
+        kp = _lib.Keep()
+        term = torch.empty(n, s_p, device=wp.device)
+        dterm = torch.empty(n, s_p, device=wp.device)
+        _lib.check(lib.sdfhip_interlevel_terms(kp(c), kp(w), kp(cp), kp(wp.detach()), n, s, s_p, float(radius), _lib.ptr(term),
+                                               _lib.ptr(dterm), None, _lib.stream()), "interlevel_terms")
+        del kp
+        ctx.save_for_backward(dterm)
+        return term.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dterm,) = ctx.saved_tensors
+        return dterm * (g / dterm.numel()), None, None, None, None
+
+
 def interlevel_loss_zip(weights_list: List[torch.Tensor], bins_list: List[torch.Tensor]) -> torch.Tensor:
     """weights_list[i]: [N,S_i] (last = field weights), bins_list[i]: [N,S_i+1] spacing bins (last = field bins)."""
+    if not weights_list[-1].is_cuda:
+        return interlevel_loss_zip_torch(weights_list, bins_list)
+    c = bins_list[-1].detach()
+    w = weights_list[-1].detach()
+    total = 0.0
+    for cp, wp, radius in zip(bins_list[:-1], weights_list[:-1], (0.03, 0.003)):
+        total = total + _InterlevelLevel.apply(wp, c, w, cp.detach(), radius)
+    return total
+
+
+def interlevel_loss_zip_torch(weights_list: List[torch.Tensor], bins_list: List[torch.Tensor]) -> torch.Tensor:
+    """The same loss as plain torch ops (any device): the formulation of the reference, statement by statement."""
     c = bins_list[-1].detach()
     w = weights_list[-1].detach()
     w_norm = w / (c[:, 1:] - c[:, :-1])

@@ -68,6 +68,17 @@ class NeuSFactoModelConfig:
     use_single_jitter: bool = True
     scene_contraction_norm: str = "inf"
     anneal_end: int = 50000
+    # neus-facto-angelo schedules (models/neus_facto.py:75-97; preset method_configs.py:381-450)
+    use_anneal_beta: bool = False
+    beta_anneal_max_num_iters: int = 1000_000
+    beta_anneal_init: float = 0.05
+    beta_anneal_end: float = 0.0002
+    enable_progressive_hash_encoding: bool = False
+    enable_numerical_gradients_schedule: bool = False
+    enable_curvature_loss_schedule: bool = False
+    curvature_loss_warmup_steps: int = 20_000
+    level_init: int = 4
+    steps_per_level: int = 10_000
 
     def setup(self, **kwargs):
         return self._target(self, **kwargs)
@@ -138,13 +149,48 @@ class NeuSFactoModel(nn.Module):
 
     # ---- training callbacks (neus.py:82-92, neus_facto.py:163-176), exposed as plain methods
     def before_train_iteration(self, step: int):
-        if self.config.anneal_end > 0:
-            self.field.set_cos_anneal_ratio(min(1.0, step / self.config.anneal_end))
-        if self.config.use_proposal_weight_anneal:
-            n = self.config.proposal_weights_anneal_max_num_iters
+        """Every BEFORE_TRAIN_ITERATION callback of the reference, in its order: cos anneal (neus.py:82-92), proposal weight
+        anneal (neus_facto.py:163-176), beta anneal (:187-205), numerical-gradient delta (:222-238), progressive hash levels
+        (:240-256), curvature loss factor (:257-282)."""
+        c = self.config
+        if c.anneal_end > 0:
+            self.field.set_cos_anneal_ratio(min(1.0, step / c.anneal_end))
+        if c.use_proposal_weight_anneal:
+            n = c.proposal_weights_anneal_max_num_iters
             frac = float(np.clip(step / n, 0, 1))
-            b = self.config.proposal_weights_anneal_slope
+            b = c.proposal_weights_anneal_slope
             self.proposal_sampler.set_anneal((b * frac) / ((b - 1) * frac + 1))
+        if c.use_anneal_beta:  # bakedsdf's beta schedule adapted to neus
+            frac = float(np.clip(step / c.beta_anneal_max_num_iters, 0, 1))
+            beta = c.beta_anneal_init / (1 + (c.beta_anneal_init - c.beta_anneal_end) / c.beta_anneal_end * (frac ** 0.8))
+            self.field.deviation_network.variance.data[...] = float(np.log(1.0 / beta) / 10.0)
+        f = self.field
+        if c.enable_numerical_gradients_schedule:
+            delta = 1.0 / (f.base_res * f.growth_factor ** (step / c.steps_per_level))
+            delta = max(1.0 / (4.0 * f.max_res), delta)
+            f.set_numerical_gradients_delta(delta * 4.0)  # points are divided by 4 to normalise them to [0, 1] (:231-233)
+        if c.enable_progressive_hash_encoding:
+            f.update_mask(max(int(step / c.steps_per_level) + 1, c.level_init))
+        self.curvature_loss_multi_factor = 1.0
+        if c.enable_curvature_loss_schedule:  # linear warm-up, then decay with the numerical-gradient delta
+            if step < c.curvature_loss_warmup_steps:
+                self.curvature_loss_multi_factor = step / c.curvature_loss_warmup_steps
+            else:
+                delta = 1.0 / (f.base_res * f.growth_factor ** ((step - c.curvature_loss_warmup_steps) / c.steps_per_level))
+                delta = max(1.0 / (f.max_res * 10.0), delta)
+                self.curvature_loss_multi_factor = delta / (1.0 / f.base_res)
+
+    def active_table_floats(self) -> int:
+        """Leading floats of the hash table that can carry gradient under the current progressive level mask (update_mask zeroes
+        the features of the levels above; their table rows get exactly zero gradient): what a data-parallel exchange has to move
+        (sdfstudio_amd/distributed.py FlatGradients.set_active_numel)."""
+        f = self.field
+        mask = f.hash_encoding_mask
+        n_active = int((mask.reshape(f.num_levels, -1).amax(dim=1) > 0).sum().item())
+        levels = f.encoding.levels
+        if n_active >= len(levels):
+            return f.encoding.params.numel()
+        return int(levels[n_active].offset) * f.features_per_level
 
     def after_train_iteration(self, step: int):
         self.proposal_sampler.step_cb(step)

@@ -437,3 +437,63 @@ def test_spaced_sampler_oracle_against_reference(kind):
         assert torch.allclose(rs.spacing_starts[..., 0], bins[:, :-1], rtol=0, atol=1e-7)
         assert torch.allclose(rs.frustums.starts[..., 0], eu[:, :-1], rtol=1e-6, atol=1e-6)
         assert torch.allclose(rs.frustums.ends[..., 0], eu[:, 1:], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/nerfstudio"), reason="the reference tree only exists in the build container")
+def test_neus_facto_training_schedules_against_reference():
+    """The config-5 (neus-facto-angelo) schedules of NeuSFactoModel.before_train_iteration against the reference's callback
+    closures (models/neus_facto.py:187-282), run on a stand-in object that carries what the closures read."""
+    import types
+
+    from oracle import ref_harness
+    from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
+    from sdfstudio_amd.models.neus_facto import NeuSFactoModel, NeuSFactoModelConfig, SceneBox
+
+    ref_harness.import_reference()
+    import nerfstudio.models.neus_facto as ref_nf
+
+    fcfg = SDFFieldConfig(num_layers=1, hidden_dim=256, geo_feat_dim=256, use_grid_feature=True, num_levels=16, max_res=4096, base_res=64,
+                          log2_hashmap_size=12, hash_features_per_level=8, hash_smoothstep=False, use_numerical_gradients=True,
+                          use_appearance_embedding=True)
+    knobs = dict(use_anneal_beta=True, beta_anneal_max_num_iters=1000, enable_progressive_hash_encoding=True,
+                 enable_numerical_gradients_schedule=True, enable_curvature_loss_schedule=True, curvature_loss_multi=5e-4,
+                 curvature_loss_warmup_steps=50, level_init=8, steps_per_level=20)
+    model = NeuSFactoModel(NeuSFactoModelConfig(sdf_field=fcfg, **knobs), SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]])), 4)
+
+    # the reference's closures only touch self.config, self.field, self.proposal_sampler, self.curvature_loss_multi_factor
+    rec = {}
+    rfield = types.SimpleNamespace(
+        num_levels=16, max_res=4096, base_res=64, growth_factor=model.field.growth_factor,
+        set_numerical_gradients_delta=lambda d: rec.__setitem__("delta", d), update_mask=lambda lv: rec.__setitem__("level", lv),
+        set_cos_anneal_ratio=lambda a: rec.__setitem__("cos", a),
+        deviation_network=types.SimpleNamespace(variance=types.SimpleNamespace(data=torch.zeros(1))))
+    rcfg = ref_nf.NeuSFactoModelConfig(**knobs)
+    stand_in = object.__new__(ref_nf.NeuSFactoModel)  # no __init__: the closures need four attributes, not a built model
+    for k, v in dict(config=rcfg, field=rfield, curvature_loss_multi_factor=1.0,
+                     proposal_sampler=types.SimpleNamespace(set_anneal=lambda a: rec.__setitem__("anneal", a),
+                                                            step_cb=lambda step: None)).items():
+        object.__setattr__(stand_in, k, v)
+    # super().get_training_callbacks() is NeuSModel's (cos anneal): call the NeuSFacto body with that part stubbed out
+    orig = ref_nf.NeuSModel.get_training_callbacks
+    ref_nf.NeuSModel.get_training_callbacks = lambda self, attrs: []
+    try:
+        cbs = ref_nf.NeuSFactoModel.get_training_callbacks(stand_in, None)
+    finally:
+        ref_nf.NeuSModel.get_training_callbacks = orig
+    for step in (0, 7, 49, 50, 120, 399, 5000):
+        for cb in cbs:
+            if cb.where_to_run[0].name == "BEFORE_TRAIN_ITERATION":
+                cb.func(step)
+        model.before_train_iteration(step)
+        assert abs(model.field.numerical_gradients_delta - rec["delta"]) <= 1e-12 * rec["delta"], step
+        lv = rec["level"]
+        want = torch.ones(16 * 8)
+        want[lv * 8:] = 0
+        assert torch.equal(model.field.hash_encoding_mask.cpu(), want), step
+        assert abs(model.curvature_loss_multi_factor - stand_in.curvature_loss_multi_factor) <= 1e-12, step
+        assert abs(float(model.field.deviation_network.variance.data) - float(rfield.deviation_network.variance.data)) <= 1e-6, step
+        assert abs(model.proposal_sampler._anneal - rec["anneal"]) <= 1e-12 if hasattr(model.proposal_sampler, "_anneal") else True
+        # exchange restriction: rows of masked levels are never touched
+        n_act = model.active_table_floats()
+        lvls = model.field.encoding.levels
+        assert n_act == (model.field.encoding.params.numel() if lv >= 16 else lvls[lv].offset * 8)
