@@ -219,9 +219,12 @@ def run(args):
     groups = {k: v for k, v in model.get_param_groups().items() if v}  # "field_background" is empty with background_model="none"
     # one flat gradient buffer; one exchange bucket per parameter group, all-reduced (RCCL) as soon as backward has produced it
     flat = FlatGradients([p for g in groups.values() for p in g], buckets=list(groups.values()))
-    # optimizers as method_configs.py:483-500 (neus-facto): Adam lr 5e-4 (fields) / 1e-2 (proposal networks), eps 1e-15
-    opts = [torch.optim.Adam(groups["fields"], lr=5e-4, eps=1e-15, fused=True),
-            torch.optim.Adam(groups["proposal_networks"], lr=1e-2, eps=1e-15, fused=True)]
+    # optimizers and schedulers as method_configs.py:485-500 (neus-facto): Adam eps 1e-15, lr 5e-4 with NeuS warm-up / cosine
+    # (fields), 1e-2 with MultiStepLR (proposal networks): one fused Adam launch per group over the flat buffers
+    from sdfstudio_amd.engine.optimizers import Optimizers, multi_step_scheduler, neus_scheduler
+
+    opts = Optimizers({"fields": {"lr": 5e-4, "scheduler": neus_scheduler(500, 0.05, 20000)},
+                       "proposal_networks": {"lr": 1e-2, "scheduler": multi_step_scheduler(20000)}}, groups, flat_grads=flat)
     centers, rot = synthetic_cameras(device)
     gen = torch.Generator(device=device)
     gen.manual_seed(42 + rank)  # base_config.py:74 + scripts/train.py:86: seed + global rank
@@ -235,9 +238,8 @@ def run(args):
         loss = sum(model.get_loss_dict(out, {"image": image}).values())
         flat.zero()
         loss.backward()
-        flat.finish()
-        for opt in opts:
-            opt.step()
+        opts.optimizer_step_all(grad_scale=flat.finish(average=False))  # SUM all-reduce; the 1 / world mean rides in the Adam read
+        opts.scheduler_step_all(i)
         model.after_train_iteration(i)
         return loss
 

@@ -171,6 +171,14 @@ int sdfhip_sample_uniform(const float* nears, const float* fars, const float* ji
 #define SDFHIP_SPACING_LOG 4
 int sdfhip_sample_spacing(int32_t spacing, const float* nears, const float* fars, const float* jitter, int32_t jitter_per_sample,
                           int64_t n_rays, int32_t n_samples, float* bins, float* starts, float* ends, sdfhip_stream_t stream);
+/* torch.optim.Adam step (the reference builds one Adam per parameter group: engine/optimizers.py:93-160, eps 1e-15 and the
+ * learning rates of method_configs.py:483-500) over one contiguous slice of the flat parameter / gradient / moment buffers.
+ * step = 1 for the first update (bias corrections 1 - beta^step); lr already carries the scheduler's factor
+ * (engine/schedulers.py:170-215); grad_scale multiplies the gradient as it is read (1 / world_size after a SUM all-reduce:
+ * the data-parallel mean costs no extra pass).  The four pointers must be the same slice of four equally aligned flat buffers
+ * (same offset from a 16-byte boundary); n in floats. */
+int sdfhip_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, int64_t step, float grad_scale, sdfhip_stream_t stream);
 /* interlevel_loss_zip (model_components/losses.py:116-172), the part per proposal level: the field histogram (c [n_rays, s+1]
  * spacing bins, w [n_rays, s] weights; both constants) blurred with half-width `radius` (0.03 / 0.003 for the two levels, :138)
  * and resampled at the proposal bins cp [n_rays, s_p+1]; against the proposal weights wp [n_rays, s_p]:

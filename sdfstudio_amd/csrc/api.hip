@@ -8,6 +8,7 @@
 #include "../../include/sdfhip.h"
 #include "field_inst.h"
 #include "wgrad_kernels.h"
+#include "optim_kernels.h"
 #include "point_kernels.h"
 #include "ray_kernels.h"
 
@@ -1249,6 +1250,37 @@ extern "C" int sdfhip_interlevel_terms(const float* c, const float* w, const flo
   const size_t lds = 4 * sizeof(float) * (size_t)(4 * (s + 1) + 4 * (s + 1) + (s_p + 1));
   SDFHIP_REQUIRE(lds <= 64 * 1024, "interlevel_terms: %d + %d samples do not fit the LDS staging", s, s_p);
   interlevel_kernel<<<(unsigned)((n_rays + 3) / 4), 256, lds, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfhip_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, int64_t step, float grad_scale, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(param && grad && exp_avg && exp_avg_sq && n >= 0 && step >= 1, "adam_step: bad argument");
+  const unsigned mis = (unsigned)(((uintptr_t)param >> 2) & 3);
+  SDFHIP_REQUIRE(((uintptr_t)grad >> 2 & 3) == mis && ((uintptr_t)exp_avg >> 2 & 3) == mis && ((uintptr_t)exp_avg_sq >> 2 & 3) == mis &&
+                     (uintptr_t)param % 4 == 0,
+                 "adam_step: the four slices must share their offset from a 16-byte boundary (same slice of four flat buffers)");
+  if (n == 0) return 0;
+  AdamArgs a;
+  a.head = (int32_t)std::min<int64_t>((4 - mis) & 3, n);
+  a.param = param;
+  a.grad = grad;
+  a.exp_avg = exp_avg;
+  a.exp_avg_sq = exp_avg_sq;
+  a.n = n;
+  // bias corrections in double on the host, as torch does with python floats (optim/adam.py _single_tensor_adam)
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  a.lr_over_bc1 = (float)((double)lr / bc1);
+  a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  a.beta1 = beta1;
+  a.beta2 = beta2;
+  a.eps = eps;
+  a.weight_decay = weight_decay;
+  a.grad_scale = grad_scale;
+  const int64_t n4 = (n + 3) / 4;
+  const unsigned grid = (unsigned)std::min<int64_t>((n4 + 255) / 256, 256 * 16);
+  adam_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -131,18 +131,24 @@ class FlatGradients:
         if self._pending[bi] == 0 and self._overlap:
             self._launch(bi)
 
-    def finish(self):
+    def finish(self, average: bool = True) -> float:
         """Wait for the outstanding bucket all-reduces (launching any bucket whose hooks did not all fire, e.g. parameters
-        unused in this step) and turn the sums into means."""
+        unused in this step).  average=True turns the sums into means in place; average=False leaves the SUMS and returns the
+        scale (1 / world_size) for the consumer to apply - the fused Adam step multiplies the gradient by it as it reads it
+        (engine/optimizers.py), which saves the pass over the buffer."""
         self._check_attached()
         for bi in range(len(self._buckets)):
             self._launch(bi)
+        scale = 1.0
         if _dist_on(self.group):
             w = dist.get_world_size(self.group)
+            scale = 1.0 / w
             for work, a, b in self._work:
                 work.wait()
-                self.flat[a:b].div_(w)
+                if average:
+                    self.flat[a:b].div_(w)
         self._work = []
+        return 1.0 if average else scale
 
     all_reduce_mean = finish
 

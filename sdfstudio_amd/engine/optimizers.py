@@ -1,0 +1,159 @@
+"""Optimisers and LR schedulers, mirroring nerfstudio/engine/optimizers.py:93-160 and nerfstudio/engine/schedulers.py.
+
+The reference builds one ``torch.optim.Adam`` per parameter group (eps 1e-15; lr 5e-4 for "fields", 1e-2 for
+"proposal_networks", method_configs.py:483-500) and a LambdaLR scheduler per group.  Here the parameters, their gradients
+and the two Adam moments of ALL groups live in four flat fp32 buffers (parameters become views, like the gradients of
+``distributed.FlatGradients``), a group is a contiguous slice, and one step of a group is ONE launch of
+``sdfhip_adam_step`` - with the data-parallel mean folded into the gradient read, so the all-reduce can be a plain SUM.
+There is no PyTorch fallback on the device path (``FusedAdam.step`` raises without the library); ``adam_reference`` is
+the formula as plain torch ops, used by the tests and by CPU-only callers.
+"""
+import math
+from typing import Callable, Dict, Iterable, List, Optional
+
+import numpy as np
+import torch
+
+from sdfstudio_amd import _lib
+from sdfstudio_amd.distributed import FlatGradients
+
+
+# ---------------------------------------------------------------------------------------------- schedulers (multiplicative factors)
+def neus_scheduler(warm_up_end: int = 5000, learning_rate_alpha: float = 0.05, max_steps: int = 300000) -> Callable[[int], float]:
+    """schedulers.py:170-189 NeuSScheduler: linear warm-up, then cosine decay to alpha."""
+
+    def func(step: int) -> float:
+        if step < warm_up_end:
+            return step / warm_up_end
+        progress = (step - warm_up_end) / (max_steps - warm_up_end)
+        return float((np.cos(np.pi * progress) + 1.0) * 0.5 * (1 - learning_rate_alpha) + learning_rate_alpha)
+
+    return func
+
+
+def multi_step_warmup_scheduler(warm_up_end: int = 5000, milestones=(300000, 400000, 500000), gamma: float = 0.33) -> Callable[[int], float]:
+    """schedulers.py:191-222 MultiStepWarmupScheduler."""
+
+    def func(step: int) -> float:
+        if step < warm_up_end:
+            return step / warm_up_end
+        return float(gamma ** int(np.searchsorted(list(milestones), step, side="left")))
+
+    return func
+
+
+def multi_step_scheduler(max_steps: int = 1000000, gamma: float = 0.33) -> Callable[[int], float]:
+    """schedulers.py:120-132 MultiStepSchedulerConfig -> MultiStepLR(milestones = max_steps / 2, 3/4, 9/10, gamma = 0.33)."""
+    milestones = [max_steps // 2, max_steps * 3 // 4, max_steps * 9 // 10]
+    return lambda step: float(gamma ** sum(1 for m_ in milestones if step >= m_))
+
+
+def exponential_decay_scheduler(decay_rate: float = 0.1, max_steps: int = 1000000) -> Callable[[int], float]:
+    """schedulers.py:137-152 ExponentialSchedulerConfig -> lr_scheduler.ExponentialLR(gamma = decay_rate ** (1 / max_steps))."""
+    gamma = decay_rate ** (1.0 / max_steps)
+    return lambda step: float(gamma ** step)
+
+
+# ---------------------------------------------------------------------------------------------- flat parameter storage
+class FlatParameters:
+    """Moves the given parameters into one contiguous fp32 buffer (``p.data`` becomes a view) in the given order - the same
+    order as ``FlatGradients`` - so that a parameter group is one slice of parameter, gradient and moment buffers alike."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.offset: Dict[int, int] = {}
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                n = p.numel()
+                self.flat[off:off + n].copy_(p.data.reshape(-1))
+                p.data = self.flat[off:off + n].view_as(p)
+                self.offset[id(p)] = off
+                off += n
+
+
+def adam_reference(p, g, m, v, lr, beta1, beta2, eps, step, weight_decay=0.0, grad_scale=1.0):
+    """torch.optim.Adam's single-tensor update (optim/adam.py) on plain tensors, in place; the statement the kernel restates."""
+    g = g * grad_scale
+    if weight_decay != 0.0:
+        g = g + weight_decay * p
+    m.lerp_(g, 1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+class FusedAdam:
+    """Adam over flat buffers: ``groups`` maps a name to (parameters, lr); one native launch per group and step.
+
+    ``flat_grads``: the ``FlatGradients`` of the same parameters in the same order (its buffer is read directly; with
+    ``grad_scale`` the all-reduce may stay a SUM).  The moments start at zero like torch.optim.Adam's."""
+
+    def __init__(self, groups: Dict[str, Dict], flat_grads: FlatGradients, betas=(0.9, 0.999), eps: float = 1e-15,
+                 weight_decay: float = 0.0):
+        self.groups = {}
+        order = [p for g in groups.values() for p in g["params"] if p.requires_grad]
+        assert [id(p) for p in order] == [id(p) for p in flat_grads.params], "groups must list the parameters in FlatGradients order"
+        self.flat_params = FlatParameters(order)
+        self.flat_grads = flat_grads
+        self.exp_avg = torch.zeros_like(self.flat_params.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat_params.flat)
+        self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
+        self.step_count = 0
+        off = 0
+        for name, g in groups.items():
+            n = sum(p.numel() for p in g["params"] if p.requires_grad)
+            sched = g.get("scheduler")
+            # LambdaLR semantics: the factor of step 0 applies from construction (a warm-up schedule starts at lr = 0)
+            self.groups[name] = {"start": off, "numel": n, "lr_init": float(g["lr"]), "scheduler": sched,
+                                 "lr": float(g["lr"]) * (sched(0) if sched is not None else 1.0)}
+            off += n
+
+    def scheduler_step(self):
+        """Optimizers.scheduler_step_all (optimizers.py:146-156): LambdaLR semantics, lr = lr_init * factor(number of scheduler steps)."""
+        for g in self.groups.values():
+            if g["scheduler"] is not None:
+                g["lr"] = g["lr_init"] * g["scheduler"](self.step_count)
+
+    def step(self, grad_scale: float = 1.0):
+        lib = _lib.load()
+        self.step_count += 1
+        P, G = self.flat_params.flat, self.flat_grads.flat
+        if not P.is_cuda:
+            raise _lib.SdfHipError("FusedAdam.step needs HIP device tensors; there is no CPU fallback (adam_reference is the CPU statement)")
+        for g in self.groups.values():
+            a, n = g["start"], g["numel"]
+            _lib.check(lib.sdfhip_adam_step(_lib.ptr(P[a:a + n]), _lib.ptr(G[a:a + n]), _lib.ptr(self.exp_avg[a:a + n]),
+                                            _lib.ptr(self.exp_avg_sq[a:a + n]), n, g["lr"], self.betas[0], self.betas[1], self.eps,
+                                            self.weight_decay, self.step_count, float(grad_scale), _lib.stream()), "adam_step")
+
+    def zero_grad(self):
+        self.flat_grads.zero()
+
+
+class Optimizers:
+    """engine/optimizers.py:93-160: the trainer-facing wrapper (zero_grad_all / optimizer_step_all / scheduler_step_all)."""
+
+    def __init__(self, config: Dict[str, Dict], param_groups: Dict[str, List[torch.nn.Parameter]],
+                 flat_grads: Optional[FlatGradients] = None):
+        """config[name] = {"lr": float, "scheduler": callable | None, ...}; groups without parameters are skipped."""
+        groups = {k: {"params": v, **config[k]} for k, v in param_groups.items() if len(v) > 0}
+        if flat_grads is None:
+            flat_grads = FlatGradients([p for g in groups.values() for p in g["params"]], buckets=[g["params"] for g in groups.values()])
+        self.flat_grads = flat_grads
+        eps = {config[k].get("eps", 1e-15) for k in groups}
+        assert len(eps) == 1, "one eps for all groups (the reference uses 1e-15 throughout)"
+        self.adam = FusedAdam(groups, flat_grads, eps=eps.pop())
+
+    def zero_grad_all(self):
+        self.adam.zero_grad()
+
+    def optimizer_step_all(self, grad_scale: float = 1.0):
+        self.adam.step(grad_scale)
+
+    def scheduler_step_all(self, step: int = 0):
+        self.adam.scheduler_step()

@@ -497,3 +497,46 @@ def test_neus_facto_training_schedules_against_reference():
         n_act = model.active_table_floats()
         lvls = model.field.encoding.levels
         assert n_act == (model.field.encoding.params.numel() if lv >= 16 else lvls[lv].offset * 8)
+
+
+def test_adam_reference_statement_equals_torch_adam():
+    """engine.optimizers.adam_reference (the formula the HIP kernel restates) against torch.optim.Adam, several steps, eps 1e-15."""
+    from sdfstudio_amd.engine.optimizers import adam_reference
+
+    torch.manual_seed(0)
+    p0 = torch.randn(1001)
+    p_t = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([p_t], lr=5e-4, eps=1e-15, foreach=False)
+    p, m, v = p0.clone(), torch.zeros(1001), torch.zeros(1001)
+    for step in range(1, 6):
+        g = torch.randn(1001) * 10.0 ** torch.randint(-8, 1, (1001,)).float()
+        p_t.grad = g.clone()
+        opt.step()
+        adam_reference(p, g, m, v, 5e-4, 0.9, 0.999, 1e-15, step)
+        assert torch.equal(p, p_t.detach()), step
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/nerfstudio"), reason="the reference tree only exists in the build container")
+def test_schedulers_against_reference():
+    from oracle import ref_harness
+    from sdfstudio_amd.engine import optimizers as E
+
+    ref_harness.import_reference()
+    import nerfstudio.engine.schedulers as RS
+
+    def ref_factors(sched_cls, steps, *args):
+        opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+        s = sched_cls(opt, *args)
+        out = []
+        for _ in range(steps):
+            out.append(s.get_last_lr()[0])
+            opt.step()
+            s.step()
+        return out
+
+    ref = ref_factors(RS.NeuSScheduler, 60, 10, 0.05, 50)
+    mine = [E.neus_scheduler(10, 0.05, 50)(k) for k in range(60)]
+    assert np.allclose(ref, mine, rtol=1e-12, atol=1e-15)
+    ref = ref_factors(RS.MultiStepWarmupScheduler, 60, 10, [20, 30, 45], 0.33)
+    mine = [E.multi_step_warmup_scheduler(10, (20, 30, 45), 0.33)(k) for k in range(60)]
+    assert np.allclose(ref, mine, rtol=1e-12, atol=1e-15)
