@@ -171,6 +171,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--small", action="store_true", help="small parity configuration (control-flow tests only, not a benchmark)")
+    ap.add_argument("--no-forward-only", action="store_true", help="skip the eval-mode leg (PMC passes: per-step launch counts stay clean)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: one process per GPU, spawned here as the reference does (scripts/train.py:190-203);
@@ -262,18 +263,20 @@ def run(args):
     _lib.profile_enable(False)
     assert math.isfinite(float(loss.detach())), "training diverged"
     # forward-only leg (eval-mode render, reported separately; outside the timed training region)
-    model.eval()
-    o, d, norm, cam = draw_rays(centers, rot, N_RAYS, gen)
-    rb_eval = RayBundle(origins=o, directions=d, directions_norm=norm, camera_indices=cam[:, None])
-    with torch.no_grad():
-        model(rb_eval)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(5):
+    fwd_ms = float("nan")
+    if not args.no_forward_only:
+        model.eval()
+        o, d, norm, cam = draw_rays(centers, rot, N_RAYS, gen)
+        rb_eval = RayBundle(origins=o, directions=d, directions_norm=norm, camera_indices=cam[:, None])
+        with torch.no_grad():
             model(rb_eval)
-        torch.cuda.synchronize()
-    fwd_ms = (time.perf_counter() - t1) / 5 * 1e3
-    model.train()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                model(rb_eval)
+            torch.cuda.synchronize()
+        fwd_ms = (time.perf_counter() - t1) / 5 * 1e3
+        model.train()
     t = torch.tensor([dt], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

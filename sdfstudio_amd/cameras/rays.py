@@ -60,11 +60,34 @@ class RaySamples:
     def shape(self):
         return self.frustums.shape
 
-    # -- compositing math (rays.py:131-230), served by the HIP kernels
+    # -- compositing math (rays.py:131-230).  get_weights is one HIP kernel (density_weights_fwd / _bwd); the fused models do
+    # alpha -> weights -> render in neus_render.  The remaining variants are the per-head statements of the reference as
+    # small torch ops on [N,S,1] tensors: the background-model paths (base_surface_model.py:266-329) compose them.
     def get_weights(self, densities: torch.Tensor) -> torch.Tensor:
         from sdfstudio_amd.model_components.renderers import density_to_weights
 
         return density_to_weights(densities[..., 0], self.flat_starts, self.flat_ends)[..., None]
+
+    def get_alphas(self, densities: torch.Tensor) -> torch.Tensor:
+        """rays.py:131-144."""
+        return 1 - torch.exp(-self.deltas * densities)
+
+    def get_weights_and_transmittance(self, densities: torch.Tensor):
+        """rays.py:169-192: (weights [N,S,1], transmittance [N,S,1] in front of each sample)."""
+        dd = self.deltas * densities
+        acc = torch.cumsum(dd[..., :-1, :], dim=-2)
+        acc = torch.cat([torch.zeros((*acc.shape[:1], 1, 1), device=densities.device), acc], dim=-2)
+        transmittance = torch.exp(-acc)
+        return (1 - torch.exp(-dd)) * transmittance, transmittance
+
+    def get_weights_and_transmittance_from_alphas(self, alphas: torch.Tensor):
+        """rays.py:210-230: transmittance is [N,S+1,1] (its last entry is what reaches the background)."""
+        transmittance = torch.cumprod(torch.cat([torch.ones((*alphas.shape[:1], 1, 1), device=alphas.device), 1.0 - alphas + 1e-7], 1), 1)
+        return alphas * transmittance[:, :-1, :], transmittance
+
+    def get_weights_from_alphas(self, alphas: torch.Tensor) -> torch.Tensor:
+        """rays.py:194-208."""
+        return self.get_weights_and_transmittance_from_alphas(alphas)[0]
 
 
 @dataclass

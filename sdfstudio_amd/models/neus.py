@@ -13,6 +13,7 @@ from sdfstudio_amd.fields.field_heads import FieldHeadNames
 from sdfstudio_amd.model_components.losses import monosdf_depth_loss, monosdf_normal_loss
 from sdfstudio_amd.model_components.ray_samplers import NeuSSampler
 from sdfstudio_amd.model_components.renderers import neus_render
+from sdfstudio_amd.models import background as B
 from sdfstudio_amd.models.neus_facto import NeuSFactoModel, NeuSFactoModelConfig, SceneContraction
 
 
@@ -35,13 +36,7 @@ class NeuSModel(NeuSFactoModel):
     def populate_modules(self):
         """base_surface_model.py:144-233 + neus.py:61-73."""
         c = self.config
-        if c.background_model != "none":
-            raise NotImplementedError("background models are outside this round's scope (SURVEY.md section 8, row f4)")
-        if self.scene_box.collider_type != "near_far":
-            raise NotImplementedError("only the near/far collider is on the path this round")
-        self.scene_contraction = SceneContraction(order=float("inf"))
-        self.field = c.sdf_field.setup(aabb=self.scene_box.aabb, spatial_distortion=self.scene_contraction,
-                                       num_images=self.num_train_data, use_average_appearance_embedding=False)
+        self._populate_surface_modules()  # contraction (scene_contraction_norm honoured), SDF field, background field, renderers
         self.sampler = NeuSSampler(num_samples=c.num_samples, num_samples_importance=c.num_samples_importance,
                                    num_samples_outside=c.num_samples_outside, num_upsample_steps=c.num_up_sample_steps,
                                    base_variance=c.base_variance)
@@ -52,7 +47,7 @@ class NeuSModel(NeuSFactoModel):
         self.anneal_end = 50000
 
     def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:
-        return {"fields": list(self.field.parameters()), "field_background": []}
+        return {"fields": list(self.field.parameters()), "field_background": self._background_params()}
 
     def before_train_iteration(self, step: int):
         if self.anneal_end > 0:
@@ -64,6 +59,13 @@ class NeuSModel(NeuSFactoModel):
     def sample_and_forward_field(self, ray_bundle: RayBundle) -> Dict:
         """neus.py:94-104."""
         ray_samples = self.sampler(ray_bundle, sdf_fn=self.field.get_sdf)
+        if B.has_background(self.config):
+            # neus.py:94-104 statement by statement: per-head outputs, and the transmittance behind the last sample for the
+            # background colour (the fused kernel returns weights only)
+            field_outputs = self.field(ray_samples, return_alphas=True)
+            weights, transmittance = ray_samples.get_weights_and_transmittance_from_alphas(field_outputs[FieldHeadNames.ALPHA])
+            return {"ray_samples": ray_samples, "field_outputs": field_outputs, "weights": weights,
+                    "bg_transmittance": transmittance[:, -1, :], "rendered": self._render_per_head(ray_samples, field_outputs, weights)}
         sdf, grad, rgb, x = self.field.forward_fused(ray_samples)
         bg = None if self.config.background_color == "black" else self.background
         out_rgb, depth, normal, acc, weights, alpha = neus_render(

@@ -21,6 +21,7 @@ from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
 from sdfstudio_amd.model_components.losses import interlevel_loss_zip, monosdf_depth_loss, monosdf_normal_loss
 from sdfstudio_amd.model_components.ray_samplers import ProposalNetworkSampler
 from sdfstudio_amd.model_components.renderers import neus_render
+from sdfstudio_amd.models import background as B
 
 
 class SceneContraction(nn.Module):
@@ -49,7 +50,9 @@ class NeuSFactoModelConfig:
     mono_normal_loss_mult: float = 0.0
     mono_depth_loss_mult: float = 0.0
     sdf_field: SDFFieldConfig = field(default_factory=SDFFieldConfig)
-    background_model: str = "none"
+    background_model: str = "none"   # the reference's default is "mlp" (base_surface_model.py:123); "grid" is not built
+    far_plane_bg: float = 1000.0
+    num_samples_outside: int = 32
     num_proposal_samples_per_ray: Tuple[int, ...] = (256, 96)
     num_neus_samples_per_ray: int = 48
     num_proposal_iterations: int = 2
@@ -108,15 +111,7 @@ class NeuSFactoModel(nn.Module):
     def populate_modules(self):
         """base_surface_model.py:144-233, neus_facto.py:110-147."""
         c = self.config
-        if c.background_model != "none":
-            raise NotImplementedError("background models are outside this round's scope (SURVEY.md section 8, row f4)")
-        if c.scene_contraction_norm not in ("inf", "l2"):
-            raise ValueError("Invalid scene contraction norm")  # base_surface_model.py:148-155
-        if self.scene_box.collider_type != "near_far":
-            raise NotImplementedError("only the near/far collider is on the path this round")
-        self.scene_contraction = SceneContraction(order=float("inf") if c.scene_contraction_norm == "inf" else None)
-        self.field = c.sdf_field.setup(aabb=self.scene_box.aabb, spatial_distortion=self.scene_contraction,
-                                       num_images=self.num_train_data, use_average_appearance_embedding=False)
+        self._populate_surface_modules()
         self.proposal_networks = nn.ModuleList()
         n_prop = c.num_proposal_iterations
         if c.use_same_proposal_network:
@@ -139,11 +134,28 @@ class NeuSFactoModel(nn.Module):
             raise NotImplementedError("background_color must be black or white on the fused path")
         self.register_buffer("background", bg, persistent=False)
 
+    def _populate_surface_modules(self):
+        """SurfaceModel.populate_modules (base_surface_model.py:144-216): contraction, SDF field, background field + sampler,
+        renderers - shared by the three model mirrors."""
+        c = self.config
+        if c.scene_contraction_norm not in ("inf", "l2"):
+            raise ValueError("Invalid scene contraction norm")  # base_surface_model.py:148-155
+        if self.scene_box.collider_type != "near_far":
+            raise NotImplementedError("only the near/far collider is on the path this round")
+        self.scene_contraction = SceneContraction(order=float("inf") if c.scene_contraction_norm == "inf" else None)
+        self.field = c.sdf_field.setup(aabb=self.scene_box.aabb, spatial_distortion=self.scene_contraction,
+                                       num_images=self.num_train_data, use_average_appearance_embedding=False)
+        B.build_background(self, c)
+
+    def _background_params(self) -> List[nn.Parameter]:
+        fb = self.field_background  # the reference's dummy Parameter (no gradient) carries nothing to optimise
+        return [] if isinstance(fb, nn.Parameter) else list(fb.parameters())
+
     def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:
         """base_surface_model.py:238-245, neus_facto.py:149-152."""
         return {
             "fields": list(self.field.parameters()),
-            "field_background": [],
+            "field_background": self._background_params(),
             "proposal_networks": list(self.proposal_networks.parameters()),
         }
 
@@ -202,9 +214,27 @@ class NeuSFactoModel(nn.Module):
         ray_bundle.fars = ones * self.scene_box.far
         return ray_bundle
 
+    def _render_per_head(self, ray_samples, field_outputs, weights):
+        """The four renderers of SurfaceModel.get_outputs (base_surface_model.py:298-310) on explicit weights (the background
+        paths change alpha / colour between the field and the compositing, so the fused field -> render kernel does not apply)."""
+        rgb = self.renderer_rgb(rgb=field_outputs[FieldHeadNames.RGB], weights=weights)
+        depth = self.renderer_depth(weights=weights, ray_samples=ray_samples)[..., 0]
+        normal = self.renderer_normal(semantics=field_outputs[FieldHeadNames.NORMAL], weights=weights)
+        acc = self.renderer_accumulation(weights=weights)[..., 0]
+        return rgb, depth, normal, acc
+
     def sample_and_forward_field(self, ray_bundle: RayBundle) -> Dict:
         """neus_facto.py:282-302 (+ get_weights_from_alphas and the renderers, fused)."""
         ray_samples, weights_list, ray_samples_list = self.proposal_sampler(ray_bundle, density_fns=self.density_fns)
+        if B.has_background(self.config):
+            # neus_facto.py:286-292: per-head field outputs, background merged into alpha / colour outside the unit sphere
+            field_outputs = self.field(ray_samples, return_alphas=True)
+            field_outputs = B.forward_background_field_and_merge(self, ray_samples, field_outputs)
+            weights = ray_samples.get_weights_from_alphas(field_outputs[FieldHeadNames.ALPHA])
+            weights_list.append(weights)
+            ray_samples_list.append(ray_samples)
+            return {"ray_samples": ray_samples, "field_outputs": field_outputs, "weights": weights, "weights_list": weights_list,
+                    "ray_samples_list": ray_samples_list, "rendered": self._render_per_head(ray_samples, field_outputs, weights)}
         sdf, grad, rgb, x = self.field.forward_fused(ray_samples)
         bg = None if self.config.background_color == "black" else self.background
         out_rgb, depth, normal, acc, weights, alpha = neus_render(
@@ -229,12 +259,15 @@ class NeuSFactoModel(nn.Module):
         rgb, depth, normal, acc = so["rendered"]
         if not self.training:
             rgb = rgb.clamp(0.0, 1.0)  # renderers.py:116-117
+        if B.has_background(self.config) and "bg_transmittance" in so:
+            rgb = rgb + B.render_background(self, ray_bundle, so["bg_transmittance"])  # base_surface_model.py:314-329
         depth = depth[:, None]
         if ray_bundle.directions_norm is not None:
             depth = depth / ray_bundle.directions_norm  # base_surface_model.py:303
         outputs = {
             "rgb": rgb, "accumulation": acc[:, None], "depth": depth, "normal": normal, "weights": so["weights"],
             "directions_norm": ray_bundle.directions_norm,
+            "ray_points": self.scene_contraction(so["ray_samples"].frustums.get_start_positions()),  # :337, visibility masks
         }
         if self.training:
             outputs.update({"eik_grad": so["field_outputs"][FieldHeadNames.GRADIENT],

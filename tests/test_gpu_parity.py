@@ -1213,3 +1213,87 @@ def test_l2_scene_contraction(device):
     dens = net.density_fn(pos.to(device))
     ref = O.proposal_density(pos, g["param"], "proposal_networks.0", pc, contraction="l2")
     assert_close("proposal density (L2)", dens[..., 0], ref, rtol=1e-4, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ background models
+def _load_reference_state_dict(model, params):
+    """Reference model.state_dict() -> our mirror: identical keys except the proposal networks' hash tables (the tinycudann shim
+    keeps them as mlp_base.encoding.params) and two reference-only entries (device_indicator_param, proposal aabb)."""
+    sd = model.state_dict()
+    for k, v in params.items():
+        if k == "device_indicator_param" or (k.startswith("proposal_networks.") and k.endswith(".aabb")):
+            continue
+        key = k.replace("mlp_base.encoding.params", "mlp_base.table") if k.startswith("proposal_networks.") else k
+        assert key in sd, f"{key} missing from the mirror's state_dict"
+        assert tuple(sd[key].shape) == tuple(v.shape), (key, tuple(sd[key].shape), tuple(v.shape))
+        sd[key] = v.clone()
+    missing = [k for k in sd if k not in {kk.replace("mlp_base.encoding.params", "mlp_base.table") for kk in params}]
+    assert not missing, f"mirror parameters the reference checkpoint does not provide: {missing}"
+    model.load_state_dict(sd)
+
+
+@pytest.mark.parametrize("name", ["neus", "volsdf", "neus_facto"])
+def test_background_mlp_models_against_reference_golden(device, name):
+    """background_model="mlp" (the reference's default): NeuS / VolSDF add transmittance x colour of the samples beyond the far
+    plane (base_surface_model.py:314-329), NeuS-facto merges the background field into alpha / colour outside the unit sphere
+    (:266-290).  Golden: the reference's own model classes run end to end (tests/golden/make_golden_bg.py), eval mode; compared:
+    rendered outputs, the rgb loss, and its gradient w.r.t. SDF field, background field and proposal networks."""
+    from sdfstudio_amd.cameras.rays import RayBundle
+    from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
+    from sdfstudio_amd.models.neus import NeuSModel, NeuSModelConfig
+    from sdfstudio_amd.models.neus_facto import NeuSFactoModel, NeuSFactoModelConfig, SceneBox
+    from sdfstudio_amd.models.volsdf import VolSDFModel, VolSDFModelConfig
+
+    g = load_golden_file(f"{name}_bg_mlp_eval.npz")
+    fcfg = SDFFieldConfig(num_layers=8, hidden_dim=64, geo_feat_dim=64, num_layers_color=4, hidden_dim_color=64, bias=0.5,
+                          inside_outside=False, use_grid_feature=True, beta_init=0.3, num_levels=8, max_res=128, base_res=4,
+                          log2_hashmap_size=11, hash_features_per_level=2, hash_smoothstep=True)
+    props = [{"hidden_dim": 16, "log2_hashmap_size": 9, "num_levels": 5, "max_res": 32, "base_res": 4},
+             {"hidden_dim": 16, "log2_hashmap_size": 9, "num_levels": 5, "max_res": 64, "base_res": 4}]
+    box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=0.5, far=4.5)
+    if name == "neus":
+        model = NeuSModel(NeuSModelConfig(sdf_field=fcfg, background_model="mlp", num_samples=16, num_samples_importance=16,
+                                          num_up_sample_steps=2, num_samples_outside=8), box, 49)
+    elif name == "volsdf":
+        model = VolSDFModel(VolSDFModelConfig(sdf_field=fcfg, background_model="mlp", num_samples=16, num_samples_eval=32,
+                                              num_samples_extra=8, num_samples_outside=8), box, 49)
+    else:
+        model = NeuSFactoModel(NeuSFactoModelConfig(sdf_field=fcfg, background_model="mlp", num_proposal_samples_per_ray=(32, 24),
+                                                    num_neus_samples_per_ray=16, proposal_net_args_list=props, num_samples_outside=8), box, 49)
+    _load_reference_state_dict(model, g["param"])
+    model = model.to(device).eval()
+    i = g["in"]
+    n = i["origins"].shape[0]
+    rb = RayBundle(origins=i["origins"].to(device), directions=i["directions"].to(device), directions_norm=torch.ones(n, 1, device=device),
+                   camera_indices=i["camera_indices"][:, None].to(device))
+    out = model(rb)
+    loss = torch.nn.functional.l1_loss(i["image"].to(device), out["rgb"])
+    model.zero_grad()
+    loss.backward()
+    o = g["out"]
+    # NeuS re-samples four times from sdf-derived pdfs: one fp32 ulp of a cdf moves a bin edge by ~5e-6 and the next level
+    # amplifies it (same 5e-3 bar as test_neus_model_against_reference_golden); the other two models follow the reference's
+    # samples to ~1e-6
+    tol = 5e-3 if name == "neus" else 5e-4
+    assert_close("weights", out["weights"], o["weights"], rtol=tol, atol=2e-6)
+    assert_close("rgb", out["rgb"], o["rgb"], rtol=tol, atol=1e-6)
+    assert_close("depth", out["depth"], o["depth"], rtol=tol, atol=1e-5)
+    assert_close("normal", out["normal"], o["normal"], rtol=tol, atol=1e-5)
+    assert_close("accumulation", out["accumulation"], o["accumulation"], rtol=tol, atol=1e-6)
+    assert_close("rgb_loss", loss, g["loss"]["rgb_loss"], rtol=1e-4, atol=1e-7)
+    got = {k.replace("mlp_base.table", "mlp_base.encoding.params") if k.startswith("proposal_networks.") else k: p.grad
+           for k, p in model.named_parameters() if p.grad is not None}
+    checked = 0
+    for k, ref in g["grad"].items():
+        assert k in got, f"no gradient for {k}"
+        # What this test pins is the background path: the background field's own gradients (they see the foreground only through
+        # the transmittance / the inside-sphere mask) at 2e-3 of the tensor's maximum.  The SDF field's gradients come from 48
+        # rays here: a single colour-network ReLU whose pre-activation the two fp32 evaluations place on opposite sides of zero
+        # (|z| ~ 1e-6, helpers.relu_flip_basis) moves single entries by up to ~1e-2 of the maximum; their tight comparison is the
+        # job of the train-mode goldens (test_*_model_against_reference_golden), here they get the loose bar.
+        # (the hash table's finest level is the extreme case: an entry sees a handful of samples, its gradient here is ~1e-4)
+        rt = 2e-3 if k.startswith("field_background") else (1e-1 if k == "field.encoding.params" else 2e-2)
+        assert_close(f"grad {k}", got[k], ref, rtol=rt, atol=1e-9)
+        checked += 1
+    assert checked >= 50
+    assert any(k.startswith("field_background.mlp_base") for k in g["grad"])

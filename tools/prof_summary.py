@@ -60,5 +60,16 @@ if rows:
                        "source": f"profiles/{tag}_pmc_summary.csv: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), FETCH_SIZE "
                                  "doubled per MI355X_MICROARCH.md (gfx950 reports half of a coalesced stream)"},
                       open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+# whole-step HBM bytes: every kernel's average launch traffic x its launches in the sampled steps (the PMC passes run
+# bench.py --steps 2 --warmup 1 --no-forward-only: 3 training steps and nothing else)
+if rows:
+    tot_r = sum(r["hbm_read_GB_corrected_x2"] * r["launches_sampled"] for r in rows if r["hbm_read_GB_corrected_x2"] == r["hbm_read_GB_corrected_x2"])
+    tot_w = sum(r["hbm_write_GB"] * r["launches_sampled"] for r in rows if r["hbm_write_GB"] == r["hbm_write_GB"])
+    gb = [r for r in rows if r["kernel"].startswith("geo_bwd_kernel")]
+    steps = gb[0]["launches_sampled"] if gb else 1  # geo_bwd runs once per training step
+    json.dump({"training_steps_sampled": steps, "hbm_read_GB_all_launches": round(tot_r, 2), "hbm_write_GB_all_launches": round(tot_w, 2),
+               "hbm_GB_per_training_step": round((tot_r + tot_w) / steps, 2),
+               "note": "sum over all sdfhip kernels of (average bytes per launch x launches sampled), divided by the training steps sampled"},
+              open(os.path.join(dst, f"{tag}_step_traffic.json"), "w"), indent=1)
 for r in rows[:12]:
     print(r)

@@ -7,10 +7,11 @@ R=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $R
 cd /tmp && export TMPDIR=/tmp
 B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline"
+BP="$B --no-forward-only"  # PMC passes: training steps only, so launches / steps = launches per step
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/kt -o kt -- $B --steps 10 --warmup 3 > $R/kt.log 2>&1
-timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/pmc_fetch -o p -- $B --steps 2 --warmup 1 > $R/pmc_fetch.log 2>&1
-timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/pmc_write -o p -- $B --steps 2 --warmup 1 > $R/pmc_write.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/pmc_fetch -o p -- $BP --steps 2 --warmup 1 > $R/pmc_fetch.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/pmc_write -o p -- $BP --steps 2 --warmup 1 > $R/pmc_write.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE \
-  --output-format csv -d $R/pmc_sq -o p -- $B --steps 2 --warmup 1 > $R/pmc_sq.log 2>&1
+  --output-format csv -d $R/pmc_sq -o p -- $BP --steps 2 --warmup 1 > $R/pmc_sq.log 2>&1
 rm -f $R/*/*kernel_trace.csv   # large; the stats and counter files carry what the summaries need
 cd $GRAFT_REPO_ROOT && python tools/prof_summary.py $TAG
