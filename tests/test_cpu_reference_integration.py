@@ -1,0 +1,143 @@
+"""Drop-in check on the REFERENCE side (build container only): the reference's own NeuSFactoModel / NeuSModel with our HIP-backed
+``SDFField`` registered through the reference's plugin mechanism (``SDFFieldConfig._target``, configs/base_config.py:58-66,
+fields/sdf_field.py:121-124), as INTEGRATION.md section 2 describes.
+
+No GPU here, so the native field call is replaced by a stub that returns tensors of the documented shapes (zeros / a unit
+gradient): what is verified is everything AROUND the kernels - construction through the reference's ``populate_modules``,
+``state_dict`` compatibility with a reference checkpoint (strict load both ways), that the reference's samplers, ``RaySamples``,
+``get_weights_from_alphas`` and renderers accept our field's outputs (dictionary keys as the reference reads them,
+shapes as sdf_field.py:614-689; our enum's members hash and compare equal to the reference's), and the callbacks the reference's models invoke on the field.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference/nerfstudio"),
+                                reason="the reference tree only exists in the build container")
+
+FIELD = dict(num_layers=8, hidden_dim=64, geo_feat_dim=64, num_layers_color=4, hidden_dim_color=64, bias=0.5, inside_outside=False,
+             use_grid_feature=True, beta_init=0.3, num_levels=8, max_res=128, base_res=4, log2_hashmap_size=11,
+             hash_features_per_level=2, hash_smoothstep=True)
+PROPS = [{"hidden_dim": 16, "log2_hashmap_size": 9, "num_levels": 5, "max_res": 32, "base_res": 4},
+         {"hidden_dim": 16, "log2_hashmap_size": 9, "num_levels": 5, "max_res": 64, "base_res": 4}]
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from oracle import ref_harness
+
+    ns = ref_harness.import_reference()
+    import nerfstudio.models.neus as rn
+    import nerfstudio.models.neus_facto as rnf
+    from nerfstudio.data.scene_box import SceneBox
+
+    ns.rn, ns.rnf = rn, rnf
+    ns.box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=0.5, far=4.5, radius=1.0, collider_type="near_far")
+    return ns
+
+
+def _stub_native_field(monkeypatch):
+    """Replace the two native entry points of our SDFField by shape-correct CPU stand-ins."""
+    from sdfstudio_amd.fields import sdf_field as F
+
+    def fake_fused(theta, table, emb, fld, o, d, st, mask):
+        n, s = st.shape
+        x = o[:, None, :] + d[:, None, :] * st[..., None]
+        sdf = (x.norm(dim=-1) - 0.5) + 0.0 * theta.sum() + 0.0 * table.sum()  # keeps the autograd edge to the parameters
+        grad = x / x.norm(dim=-1, keepdim=True)
+        rgb = torch.sigmoid(x) + 0.0 * theta.sum()
+        return sdf, grad, rgb, x.detach()
+
+    def fake_infer(self, mode, origins, dirs, starts, n, s, want_feat):
+        if dirs is None:
+            x = origins
+        else:
+            x = (origins[:, None, :] + dirs[:, None, :] * starts[..., None]).reshape(-1, 3)
+        sdf = x.norm(dim=-1) - 0.5
+        return sdf, (torch.zeros(x.shape[0], self.config.geo_feat_dim) if want_feat else None)
+
+    monkeypatch.setattr(F._FieldFunction, "apply", staticmethod(fake_fused))
+    monkeypatch.setattr(F.SDFField, "_run_inference", fake_infer)
+
+
+def test_field_head_keys_interoperate_with_the_reference_enum(ref):
+    from sdfstudio_amd.fields.field_heads import FieldHeadNames as Ours
+
+    Theirs = ref.FieldHeadNames
+    assert [m.name for m in Ours] == [m.name for m in Theirs] and [m.value for m in Ours] == [m.value for m in Theirs]
+    for a, b in zip(Ours, Theirs):
+        assert {a: 1}[b] == 1 and {b: 2}[a] == 2 and a == b and b == a and hash(a) == hash(b)
+    assert Ours.RGB != Theirs.SDF and Theirs.SDF != Ours.RGB and Ours.RGB not in {Theirs.SDF: 0}
+
+
+@pytest.mark.parametrize("which", ["neus_facto", "neus"])
+def test_reference_model_runs_with_the_hip_field_plugged_in(ref, which, monkeypatch):
+    from sdfstudio_amd.fields.sdf_field import SDFField, SDFFieldConfig
+
+    ours = SDFFieldConfig(**FIELD)                      # _target = sdfstudio_amd's SDFField
+    theirs = ref.sf.SDFFieldConfig(**FIELD)             # _target = the reference's SDFField
+    if which == "neus_facto":
+        mk = lambda f: ref.rnf.NeuSFactoModelConfig(sdf_field=f, background_model="none", num_proposal_samples_per_ray=(32, 24),
+                                                    num_neus_samples_per_ray=16, proposal_net_args_list=PROPS)
+    else:
+        mk = lambda f: ref.rn.NeuSModelConfig(sdf_field=f, background_model="none", num_samples=16, num_samples_importance=16,
+                                              num_up_sample_steps=2)
+    torch.manual_seed(0)
+    hybrid = mk(ours).setup(scene_box=ref.box, num_train_data=49, world_size=1, local_rank=0)
+    pure = mk(theirs).setup(scene_box=ref.box, num_train_data=49, world_size=1, local_rank=0)
+    assert isinstance(hybrid.field, SDFField) and hybrid.field.spatial_distortion is hybrid.scene_contraction
+
+    # ---- state_dict: same keys and shapes as a reference checkpoint; strict load in both directions
+    sd_h, sd_p = hybrid.state_dict(), pure.state_dict()
+    assert set(sd_h) == set(sd_p), (sorted(set(sd_h) ^ set(sd_p)))
+    assert all(tuple(sd_h[k].shape) == tuple(sd_p[k].shape) for k in sd_p)
+    hybrid.load_state_dict(sd_p, strict=True)
+    pure.load_state_dict(hybrid.state_dict(), strict=True)
+    assert {k for k, _ in hybrid.field.named_parameters()} == {k for k, _ in pure.field.named_parameters()}
+    assert set(hybrid.get_param_groups()) == set(pure.get_param_groups())
+
+    # ---- the callbacks the reference's models run against the field (neus.py:80-92, neus_facto.py:187-262)
+    hybrid.field.set_cos_anneal_ratio(0.25)
+    hybrid.field.update_mask(3)
+    hybrid.field.set_numerical_gradients_delta(1e-3)
+    assert hybrid.field.hash_encoding_mask.shape == pure.field.hash_encoding_mask.shape
+    hybrid.field.update_mask(8)
+    for attr in ("num_levels", "max_res", "base_res", "growth_factor", "numerical_gradients_delta", "config", "encoding"):
+        assert hasattr(hybrid.field, attr)
+    assert float(hybrid.field.deviation_network.get_variance()) == float(pure.field.deviation_network.get_variance())
+    beta = hybrid.field.laplace_density.get_beta()
+    assert torch.equal(hybrid.field.laplace_density(torch.tensor([[0.1]]), beta), pure.field.laplace_density(torch.tensor([[0.1]]), beta))
+
+    # ---- forward through the reference's model code with the native field call stubbed
+    _stub_native_field(monkeypatch)
+    n = 12
+    from oracle import sdf_path as O
+
+    o, d, cam = O.synthetic_rays(n, seed=3)
+    outs = {}
+    for name, model in (("hybrid", hybrid), ("pure", pure)):
+        model.train()
+        rb = ref.rays.RayBundle(origins=o.clone(), directions=d.clone(), pixel_area=torch.ones(n, 1), directions_norm=torch.ones(n, 1),
+                                camera_indices=cam[:, None])
+        out = model(rb)
+        loss = model.get_loss_dict(out, {"image": torch.rand(n, 3)})
+        sum(loss.values()).backward()
+        outs[name] = (out, loss)
+    oh, op = outs["hybrid"][0], outs["pure"][0]
+    assert set(oh) == set(op), sorted(set(oh) ^ set(op))
+    for k in op:
+        if isinstance(op[k], torch.Tensor):
+            assert tuple(oh[k].shape) == tuple(op[k].shape), (k, tuple(oh[k].shape), tuple(op[k].shape))
+    fh, fp = oh["field_outputs"], op["field_outputs"]
+    assert set(fh) == set(fp), (set(fh) ^ set(fp))
+    for k in fp:
+        if isinstance(fp[k], torch.Tensor):
+            assert tuple(fh[k].shape) == tuple(fp[k].shape), (k, tuple(fh[k].shape), tuple(fp[k].shape))
+    assert set(outs["hybrid"][1]) == set(outs["pure"][1])
+    assert all(torch.isfinite(v) for v in outs["hybrid"][1].values())
