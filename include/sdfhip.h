@@ -179,6 +179,12 @@ int sdfhip_sample_spacing(int32_t spacing, const float* nears, const float* fars
  * (same offset from a 16-byte boundary); n in floats. */
 int sdfhip_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int64_t step, float grad_scale, sdfhip_stream_t stream);
+/* PDFSampler (ray_samplers.py:250-370) in any spacing domain and with either jitter mode (one draw per ray, or per bin edge with
+ * jitter_per_sample != 0: jitter [n_rays, s_out + 1], :321-326); include_original = False (the merge with the existing bins of
+ * include_original = True is a sort of the two bin sets on the host side).  Otherwise as sdfhip_sample_pdf. */
+int sdfhip_sample_pdf_spacing(int32_t spacing, const float* weights, const float* bins_in, const float* nears, const float* fars,
+                              const float* jitter, int32_t jitter_per_sample, int64_t n_rays, int32_t s_in, int32_t s_out, float anneal,
+                              float histogram_padding, float* bins_out, float* starts, float* ends, sdfhip_stream_t stream);
 /* interlevel_loss_zip (model_components/losses.py:116-172), the part per proposal level: the field histogram (c [n_rays, s+1]
  * spacing bins, w [n_rays, s] weights; both constants) blurred with half-width `radius` (0.03 / 0.003 for the two levels, :138)
  * and resampled at the proposal bins cp [n_rays, s_p+1]; against the proposal weights wp [n_rays, s_p]:

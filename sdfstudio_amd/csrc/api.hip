@@ -1339,6 +1339,15 @@ extern "C" int sdfhip_sample_pdf_uniform(const float* weights, const float* bins
                          starts, ends, stream);
 }
 
+extern "C" int sdfhip_sample_pdf_spacing(int32_t spacing, const float* weights, const float* bins_in, const float* nears, const float* fars,
+                                         const float* jitter, int32_t jitter_per_sample, int64_t n_rays, int32_t s_in, int32_t s_out,
+                                         float anneal, float histogram_padding, float* bins_out, float* starts, float* ends,
+                                         sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(spacing >= SP_PIECEWISE && spacing <= SP_LOG, "sample_pdf_spacing: unknown spacing %d", spacing);
+  return sample_pdf_impl(weights, bins_in, nears, fars, jitter, jitter_per_sample, spacing, n_rays, s_in, s_out, anneal, histogram_padding,
+                         bins_out, starts, ends, stream);
+}
+
 extern "C" int sdfhip_merge_uniform(const float* bins_1, const float* bins_2, const float* nears, const float* fars, int64_t n_rays,
                                     int32_t s1, int32_t s2, float* merged_bins, int32_t* merged_index, float* merged_starts,
                                     float* merged_ends, sdfhip_stream_t stream) {

@@ -471,7 +471,7 @@ struct PdfArgs {
   const float* nears;
   const float* fars;
   const float* jitter;    // [N], [N,S_out+1] (jitter_stride = S_out+1) or null
-  int32_t jitter_stride, uniform;  // uniform: UniformSampler spacing (euclid = x far + (1 - x) near) instead of the piecewise one
+  int32_t jitter_stride, uniform;  // uniform: the SP_* spacing of the bins (0 piecewise, 1 uniform: x far + (1 - x) near, 2 .. 4)
   int32_t N, S_in, S_out;
   float anneal, histogram_padding, eps;
   float u_end;      // float(1 - 1/(S_out+1))            (ray_samplers.py:323)
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void pdf_sample_kernel(const PdfArgs a) {
   __builtin_amdgcn_wave_barrier();
   const int nbins = a.S_out + 1;
   const float near_ = a.nears[ray], far_ = a.fars[ray];
-  const float sn = piecewise_fn(near_), sf = piecewise_fn(far_);
+  const float sn = spacing_fn(a.uniform, near_), sf = spacing_fn(a.uniform, far_);
   const float* bin = a.bins_in + (int64_t)ray * (Si + 1);
   for (int j = lane; j < nbins; j += 64) {
     // u = linspace(0, 1 - 1/nbins, nbins)[j] + (jitter / nbins | 1/(2 nbins))      (ray_samplers.py:321-334)
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void pdf_sample_kernel(const PdfArgs a) {
     t = fminf(fmaxf(t, 0.0f), 1.0f); // +-inf clip like torch.clip after nan_to_num
     const float b = b0 + t * (b1 - b0);
     a.bins_out[(int64_t)ray * nbins + j] = b;
-    const float e = a.uniform ? b * far_ + (1.0f - b) * near_ : piecewise_inv(b * sf + (1.0f - b) * sn);
+    const float e = a.uniform == SP_UNIFORM ? b * far_ + (1.0f - b) * near_ : spacing_inv(a.uniform, b * sf + (1.0f - b) * sn);
     if (j < a.S_out) a.starts[(int64_t)ray * a.S_out + j] = e;
     if (j > 0) a.ends[(int64_t)ray * a.S_out + j - 1] = e;
   }

@@ -337,42 +337,54 @@ class ErrorBoundedSampler(Sampler):
 
 
 class PDFSampler(Sampler):
-    """ray_samplers.py:250-370 with include_original=False (the ProposalNetworkSampler setting, :525)."""
+    """ray_samplers.py:250-370.  The inverse-CDF resampling is one kernel (sdfhip_sample_pdf_spacing) in the spacing domain of the
+    incoming samples, for both jitter modes; with include_original=True (the reference's default, though every caller on the
+    SDF path passes False: :525, :835, :601) the new bins are merged with the existing ones by a sort, as the reference does (:355)."""
 
     def __init__(self, num_samples: Optional[int] = None, train_stratified: bool = True, single_jitter: bool = True,
-                 include_original: bool = False, histogram_padding: float = 0.01) -> None:
+                 include_original: bool = False, histogram_padding: float = 0.01, spacing: str = "piecewise") -> None:
         super().__init__(num_samples=num_samples)
-        if include_original or not single_jitter:
-            raise NotImplementedError("only include_original=False, single_jitter=True is built")
+        if spacing not in _SPACINGS:
+            raise ValueError(f"unknown spacing {spacing!r}; built: {sorted(_SPACINGS)}")
         self.train_stratified = train_stratified
+        self.single_jitter = single_jitter
+        self.include_original = include_original
         self.histogram_padding = histogram_padding
+        self.spacing = spacing  # the spacing domain the incoming ray samples' bins live in (RaySamples carry only the closure)
         self.jitter_override: Optional[torch.Tensor] = None
 
     def generate_ray_samples(self, ray_bundle: RayBundle, ray_samples: RaySamples, weights: torch.Tensor,
                              num_samples: Optional[int] = None, anneal: float = 1.0) -> RaySamples:
         lib = _lib.load()
+        if ray_samples is None or ray_bundle is None:
+            raise ValueError("ray_samples and ray_bundle must be provided")
         s_out = num_samples or self.num_samples
         w = weights[..., 0] if weights.dim() == 3 else weights
-        w = w.detach().contiguous()
+        w = w.detach()
         n, s_in = w.shape
         dev = w.device
         bins_in = ray_samples.flat_bins
         if bins_in is None:
             bins_in = torch.cat([ray_samples.spacing_starts[..., 0], ray_samples.spacing_ends[..., -1:, 0]], dim=-1)
-        bins_in = bins_in.contiguous()
-        nears = ray_bundle.nears.reshape(-1).contiguous()
-        fars = ray_bundle.fars.reshape(-1).contiguous()
         jitter = None
         if self.train_stratified and self.training:
-            jitter = self.jitter_override if self.jitter_override is not None else torch.rand(n, device=dev)
-            jitter = jitter.reshape(-1).contiguous()
+            shape = (n,) if self.single_jitter else (n, s_out + 1)
+            jitter = self.jitter_override if self.jitter_override is not None else torch.rand(shape, device=dev)
+            jitter = jitter.reshape(shape)
         bins = torch.empty(n, s_out + 1, device=dev)
         starts = torch.empty(n, s_out, device=dev)
         ends = torch.empty(n, s_out, device=dev)
-        _lib.check(lib.sdfhip_sample_pdf(_lib.ptr(w), _lib.ptr(bins_in), _lib.ptr(nears), _lib.ptr(fars), _lib.ptr(jitter),
-                                         n, s_in, s_out, float(anneal), float(self.histogram_padding), _lib.ptr(bins),
-                                         _lib.ptr(starts), _lib.ptr(ends), _lib.stream()), "sample_pdf")
-        return _make_samples(ray_bundle, bins, starts, ends)
+        kp = _lib.Keep()
+        _lib.check(lib.sdfhip_sample_pdf_spacing(_SPACINGS[self.spacing][0], kp(w), kp(bins_in), kp(ray_bundle.nears.reshape(-1)),
+                                                 kp(ray_bundle.fars.reshape(-1)), kp(jitter), 0 if self.single_jitter else 1, n, s_in,
+                                                 s_out, float(anneal), float(self.histogram_padding), _lib.ptr(bins), _lib.ptr(starts),
+                                                 _lib.ptr(ends), _lib.stream()), "sample_pdf_spacing")
+        del kp
+        if self.include_original:
+            bins, _ = torch.sort(torch.cat([bins_in, bins], -1), -1)  # ray_samplers.py:354-355
+            eu = _spacing_to_euclidean(self.spacing, ray_bundle.nears, ray_bundle.fars)(bins)
+            starts, ends = eu[:, :-1].contiguous(), eu[:, 1:].contiguous()
+        return _make_samples(ray_bundle, bins, starts, ends, self.spacing)
 
 
 class ProposalNetworkSampler(Sampler):

@@ -540,3 +540,39 @@ def test_schedulers_against_reference():
     ref = ref_factors(RS.MultiStepWarmupScheduler, 60, 10, [20, 30, 45], 0.33)
     mine = [E.multi_step_warmup_scheduler(10, (20, 30, 45), 0.33)(k) for k in range(60)]
     assert np.allclose(ref, mine, rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/nerfstudio"), reason="the reference tree only exists in the build container")
+@pytest.mark.parametrize("include_original", [False, True])
+@pytest.mark.parametrize("single_jitter", [True, False])
+def test_pdf_sampler_oracle_against_reference(single_jitter, include_original):
+    """oracle.pdf_sample (+ the include_original merge, ray_samplers.py:354-355) pinned on the reference's PDFSampler for both
+    jitter modes, on linear-disparity samples (the background sampler's spacing)."""
+    from oracle import ref_harness
+
+    ns = ref_harness.import_reference()
+    torch.manual_seed(4)
+    n, s_in, s_out = 11, 20, 13
+    o, d, _ = O.synthetic_rays(n)
+    nears, fars = 0.5 + torch.rand(n, 1), 3.0 + 20 * torch.rand(n, 1)
+    rb = ns.rays.RayBundle(origins=o, directions=d, pixel_area=torch.ones(n, 1), nears=nears, fars=fars)
+    base = ns.rs.LinearDisparitySampler(num_samples=s_in).eval()(rb)
+    w = torch.rand(n, s_in, 1) * (torch.rand(n, s_in, 1) < 0.6)
+    w[2] = 0.0
+    jit = torch.rand(n, 1) if single_jitter else torch.rand(n, s_out + 1)
+    smp = ns.rs.PDFSampler(num_samples=s_out, single_jitter=single_jitter, include_original=include_original).train()
+    real_rand = torch.rand
+    torch.rand = lambda *a, **k: jit.clone()
+    try:
+        rs = smp(rb, base, w)
+    finally:
+        torch.rand = real_rand
+    existing = torch.cat([base.spacing_starts[..., 0], base.spacing_ends[..., -1:, 0]], -1)
+    bins = O.pdf_sample(w[..., 0], existing, s_out, jit)
+    if include_original:
+        bins = torch.sort(torch.cat([existing, bins], -1), -1)[0]
+    eu = O.spaced_to_euclidean("lindisp", bins, nears[:, 0], fars[:, 0])
+    got_bins = torch.cat([rs.spacing_starts[..., 0], rs.spacing_ends[..., -1:, 0]], -1)
+    assert torch.allclose(got_bins, bins, rtol=0, atol=1e-7)
+    assert torch.allclose(rs.frustums.starts[..., 0], eu[:, :-1], rtol=1e-6, atol=1e-6)
+    assert torch.allclose(rs.frustums.ends[..., 0], eu[:, 1:], rtol=1e-6, atol=1e-6)

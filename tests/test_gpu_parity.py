@@ -111,6 +111,39 @@ def test_spaced_sampler_family(device, kind, single_jitter):
                      O.spaced_to_euclidean(kind, x, nears, fars), rtol=2e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("include_original", [False, True])
+@pytest.mark.parametrize("single_jitter", [True, False])
+@pytest.mark.parametrize("kind", ["piecewise", "lindisp"])
+def test_pdf_sampler_general(device, kind, single_jitter, include_original):
+    """PDFSampler in a non-default spacing domain, per-bin-edge jitter (ray_samplers.py:321-326) and include_original=True (:354-355)
+    against the oracle (pinned on the reference's PDFSampler by test_pdf_sampler_oracle_against_reference)."""
+    from sdfstudio_amd.model_components import ray_samplers as RS
+
+    torch.manual_seed(9)
+    n, s_in, s_out = 41, 48, 29
+    o, d, cam = O.synthetic_rays(n)
+    nears, fars = 0.5 + torch.rand(n), 3.0 + 20 * torch.rand(n)
+    rb = _bundle(o, d, cam, 0.5, 4.5, device)
+    rb.nears, rb.fars = nears[:, None].to(device), fars[:, None].to(device)
+    base = (RS.UniformLinDispPiecewiseSampler if kind == "piecewise" else RS.LinearDisparitySampler)(single_jitter=True).eval()(rb, num_samples=s_in)
+    w = torch.rand(n, s_in) * (torch.rand(n, s_in) < 0.6)
+    w[2] = 0.0
+    for training in (True, False):
+        jit = torch.rand(n, 1) if single_jitter else torch.rand(n, s_out + 1)
+        smp = RS.PDFSampler(num_samples=s_out, single_jitter=single_jitter, include_original=include_original, spacing=kind).train(training)
+        smp.jitter_override = jit.to(device)
+        rs = smp(rb, base, w[..., None].to(device))
+        existing = base.flat_bins.cpu()
+        bins = O.pdf_sample(w, existing, s_out, jit if training else None)
+        if include_original:
+            bins = torch.sort(torch.cat([existing, bins], -1), -1)[0]
+        eu = O.spaced_to_euclidean(kind, bins, nears, fars)
+        # one fp32 ulp of the cdf (a cumsum of ~50 terms) moves a bin edge by ~5e-6 of the spacing range (DESIGN.md section 2)
+        assert_close("bins", rs.flat_bins, bins, rtol=0, atol=1e-5)
+        assert_close("starts", rs.flat_starts, eu[:, :-1], rtol=1e-4, atol=1e-5)
+        assert_close("ends", rs.flat_ends, eu[:, 1:], rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("training", [True, False])
 def test_uniform_sampler(device, training):
     from sdfstudio_amd.model_components.ray_samplers import UniformSampler
@@ -1292,8 +1325,35 @@ def test_background_mlp_models_against_reference_golden(device, name):
         # (|z| ~ 1e-6, helpers.relu_flip_basis) moves single entries by up to ~1e-2 of the maximum; their tight comparison is the
         # job of the train-mode goldens (test_*_model_against_reference_golden), here they get the loose bar.
         # (the hash table's finest level is the extreme case: an entry sees a handful of samples, its gradient here is ~1e-4)
-        rt = 2e-3 if k.startswith("field_background") else (1e-1 if k == "field.encoding.params" else 2e-2)
+        # background: 2e-3 on the heads / head MLP; the 8 x 256 base MLP's gradients (scale ~5e-5 here, sums of 256-term products
+        # through rocBLAS on the device vs the CPU reference) get 1e-2
+        rt = (1e-2 if "mlp_base" in k else 2e-3) if k.startswith("field_background") else (1e-1 if k == "field.encoding.params" else 2e-2)
         assert_close(f"grad {k}", got[k], ref, rtol=rt, atol=1e-9)
         checked += 1
     assert checked >= 50
     assert any(k.startswith("field_background.mlp_base") for k in g["grad"])
+
+
+def test_dense_grid_sdf_for_mesh_extraction(device):
+    """scripts/extract_mesh.py:94-133 / utils/marching_cubes.py: sdf_on_grid (ray layout, sdf row only) and sdf_on_points against
+    the oracle's forward_geonetwork on a lattice; the coarse-to-fine pyramid must reproduce the dense evaluation wherever the
+    surface can be (|sdf| below the final threshold) while evaluating a fraction of the points."""
+    from sdfstudio_amd.utils.marching_cubes import evaluate_crop_pyramid, sdf_on_grid, sdf_on_points
+
+    g = load_golden("train")
+    cfg = small_oracle_cfg()
+    model = product_model_from_params(g["param"], cfg, device).eval()
+    lo, hi, res = (-0.9, -0.8, -0.7), (0.9, 0.85, 0.8), (13, 9, 21)
+    vol = sdf_on_grid(model.field, lo, hi, res, chunk_points=1000)  # several x slabs
+    ax = [torch.linspace(lo[a], hi[a], res[a]) for a in range(3)]
+    pts = torch.stack(torch.meshgrid(*ax, indexing="ij"), -1).reshape(-1, 3)
+    ref = O.geo_network(pts, g["param"], cfg.field)[:, 0].reshape(res)
+    assert_close("sdf_on_grid", vol, ref, rtol=0, atol=1e-5)
+    assert_close("sdf_on_points", sdf_on_points(model.field, pts.to(device), chunk=700), ref.reshape(-1), rtol=0, atol=1e-5)
+    n = 32
+    ax = [torch.linspace(-1.0, 1.0, n, device=device)] * 3
+    cube = torch.stack(torch.meshgrid(*ax, indexing="ij"), 0)
+    z, counts, fine = evaluate_crop_pyramid(lambda p: sdf_on_points(model.field, p), cube, 2.0)
+    dense = sdf_on_points(model.field, cube.reshape(3, -1).T.contiguous())
+    assert fine.any() and counts[-1] == int(fine.sum()) < n ** 3 and counts[0] == (n // 8) ** 3
+    assert_close("pyramid == dense where it refined to full resolution", z[fine], dense[fine], rtol=0, atol=1e-6)
