@@ -12,9 +12,11 @@ Inputs are synthetic (DTU-scan65-like cameras) and already
 Rank 0 prints ONE JSON line.  `value` = whole-job field ray-samples per second (N * 4096 * 128 / step time).
 `roofline` is for the dominant kernel (geo_bwd_kernel: tangent + data backward of the geometry MLP), with its launch
 time measured live by HIP events recorded on the launch stream inside the timed region (sdfhip_profile_*).  With the
-matrix products on the bf16 pipe (split-bf16, fp32 accumulate) that kernel is bound by the HBM traffic of the saved
-per-layer tensors it must read and write (DESIGN.md section 4 derives the 58.9 KB per ray-sample), not by MFMA.
-`cpu_baseline` times the CPU oracle (a port of the reference's PyTorch path) on this host for a bounded sample.
+matrix products on the 16-bit pipe (hi + lo parts, fp32 accumulate) that kernel is bound by the HBM traffic of the saved
+per-layer tensors it reads and writes (DESIGN.md section 4 derives the 58.9 KB per ray-sample = `dataflow_bytes`;
+`algorithmic_bytes` is SURVEY 8(d)'s boundary-only figure and `waste_ratio` the traffic over it).  `step_roofline` is the
+whole step.  `cpu_baseline` times the CPU oracle (a port of the reference's PyTorch path) on this host for a bounded sample;
+`cpu_baseline_reference` quotes the reference's own Python timed in the build container (profiles/cpu_reference_r2.json).
 """
 import argparse
 import json
@@ -35,10 +37,18 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA, f32 accu
 PEAK_HBM_GBS = 8000.0
 
 
+def geo_bwd_io_bytes(nb0=3, nbf=8):
+    """SURVEY section 8(d)'s notion of algorithmic bytes for geo_bwd_kernel: what crosses its boundary if nothing were saved
+    between kernels - the tangent seed (nb0 blocks of 128 B), d L / d feature (nbf), d L / d sdf (4 B) in, d L / d in0 (nb0) out."""
+    return 128 * (nb0 + nbf + nb0) + 4
+
+
 def geo_bwd_algorithmic_bytes(nbh=8, nb0=3, nb3=6, nl=8, skip=4, nbf=8):
-    """HBM bytes per ray-sample that geo_bwd_kernel's algorithm moves: every tensor is tile-packed in
+    """HBM bytes per ray-sample that geo_bwd_kernel's DATA FLOW moves: every tensor is tile-packed in
     blocks of 32 features x 4 B = 128 B per point.  Tangent pass: reads the seed, z_l and r_l; writes the tangent qb_l
-    entering every layer and zc_l.  Data backward: reads featbar, z_l and zc_l; writes zbar_l and d L / d in0."""
+    entering every layer and zc_l.  Data backward: reads featbar, z_l and zc_l; writes zbar_l and d L / d in0.  These saved
+    per-layer tensors exist because the three sweeps over the layers alternate direction and the weight gradients are separate
+    GEMMs; geo_bwd_io_bytes is the (27x smaller) figure of an ideal implementation that keeps them on chip."""
     kb = lambda l: nb0 if l == 0 else (nb3 + nb0 if l == skip else nbh)
     nbo = lambda l: nbf if l == nl else (nb3 if l + 1 == skip else nbh)
     rd = nb0 + sum(2 * nbo(l - 1) for l in range(1, nl)) + (nb0 if 0 < skip < nl else 0) + 2 * nbo(nl - 1)
@@ -124,7 +134,7 @@ def cpu_baseline():
         if v.is_floating_point() and k != "laplace_density.beta_min":
             v.requires_grad_(True)
     opt = torch.optim.Adam([v for v in p.values() if v.requires_grad], lr=5e-4, eps=1e-15)
-    n = 128
+    n = 512  # large enough for the 8x256 GEMMs to spread over 64 threads (128 rays left most of them idle)
     o, d, cam = O.synthetic_rays(n, seed=1)
     image = torch.rand(n, 3)
 
@@ -139,7 +149,7 @@ def cpu_baseline():
     step()
     t0 = time.perf_counter()
     iters = 0
-    while iters < 2 or (time.perf_counter() - t0 < 10.0 and iters < 50):
+    while iters < 2 or (time.perf_counter() - t0 < 15.0 and iters < 50):
         step()
         iters += 1
     dt = (time.perf_counter() - t0) / iters
@@ -304,12 +314,17 @@ def run(args):
                 traffic = tj["hbm_read_bytes"] + tj["hbm_write_bytes"]  # HBM bytes per launch
                 traffic_source = tj["source"]
             flops = 2 * g * P
+            io_bytes = geo_bwd_io_bytes() * P
             roof = {"kernel": "geo_bwd_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS,
                     "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_unit": "bytes per launch",
-                    "traffic_source": traffic_source, "algorithmic_bytes": alg_bytes,
+                    "traffic_source": traffic_source, "dataflow_bytes": alg_bytes,
                     "avg_launch_ms": round(kt_ms / kn, 4), "launches": kn,
-                    "algorithmic": f"{geo_bwd_algorithmic_bytes()} B per ray-sample (saved per-layer tensors read + written, DESIGN.md "
-                                   f"section 4) x {P} ray-samples per launch",
+                    "achieved_is": f"data-flow bytes / launch time: {geo_bwd_algorithmic_bytes()} B per ray-sample (the per-layer tensors the "
+                                   f"kernel reads and writes, DESIGN.md section 4) x {P} ray-samples; the PMC traffic agrees to 2 %",
+                    # SURVEY 8(d)'s definition: only what must cross the kernel boundary (inputs + outputs); traffic / this = waste
+                    "algorithmic_bytes": io_bytes,
+                    "waste_ratio": round((traffic if traffic else alg_bytes) / io_bytes, 1),
+                    "frac_at_algorithmic_bytes": round(io_bytes / avg_s / 1e9 / PEAK_HBM_GBS, 4),
                     # the matrix side of the same kernel: 2G algorithmic flop per sample, each product issued as 3 bf16 MFMA terms
                     "mfma": {"algorithmic_tflops": round(flops / avg_s / 1e12, 1), "issued_bf16_tflops": round(3 * flops / avg_s / 1e12, 1),
                              "peak_bf16_tflops": PEAK_BF16_MFMA_TFLOPS, "frac_issued": round(3 * flops / avg_s / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}}
@@ -320,8 +335,9 @@ def run(args):
             "metric": "ray-samples/sec (NeuS-facto train step, 4096 rays x 128 samples per GPU)",
             "value": round(value, 1), "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "dtype_note": "fp32 tensors and accumulators; matrix products as split-bf16 terms on the bf16 MFMA pipe (6 terms = fp32-class "
-                          "for everything the forward returns, 3 terms in the backward kernels and weight-gradient GEMMs)",
+            "dtype_note": "fp32 tensors and accumulators; matrix products as three 16-bit MFMA terms of hi + lo operand parts: fp16 parts "
+                          "(22 mantissa bits, fp32-class) for everything the forward returns, bf16 parts (2^-17 per product, full exponent "
+                          "range) in the backward kernels and weight-gradient GEMMs",
             "data": "synthetic", "iters_per_sec": round(1e3 / ms, 3), "per_gpu": round(value / world, 1),
             "config": {"workload": "SMALL parity configuration (control-flow test only, NOT a benchmark)" if args.small else
                                    "BASELINE config 2: NeuS-facto hash-grid 16x2x2^19 smoothstep + 8x256 geo MLP + 4x256 colour MLP, "
@@ -338,6 +354,26 @@ def run(args):
             "mfma_kernels_ms_per_step": round(mfma_ms, 3),
             "kernels": kernels,
         }
+        # whole-step view: model FLOPs (6G + 3C per sample) against the fp32 matrix peak an exact-fp32 implementation would be
+        # bound by, the issued 16-bit MFMA terms (3 per product in every pass) against the dense bf16 / fp16 peak, and the whole
+        # step's HBM bytes from the committed PMC passes
+        step_bytes = None
+        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_step_traffic.json"))
+        if cands:
+            with open(os.path.join(ROOT, "profiles", cands[-1])) as fh:
+                step_bytes = json.load(fh).get("hbm_GB_per_training_step")
+        model_tf = (6 * g + 3 * c) * P / (ms * 1e-3) / 1e12
+        line["step_roofline"] = {
+            "model_tflops": round(model_tf, 1), "fp32_matrix_peak_tflops": 157.3, "frac_of_fp32_matrix_peak": round(model_tf / 157.3, 3),
+            "issued_16bit_mfma_tflops": round(3 * model_tf, 1), "frac_of_dense_bf16_peak": round(3 * model_tf / PEAK_BF16_MFMA_TFLOPS, 4),
+            "hbm_GB_per_step_pmc": step_bytes,
+            "hbm_GBps": None if step_bytes is None else round(step_bytes / (ms * 1e-3), 1),
+            "hbm_frac_of_8TBps": None if step_bytes is None else round(step_bytes / (ms * 1e-3) / PEAK_HBM_GBS, 4),
+        }
+        ref_path = os.path.join(ROOT, "profiles", "cpu_reference_r2.json")
+        if os.path.exists(ref_path):
+            with open(ref_path) as fh:
+                line["cpu_baseline_reference"] = json.load(fh)  # the reference's own Python, timed in the build container (no GPU box has it)
         if world == 1 and not args.no_cpu_baseline and not args.small:
             print("[bench] GPU leg done: " + json.dumps(line), file=sys.stderr, flush=True)
             line["cpu_baseline"] = cpu_baseline()

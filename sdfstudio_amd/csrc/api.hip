@@ -15,6 +15,7 @@
 const FieldKernels* sdfhip_kernels_A();
 const FieldKernels* sdfhip_kernels_B();
 const FieldKernels* sdfhip_kernels_C();
+const FieldKernels* sdfhip_kernels_D();
 
 static thread_local char g_err[1024] = "";
 void sdfhip_set_error(const char* fmt, ...) {
@@ -234,7 +235,7 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
   if (skip >= 0 && (skip < 1 || skip >= NL || H - D0 <= 0)) return fail("bad skip layer");
   if (NL + 1 > kMaxLayers || NLC + 1 > kMaxLayers) return fail("too many layers");
   const int nb0 = (D0 + 31) / 32, nb3 = skip >= 0 ? (H - D0 + 31) / 32 : 0, nbs = (33 + E + 31) / 32;
-  const FieldKernels* cands[] = {sdfhip_kernels_A(), sdfhip_kernels_B(), sdfhip_kernels_C()};
+  const FieldKernels* cands[] = {sdfhip_kernels_A(), sdfhip_kernels_B(), sdfhip_kernels_C(), sdfhip_kernels_D()};
   f->k = nullptr;
   for (const FieldKernels* k : cands) {
     if (k->nbh == H / 32 && k->nb0 == nb0 && k->nb3 == nb3 && k->nl == NL && k->skip == skip && k->nbf == GF / 32 && k->nbs == nbs &&
