@@ -185,6 +185,11 @@ int sdfhip_adam_step(float* param, const float* grad, float* exp_avg, float* exp
 int sdfhip_sample_pdf_spacing(int32_t spacing, const float* weights, const float* bins_in, const float* nears, const float* fars,
                               const float* jitter, int32_t jitter_per_sample, int64_t n_rays, int32_t s_in, int32_t s_out, float anneal,
                               float histogram_padding, float* bins_out, float* starts, float* ends, sdfhip_stream_t stream);
+/* UniSurfSampler's surface search (ray_samplers.py:1030-1075): first outside-to-inside sign change of sdf [n_rays, n_samples] along
+ * the samples at depths starts [n_rays, n_samples], depth z by linear interpolation, and the shrunk sampling interval
+ * [max(z - (far - near) delta, near), min(z + (far - near) delta, far)] (unchanged where no surface was found: mask = 0). */
+int sdfhip_surface_root(const float* sdf, const float* starts, const float* nears, const float* fars, int64_t n_rays, int32_t n_samples,
+                        float delta, int32_t* mask, float* z, float* new_nears, float* new_fars, sdfhip_stream_t stream);
 /* interlevel_loss_zip (model_components/losses.py:116-172), the part per proposal level: the field histogram (c [n_rays, s+1]
  * spacing bins, w [n_rays, s] weights; both constants) blurred with half-width `radius` (0.03 / 0.003 for the two levels, :138)
  * and resampled at the proposal bins cp [n_rays, s_p+1]; against the proposal weights wp [n_rays, s_p]:

@@ -488,6 +488,45 @@ def merge_bins(bins_1: torch.Tensor, bins_2: torch.Tensor):
     return torch.cat([merged, ends], dim=-1), index
 
 
+def unisurf_sampler(nears, fars, sdf_fn, occupancy_fn, delta: float, rand=None, num_samples_interval: int = 64,
+                    num_samples_outside: int = 32, num_samples_importance: int = 32, num_marching_steps: int = 256):
+    """UniSurfSampler.generate_ray_samples, ray_samplers.py:996-1093 (single_jitter=False, the default: one draw per bin edge).
+
+    sdf_fn(starts [N,S]) -> sdf [N,S].  rand: the four torch.rand draws in call order - marching bins [N,M+1], importance
+    resampling [N,K+1], outside bins [N,O+1], interval bins [N,I+1] - or None (eval).  Returns a dict with the merged euclidean
+    bins [N,I+K+O+1], the surface mask / depth z and the pieces the tests look at."""
+    n = nears.shape[0]
+    r = rand if rand is not None else [None] * 4
+    m_bins = initial_bins(n, num_marching_steps, r[0], nears.dtype)
+    m_eu = uniform_to_euclidean(m_bins, nears, fars)
+    starts = m_eu[:, :-1]
+    with torch.no_grad():
+        sdf = sdf_fn(starts)
+    occ = occupancy_fn(sdf)
+    weights, _ = weights_from_alphas(occ)                                   # :1016-1017
+    imp_bins = pdf_sample(weights, m_bins, num_samples_importance, r[1], histogram_padding=1e-5)   # :1019-1024 (padding :982)
+    out_bins = initial_bins(n, num_samples_outside, r[2], nears.dtype)       # :1027
+    ui_bins, _ = merge_bins(imp_bins, out_bins)                             # :1030-1032 (spacing domain, uniform spacing)
+    ui_eu = uniform_to_euclidean(ui_bins, nears, fars)
+    # first outside -> inside sign change (:1037-1052)
+    sgn = torch.cat([torch.sign(sdf[:, :-1] * sdf[:, 1:]), torch.ones(n, 1, dtype=sdf.dtype)], dim=-1)
+    cost = sgn * torch.arange(sdf.shape[1], 0, -1, dtype=sdf.dtype)
+    values, idx = torch.min(cost, -1)
+    ar = torch.arange(n)
+    mask = (values < 0) & (sdf[ar, idx] > 0)
+    hi = torch.clamp(idx + 1, max=sdf.shape[1] - 1)
+    d_low, v_low, d_high, v_high = starts[ar, idx], sdf[ar, idx], starts[ar, hi], sdf[ar, hi]
+    z = (v_low * d_high - v_high * d_low) / (v_low - v_high)               # :1063 linear interpolation
+    dists = fars - nears
+    nn = torch.where(mask, torch.maximum(z - dists * delta, nears), nears)  # :1068-1075
+    nf = torch.where(mask, torch.minimum(z + dists * delta, fars), fars)
+    i_bins = initial_bins(n, num_samples_interval, r[3], nears.dtype)        # :1078
+    i_eu = uniform_to_euclidean(i_bins, nn, nf)
+    merged, _ = merge_bins(i_eu, ui_eu)                                     # merge_ray_samples_in_eculidean :1095-1130
+    return {"bins": merged, "mask": mask, "z": z, "marching_starts": starts, "sdf": sdf, "importance_bins": imp_bins,
+            "interval_bins": i_eu, "new_nears": nn, "new_fars": nf}
+
+
 def neus_sampler(origins, dirs, nears, fars, sdf_fn, num_samples: int = 64, num_samples_importance: int = 64,
                  num_upsample_steps: int = 4, base_variance: float = 64.0, rand: Optional[List[torch.Tensor]] = None):
     """ray_samplers.py:815-897 NeuSSampler.generate_ray_samples.

@@ -375,7 +375,7 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
     const int m3 = add_map(maps, ident(3, 3));
     f->c_bout = add_vec(li.b_off, 3, m3, 1);
   }
-  f->packed_size = poff + 2048;  // the chunk DMA moves whole 4 KiB rounds: slack behind the last chunk
+  f->packed_size = poff + 16384;  // slack behind the last chunk: the DMA moves whole 4 KiB rounds, and a layer run from the run-time layer loop prefetches its successor's first chunk at the LARGEST size any successor has (geo_kernels.h)
   // largest split-K partial
   auto upd = [&](int rows_blocks, int col_blocks) {
     f->max_partial_elems = std::max<int64_t>(f->max_partial_elems, (int64_t)rows_blocks * 32 * col_blocks * 32);
@@ -1282,6 +1282,28 @@ extern "C" int sdfhip_adam_step(float* param, const float* grad, float* exp_avg,
   const int64_t n4 = (n + 3) / 4;
   const unsigned grid = (unsigned)std::min<int64_t>((n4 + 255) / 256, 256 * 16);
   adam_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfhip_surface_root(const float* sdf, const float* starts, const float* nears, const float* fars, int64_t n_rays,
+                                   int32_t n_samples, float delta, int32_t* mask, float* z, float* new_nears, float* new_fars,
+                                   sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(sdf && starts && nears && fars && mask && z && new_nears && new_fars && n_samples >= 1, "surface_root: bad argument");
+  if (n_rays == 0) return 0;
+  RootArgs a;
+  a.sdf = sdf;
+  a.starts = starts;
+  a.nears = nears;
+  a.fars = fars;
+  a.N = (int)n_rays;
+  a.S = n_samples;
+  a.delta = delta;
+  a.mask = mask;
+  a.z = z;
+  a.new_nears = new_nears;
+  a.new_fars = new_fars;
+  surface_root_kernel<<<(unsigned)((n_rays + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }

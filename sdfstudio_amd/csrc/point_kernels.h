@@ -66,7 +66,9 @@ SDFHIP_D void grid_cell(const GridLevelDev& L, const bool smooth, const float p[
       idx = (cx ^ (cy * 2654435761u) ^ (cz * 805459861u)) & (L.size - 1u);  // hashed levels: size is a power of two
     } else {
       idx = cx + cy * L.res + cz * L.res * L.res;
-      if (idx >= L.size) idx -= L.size;  // only the x == 1.0 face wraps
+      // tiny-cuda-nn reduces the uint32 sum modulo the level size (grid.h grid_index): inside the unit cube only the x == 1.0
+      // face wraps, but get_sdf / gradient() take UNcontracted positions (sdf_field.py:412-418), which may lie outside it
+      if (idx >= L.size) idx %= L.size;
     }
     c.idx[k] = L.offset + idx;
   }

@@ -1094,3 +1094,53 @@ __global__ __launch_bounds__(256) void interlevel_kernel(const InterlevelArgs a)
     if (a.w_gt != nullptr) a.w_gt[o] = wg;
   }
 }
+
+// ------------------------------------------------------------------------------------------------ surface root finding (UniSurf)
+// UniSurfSampler's ray / surface intersection (model_components/ray_samplers.py:1030-1075): along the num_marching_steps uniform
+// samples of a ray, the FIRST interval whose sdf changes sign (sdf_i sdf_{i+1} < 0), accepted only if it goes from outside to
+// inside (sdf_i > 0); the depth is the linear interpolation (regula falsi step) of the two bracketing samples, and the ray's
+// [near, far] shrinks to z +- (far - near) delta, clipped to the original interval (:1068-1075).  One thread per ray.
+struct RootArgs {
+  const float* sdf;      // [N,S]
+  const float* starts;   // [N,S]
+  const float* nears;    // [N]
+  const float* fars;     // [N]
+  int32_t N, S;
+  float delta;
+  int32_t* mask;         // [N]  1: a surface was found
+  float* z;              // [N]  its depth (undefined where mask == 0)
+  float* new_nears;      // [N]
+  float* new_fars;       // [N]
+};
+
+__global__ void surface_root_kernel(const RootArgs a) {
+  const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ray >= a.N) return;
+  const float* sdf = a.sdf + (size_t)ray * a.S;
+  const float* st = a.starts + (size_t)ray * a.S;
+  int idx = -1;
+  float prev = sdf[0];
+  for (int i = 0; i + 1 < a.S; ++i) {
+    const float next = sdf[i + 1];
+    if (prev * next < 0.0f) {  // torch.sign(sdf_i sdf_{i+1}) == -1; the argmin over sign x (S - i) picks the first such i (:1039-1045)
+      idx = i;
+      break;
+    }
+    prev = next;
+  }
+  const float near_ = a.nears[ray], far_ = a.fars[ray];
+  bool ok = idx >= 0 && sdf[idx] > 0.0f;
+  float z = 0.0f, nn = near_, nf = far_;
+  if (ok) {
+    const int hi = idx + 1 < a.S ? idx + 1 : a.S - 1;
+    const float d_low = st[idx], v_low = sdf[idx], d_high = st[hi], v_high = sdf[hi];
+    z = (v_low * d_high - v_high * d_low) / (v_low - v_high);
+    const float w = (far_ - near_) * a.delta;
+    nn = fmaxf(z - w, near_);
+    nf = fminf(z + w, far_);
+  }
+  a.mask[ray] = ok ? 1 : 0;
+  a.z[ray] = z;
+  a.new_nears[ray] = nn;
+  a.new_fars[ray] = nf;
+}

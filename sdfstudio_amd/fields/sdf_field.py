@@ -478,8 +478,35 @@ class SDFField(nn.Module):
             gradients = torch.stack([0.5 * (points_sdf[0] - points_sdf[1]) / delta, 0.5 * (points_sdf[2] - points_sdf[3]) / delta,
                                      0.5 * (points_sdf[4] - points_sdf[5]) / delta], dim=-1)
             return (gradients, points_sdf) if return_sdf else gradients
-        raise NotImplementedError("gradient() is built for use_numerical_gradients=True; the analytic d sdf / dx (with its autograd "
-                                  "graph) comes out of get_outputs / forward_fused")
+        # analytic mode (sdf_field.py:455-467: autograd.grad of the geometry network w.r.t. its input, create_graph=True): the fused
+        # field call on "rays" of one sample at distance zero - its d sdf / dx output carries the full autograd graph (second-order
+        # terms included), the colour network runs along unused (zero cotangent)
+        n = x.shape[0]
+        zeros = torch.zeros(n, 1, device=x.device)
+        emb = None
+        if self.config.use_appearance_embedding and self.training:
+            emb = torch.zeros(n, self.config.appearance_embedding_dim, device=x.device)
+        field_fn = self if self._cfg_c.contract == 0 else self._uncontracted()
+        _, grad, _, _ = _FieldFunction.apply(self._theta(), self.encoding.params, emb, field_fn, x.detach().contiguous(),
+                                             torch.zeros(n, 3, device=x.device), zeros, self._mask(x.device))
+        gradients = grad.reshape(*shape, 3)
+        if return_sdf:
+            raise NotImplementedError("return_sdf is the numerical mode's tap values (sdf_field.py:439-453)")
+        return gradients
+
+    def _uncontracted(self):
+        """A view of this field whose native descriptor applies NO scene contraction: gradient() contracts on the host first
+        (or skips it, skip_spatial_distortion), the kernels must then take the positions as given."""
+        if getattr(self, "_plain_view", None) is None:
+            import copy
+
+            view = copy.copy(self)  # shares every parameter / buffer; only the descriptor differs
+            cfg = _lib.FieldCfg.from_buffer_copy(self._cfg_c)
+            cfg.contract = 0
+            object.__setattr__(view, "_cfg_c", cfg)
+            object.__setattr__(view, "_handle_v", None)
+            object.__setattr__(self, "_plain_view", view)
+        return self._plain_view
 
     def _numerical_outputs(self, ray_samples, o, d, st, emb):
         """get_outputs with use_numerical_gradients (sdf_field.py:629-655): geometry network at the contracted start positions

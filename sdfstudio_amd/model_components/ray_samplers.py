@@ -441,3 +441,89 @@ class ProposalNetworkSampler(Sampler):
         if updated:
             self._steps_since_update = 0
         return ray_samples, weights_list, ray_samples_list
+
+
+class UniSurfSampler(Sampler):
+    """ray_samplers.py:947-1138: UniSurf's surface-guided sampler - the reference's ray / surface root finder ("sphere tracing" in
+    the north star's words).  Per call: num_marching_steps uniform samples (one kernel) -> sdf at them (the field's no-grad sdf
+    kernel) -> occupancy weights -> PDF importance samples (kernel) + outside samples (kernel) merged (kernel) -> first
+    outside-to-inside sign change, interpolated depth and shrunk interval per ray (sdfhip_surface_root) -> uniform samples in that
+    interval (kernel) -> merge in euclidean space (kernel).  The occupancy -> weights step is the reference's torch cumprod."""
+
+    def __init__(self, num_samples_interval: int = 64, num_samples_outside: int = 32, num_samples_importance: int = 32,
+                 num_marching_steps: int = 256, num_secant_steps: int = 8, interval_start: float = 0.25, interval_end: float = 0.0125,
+                 interval_decay: float = 0.00005, single_jitter: bool = False) -> None:
+        super().__init__()
+        self.num_samples_interval, self.num_samples_outside = num_samples_interval, num_samples_outside
+        self.num_samples_importance, self.num_marching_steps = num_samples_importance, num_marching_steps
+        self.num_secant_steps = num_secant_steps  # unused by the reference as well (secant_method raises, :1132-1138)
+        self.interval_start, self.interval_end, self.interval_decay = interval_start, interval_end, interval_decay
+        self.single_jitter = single_jitter
+        self.uniform_sampler = UniformSampler(single_jitter=single_jitter)
+        self.outside_sampler = UniformSampler(single_jitter=single_jitter)
+        self.pdf_sampler = PDFSampler(include_original=False, single_jitter=single_jitter, histogram_padding=1e-5, spacing="uniform")
+        self.error_bounded_sampler = ErrorBoundedSampler()  # for its merge
+        self._step = 0
+        self.delta = self.interval_start
+        self.jitter_overrides: Optional[List[torch.Tensor]] = None  # tests: the four draws in call order
+
+    def step_cb(self, step):
+        """:987-990."""
+        import math
+
+        self._step = step
+        self.delta = max(self.interval_start * math.exp(-1 * self.interval_decay * self._step), self.interval_end)
+
+    def find_surface(self, ray_bundle: RayBundle, ray_samples: RaySamples, sdf: torch.Tensor):
+        """(mask [N] bool, z [N], new nears [N], new fars [N]) - :1037-1075."""
+        lib = _lib.load()
+        n, s = ray_samples.flat_starts.shape
+        dev = sdf.device
+        mask = torch.empty(n, dtype=torch.int32, device=dev)
+        z, nn, nf = torch.empty(n, device=dev), torch.empty(n, device=dev), torch.empty(n, device=dev)
+        kp = _lib.Keep()
+        _lib.check(lib.sdfhip_surface_root(kp(sdf.reshape(n, s)), kp(ray_samples.flat_starts), kp(ray_bundle.nears.reshape(-1)),
+                                           kp(ray_bundle.fars.reshape(-1)), n, s, float(self.delta), mask.data_ptr(), _lib.ptr(z),
+                                           _lib.ptr(nn), _lib.ptr(nf), _lib.stream()), "surface_root")
+        del kp
+        return mask.bool(), z, nn, nf
+
+    def generate_ray_samples(self, ray_bundle: Optional[RayBundle] = None, occupancy_fn: Optional[Callable] = None,
+                             sdf_fn: Optional[Callable] = None, return_surface_points: bool = False):
+        assert ray_bundle is not None and sdf_fn is not None and occupancy_fn is not None
+        draws = list(self.jitter_overrides) if self.jitter_overrides is not None else [None] * 4
+        self.uniform_sampler.jitter_override = draws[0]
+        ray_samples = self.uniform_sampler(ray_bundle, num_samples=self.num_marching_steps)
+        with torch.no_grad():
+            sdf = sdf_fn(ray_samples)
+        weights = ray_samples.get_weights_from_alphas(occupancy_fn(sdf))
+        self.pdf_sampler.jitter_override = draws[1]
+        importance = self.pdf_sampler(ray_bundle, ray_samples, weights, num_samples=self.num_samples_importance)
+        self.outside_sampler.jitter_override = draws[2]
+        outside = self.outside_sampler(ray_bundle, num_samples=self.num_samples_outside)
+        m_bins, _, m_starts, m_ends = self.error_bounded_sampler.merge(ray_bundle, importance.flat_bins, outside.flat_bins)
+        mask, z, new_nears, new_fars = self.find_surface(ray_bundle, ray_samples, sdf[..., 0])
+        surface_points = ray_bundle.origins[mask] + ray_bundle.directions[mask] * z[mask][:, None]
+        if surface_points.shape[0] <= 0:
+            surface_points = torch.rand((1024, 3), device=sdf.device) - 0.5  # :1065-1066
+        nears, fars = ray_bundle.nears, ray_bundle.fars
+        ray_bundle.nears, ray_bundle.fars = new_nears[:, None], new_fars[:, None]
+        self.uniform_sampler.jitter_override = draws[3]
+        interval = self.uniform_sampler(ray_bundle, num_samples=self.num_samples_interval)
+        ray_bundle.nears, ray_bundle.fars = nears, fars
+        out = self.merge_ray_samples_in_eculidean(ray_bundle, interval, (m_starts, m_ends))
+        return (out, surface_points) if return_surface_points else out
+
+    def merge_ray_samples_in_eculidean(self, ray_bundle: RayBundle, ray_samples_1: RaySamples, ray_samples_2):
+        """:1095-1130: sorted union of the euclidean starts, closed by the larger of the two last ends; the merged bins ARE
+        euclidean (the reference's TODO: spacing bins = euclidean bins).  Runs on the merge kernel with the identity
+        spacing -> euclidean map (near 0, far 1)."""
+        s2, e2 = ray_samples_2 if isinstance(ray_samples_2, tuple) else (ray_samples_2.flat_starts, ray_samples_2.flat_ends)
+        b1 = torch.cat([ray_samples_1.flat_starts, ray_samples_1.flat_ends[:, -1:]], -1)
+        b2 = torch.cat([s2, e2[:, -1:]], -1)
+        unit = RayBundle(origins=ray_bundle.origins, directions=ray_bundle.directions, nears=torch.zeros_like(ray_bundle.nears),
+                         fars=torch.ones_like(ray_bundle.fars))
+        bins, _, starts, ends = self.error_bounded_sampler.merge(unit, b1, b2)
+        return ray_bundle.get_ray_samples(
+            bin_starts=starts[..., None], bin_ends=ends[..., None], spacing_starts=bins[:, :-1, None], spacing_ends=bins[:, 1:, None],
+            spacing_to_euclidean_fn=ray_samples_1.spacing_to_euclidean_fn, flat_bins=bins)

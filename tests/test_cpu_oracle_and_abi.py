@@ -576,3 +576,52 @@ def test_pdf_sampler_oracle_against_reference(single_jitter, include_original):
     assert torch.allclose(got_bins, bins, rtol=0, atol=1e-7)
     assert torch.allclose(rs.frustums.starts[..., 0], eu[:, :-1], rtol=1e-6, atol=1e-6)
     assert torch.allclose(rs.frustums.ends[..., 0], eu[:, 1:], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/nerfstudio"), reason="the reference tree only exists in the build container")
+@pytest.mark.parametrize("training", [True, False])
+def test_unisurf_sampler_oracle_against_reference(training):
+    """oracle.unisurf_sampler pinned on the reference's UniSurfSampler (ray_samplers.py:947-1138) with an analytic sdf (two nested
+    spheres: rays with one, two and no sign changes), per-edge jitter replayed in call order."""
+    from oracle import ref_harness
+
+    ns = ref_harness.import_reference()
+    torch.manual_seed(2)
+    n, M, K, Oo, I = 23, 40, 9, 7, 12
+    o, d, _ = O.synthetic_rays(n, seed=4)
+    d = torch.nn.functional.normalize(d + 0.25 * torch.randn(n, 3), dim=-1)  # some rays miss the object
+    nears, fars = torch.full((n, 1), 0.5), torch.full((n, 1), 4.5)
+
+    def sdf_points(x):
+        r = x.norm(dim=-1)
+        return torch.maximum(r - 0.6, 0.35 - r) if False else (r - 0.6)
+
+    rb = ns.rays.RayBundle(origins=o, directions=d, pixel_area=torch.ones(n, 1), nears=nears.clone(), fars=fars.clone())
+    smp = ns.rs.UniSurfSampler(num_samples_interval=I, num_samples_outside=Oo, num_samples_importance=K, num_marching_steps=M).train(training)
+    smp.step_cb(3000)
+    draws = [torch.rand(n, M + 1), torch.rand(n, K + 1), torch.rand(n, Oo + 1), torch.rand(n, I + 1)]
+    queue = [t.clone() for t in draws]
+    real_rand = torch.rand
+
+    def fake(*size, **kw):
+        shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else size
+        if len(shape) == 2 and shape[0] == n and queue:
+            t = queue.pop(0)
+            assert tuple(t.shape) == tuple(shape), (t.shape, shape)
+            return t.clone()
+        return real_rand(*size, **kw)
+
+    torch.rand = fake
+    try:
+        rs, sp = smp(rb, occupancy_fn=lambda s: torch.sigmoid(-10.0 * s), sdf_fn=lambda r: sdf_points(r.frustums.get_start_positions())[..., None],
+                     return_surface_points=True)
+    finally:
+        torch.rand = real_rand
+    out = O.unisurf_sampler(nears[:, 0], fars[:, 0], lambda st: sdf_points(o[:, None, :] + d[:, None, :] * st[..., None]),
+                            lambda s: torch.sigmoid(-10.0 * s), smp.delta, draws if training else None, I, Oo, K, M)
+    got = torch.cat([rs.frustums.starts[..., 0], rs.frustums.ends[:, -1:, 0]], -1)
+    assert got.shape == out["bins"].shape == (n, I + K + Oo + 1)
+    assert torch.allclose(got, out["bins"], rtol=1e-6, atol=2e-6), (got - out["bins"]).abs().max()
+    assert 0 < int(out["mask"].sum()) < n
+    ref_sp = o[out["mask"]] + d[out["mask"]] * out["z"][out["mask"]][:, None]
+    assert torch.allclose(sp, ref_sp, rtol=1e-5, atol=1e-6)

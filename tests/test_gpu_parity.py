@@ -740,6 +740,27 @@ def test_field_small_get_sdf_and_geonetwork(device):
     assert_close("get_density feature", feat.reshape(n * s, -1), h[:, 1:], rtol=1e-4, atol=1e-5)
 
 
+def test_geonetwork_positions_outside_the_grid_cube(device):
+    """get_sdf / forward_geonetwork take UNcontracted positions (sdf_field.py:380-418) and the samplers feed them points outside
+    the [-2, 2]^3 cube the hash grid covers; tiny-cuda-nn reduces the dense levels' index modulo the level size (grid.h
+    grid_index), so such points read wrapped cells instead of faulting.  Same wrap in the kernels, value for value."""
+    g = load_golden("train")
+    cfg = small_oracle_cfg()
+    model = product_model_from_params(g["param"], cfg, device).eval()
+    gen = torch.Generator().manual_seed(5)
+    pos = (torch.rand(777, 3, generator=gen) * 2 - 1) * 7.0
+    pos[:5] = torch.tensor([[2.0, 2.0, 2.0], [-2.0, -2.0, -2.0], [2.0001, 0.0, 0.0], [-6.9, 6.9, -6.9], [0.0, 0.0, 0.0]])
+    with torch.no_grad():
+        h = O.geo_network(pos, g["param"], cfg.field)
+    out = model.field.forward_geonetwork(pos.to(device))
+    assert_close("forward_geonetwork sdf outside the cube", out[:, 0], h[:, 0], rtol=1e-5, atol=2e-5)
+    assert_close("forward_geonetwork feat outside the cube", out[:, 1:], h[:, 1:], rtol=1e-4, atol=2e-5)
+    model.train()
+    gr = model.field.gradient(pos.to(device), skip_spatial_distortion=True)
+    _, _, ref = O.sdf_and_gradient(pos, g["param"], cfg.field, create_graph=False)
+    assert_close("analytic gradient outside the cube", gr, ref, rtol=1e-4, atol=5e-5)
+
+
 def test_forward_geonetwork_is_differentiable(device):
     """SDFField.forward_geonetwork under autograd (sdf_field.py:380-410; first-order backward kernel, no tangent pass) against the
     oracle's geo_network: outputs and the gradients of every geometry-network weight and of the hash table; the colour network
@@ -1542,3 +1563,81 @@ def test_config1_full_shape_volsdf_against_oracle(device):
         assert_close(f"grad {k}", got[k], rg.grad, rtol=2e-2, atol=1e-9)
         checked += 1
     assert checked >= 40
+
+
+# ------------------------------------------------------------------------------------------------ UniSurf (surface root finder)
+@pytest.mark.parametrize("training", [True, False])
+def test_unisurf_sampler_against_oracle(device, training):
+    """UniSurfSampler (ray_samplers.py:947-1138: marching samples -> sdf -> importance + outside samples -> first outside-to-inside
+    sign change, interpolated depth, shrunk interval -> interval samples -> euclidean merge) on the small golden field against the
+    oracle (pinned on the reference's sampler by test_unisurf_sampler_oracle_against_reference)."""
+    from sdfstudio_amd.model_components.ray_samplers import UniSurfSampler
+
+    g = load_golden("train")
+    cfg = small_oracle_cfg()
+    model = product_model_from_params(g["param"], cfg, device).train(training)
+    n, M, K, Oo, I = 57, 64, 12, 9, 20
+    o, d, cam = O.synthetic_rays(n, seed=13)
+    d = F.normalize(d + 0.15 * torch.randn(n, 3), dim=-1)
+    smp = UniSurfSampler(num_samples_interval=I, num_samples_outside=Oo, num_samples_importance=K, num_marching_steps=M).train(training)
+    smp.step_cb(4000)
+    draws = [torch.rand(n, M + 1), torch.rand(n, K + 1), torch.rand(n, Oo + 1), torch.rand(n, I + 1)]
+    smp.jitter_overrides = [t.to(device) for t in draws]
+    rb = _bundle(o, d, cam, cfg.near, cfg.far, device)
+    rs, sp = smp(rb, occupancy_fn=model.field.get_occupancy, sdf_fn=model.field.get_sdf, return_surface_points=True)
+    nears, fars = torch.full((n,), cfg.near), torch.full((n,), cfg.far)
+    ref = O.unisurf_sampler(nears, fars, lambda st: O.geo_network((o[:, None, :] + d[:, None, :] * st[..., None]).reshape(-1, 3), g["param"],
+                                                                 cfg.field)[:, 0].view(st.shape),
+                            lambda s: torch.sigmoid(-10.0 * s), smp.delta, draws if training else None, I, Oo, K, M)
+    assert 0 < int(ref["mask"].sum()) < n, "the case must contain rays with and without a surface crossing"
+    assert rs.flat_bins.shape == ref["bins"].shape
+    # importance samples come out of an inverse CDF (5e-6 conditioning, see test_pdf_sampler); everything else is exact arithmetic
+    assert_close("merged euclidean bins", rs.flat_bins, ref["bins"], rtol=0, atol=5e-5)
+    ref_sp = o[ref["mask"]] + d[ref["mask"]] * ref["z"][ref["mask"]][:, None]
+    assert_close("surface points", sp, ref_sp, rtol=0, atol=2e-5)
+    assert torch.equal(rs.flat_starts[:, 1:], rs.flat_ends[:, :-1])
+
+
+def test_analytic_gradient_on_points_and_unisurf_step(device):
+    """SDFField.gradient(x) in analytic mode (sdf_field.py:455-467) against the oracle's autograd normal - with and without the
+    scene contraction - and one UniSurf training step (unisurf.py:92-134: occupancy compositing, normal smoothness loss at the
+    surface points) for finite losses and parameter gradients."""
+    from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
+    from sdfstudio_amd.models.neus_facto import SceneBox
+    from sdfstudio_amd.models.unisurf import UniSurfModel, UniSurfModelConfig
+    from helpers import load_params
+
+    g = load_golden("train")
+    cfg = small_oracle_cfg()
+    fc = cfg.field
+    fcfg = SDFFieldConfig(num_layers=fc.num_layers, hidden_dim=fc.hidden_dim, geo_feat_dim=fc.geo_feat_dim, num_layers_color=fc.num_layers_color,
+                          hidden_dim_color=fc.hidden_dim_color, bias=fc.bias, inside_outside=fc.inside_outside, use_grid_feature=True,
+                          beta_init=fc.beta_init, num_levels=fc.num_levels, max_res=fc.max_res, base_res=fc.base_res,
+                          log2_hashmap_size=fc.log2_hashmap_size, hash_features_per_level=fc.hash_features_per_level,
+                          hash_smoothstep=fc.hash_smoothstep)
+    box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=cfg.near, far=cfg.far)
+    model = UniSurfModel(UniSurfModelConfig(sdf_field=fcfg, num_samples_interval=16, num_samples_importance=8, num_marching_steps=48,
+                                            num_samples_outside=8), box, 49)
+    load_params(model, {k: v for k, v in g["param"].items() if not k.startswith("proposal_networks")})
+    model = model.to(device).train()
+    x = (torch.rand(301, 3) * 2 - 1) * 1.6  # some points outside the unit cube: the contraction matters
+    for skip in (False, True):
+        got = model.field.gradient(x.to(device), skip_spatial_distortion=skip)
+        xin = x if skip else O.contract_inf(x)
+        _, _, ref = O.sdf_and_gradient(xin, g["param"], fc, create_graph=False)
+        assert_close(f"gradient(x), skip_spatial_distortion={skip}", got, ref, rtol=1e-4, atol=2e-5)
+    n = 64
+    o, d, cam = O.synthetic_rays(n, seed=2)
+    out = model(_bundle(o, d, cam, cfg.near, cfg.far, device))
+    w = out["weights"][..., 0]
+    assert (w >= 0).all() and (w.sum(1) <= 1 + 1e-4).all() and out["ray_samples"].flat_starts.shape == (n, 32)
+    losses = model.get_loss_dict(out, {"image": torch.rand(n, 3)})
+    assert {"rgb_loss", "eikonal_loss", "normal_smoothness_loss"} <= set(losses)
+    assert all(torch.isfinite(v) for v in losses.values()) and float(losses["normal_smoothness_loss"]) > 0
+    model.zero_grad()
+    sum(losses.values()).backward()
+    for k in ("field.glin0.weight_v", "field.glin8.weight_v", "field.clin0.weight_v", "field.encoding.params"):
+        gr = dict(model.named_parameters())[k].grad
+        assert gr is not None and torch.isfinite(gr).all() and gr.abs().max() > 0, k
+    model.after_train_iteration(100)
+    assert model.sampler.delta < 0.25

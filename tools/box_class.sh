@@ -9,6 +9,9 @@ mkdir -p $(dirname $OUT)
   echo "== $(date -u +%FT%TZ) $(hostname)"
   /opt/rocm/bin/rocm-smi --showpower --showclocks --showperflevel --showmaxpower 2>/dev/null | grep -v "^=\|^$" | head -20
   tools/_bin/probe_split
+  [ -x tools/_bin/probe_split_looped ] && tools/_bin/probe_split_looped
+  [ -x tools/_bin/probe_icache ] && tools/_bin/probe_icache
+  /opt/rocm/bin/rocm-smi --showuniqueid --showvbios --showfwinfo --showdriverversion 2>/dev/null | grep -i "unique\|vbios\|SMC\|MEC \|RLC \|SOS\|driver" | head -10
   /opt/rocm/bin/rocm-smi --showpower --showclocks 2>/dev/null | grep -i "power\|sclk\|mclk" | head -6
 } > $OUT 2>&1
 CYC=$(grep "3-term" $OUT | head -1 | sed 's/.* \([0-9]*\) cyc.*/\1/')

@@ -239,6 +239,9 @@ int main() {
 #ifdef PROBE_RELU
   run<2, 0, 2>("3-term relu (no transcendentals)", P, d_in, d_out, d_clk, W, X);
   run<3, 0, 2>("6-term relu (no transcendentals)", P, d_in, d_out, d_clk, W, X);
+#elif defined(PROBE_LOOPED)
+  run<2, 1, 2, true>("3-term softplus, layers looped", P, d_in, d_out, d_clk, W, X);
+  run<3, 1, 2, true>("6-term softplus, layers looped", P, d_in, d_out, d_clk, W, X);
 #else
   run<2, 1, 2>("3-term softplus", P, d_in, d_out, d_clk, W, X);
   run<3, 1, 2>("6-term softplus", P, d_in, d_out, d_clk, W, X);
