@@ -43,7 +43,7 @@ def geo_bwd_io_bytes(nb0=3, nbf=8):
     return 128 * (nb0 + nbf + nb0) + 4
 
 
-def geo_bwd_algorithmic_bytes(nbh=8, nb0=3, nb3=6, nl=8, skip=4, nbf=8):
+def geo_bwd_algorithmic_bytes(nbh=8, nb0=3, nb3=8, nl=8, skip=4, nbf=8):
     """HBM bytes per ray-sample that geo_bwd_kernel's DATA FLOW moves: every tensor is tile-packed in
     blocks of 32 features x 4 B = 128 B per point.  Tangent pass: reads the seed, z_l and r_l; writes the tangent qb_l
     entering every layer and zc_l.  Data backward: reads featbar, z_l and zc_l; writes zbar_l and d L / d in0.  These saved

@@ -185,6 +185,7 @@ struct SdfHipField {
   std::vector<LinearInfo> lin;   // geometry layers then colour layers
   int64_t theta_size, table_floats, packed_size;
   int64_t g_wp[kMaxLayers], g_wpT[kMaxLayers], g_bias[kMaxLayers], g_wsdf, g_bsdf;
+  int64_t g_wpT_in0 = 0;  // W_skip^T restricted to the in0 columns (g_wpT[skip] holds the hidden columns only)
   int64_t c_wp[kMaxLayers], c_wpT[kMaxLayers], c_bias[kMaxLayers], c_wout, c_bout;
   int g_rowmap[kMaxLayers], g_colmap[kMaxLayers], c_rowmap[kMaxLayers], c_colmap[kMaxLayers];
   float g_scale[kMaxLayers];
@@ -234,7 +235,9 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
   if (H % 32 || GF % 32 || HC % 32) return fail("dims must be multiples of 32");
   if (skip >= 0 && (skip < 1 || skip >= NL || H - D0 <= 0)) return fail("bad skip layer");
   if (NL + 1 > kMaxLayers || NLC + 1 > kMaxLayers) return fail("too many layers");
-  const int nb0 = (D0 + 31) / 32, nb3 = skip >= 0 ? (H - D0 + 31) / 32 : 0, nbs = (33 + E + 31) / 32;
+  // nb3: width (blocks) of the layer below the skip concatenation.  Its H - D0 real rows are padded to the FULL hidden width,
+  // so that every hidden layer has the same shape and the fused kernels can loop over them (geo_kernels.h)
+  const int nb0 = (D0 + 31) / 32, nb3 = skip >= 0 ? H / 32 : 0, nbs = (33 + E + 31) / 32;
   const FieldKernels* cands[] = {sdfhip_kernels_A(), sdfhip_kernels_B(), sdfhip_kernels_C(), sdfhip_kernels_D()};
   f->k = nullptr;
   for (const FieldKernels* k : cands) {
@@ -337,7 +340,14 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
     f->g_colmap[l] = add_map(maps, colmap);
     f->g_scale[l] = scale;
     f->g_wp[l] = add_pack(li.w_off, li.in_dim, kb, nbo, f->g_rowmap[l], f->g_colmap[l], 0, scale);
-    f->g_wpT[l] = add_pack(li.w_off, li.in_dim, nbo, kb, f->g_rowmap[l], f->g_colmap[l], 1, scale);
+    if (l == skip) {
+      // W_skip^T as two matrices: the columns over h (the regular hidden -> hidden shape) and the columns over in0
+      const std::vector<int32_t> ch(colmap.begin(), colmap.begin() + k->nb3 * 32), c0(colmap.begin() + k->nb3 * 32, colmap.end());
+      f->g_wpT[l] = add_pack(li.w_off, li.in_dim, nbo, k->nb3, f->g_rowmap[l], add_map(maps, ch), 1, scale);
+      f->g_wpT_in0 = add_pack(li.w_off, li.in_dim, nbo, k->nb0, f->g_rowmap[l], add_map(maps, c0), 1, scale);
+    } else {
+      f->g_wpT[l] = add_pack(li.w_off, li.in_dim, nbo, kb, f->g_rowmap[l], f->g_colmap[l], 1, scale);
+    }
     f->g_bias[l] = add_vec(li.b_off, nbo * 32, f->g_rowmap[l], 1);
   }
   {
@@ -495,9 +505,10 @@ static void fill_geo_ptrs(const SdfHipField* f, const float* packed, GeoPtrs* p,
   memset(p, 0, sizeof(*p));
   for (int l = 0; l <= f->k->nl; ++l) {
     p->wp[l] = packed + f->g_wp[l] + chunk_part_offset(f->nbo_geo(l), ns);
-    p->wpT[l] = packed + f->g_wpT[l] + chunk_part_offset(f->kb_geo(l), ns);
+    p->wpT[l] = packed + f->g_wpT[l] + chunk_part_offset(l == f->k->skip ? f->k->nb3 : f->kb_geo(l), ns);
     p->bias[l] = packed + f->g_bias[l];
   }
+  if (f->k->skip >= 0) p->wpT_in0 = packed + f->g_wpT_in0 + chunk_part_offset(f->k->nb0, ns);
   p->w_sdf = packed + f->g_wsdf;
   p->b_sdf = packed + f->g_bsdf;
 }
@@ -1094,6 +1105,7 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
     gb.r_tp[l] = w.r[l];
     gb.zb_tp[l] = w.zb[l];
   }
+  gb.qb_tp[0] = w.ebar;  // the tangent entering layer 0 IS the seed: the in0 gemm of the tangent pass rewrites it with itself
   for (int l = 1; l <= k->nl; ++l) gb.qb_tp[l] = w.qb[l];
   gb.in0bar_tp = w.in0bar;
   { ProfScope ps_(PS_GEO_BWD, s); k->geo_bwd(gb, grid, s); }

@@ -14,6 +14,19 @@
 // Every line above is one tp_gemm (mlp_core.h) whose input blocks are produced just in time from the previous gemm's
 // accumulators; the elementwise work (softplus, its derivatives, loads / stores of the saved tensors) rides in the
 // producer, interleaved with the MFMAs of the previous block.
+//
+// Code size and the layer loops.  Unrolled over the layers these kernels were 330 - 380 KB of straight-line code against
+// a 64 KB instruction cache shared by two CUs: every workgroup streamed the whole kernel through it.  Most MI355X boxes hide
+// that behind the sequential instruction prefetch; on some the fetch rate of code that misses the cache drops from 1.2 to
+// 2.9 cycles per instruction (tools/probe_icache.hip) and exactly the kernels larger than the cache ran 2.4x slower
+// (DESIGN.md section 5).  Each pass below is therefore a RUN-TIME loop over the layers around ONE instance of the
+// hidden -> hidden gemm (~20 KB) and one of the small in0 gemm:
+//   * every hidden layer is NBH blocks wide - the layer below the skip concatenation is padded from H - D0 to H rows
+//     (zero weights, NB3 == NBH), so that layer and the skip layer have the regular shape;
+//   * the skip layer's input cat([h, in0]) is two gemms into the same accumulators: the regular one over h and the in0 gemm
+//     that also serves layer 0 (forward / tangent: in0 -> hidden; chain / backward: hidden -> in0);
+//   * accumulator roles are fixed (accIn: the previous layer's result, accOut: this layer's), with a register copy per layer
+//     in place of the compile-time ping-pong; pointers, biases and weight chunks are indexed by the run-time layer.
 #pragma once
 #include "mlp_core.h"
 
@@ -34,21 +47,27 @@ constexpr int kNsMax = ns_parts(kNsFwd) > ns_parts(kNsGrad) ? kNsFwd : kNsGrad; 
 template <int NBH_, int NB0_, int NB3_, int NL_, int SKIP_, int NBF_>
 struct GeoDims {
   static constexpr int NBH = NBH_, NB0 = NB0_, NB3 = NB3_, NL = NL_, SKIP = SKIP_, NBF = NBF_;
-  // input blocks of layer l (l in [0, NL]; l == NL is the output layer)
-  static constexpr int kb(int l) { return l == 0 ? NB0 : (l == SKIP ? NB3 + NB0 : NBH); }
-  // output blocks of layer l
-  static constexpr int nbo(int l) { return l == NL ? NBF : ((l + 1 == SKIP) ? NB3 : NBH); }
+  static_assert(SKIP < 0 || NB3 == NBH, "the layer below the skip concatenation is padded to the full hidden width");
+  static_assert(SKIP < 0 || (SKIP >= 1 && SKIP < NL), "skip layer out of range");
+  // input blocks of layer l (l in [0, NL]; l == NL is the output layer): layout of qb_tp[l]
+  static constexpr int kb(int l) { return l == 0 ? NB0 : (l == SKIP ? NBH + NB0 : NBH); }
+  // output blocks of layer l: layout of z_tp[l], r_tp[l], zb_tp[l]
+  static constexpr int nbo(int l) { return l == NL ? NBF : NBH; }
   static constexpr int cmax(int a, int b) { return a > b ? a : b; }
-  static constexpr int MAXB = cmax(cmax(NBH, NBF), cmax(NB0, SKIP >= 0 ? NB3 + NB0 : 0));
-  static constexpr int buf_floats(int ns) { return chunk_pieces(MAXB, ns) * 256; }  // one weight chunk buffer
-  static constexpr int CW = cmax(NBH, NBF) * 32;                         // stride of the constant-vector area
+  static constexpr int MAXO = cmax(NBH, NBF);                            // widest chunk (out-blocks) any gemm streams
+  static constexpr int buf_floats(int ns) { return chunk_pieces(MAXO, ns) * 256; }  // one weight chunk buffer
+  static constexpr int CW = MAXO * 32;                                   // stride of the constant-vector area
   static constexpr int CVEC_FLOATS = (NL + 2) * CW;                      // biases of layers 0..NL, then w_sdf
   static constexpr int lds_floats(int ns) { return 2 * buf_floats(ns) + CVEC_FLOATS; }
+  // every gemm prefetches the first chunk of whatever follows it (a run-time choice) at this size; a smaller chunk is
+  // over-read into the one behind it (the packed buffer ends in slack)
+  static constexpr int pieces(int ns) { return chunk_pieces(MAXO, ns); }
 };
 
 struct GeoPtrs {
-  const float* wp[kMaxLayers];    // packed W_l      [kb][3][nbo][2][64] x 8 bf16
-  const float* wpT[kMaxLayers];   // packed W_l^T    [nbo][3][kb][2][64] x 8 bf16
+  const float* wp[kMaxLayers];    // packed W_l      [kb][parts][nbo][2][64] x 8 ; the skip layer: NBH chunks over h, then NB0 over in0
+  const float* wpT[kMaxLayers];   // packed W_l^T    [nbo][parts][kb][2][64] x 8 ; the skip layer: the NBH columns over h only
+  const float* wpT_in0;           // packed W_SKIP^T restricted to the in0 columns: [NBH][parts][NB0][2][64] x 8
   const float* bias[kMaxLayers];  // natural order, padded to nbo*32
   const float* w_sdf;             // [NBH*32]  row of the output layer that produces sdf
   const float* b_sdf;             // [1]
@@ -74,77 +93,88 @@ SDFHIP_D void geo_stage_cvec(float* cvec, const GeoPtrs& p, const int tid) {
   if (tid < D::NBH * 32) cvec[(D::NL + 1) * D::CW + tid] = p.w_sdf[tid];
 }
 
+template <int N>
+SDFHIP_D void acc_copy(f32x16 (&dst)[N], const f32x16 (&src)[N]) {
+#pragma unroll
+  for (int b = 0; b < N; ++b) dst[b] = src[b];
+}
+template <int N, int M>
+SDFHIP_D void acc_copy_n(f32x16 (&dst)[N], const f32x16 (&src)[M]) {
+  static_assert(N <= M, "");
+#pragma unroll
+  for (int b = 0; b < N; ++b) dst[b] = src[b];
+}
+// first chunk of the in0 part of the skip layer's packed weights (NBH chunks of NBH out-blocks come first)
+template <class D>
+SDFHIP_D const float* geo_skip_in0(const float* wp_skip) {
+  return wp_skip + (size_t)D::NBH * D::NBH * kChunkBlockFloats;
+}
+
 template <class D, bool GRAD, bool SAVE, bool FEAT>
 __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, hf = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-  constexpr int MAXB = D::MAXB, W = D::CW;
-  constexpr int NSF = kNsFwd, NSC = kNsFwd, NSB = kNsFwd;
-  float* cvec = lds + 2 * D::buf_floats(NSB);
+  constexpr int W = D::CW, NS = kNsFwd, PCS = D::pieces(NS);
+  float* cvec = lds + 2 * D::buf_floats(NS);
 
-  WStream ws{lds, D::buf_floats(NSB), 0, wave, lane};
-  ws.issue(a.p.wp[0], chunk_pieces(D::nbo(0), NSF), true);
+  WStream ws{lds, D::buf_floats(NS), 0, wave, lane};
+  ws.issue(a.p.wp[0], chunk_pieces(D::NBH, NS), true);
   geo_stage_cvec<D>(cvec, a.p, tid);
   __syncthreads();
 
-  f32x16 accA[MAXB], accB[MAXB];
+  f32x16 accIn[D::NBH], accOut[D::MAXO];
   Raw carry;
-
-  // HBM operands of input block kb of forward layer l (only in0 blocks come from memory)
-  auto fwd_fetch = [&](auto lc, auto kbc) __attribute__((always_inline)) {
-    constexpr int l = decltype(lc)::value, kb = decltype(kbc)::value;
-    if constexpr (l == 0) return BlkSrc<1>{{tp_block_ptr(a.in0_tp, tile, D::NB0, kb)}};
-    else if constexpr (l == D::SKIP && kb >= D::NB3) return BlkSrc<1>{{tp_block_ptr(a.in0_tp, tile, D::NB0, kb - D::NB3)}};
-    else return BlkSrc<0>{};
-  };
-  // HBM operands of block b of the chain step through layer l
-  auto chain_fetch = [&](auto lc, auto bc) __attribute__((always_inline)) {
-    constexpr int l = decltype(lc)::value, b = decltype(bc)::value;
-    return BlkSrc<1>{{tp_block_ptr(a.z_tp[l], tile, D::nbo(l), b)}};
-  };
+  auto in0_blk0 = [&]() __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(a.in0_tp, tile, D::NB0, 0)}}; };
+  constexpr int ZS = (SAVE || GRAD) ? 16 : 0;  // z stores per produced block
 
   // ---- forward layers 0 .. NL-1: out_l = b_l + W_l u_l
-  carry = load_src(fwd_fetch(IC<0>{}, IC<0>{}), lane);
-  static_for<0, D::NL>([&](auto lc) __attribute__((always_inline)) {
-    constexpr int l = decltype(lc)::value;
-    constexpr int KB = D::kb(l), NBO = D::nbo(l);
-    auto& in = pick<(l % 2) == 0>(accA, accB);   // accumulators of layer l - 1 (l >= 1)
-    auto& out = pick<(l % 2) == 0>(accB, accA);
+  carry = load_src(in0_blk0(), lane);
+#pragma unroll 1
+  for (int l = 0; l < D::NL; ++l) {
+    // weights that follow the last hidden layer: the output layer's, else the first chain gemm's, else nothing (re-read own)
+    const float* after_last = FEAT ? a.p.wp[D::NL] : (GRAD ? (D::SKIP == D::NL - 1 ? a.p.wpT_in0 : a.p.wpT[D::NL - 1]) : a.p.wp[l]);
+    {
+      const float* bias = cvec + l * W;
 #pragma unroll
-    for (int b = 0; b < NBO; ++b) out[b] = tp_rowvec_blk(cvec + l * W, b, hf);
-    auto fetch = [&](auto kbc) __attribute__((always_inline)) { return fwd_fetch(lc, kbc); };
-    auto make = [&](auto kbc, const Raw& raw, auto ec) __attribute__((always_inline)) {
-      constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
-      if constexpr (l == 0 || (l == D::SKIP && kb >= D::NB3)) {
-        return raw.a[e];
-      } else {
-        const float z = in[kb][e];
-        if constexpr (SAVE || GRAD) *tp_elem(a.z_tp[l > 0 ? l - 1 : 0], tile, D::nbo(l > 0 ? l - 1 : 0), kb, e, lane) = z;
+      for (int b = 0; b < D::NBH; ++b) accOut[b] = tp_rowvec_blk(bias, b, hf);
+    }
+    if (l > 0) {
+      // hidden -> hidden: u_l = softplus(z_{l-1}) made from the accumulators of the layer below, z_{l-1} saved on the way
+      float* zprev = a.z_tp[l - 1];
+      auto make = [&](auto kbc, const Raw&, auto ec) __attribute__((always_inline)) {
+        constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
+        const float z = accIn[kb][e];
+        if constexpr (SAVE || GRAD) *tp_elem(zprev, tile, D::NBH, kb, e, lane) = z;
         return softplus100_h(z);
-      }
-    };
-    constexpr bool last = l + 1 == D::NL;
-    const float* next = last ? (FEAT ? a.p.wp[D::NL] : (GRAD ? a.p.wpT[D::NL - 1] : nullptr)) : a.p.wp[l + 1];
-    constexpr int next_pieces = last ? (FEAT ? chunk_pieces(D::NBF, NSF) : (GRAD ? chunk_pieces(D::kb(D::NL - 1), NSC) : 0)) : chunk_pieces(D::nbo(l + 1), NSF);
-    auto next_fetch = [&]() __attribute__((always_inline)) {
-      if constexpr (!last) return fwd_fetch(IC<(last ? l : l + 1)>{}, IC<0>{});
-      else return BlkSrc<0>{};
-    };
-    constexpr int ZS = (SAVE || GRAD) ? 16 : 0;  // z stores per produced block
-    using ST = Stores<(l == 0 ? 0 : ZS), (l == 0 ? 0 : (l == D::SKIP ? 0 : ZS)), (l == D::SKIP ? D::NB3 : (1 << 30))>;
-    tp_gemm<KB, NBO, ST, NSF, next_pieces>(out, carry, fetch, make, next_fetch, ws, a.p.wp[l], next);
-  });
+      };
+      const float* nxt = l == D::SKIP ? geo_skip_in0<D>(a.p.wp[l]) : (l + 1 < D::NL ? a.p.wp[l + 1] : after_last);
+      tp_gemm<D::NBH, D::NBH, Stores<ZS>, NS, PCS>(accOut, carry, NoFetch{}, make, in0_blk0, ws, a.p.wp[l], nxt);
+    }
+    if (l == 0 || l == D::SKIP) {
+      // in0 -> hidden: layer 0, and the in0 columns of the skip layer (cat([h, in0]) / sqrt(2), the factor folded into W)
+      auto fetch = [&](auto kbc) __attribute__((always_inline)) {
+        return BlkSrc<1>{{tp_block_ptr(a.in0_tp, tile, D::NB0, decltype(kbc)::value)}};
+      };
+      auto make = [&](auto, const Raw& raw, auto ec) __attribute__((always_inline)) { return raw.a[decltype(ec)::value]; };
+      const float* w = l == 0 ? a.p.wp[0] : geo_skip_in0<D>(a.p.wp[l]);
+      tp_gemm<D::NB0, D::NBH, Stores<0>, NS, PCS>(accOut, carry, fetch, make, NoFetch{}, ws, w, l + 1 < D::NL ? a.p.wp[l + 1] : after_last);
+    }
+    acc_copy_n(accIn, accOut);
+  }
+
+  // first gemm of the chain: the in0 part if the last hidden layer is the skip layer, the hidden part otherwise; its operands
+  // are block 0 of z_{NL-1} either way
+  auto chain_first_src = [&]() __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(a.z_tp[D::NL - 1], tile, D::NBH, 0)}}; };
+  const float* chain_first_w = D::SKIP == D::NL - 1 ? a.p.wpT_in0 : a.p.wpT[D::NL - 1];
 
   // ---- output layer: the sdf row as a lane-local dot product riding in the producer, feature rows on the MFMA path
   {
-    auto& in = pick<(D::NL % 2) == 0>(accA, accB);
-    auto& out = pick<(D::NL % 2) == 0>(accB, accA);
     float part = 0.0f;
     auto make = [&](auto kbc, const Raw&, auto ec) __attribute__((always_inline)) {
       constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
-      const float z = in[kb][e];
+      const float z = accIn[kb][e];
       if constexpr (SAVE || GRAD) *tp_elem(a.z_tp[D::NL - 1], tile, D::NBH, kb, e, lane) = z;
       const float h = softplus100_h(z);
       part = fmaf(cvec[(D::NL + 1) * W + kb * 32 + tp_row(e, hf)], h, part);
@@ -152,63 +182,66 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
     };
     if constexpr (FEAT) {
 #pragma unroll
-      for (int b = 0; b < D::NBF; ++b) out[b] = tp_rowvec_blk(cvec + D::NL * W, b, hf);
+      for (int b = 0; b < D::NBF; ++b) accOut[b] = tp_rowvec_blk(cvec + D::NL * W, b, hf);
       auto next_fetch = [&]() __attribute__((always_inline)) {
-        if constexpr (GRAD) return chain_fetch(IC<D::NL - 1>{}, IC<0>{});
+        if constexpr (GRAD) return chain_first_src();
         else return BlkSrc<0>{};
       };
-      tp_gemm<D::NBH, D::NBF, Stores<((SAVE || GRAD) ? 16 : 0)>, NSF, (GRAD ? chunk_pieces(D::kb(D::NL - 1), NSC) : 0)>(
-          out, carry, NoFetch{}, make, next_fetch, ws, a.p.wp[D::NL], GRAD ? a.p.wpT[D::NL - 1] : nullptr);
+      tp_gemm<D::NBH, D::NBF, Stores<ZS>, NS, (GRAD ? PCS : 0)>(accOut, carry, NoFetch{}, make, next_fetch, ws, a.p.wp[D::NL],
+                                                                GRAD ? chain_first_w : nullptr);
 #pragma unroll
-      for (int b = 0; b < D::NBF; ++b) tp_store_blk(out[b], a.feat_tp, tile, D::NBF, b, lane);
+      for (int b = 0; b < D::NBF; ++b) tp_store_blk(accOut[b], a.feat_tp, tile, D::NBF, b, lane);
     } else {
       static_for<0, D::NBH>([&](auto kbc) __attribute__((always_inline)) {
         static_for<0, 16>([&](auto ec) __attribute__((always_inline)) { (void)make(kbc, carry, ec); });
       });
-      if constexpr (GRAD) carry = load_src(chain_fetch(IC<D::NL - 1>{}, IC<0>{}), lane);
+      if constexpr (GRAD) carry = load_src(chain_first_src(), lane);
     }
     part += __shfl_xor(part, 32);
     if (hf == 0) a.sdf[tile * 32 + lane] = part + a.p.b_sdf[0];
   }
 
-  // ---- chain: q_l = W_l^T (q_{l+1} * s'(z_l)),  q_NL = w_sdf
+  // ---- chain: q_l = W_l^T (q_{l+1} * s'(z_l)),  q_NL = w_sdf.  accIn holds q_{l+1}
   if constexpr (GRAD) {
 #pragma unroll
-    for (int b = 0; b < D::NBH; ++b) accA[b] = tp_rowvec_blk(cvec + (D::NL + 1) * W, b, hf);
-    static_for<0, D::NL>([&](auto sc) __attribute__((always_inline)) {
-      constexpr int step = decltype(sc)::value;
-      constexpr int l = D::NL - 1 - step;
-      constexpr int KB = D::kb(l), NBO = D::nbo(l);
-      auto& q = pick<(step % 2) == 0>(accA, accB);
-      auto& qn = pick<(step % 2) == 0>(accB, accA);
-#pragma unroll
-      for (int b = 0; b < KB; ++b) qn[b] = f32x16_zero();
-      auto fetch = [&](auto bc) __attribute__((always_inline)) { return chain_fetch(IC<l>{}, bc); };
+    for (int b = 0; b < D::NBH; ++b) accIn[b] = tp_rowvec_blk(cvec + (D::NL + 1) * W, b, hf);
+#pragma unroll 1
+    for (int l = D::NL - 1; l >= 0; --l) {
+      const float* zl = a.z_tp[l];
+      float* rl = a.r_tp[l];
+      auto fetch = [&](auto bc) __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(zl, tile, D::NBH, decltype(bc)::value)}}; };
       auto make = [&](auto bc, const Raw& raw, auto ec) __attribute__((always_inline)) {
         constexpr int b = decltype(bc)::value, e = decltype(ec)::value;
-        const float r = q[b][e] * softplus100_d1(raw.a[e]);
-        if constexpr (SAVE) *tp_elem(a.r_tp[l], tile, NBO, b, e, lane) = r;
+        const float r = accIn[b][e] * softplus100_d1(raw.a[e]);
+        if constexpr (SAVE) *tp_elem(rl, tile, D::NBH, b, e, lane) = r;
         return r;
       };
-      auto next_fetch = [&]() __attribute__((always_inline)) {
-        if constexpr (l > 0) return chain_fetch(IC<(l > 0 ? l - 1 : 0)>{}, IC<0>{});
-        else return BlkSrc<0>{};
-      };
-      tp_gemm<NBO, KB, Stores<(SAVE ? 16 : 0)>, NSC, (l > 0 ? chunk_pieces(D::kb(l > 0 ? l - 1 : 0), NSC) : 0)>(
-          qn, carry, fetch, make, next_fetch, ws, a.p.wpT[l], l > 0 ? a.p.wpT[l > 0 ? l - 1 : 0] : nullptr);
-      if constexpr (l == D::SKIP) {
-        // the part of d sdf / d (layer input) that goes straight to in0: park it in e_tp, layer 0 adds to it
+      if (l == 0 || l == D::SKIP) {
+        // hidden -> in0: layer 0, and the part of the skip layer's input gradient that goes straight to in0 (parked in e_tp,
+        // layer 0 adds to it).  The hidden part of the skip layer follows with the same operands (z_l block 0)
+        f32x16 accE[D::NB0];
 #pragma unroll
-        for (int b = 0; b < D::NB0; ++b) tp_store_blk(qn[D::NB3 + b], a.e_tp, tile, D::NB0, b, lane);
-      }
-      if constexpr (l == 0) {
+        for (int b = 0; b < D::NB0; ++b) accE[b] = f32x16_zero();
+        auto next_fetch = [&]() __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(zl, tile, D::NBH, 0)}}; };
+        tp_gemm<D::NBH, D::NB0, Stores<(SAVE ? 16 : 0)>, NS, PCS>(accE, carry, fetch, make, next_fetch, ws, l == 0 ? a.p.wpT[0] : a.p.wpT_in0,
+                                                                  a.p.wpT[l]);
+        if (l == 0 && D::SKIP > 0) {
 #pragma unroll
-        for (int b = 0; b < D::NB0; ++b) {
-          if constexpr (D::SKIP > 0) qn[b] += tp_load_blk(a.e_tp, tile, D::NB0, b, lane);
-          tp_store_blk(qn[b], a.e_tp, tile, D::NB0, b, lane);
+          for (int b = 0; b < D::NB0; ++b) accE[b] += tp_load_blk(a.e_tp, tile, D::NB0, b, lane);
         }
+#pragma unroll
+        for (int b = 0; b < D::NB0; ++b) tp_store_blk(accE[b], a.e_tp, tile, D::NB0, b, lane);
       }
-    });
+      if (l > 0) {
+#pragma unroll
+        for (int b = 0; b < D::NBH; ++b) accOut[b] = f32x16_zero();
+        const float* zbelow = a.z_tp[l - 1];
+        auto next_fetch = [&]() __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(zbelow, tile, D::NBH, 0)}}; };
+        tp_gemm<D::NBH, D::NBH, Stores<(SAVE ? 16 : 0)>, NS, PCS>(accOut, carry, fetch, make, next_fetch, ws, a.p.wpT[l],
+                                                                  l - 1 == D::SKIP ? a.p.wpT_in0 : a.p.wpT[l - 1]);
+        acc_copy_n(accIn, accOut);
+      }
+    }
   }
 }
 
@@ -219,7 +252,7 @@ struct GeoBwdArgs {
   const float* sdfbar;      // [T*32]
   const float* z_tp[kMaxLayers];
   const float* r_tp[kMaxLayers];
-  float* qb_tp[kMaxLayers + 1];  // [T][kb(l)]  tangent entering layer l  (l == NL: the tangent reaching the sdf row)
+  float* qb_tp[kMaxLayers + 1];  // [T][kb(l)]  tangent entering layer l  (l == NL: the tangent reaching the sdf row); qb_tp[0] == ebar_tp
   float* zb_tp[kMaxLayers];      // [T][nbo(l)] holds zc_l after the tangent pass, zbar_l after the backward pass
   float* in0bar_tp;              // [T][NB0]
 };
@@ -231,93 +264,96 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, hf = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-  constexpr int MAXB = D::MAXB;
-  constexpr int NS = kNsGrad;
+  constexpr int NS = kNsGrad, PCS = D::pieces(NS);
   float* cvec = lds + 2 * D::buf_floats(NS);
+  // first gemm of the backward pass proper (after the feature gemm)
+  const float* bwd_first_w = D::SKIP == D::NL - 1 ? a.p.wpT_in0 : a.p.wpT[D::NL - 1];
 
   WStream ws{lds, D::buf_floats(NS), 0, wave, lane};
-  if constexpr (TANGENT) ws.issue(a.p.wp[0], chunk_pieces(D::nbo(0), NS), true);
+  if constexpr (TANGENT) ws.issue(a.p.wp[0], chunk_pieces(D::NBH, NS), true);
   else ws.issue(a.p.wpT[D::NL], chunk_pieces(D::NBH, NS), true);
   if (tid < D::NBH * 32) cvec[tid] = a.p.w_sdf[tid];
   __syncthreads();
 
-  f32x16 accA[MAXB], accB[MAXB];
+  f32x16 accIn[D::NBH], accOut[D::NBH];
   Raw carry;
 
-  // HBM operands of input block kb of tangent layer l: the seed blocks, or (z, r) of the layer below
-  auto tan_fetch = [&](auto lc, auto kbc) __attribute__((always_inline)) {
-    constexpr int l = decltype(lc)::value, kb = decltype(kbc)::value;
-    if constexpr (l == 0) {
-      return BlkSrc<1>{{tp_block_ptr(a.ebar_tp, tile, D::NB0, kb)}};  // qb_0 == ebar (already in HBM)
-    } else if constexpr (l == D::SKIP && kb >= D::NB3) {
-      return BlkSrc<1>{{tp_block_ptr(a.ebar_tp, tile, D::NB0, kb - D::NB3)}};
-    } else {
-      return BlkSrc<2>{{tp_block_ptr(a.z_tp[l > 0 ? l - 1 : 0], tile, D::nbo(l > 0 ? l - 1 : 0), kb),
-                        tp_block_ptr(a.r_tp[l > 0 ? l - 1 : 0], tile, D::nbo(l > 0 ? l - 1 : 0), kb)}};
-    }
-  };
-  // tangent epilogue of layer l on element e of block b:  qb_{l+1} = s'(z_l) v ;  zc_l = v r_l 100 (1 - s'(z_l))  (-> zb_tp[l])
-  auto tangent_elem = [&](auto lc, auto bc, auto ec, const float v, const Raw& raw) __attribute__((always_inline)) {
-    constexpr int l = decltype(lc)::value, b = decltype(bc)::value, e = decltype(ec)::value;
-    const float d1 = softplus100_d1(raw.a[e]);
-    *tp_elem(a.zb_tp[l], tile, D::nbo(l), b, e, lane) = v * raw.b[e] * (100.0f * (1.0f - d1));
-    return d1 * v;
-  };
-  auto bwd_fetch = [&](auto lc, auto bc) __attribute__((always_inline)) {
-    constexpr int l = decltype(lc)::value, b = decltype(bc)::value;
-    if constexpr (TANGENT) return BlkSrc<2>{{tp_block_ptr(a.z_tp[l], tile, D::nbo(l), b), tp_block_ptr(a.zb_tp[l], tile, D::nbo(l), b)}};
-    else return BlkSrc<1>{{tp_block_ptr(a.z_tp[l], tile, D::nbo(l), b)}};
-  };
-
   if constexpr (TANGENT) {
-    // ---- tangent pass (second-order terms): v_l = W_l qb_l
-    carry = load_src(tan_fetch(IC<0>{}, IC<0>{}), lane);
-    static_for<0, D::NL>([&](auto lc) __attribute__((always_inline)) {
-      constexpr int l = decltype(lc)::value;
-      constexpr int KB = D::kb(l), NBO = D::nbo(l);
-      auto& in = pick<(l % 2) == 0>(accA, accB);  // v_{l-1}
-      auto& out = pick<(l % 2) == 0>(accB, accA);
+    // ---- tangent pass (second-order terms): v_l = W_l qb_l ; accIn holds v_{l-1}
+    carry = load_src(BlkSrc<1>{{tp_block_ptr(a.ebar_tp, tile, D::NB0, 0)}}, lane);
+#pragma unroll 1
+    for (int l = 0; l < D::NL; ++l) {
 #pragma unroll
-      for (int b = 0; b < NBO; ++b) out[b] = f32x16_zero();
-      auto fetch = [&](auto kbc) __attribute__((always_inline)) { return tan_fetch(lc, kbc); };
-      auto make = [&](auto kbc, const Raw& raw, auto ec) __attribute__((always_inline)) {
-        constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
-        if constexpr (l == 0) {
-          return raw.a[e];
-        } else if constexpr (l == D::SKIP && kb >= D::NB3) {
-          *tp_elem(a.qb_tp[l], tile, KB, kb, e, lane) = raw.a[e];
-          return raw.a[e];
-        } else {
-          const float qn = tangent_elem(IC<(l > 0 ? l - 1 : 0)>{}, kbc, ec, in[kb][e], raw);
-          *tp_elem(a.qb_tp[l], tile, KB, kb, e, lane) = qn;
+      for (int b = 0; b < D::NBH; ++b) accOut[b] = f32x16_zero();
+      float* qbl = a.qb_tp[l];
+      const int qb_nb = l == 0 ? D::NB0 : (l == D::SKIP ? D::NBH + D::NB0 : D::NBH);  // blocks per tile of qb_tp[l]
+      if (l > 0) {
+        // hidden -> hidden.  The producer is the tangent epilogue of the layer below on element e of block kb:
+        //   qb_l = s'(z_{l-1}) v_{l-1} ;  zc_{l-1} = v_{l-1} r_{l-1} 100 (1 - s'(z_{l-1}))  (-> zb_tp[l-1])
+        const float* zp = a.z_tp[l - 1];
+        const float* rp = a.r_tp[l - 1];
+        float* zbp = a.zb_tp[l - 1];
+        auto fetch = [&](auto kbc) __attribute__((always_inline)) {
+          constexpr int kb = decltype(kbc)::value;
+          return BlkSrc<2>{{tp_block_ptr(zp, tile, D::NBH, kb), tp_block_ptr(rp, tile, D::NBH, kb)}};
+        };
+        auto make = [&](auto kbc, const Raw& raw, auto ec) __attribute__((always_inline)) {
+          constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
+          const float v = accIn[kb][e];
+          const float d1 = softplus100_d1(raw.a[e]);
+          *tp_elem(zbp, tile, D::NBH, kb, e, lane) = v * raw.b[e] * (100.0f * (1.0f - d1));
+          const float qn = d1 * v;
+          *tp_elem(qbl, tile, qb_nb, kb, e, lane) = qn;
           return qn;
-        }
-      };
-      constexpr bool last = l + 1 == D::NL;
-      auto next_fetch = [&]() __attribute__((always_inline)) {
-        if constexpr (!last) return tan_fetch(IC<(last ? l : l + 1)>{}, IC<0>{});
-        else return BlkSrc<0>{};
-      };
-      // stores per produced block: zc + qb (32) for blocks computed from the layer below, qb only (16) for the seed blocks of
-      // the skip layer, none for layer 0
-      using ST = Stores<(l == 0 ? 0 : 32), (l == 0 ? 0 : (l == D::SKIP ? 16 : 32)), (l == D::SKIP ? D::NB3 : (1 << 30))>;
-      tp_gemm<KB, NBO, ST, NS, chunk_pieces(last ? D::NBH : D::nbo(last ? l : l + 1), NS)>(
-          out, carry, fetch, make, next_fetch, ws, a.p.wp[l], last ? a.p.wpT[D::NL] : a.p.wp[last ? l : l + 1]);
-    });
+        };
+        // what follows: the in0 part of this layer (operands: seed block 0), or the next layer (operands: (z_l, r_l) block 0)
+        const float* na = l == D::SKIP ? a.ebar_tp : a.z_tp[l];
+        const float* nb = l == D::SKIP ? a.ebar_tp : a.r_tp[l];
+        const int nnb = l == D::SKIP ? D::NB0 : D::NBH;
+        auto next_fetch = [&]() __attribute__((always_inline)) { return BlkSrc<2>{{tp_block_ptr(na, tile, nnb, 0), tp_block_ptr(nb, tile, nnb, 0)}}; };
+        const float* nxt = l == D::SKIP ? geo_skip_in0<D>(a.p.wp[l]) : (l + 1 < D::NL ? a.p.wp[l + 1] : a.p.wpT[D::NL]);
+        tp_gemm<D::NBH, D::NBH, Stores<32>, NS, PCS>(accOut, carry, fetch, make, next_fetch, ws, a.p.wp[l], nxt);
+      }
+      if (l == 0 || l == D::SKIP) {
+        // in0 -> hidden on the tangent seed (qb_0 == ebar; the seed blocks of the skip layer's qb are copies of it)
+        const int b0 = l == 0 ? 0 : D::NBH;
+        auto fetch = [&](auto kbc) __attribute__((always_inline)) {
+          return BlkSrc<1>{{tp_block_ptr(a.ebar_tp, tile, D::NB0, decltype(kbc)::value)}};
+        };
+        auto make = [&](auto kbc, const Raw& raw, auto ec) __attribute__((always_inline)) {
+          constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
+          *tp_elem(qbl, tile, qb_nb, b0 + kb, e, lane) = raw.a[e];  // layer 0: rewrites ebar with itself (qb_tp[0] == ebar_tp)
+          return raw.a[e];
+        };
+        auto next_fetch = [&]() __attribute__((always_inline)) {
+          return BlkSrc<2>{{tp_block_ptr(a.z_tp[l], tile, D::NBH, 0), tp_block_ptr(a.r_tp[l], tile, D::NBH, 0)}};
+        };
+        const float* w = l == 0 ? a.p.wp[0] : geo_skip_in0<D>(a.p.wp[l]);
+        tp_gemm<D::NB0, D::NBH, Stores<16>, NS, PCS>(accOut, carry, fetch, make, next_fetch, ws, w,
+                                                     l + 1 < D::NL ? a.p.wp[l + 1] : a.p.wpT[D::NL]);
+      }
+      acc_copy(accIn, accOut);
+    }
     {
       // epilogue of the last hidden layer: qb_NL (tangent reaching the sdf row; only the weight gradient needs it) and zc_{NL-1}
-      auto& v = pick<(D::NL % 2) == 0>(accA, accB);
       static_for<0, D::NBH>([&](auto bc) __attribute__((always_inline)) {
         constexpr int b = decltype(bc)::value;
-        const Raw raw = load_src(tan_fetch(IC<D::NL>{}, bc), lane);
+        const Raw raw = load_src(BlkSrc<2>{{tp_block_ptr(a.z_tp[D::NL - 1], tile, D::NBH, b), tp_block_ptr(a.r_tp[D::NL - 1], tile, D::NBH, b)}}, lane);
         static_for<0, 16>([&](auto ec) __attribute__((always_inline)) {
           constexpr int e = decltype(ec)::value;
-          *tp_elem(a.qb_tp[D::NL], tile, D::NBH, b, e, lane) = tangent_elem(IC<D::NL - 1>{}, bc, ec, v[b][e], raw);
+          const float v = accIn[b][e];
+          const float d1 = softplus100_d1(raw.a[e]);
+          *tp_elem(a.zb_tp[D::NL - 1], tile, D::NBH, b, e, lane) = v * raw.b[e] * (100.0f * (1.0f - d1));
+          *tp_elem(a.qb_tp[D::NL], tile, D::NBH, b, e, lane) = d1 * v;
         });
       });
     }
-
   }
+
+  auto bwd_src = [&](const int l, const int b) __attribute__((always_inline)) {
+    if constexpr (TANGENT) return BlkSrc<2>{{tp_block_ptr(a.z_tp[l], tile, D::NBH, b), tp_block_ptr(a.zb_tp[l], tile, D::NBH, b)}};
+    else return BlkSrc<1>{{tp_block_ptr(a.z_tp[l], tile, D::NBH, b)}};
+  };
 
   // ---- backward pass: ub_NL = w_s sdfbar + W_f^T featbar
   {
@@ -326,50 +362,59 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
     for (int b = 0; b < D::NBH; ++b) {
       const f32x16 w = tp_rowvec_blk(cvec, b, hf);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) accA[b][i] = w[i] * sb;
+      for (int i = 0; i < 16; ++i) accIn[b][i] = w[i] * sb;
     }
     auto fetch = [&](auto bc) __attribute__((always_inline)) {
       constexpr int b = decltype(bc)::value;
       return BlkSrc<1>{{tp_block_ptr(a.featbar_tp, tile, D::NBF, b)}};
     };
     auto make = [&](auto, const Raw& raw, auto ec) __attribute__((always_inline)) { return raw.a[decltype(ec)::value]; };
-    auto next_fetch = [&]() __attribute__((always_inline)) { return bwd_fetch(IC<D::NL - 1>{}, IC<0>{}); };
+    auto next_fetch = [&]() __attribute__((always_inline)) { return bwd_src(D::NL - 1, 0); };
     carry = load_src(fetch(IC<0>{}), lane);
-    tp_gemm<D::NBF, D::NBH, Stores<0>, NS, chunk_pieces(D::kb(D::NL - 1), NS)>(accA, carry, fetch, make, next_fetch, ws, a.p.wpT[D::NL],
-                                                                               a.p.wpT[D::NL - 1]);
+    tp_gemm<D::NBF, D::NBH, Stores<0>, NS, PCS>(accIn, carry, fetch, make, next_fetch, ws, a.p.wpT[D::NL], bwd_first_w);
   }
-  static_for<0, D::NL>([&](auto sc) __attribute__((always_inline)) {
-    constexpr int step = decltype(sc)::value;
-    constexpr int l = D::NL - 1 - step;
-    constexpr int KB = D::kb(l), NBO = D::nbo(l);
-    auto& ub = pick<(step % 2) == 0>(accA, accB);
-    auto& un = pick<(step % 2) == 0>(accB, accA);
+  // accIn holds ub_{l+1}.  zb_l = ub * s'(z_l) + zc_l (zc from the tangent pass, in zb_tp[l]) is produced, stored for the weight
+  // gradient and multiplied by W_l^T: its in0 columns first where the layer has them (skip layer -> parked in in0bar, layer 0),
+  // then the hidden columns.  The second gemm of the skip layer finds the FINISHED zb_l in zb_tp[l] (this lane's own stores)
+#pragma unroll 1
+  for (int l = D::NL - 1; l >= 0; --l) {
+    float* zbl = a.zb_tp[l];
+    auto fetch = [&](auto bc) __attribute__((always_inline)) { return bwd_src(l, decltype(bc)::value); };
+    if (l == 0 || l == D::SKIP) {
+      auto make = [&](auto bc, const Raw& raw, auto ec) __attribute__((always_inline)) {
+        constexpr int b = decltype(bc)::value, e = decltype(ec)::value;
+        const float zb = TANGENT ? fmaf(accIn[b][e], softplus100_d1(raw.a[e]), raw.b[e]) : accIn[b][e] * softplus100_d1(raw.a[e]);
+        *tp_elem(zbl, tile, D::NBH, b, e, lane) = zb;
+        return zb;
+      };
+      f32x16 accE[D::NB0];
 #pragma unroll
-    for (int b = 0; b < KB; ++b) un[b] = f32x16_zero();
-    // zb_l = ub * s'(z_l) + zc_l
-    auto fetch = [&](auto bc) __attribute__((always_inline)) { return bwd_fetch(IC<l>{}, bc); };
-    auto make = [&](auto bc, const Raw& raw, auto ec) __attribute__((always_inline)) {
-      constexpr int b = decltype(bc)::value, e = decltype(ec)::value;
-      const float zb = TANGENT ? fmaf(ub[b][e], softplus100_d1(raw.a[e]), raw.b[e]) : ub[b][e] * softplus100_d1(raw.a[e]);
-      *tp_elem(a.zb_tp[l], tile, NBO, b, e, lane) = zb;
-      return zb;
-    };
-    auto next_fetch = [&]() __attribute__((always_inline)) {
-      if constexpr (l > 0) return bwd_fetch(IC<(l > 0 ? l - 1 : 0)>{}, IC<0>{});
-      else return BlkSrc<0>{};
-    };
-    tp_gemm<NBO, KB, Stores<16>, NS, (l > 0 ? chunk_pieces(D::kb(l > 0 ? l - 1 : 0), NS) : 0)>(
-        un, carry, fetch, make, next_fetch, ws, a.p.wpT[l], l > 0 ? a.p.wpT[l > 0 ? l - 1 : 0] : nullptr);
-    if constexpr (l == D::SKIP) {
+      for (int b = 0; b < D::NB0; ++b) accE[b] = f32x16_zero();
+      auto next_fetch = [&]() __attribute__((always_inline)) { return bwd_src(l, 0); };
+      tp_gemm<D::NBH, D::NB0, Stores<16>, NS, PCS>(accE, carry, fetch, make, next_fetch, ws, l == 0 ? a.p.wpT[0] : a.p.wpT_in0, a.p.wpT[l]);
+      if (l == 0 && D::SKIP > 0) {
 #pragma unroll
-      for (int b = 0; b < D::NB0; ++b) tp_store_blk(un[D::NB3 + b], a.in0bar_tp, tile, D::NB0, b, lane);
-    }
-    if constexpr (l == 0) {
-#pragma unroll
-      for (int b = 0; b < D::NB0; ++b) {
-        if constexpr (D::SKIP > 0) un[b] += tp_load_blk(a.in0bar_tp, tile, D::NB0, b, lane);
-        tp_store_blk(un[b], a.in0bar_tp, tile, D::NB0, b, lane);
+        for (int b = 0; b < D::NB0; ++b) accE[b] += tp_load_blk(a.in0bar_tp, tile, D::NB0, b, lane);
       }
+#pragma unroll
+      for (int b = 0; b < D::NB0; ++b) tp_store_blk(accE[b], a.in0bar_tp, tile, D::NB0, b, lane);
     }
-  });
+    if (l > 0) {
+      const bool done = l == D::SKIP;  // zb_l already finished by the in0 gemm above: take it as stored
+      auto make = [&](auto bc, const Raw& raw, auto ec) __attribute__((always_inline)) {
+        constexpr int b = decltype(bc)::value, e = decltype(ec)::value;
+        float zb;
+        if constexpr (TANGENT) zb = done ? raw.b[e] : fmaf(accIn[b][e], softplus100_d1(raw.a[e]), raw.b[e]);
+        else zb = accIn[b][e] * softplus100_d1(raw.a[e]);
+        *tp_elem(zbl, tile, D::NBH, b, e, lane) = zb;
+        return zb;
+      };
+#pragma unroll
+      for (int b = 0; b < D::NBH; ++b) accOut[b] = f32x16_zero();
+      auto next_fetch = [&]() __attribute__((always_inline)) { return bwd_src(l - 1, 0); };
+      tp_gemm<D::NBH, D::NBH, Stores<16>, NS, PCS>(accOut, carry, fetch, make, next_fetch, ws, a.p.wpT[l],
+                                                   l - 1 == D::SKIP ? a.p.wpT_in0 : a.p.wpT[l - 1]);
+      acc_copy(accIn, accOut);
+    }
+  }
 }

@@ -1569,14 +1569,17 @@ def test_config1_full_shape_volsdf_against_oracle(device):
 @pytest.mark.parametrize("training", [True, False])
 def test_unisurf_sampler_against_oracle(device, training):
     """UniSurfSampler (ray_samplers.py:947-1138: marching samples -> sdf -> importance + outside samples -> first outside-to-inside
-    sign change, interpolated depth, shrunk interval -> interval samples -> euclidean merge) on the small golden field against the
-    oracle (pinned on the reference's sampler by test_unisurf_sampler_oracle_against_reference)."""
+    sign change, interpolated depth, shrunk interval -> interval samples -> euclidean merge) on a geometric-init field (a sphere
+    of radius 0.5: about half of the perturbed rays cross it) against the oracle (pinned on the reference's sampler by
+    test_unisurf_sampler_oracle_against_reference)."""
     from sdfstudio_amd.model_components.ray_samplers import UniSurfSampler
 
-    g = load_golden("train")
     cfg = small_oracle_cfg()
-    model = product_model_from_params(g["param"], cfg, device).train(training)
+    params = O.init_field_params(cfg.field, num_images=49, seed=3)
+    g = {"param": params}
+    model = product_model_from_params(params, cfg, device).train(training)
     n, M, K, Oo, I = 57, 64, 12, 9, 20
+    torch.manual_seed(1)
     o, d, cam = O.synthetic_rays(n, seed=13)
     d = F.normalize(d + 0.15 * torch.randn(n, 3), dim=-1)
     smp = UniSurfSampler(num_samples_interval=I, num_samples_outside=Oo, num_samples_importance=K, num_marching_steps=M).train(training)
