@@ -51,10 +51,15 @@ def geo_bwd_algorithmic_bytes(nbh=8, nb0=3, nb3=8, nl=8, skip=4, nbf=8):
     GEMMs; geo_bwd_io_bytes is the (27x smaller) figure of an ideal implementation that keeps them on chip."""
     kb = lambda l: nb0 if l == 0 else (nb3 + nb0 if l == skip else nbh)
     nbo = lambda l: nbf if l == nl else (nb3 if l + 1 == skip else nbh)
-    rd = nb0 + sum(2 * nbo(l - 1) for l in range(1, nl)) + (nb0 if 0 < skip < nl else 0) + 2 * nbo(nl - 1)
-    wr = sum(kb(l) + nbo(l - 1) for l in range(1, nl)) + 2 * nbh
-    rd += nbf + sum(2 * nbo(l) for l in range(nl)) + (nb0 if skip > 0 else 0)
-    wr += sum(nbo(l) for l in range(nl)) + nb0 * (2 if skip > 0 else 1)
+    has_skip = 0 < skip < nl
+    # tangent pass: layer 0 reads the seed (and rewrites it: qb_0 == seed); layer l >= 1 reads (z, r) of the layer below and
+    # writes qb_l and zc_{l-1}; the skip layer's in0 gemm reads the seed again; the epilogue reads (z, r) and writes qb_NL, zc
+    rd = nb0 + sum(2 * nbo(l - 1) for l in range(1, nl)) + (nb0 if has_skip else 0) + 2 * nbo(nl - 1)
+    wr = nb0 + sum(kb(l) + nbo(l - 1) for l in range(1, nl)) + 2 * nbh
+    # data backward: featbar; per layer (z_l, zc_l) -> zbar_l; the skip layer makes two passes over its zbar (in0 columns, then
+    # hidden columns) and parks its part of d L / d in0, which layer 0 re-reads and completes
+    rd += nbf + sum(2 * nbo(l) for l in range(nl)) + ((nb0 + 2 * nbo(skip)) if has_skip else 0)
+    wr += sum(nbo(l) for l in range(nl)) + nb0 * (2 if has_skip else 1) + (nbo(skip) if has_skip else 0)
     return 128 * (rd + wr)
 
 

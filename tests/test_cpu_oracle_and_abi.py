@@ -302,28 +302,30 @@ def test_mono_prior_losses_against_reference():
 
 def test_bench_algorithmic_bytes_of_geo_bwd():
     """bench.py's roofline numerator: the tile-packed blocks geo_bwd_kernel reads and writes per ray-sample, enumerated
-    independently here (config 2: 8x256 geometry MLP, skip at layer 4, in0 = 3 blocks, h_3 = 6 blocks)."""
+    independently here (config 2: 8x256 geometry MLP, skip at layer 4, in0 = 3 blocks, h_3 padded to the full 8 blocks)."""
     import importlib.util
     import os
 
     spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(__file__), "..", "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    kb = [3, 8, 8, 8, 9, 8, 8, 8]    # input blocks of layers 0..7
-    nbo = [8, 8, 8, 6, 8, 8, 8, 8]   # output blocks of layers 0..7
+    kb = [3, 8, 8, 8, 11, 8, 8, 8]   # input blocks of layers 0..7 (layout of qb_l)
+    nbo = [8, 8, 8, 8, 8, 8, 8, 8]   # output blocks of layers 0..7
     blocks = 0
-    # tangent pass: layer 0 reads the seed; layer l >= 1 reads z_{l-1}, r_{l-1} (the skip layer also the seed), writes qb_l, zc_{l-1}
-    blocks += 3
+    # tangent pass: layer 0 reads the seed and rewrites it; layer l >= 1 reads z_{l-1}, r_{l-1} (the skip layer also the seed),
+    # writes qb_l, zc_{l-1}
+    blocks += 3 + 3
     for l in range(1, 8):
         blocks += 2 * nbo[l - 1] + (3 if l == 4 else 0) + kb[l] + nbo[l - 1]
     blocks += 2 * nbo[7] + 8 + nbo[7]          # epilogue: z_7, r_7 -> qb_8, zc_7
-    # data backward: featbar; per layer z_l, zc_l -> zbar_l; the skip part of d L / d in0 parked, re-read and the sum written
+    # data backward: featbar; per layer z_l, zc_l -> zbar_l (twice for the skip layer: in0 columns, hidden columns); the skip part of
+    # d L / d in0 parked, re-read and the sum written
     blocks += 8
     for l in range(8):
-        blocks += 2 * nbo[l] + nbo[l]
+        blocks += (2 * nbo[l] + nbo[l]) * (2 if l == 4 else 1)
     blocks += 3 + 3 + 3
-    assert blocks == 460
-    assert bench.geo_bwd_algorithmic_bytes() == 128 * blocks == 58880
+    assert blocks == 501
+    assert bench.geo_bwd_algorithmic_bytes() == 128 * blocks == 64128
 
 
 def test_oracle_numerical_gradients_against_reference_golden():
