@@ -15,7 +15,6 @@
 const FieldKernels* sdfhip_kernels_A();
 const FieldKernels* sdfhip_kernels_B();
 const FieldKernels* sdfhip_kernels_C();
-const FieldKernels* sdfhip_kernels_D();
 
 static thread_local char g_err[1024] = "";
 void sdfhip_set_error(const char* fmt, ...) {
@@ -197,8 +196,10 @@ struct SdfHipField {
   int max_pack_elems = 0, max_vec_n = 0;
   int64_t max_partial_elems = 0, max_partial_rows = 0;
 
-  int kb_geo(int l) const { return l == 0 ? k->nb0 : (l == k->skip ? k->nb3 + k->nb0 : k->nbh); }
-  int nbo_geo(int l) const { return l == k->nl ? k->nbf : ((l + 1 == k->skip) ? k->nb3 : k->nbh); }
+  // network depth is a run-time property of the field (the kernels loop over the layers); the table k fixes the block widths
+  int nl = 0, skip = -1, nlc = 0, nb3 = 0;  // hidden geometry layers, skip layer (-1: none), hidden colour layers, width below the skip
+  int kb_geo(int l) const { return l == 0 ? k->nb0 : (l == skip ? nb3 + k->nb0 : k->nbh); }
+  int nbo_geo(int l) const { return l == nl ? k->nbf : ((l + 1 == skip) ? nb3 : k->nbh); }
   int kb_col(int l) const { return l == 0 ? k->nbf + k->nbs : k->nbc; }
 };
 
@@ -238,15 +239,18 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
   // nb3: width (blocks) of the layer below the skip concatenation.  Its H - D0 real rows are padded to the FULL hidden width,
   // so that every hidden layer has the same shape and the fused kernels can loop over them (geo_kernels.h)
   const int nb0 = (D0 + 31) / 32, nb3 = skip >= 0 ? H / 32 : 0, nbs = (33 + E + 31) / 32;
-  const FieldKernels* cands[] = {sdfhip_kernels_A(), sdfhip_kernels_B(), sdfhip_kernels_C(), sdfhip_kernels_D()};
+  const FieldKernels* cands[] = {sdfhip_kernels_A(), sdfhip_kernels_B(), sdfhip_kernels_C()};
   f->k = nullptr;
   for (const FieldKernels* k : cands) {
-    if (k->nbh == H / 32 && k->nb0 == nb0 && k->nb3 == nb3 && k->nl == NL && k->skip == skip && k->nbf == GF / 32 && k->nbs == nbs &&
-        k->nbc == HC / 32 && k->nlc == NLC)
+    if (k->nbh == H / 32 && k->nb0 == nb0 && k->nbf == GF / 32 && k->nbs == nbs && k->nbc == HC / 32)
       f->k = k;
   }
   if (f->k == nullptr) return fail("no kernel instantiation was built for this shape");
   const FieldKernels* k = f->k;
+  f->nl = NL;
+  f->skip = skip;
+  f->nlc = NLC;
+  f->nb3 = nb3;
 
   // ---- natural theta layout
   f->n_geo = NL + 1;
@@ -330,7 +334,7 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
         // layer input = cat([h, in0]) / sqrt(2)  (sdf_field.py:403-404): h occupies nb3 blocks, in0 nb0 blocks
         colmap.assign(kb * 32, -1);
         for (int i = 0; i < H - D0; ++i) colmap[i] = i;
-        for (int j = 0; j < D0; ++j) colmap[k->nb3 * 32 + j] = (H - D0) + j;
+        for (int j = 0; j < D0; ++j) colmap[f->nb3 * 32 + j] = (H - D0) + j;
         scale = (float)(1.0 / std::sqrt(2.0));
       } else {
         colmap = ident(kb * 32, li.in_dim);
@@ -342,8 +346,8 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
     f->g_wp[l] = add_pack(li.w_off, li.in_dim, kb, nbo, f->g_rowmap[l], f->g_colmap[l], 0, scale);
     if (l == skip) {
       // W_skip^T as two matrices: the columns over h (the regular hidden -> hidden shape) and the columns over in0
-      const std::vector<int32_t> ch(colmap.begin(), colmap.begin() + k->nb3 * 32), c0(colmap.begin() + k->nb3 * 32, colmap.end());
-      f->g_wpT[l] = add_pack(li.w_off, li.in_dim, nbo, k->nb3, f->g_rowmap[l], add_map(maps, ch), 1, scale);
+      const std::vector<int32_t> ch(colmap.begin(), colmap.begin() + f->nb3 * 32), c0(colmap.begin() + f->nb3 * 32, colmap.end());
+      f->g_wpT[l] = add_pack(li.w_off, li.in_dim, nbo, f->nb3, f->g_rowmap[l], add_map(maps, ch), 1, scale);
       f->g_wpT_in0 = add_pack(li.w_off, li.in_dim, nbo, k->nb0, f->g_rowmap[l], add_map(maps, c0), 1, scale);
     } else {
       f->g_wpT[l] = add_pack(li.w_off, li.in_dim, nbo, kb, f->g_rowmap[l], f->g_colmap[l], 1, scale);
@@ -458,21 +462,21 @@ static void carve(const SdfHipField* f, int64_t n_points, int full, void* base, 
   w->feat = take(np * k->nbf * 32);
   if (full) {
     w->dydp = take(np * f->n_feat * 3);
-    for (int l = 0; l < k->nl; ++l) {
+    for (int l = 0; l < f->nl; ++l) {
       w->z[l] = take(np * f->nbo_geo(l) * 32);
       w->r[l] = take(np * f->nbo_geo(l) * 32);
     }
     w->e = take(np * k->nb0 * 32);
     w->csmall = take(np * k->nbs * 32);
-    for (int l = 0; l < k->nlc; ++l) w->h[l] = take(np * k->nbc * 32);
+    for (int l = 0; l < f->nlc; ++l) w->h[l] = take(np * k->nbc * 32);
     w->rgb = take(np * 3);
     w->gtot = take(np * 3);
     w->ebar = take(np * k->nb0 * 32);
     w->sdfbar = take(np);
-    for (int l = 1; l <= k->nl; ++l) w->qb[l] = take(np * f->kb_geo(l) * 32);
-    for (int l = 0; l < k->nl; ++l) w->zb[l] = take(np * f->nbo_geo(l) * 32);
+    for (int l = 1; l <= f->nl; ++l) w->qb[l] = take(np * f->kb_geo(l) * 32);
+    for (int l = 0; l < f->nl; ++l) w->zb[l] = take(np * f->nbo_geo(l) * 32);
     w->in0bar = take(np * k->nb0 * 32);
-    for (int l = 0; l < k->nlc; ++l) w->d[l] = take(np * k->nbc * 32);
+    for (int l = 0; l < f->nlc; ++l) w->d[l] = take(np * k->nbc * 32);
     w->dout = take(np * 32);
     w->featbar = take(np * k->nbf * 32);
     w->csmallbar = take(np * k->nbs * 32);
@@ -503,18 +507,21 @@ extern "C" int sdfhip_field_pack(const SdfHipField* f, const float* theta, float
 // ns: the precision mode of the kernel that will read the weights (mlp_core.h): the pointers address the first part it streams
 static void fill_geo_ptrs(const SdfHipField* f, const float* packed, GeoPtrs* p, const int ns) {
   memset(p, 0, sizeof(*p));
-  for (int l = 0; l <= f->k->nl; ++l) {
+  p->nl = f->nl;
+  p->skip = f->skip;
+  for (int l = 0; l <= f->nl; ++l) {
     p->wp[l] = packed + f->g_wp[l] + chunk_part_offset(f->nbo_geo(l), ns);
-    p->wpT[l] = packed + f->g_wpT[l] + chunk_part_offset(l == f->k->skip ? f->k->nb3 : f->kb_geo(l), ns);
+    p->wpT[l] = packed + f->g_wpT[l] + chunk_part_offset(l == f->skip ? f->nb3 : f->kb_geo(l), ns);
     p->bias[l] = packed + f->g_bias[l];
   }
-  if (f->k->skip >= 0) p->wpT_in0 = packed + f->g_wpT_in0 + chunk_part_offset(f->k->nb0, ns);
+  if (f->skip >= 0) p->wpT_in0 = packed + f->g_wpT_in0 + chunk_part_offset(f->k->nb0, ns);
   p->w_sdf = packed + f->g_wsdf;
   p->b_sdf = packed + f->g_bsdf;
 }
 static void fill_col_ptrs(const SdfHipField* f, const float* packed, ColPtrs* p, const int ns) {
   memset(p, 0, sizeof(*p));
-  for (int l = 0; l < f->k->nlc; ++l) {
+  p->nlc = f->nlc;
+  for (int l = 0; l < f->nlc; ++l) {
     p->wp[l] = packed + f->c_wp[l] + chunk_part_offset(f->k->nbc, ns);
     p->wpT[l] = packed + f->c_wpT[l] + chunk_part_offset(f->kb_col(l), ns);
     p->bias[l] = packed + f->c_bias[l];
@@ -574,7 +581,7 @@ extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, c
   memset(&ga, 0, sizeof(ga));
   fill_geo_ptrs(f, packed, &ga.p, kNsFwd);
   ga.in0_tp = w.in0;
-  for (int l = 0; l < k->nl; ++l) {
+  for (int l = 0; l < f->nl; ++l) {
     ga.z_tp[l] = w.z[l];
     ga.r_tp[l] = w.r[l];
   }
@@ -611,7 +618,7 @@ extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, c
     fill_col_ptrs(f, packed, &ca.p, kNsCol);
     ca.feat_tp = w.feat;
     ca.csmall_tp = w.csmall;
-    for (int l = 0; l < k->nlc; ++l) ca.h_tp[l] = w.h[l];
+    for (int l = 0; l < f->nlc; ++l) ca.h_tp[l] = w.h[l];
     ca.rgb = w.rgb;  // kept for the backward's sigmoid derivative; the caller gets a copy
     { ProfScope ps_(PS_COL_FWD, s); k->col_fwd(ca, grid, s); }
     SDFHIP_CHECK_HIP(hipMemcpyAsync(rgb, w.rgb, (size_t)NP * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -707,7 +714,7 @@ static TpOperand seg2(const float* p0, int nb0, int xf0, const float* p1, int nb
 static void run_geo_wgrads(const SdfHipField* f, const FieldWs& w, const bool tangent, const int64_t n_tiles, float* theta_bar,
                            hipStream_t s) {
   const FieldKernels* k = f->k;
-  for (int l = 0; l < k->nl; ++l) {
+  for (int l = 0; l < f->nl; ++l) {
     const LinearInfo& li = f->lin[l];
     WgradArgs a;
     memset(&a, 0, sizeof(a));
@@ -720,8 +727,8 @@ static void run_geo_wgrads(const SdfHipField* f, const FieldWs& w, const bool ta
     if (l == 0) {
       a.B[0] = seg1(w.in0, k->nb0, 0);
       a.B[1] = seg1(w.ebar, k->nb0, 0);
-    } else if (l == k->skip) {
-      a.B[0] = seg2(w.z[l - 1], k->nb3, 1, w.in0, k->nb0, 0);
+    } else if (l == f->skip) {
+      a.B[0] = seg2(w.z[l - 1], f->nb3, 1, w.in0, k->nb0, 0);
       a.B[1] = seg1(w.qb[l], a.nbb, 0);
     } else {
       a.B[0] = seg1(w.z[l - 1], a.nbb, 1);
@@ -731,7 +738,7 @@ static void run_geo_wgrads(const SdfHipField* f, const FieldWs& w, const bool ta
   }
   {
     // output layer: feature rows through the GEMM, sdf row through its own reduction
-    const LinearInfo& li = f->lin[k->nl];
+    const LinearInfo& li = f->lin[f->nl];
     WgradArgs a;
     memset(&a, 0, sizeof(a));
     a.n_pairs = 1;
@@ -739,10 +746,10 @@ static void run_geo_wgrads(const SdfHipField* f, const FieldWs& w, const bool ta
     a.nbb = k->nbh;
     a.n_tiles = n_tiles;
     a.A[0] = seg1(w.featbar, k->nbf, 0);
-    a.B[0] = seg1(w.z[k->nl - 1], k->nbh, 1);
-    run_wgrad(f, w, a, f->g_rowmap[k->nl], f->g_colmap[k->nl], li.w_off, li.in_dim, 1.0f, li.b_off, theta_bar, s);
+    a.B[0] = seg1(w.z[f->nl - 1], k->nbh, 1);
+    run_wgrad(f, w, a, f->g_rowmap[f->nl], f->g_colmap[f->nl], li.w_off, li.in_dim, 1.0f, li.b_off, theta_bar, s);
     const int tps = (int)((n_tiles + w.n_split - 1) / w.n_split);
-    { ProfScope ps_(PS_WGRAD, s); k->sdfrow(w.z[k->nl - 1], tangent ? w.qb[k->nl] : nullptr, w.sdfbar, n_tiles, tps, w.partial, (unsigned)w.n_split, s); }
+    { ProfScope ps_(PS_WGRAD, s); k->sdfrow(w.z[f->nl - 1], tangent ? w.qb[f->nl] : nullptr, w.sdfbar, n_tiles, tps, w.partial, (unsigned)w.n_split, s); }
     const int stride = k->nbh * 32 + 32;
     sdfrow_reduce_kernel<<<(stride + 255) / 256, 256, 0, s>>>(w.partial, w.n_split, stride, f->cfg.hidden_dim, theta_bar + li.w_off,
                                                               theta_bar + li.b_off);
@@ -752,7 +759,7 @@ static void run_geo_wgrads(const SdfHipField* f, const FieldWs& w, const bool ta
 // Weight gradients of the colour network (first order only).
 static void run_col_wgrads(const SdfHipField* f, const FieldWs& w, const int64_t n_tiles, float* theta_bar, hipStream_t s) {
   const FieldKernels* k = f->k;
-  for (int l = 0; l < k->nlc; ++l) {
+  for (int l = 0; l < f->nlc; ++l) {
     const LinearInfo& li = f->lin[f->n_geo + l];
     WgradArgs a;
     memset(&a, 0, sizeof(a));
@@ -765,7 +772,7 @@ static void run_col_wgrads(const SdfHipField* f, const FieldWs& w, const int64_t
     run_wgrad(f, w, a, f->c_rowmap[l], f->c_colmap[l], li.w_off, li.in_dim, 1.0f, li.b_off, theta_bar, s);
   }
   {
-    const LinearInfo& li = f->lin[f->n_geo + k->nlc];
+    const LinearInfo& li = f->lin[f->n_geo + f->nlc];
     WgradArgs a;
     memset(&a, 0, sizeof(a));
     a.n_pairs = 1;
@@ -773,8 +780,8 @@ static void run_col_wgrads(const SdfHipField* f, const FieldWs& w, const int64_t
     a.nbb = k->nbc;
     a.n_tiles = n_tiles;
     a.A[0] = seg1(w.dout, 1, 0);
-    a.B[0] = seg1(w.h[k->nlc - 1], k->nbc, 0);
-    run_wgrad(f, w, a, f->c_rowmap[k->nlc], f->c_colmap[k->nlc], li.w_off, li.in_dim, 1.0f, li.b_off, theta_bar, s);
+    a.B[0] = seg1(w.h[f->nlc - 1], k->nbc, 0);
+    run_wgrad(f, w, a, f->c_rowmap[f->nlc], f->c_colmap[f->nlc], li.w_off, li.in_dim, 1.0f, li.b_off, theta_bar, s);
   }
 }
 
@@ -795,9 +802,9 @@ static void carve_geo(const SdfHipField* f, int64_t n_points, void* base, FieldW
   w->x = take(np * 3);
   w->in0 = take(np * k->nb0 * 32);
   w->feat = take(np * k->nbf * 32);
-  for (int l = 0; l < k->nl; ++l) w->z[l] = take(np * f->nbo_geo(l) * 32);
+  for (int l = 0; l < f->nl; ++l) w->z[l] = take(np * f->nbo_geo(l) * 32);
   w->sdfbar = take(np);
-  for (int l = 0; l < k->nl; ++l) w->zb[l] = take(np * f->nbo_geo(l) * 32);
+  for (int l = 0; l < f->nl; ++l) w->zb[l] = take(np * f->nbo_geo(l) * 32);
   w->in0bar = take(np * k->nb0 * 32);
   w->featbar = take(np * k->nbf * 32);
   const int64_t n_tiles = np / 32;
@@ -857,7 +864,7 @@ extern "C" int sdfhip_geo_forward(const SdfHipField* f, const float* packed, con
   memset(&ga, 0, sizeof(ga));
   fill_geo_ptrs(f, packed, &ga.p, kNsFwd);
   ga.in0_tp = w.in0;
-  for (int l = 0; l < k->nl; ++l) ga.z_tp[l] = w.z[l];
+  for (int l = 0; l < f->nl; ++l) ga.z_tp[l] = w.z[l];
   ga.feat_tp = w.feat;
   ga.sdf = sdf;
   { ProfScope ps_(PS_GEO_FWD, s); k->geo_fwd(3, ga, (unsigned)(NP / 128), s); }
@@ -889,7 +896,7 @@ extern "C" int sdfhip_geo_backward(const SdfHipField* f, const float* packed, co
   fill_geo_ptrs(f, packed, &gb.p, kNsGrad);
   gb.featbar_tp = w.featbar;
   gb.sdfbar = w.sdfbar;
-  for (int l = 0; l < k->nl; ++l) {
+  for (int l = 0; l < f->nl; ++l) {
     gb.z_tp[l] = w.z[l];
     gb.zb_tp[l] = w.zb[l];
   }
@@ -928,9 +935,9 @@ static void carve_col(const SdfHipField* f, int64_t n_points, void* base, FieldW
   memset(w, 0, sizeof(*w));
   w->feat = take(np * k->nbf * 32);
   w->csmall = take(np * k->nbs * 32);
-  for (int l = 0; l < k->nlc; ++l) w->h[l] = take(np * k->nbc * 32);
+  for (int l = 0; l < f->nlc; ++l) w->h[l] = take(np * k->nbc * 32);
   w->rgb = take(np * 3);
-  for (int l = 0; l < k->nlc; ++l) w->d[l] = take(np * k->nbc * 32);
+  for (int l = 0; l < f->nlc; ++l) w->d[l] = take(np * k->nbc * 32);
   w->dout = take(np * 32);
   w->featbar = take(np * k->nbf * 32);
   w->csmallbar = take(np * k->nbs * 32);
@@ -982,7 +989,7 @@ extern "C" int sdfhip_color_forward(const SdfHipField* f, const float* packed, c
   fill_col_ptrs(f, packed, &ca.p, kNsCol);
   ca.feat_tp = w.feat;
   ca.csmall_tp = w.csmall;
-  for (int l = 0; l < k->nlc; ++l) ca.h_tp[l] = w.h[l];
+  for (int l = 0; l < f->nlc; ++l) ca.h_tp[l] = w.h[l];
   ca.rgb = w.rgb;
   { ProfScope ps_(PS_COL_FWD, s); k->col_fwd(ca, (unsigned)(NP / 128), s); }
   SDFHIP_CHECK_HIP(hipMemcpyAsync(rgb, w.rgb, (size_t)NP * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1019,7 +1026,7 @@ extern "C" int sdfhip_color_backward(const SdfHipField* f, const float* packed, 
   cb.rgb = w.rgb;
   cb.rgbbar = rgb_bar;
   cb.n_points = P;
-  for (int l = 0; l < k->nlc; ++l) {
+  for (int l = 0; l < f->nlc; ++l) {
     cb.h_tp[l] = w.h[l];
     cb.d_tp[l] = w.d[l];
   }
@@ -1060,7 +1067,7 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
   cb.rgb = w.rgb;
   cb.rgbbar = rgb_bar;
   cb.n_points = rgb_bar != nullptr ? P : 0;
-  for (int l = 0; l < k->nlc; ++l) {
+  for (int l = 0; l < f->nlc; ++l) {
     cb.h_tp[l] = w.h[l];
     cb.d_tp[l] = w.d[l];
   }
@@ -1100,13 +1107,13 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
   gb.ebar_tp = w.ebar;
   gb.featbar_tp = w.featbar;
   gb.sdfbar = w.sdfbar;
-  for (int l = 0; l < k->nl; ++l) {
+  for (int l = 0; l < f->nl; ++l) {
     gb.z_tp[l] = w.z[l];
     gb.r_tp[l] = w.r[l];
     gb.zb_tp[l] = w.zb[l];
   }
   gb.qb_tp[0] = w.ebar;  // the tangent entering layer 0 IS the seed: the in0 gemm of the tangent pass rewrites it with itself
-  for (int l = 1; l <= k->nl; ++l) gb.qb_tp[l] = w.qb[l];
+  for (int l = 1; l <= f->nl; ++l) gb.qb_tp[l] = w.qb[l];
   gb.in0bar_tp = w.in0bar;
   { ProfScope ps_(PS_GEO_BWD, s); k->geo_bwd(gb, grid, s); }
 

@@ -3,25 +3,27 @@
 //   small inputs = x(3), NeRF-PE(view dir, 4 freqs, include_input)(27), RAW d sdf/dx (3), appearance embedding
 //   NLC x (Linear + ReLU)  ->  Linear(3)  ->  sigmoid  ->  rgb * (1 + 2 pad) - pad
 // Hidden layers run on the MFMA core (mlp_core.h: activations produced block by block from the previous layer's
-// accumulators); the 3-row output layer is a lane-local dot product.
+// accumulators); the 3-row output layer is a lane-local dot product.  Like the geometry kernels (geo_kernels.h) the layers
+// after the first are ONE instance of the hidden -> hidden gemm in a run-time loop: the depth NLC is a run-time property.
 #pragma once
 #include "geo_kernels.h"
 
-template <int NBF_, int NBS_, int NBC_, int NLC_>
+template <int NBF_, int NBS_, int NBC_>
 struct ColDims {
-  static constexpr int NBF = NBF_, NBS = NBS_, NBC = NBC_, NLC = NLC_;
-  static constexpr int kb(int l) { return l == 0 ? NBF + NBS : NBC; }
-  static constexpr int MAXB = (NBF + NBS) > NBC ? (NBF + NBS) : NBC;
-  static constexpr int buf_floats(int ns) { return chunk_pieces(MAXB, ns) * 256; }
+  static constexpr int NBF = NBF_, NBS = NBS_, NBC = NBC_;
+  static constexpr int KB0 = NBF + NBS;  // input blocks of layer 0
+  static constexpr int MAXO = KB0 > NBC ? KB0 : NBC;  // widest chunk: the first layer's transposed weights (KB0 out-blocks)
+  static constexpr int buf_floats(int ns) { return chunk_pieces(MAXO, ns) * 256; }
   static constexpr int CW = NBC * 32;
-  static constexpr int CVEC_FLOATS = (NLC + 3) * CW;  // biases of the NLC hidden layers, then the 3 output rows
-  static constexpr int lds_floats(int ns) { return 2 * buf_floats(ns) + CVEC_FLOATS; }
+  // LDS: two chunk buffers, then the biases of the NLC hidden layers and the 3 output rows
+  static constexpr int lds_floats(int ns, int nlc) { return 2 * buf_floats(ns) + (nlc + 3) * CW; }
 };
-constexpr int kNsCol = kNsFwd;  // forward: 6-term products (a 3-term forward flips ReLU branches at |z| ~ 1e-5)
+constexpr int kNsCol = kNsFwd;  // forward: fp32-class products (a 3-term bf16 forward flips ReLU branches at |z| ~ 1e-5)
 
 struct ColPtrs {
-  const float* wp[kMaxLayers];    // packed W_l   [kb][3][NBC][2][64] x 8 bf16
-  const float* wpT[kMaxLayers];   // packed W_l^T [NBC][3][kb][2][64] x 8 bf16
+  int32_t nlc, pad_;              // hidden layers (>= 1)
+  const float* wp[kMaxLayers];    // packed W_l   [kb][parts][NBC][2][64] x 8
+  const float* wpT[kMaxLayers];   // packed W_l^T [NBC][parts][kb][2][64] x 8
   const float* bias[kMaxLayers];  // padded natural order
   const float* w_out;             // [3][NBC*32]
   const float* b_out;             // [3]
@@ -42,20 +44,18 @@ __global__ __launch_bounds__(256, 1) void col_fwd_kernel(const ColFwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, hf = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-  constexpr int MAXB = D::MAXB, W = D::CW;
-  constexpr int NS = kNsCol;
+  constexpr int W = D::CW, NS = kNsCol, PCS = chunk_pieces(D::NBC, NS);
+  const int NLC = a.p.nlc;
   float* cvec = lds + 2 * D::buf_floats(NS);
 
   WStream ws{lds, D::buf_floats(NS), 0, wave, lane};
-  ws.issue(a.p.wp[0], chunk_pieces(D::NBC, NS), true);
-  static_for<0, D::NLC>([&](auto lc) __attribute__((always_inline)) {
-    constexpr int l = decltype(lc)::value;
+  ws.issue(a.p.wp[0], PCS, true);
+  for (int l = 0; l < NLC; ++l)
     if (tid < W) cvec[l * W + tid] = a.p.bias[l][tid];
-  });
-  for (int i = tid; i < 3 * W; i += 256) cvec[D::NLC * W + i] = a.p.w_out[i];
+  for (int i = tid; i < 3 * W; i += 256) cvec[NLC * W + i] = a.p.w_out[i];
   __syncthreads();
 
-  f32x16 accA[MAXB], accB[MAXB];
+  f32x16 accIn[D::NBC], accOut[D::NBC];
   Raw carry;
   auto in_fetch = [&](auto kbc) __attribute__((always_inline)) {
     constexpr int kb = decltype(kbc)::value;
@@ -63,44 +63,46 @@ __global__ __launch_bounds__(256, 1) void col_fwd_kernel(const ColFwdArgs a) {
     else return BlkSrc<1>{{tp_block_ptr(a.csmall_tp, tile, D::NBS, kb - D::NBF)}};
   };
   carry = load_src(in_fetch(IC<0>{}), lane);
-  static_for<0, D::NLC>([&](auto lc) __attribute__((always_inline)) {
-    constexpr int l = decltype(lc)::value;
-    constexpr int KB = D::kb(l);
-    auto& in = pick<(l % 2) == 0>(accA, accB);
-    auto& out = pick<(l % 2) == 0>(accB, accA);
+  // layer 0: [feature | small inputs] -> hidden
+  {
 #pragma unroll
-    for (int b = 0; b < D::NBC; ++b) out[b] = tp_rowvec_blk(cvec + l * W, b, hf);
-    auto fetch = [&](auto kbc) __attribute__((always_inline)) {
-      if constexpr (l == 0) return in_fetch(kbc);
-      else return BlkSrc<0>{};
-    };
-    auto make = [&](auto kbc, const Raw& raw, auto ec) __attribute__((always_inline)) {
+    for (int b = 0; b < D::NBC; ++b) accOut[b] = tp_rowvec_blk(cvec, b, hf);
+    auto make = [&](auto, const Raw& raw, auto ec) __attribute__((always_inline)) { return raw.a[decltype(ec)::value]; };
+    tp_gemm<D::KB0, D::NBC, Stores<0>, NS, PCS>(accOut, carry, in_fetch, make, NoFetch{}, ws, a.p.wp[0], a.p.wp[NLC > 1 ? 1 : 0]);
+    acc_copy(accIn, accOut);
+  }
+  // layers 1 .. NLC-1: hidden -> hidden, input = relu of the layer below (saved on the way for the backward)
+#pragma unroll 1
+  for (int l = 1; l < NLC; ++l) {
+    const float* bias = cvec + l * W;
+#pragma unroll
+    for (int b = 0; b < D::NBC; ++b) accOut[b] = tp_rowvec_blk(bias, b, hf);
+    float* hprev = a.h_tp[l - 1];
+    auto make = [&](auto kbc, const Raw&, auto ec) __attribute__((always_inline)) {
       constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
-      if constexpr (l == 0) {
-        return raw.a[e];
-      } else {
-        const float h = fmaxf(in[kb][e], 0.0f);
-        if constexpr (SAVE) *tp_elem(a.h_tp[l > 0 ? l - 1 : 0], tile, D::NBC, kb, e, lane) = h;
-        return h;
-      }
+      const float h = fmaxf(accIn[kb][e], 0.0f);
+      if constexpr (SAVE) *tp_elem(hprev, tile, D::NBC, kb, e, lane) = h;
+      return h;
     };
-    tp_gemm<KB, D::NBC, Stores<((l > 0 && SAVE) ? 16 : 0)>, NS, (l + 1 < D::NLC ? chunk_pieces(D::NBC, NS) : 0)>(
-        out, carry, fetch, make, NoFetch{}, ws, a.p.wp[l], l + 1 < D::NLC ? a.p.wp[l + 1 < D::NLC ? l + 1 : l] : nullptr);
-  });
+    tp_gemm<D::NBC, D::NBC, Stores<(SAVE ? 16 : 0)>, NS, PCS>(accOut, carry, NoFetch{}, make, NoFetch{}, ws, a.p.wp[l],
+                                                              a.p.wp[l + 1 < NLC ? l + 1 : l]);
+    acc_copy(accIn, accOut);
+  }
 
   // last hidden activation + the 3-row output layer
-  auto& z = pick<(D::NLC % 2) == 0>(accA, accB);
   float part[3] = {0.f, 0.f, 0.f};
+  float* hlast = a.h_tp[NLC - 1];
+  const float* wout = cvec + NLC * W;
 #pragma unroll
   for (int b = 0; b < D::NBC; ++b) {
     f32x16 h;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) h[r] = fmaxf(z[b][r], 0.0f);
-    if constexpr (SAVE) tp_store_blk(h, a.h_tp[D::NLC - 1], tile, D::NBC, b, lane);
+    for (int r = 0; r < 16; ++r) h[r] = fmaxf(accIn[b][r], 0.0f);
+    if constexpr (SAVE) tp_store_blk(h, hlast, tile, D::NBC, b, lane);
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) part[c] = fmaf(cvec[(D::NLC + c) * W + b * 32 + tp_row(r, hf)], h[r], part[c]);
+      for (int r = 0; r < 16; ++r) part[c] = fmaf(wout[c * W + b * 32 + tp_row(r, hf)], h[r], part[c]);
   }
   float o[3];
 #pragma unroll
@@ -135,12 +137,13 @@ __global__ __launch_bounds__(256, 1) void col_bwd_kernel(const ColBwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, hf = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-  constexpr int MAXB = D::MAXB, W = D::CW;
-  constexpr int NS = kNsGrad;
+  constexpr int W = D::CW, NS = kNsGrad;
+  constexpr int PCS = chunk_pieces(D::MAXO, NS);  // prefetch size: the first layer's transposed chunk is the widest
+  const int NLC = a.p.nlc;
   float* cvec = lds + 2 * D::buf_floats(NS);
 
   WStream ws{lds, D::buf_floats(NS), 0, wave, lane};
-  ws.issue(a.p.wpT[D::NLC - 1], chunk_pieces(D::kb(D::NLC - 1), NS), true);
+  ws.issue(a.p.wpT[NLC - 1], PCS, true);
   for (int i = tid; i < 3 * W; i += 256) cvec[i] = a.p.w_out[i];
   __syncthreads();
 
@@ -159,49 +162,55 @@ __global__ __launch_bounds__(256, 1) void col_bwd_kernel(const ColBwdArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dst[r * 64] = (hf == 0 && r < 3) ? dl[r] : 0.0f;
   }
-  f32x16 accA[MAXB], accB[MAXB];
+  f32x16 accIn[D::NBC], accOut[D::NBC];
   // hbar of the last hidden layer = w_out^T delta_out
 #pragma unroll
   for (int b = 0; b < D::NBC; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int k = b * 32 + tp_row(r, hf);
-      accA[b][r] = cvec[k] * dl[0] + cvec[W + k] * dl[1] + cvec[2 * W + k] * dl[2];
+      accIn[b][r] = cvec[k] * dl[0] + cvec[W + k] * dl[1] + cvec[2 * W + k] * dl[2];
     }
 
   Raw carry;
-  auto h_fetch = [&](auto lc, auto bc) __attribute__((always_inline)) {
-    constexpr int l = decltype(lc)::value, b = decltype(bc)::value;
-    return BlkSrc<1>{{tp_block_ptr(a.h_tp[l], tile, D::NBC, b)}};
-  };
-  carry = load_src(h_fetch(IC<D::NLC - 1>{}, IC<0>{}), lane);
-  static_for<0, D::NLC>([&](auto sc) __attribute__((always_inline)) {
-    constexpr int step = decltype(sc)::value;
-    constexpr int l = D::NLC - 1 - step;
-    constexpr int KB = D::kb(l);
-    auto& hb = pick<(step % 2) == 0>(accA, accB);
-    auto& un = pick<(step % 2) == 0>(accB, accA);
+  carry = load_src(BlkSrc<1>{{tp_block_ptr(a.h_tp[NLC - 1], tile, D::NBC, 0)}}, lane);
+  // layers NLC-1 .. 1: delta_l = hbar_l masked by the ReLU (saved for the weight gradients); hbar_{l-1} = W_l^T delta_l
+#pragma unroll 1
+  for (int l = NLC - 1; l >= 1; --l) {
+    const float* hl = a.h_tp[l];
+    const float* hbelow = a.h_tp[l - 1];
+    float* dlp = a.d_tp[l];
 #pragma unroll
-    for (int b = 0; b < KB; ++b) un[b] = f32x16_zero();
-    // delta_l = hbar_l masked by the ReLU
-    auto fetch = [&](auto bc) __attribute__((always_inline)) { return h_fetch(IC<l>{}, bc); };
+    for (int b = 0; b < D::NBC; ++b) accOut[b] = f32x16_zero();
+    auto fetch = [&](auto bc) __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(hl, tile, D::NBC, decltype(bc)::value)}}; };
     auto make = [&](auto bc, const Raw& raw, auto ec) __attribute__((always_inline)) {
       constexpr int b = decltype(bc)::value, e = decltype(ec)::value;
-      const float d = raw.a[e] > 0.0f ? hb[b][e] : 0.0f;
-      *tp_elem(a.d_tp[l], tile, D::NBC, b, e, lane) = d;
+      const float d = raw.a[e] > 0.0f ? accIn[b][e] : 0.0f;
+      *tp_elem(dlp, tile, D::NBC, b, e, lane) = d;
       return d;
     };
-    auto next_fetch = [&]() __attribute__((always_inline)) {
-      if constexpr (l > 0) return h_fetch(IC<(l > 0 ? l - 1 : 0)>{}, IC<0>{});
-      else return BlkSrc<0>{};
+    auto next_fetch = [&]() __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(hbelow, tile, D::NBC, 0)}}; };
+    tp_gemm<D::NBC, D::NBC, Stores<16>, NS, PCS>(accOut, carry, fetch, make, next_fetch, ws, a.p.wpT[l], a.p.wpT[l - 1]);
+    acc_copy(accIn, accOut);
+  }
+  // layer 0: the gradient of [feature | small inputs]
+  {
+    f32x16 acc0[D::KB0];
+#pragma unroll
+    for (int b = 0; b < D::KB0; ++b) acc0[b] = f32x16_zero();
+    const float* hl = a.h_tp[0];
+    float* dlp = a.d_tp[0];
+    auto fetch = [&](auto bc) __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(hl, tile, D::NBC, decltype(bc)::value)}}; };
+    auto make = [&](auto bc, const Raw& raw, auto ec) __attribute__((always_inline)) {
+      constexpr int b = decltype(bc)::value, e = decltype(ec)::value;
+      const float d = raw.a[e] > 0.0f ? accIn[b][e] : 0.0f;
+      *tp_elem(dlp, tile, D::NBC, b, e, lane) = d;
+      return d;
     };
-    tp_gemm<D::NBC, KB, Stores<16>, NS, (l > 0 ? chunk_pieces(D::kb(l > 0 ? l - 1 : 0), NS) : 0)>(
-        un, carry, fetch, make, next_fetch, ws, a.p.wpT[l], l > 0 ? a.p.wpT[l > 0 ? l - 1 : 0] : nullptr);
-    if constexpr (l == 0) {
+    tp_gemm<D::NBC, D::KB0, Stores<16>, NS, 0>(acc0, carry, fetch, make, NoFetch{}, ws, a.p.wpT[0], nullptr);
 #pragma unroll
-      for (int b = 0; b < D::NBF; ++b) tp_store_blk(un[b], a.featbar_tp, tile, D::NBF, b, lane);
+    for (int b = 0; b < D::NBF; ++b) tp_store_blk(acc0[b], a.featbar_tp, tile, D::NBF, b, lane);
 #pragma unroll
-      for (int b = 0; b < D::NBS; ++b) tp_store_blk(un[D::NBF + b], a.csmallbar_tp, tile, D::NBS, b, lane);
-    }
-  });
+    for (int b = 0; b < D::NBS; ++b) tp_store_blk(acc0[D::NBF + b], a.csmallbar_tp, tile, D::NBS, b, lane);
+  }
 }

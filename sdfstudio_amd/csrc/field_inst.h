@@ -5,8 +5,7 @@
 #include "sdfrow_kernel.h"
 
 struct FieldKernels {
-  int nbh, nb0, nb3, nl, skip, nbf, nbs, nbc, nlc;
-  size_t geo_lds, col_lds;
+  int nbh, nb0, nbf, nbs, nbc;  // block widths: hidden, in0, geometry feature, small colour inputs, colour hidden
   void (*geo_fwd)(int mode_train_geo_sdf, const GeoFwdArgs&, unsigned grid, hipStream_t);
   void (*geo_bwd)(const GeoBwdArgs&, unsigned grid, hipStream_t);   // tangent pass + data backward (after MODE_FULL)
   void (*geo_bwd1)(const GeoBwdArgs&, unsigned grid, hipStream_t);  // first-order data backward only (after sdfhip_geo_forward)
@@ -23,71 +22,66 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), lds, s, a);
 }
 
-// mode: 0 = train/full (GRAD, SAVE, FEAT), 1 = geonetwork (FEAT only), 2 = sdf only, 3 = geonetwork saving z_l (differentiable)
-// The three heavy kernel families of one network shape can live in separate translation units (the fully unrolled fused
-// kernels take minutes each to compile): GEO_FWD_TRAIN / GEO_FWD_INFER / GEO_BWD define plain functions, COL defines the rest and the table.
-#define SDFHIP_GEO_DIMS(NBH, NB0, NB3, NL, SKIP, NBF) GeoDims<NBH, NB0, NB3, NL, SKIP, NBF>
-
-#define SDFHIP_DEFINE_GEO_FWD_TRAIN(NAME, NBH, NB0, NB3, NL, SKIP, NBF)                                              \
-  void sdfhip_geo_fwd_train_##NAME(const GeoFwdArgs& a, unsigned grid, hipStream_t s) {                              \
-    using GD = SDFHIP_GEO_DIMS(NBH, NB0, NB3, NL, SKIP, NBF);                                                        \
-    launch_lds(geo_fwd_kernel<GD, true, true, true>, a, grid, 256, GD::lds_floats(kNsFwd) * sizeof(float), s);       \
+// One instantiation serves every DEPTH of a network with these block widths (layers and skip position are run-time values,
+// the kernels loop over the layers).  mode: 0 = train/full (GRAD, SAVE, FEAT), 1 = geonetwork (FEAT only), 2 = sdf only,
+// 3 = geonetwork saving z_l (differentiable).  The kernel families of one shape can live in separate translation units so the
+// build parallelises: GEO_FWD_TRAIN / GEO_FWD_INFER / GEO_BWD define plain functions, COL defines the rest and the table.
+#define SDFHIP_DEFINE_GEO_FWD_TRAIN(NAME, NBH, NB0, NBF)                                                                  \
+  void sdfhip_geo_fwd_train_##NAME(const GeoFwdArgs& a, unsigned grid, hipStream_t s) {                                   \
+    using GD = GeoDims<NBH, NB0, NBF>;                                                                                     \
+    launch_lds(geo_fwd_kernel<GD, true, true, true>, a, grid, 256, GD::lds_floats(kNsFwd, a.p.nl) * sizeof(float), s);    \
   }
 
-#define SDFHIP_DEFINE_GEO_FWD_INFER(NAME, NBH, NB0, NB3, NL, SKIP, NBF)                                              \
-  void sdfhip_geo_fwd_infer_##NAME(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s) {                    \
-    using GD = SDFHIP_GEO_DIMS(NBH, NB0, NB3, NL, SKIP, NBF);                                                        \
-    const size_t lds = GD::lds_floats(kNsFwd) * sizeof(float);                                                       \
-    if (mode == 1) launch_lds(geo_fwd_kernel<GD, false, false, true>, a, grid, 256, lds, s);                         \
-    else if (mode == 3) launch_lds(geo_fwd_kernel<GD, false, true, true>, a, grid, 256, lds, s);                     \
-    else launch_lds(geo_fwd_kernel<GD, false, false, false>, a, grid, 256, lds, s);                                  \
+#define SDFHIP_DEFINE_GEO_FWD_INFER(NAME, NBH, NB0, NBF)                                                                  \
+  void sdfhip_geo_fwd_infer_##NAME(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s) {                         \
+    using GD = GeoDims<NBH, NB0, NBF>;                                                                                     \
+    const size_t lds = GD::lds_floats(kNsFwd, a.p.nl) * sizeof(float);                                                     \
+    if (mode == 1) launch_lds(geo_fwd_kernel<GD, false, false, true>, a, grid, 256, lds, s);                              \
+    else if (mode == 3) launch_lds(geo_fwd_kernel<GD, false, true, true>, a, grid, 256, lds, s);                          \
+    else launch_lds(geo_fwd_kernel<GD, false, false, false>, a, grid, 256, lds, s);                                       \
   }
 
-#define SDFHIP_DEFINE_GEO_BWD(NAME, NBH, NB0, NB3, NL, SKIP, NBF)                                                    \
-  void sdfhip_geo_bwd_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s) {                                    \
-    using GD = SDFHIP_GEO_DIMS(NBH, NB0, NB3, NL, SKIP, NBF);                                                        \
-    launch_lds(geo_bwd_kernel<GD>, a, grid, 256, GD::lds_floats(kNsGrad) * sizeof(float), s);                        \
-  }                                                                                                                  \
-  void sdfhip_geo_bwd1_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s) {                                   \
-    using GD = SDFHIP_GEO_DIMS(NBH, NB0, NB3, NL, SKIP, NBF);                                                        \
-    launch_lds(geo_bwd_kernel<GD, false>, a, grid, 256, GD::lds_floats(kNsGrad) * sizeof(float), s);                 \
+#define SDFHIP_DEFINE_GEO_BWD(NAME, NBH, NB0, NBF)                                                                        \
+  void sdfhip_geo_bwd_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s) {                                         \
+    using GD = GeoDims<NBH, NB0, NBF>;                                                                                     \
+    launch_lds(geo_bwd_kernel<GD>, a, grid, 256, GD::lds_floats(kNsGrad, a.p.nl) * sizeof(float), s);                     \
+  }                                                                                                                       \
+  void sdfhip_geo_bwd1_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s) {                                        \
+    using GD = GeoDims<NBH, NB0, NBF>;                                                                                     \
+    launch_lds(geo_bwd_kernel<GD, false>, a, grid, 256, GD::lds_floats(kNsGrad, a.p.nl) * sizeof(float), s);              \
   }
 
-#define SDFHIP_DEFINE_COL_AND_TABLE(NAME, NBH, NB0, NB3, NL, SKIP, NBF, NBS, NBC, NLC)                               \
-  void sdfhip_geo_fwd_train_##NAME(const GeoFwdArgs& a, unsigned grid, hipStream_t s);                              \
-  void sdfhip_geo_fwd_infer_##NAME(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s);                     \
-  void sdfhip_geo_bwd_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s);                                     \
-  void sdfhip_geo_bwd1_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s);                                    \
-  namespace NAME##_ns {                                                                                              \
-  static void geo_fwd(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s) {                                 \
-    if (mode == 0) sdfhip_geo_fwd_train_##NAME(a, grid, s);                                                          \
-    else sdfhip_geo_fwd_infer_##NAME(mode, a, grid, s);                                                              \
-  }                                                                                                                  \
-  using GD = SDFHIP_GEO_DIMS(NBH, NB0, NB3, NL, SKIP, NBF);                                                          \
-  using CD = ColDims<NBF, NBS, NBC, NLC>;                                                                            \
-  static void col_fwd(const ColFwdArgs& a, unsigned grid, hipStream_t s) {                                           \
-    launch_lds(col_fwd_kernel<CD, true>, a, grid, 256, CD::lds_floats(kNsCol) * sizeof(float), s);                   \
-  }                                                                                                                  \
-  static void col_bwd(const ColBwdArgs& a, unsigned grid, hipStream_t s) {                                           \
-    launch_lds(col_bwd_kernel<CD>, a, grid, 256, CD::lds_floats(kNsGrad) * sizeof(float), s);                        \
-  }                                                                                                                  \
-  static void sdfrow(const float* z, const float* q, const float* sb, int64_t nt, int tps, float* part,             \
-                     unsigned grid, hipStream_t s) {                                                                 \
-    sdfrow_grad_kernel<NBH><<<grid, 256, 0, s>>>(z, q, sb, nt, tps, part);                                           \
-  }                                                                                                                  \
-  }                                                                                                                  \
-  const FieldKernels* sdfhip_kernels_##NAME() {                                                                      \
-    static const FieldKernels k = {NBH, NB0, NB3, NL, SKIP, NBF, NBS, NBC, NLC,                                      \
-                                   NAME##_ns::GD::lds_floats(kNsMax) * sizeof(float), NAME##_ns::CD::lds_floats(kNsMax) * sizeof(float), \
-                                   NAME##_ns::geo_fwd, sdfhip_geo_bwd_##NAME, sdfhip_geo_bwd1_##NAME, NAME##_ns::col_fwd,   \
-                                   NAME##_ns::col_bwd,                                                               \
-                                   NAME##_ns::sdfrow};                                                               \
-    return &k;                                                                                                       \
+#define SDFHIP_DEFINE_COL_AND_TABLE(NAME, NBH, NB0, NBF, NBS, NBC)                                                        \
+  void sdfhip_geo_fwd_train_##NAME(const GeoFwdArgs& a, unsigned grid, hipStream_t s);                                    \
+  void sdfhip_geo_fwd_infer_##NAME(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s);                          \
+  void sdfhip_geo_bwd_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s);                                          \
+  void sdfhip_geo_bwd1_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s);                                         \
+  namespace NAME##_ns {                                                                                                   \
+  static void geo_fwd(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s) {                                      \
+    if (mode == 0) sdfhip_geo_fwd_train_##NAME(a, grid, s);                                                               \
+    else sdfhip_geo_fwd_infer_##NAME(mode, a, grid, s);                                                                   \
+  }                                                                                                                       \
+  using CD = ColDims<NBF, NBS, NBC>;                                                                                      \
+  static void col_fwd(const ColFwdArgs& a, unsigned grid, hipStream_t s) {                                                \
+    launch_lds(col_fwd_kernel<CD, true>, a, grid, 256, CD::lds_floats(kNsCol, a.p.nlc) * sizeof(float), s);               \
+  }                                                                                                                       \
+  static void col_bwd(const ColBwdArgs& a, unsigned grid, hipStream_t s) {                                                \
+    launch_lds(col_bwd_kernel<CD>, a, grid, 256, CD::lds_floats(kNsGrad, a.p.nlc) * sizeof(float), s);                    \
+  }                                                                                                                       \
+  static void sdfrow(const float* z, const float* q, const float* sb, int64_t nt, int tps, float* part,                  \
+                     unsigned grid, hipStream_t s) {                                                                      \
+    sdfrow_grad_kernel<NBH><<<grid, 256, 0, s>>>(z, q, sb, nt, tps, part);                                                \
+  }                                                                                                                       \
+  }                                                                                                                       \
+  const FieldKernels* sdfhip_kernels_##NAME() {                                                                           \
+    static const FieldKernels k = {NBH, NB0, NBF, NBS, NBC, NAME##_ns::geo_fwd, sdfhip_geo_bwd_##NAME,                    \
+                                   sdfhip_geo_bwd1_##NAME, NAME##_ns::col_fwd, NAME##_ns::col_bwd, NAME##_ns::sdfrow};    \
+    return &k;                                                                                                            \
   }
 
 // everything of one shape in one translation unit
-#define SDFHIP_DEFINE_FIELD_KERNELS(NAME, NBH, NB0, NB3, NL, SKIP, NBF, NBS, NBC, NLC) \
-  SDFHIP_DEFINE_GEO_FWD_TRAIN(NAME, NBH, NB0, NB3, NL, SKIP, NBF)                       \
-  SDFHIP_DEFINE_GEO_FWD_INFER(NAME, NBH, NB0, NB3, NL, SKIP, NBF)                       \
-  SDFHIP_DEFINE_GEO_BWD(NAME, NBH, NB0, NB3, NL, SKIP, NBF)                             \
-  SDFHIP_DEFINE_COL_AND_TABLE(NAME, NBH, NB0, NB3, NL, SKIP, NBF, NBS, NBC, NLC)
+#define SDFHIP_DEFINE_FIELD_KERNELS(NAME, NBH, NB0, NBF, NBS, NBC) \
+  SDFHIP_DEFINE_GEO_FWD_TRAIN(NAME, NBH, NB0, NBF)                 \
+  SDFHIP_DEFINE_GEO_FWD_INFER(NAME, NBH, NB0, NBF)                 \
+  SDFHIP_DEFINE_GEO_BWD(NAME, NBH, NB0, NBF)                       \
+  SDFHIP_DEFINE_COL_AND_TABLE(NAME, NBH, NB0, NBF, NBS, NBC)

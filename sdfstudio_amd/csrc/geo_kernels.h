@@ -44,27 +44,26 @@ constexpr int kMaxLayers = 10;
 constexpr int kNsFwd = SDFHIP_NS_FWD, kNsGrad = SDFHIP_NS_GRAD;
 constexpr int kNsMax = ns_parts(kNsFwd) > ns_parts(kNsGrad) ? kNsFwd : kNsGrad;  // the mode with the larger weight chunks
 
-template <int NBH_, int NB0_, int NB3_, int NL_, int SKIP_, int NBF_>
+// Block widths of a geometry network (32 features per block): hidden, in0 (position + encodings + grid features), geometry
+// feature.  The DEPTH (hidden layers NL, skip layer SKIP or -1) is a run-time property carried in GeoPtrs: the kernels loop.
+template <int NBH_, int NB0_, int NBF_>
 struct GeoDims {
-  static constexpr int NBH = NBH_, NB0 = NB0_, NB3 = NB3_, NL = NL_, SKIP = SKIP_, NBF = NBF_;
-  static_assert(SKIP < 0 || NB3 == NBH, "the layer below the skip concatenation is padded to the full hidden width");
-  static_assert(SKIP < 0 || (SKIP >= 1 && SKIP < NL), "skip layer out of range");
-  // input blocks of layer l (l in [0, NL]; l == NL is the output layer): layout of qb_tp[l]
-  static constexpr int kb(int l) { return l == 0 ? NB0 : (l == SKIP ? NBH + NB0 : NBH); }
-  // output blocks of layer l: layout of z_tp[l], r_tp[l], zb_tp[l]
-  static constexpr int nbo(int l) { return l == NL ? NBF : NBH; }
+  static constexpr int NBH = NBH_, NB0 = NB0_, NBF = NBF_;
   static constexpr int cmax(int a, int b) { return a > b ? a : b; }
   static constexpr int MAXO = cmax(NBH, NBF);                            // widest chunk (out-blocks) any gemm streams
   static constexpr int buf_floats(int ns) { return chunk_pieces(MAXO, ns) * 256; }  // one weight chunk buffer
   static constexpr int CW = MAXO * 32;                                   // stride of the constant-vector area
-  static constexpr int CVEC_FLOATS = (NL + 2) * CW;                      // biases of layers 0..NL, then w_sdf
-  static constexpr int lds_floats(int ns) { return 2 * buf_floats(ns) + CVEC_FLOATS; }
+  // LDS: two chunk buffers, then biases of layers 0..NL and w_sdf
+  static constexpr int lds_floats(int ns, int nl) { return 2 * buf_floats(ns) + (nl + 2) * CW; }
   // every gemm prefetches the first chunk of whatever follows it (a run-time choice) at this size; a smaller chunk is
   // over-read into the one behind it (the packed buffer ends in slack)
   static constexpr int pieces(int ns) { return chunk_pieces(MAXO, ns); }
 };
+// tensor layouts that depend on the depth: qb_tp[l] has kb(l) blocks per tile (NB0 / NBH + NB0 at the skip layer / NBH),
+// z_tp[l], r_tp[l], zb_tp[l] have NBH (every hidden layer is NBH wide: the one below the skip concatenation is padded)
 
 struct GeoPtrs {
+  int32_t nl, skip;               // hidden layers (the output layer is layer nl), skip layer (-1: none; 1 <= skip < nl)
   const float* wp[kMaxLayers];    // packed W_l      [kb][parts][nbo][2][64] x 8 ; the skip layer: NBH chunks over h, then NB0 over in0
   const float* wpT[kMaxLayers];   // packed W_l^T    [nbo][parts][kb][2][64] x 8 ; the skip layer: the NBH columns over h only
   const float* wpT_in0;           // packed W_SKIP^T restricted to the in0 columns: [NBH][parts][NB0][2][64] x 8
@@ -86,11 +85,10 @@ struct GeoFwdArgs {
 // biases (layers 0..NL) and w_sdf into the constant area of LDS: cvec[l * CW + i], w_sdf at l = NL + 1
 template <class D>
 SDFHIP_D void geo_stage_cvec(float* cvec, const GeoPtrs& p, const int tid) {
-  static_for<0, D::NL + 1>([&](auto lc) __attribute__((always_inline)) {
-    constexpr int l = decltype(lc)::value;
-    if (tid < D::nbo(l) * 32) cvec[l * D::CW + tid] = p.bias[l][tid];
-  });
-  if (tid < D::NBH * 32) cvec[(D::NL + 1) * D::CW + tid] = p.w_sdf[tid];
+  for (int l = 0; l < p.nl; ++l)
+    if (tid < D::NBH * 32) cvec[l * D::CW + tid] = p.bias[l][tid];
+  if (tid < D::NBF * 32) cvec[p.nl * D::CW + tid] = p.bias[p.nl][tid];
+  if (tid < D::NBH * 32) cvec[(p.nl + 1) * D::CW + tid] = p.w_sdf[tid];
 }
 
 template <int N>
@@ -117,6 +115,7 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
   constexpr int W = D::CW, NS = kNsFwd, PCS = D::pieces(NS);
+  const int NL = a.p.nl, SKIP = a.p.skip;
   float* cvec = lds + 2 * D::buf_floats(NS);
 
   WStream ws{lds, D::buf_floats(NS), 0, wave, lane};
@@ -132,9 +131,9 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
   // ---- forward layers 0 .. NL-1: out_l = b_l + W_l u_l
   carry = load_src(in0_blk0(), lane);
 #pragma unroll 1
-  for (int l = 0; l < D::NL; ++l) {
+  for (int l = 0; l < NL; ++l) {
     // weights that follow the last hidden layer: the output layer's, else the first chain gemm's, else nothing (re-read own)
-    const float* after_last = FEAT ? a.p.wp[D::NL] : (GRAD ? (D::SKIP == D::NL - 1 ? a.p.wpT_in0 : a.p.wpT[D::NL - 1]) : a.p.wp[l]);
+    const float* after_last = FEAT ? a.p.wp[NL] : (GRAD ? (SKIP == NL - 1 ? a.p.wpT_in0 : a.p.wpT[NL - 1]) : a.p.wp[l]);
     {
       const float* bias = cvec + l * W;
 #pragma unroll
@@ -149,45 +148,47 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
         if constexpr (SAVE || GRAD) *tp_elem(zprev, tile, D::NBH, kb, e, lane) = z;
         return softplus100_h(z);
       };
-      const float* nxt = l == D::SKIP ? geo_skip_in0<D>(a.p.wp[l]) : (l + 1 < D::NL ? a.p.wp[l + 1] : after_last);
+      const float* nxt = l == SKIP ? geo_skip_in0<D>(a.p.wp[l]) : (l + 1 < NL ? a.p.wp[l + 1] : after_last);
       tp_gemm<D::NBH, D::NBH, Stores<ZS>, NS, PCS>(accOut, carry, NoFetch{}, make, in0_blk0, ws, a.p.wp[l], nxt);
     }
-    if (l == 0 || l == D::SKIP) {
+    if (l == 0 || l == SKIP) {
       // in0 -> hidden: layer 0, and the in0 columns of the skip layer (cat([h, in0]) / sqrt(2), the factor folded into W)
       auto fetch = [&](auto kbc) __attribute__((always_inline)) {
         return BlkSrc<1>{{tp_block_ptr(a.in0_tp, tile, D::NB0, decltype(kbc)::value)}};
       };
       auto make = [&](auto, const Raw& raw, auto ec) __attribute__((always_inline)) { return raw.a[decltype(ec)::value]; };
       const float* w = l == 0 ? a.p.wp[0] : geo_skip_in0<D>(a.p.wp[l]);
-      tp_gemm<D::NB0, D::NBH, Stores<0>, NS, PCS>(accOut, carry, fetch, make, NoFetch{}, ws, w, l + 1 < D::NL ? a.p.wp[l + 1] : after_last);
+      tp_gemm<D::NB0, D::NBH, Stores<0>, NS, PCS>(accOut, carry, fetch, make, NoFetch{}, ws, w, l + 1 < NL ? a.p.wp[l + 1] : after_last);
     }
     acc_copy_n(accIn, accOut);
   }
 
   // first gemm of the chain: the in0 part if the last hidden layer is the skip layer, the hidden part otherwise; its operands
   // are block 0 of z_{NL-1} either way
-  auto chain_first_src = [&]() __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(a.z_tp[D::NL - 1], tile, D::NBH, 0)}}; };
-  const float* chain_first_w = D::SKIP == D::NL - 1 ? a.p.wpT_in0 : a.p.wpT[D::NL - 1];
+  auto chain_first_src = [&]() __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(a.z_tp[NL - 1], tile, D::NBH, 0)}}; };
+  const float* chain_first_w = SKIP == NL - 1 ? a.p.wpT_in0 : a.p.wpT[NL - 1];
 
   // ---- output layer: the sdf row as a lane-local dot product riding in the producer, feature rows on the MFMA path
   {
     float part = 0.0f;
+    float* zlast = a.z_tp[NL - 1];
+    const float* wsdf = cvec + (NL + 1) * W;
     auto make = [&](auto kbc, const Raw&, auto ec) __attribute__((always_inline)) {
       constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
       const float z = accIn[kb][e];
-      if constexpr (SAVE || GRAD) *tp_elem(a.z_tp[D::NL - 1], tile, D::NBH, kb, e, lane) = z;
+      if constexpr (SAVE || GRAD) *tp_elem(zlast, tile, D::NBH, kb, e, lane) = z;
       const float h = softplus100_h(z);
-      part = fmaf(cvec[(D::NL + 1) * W + kb * 32 + tp_row(e, hf)], h, part);
+      part = fmaf(wsdf[kb * 32 + tp_row(e, hf)], h, part);
       return h;
     };
     if constexpr (FEAT) {
 #pragma unroll
-      for (int b = 0; b < D::NBF; ++b) accOut[b] = tp_rowvec_blk(cvec + D::NL * W, b, hf);
+      for (int b = 0; b < D::NBF; ++b) accOut[b] = tp_rowvec_blk(cvec + NL * W, b, hf);
       auto next_fetch = [&]() __attribute__((always_inline)) {
         if constexpr (GRAD) return chain_first_src();
         else return BlkSrc<0>{};
       };
-      tp_gemm<D::NBH, D::NBF, Stores<ZS>, NS, (GRAD ? PCS : 0)>(accOut, carry, NoFetch{}, make, next_fetch, ws, a.p.wp[D::NL],
+      tp_gemm<D::NBH, D::NBF, Stores<ZS>, NS, (GRAD ? PCS : 0)>(accOut, carry, NoFetch{}, make, next_fetch, ws, a.p.wp[NL],
                                                                 GRAD ? chain_first_w : nullptr);
 #pragma unroll
       for (int b = 0; b < D::NBF; ++b) tp_store_blk(accOut[b], a.feat_tp, tile, D::NBF, b, lane);
@@ -204,9 +205,9 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
   // ---- chain: q_l = W_l^T (q_{l+1} * s'(z_l)),  q_NL = w_sdf.  accIn holds q_{l+1}
   if constexpr (GRAD) {
 #pragma unroll
-    for (int b = 0; b < D::NBH; ++b) accIn[b] = tp_rowvec_blk(cvec + (D::NL + 1) * W, b, hf);
+    for (int b = 0; b < D::NBH; ++b) accIn[b] = tp_rowvec_blk(cvec + (NL + 1) * W, b, hf);
 #pragma unroll 1
-    for (int l = D::NL - 1; l >= 0; --l) {
+    for (int l = NL - 1; l >= 0; --l) {
       const float* zl = a.z_tp[l];
       float* rl = a.r_tp[l];
       auto fetch = [&](auto bc) __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(zl, tile, D::NBH, decltype(bc)::value)}}; };
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
         if constexpr (SAVE) *tp_elem(rl, tile, D::NBH, b, e, lane) = r;
         return r;
       };
-      if (l == 0 || l == D::SKIP) {
+      if (l == 0 || l == SKIP) {
         // hidden -> in0: layer 0, and the part of the skip layer's input gradient that goes straight to in0 (parked in e_tp,
         // layer 0 adds to it).  The hidden part of the skip layer follows with the same operands (z_l block 0)
         f32x16 accE[D::NB0];
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
         auto next_fetch = [&]() __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(zl, tile, D::NBH, 0)}}; };
         tp_gemm<D::NBH, D::NB0, Stores<(SAVE ? 16 : 0)>, NS, PCS>(accE, carry, fetch, make, next_fetch, ws, l == 0 ? a.p.wpT[0] : a.p.wpT_in0,
                                                                   a.p.wpT[l]);
-        if (l == 0 && D::SKIP > 0) {
+        if (l == 0 && SKIP > 0) {
 #pragma unroll
           for (int b = 0; b < D::NB0; ++b) accE[b] += tp_load_blk(a.e_tp, tile, D::NB0, b, lane);
         }
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
         const float* zbelow = a.z_tp[l - 1];
         auto next_fetch = [&]() __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(zbelow, tile, D::NBH, 0)}}; };
         tp_gemm<D::NBH, D::NBH, Stores<(SAVE ? 16 : 0)>, NS, PCS>(accOut, carry, fetch, make, next_fetch, ws, a.p.wpT[l],
-                                                                  l - 1 == D::SKIP ? a.p.wpT_in0 : a.p.wpT[l - 1]);
+                                                                  l - 1 == SKIP ? a.p.wpT_in0 : a.p.wpT[l - 1]);
         acc_copy_n(accIn, accOut);
       }
     }
@@ -265,13 +266,14 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
   constexpr int NS = kNsGrad, PCS = D::pieces(NS);
+  const int NL = a.p.nl, SKIP = a.p.skip;
   float* cvec = lds + 2 * D::buf_floats(NS);
   // first gemm of the backward pass proper (after the feature gemm)
-  const float* bwd_first_w = D::SKIP == D::NL - 1 ? a.p.wpT_in0 : a.p.wpT[D::NL - 1];
+  const float* bwd_first_w = SKIP == NL - 1 ? a.p.wpT_in0 : a.p.wpT[NL - 1];
 
   WStream ws{lds, D::buf_floats(NS), 0, wave, lane};
   if constexpr (TANGENT) ws.issue(a.p.wp[0], chunk_pieces(D::NBH, NS), true);
-  else ws.issue(a.p.wpT[D::NL], chunk_pieces(D::NBH, NS), true);
+  else ws.issue(a.p.wpT[NL], chunk_pieces(D::NBH, NS), true);
   if (tid < D::NBH * 32) cvec[tid] = a.p.w_sdf[tid];
   __syncthreads();
 
@@ -282,11 +284,11 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
     // ---- tangent pass (second-order terms): v_l = W_l qb_l ; accIn holds v_{l-1}
     carry = load_src(BlkSrc<1>{{tp_block_ptr(a.ebar_tp, tile, D::NB0, 0)}}, lane);
 #pragma unroll 1
-    for (int l = 0; l < D::NL; ++l) {
+    for (int l = 0; l < NL; ++l) {
 #pragma unroll
       for (int b = 0; b < D::NBH; ++b) accOut[b] = f32x16_zero();
       float* qbl = a.qb_tp[l];
-      const int qb_nb = l == 0 ? D::NB0 : (l == D::SKIP ? D::NBH + D::NB0 : D::NBH);  // blocks per tile of qb_tp[l]
+      const int qb_nb = l == 0 ? D::NB0 : (l == SKIP ? D::NBH + D::NB0 : D::NBH);  // blocks per tile of qb_tp[l]
       if (l > 0) {
         // hidden -> hidden.  The producer is the tangent epilogue of the layer below on element e of block kb:
         //   qb_l = s'(z_{l-1}) v_{l-1} ;  zc_{l-1} = v_{l-1} r_{l-1} 100 (1 - s'(z_{l-1}))  (-> zb_tp[l-1])
@@ -307,14 +309,14 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
           return qn;
         };
         // what follows: the in0 part of this layer (operands: seed block 0), or the next layer (operands: (z_l, r_l) block 0)
-        const float* na = l == D::SKIP ? a.ebar_tp : a.z_tp[l];
-        const float* nb = l == D::SKIP ? a.ebar_tp : a.r_tp[l];
-        const int nnb = l == D::SKIP ? D::NB0 : D::NBH;
+        const float* na = l == SKIP ? a.ebar_tp : a.z_tp[l];
+        const float* nb = l == SKIP ? a.ebar_tp : a.r_tp[l];
+        const int nnb = l == SKIP ? D::NB0 : D::NBH;
         auto next_fetch = [&]() __attribute__((always_inline)) { return BlkSrc<2>{{tp_block_ptr(na, tile, nnb, 0), tp_block_ptr(nb, tile, nnb, 0)}}; };
-        const float* nxt = l == D::SKIP ? geo_skip_in0<D>(a.p.wp[l]) : (l + 1 < D::NL ? a.p.wp[l + 1] : a.p.wpT[D::NL]);
+        const float* nxt = l == SKIP ? geo_skip_in0<D>(a.p.wp[l]) : (l + 1 < NL ? a.p.wp[l + 1] : a.p.wpT[NL]);
         tp_gemm<D::NBH, D::NBH, Stores<32>, NS, PCS>(accOut, carry, fetch, make, next_fetch, ws, a.p.wp[l], nxt);
       }
-      if (l == 0 || l == D::SKIP) {
+      if (l == 0 || l == SKIP) {
         // in0 -> hidden on the tangent seed (qb_0 == ebar; the seed blocks of the skip layer's qb are copies of it)
         const int b0 = l == 0 ? 0 : D::NBH;
         auto fetch = [&](auto kbc) __attribute__((always_inline)) {
@@ -330,21 +332,25 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
         };
         const float* w = l == 0 ? a.p.wp[0] : geo_skip_in0<D>(a.p.wp[l]);
         tp_gemm<D::NB0, D::NBH, Stores<16>, NS, PCS>(accOut, carry, fetch, make, next_fetch, ws, w,
-                                                     l + 1 < D::NL ? a.p.wp[l + 1] : a.p.wpT[D::NL]);
+                                                     l + 1 < NL ? a.p.wp[l + 1] : a.p.wpT[NL]);
       }
       acc_copy(accIn, accOut);
     }
     {
       // epilogue of the last hidden layer: qb_NL (tangent reaching the sdf row; only the weight gradient needs it) and zc_{NL-1}
+      const float* zlast = a.z_tp[NL - 1];
+      const float* rlast = a.r_tp[NL - 1];
+      float* zblast = a.zb_tp[NL - 1];
+      float* qblast = a.qb_tp[NL];
       static_for<0, D::NBH>([&](auto bc) __attribute__((always_inline)) {
         constexpr int b = decltype(bc)::value;
-        const Raw raw = load_src(BlkSrc<2>{{tp_block_ptr(a.z_tp[D::NL - 1], tile, D::NBH, b), tp_block_ptr(a.r_tp[D::NL - 1], tile, D::NBH, b)}}, lane);
+        const Raw raw = load_src(BlkSrc<2>{{tp_block_ptr(zlast, tile, D::NBH, b), tp_block_ptr(rlast, tile, D::NBH, b)}}, lane);
         static_for<0, 16>([&](auto ec) __attribute__((always_inline)) {
           constexpr int e = decltype(ec)::value;
           const float v = accIn[b][e];
           const float d1 = softplus100_d1(raw.a[e]);
-          *tp_elem(a.zb_tp[D::NL - 1], tile, D::NBH, b, e, lane) = v * raw.b[e] * (100.0f * (1.0f - d1));
-          *tp_elem(a.qb_tp[D::NL], tile, D::NBH, b, e, lane) = d1 * v;
+          *tp_elem(zblast, tile, D::NBH, b, e, lane) = v * raw.b[e] * (100.0f * (1.0f - d1));
+          *tp_elem(qblast, tile, D::NBH, b, e, lane) = d1 * v;
         });
       });
     }
@@ -369,18 +375,18 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
       return BlkSrc<1>{{tp_block_ptr(a.featbar_tp, tile, D::NBF, b)}};
     };
     auto make = [&](auto, const Raw& raw, auto ec) __attribute__((always_inline)) { return raw.a[decltype(ec)::value]; };
-    auto next_fetch = [&]() __attribute__((always_inline)) { return bwd_src(D::NL - 1, 0); };
+    auto next_fetch = [&]() __attribute__((always_inline)) { return bwd_src(NL - 1, 0); };
     carry = load_src(fetch(IC<0>{}), lane);
-    tp_gemm<D::NBF, D::NBH, Stores<0>, NS, PCS>(accIn, carry, fetch, make, next_fetch, ws, a.p.wpT[D::NL], bwd_first_w);
+    tp_gemm<D::NBF, D::NBH, Stores<0>, NS, PCS>(accIn, carry, fetch, make, next_fetch, ws, a.p.wpT[NL], bwd_first_w);
   }
   // accIn holds ub_{l+1}.  zb_l = ub * s'(z_l) + zc_l (zc from the tangent pass, in zb_tp[l]) is produced, stored for the weight
   // gradient and multiplied by W_l^T: its in0 columns first where the layer has them (skip layer -> parked in in0bar, layer 0),
   // then the hidden columns.  The second gemm of the skip layer finds the FINISHED zb_l in zb_tp[l] (this lane's own stores)
 #pragma unroll 1
-  for (int l = D::NL - 1; l >= 0; --l) {
+  for (int l = NL - 1; l >= 0; --l) {
     float* zbl = a.zb_tp[l];
     auto fetch = [&](auto bc) __attribute__((always_inline)) { return bwd_src(l, decltype(bc)::value); };
-    if (l == 0 || l == D::SKIP) {
+    if (l == 0 || l == SKIP) {
       auto make = [&](auto bc, const Raw& raw, auto ec) __attribute__((always_inline)) {
         constexpr int b = decltype(bc)::value, e = decltype(ec)::value;
         const float zb = TANGENT ? fmaf(accIn[b][e], softplus100_d1(raw.a[e]), raw.b[e]) : accIn[b][e] * softplus100_d1(raw.a[e]);
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
       for (int b = 0; b < D::NB0; ++b) accE[b] = f32x16_zero();
       auto next_fetch = [&]() __attribute__((always_inline)) { return bwd_src(l, 0); };
       tp_gemm<D::NBH, D::NB0, Stores<16>, NS, PCS>(accE, carry, fetch, make, next_fetch, ws, l == 0 ? a.p.wpT[0] : a.p.wpT_in0, a.p.wpT[l]);
-      if (l == 0 && D::SKIP > 0) {
+      if (l == 0 && SKIP > 0) {
 #pragma unroll
         for (int b = 0; b < D::NB0; ++b) accE[b] += tp_load_blk(a.in0bar_tp, tile, D::NB0, b, lane);
       }
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
       for (int b = 0; b < D::NB0; ++b) tp_store_blk(accE[b], a.in0bar_tp, tile, D::NB0, b, lane);
     }
     if (l > 0) {
-      const bool done = l == D::SKIP;  // zb_l already finished by the in0 gemm above: take it as stored
+      const bool done = l == SKIP;  // zb_l already finished by the in0 gemm above: take it as stored
       auto make = [&](auto bc, const Raw& raw, auto ec) __attribute__((always_inline)) {
         constexpr int b = decltype(bc)::value, e = decltype(ec)::value;
         float zb;
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
       for (int b = 0; b < D::NBH; ++b) accOut[b] = f32x16_zero();
       auto next_fetch = [&]() __attribute__((always_inline)) { return bwd_src(l - 1, 0); };
       tp_gemm<D::NBH, D::NBH, Stores<16>, NS, PCS>(accOut, carry, fetch, make, next_fetch, ws, a.p.wpT[l],
-                                                   l - 1 == D::SKIP ? a.p.wpT_in0 : a.p.wpT[l - 1]);
+                                                   l - 1 == SKIP ? a.p.wpT_in0 : a.p.wpT[l - 1]);
       acc_copy(accIn, accOut);
     }
   }

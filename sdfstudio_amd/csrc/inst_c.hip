@@ -1,4 +1,5 @@
-// neus-facto-angelo field shape (BASELINE config 5, method_configs.py:403-422): 1-hidden-layer 256-wide geometry MLP on
-// in0 = 3 + 36 (zeroed PE) + 16 x 8 grid features = 167 (6 blocks), no skip connection, 4x256 colour MLP with appearance embedding.
+// neus-facto-angelo field widths (BASELINE config 5, method_configs.py:403-422): 256-wide geometry MLP on
+// in0 = 3 + 36 (zeroed PE) + 16 x 8 grid features = 167 (6 blocks), 256-wide colour MLP with appearance embedding; any depth
+// (the preset: 1 hidden geometry layer, no skip, 4 colour layers).
 #include "field_inst.h"
-SDFHIP_DEFINE_FIELD_KERNELS(C, 8, 6, 0, 1, -1, 8, 3, 8, 4)
+SDFHIP_DEFINE_FIELD_KERNELS(C, 8, 6, 8, 3, 8)

@@ -940,22 +940,35 @@ def test_field_full_size_fwd_bwd(device):
     _check_field_grads(model, po, rtol=1e-3, truth=p64)
 
 
-def test_neus_facto_preset_shape_field_fwd_bwd(device):
-    """The `neus-facto` PRESET's field (method_configs.py:472-480: 2 x 256 geometry MLP without skip connection, 2 x 256 colour MLP,
-    16 x 2 x 2^19 grid) - the shape `ns-train neus-facto` runs by default (csrc/inst_d.hip) - against the oracle, fp64-anchored."""
-    cfg = O.ModelCfg(field=O.FieldCfg(num_layers=2, num_layers_color=2, bias=0.5, inside_outside=False, beta_init=0.3))
-    p = _full_shape_params(cfg, seed=5)
+@pytest.mark.parametrize("shape", [(2, 2, 256), (1, 1, 256), (5, 2, 256), (6, 3, 256), (7, 4, 256), (9, 5, 256), (5, 1, 64), (2, 3, 64), (9, 2, 64)],
+                         ids=lambda t: f"{t[0]}x{t[2]}+{t[1]}x{t[2]}")
+def test_field_depth_sweep_fwd_bwd(device, shape):
+    """Depth is a run-time property of the fused kernels (they loop over the layers): (geometry layers, colour layers, width)
+    swept against the oracle, fp64-anchored - forward outputs and every parameter gradient.  (2, 2, 256) is the `neus-facto`
+    PRESET's field (method_configs.py:472-480: no skip connection), depths >= 5 have the skip connection at layer 4
+    (sdf_field.py:280,300-305), 9 is the deepest the argument tables hold; 256-wide shapes run on the 16 x 2 x 2^19 grid of
+    BASELINE config 2, 64-wide ones on the small golden grid."""
+    nl, nlc, width = shape
+    if width == 256:
+        fcfg = O.FieldCfg(num_layers=nl, num_layers_color=nlc, bias=0.5, inside_outside=False, beta_init=0.3)
+    else:
+        base = small_oracle_cfg().field
+        fcfg = O.FieldCfg(**{**base.__dict__, "num_layers": nl, "num_layers_color": nlc})
+    cfg = O.ModelCfg(field=fcfg) if width == 256 else small_oracle_cfg()
+    cfg.field = fcfg
+    p = _full_shape_params(cfg, seed=5 + nl)
     model = product_model_from_params(p, cfg, device).train()
     n, s = 33, 40
     o, d, cam, starts = _field_case(cfg, p, n, s, seed=19)
     coefs = [torch.randn(n, s), torch.randn(n, s, 3) * 0.3, torch.randn(n, s, 3)]
     fo, po = _oracle_field(cfg.field, p, o, d, cam, starts, coefs)
     sdf, grad, rgb, _ = _product_field(model, o, d, cam, starts, coefs, device)
-    assert_close("sdf (2x256)", sdf, fo["sdf"], rtol=0, atol=1e-5)
+    tag = f"({nl}x{width} + {nlc}x{width})"
+    assert_close(f"sdf {tag}", sdf, fo["sdf"], rtol=0, atol=1e-5)
     f64, p64 = _oracle_field(cfg.field, to_double(p), o.double(), d.double(), cam, starts.double(), [c.double() for c in coefs])
-    assert_fp32_class("gradient (2x256)", grad, fo["gradient"], f64["gradient"], factor=3.0, atol=2e-5)
-    assert_fp32_class("rgb (2x256)", rgb, fo["rgb"], f64["rgb"], factor=3.0, atol=2e-5)
-    _check_field_grads(model, po, rtol=1e-3, truth=p64, min_checked=14)
+    assert_fp32_class(f"gradient {tag}", grad, fo["gradient"], f64["gradient"], factor=3.0, atol=2e-5)
+    assert_fp32_class(f"rgb {tag}", rgb, fo["rgb"], f64["rgb"], factor=3.0, atol=2e-5)
+    _check_field_grads(model, po, rtol=1e-3, truth=p64, min_checked=2 * (nl + 1) + 2 * (nlc + 1))
 
 
 def test_full_size_properties(device):
