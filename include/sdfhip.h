@@ -79,10 +79,13 @@ int32_t sdfhip_field_num_linear(const SdfHipField* f);
 int sdfhip_field_theta_layout(const SdfHipField* f, int64_t* w_off, int64_t* b_off, int32_t* out_dim, int32_t* in_dim);
 int64_t sdfhip_field_table_size(const SdfHipField* f);    /* floats in the hash table (tcnn `params`) */
 int64_t sdfhip_field_packed_size(const SdfHipField* f);   /* floats in the MFMA-packed weight blob */
-int64_t sdfhip_field_workspace_size(const SdfHipField* f, int64_t n_points, int32_t training); /* bytes */
+/* bytes.  level: 0 = SDFHIP_MODE_SDF / SDFHIP_MODE_GEO calls; 1 = SDFHIP_MODE_FULL with training = 1 (every tensor the backward
+ * needs, its staging buffers and split-K partials: ~48 KB per point at 8 x 256 + 4 x 256); 2 = SDFHIP_MODE_FULL with training = 0
+ * (forward only, e.g. rendering under torch.no_grad(): ~11 KB per point). */
+int64_t sdfhip_field_workspace_size(const SdfHipField* f, int64_t n_points, int32_t level);
 
-/* theta -> split-bf16 MFMA operand order: every weight as three bf16 parts w0 + w1 + w2 (all 24 mantissa bits), W and W^T
- * chunked per 32-wide k block (once per optimiser step). */
+/* theta -> MFMA operand order: every weight as five 16-bit parts (bf16 w0 + w1 + w2, fp16 hi + lo; a kernel streams the two of its
+ * precision mode), W and W^T chunked per 32-wide k block (once per optimiser step). */
 int sdfhip_field_pack(const SdfHipField* f, const float* theta, float* packed, sdfhip_stream_t stream);
 
 enum {
@@ -95,7 +98,9 @@ enum {
  * and n_samples = 1 to evaluate at explicit positions origins[P,3].
  * Outputs (rows = sdfhip_padded_points(P)): sdf [rows], grad [rows,3], rgb [rows,3], feat [rows, geo_feat_dim]
  * (feat may be NULL; grad/rgb only written in MODE_FULL). emb: per-ray appearance embedding [n_rays, appearance_dim]
- * or NULL (zeros, sdf_field.py:554-564). level_mask: [n_levels*n_features] (hash_encoding_mask). */
+ * or NULL (zeros, sdf_field.py:554-564). level_mask: [n_levels*n_features] (hash_encoding_mask).
+ * training (MODE_FULL only): 1 = sdfhip_field_backward will follow with the same workspace (level 1); 0 = forward only: the
+ * kernels save nothing (no r_l / h_l stores, workspace level 2). */
 int sdfhip_field_forward(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
                          const float* origins, const float* dirs, const float* starts, int64_t n_rays, int32_t n_samples,
                          const float* emb, int32_t mode, int32_t training, void* workspace,
@@ -190,6 +195,29 @@ int sdfhip_sample_pdf_spacing(int32_t spacing, const float* weights, const float
  * [max(z - (far - near) delta, near), min(z + (far - near) delta, far)] (unchanged where no surface was found: mask = 0). */
 int sdfhip_surface_root(const float* sdf, const float* starts, const float* nears, const float* fars, int64_t n_rays, int32_t n_samples,
                         float delta, int32_t* mask, float* z, float* new_nears, float* new_fars, sdfhip_stream_t stream);
+/* ---- packed-sample path of NeuS-acc.  The reference calls three nerfacc (== 0.3.5, CUDA-only) operators; these
+ * replace them.  "Packed": the samples of all rays in one array, ray r owning [offsets[r], offsets[r] + counts[r]).
+ *
+ * nerfacc.cuda.ray_marching (model_components/ray_samplers.py:1474-1484; ContractionType AABB, cone_angle 0): march each ray
+ * from t_min to t_max in steps of `step`, keep the intervals whose mid point lies in an occupied voxel of binary
+ * [resolution]^3 (torch.bool storage, x-major) over the region roi_aabb6 = (min xyz, max xyz) - a HOST array -, skip empty voxels
+ * to their far boundary in whole steps.  Two passes: counts [n_rays] (int32); then, with offsets = exclusive scan of the
+ * counts (int64), ray_indices (int64) / t_starts / t_ends [sum of counts]. */
+int sdfhip_march_count(const float* origins, const float* dirs, const float* t_min, const float* t_max, const float* roi_aabb6_host,
+                       const uint8_t* binary, int64_t n_rays, int32_t resolution, float step, int32_t* counts, sdfhip_stream_t stream);
+int sdfhip_march_write(const float* origins, const float* dirs, const float* t_min, const float* t_max, const float* roi_aabb6_host,
+                       const uint8_t* binary, int64_t n_rays, int32_t resolution, float step, const int64_t* offsets,
+                       int64_t* ray_indices, float* t_starts, float* t_ends, sdfhip_stream_t stream);
+/* nerfacc.render_weight_from_alpha (models/neus_acc.py:103-107): weights_i = alpha_i T_i with T_i = prod_{j<i} (1 - alpha_j)
+ * inside each ray's segment; trans receives T (the backward reads it).  Backward: alpha_bar from weights_bar. */
+int sdfhip_packed_weights_forward(const float* alpha, const int64_t* offsets, const int32_t* counts, int64_t n_rays, float* weights,
+                                  float* trans, sdfhip_stream_t stream);
+int sdfhip_packed_weights_backward(const float* alpha, const float* weights, const float* trans, const float* weights_bar,
+                                   const int64_t* offsets, const int32_t* counts, int64_t n_rays, float* alpha_bar, sdfhip_stream_t stream);
+/* nerfacc.accumulate_along_rays (models/neus_acc.py:108-121): out[r, :] = sum over ray r's segment of weights_i * values[i, :]
+ * (values NULL: of weights_i, dim = 1); rays without samples get zeros.  Deterministic (one wavefront per ray, no atomics). */
+int sdfhip_packed_accumulate(const float* weights, const float* values, const int64_t* offsets, const int32_t* counts, int64_t n_rays,
+                             int32_t dim, float* out, sdfhip_stream_t stream);
 /* interlevel_loss_zip (model_components/losses.py:116-172), the part per proposal level: the field histogram (c [n_rays, s+1]
  * spacing bins, w [n_rays, s] weights; both constants) blurred with half-width `radius` (0.03 / 0.003 for the two levels, :138)
  * and resampled at the proposal bins cp [n_rays, s_p+1]; against the proposal weights wp [n_rays, s_p]:

@@ -837,3 +837,106 @@ def synthetic_rays(n: int, seed: int = 42, radius: float = 2.73, dtype=torch.flo
     d = target - o
     d = d / d.norm(dim=-1, keepdim=True)
     return o.to(dtype), d.to(dtype), cam
+
+
+# ----------------------------------------------------------------------------- packed-sample path (NeuS-acc)
+# The reference calls three operators of nerfacc == 0.3.5 (pyproject.toml:31), a CUDA-only dependency that is NOT vendored in
+# /root/reference and cannot be built here: PARITY UNPINNED for ray_marching (restated from the published algorithm of
+# nerfacc/cuda/csrc/ray_marching.cu + helpers_*.h of that release); render_weight_from_alpha and accumulate_along_rays are
+# pinned by their definitions (exclusive product scan / index_add), checked against plain torch below.
+def ray_marching(origins, dirs, t_min, t_max, roi_aabb, binary, step_size: float):
+    """nerfacc.cuda.ray_marching(origins, dirs, t_min, t_max, roi, binary, ContractionType.AABB, step_size, cone_angle = 0) as
+    called at model_components/ray_samplers.py:1474-1484.  fp32 arithmetic operation by operation (numpy scalars), positions
+    with one rounding (fma).  Returns (packed_info [N,2] = (offset, count), ray_indices [P], t_starts [P,1], t_ends [P,1])."""
+    import numpy as np
+
+    f = np.float32
+    o_, d_ = origins.numpy().astype(np.float32), dirs.numpy().astype(np.float32)
+    tmin, tmax = t_min.numpy().astype(np.float32), t_max.numpy().astype(np.float32)
+    roi = roi_aabb.numpy().astype(np.float32).reshape(2, 3)
+    occ = binary.numpy().astype(bool)
+    R = occ.shape[0]
+    Rf, step, half = f(R), f(step_size), f(0.5)
+
+    def fma(a, b, c):
+        return f(np.float64(a) * np.float64(b) + np.float64(c))
+
+    def occupied(p):
+        if any(p[k] < roi[0, k] or p[k] > roi[1, k] for k in range(3)):
+            return False
+        idx = []
+        for k in range(3):
+            u = f(f(f(p[k] - roi[0, k]) / f(roi[1, k] - roi[0, k])) * Rf)
+            idx.append(min(max(int(u), 0), R - 1))
+        return bool(occ[idx[0], idx[1], idx[2]])
+
+    def advance(t, p, d, inv_d):
+        tt = f(3.0e38)
+        for k in range(3):
+            ext = f(roi[1, k] - roi[0, k])
+            u = f(f(f(p[k] - roi[0, k]) / ext) * Rf)
+            sg = f(1.0) if d[k] > 0 else (f(-1.0) if d[k] < 0 else f(0.0))
+            tk = f(f(f(f(np.floor(f(f(u + half) + f(half * sg))) - u) * inv_d[k]) / Rf) * ext)
+            tt = min(tt, tk)
+        target = f(t + max(tt, f(0.0)))
+        while True:
+            t = f(t + step)
+            if not t < target:
+                return t
+
+    ray_idx, ts, te, info = [], [], [], []
+    with np.errstate(divide="ignore"):
+        for r in range(o_.shape[0]):
+            o, d = o_[r], d_[r]
+            inv_d = f(1.0) / d
+            t0 = tmin[r]
+            t1 = f(t0 + step)
+            tm = f(f(t0 + t1) * half)
+            n0 = len(ts)
+            while tm < tmax[r]:
+                p = [fma(tm, d[k], o[k]) for k in range(3)]
+                if occupied(p):
+                    ray_idx.append(r)
+                    ts.append(t0)
+                    te.append(t1)
+                    t0 = t1
+                    t1 = f(t0 + step)
+                    tm = f(f(t0 + t1) * half)
+                else:
+                    tm = advance(tm, p, d, inv_d)
+                    t0 = f(tm - f(step * half))
+                    t1 = f(tm + f(step * half))
+            info.append((n0, len(ts) - n0))
+    return (torch.tensor(info, dtype=torch.int64).view(-1, 2), torch.tensor(ray_idx, dtype=torch.int64),
+            torch.tensor(np.array(ts, dtype=np.float32)).view(-1, 1), torch.tensor(np.array(te, dtype=np.float32)).view(-1, 1))
+
+
+def packed_weights_from_alpha(alpha: torch.Tensor, packed_info: torch.Tensor) -> torch.Tensor:
+    """nerfacc.render_weight_from_alpha (models/neus_acc.py:103-107): w_i = alpha_i prod_{j<i, same ray} (1 - alpha_j).  alpha [P]."""
+    out = []
+    for off, cnt in packed_info.tolist():
+        a = alpha[off:off + cnt]
+        T = torch.cumprod(torch.cat([torch.ones_like(a[:1]), 1.0 - a[:-1]]), dim=0) if cnt > 0 else a
+        out.append(a * T)
+    return torch.cat(out) if out else alpha
+
+
+def accumulate_along_rays(weights: torch.Tensor, ray_indices: torch.Tensor, values: Optional[torch.Tensor], n_rays: int) -> torch.Tensor:
+    """nerfacc.accumulate_along_rays (models/neus_acc.py:108-121): index_add of weights * values (values None: of the weights)."""
+    src = weights[:, None] * values if values is not None else weights[:, None]
+    return torch.zeros(n_rays, src.shape[-1], dtype=src.dtype).index_add_(0, ray_indices, src)
+
+
+def neus_acc_binary_update(binary: torch.Tensor, cube_coordinate: torch.Tensor, sdf_fn, inv_s: torch.Tensor, voxel_size: float,
+                           step_size: float, alpha_thres: float = 0.001) -> torch.Tensor:
+    """NeuSAccSampler.update_binary_grid (model_components/ray_samplers.py:1383-1432): occupied voxels whose |sdf| minus the voxel's
+    half diagonal still yields an alpha above the threshold stay occupied (pruned voxels never come back)."""
+    mask = binary.reshape(-1).clone()
+    sdf = sdf_fn(cube_coordinate[mask]).abs()
+    bound = voxel_size * (3 ** 0.5) / 2.0
+    sdf = torch.maximum(sdf - bound, torch.zeros_like(sdf))
+    prev_cdf = torch.sigmoid((sdf + step_size * 0.5) * inv_s)
+    next_cdf = torch.sigmoid((sdf - step_size * 0.5) * inv_s)
+    alpha = ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).clip(0.0, 1.0)
+    mask[mask.clone()] = alpha > alpha_thres
+    return mask.reshape(binary.shape)

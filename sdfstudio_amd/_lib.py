@@ -90,6 +90,14 @@ _SIGNATURES = {
                                           c_f32, c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
     "sdfhip_surface_root": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, c_i64, c_i32, c_f32, ctypes.c_void_p, c_float_p,
                                     c_float_p, c_float_p, ctypes.c_void_p]),
+    "sdfhip_march_count": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, c_i64, c_i32,
+                                   c_f32, ctypes.c_void_p, ctypes.c_void_p]),
+    "sdfhip_march_write": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, c_i64, c_i32,
+                                   c_f32, ctypes.c_void_p, ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_void_p]),
+    "sdfhip_packed_weights_forward": (c_i32, [c_float_p, ctypes.c_void_p, ctypes.c_void_p, c_i64, c_float_p, c_float_p, ctypes.c_void_p]),
+    "sdfhip_packed_weights_backward": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_void_p, c_i64, c_float_p,
+                                               ctypes.c_void_p]),
+    "sdfhip_packed_accumulate": (c_i32, [c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_void_p, c_i64, c_i32, c_float_p, ctypes.c_void_p]),
     "sdfhip_interlevel_terms": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, c_i64, c_i32, c_i32, c_f32, c_float_p, c_float_p,
                                         c_float_p, ctypes.c_void_p]),
     "sdfhip_sample_pdf_uniform": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_i32, c_i64, c_i32, c_i32, c_f32,

@@ -11,6 +11,7 @@
 #include "optim_kernels.h"
 #include "point_kernels.h"
 #include "ray_kernels.h"
+#include "packed_kernels.h"
 
 const FieldKernels* sdfhip_kernels_A();
 const FieldKernels* sdfhip_kernels_B();
@@ -447,7 +448,10 @@ struct FieldWs {
   size_t bytes;
 };
 
-static void carve(const SdfHipField* f, int64_t n_points, int full, void* base, FieldWs* w) {
+// level: 0 = point modes (sdf / geonetwork inference), 1 = MODE_FULL with a backward to follow (every saved tensor, gradient
+// staging, split-K partials), 2 = MODE_FULL forward only (z_l for the analytic-normal chain; no r_l, h_l or gradient buffers)
+static void carve(const SdfHipField* f, int64_t n_points, int level, void* base, FieldWs* w) {
+  const int full = level != 0, train = level == 1;
   const FieldKernels* k = f->k;
   const int64_t np = sdfhip_padded_points(n_points);
   size_t off = 0;
@@ -464,12 +468,14 @@ static void carve(const SdfHipField* f, int64_t n_points, int full, void* base, 
     w->dydp = take(np * f->n_feat * 3);
     for (int l = 0; l < f->nl; ++l) {
       w->z[l] = take(np * f->nbo_geo(l) * 32);
-      w->r[l] = take(np * f->nbo_geo(l) * 32);
+      if (train) w->r[l] = take(np * f->nbo_geo(l) * 32);
     }
     w->e = take(np * k->nb0 * 32);
     w->csmall = take(np * k->nbs * 32);
-    for (int l = 0; l < f->nlc; ++l) w->h[l] = take(np * k->nbc * 32);
     w->rgb = take(np * 3);
+  }
+  if (train) {
+    for (int l = 0; l < f->nlc; ++l) w->h[l] = take(np * k->nbc * 32);
     w->gtot = take(np * 3);
     w->ebar = take(np * k->nb0 * 32);
     w->sdfbar = take(np);
@@ -543,7 +549,6 @@ extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, c
                                     const float* origins, const float* dirs, const float* starts, int64_t n_rays, int32_t n_samples,
                                     const float* emb, int32_t mode, int32_t training, void* workspace, float* sdf, float* grad,
                                     float* rgb, float* feat, sdfhip_stream_t stream) {
-  (void)training;
   SDFHIP_REQUIRE(f && packed && table && level_mask && origins && workspace && sdf, "field_forward: null argument");
   SDFHIP_REQUIRE(mode >= SDFHIP_MODE_SDF && mode <= SDFHIP_MODE_FULL, "field_forward: bad mode %d", mode);
   SDFHIP_REQUIRE(n_samples >= 1 && n_rays >= 0, "field_forward: bad shape");
@@ -554,7 +559,8 @@ extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, c
   const int64_t P = n_rays * n_samples, NP = sdfhip_padded_points(P);
   const int full = mode == SDFHIP_MODE_FULL;
   FieldWs w;
-  carve(f, P, full, workspace, &w);
+  const int save = full && training != 0;  // MODE_FULL without a backward to follow: nothing is saved (workspace level 2)
+  carve(f, P, full ? (save ? 1 : 2) : 0, workspace, &w);
 
   EncodeArgs ea;
   memset(&ea, 0, sizeof(ea));
@@ -589,7 +595,7 @@ extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, c
   ga.sdf = sdf;
   ga.e_tp = w.e;
   const unsigned grid = (unsigned)(NP / 128);
-  { ProfScope ps_(PS_GEO_FWD, s); k->geo_fwd(full ? 0 : (mode == SDFHIP_MODE_GEO ? 1 : 2), ga, grid, s); }
+  { ProfScope ps_(PS_GEO_FWD, s); k->geo_fwd(full ? (save ? 0 : 4) : (mode == SDFHIP_MODE_GEO ? 1 : 2), ga, grid, s); }
 
   if (full) {
     AssembleArgs aa;
@@ -620,7 +626,7 @@ extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, c
     ca.csmall_tp = w.csmall;
     for (int l = 0; l < f->nlc; ++l) ca.h_tp[l] = w.h[l];
     ca.rgb = w.rgb;  // kept for the backward's sigmoid derivative; the caller gets a copy
-    { ProfScope ps_(PS_COL_FWD, s); k->col_fwd(ca, grid, s); }
+    { ProfScope ps_(PS_COL_FWD, s); k->col_fwd(ca, save, grid, s); }
     SDFHIP_CHECK_HIP(hipMemcpyAsync(rgb, w.rgb, (size_t)NP * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
   if (feat != nullptr && mode != SDFHIP_MODE_SDF) {
@@ -991,7 +997,7 @@ extern "C" int sdfhip_color_forward(const SdfHipField* f, const float* packed, c
   ca.csmall_tp = w.csmall;
   for (int l = 0; l < f->nlc; ++l) ca.h_tp[l] = w.h[l];
   ca.rgb = w.rgb;
-  { ProfScope ps_(PS_COL_FWD, s); k->col_fwd(ca, (unsigned)(NP / 128), s); }
+  { ProfScope ps_(PS_COL_FWD, s); k->col_fwd(ca, 1, (unsigned)(NP / 128), s); }
   SDFHIP_CHECK_HIP(hipMemcpyAsync(rgb, w.rgb, (size_t)NP * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
@@ -1323,6 +1329,105 @@ extern "C" int sdfhip_surface_root(const float* sdf, const float* starts, const 
   a.new_nears = new_nears;
   a.new_fars = new_fars;
   surface_root_kernel<<<(unsigned)((n_rays + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- packed-sample path (NeuS-acc): occupancy-grid marching, segmented compositing
+static void fill_march(MarchArgs* a, const float* origins, const float* dirs, const float* t_min, const float* t_max, const float* roi_aabb6,
+                       const uint8_t* binary, int64_t n_rays, int32_t resolution, float step) {
+  memset(a, 0, sizeof(*a));
+  a->origins = origins;
+  a->dirs = dirs;
+  a->t_min = t_min;
+  a->t_max = t_max;
+  a->binary = binary;
+  for (int k = 0; k < 3; ++k) {
+    a->roi_min[k] = roi_aabb6[k];
+    a->roi_max[k] = roi_aabb6[3 + k];
+  }
+  a->N = (int)n_rays;
+  a->R = resolution;
+  a->step = step;
+}
+extern "C" int sdfhip_march_count(const float* origins, const float* dirs, const float* t_min, const float* t_max, const float* roi_aabb6_host,
+                                  const uint8_t* binary, int64_t n_rays, int32_t resolution, float step, int32_t* counts,
+                                  sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(origins && dirs && t_min && t_max && roi_aabb6_host && binary && counts && resolution >= 1 && step > 0.0f,
+                 "march_count: bad argument");
+  if (n_rays == 0) return 0;
+  MarchArgs a;
+  fill_march(&a, origins, dirs, t_min, t_max, roi_aabb6_host, binary, n_rays, resolution, step);
+  a.counts = counts;
+  march_kernel<false><<<(unsigned)((n_rays + 127) / 128), 128, 0, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int sdfhip_march_write(const float* origins, const float* dirs, const float* t_min, const float* t_max, const float* roi_aabb6_host,
+                                  const uint8_t* binary, int64_t n_rays, int32_t resolution, float step, const int64_t* offsets,
+                                  int64_t* ray_indices, float* t_starts, float* t_ends, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(origins && dirs && t_min && t_max && roi_aabb6_host && binary && offsets && ray_indices && t_starts && t_ends &&
+                     resolution >= 1 && step > 0.0f, "march_write: bad argument");
+  if (n_rays == 0) return 0;
+  MarchArgs a;
+  fill_march(&a, origins, dirs, t_min, t_max, roi_aabb6_host, binary, n_rays, resolution, step);
+  a.offsets = offsets;
+  a.ray_indices = ray_indices;
+  a.t_starts = t_starts;
+  a.t_ends = t_ends;
+  march_kernel<true><<<(unsigned)((n_rays + 127) / 128), 128, 0, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int sdfhip_packed_weights_forward(const float* alpha, const int64_t* offsets, const int32_t* counts, int64_t n_rays,
+                                             float* weights, float* trans, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(offsets && counts && weights && trans, "packed_weights_forward: null argument");
+  if (n_rays == 0) return 0;
+  PackedArgs a;
+  memset(&a, 0, sizeof(a));
+  a.offsets = offsets;
+  a.counts = counts;
+  a.N = (int)n_rays;
+  a.alpha = alpha;
+  a.weights = weights;
+  a.trans = trans;
+  packed_weights_fwd_kernel<<<(unsigned)((n_rays + 3) / 4), 256, 0, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int sdfhip_packed_weights_backward(const float* alpha, const float* weights, const float* trans, const float* weights_bar,
+                                              const int64_t* offsets, const int32_t* counts, int64_t n_rays, float* alpha_bar,
+                                              sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(offsets && counts && alpha_bar, "packed_weights_backward: null argument");
+  if (n_rays == 0) return 0;
+  PackedArgs a;
+  memset(&a, 0, sizeof(a));
+  a.offsets = offsets;
+  a.counts = counts;
+  a.N = (int)n_rays;
+  a.alpha = alpha;
+  a.weights = const_cast<float*>(weights);
+  a.trans = const_cast<float*>(trans);
+  a.wbar = weights_bar;
+  a.alphabar = alpha_bar;
+  packed_weights_bwd_kernel<<<(unsigned)((n_rays + 3) / 4), 256, 0, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int sdfhip_packed_accumulate(const float* weights, const float* values, const int64_t* offsets, const int32_t* counts,
+                                        int64_t n_rays, int32_t dim, float* out, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(offsets && counts && out && dim >= 1, "packed_accumulate: bad argument");
+  if (n_rays == 0) return 0;
+  PackedArgs a;
+  memset(&a, 0, sizeof(a));
+  a.offsets = offsets;
+  a.counts = counts;
+  a.N = (int)n_rays;
+  a.D = dim;
+  a.weights = const_cast<float*>(weights);
+  a.values = values;
+  a.out = out;
+  packed_accumulate_kernel<<<(unsigned)((n_rays + 3) / 4), 256, 0, (hipStream_t)stream>>>(a);
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }

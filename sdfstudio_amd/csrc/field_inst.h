@@ -9,7 +9,7 @@ struct FieldKernels {
   void (*geo_fwd)(int mode_train_geo_sdf, const GeoFwdArgs&, unsigned grid, hipStream_t);
   void (*geo_bwd)(const GeoBwdArgs&, unsigned grid, hipStream_t);   // tangent pass + data backward (after MODE_FULL)
   void (*geo_bwd1)(const GeoBwdArgs&, unsigned grid, hipStream_t);  // first-order data backward only (after sdfhip_geo_forward)
-  void (*col_fwd)(const ColFwdArgs&, unsigned grid, hipStream_t);
+  void (*col_fwd)(const ColFwdArgs&, int save_activations, unsigned grid, hipStream_t);
   void (*col_bwd)(const ColBwdArgs&, unsigned grid, hipStream_t);
   void (*sdfrow)(const float* z_last, const float* qb_last, const float* sdfbar, int64_t n_tiles, int tiles_per_split,
                  float* partial, unsigned grid, hipStream_t);
@@ -24,12 +24,30 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
 
 // One instantiation serves every DEPTH of a network with these block widths (layers and skip position are run-time values,
 // the kernels loop over the layers).  mode: 0 = train/full (GRAD, SAVE, FEAT), 1 = geonetwork (FEAT only), 2 = sdf only,
-// 3 = geonetwork saving z_l (differentiable).  The kernel families of one shape can live in separate translation units so the
+// 3 = geonetwork saving z_l (differentiable), 4 = full forward without a backward to follow (GRAD, FEAT: d sdf / dx, nothing saved).  The kernel families of one shape can live in separate translation units so the
 // build parallelises: GEO_FWD_TRAIN / GEO_FWD_INFER / GEO_BWD define plain functions, COL defines the rest and the table.
+// The second-order kernels run as two launches each (forward | chain, tangent | backward: geo_kernels.h, PHASE);
+// -DSDFHIP_SINGLE_LAUNCH keeps them in one for A/B runs.
+#ifdef SDFHIP_SINGLE_LAUNCH
+#define SDFHIP_GEO_FWD_LAUNCH(GD, SAVE, a, grid, lds, s) launch_lds(geo_fwd_kernel<GD, true, SAVE, true>, a, grid, 256, lds, s)
+#define SDFHIP_GEO_BWD_LAUNCH(GD, a, grid, lds, s) launch_lds(geo_bwd_kernel<GD>, a, grid, 256, lds, s)
+#else
+#define SDFHIP_GEO_FWD_LAUNCH(GD, SAVE, a, grid, lds, s)                                  \
+  do {                                                                                     \
+    launch_lds(geo_fwd_kernel<GD, true, SAVE, true, 1>, a, grid, 256, lds, s);             \
+    launch_lds(geo_fwd_kernel<GD, true, SAVE, true, 2>, a, grid, 256, lds, s);             \
+  } while (0)
+#define SDFHIP_GEO_BWD_LAUNCH(GD, a, grid, lds, s)                                         \
+  do {                                                                                     \
+    launch_lds(geo_bwd_kernel<GD, true, 1>, a, grid, 256, lds, s);                         \
+    launch_lds(geo_bwd_kernel<GD, true, 2>, a, grid, 256, lds, s);                         \
+  } while (0)
+#endif
+
 #define SDFHIP_DEFINE_GEO_FWD_TRAIN(NAME, NBH, NB0, NBF)                                                                  \
   void sdfhip_geo_fwd_train_##NAME(const GeoFwdArgs& a, unsigned grid, hipStream_t s) {                                   \
     using GD = GeoDims<NBH, NB0, NBF>;                                                                                     \
-    launch_lds(geo_fwd_kernel<GD, true, true, true>, a, grid, 256, GD::lds_floats(kNsFwd, a.p.nl) * sizeof(float), s);    \
+    SDFHIP_GEO_FWD_LAUNCH(GD, true, a, grid, GD::lds_floats(kNsFwd, a.p.nl) * sizeof(float), s);                          \
   }
 
 #define SDFHIP_DEFINE_GEO_FWD_INFER(NAME, NBH, NB0, NBF)                                                                  \
@@ -38,13 +56,14 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
     const size_t lds = GD::lds_floats(kNsFwd, a.p.nl) * sizeof(float);                                                     \
     if (mode == 1) launch_lds(geo_fwd_kernel<GD, false, false, true>, a, grid, 256, lds, s);                              \
     else if (mode == 3) launch_lds(geo_fwd_kernel<GD, false, true, true>, a, grid, 256, lds, s);                          \
+    else if (mode == 4) SDFHIP_GEO_FWD_LAUNCH(GD, false, a, grid, lds, s);                                                 \
     else launch_lds(geo_fwd_kernel<GD, false, false, false>, a, grid, 256, lds, s);                                       \
   }
 
 #define SDFHIP_DEFINE_GEO_BWD(NAME, NBH, NB0, NBF)                                                                        \
   void sdfhip_geo_bwd_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s) {                                         \
     using GD = GeoDims<NBH, NB0, NBF>;                                                                                     \
-    launch_lds(geo_bwd_kernel<GD>, a, grid, 256, GD::lds_floats(kNsGrad, a.p.nl) * sizeof(float), s);                     \
+    SDFHIP_GEO_BWD_LAUNCH(GD, a, grid, GD::lds_floats(kNsGrad, a.p.nl) * sizeof(float), s);                               \
   }                                                                                                                       \
   void sdfhip_geo_bwd1_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s) {                                        \
     using GD = GeoDims<NBH, NB0, NBF>;                                                                                     \
@@ -62,8 +81,10 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
     else sdfhip_geo_fwd_infer_##NAME(mode, a, grid, s);                                                                   \
   }                                                                                                                       \
   using CD = ColDims<NBF, NBS, NBC>;                                                                                      \
-  static void col_fwd(const ColFwdArgs& a, unsigned grid, hipStream_t s) {                                                \
-    launch_lds(col_fwd_kernel<CD, true>, a, grid, 256, CD::lds_floats(kNsCol, a.p.nlc) * sizeof(float), s);               \
+  static void col_fwd(const ColFwdArgs& a, int save, unsigned grid, hipStream_t s) {                                      \
+    const size_t lds = CD::lds_floats(kNsCol, a.p.nlc) * sizeof(float);                                                   \
+    if (save) launch_lds(col_fwd_kernel<CD, true>, a, grid, 256, lds, s);                                                 \
+    else launch_lds(col_fwd_kernel<CD, false>, a, grid, 256, lds, s);                                                     \
   }                                                                                                                       \
   static void col_bwd(const ColBwdArgs& a, unsigned grid, hipStream_t s) {                                                \
     launch_lds(col_bwd_kernel<CD>, a, grid, 256, CD::lds_floats(kNsGrad, a.p.nlc) * sizeof(float), s);                    \

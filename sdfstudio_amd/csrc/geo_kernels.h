@@ -108,8 +108,14 @@ SDFHIP_D const float* geo_skip_in0(const float* wp_skip) {
   return wp_skip + (size_t)D::NBH * D::NBH * kChunkBlockFloats;
 }
 
-template <class D, bool GRAD, bool SAVE, bool FEAT>
+// PHASE splits the kernel in two launches (0: everything in one).  The chain starts from a constant (q_NL = w_sdf) and reads z_l
+// from HBM either way, so running it as its own launch (PHASE 2) after the forward (PHASE 1) moves no extra data - and every CU
+// of a launch then sits in the SAME layer loop.  That matters on the boxes of DESIGN.md section 5: two CUs share an instruction
+// cache, and a forward loop (25 KB) next to a chain loop (37 KB) does not fit its fast half.
+template <class D, bool GRAD, bool SAVE, bool FEAT, int PHASE = 0>
 __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
+  static_assert(PHASE == 0 || GRAD, "the chain only exists with GRAD");
+  constexpr bool CHAIN = GRAD && PHASE != 1;  // this launch runs (and prefetches for) the chain
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, hf = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,8 +124,13 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
   const int NL = a.p.nl, SKIP = a.p.skip;
   float* cvec = lds + 2 * D::buf_floats(NS);
 
+  // first gemm of the chain: the in0 part if the last hidden layer is the skip layer, the hidden part otherwise; its operands
+  // are block 0 of z_{NL-1} either way
+  auto chain_first_src = [&]() __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(a.z_tp[NL - 1], tile, D::NBH, 0)}}; };
+  const float* chain_first_w = SKIP == NL - 1 ? a.p.wpT_in0 : a.p.wpT[NL - 1];
+
   WStream ws{lds, D::buf_floats(NS), 0, wave, lane};
-  ws.issue(a.p.wp[0], chunk_pieces(D::NBH, NS), true);
+  ws.issue(PHASE == 2 ? chain_first_w : a.p.wp[0], PHASE == 2 ? PCS : chunk_pieces(D::NBH, NS), true);
   geo_stage_cvec<D>(cvec, a.p, tid);
   __syncthreads();
 
@@ -128,12 +139,14 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
   auto in0_blk0 = [&]() __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(a.in0_tp, tile, D::NB0, 0)}}; };
   constexpr int ZS = (SAVE || GRAD) ? 16 : 0;  // z stores per produced block
 
+  if constexpr (PHASE == 2) carry = load_src(chain_first_src(), lane);
+  if constexpr (PHASE != 2) {
   // ---- forward layers 0 .. NL-1: out_l = b_l + W_l u_l
   carry = load_src(in0_blk0(), lane);
 #pragma unroll 1
   for (int l = 0; l < NL; ++l) {
     // weights that follow the last hidden layer: the output layer's, else the first chain gemm's, else nothing (re-read own)
-    const float* after_last = FEAT ? a.p.wp[NL] : (GRAD ? (SKIP == NL - 1 ? a.p.wpT_in0 : a.p.wpT[NL - 1]) : a.p.wp[l]);
+    const float* after_last = FEAT ? a.p.wp[NL] : (CHAIN ? chain_first_w : a.p.wp[l]);
     {
       const float* bias = cvec + l * W;
 #pragma unroll
@@ -163,11 +176,6 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
     acc_copy_n(accIn, accOut);
   }
 
-  // first gemm of the chain: the in0 part if the last hidden layer is the skip layer, the hidden part otherwise; its operands
-  // are block 0 of z_{NL-1} either way
-  auto chain_first_src = [&]() __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(a.z_tp[NL - 1], tile, D::NBH, 0)}}; };
-  const float* chain_first_w = SKIP == NL - 1 ? a.p.wpT_in0 : a.p.wpT[NL - 1];
-
   // ---- output layer: the sdf row as a lane-local dot product riding in the producer, feature rows on the MFMA path
   {
     float part = 0.0f;
@@ -185,25 +193,26 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
 #pragma unroll
       for (int b = 0; b < D::NBF; ++b) accOut[b] = tp_rowvec_blk(cvec + NL * W, b, hf);
       auto next_fetch = [&]() __attribute__((always_inline)) {
-        if constexpr (GRAD) return chain_first_src();
+        if constexpr (CHAIN) return chain_first_src();
         else return BlkSrc<0>{};
       };
-      tp_gemm<D::NBH, D::NBF, Stores<ZS>, NS, (GRAD ? PCS : 0)>(accOut, carry, NoFetch{}, make, next_fetch, ws, a.p.wp[NL],
-                                                                GRAD ? chain_first_w : nullptr);
+      tp_gemm<D::NBH, D::NBF, Stores<ZS>, NS, (CHAIN ? PCS : 0)>(accOut, carry, NoFetch{}, make, next_fetch, ws, a.p.wp[NL],
+                                                                 CHAIN ? chain_first_w : nullptr);
 #pragma unroll
       for (int b = 0; b < D::NBF; ++b) tp_store_blk(accOut[b], a.feat_tp, tile, D::NBF, b, lane);
     } else {
       static_for<0, D::NBH>([&](auto kbc) __attribute__((always_inline)) {
         static_for<0, 16>([&](auto ec) __attribute__((always_inline)) { (void)make(kbc, carry, ec); });
       });
-      if constexpr (GRAD) carry = load_src(chain_first_src(), lane);
+      if constexpr (CHAIN) carry = load_src(chain_first_src(), lane);
     }
     part += __shfl_xor(part, 32);
     if (hf == 0) a.sdf[tile * 32 + lane] = part + a.p.b_sdf[0];
   }
+  }  // PHASE != 2
 
   // ---- chain: q_l = W_l^T (q_{l+1} * s'(z_l)),  q_NL = w_sdf.  accIn holds q_{l+1}
-  if constexpr (GRAD) {
+  if constexpr (CHAIN) {
 #pragma unroll
     for (int b = 0; b < D::NBH; ++b) accIn[b] = tp_rowvec_blk(cvec + (NL + 1) * W, b, hf);
 #pragma unroll 1
@@ -259,8 +268,12 @@ struct GeoBwdArgs {
 };
 
 // TANGENT = false: first-order backward only (no second-order terms: the caller differentiated sdf / feature, not d sdf / dx).
-template <class D, bool TANGENT = true>
+// PHASE (TANGENT only): 0 = tangent pass and data backward in one launch, 1 = tangent pass only, 2 = data backward only (zc from
+// the tangent launch is in zb_tp).  The backward starts from ub_NL = w_s sdfbar + W_f^T featbar, not from registers of the
+// tangent pass, so the split moves no extra data; the reason for it is the one given at geo_fwd_kernel.
+template <class D, bool TANGENT = true, int PHASE = 0>
 __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
+  static_assert(PHASE == 0 || TANGENT, "phases split the second-order kernel");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, hf = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -272,7 +285,7 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
   const float* bwd_first_w = SKIP == NL - 1 ? a.p.wpT_in0 : a.p.wpT[NL - 1];
 
   WStream ws{lds, D::buf_floats(NS), 0, wave, lane};
-  if constexpr (TANGENT) ws.issue(a.p.wp[0], chunk_pieces(D::NBH, NS), true);
+  if constexpr (TANGENT && PHASE != 2) ws.issue(a.p.wp[0], chunk_pieces(D::NBH, NS), true);
   else ws.issue(a.p.wpT[NL], chunk_pieces(D::NBH, NS), true);
   if (tid < D::NBH * 32) cvec[tid] = a.p.w_sdf[tid];
   __syncthreads();
@@ -280,7 +293,7 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
   f32x16 accIn[D::NBH], accOut[D::NBH];
   Raw carry;
 
-  if constexpr (TANGENT) {
+  if constexpr (TANGENT && PHASE != 2) {
     // ---- tangent pass (second-order terms): v_l = W_l qb_l ; accIn holds v_{l-1}
     carry = load_src(BlkSrc<1>{{tp_block_ptr(a.ebar_tp, tile, D::NB0, 0)}}, lane);
 #pragma unroll 1
@@ -361,6 +374,7 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
     else return BlkSrc<1>{{tp_block_ptr(a.z_tp[l], tile, D::NBH, b)}};
   };
 
+  if constexpr (PHASE == 1) return;
   // ---- backward pass: ub_NL = w_s sdfbar + W_f^T featbar
   {
     const float sb = a.sdfbar[tile * 32 + (lane & 31)];

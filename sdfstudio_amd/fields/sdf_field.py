@@ -142,18 +142,24 @@ class _FieldFunction(torch.autograd.Function):
         packed = torch.empty(lib.sdfhip_field_packed_size(h), device=dev)
         theta_c = theta.contiguous()  # every contiguous() copy stays bound to a local until the launch has been issued
         _lib.check(lib.sdfhip_field_pack(h, _lib.ptr(theta_c), _lib.ptr(packed), _lib.stream()), "field_pack")
-        ws = torch.empty(lib.sdfhip_field_workspace_size(h, P, 1), dtype=torch.uint8, device=dev)
+        # no gradient will be asked for (torch.no_grad() rendering, frozen parameters): the kernels save nothing and the
+        # workspace is the forward-only one (a quarter of the size)
+        train = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        ws = torch.empty(lib.sdfhip_field_workspace_size(h, P, 1 if train else 2), dtype=torch.uint8, device=dev)
         sdf = torch.empty(NP, device=dev)
         grad = torch.empty(NP, 3, device=dev)
         rgb = torch.empty(NP, 3, device=dev)
         emb_c = None if emb is None else emb.contiguous()
         _lib.check(lib.sdfhip_field_forward(h, _lib.ptr(packed), _lib.ptr(table), _lib.ptr(mask), _lib.ptr(origins),
-                                            _lib.ptr(dirs), _lib.ptr(starts), n, s, _lib.ptr(emb_c), _lib.MODE_FULL, 1,
+                                            _lib.ptr(dirs), _lib.ptr(starts), n, s, _lib.ptr(emb_c), _lib.MODE_FULL, 1 if train else 0,
                                             ctypes.c_void_p(ws.data_ptr()), _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(rgb), None,
                                             _lib.stream()), "field_forward")
-        ctx.save_for_backward(packed, table, mask, ws)
-        ctx.fld, ctx.shape, ctx.has_emb = fld, (n, s), emb is not None
         x = ws[: NP * 12].view(torch.float32).view(NP, 3)[:P].view(n, s, 3)  # contracted positions live first in the workspace
+        if train:
+            ctx.save_for_backward(packed, table, mask, ws)
+            ctx.fld, ctx.shape, ctx.has_emb = fld, (n, s), emb is not None
+        else:
+            x = x.clone()  # lets the workspace go
         ctx.mark_non_differentiable(x)
         return sdf[:P].view(n, s), grad[:P].view(n, s, 3), rgb[:P].view(n, s, 3), x
 

@@ -7,6 +7,8 @@ carry no gradient (bins.detach(), ray_samplers.py:358).  Stratified jitter uses 
 """
 from typing import Callable, List, Optional, Tuple
 
+import ctypes
+
 import torch
 from torch import nn
 
@@ -527,3 +529,110 @@ class UniSurfSampler(Sampler):
         return ray_bundle.get_ray_samples(
             bin_starts=starts[..., None], bin_ends=ends[..., None], spacing_starts=bins[:, :-1, None], spacing_ends=bins[:, 1:, None],
             spacing_to_euclidean_fn=ray_samples_1.spacing_to_euclidean_fn, flat_bins=bins)
+
+
+def march_occupancy_grid(origins, directions, t_min, t_max, roi_aabb, binary, step_size: float):
+    """nerfacc.cuda.ray_marching as the reference calls it (ray_samplers.py:1474-1484): two native launches (count, write) around an
+    exclusive scan.  Returns (packed_info [N,2] int64 = (offset, count), counts [N] int32, ray_indices [P] int64, t_starts [P,1],
+    t_ends [P,1]).  The only host synchronisation is reading the total sample count (the reference's own call returns
+    data-dependent shapes as well)."""
+    lib = _lib.load()
+    n = origins.shape[0]
+    dev = origins.device
+    kp = _lib.Keep()
+    roi = (ctypes.c_float * 6)(*[float(v) for v in roi_aabb.reshape(-1).tolist()])
+    occ = binary.contiguous()
+    assert occ.dtype == torch.bool and occ.dim() == 3 and occ.shape[0] == occ.shape[1] == occ.shape[2]
+    counts = torch.empty(n, dtype=torch.int32, device=dev)
+    o, d, tn, tf = kp(origins), kp(directions), kp(t_min.reshape(-1)), kp(t_max.reshape(-1))
+    _lib.check(lib.sdfhip_march_count(o, d, tn, tf, roi, occ.data_ptr(), n, occ.shape[0], float(step_size), counts.data_ptr(),
+                                      _lib.stream()), "march_count")
+    ends = torch.cumsum(counts.long(), dim=0)
+    offsets = ends - counts.long()
+    total = int(ends[-1].item()) if n > 0 else 0
+    ray_indices = torch.empty(total, dtype=torch.int64, device=dev)
+    t_starts = torch.empty(total, 1, device=dev)
+    t_ends = torch.empty(total, 1, device=dev)
+    if total > 0:
+        _lib.check(lib.sdfhip_march_write(o, d, tn, tf, roi, occ.data_ptr(), n, occ.shape[0], float(step_size), offsets.data_ptr(),
+                                          ray_indices.data_ptr(), _lib.ptr(t_starts), _lib.ptr(t_ends), _lib.stream()), "march_write")
+    del kp
+    return torch.stack([offsets, counts.long()], dim=-1), counts, ray_indices, t_starts, t_ends
+
+
+class NeuSAccSampler(Sampler):
+    """ray_samplers.py:1315-1503: the voxel-surface guided sampler of NeuS-acc.  An occupancy grid over the scene box, pruned every
+    `steps_per_grid_update` steps from the SDF at the voxel centres (update_binary_grid), drives a fixed-step march that only
+    keeps samples in occupied voxels (packed samples: one flat array for all rays); until the first grid update the model runs on
+    the NeuS sampler.  importance_sampling (nerfacc.ray_resampling; off by default, :1326) is not built."""
+
+    def __init__(self, aabb, neus_sampler: Optional[NeuSSampler] = None, resolution: int = 128, num_samples: int = 8,
+                 num_samples_importance: int = 16, num_samples_boundary: int = 10, steps_warpup: int = 2000,
+                 steps_per_grid_update: int = 1000, importance_sampling: bool = False, local_rank: int = 0,
+                 single_jitter: bool = False) -> None:
+        super().__init__()
+        if importance_sampling:
+            raise NotImplementedError("NeuSAccSampler(importance_sampling=True) (nerfacc.ray_resampling) is not built")
+        self.resolution, self.num_samples, self.num_samples_importance = resolution, num_samples, num_samples_importance
+        self.num_samples_boundary, self.single_jitter, self.importance_sampling = num_samples_boundary, single_jitter, importance_sampling
+        self.steps_warpup, self.steps_per_grid_update, self.local_rank = steps_warpup, steps_per_grid_update, local_rank
+        self.step_size = 0.01 / 5.0
+        self.alpha_thres = 0.001
+        assert aabb[0, 0] == aabb[0, 1] and aabb[0, 0] == aabb[0, 2]  # cubic boxes only (:1347-1349)
+        assert aabb[1, 0] == aabb[1, 1] and aabb[1, 0] == aabb[1, 2]
+        self.grid_size = resolution
+        self.voxel_size = float(aabb[1, 0] - aabb[0, 0]) / self.grid_size
+        self.neus_sampler = neus_sampler
+        self.register_buffer("aabb", aabb.clone().float(), persistent=False)
+        self.register_buffer("_binary", torch.ones((self.grid_size,) * 3, dtype=torch.bool))
+        self.register_buffer("_update_counter", torch.zeros(1, dtype=torch.int32))
+        lo, hi = float(aabb[0, 0]) + self.voxel_size / 2.0, float(aabb[1, 0]) - self.voxel_size / 2.0
+        off = torch.linspace(lo, hi, self.grid_size)
+        x, y, z = torch.meshgrid(off, off, off, indexing="ij")
+        self.register_buffer("cube_coordinate", torch.stack([x, y, z], dim=-1).reshape(-1, 3))  # :1362-1377
+
+    def update_step_size(self, step, inv_s=None):
+        """:1379-1382."""
+        assert inv_s is not None
+        self.step_size = 14.0 / float(inv_s()) / 16
+
+    @torch.no_grad()
+    def update_binary_grid(self, step, sdf_fn=None, inv_s=None):
+        """:1383-1432: voxels whose |sdf| minus the half diagonal still gives alpha > 1e-3 stay occupied; pruned voxels never
+        come back.  sdf_fn is the geometry network on explicit points (one native call per 100 000 voxels, like the reference)."""
+        assert sdf_fn is not None and inv_s is not None
+        if step >= self.steps_warpup and step % self.steps_per_grid_update == 0:
+            mask = self._binary.reshape(-1)
+            occupied_voxel = self.cube_coordinate[mask]
+            sdf = torch.cat([sdf_fn(p) for p in torch.split(occupied_voxel, 100000, dim=0)], dim=0) if occupied_voxel.shape[0] else \
+                occupied_voxel.new_zeros(0)
+            bound = self.voxel_size * (3 ** 0.5) / 2.0
+            sdf = torch.maximum(sdf.abs() - bound, torch.zeros_like(sdf))
+            s = inv_s()
+            prev_cdf = torch.sigmoid((sdf + self.step_size * 0.5) * s)
+            next_cdf = torch.sigmoid((sdf - self.step_size * 0.5) * s)
+            alpha = ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).clip(0.0, 1.0)
+            mask[mask.clone()] = alpha > self.alpha_thres
+            self._binary = mask.reshape([self.grid_size] * 3).contiguous()
+            self._update_counter += 1
+
+    def create_ray_samples_from_ray_indices(self, ray_bundle: RayBundle, ray_indices, t_starts, t_ends) -> RaySamples:
+        """:1434-1455.  Packed samples are [P,1] here (every sample its own one-sample ray), the layout the field kernels take."""
+        packed = RayBundle(origins=ray_bundle.origins[ray_indices], directions=ray_bundle.directions[ray_indices],
+                           pixel_area=torch.ones(ray_indices.shape[0], 1, device=t_starts.device),
+                           camera_indices=None if ray_bundle.camera_indices is None else ray_bundle.camera_indices[ray_indices])
+        return packed.get_ray_samples(t_starts[:, None, :], t_ends[:, None, :])
+
+    @torch.no_grad()
+    def generate_ray_samples(self, ray_bundle: Optional[RayBundle] = None, sdf_fn: Optional[Callable] = None,
+                             alpha_fn: Optional[Callable] = None):
+        """:1457-1503.  After the first grid update: (ray_samples [P,1], ray_indices [P]); `packed_info` / `counts` of the call are
+        kept on the sampler for the compositing kernels."""
+        assert ray_bundle is not None and sdf_fn is not None
+        if int(self._update_counter.item()) <= 0:
+            return self.neus_sampler(ray_bundle, sdf_fn=sdf_fn)
+        info, counts, ray_indices, t_starts, t_ends = march_occupancy_grid(
+            ray_bundle.origins, ray_bundle.directions, ray_bundle.nears[:, 0], ray_bundle.fars[:, 0], self.aabb, self._binary,
+            self.step_size)
+        self.packed_info, self.packed_counts = info, counts
+        return self.create_ray_samples_from_ray_indices(ray_bundle, ray_indices, t_starts, t_ends), ray_indices

@@ -159,3 +159,68 @@ class SemanticRenderer(nn.Module):
 
     def forward(self, semantics: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
         return torch.sum(weights * semantics, dim=-2)
+
+
+# ---- packed samples (NeuS-acc): the two nerfacc compositing operators the reference calls (models/neus_acc.py:103-121)
+class _PackedWeights(torch.autograd.Function):
+    """nerfacc.render_weight_from_alpha: w_i = alpha_i prod_{j<i, same ray} (1 - alpha_j) on packed samples."""
+
+    @staticmethod
+    def forward(ctx, alpha, offsets, counts):
+        lib = _lib.load()
+        alpha = alpha.contiguous()
+        weights, trans = torch.empty_like(alpha), torch.empty_like(alpha)
+        _lib.check(lib.sdfhip_packed_weights_forward(_lib.ptr(alpha), offsets.data_ptr(), counts.data_ptr(), counts.shape[0],
+                                                     _lib.ptr(weights), _lib.ptr(trans), _lib.stream()), "packed_weights_forward")
+        ctx.save_for_backward(alpha, weights, trans, offsets, counts)
+        return weights
+
+    @staticmethod
+    def backward(ctx, wbar):
+        alpha, weights, trans, offsets, counts = ctx.saved_tensors
+        lib = _lib.load()
+        abar = torch.empty_like(alpha)
+        kp = _lib.Keep()
+        _lib.check(lib.sdfhip_packed_weights_backward(_lib.ptr(alpha), _lib.ptr(weights), _lib.ptr(trans), kp(wbar), offsets.data_ptr(),
+                                                      counts.data_ptr(), counts.shape[0], _lib.ptr(abar), _lib.stream()),
+                   "packed_weights_backward")
+        del kp
+        return abar, None, None
+
+
+class _PackedAccumulate(torch.autograd.Function):
+    """nerfacc.accumulate_along_rays: out[r] = sum over ray r's samples of w_i values_i (deterministic, no atomics)."""
+
+    @staticmethod
+    def forward(ctx, weights, values, offsets, counts, ray_indices):
+        lib = _lib.load()
+        weights = weights.contiguous()
+        values = None if values is None else values.contiguous()
+        dim = 1 if values is None else values.shape[-1]
+        out = torch.empty(counts.shape[0], dim, device=weights.device)
+        _lib.check(lib.sdfhip_packed_accumulate(_lib.ptr(weights), _lib.ptr(values), offsets.data_ptr(), counts.data_ptr(), counts.shape[0],
+                                                dim, _lib.ptr(out), _lib.stream()), "packed_accumulate")
+        ctx.save_for_backward(weights, values, ray_indices)
+        ctx.has_values = values is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, obar):
+        weights, values, ray_indices = ctx.saved_tensors
+        g = obar[ray_indices]  # [P, D]
+        if not ctx.has_values:
+            return g[:, 0], None, None, None, None
+        return (g * values).sum(-1), weights[:, None] * g, None, None, None
+
+
+def render_weight_from_alpha(alphas: torch.Tensor, packed_info: torch.Tensor, counts: torch.Tensor) -> torch.Tensor:
+    """alphas [P,1] (or [P]) -> weights of the same shape; packed_info [N,2] = (offset, count) int64, counts [N] int32."""
+    w = _PackedWeights.apply(alphas.reshape(-1), packed_info[:, 0].contiguous(), counts)
+    return w.view(alphas.shape)
+
+
+def accumulate_along_rays(weights: torch.Tensor, ray_indices: torch.Tensor, values: Optional[torch.Tensor], packed_info: torch.Tensor,
+                          counts: torch.Tensor) -> torch.Tensor:
+    """weights [P,1] (or [P]), values [P,D] or None -> [N,D] ([N,1])."""
+    v = None if values is None else values.reshape(values.shape[0], -1)
+    return _PackedAccumulate.apply(weights.reshape(-1), v, packed_info[:, 0].contiguous(), counts, ray_indices)

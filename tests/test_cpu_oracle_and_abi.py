@@ -627,3 +627,57 @@ def test_unisurf_sampler_oracle_against_reference(training):
     assert 0 < int(out["mask"].sum()) < n
     ref_sp = o[out["mask"]] + d[out["mask"]] * out["z"][out["mask"]][:, None]
     assert torch.allclose(sp, ref_sp, rtol=1e-5, atol=1e-6)
+
+
+def test_oracle_packed_sample_path_properties():
+    """The packed-sample restatement (nerfacc 0.3.5's ray_marching / render_weight_from_alpha / accumulate_along_rays as the reference
+    calls them; nerfacc itself is absent: parity unpinned for the march) against what the operators are DEFINED to do: every sample's
+    mid point lies in an occupied voxel inside the region, intervals of a ray are disjoint, ordered, `step` wide and inside
+    [t_min, t_max); no occupied stretch of a ray longer than two steps goes unsampled; weights / accumulation equal the naive loops."""
+    gen = torch.Generator().manual_seed(2)
+    R, step, n = 16, 0.04, 40
+    binary = torch.rand(R, R, R, generator=gen) > 0.65
+    o, d, _ = O.synthetic_rays(n, seed=5)
+    d = torch.nn.functional.normalize(d + 0.2 * torch.randn(n, 3, generator=gen), dim=-1)
+    t_min, t_max = torch.full((n,), 0.5), torch.full((n,), 4.5)
+    roi = torch.tensor([-1.0, -1, -1, 1, 1, 1])
+    info, ri, ts, te = O.ray_marching(o, d, t_min, t_max, roi, binary, step)
+    assert int(info[:, 1].sum()) == ri.shape[0] > 200
+    assert torch.equal(info[:, 0], torch.cumsum(info[:, 1], 0) - info[:, 1])
+    mid = (ts + te)[:, 0] / 2
+    p = o[ri] + d[ri] * mid[:, None]
+
+    def occupied(q):
+        inside = ((q >= -1) & (q <= 1)).all(-1)
+        idx = ((q + 1) / 2 * R).floor().long().clamp(0, R - 1)
+        return inside & binary[idx[:, 0], idx[:, 1], idx[:, 2]]
+
+    assert bool(occupied(p).all())
+    assert torch.allclose(te - ts, torch.full_like(ts, step), atol=1e-6)
+    for r, (off, cnt) in enumerate(info.tolist()):
+        s, e = ts[off:off + cnt, 0], te[off:off + cnt, 0]
+        assert bool((s[1:] >= e[:-1] - 1e-6).all()) and (cnt == 0 or (float(s[0]) >= 0.5 - 1e-6 and float(mid[off + cnt - 1]) < 4.5))
+        # completeness: walk the ray finely; an occupied stretch longer than two steps must contain a sample mid point
+        tt = torch.arange(0.5, 4.5, step / 8)
+        occ_t = occupied(o[r] + d[r] * tt[:, None])
+        mids = mid[off:off + cnt]
+        run_start = None
+        for i, flag in enumerate(occ_t.tolist() + [False]):
+            if flag and run_start is None:
+                run_start = i
+            if not flag and run_start is not None:
+                a, b = float(tt[run_start]), float(tt[i - 1])
+                if b - a > 2 * step:
+                    assert bool(((mids > a - step) & (mids < b + step)).any()), (r, a, b)
+                run_start = None
+    alpha = torch.rand(ri.shape[0], generator=gen) * 0.3
+    w = O.packed_weights_from_alpha(alpha, info)
+    vals = torch.randn(ri.shape[0], 2, generator=gen)
+    acc = O.accumulate_along_rays(w, ri, vals, n)
+    for r, (off, cnt) in enumerate(info.tolist()):
+        T, tot = 1.0, torch.zeros(2)
+        for i in range(off, off + cnt):
+            assert abs(float(w[i]) - float(alpha[i]) * T) < 1e-6
+            tot += w[i] * vals[i]
+            T *= 1.0 - float(alpha[i])
+        assert torch.allclose(acc[r], tot, atol=1e-5)

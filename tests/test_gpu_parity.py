@@ -1657,3 +1657,131 @@ def test_analytic_gradient_on_points_and_unisurf_step(device):
         assert gr is not None and torch.isfinite(gr).all() and gr.abs().max() > 0, k
     model.after_train_iteration(100)
     assert model.sampler.delta < 0.25
+
+
+# ------------------------------------------------------------------------------------------------ packed-sample path (NeuS-acc)
+@pytest.mark.parametrize("res,step", [(16, 0.05), (32, 0.013)])
+def test_occupancy_grid_marching(device, res, step):
+    """sdfhip_march_count / _write (nerfacc.cuda.ray_marching as called at ray_samplers.py:1474-1484) against the fp32 oracle:
+    sample counts, ray indices and interval ends bit for bit, on a random occupancy grid with rays that miss the box, graze it
+    and cross it (parity unpinned: nerfacc is absent, the oracle restates its published algorithm)."""
+    from sdfstudio_amd.model_components.ray_samplers import march_occupancy_grid
+
+    gen = torch.Generator().manual_seed(res)
+    binary = torch.rand(res, res, res, generator=gen) > 0.6
+    n = 96
+    o, d, _ = O.synthetic_rays(n, seed=7)
+    d = F.normalize(d + 0.25 * torch.randn(n, 3, generator=gen), dim=-1)
+    t_min, t_max = torch.full((n,), 0.5), torch.full((n,), 4.5)
+    t_max[:7] = 0.4  # empty intervals
+    roi = torch.tensor([-1.0, -1, -1, 1, 1, 1])
+    info, ri, ts, te = O.ray_marching(o, d, t_min, t_max, roi, binary, step)
+    g_info, g_counts, g_ri, g_ts, g_te = march_occupancy_grid(o.to(device), d.to(device), t_min.to(device), t_max.to(device), roi,
+                                                              binary.to(device), step)
+    assert int(info[:, 1].sum()) > 500 and int((info[:, 1] == 0).sum()) >= 7
+    assert torch.equal(g_info.cpu(), info) and torch.equal(g_counts.cpu().long(), info[:, 1])
+    assert torch.equal(g_ri.cpu(), ri)
+    assert torch.equal(g_ts.cpu(), ts) and torch.equal(g_te.cpu(), te)
+
+
+def test_packed_weights_and_accumulate_fwd_bwd(device):
+    """nerfacc.render_weight_from_alpha / accumulate_along_rays (models/neus_acc.py:103-121) on packed samples: segments of 0, 1,
+    63..200 samples (several 64-sample rounds), alphas that are exactly 0 and exactly 1, forward and backward against autograd
+    through the oracle's definitions."""
+    from sdfstudio_amd.model_components.renderers import accumulate_along_rays, render_weight_from_alpha
+
+    gen = torch.Generator().manual_seed(4)
+    counts = torch.tensor([0, 1, 63, 64, 65, 0, 200, 17, 128, 0, 5], dtype=torch.int64)
+    offs = torch.cumsum(counts, 0) - counts
+    info = torch.stack([offs, counts], -1)
+    P = int(counts.sum())
+    ri = torch.repeat_interleave(torch.arange(len(counts)), counts)
+    alpha = torch.rand(P, generator=gen) * 0.2
+    alpha[torch.rand(P, generator=gen) < 0.05] = 0.0
+    alpha[int(offs[6]) + 150] = 1.0  # ends ray 6 early
+    values = torch.randn(P, 3, generator=gen)
+    co = [torch.randn(len(counts), 3, generator=gen), torch.randn(len(counts), 1, generator=gen), torch.randn(P, generator=gen)]
+
+    a_ref = alpha.clone().double().requires_grad_(True)
+    v_ref = values.clone().double().requires_grad_(True)
+    w_ref = O.packed_weights_from_alpha(a_ref, info)
+    out_ref = O.accumulate_along_rays(w_ref, ri, v_ref, len(counts))
+    acc_ref = O.accumulate_along_rays(w_ref, ri, None, len(counts))
+    ((out_ref * co[0].double()).sum() + (acc_ref * co[1].double()).sum() + (w_ref * co[2].double()).sum()).backward()
+
+    a = alpha.clone().to(device).requires_grad_(True)
+    v = values.clone().to(device).requires_grad_(True)
+    g_info, g_counts, g_ri = info.to(device), counts.to(torch.int32).to(device), ri.to(device)
+    w = render_weight_from_alpha(a, g_info, g_counts)
+    out = accumulate_along_rays(w, g_ri, v, g_info, g_counts)
+    acc = accumulate_along_rays(w, g_ri, None, g_info, g_counts)
+    ((out * co[0].to(device)).sum() + (acc * co[1].to(device)).sum() + (w * co[2].to(device)).sum()).backward()
+    assert_close("packed weights", w, w_ref.float(), rtol=1e-5, atol=1e-7)
+    assert_close("accumulated values", out, out_ref.float(), rtol=1e-5, atol=1e-6)
+    assert_close("accumulation", acc, acc_ref.float(), rtol=1e-5, atol=1e-6)
+    assert_close("d / d alpha", a.grad, a_ref.grad.float(), rtol=1e-4, atol=1e-6)
+    assert_close("d / d values", v.grad, v_ref.grad.float(), rtol=1e-5, atol=1e-7)
+    assert float(w[int(offs[6]) + 151:int(offs[6]) + 200].abs().max()) == 0.0  # nothing passes an alpha of 1
+
+
+def test_neus_acc_model_packed_path(device):
+    """NeuSAccModel (models/neus_acc.py:92-143) after its first occupancy-grid update (ray_samplers.py:1383-1432), on a geometric-init
+    field (a sphere of radius 0.5): the pruned grid against the oracle's update rule, the packed samples against the oracle's march,
+    rendered rgb / depth / normal / accumulation against the oracle's field + compositing on those samples, and one backward."""
+    from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
+    from sdfstudio_amd.models.neus_acc import NeuSAccModel, NeuSAccModelConfig
+    from sdfstudio_amd.models.neus_facto import SceneBox
+    from helpers import load_params
+
+    cfg = small_oracle_cfg()
+    fc = cfg.field
+    params = O.init_field_params(fc, num_images=49, seed=3)
+    params["deviation_network.variance"] = torch.tensor([0.5])  # a trained-looking sharpness: inv_s = e^5, march step 5.9e-3
+    fcfg = SDFFieldConfig(num_layers=fc.num_layers, hidden_dim=fc.hidden_dim, geo_feat_dim=fc.geo_feat_dim, num_layers_color=fc.num_layers_color,
+                          hidden_dim_color=fc.hidden_dim_color, bias=fc.bias, inside_outside=fc.inside_outside, use_grid_feature=True,
+                          beta_init=fc.beta_init, num_levels=fc.num_levels, max_res=fc.max_res, base_res=fc.base_res,
+                          log2_hashmap_size=fc.log2_hashmap_size, hash_features_per_level=fc.hash_features_per_level,
+                          hash_smoothstep=fc.hash_smoothstep)
+    box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=cfg.near, far=cfg.far)
+    model = NeuSAccModel(NeuSAccModelConfig(sdf_field=fcfg, num_samples=16, num_samples_importance=16, num_up_sample_steps=2), box, 49)
+    load_params(model, params)
+    model = model.to(device).train()
+    smp = model.sampler
+    assert smp.resolution == 128 and int(smp._update_counter) == 0
+    model.before_train_iteration(2000)  # step size from the variance (:1379-1382)
+    inv_s = O.neus_inv_s(params["deviation_network.variance"])
+    assert abs(smp.step_size - 14.0 / float(inv_s) / 16) < 1e-9
+    model.after_train_iteration(2000)   # first grid update
+    assert int(smp._update_counter) == 1
+    ref_binary = O.neus_acc_binary_update(torch.ones(128, 128, 128, dtype=torch.bool), smp.cube_coordinate.cpu(),
+                                          lambda x: O.geo_network(x, params, fc)[:, 0], inv_s, smp.voxel_size, smp.step_size)
+    occ = smp._binary.cpu()
+    assert 0.001 < float(ref_binary.float().mean()) < 0.5, float(ref_binary.float().mean())
+    assert float((occ != ref_binary).float().mean()) < 1e-4  # voxels within round-off of the threshold may differ
+
+    n = 64
+    o, d, cam = O.synthetic_rays(n, seed=13)
+    d = F.normalize(d + 0.1 * torch.randn(n, 3), dim=-1)
+    out = model(_bundle(o, d, cam, cfg.near, cfg.far, device))
+    info, ri, ts, te = O.ray_marching(o, d, torch.full((n,), cfg.near), torch.full((n,), cfg.far), torch.tensor([-1.0, -1, -1, 1, 1, 1]), occ,
+                                      smp.step_size)
+    assert ri.shape[0] > 100 and torch.equal(out["ray_indices"].cpu(), ri)
+    assert torch.equal(out["ray_samples"].flat_starts.cpu(), ts) and torch.equal(out["ray_samples"].flat_ends.cpu(), te)
+    with torch.no_grad():
+        fo = O.field_outputs(o[ri], d[ri], ts, te - ts, cam[ri], params, fc, cos_anneal_ratio=model.field._cos_anneal_ratio, training=True)
+    w = O.packed_weights_from_alpha(fo["alpha"][:, 0], info)
+    assert_close("packed weights", out["packed_weights"][:, 0], w, rtol=1e-4, atol=1e-6)
+    assert_close("rgb", out["rgb"], O.accumulate_along_rays(w, ri, fo["rgb"][:, 0], n), rtol=1e-4, atol=1e-5)
+    assert_close("normal", out["normal"], O.accumulate_along_rays(w, ri, fo["normal"][:, 0], n), rtol=1e-4, atol=1e-5)
+    assert_close("accumulation", out["accumulation"], O.accumulate_along_rays(w, ri, None, n), rtol=1e-4, atol=1e-5)
+    assert_close("depth", out["depth"], O.accumulate_along_rays(w, ri, (ts + te) / 2, n), rtol=1e-4, atol=1e-5)
+    losses = model.get_loss_dict(out, {"image": torch.rand(n, 3)})
+    model.zero_grad()
+    sum(losses.values()).backward()
+    for k in ("field.glin0.weight_v", "field.clin0.weight_v", "field.encoding.params", "field.deviation_network.variance"):
+        gr = dict(model.named_parameters())[k].grad
+        assert gr is not None and torch.isfinite(gr).all() and gr.abs().max() > 0, k
+    # rays that hit nothing: all-zero outputs, still a valid training step
+    far_bundle = _bundle(o + 10.0, d, cam, cfg.near, cfg.far, device)
+    out0 = model(far_bundle)
+    assert float(out0["rgb"].abs().max()) == 0.0 and out0["eik_grad"].shape == (n, 3)
