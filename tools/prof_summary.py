@@ -54,12 +54,14 @@ if rows:
         w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
         w.writeheader()
         w.writerows(rows[:24])
-    for r in rows:
-        if r["kernel"].startswith("geo_bwd_kernel"):
-            json.dump({"kernel": "geo_bwd_kernel", "hbm_read_bytes": r["hbm_read_GB_corrected_x2"] * 1e9, "hbm_write_bytes": r["hbm_write_GB"] * 1e9,
-                       "source": f"profiles/{tag}_pmc_summary.csv: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), FETCH_SIZE "
-                                 "doubled per MI355X_MICROARCH.md (gfx950 reports half of a coalesced stream)"},
-                      open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+    # the dominant kernel runs as two launches per step (tangent pass | data backward, geo_kernels.h PHASE): its traffic is their sum
+    gb = [r for r in rows if r["kernel"].startswith("geo_bwd_kernel")]
+    if gb:
+        json.dump({"kernel": "geo_bwd_kernel", "launches_per_step": len(gb),
+                   "hbm_read_bytes": sum(r["hbm_read_GB_corrected_x2"] for r in gb) * 1e9, "hbm_write_bytes": sum(r["hbm_write_GB"] for r in gb) * 1e9,
+                   "source": f"profiles/{tag}_pmc_summary.csv: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), FETCH_SIZE "
+                             "doubled per MI355X_MICROARCH.md (gfx950 reports half of a coalesced stream); sum over the kernel's launches of a step"},
+                  open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 # whole-step HBM bytes: every kernel's average launch traffic x its launches in the sampled steps (the PMC passes run
 # bench.py --steps 2 --warmup 1 --no-forward-only: 3 training steps and nothing else)
 if rows:
