@@ -47,6 +47,15 @@ typedef struct {
 /* Host-only: per-level table (no GPU needed). levels: [n_levels]. Returns total entries via n_entries. */
 int sdfhip_grid_levels(const SdfHipGridCfg* cfg, SdfHipGridLevel* levels, int64_t* n_entries);
 
+/* The encoding as a standalone operator - what the reference gets from tcnn.Encoding("HashGrid") where it is not fused into a
+ * field kernel (fields/nerfacto_field.py:137-156, the background field of BASELINE config 5).  x: [n_points, 3] in [0,1]
+ * (positions outside wrap like tiny-cuda-nn's); feat: [n_points, n_levels * n_features] row-major, level-major columns.
+ * Backward: table_bar (same shape as the table) is ACCUMULATED with atomics (caller zeroes); no gradient w.r.t. x. */
+int sdfhip_grid_encode_forward(const SdfHipGridCfg* grid, const float* table, const float* x, int64_t n_points, float* feat,
+                               sdfhip_stream_t stream);
+int sdfhip_grid_encode_backward(const SdfHipGridCfg* grid, const float* x, int64_t n_points, const float* feat_bar, float* table_bar,
+                                sdfhip_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------- SDF field
  * Replaces nerfstudio.fields.sdf_field.SDFField's compute: forward_geonetwork (:380-410), get_sdf (:412-418),
  * the analytic gradient (:646-654), get_colors (:532-612), and their autograd backward (including the

@@ -133,6 +133,14 @@ class _ShimEncoding(nn.Module):
 
     def __init__(self, n_input_dims, encoding_config, seed=1337, dtype=None):
         super().__init__()
+        self.otype = encoding_config["otype"]
+        if self.otype == "SphericalHarmonics":  # fields/nerfacto_field.py:128-134 (degree 4): the oracle's restatement
+            assert n_input_dims == 3 and encoding_config["degree"] == 4
+            self.n_output_dims = 16
+            return
+        if self.otype == "Frequency":  # :136-139, only consumed by the predicted-normal head (off): shape only
+            self.n_output_dims = n_input_dims * 2 * encoding_config["n_frequencies"]
+            return
         assert n_input_dims == 3 and encoding_config["otype"] in ("HashGrid", "Grid")
         self.levels = hashgrid.make_levels(
             n_levels=encoding_config["n_levels"],
@@ -148,6 +156,12 @@ class _ShimEncoding(nn.Module):
         self.params = nn.Parameter(init)
 
     def forward(self, x):
+        if self.otype == "SphericalHarmonics":
+            from oracle import sdf_path
+
+            return sdf_path.sh_degree4(x)
+        if self.otype == "Frequency":
+            raise NotImplementedError("Frequency encoding shim: shape only")
         table = self.params.view(self.levels.n_entries, self.levels.n_features)
         return hashgrid.grid_encode(x, table, self.levels)
 
@@ -180,11 +194,35 @@ class _ShimNetworkWithInputEncoding(nn.Module):
         return torch.relu(f @ self.w1.t()) @ self.w2.t()
 
 
+class _ShimNetwork(nn.Module):
+    """tcnn.Network(FullyFusedMLP: ReLU hidden layers, no biases, optional sigmoid output) on CPU fp32; weights w1 .. wK [out, in]."""
+
+    def __init__(self, n_input_dims, n_output_dims, network_config, seed=1337):
+        super().__init__()
+        h, k = network_config["n_neurons"], network_config["n_hidden_layers"]
+        assert network_config["activation"] == "ReLU" and network_config["output_activation"] in ("None", "Sigmoid")
+        self.sigmoid = network_config["output_activation"] == "Sigmoid"
+        gen = torch.Generator().manual_seed(seed + 2)
+        dims = [n_input_dims] + [h] * k + [n_output_dims]
+        self.n_layers = len(dims) - 1
+        for i in range(self.n_layers):
+            a = float(np.sqrt(6.0 / (dims[i] + dims[i + 1])))
+            setattr(self, f"w{i + 1}", nn.Parameter((torch.rand(dims[i + 1], dims[i], generator=gen) * 2 - 1) * a))
+        self.n_output_dims = n_output_dims
+
+    def forward(self, x):
+        for i in range(self.n_layers):
+            x = x @ getattr(self, f"w{i + 1}").t()
+            if i + 1 < self.n_layers:
+                x = torch.relu(x)
+        return torch.sigmoid(x) if self.sigmoid else x
+
+
 def install_tcnn_shim():
     m = types.ModuleType("tinycudann")
     m.Encoding = _ShimEncoding
     m.NetworkWithInputEncoding = _ShimNetworkWithInputEncoding
-    m.Network = _Anything
+    m.Network = _ShimNetwork
     sys.modules["tinycudann"] = m
 
 

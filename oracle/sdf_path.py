@@ -940,3 +940,47 @@ def neus_acc_binary_update(binary: torch.Tensor, cube_coordinate: torch.Tensor, 
     alpha = ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).clip(0.0, 1.0)
     mask[mask.clone()] = alpha > alpha_thres
     return mask.reshape(binary.shape)
+
+
+# ----------------------------------------------------------------------------- "grid" background field (BASELINE config 5)
+def sh_degree4(d01: torch.Tensor) -> torch.Tensor:
+    """tiny-cuda-nn's SphericalHarmonics encoding of degree 4 (spherical_harmonics.h of NVlabs/tiny-cuda-nn; the dependency is absent
+    from /root/reference: PARITY UNPINNED, like the hash grid).  Input in [0,1]^3, mapped to [-1,1]^3 inside."""
+    v = d01 * 2.0 - 1.0
+    x, y, z = v[..., 0], v[..., 1], v[..., 2]
+    xy, xz, yz, x2, y2, z2 = x * y, x * z, y * z, x * x, y * y, z * z
+    return torch.stack([
+        torch.full_like(x, 0.28209479177387814),
+        -0.48860251190291987 * y, 0.48860251190291987 * z, -0.48860251190291987 * x,
+        1.0925484305920792 * xy, -1.0925484305920792 * yz, 0.94617469575755997 * z2 - 0.31539156525251999,
+        -1.0925484305920792 * xz, 0.54627421529603959 * x2 - 0.54627421529603959 * y2,
+        0.59004358992664352 * y * (-3.0 * x2 + y2), 2.8906114426405538 * xy * z, 0.45704579946446572 * y * (1.0 - 5.0 * z2),
+        0.3731763325901154 * z * (5.0 * z2 - 3.0), 0.45704579946446572 * x * (1.0 - 5.0 * z2),
+        1.4453057213202769 * z * (x2 - y2), 0.59004358992664352 * x * (-x2 + 3.0 * y2),
+    ], dim=-1)
+
+
+def nerfacto_field(origins, dirs, starts, ends, cam_idx, p: Params, prefix: str, lv: "hashgrid.GridLevels", geo_feat_dim: int = 15,
+                   training: bool = True, contraction: str = "inf") -> Dict[str, torch.Tensor]:
+    """TCNNNerfactoField.forward (fields/nerfacto_field.py:225-330) as base_surface_model.py:181-187 builds it: contracted frustum
+    MID points -> (x + 2) / 4 -> hash grid -> ReLU MLP without biases -> trunc_exp density + features; SH(view dir) | features |
+    appearance embedding -> ReLU MLP -> sigmoid rgb.  Parameters under `prefix`: mlp_base.{table, w1, w2}, mlp_head.{w1, w2, w3},
+    embedding_appearance.embedding.weight."""
+    n, s = starts.shape
+    mid = (starts + ends) / 2
+    pos = origins[:, None, :] + dirs[:, None, :] * mid[..., None]
+    x = (contract_inf if contraction == "inf" else contract_l2)(pos.reshape(-1, 3))
+    x = (x + 2.0) / 4.0
+    table = p[f"{prefix}mlp_base.table"].view(lv.n_entries, lv.n_features)
+    feat = hashgrid.grid_encode(x, table, lv)
+    h = torch.relu(feat @ p[f"{prefix}mlp_base.w1"].t()) @ p[f"{prefix}mlp_base.w2"].t()
+    density = trunc_exp(h[:, :1])
+    d = sh_degree4(((dirs + 1.0) / 2.0)[:, None, :].expand(n, s, 3).reshape(-1, 3))
+    dim = p[f"{prefix}embedding_appearance.embedding.weight"].shape[1]
+    if training:
+        emb = p[f"{prefix}embedding_appearance.embedding.weight"][cam_idx][:, None, :].expand(n, s, -1).reshape(n * s, -1)
+    else:
+        emb = torch.zeros(n * s, dim, dtype=x.dtype)
+    hh = torch.cat([d, h[:, 1:1 + geo_feat_dim], emb], dim=-1)
+    rgb = torch.sigmoid(torch.relu(torch.relu(hh @ p[f"{prefix}mlp_head.w1"].t()) @ p[f"{prefix}mlp_head.w2"].t()) @ p[f"{prefix}mlp_head.w3"].t())
+    return {"density": density.view(n, s), "rgb": rgb.view(n, s, 3)}

@@ -12,6 +12,7 @@
 #include "point_kernels.h"
 #include "ray_kernels.h"
 #include "packed_kernels.h"
+#include "grid_encode_kernels.h"
 
 const FieldKernels* sdfhip_kernels_A();
 const FieldKernels* sdfhip_kernels_B();
@@ -1329,6 +1330,42 @@ extern "C" int sdfhip_surface_root(const float* sdf, const float* starts, const 
   a.new_nears = new_nears;
   a.new_fars = new_fars;
   surface_root_kernel<<<(unsigned)((n_rays + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- standalone hash-grid encoding (tcnn.Encoding("HashGrid") outside the fused fields)
+extern "C" int sdfhip_grid_encode_forward(const SdfHipGridCfg* grid, const float* table, const float* x, int64_t n_points, float* feat,
+                                          sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(grid && table && x && feat, "grid_encode_forward: null argument");
+  SDFHIP_REQUIRE(grid->n_features >= 2 && grid->n_features % 2 == 0, "grid_encode: n_features must be even");
+  if (n_points == 0) return 0;
+  GridEncodeArgs a;
+  memset(&a, 0, sizeof(a));
+  const int rc = make_grid_dev(grid, &a.grid);
+  if (rc != 0) return rc;
+  a.x = x;
+  a.n_points = n_points;
+  a.table = table;
+  a.feat = feat;
+  grid_encode_kernel<false><<<dim3((unsigned)((n_points + 255) / 256), grid->n_levels * (grid->n_features / 2)), 256, 0, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int sdfhip_grid_encode_backward(const SdfHipGridCfg* grid, const float* x, int64_t n_points, const float* feat_bar,
+                                           float* table_bar, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(grid && x && feat_bar && table_bar, "grid_encode_backward: null argument");
+  SDFHIP_REQUIRE(grid->n_features >= 2 && grid->n_features % 2 == 0, "grid_encode: n_features must be even");
+  if (n_points == 0) return 0;
+  GridEncodeArgs a;
+  memset(&a, 0, sizeof(a));
+  const int rc = make_grid_dev(grid, &a.grid);
+  if (rc != 0) return rc;
+  a.x = x;
+  a.n_points = n_points;
+  a.featbar = feat_bar;
+  a.tablebar = table_bar;
+  grid_encode_kernel<true><<<dim3((unsigned)((n_points + 255) / 256), grid->n_levels * (grid->n_features / 2)), 256, 0, (hipStream_t)stream>>>(a);
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -1,0 +1,167 @@
+"""The "grid" background field of the surface models: nerfstudio/fields/nerfacto_field.py:65-332 (TCNNNerfactoField) as
+base_surface_model.py:181-187 builds it for BASELINE config 5 (neus-facto-angelo / bakedangelo, method_configs.py:423): a
+16-level hash grid + 2-layer 64-wide ReLU MLP -> (density, 15 geometry features), then spherical harmonics of the view direction
++ features + appearance embedding -> 3-layer 64-wide ReLU MLP -> sigmoid rgb.
+
+The reference builds every piece from tiny-cuda-nn (HashGrid, FullyFusedMLP without biases, SphericalHarmonics degree 4); here the
+hash-grid encoding is the sdfhip operator (sdfhip_grid_encode_forward / _backward, csrc/grid_encode_kernels.h), the two small MLPs
+and the harmonics are torch ops on device tensors (rocBLAS) - NOT hand-written kernels, stated plainly; this field is off BASELINE
+config 2's path.  Optional heads of the reference (transients, semantics, predicted normals: all off in the surface models) raise.
+tcnn keeps each network's weights in one fp16 ``params`` vector in an internal padded layout, so reference checkpoints of THIS field do
+not load (fp32 ``mlp_base.{table, w1, w2}``, ``mlp_head.{w1, w2, w3}`` here), as for the proposal networks.
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from sdfstudio_amd import _lib
+from sdfstudio_amd.fields.field_heads import FieldHeadNames
+
+
+class _GridEncode(torch.autograd.Function):
+    """tcnn.Encoding("HashGrid"): x [P,3] in [0,1] -> features [P, L*F]; gradient w.r.t. the table only."""
+
+    @staticmethod
+    def forward(ctx, table, x, cfg):
+        lib = _lib.load()
+        x = x.contiguous()
+        feat = torch.empty(x.shape[0], cfg.n_levels * cfg.n_features, device=x.device)
+        _lib.check(lib.sdfhip_grid_encode_forward(cfg, _lib.ptr(table), _lib.ptr(x), x.shape[0], _lib.ptr(feat), _lib.stream()),
+                   "grid_encode_forward")
+        ctx.save_for_backward(x)
+        ctx.cfg, ctx.n_table = cfg, table.numel()
+        return feat
+
+    @staticmethod
+    def backward(ctx, fbar):
+        (x,) = ctx.saved_tensors
+        lib = _lib.load()
+        tbar = torch.zeros(ctx.n_table, device=x.device)
+        kp = _lib.Keep()
+        _lib.check(lib.sdfhip_grid_encode_backward(ctx.cfg, _lib.ptr(x), x.shape[0], kp(fbar), _lib.ptr(tbar), _lib.stream()),
+                   "grid_encode_backward")
+        del kp
+        return tbar, None, None
+
+
+def hash_grid_encode(table: torch.Tensor, x: torch.Tensor, cfg) -> torch.Tensor:
+    return _GridEncode.apply(table, x, cfg)
+
+
+def sh_degree4(d: torch.Tensor) -> torch.Tensor:
+    """tiny-cuda-nn's SphericalHarmonics encoding, degree 4 (16 real harmonics), on directions given in [0,1]^3 (the encoding maps
+    them back to [-1,1]^3 itself; nerfacto_field.py:128-134 feeds get_normalized_directions(d) = (d + 1) / 2)."""
+    v = d * 2.0 - 1.0
+    x, y, z = v[..., 0], v[..., 1], v[..., 2]
+    xy, xz, yz, x2, y2, z2 = x * y, x * z, y * z, x * x, y * y, z * z
+    return torch.stack([
+        torch.full_like(x, 0.28209479177387814),
+        -0.48860251190291987 * y, 0.48860251190291987 * z, -0.48860251190291987 * x,
+        1.0925484305920792 * xy, -1.0925484305920792 * yz, 0.94617469575755997 * z2 - 0.31539156525251999,
+        -1.0925484305920792 * xz, 0.54627421529603959 * x2 - 0.54627421529603959 * y2,
+        0.59004358992664352 * y * (-3.0 * x2 + y2), 2.8906114426405538 * xy * z, 0.45704579946446572 * y * (1.0 - 5.0 * z2),
+        0.3731763325901154 * z * (5.0 * z2 - 3.0), 0.45704579946446572 * x * (1.0 - 5.0 * z2),
+        1.4453057213202769 * z * (x2 - y2), 0.59004358992664352 * x * (-x2 + 3.0 * y2),
+    ], dim=-1)
+
+
+class _TruncExp(torch.autograd.Function):
+    """field_components/activations.py:23-39: exp forward, gradient exp(clamp(x, -15, 15))."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return g * torch.exp(x.clamp(-15, 15))
+
+
+def _xavier(o: int, i: int) -> nn.Parameter:
+    a = math.sqrt(6.0 / (i + o))
+    return nn.Parameter((torch.rand(o, i) * 2 - 1) * a)  # tcnn FullyFusedMLP: xavier_uniform, no biases
+
+
+class _BaseParams(nn.Module):
+    def __init__(self, n_table: int, d_in: int, hidden: int, d_out: int):
+        super().__init__()
+        self.table = nn.Parameter((torch.rand(n_table) * 2 - 1) * 1e-4)  # tcnn grid init U(-1e-4, 1e-4)
+        self.w1, self.w2 = _xavier(hidden, d_in), _xavier(d_out, hidden)
+
+
+class _HeadParams(nn.Module):
+    def __init__(self, d_in: int, hidden: int, d_out: int):
+        super().__init__()
+        self.w1, self.w2, self.w3 = _xavier(hidden, d_in), _xavier(hidden, hidden), _xavier(d_out, hidden)
+
+
+class TCNNNerfactoField(nn.Module):
+    """nerfacto_field.py:65-332 with the defaults base_surface_model.py:181-187 relies on."""
+
+    def __init__(self, aabb, num_images: int, num_layers: int = 2, hidden_dim: int = 64, geo_feat_dim: int = 15, num_levels: int = 16,
+                 max_res: int = 1024, log2_hashmap_size: int = 19, num_layers_color: int = 3, hidden_dim_color: int = 64,
+                 appearance_embedding_dim: int = 32, use_transient_embedding: bool = False, use_semantics: bool = False,
+                 use_pred_normals: bool = False, use_average_appearance_embedding: bool = False, spatial_distortion=None) -> None:
+        super().__init__()
+        if use_transient_embedding or use_semantics or use_pred_normals:
+            raise NotImplementedError("transient / semantic / predicted-normal heads of TCNNNerfactoField are not built (off in the surface models)")
+        if num_layers != 2 or num_layers_color != 3:
+            raise NotImplementedError("built for the reference's defaults: 2-layer base MLP, 3-layer colour MLP")
+        self.aabb = nn.Parameter(torch.as_tensor(aabb, dtype=torch.float32).clone(), requires_grad=False)  # a Parameter in the reference too (:110)
+        self.geo_feat_dim, self.num_images, self.appearance_embedding_dim = geo_feat_dim, num_images, appearance_embedding_dim
+        self.spatial_distortion = spatial_distortion
+        self.use_average_appearance_embedding = use_average_appearance_embedding
+        from sdfstudio_amd.fields.sdf_field import _Embedding
+
+        self.embedding_appearance = _Embedding(num_images, appearance_embedding_dim)  # field_components/embedding.py (:116)
+        base_res, features_per_level = 16, 2
+        growth = math.exp((math.log(max_res) - math.log(base_res)) / (num_levels - 1))
+        self.grid_cfg = _lib.GridCfg(num_levels, features_per_level, log2_hashmap_size, base_res, growth, 0)
+        _, n_entries = _lib.grid_levels(self.grid_cfg)
+        self.mlp_base = _BaseParams(n_entries * features_per_level, num_levels * features_per_level, hidden_dim, 1 + geo_feat_dim)
+        self.mlp_head = _HeadParams(16 + geo_feat_dim + appearance_embedding_dim, hidden_dim_color, 3)
+
+    def get_density(self, ray_samples):
+        """:225-246: contracted frustum MID points -> (x + 2) / 4 -> hash grid -> MLP -> trunc_exp of the first output."""
+        positions = ray_samples.frustums.get_positions()
+        if self.spatial_distortion is not None:
+            positions = (self.spatial_distortion(positions) + 2.0) / 4.0
+        else:
+            positions = (positions - self.aabb[0]) / (self.aabb[1] - self.aabb[0])  # SceneBox.get_normalized_positions
+        shape = positions.shape[:-1]
+        feat = hash_grid_encode(self.mlp_base.table, positions.reshape(-1, 3).detach().float(), self.grid_cfg)
+        h = torch.relu(feat @ self.mlp_base.w1.t()) @ self.mlp_base.w2.t()
+        h = h.view(*shape, -1)
+        density = _TruncExp.apply(h[..., :1])
+        return density, h[..., 1:]
+
+    def get_outputs(self, ray_samples, density_embedding: Optional[torch.Tensor] = None) -> Dict:
+        """:248-330."""
+        assert density_embedding is not None
+        if ray_samples.camera_indices is None:
+            raise AttributeError("Camera indices are not provided.")
+        shape = density_embedding.shape[:-1]
+        directions = (ray_samples.frustums.directions.expand(*shape, 3) + 1.0) / 2.0  # get_normalized_directions
+        d = sh_degree4(directions.reshape(-1, 3))
+        if self.training:
+            emb = self.embedding_appearance(ray_samples.camera_indices.reshape(shape[0], -1)[:, 0])
+            emb = emb[:, None, :].expand(*shape, -1) if len(shape) == 2 else emb
+        elif self.use_average_appearance_embedding:
+            emb = self.embedding_appearance.mean(dim=0).expand(*shape, -1)
+        else:
+            emb = torch.zeros(*shape, self.appearance_embedding_dim, device=d.device)
+        h = torch.cat([d, density_embedding.reshape(-1, self.geo_feat_dim), emb.reshape(-1, self.appearance_embedding_dim)], dim=-1)
+        p = self.mlp_head
+        rgb = torch.sigmoid(torch.relu(torch.relu(h @ p.w1.t()) @ p.w2.t()) @ p.w3.t())
+        return {FieldHeadNames.RGB: rgb.view(*shape, 3)}
+
+    def forward(self, ray_samples) -> Dict:
+        """fields/base_field.py:111-126."""
+        density, emb = self.get_density(ray_samples)
+        out = self.get_outputs(ray_samples, density_embedding=emb)
+        out[FieldHeadNames.DENSITY] = density
+        return out

@@ -6,8 +6,8 @@ Two mechanisms exist in the reference and both are mirrored:
     shaded by the background field (base_surface_model.py:314-329);
   * NeuS-facto (neus_facto.py:289-290): the background field is evaluated on the SDF samples themselves and replaces alpha and
     colour of the samples outside the unit sphere (forward_background_field_and_merge, base_surface_model.py:266-290).
-The samplers, positions and compositing run on device tensors / sdfhip kernels; the background MLP is torch (see
-fields/vanilla_nerf_field.py).  "grid" (TCNNNerfactoField, a tcnn hash field) is not built.
+The samplers, positions and compositing run on device tensors / sdfhip kernels; the background networks are torch ("mlp":
+fields/vanilla_nerf_field.py; "grid": fields/nerfacto_field.py, whose hash-grid encoding is the sdfhip operator).
 """
 from typing import Dict
 
@@ -15,6 +15,7 @@ import torch
 from torch import nn
 
 from sdfstudio_amd.fields.field_heads import FieldHeadNames
+from sdfstudio_amd.fields.nerfacto_field import TCNNNerfactoField
 from sdfstudio_amd.fields.vanilla_nerf_field import NeRFEncoding, NeRFField
 from sdfstudio_amd.model_components.ray_samplers import LinearDisparitySampler
 from sdfstudio_amd.model_components.renderers import AccumulationRenderer, DepthRenderer, RGBRenderer, SemanticRenderer
@@ -27,11 +28,14 @@ def build_background(model, config) -> None:
             position_encoding=NeRFEncoding(in_dim=3, num_frequencies=10, min_freq_exp=0.0, max_freq_exp=9.0, include_input=True),
             direction_encoding=NeRFEncoding(in_dim=3, num_frequencies=4, min_freq_exp=0.0, max_freq_exp=3.0, include_input=True),
             spatial_distortion=model.scene_contraction)
+    elif config.background_model == "grid":
+        model.field_background = TCNNNerfactoField(  # :181-187
+            model.scene_box.aabb, spatial_distortion=model.scene_contraction, num_images=model.num_train_data,
+            use_average_appearance_embedding=getattr(config, "use_average_appearance_embedding", False))
     elif config.background_model == "none":
         model.field_background = nn.Parameter(torch.ones(1), requires_grad=False)  # the reference's dummy (:201-203)
     else:
-        raise NotImplementedError(f"background_model={config.background_model!r}: 'mlp' and 'none' are built; 'grid' is "
-                                  "TCNNNerfactoField (fields/nerfacto_field.py), a tcnn hash field outside this round")
+        raise ValueError(f"background_model={config.background_model!r}: 'grid', 'mlp' or 'none' (base_surface_model.py:122-123)")
     model.sampler_bg = LinearDisparitySampler(num_samples=config.num_samples_outside)
     bg = {"black": torch.zeros(3), "white": torch.ones(3)}.get(config.background_color)
     model.renderer_rgb = RGBRenderer(background_color=None if config.background_color == "black" else bg)

@@ -1,6 +1,7 @@
 """Mint golden vectors for the BACKGROUND-MODEL paths by running the reference's own model classes (build container only).
 
-    python tests/golden/make_golden_bg.py     # writes tests/golden/{neus,volsdf,neus_facto}_bg_mlp_eval.npz
+    python tests/golden/make_golden_bg.py     # writes tests/golden/{neus,volsdf,neus_facto}_bg_mlp_eval.npz and
+                                              # {neus,neus_facto}_bg_grid_eval.npz (GOLDEN_ONLY=grid: the latter two only)
 
 Unlike make_golden.py (which drives field / sampler / renderer objects by hand), this script instantiates the reference's
 ``NeuSModel``, ``VolSDFModel`` and ``NeuSFactoModel`` (nerfstudio/models/*.py, unmodified, imported through
@@ -59,6 +60,14 @@ def main():
     o, d, cam = O.synthetic_rays(n, seed=11)
     g = torch.Generator().manual_seed(3)
     image = torch.rand(n, 3, generator=g)
+    # background_model="grid" (BASELINE config 5, method_configs.py:423): base_surface_model.py:181-187 builds TCNNNerfactoField with
+    # its defaults (16 levels x 2^19 entries: a 67 MB table); the golden shrinks the table through the constructor's own arguments
+    import functools
+
+    import nerfstudio.fields.nerfacto_field as rnff
+    import nerfstudio.models.base_surface_model as rbsm
+
+    rbsm.TCNNNerfactoField = functools.partial(rnff.TCNNNerfactoField, num_levels=6, max_res=64, log2_hashmap_size=10)
     builds = {
         "neus": lambda: rn.NeuSModelConfig(sdf_field=fcfg, background_model="mlp", num_samples=16, num_samples_importance=16,
                                            num_up_sample_steps=2, num_samples_outside=8),
@@ -66,8 +75,15 @@ def main():
                                                num_samples_extra=8, num_samples_outside=8),
         "neus_facto": lambda: rnf.NeuSFactoModelConfig(sdf_field=fcfg, background_model="mlp", num_proposal_samples_per_ray=(32, 24),
                                                        num_neus_samples_per_ray=16, proposal_net_args_list=PROPS, num_samples_outside=8),
+        "neus_facto_grid": lambda: rnf.NeuSFactoModelConfig(sdf_field=fcfg, background_model="grid", num_proposal_samples_per_ray=(32, 24),
+                                                            num_neus_samples_per_ray=16, proposal_net_args_list=PROPS, num_samples_outside=8),
+        "neus_grid": lambda: rn.NeuSModelConfig(sdf_field=fcfg, background_model="grid", num_samples=16, num_samples_importance=16,
+                                                num_up_sample_steps=2, num_samples_outside=8),
     }
+    only = os.environ.get("GOLDEN_ONLY")  # e.g. GOLDEN_ONLY=grid re-mints the two grid-background goldens only
     for name, mk in builds.items():
+        if only == "grid" and not name.endswith("_grid"):
+            continue
         torch.manual_seed(0)
         model = mk().setup(scene_box=sb, num_train_data=49, world_size=1, local_rank=0)
         perturb(model, seed=5)
@@ -96,7 +112,7 @@ def main():
             n_grad += 1
         bg_keys = [k for k in blob if k.startswith("grad/field_background")]
         assert bg_keys and all(np.abs(blob[k]).max() > 0 for k in bg_keys), "the background field must receive gradient"
-        path = os.path.join(HERE, f"{name}_bg_mlp_eval.npz")
+        path = os.path.join(HERE, f"{name}_bg_mlp_eval.npz" if not name.endswith("_grid") else f"{name[:-5]}_bg_grid_eval.npz")
         np.savez_compressed(path, **blob)
         print(f"[{name}] rgb mean {out['rgb'].mean().item():.4f}, loss {loss.item():.5f}, {n_grad} parameter gradients -> {path} "
               f"({os.path.getsize(path) / 1e6:.2f} MB)")

@@ -681,3 +681,42 @@ def test_oracle_packed_sample_path_properties():
             tot += w[i] * vals[i]
             T *= 1.0 - float(alpha[i])
         assert torch.allclose(acc[r], tot, atol=1e-5)
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_oracle_nerfacto_background_field_against_reference(training):
+    """The "grid" background field of BASELINE config 5: the oracle's restatement against the reference's own TCNNNerfactoField
+    (fields/nerfacto_field.py:65-332, constructed as base_surface_model.py:181-187 does) run on CPU through the tinycudann shim
+    of oracle/ref_harness.py (hash grid, bias-free ReLU MLPs, degree-4 spherical harmonics: the tcnn pieces are restatements -
+    parity unpinned - everything around them is the reference's code): density and rgb, train and eval mode."""
+    from oracle import ref_harness
+
+    if not ref_harness.reference_available():
+        pytest.skip("needs /root/reference (build container)")
+    ns = ref_harness.import_reference()
+    import nerfstudio.fields.nerfacto_field as nf
+    from nerfstudio.field_components.spatial_distortions import SceneContraction
+
+    torch.manual_seed(3)
+    fld = nf.TCNNNerfactoField(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_images=9, num_levels=5, max_res=48, log2_hashmap_size=9,
+                               spatial_distortion=SceneContraction(order=float("inf")))
+    with torch.no_grad():
+        fld.mlp_base.encoding.params.copy_((torch.rand_like(fld.mlp_base.encoding.params) * 2 - 1) * 0.4)
+    fld.train(training)
+    n, s = 23, 7
+    o, d, cam = O.synthetic_rays(n, seed=4)
+    cam = cam % 9
+    starts = torch.sort(torch.rand(n, s) * 6.0 + 0.3, dim=-1).values
+    ends = starts + torch.rand(n, s) * 0.4 + 0.01
+    rb = ns.rays.RayBundle(origins=o, directions=d, pixel_area=torch.ones(n, 1), directions_norm=torch.ones(n, 1), camera_indices=cam[:, None])
+    rs = rb.get_ray_samples(bin_starts=starts[..., None], bin_ends=ends[..., None])
+    ref = fld(rs)
+    key = {str(k).split(".")[-1]: v for k, v in ref.items()}
+    sd = fld.state_dict()
+    p = {"bg.mlp_base.table": sd["mlp_base.encoding.params"], "bg.mlp_base.w1": sd["mlp_base.w1"], "bg.mlp_base.w2": sd["mlp_base.w2"],
+         "bg.mlp_head.w1": sd["mlp_head.w1"], "bg.mlp_head.w2": sd["mlp_head.w2"], "bg.mlp_head.w3": sd["mlp_head.w3"],
+         "bg.embedding_appearance.embedding.weight": sd["embedding_appearance.embedding.weight"]}
+    out = O.nerfacto_field(o, d, starts, ends, cam, p, "bg.", fld.mlp_base.encoding.levels, training=training)
+    assert_close("density", out["density"], key["DENSITY"][..., 0], rtol=1e-5, atol=1e-7)
+    assert_close("rgb", out["rgb"], key["RGB"], rtol=1e-5, atol=1e-6)
+    assert float(out["density"].std()) > 0 and float(out["rgb"].std()) > 1e-3

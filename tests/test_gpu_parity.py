@@ -1308,7 +1308,7 @@ def _load_reference_state_dict(model, params):
     for k, v in params.items():
         if k == "device_indicator_param" or (k.startswith("proposal_networks.") and k.endswith(".aabb")):
             continue
-        key = k.replace("mlp_base.encoding.params", "mlp_base.table") if k.startswith("proposal_networks.") else k
+        key = k.replace("mlp_base.encoding.params", "mlp_base.table") if k.startswith(("proposal_networks.", "field_background.")) else k
         assert key in sd, f"{key} missing from the mirror's state_dict"
         assert tuple(sd[key].shape) == tuple(v.shape), (key, tuple(sd[key].shape), tuple(v.shape))
         sd[key] = v.clone()
@@ -1317,19 +1317,30 @@ def _load_reference_state_dict(model, params):
     model.load_state_dict(sd)
 
 
-@pytest.mark.parametrize("name", ["neus", "volsdf", "neus_facto"])
+@pytest.mark.parametrize("name", ["neus", "volsdf", "neus_facto", "neus_facto_grid", "neus_grid"])
 def test_background_mlp_models_against_reference_golden(device, name):
-    """background_model="mlp" (the reference's default): NeuS / VolSDF add transmittance x colour of the samples beyond the far
-    plane (base_surface_model.py:314-329), NeuS-facto merges the background field into alpha / colour outside the unit sphere
-    (:266-290).  Golden: the reference's own model classes run end to end (tests/golden/make_golden_bg.py), eval mode; compared:
-    rendered outputs, the rgb loss, and its gradient w.r.t. SDF field, background field and proposal networks."""
+    """background_model="mlp" (the reference's default) and "grid" (BASELINE config 5: TCNNNerfactoField, fields/nerfacto_field.py):
+    NeuS / VolSDF add transmittance x colour of the samples beyond the far plane (base_surface_model.py:314-329), NeuS-facto merges
+    the background field into alpha / colour outside the unit sphere (:266-290).  Golden: the reference's own model classes run end
+    to end (tests/golden/make_golden_bg.py), eval mode; compared: rendered outputs, the rgb loss, and its gradient w.r.t. SDF
+    field, background field and proposal networks."""
+    import functools
+
+    from sdfstudio_amd.fields.nerfacto_field import TCNNNerfactoField
+    from sdfstudio_amd.models import background as BG
     from sdfstudio_amd.cameras.rays import RayBundle
     from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
     from sdfstudio_amd.models.neus import NeuSModel, NeuSModelConfig
     from sdfstudio_amd.models.neus_facto import NeuSFactoModel, NeuSFactoModelConfig, SceneBox
     from sdfstudio_amd.models.volsdf import VolSDFModel, VolSDFModelConfig
 
-    g = load_golden_file(f"{name}_bg_mlp_eval.npz")
+    grid = name.endswith("_grid")
+    bgm = "grid" if grid else "mlp"
+    name = name[:-5] if grid else name
+    g = load_golden_file(f"{name}_bg_{bgm}_eval.npz")
+    if grid:  # the golden shrinks the background table through the field's own constructor arguments (make_golden_bg.py)
+        full = BG.TCNNNerfactoField
+        BG.TCNNNerfactoField = functools.partial(TCNNNerfactoField, num_levels=6, max_res=64, log2_hashmap_size=10)
     fcfg = SDFFieldConfig(num_layers=8, hidden_dim=64, geo_feat_dim=64, num_layers_color=4, hidden_dim_color=64, bias=0.5,
                           inside_outside=False, use_grid_feature=True, beta_init=0.3, num_levels=8, max_res=128, base_res=4,
                           log2_hashmap_size=11, hash_features_per_level=2, hash_smoothstep=True)
@@ -1337,14 +1348,16 @@ def test_background_mlp_models_against_reference_golden(device, name):
              {"hidden_dim": 16, "log2_hashmap_size": 9, "num_levels": 5, "max_res": 64, "base_res": 4}]
     box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=0.5, far=4.5)
     if name == "neus":
-        model = NeuSModel(NeuSModelConfig(sdf_field=fcfg, background_model="mlp", num_samples=16, num_samples_importance=16,
+        model = NeuSModel(NeuSModelConfig(sdf_field=fcfg, background_model=bgm, num_samples=16, num_samples_importance=16,
                                           num_up_sample_steps=2, num_samples_outside=8), box, 49)
     elif name == "volsdf":
         model = VolSDFModel(VolSDFModelConfig(sdf_field=fcfg, background_model="mlp", num_samples=16, num_samples_eval=32,
                                               num_samples_extra=8, num_samples_outside=8), box, 49)
     else:
-        model = NeuSFactoModel(NeuSFactoModelConfig(sdf_field=fcfg, background_model="mlp", num_proposal_samples_per_ray=(32, 24),
+        model = NeuSFactoModel(NeuSFactoModelConfig(sdf_field=fcfg, background_model=bgm, num_proposal_samples_per_ray=(32, 24),
                                                     num_neus_samples_per_ray=16, proposal_net_args_list=props, num_samples_outside=8), box, 49)
+    if grid:
+        BG.TCNNNerfactoField = full
     _load_reference_state_dict(model, g["param"])
     model = model.to(device).eval()
     i = g["in"]
@@ -1366,7 +1379,7 @@ def test_background_mlp_models_against_reference_golden(device, name):
     assert_close("normal", out["normal"], o["normal"], rtol=tol, atol=1e-5)
     assert_close("accumulation", out["accumulation"], o["accumulation"], rtol=tol, atol=1e-6)
     assert_close("rgb_loss", loss, g["loss"]["rgb_loss"], rtol=1e-4, atol=1e-7)
-    got = {k.replace("mlp_base.table", "mlp_base.encoding.params") if k.startswith("proposal_networks.") else k: p.grad
+    got = {k.replace("mlp_base.table", "mlp_base.encoding.params") if k.startswith(("proposal_networks.", "field_background.")) else k: p.grad
            for k, p in model.named_parameters() if p.grad is not None}
     checked = 0
     for k, ref in g["grad"].items():
@@ -1382,7 +1395,7 @@ def test_background_mlp_models_against_reference_golden(device, name):
         rt = (1e-2 if "mlp_base" in k else 2e-3) if k.startswith("field_background") else (1e-1 if k == "field.encoding.params" else 2e-2)
         assert_close(f"grad {k}", got[k], ref, rtol=rt, atol=1e-9)
         checked += 1
-    assert checked >= 50
+    assert checked >= (44 if grid else 50)
     assert any(k.startswith("field_background.mlp_base") for k in g["grad"])
 
 
@@ -1787,3 +1800,74 @@ def test_neus_acc_model_packed_path(device):
     far_bundle = _bundle(o + 10.0, d, cam, cfg.near, cfg.far, device)
     out0 = model(far_bundle)
     assert float(out0["rgb"].abs().max()) == 0.0 and out0["eik_grad"].shape == (n, 3)
+
+
+# ------------------------------------------------------------------------------------------------ "grid" background field (config 5)
+@pytest.mark.parametrize("features,smooth", [(2, False), (8, False), (2, True)])
+def test_standalone_hash_grid_encode(device, features, smooth):
+    """sdfhip_grid_encode_forward / _backward (the tcnn.Encoding("HashGrid") operator outside the fused fields) against
+    oracle/hashgrid.py: features and the table gradient, positions inside and outside [0,1]^3 (wrapping)."""
+    from oracle import hashgrid
+    from sdfstudio_amd import _lib
+    from sdfstudio_amd.fields.nerfacto_field import hash_grid_encode
+
+    L, log2, base, max_res = 6, 11, 4, 96
+    growth = math.exp((math.log(max_res) - math.log(base)) / (L - 1))
+    lv = hashgrid.make_levels(L, features, log2, base, growth, smooth)
+    cfg = _lib.GridCfg(L, features, log2, base, growth, 1 if smooth else 0)
+    gen = torch.Generator().manual_seed(9)
+    table = (torch.rand(lv.n_entries * features, generator=gen) * 2 - 1) * 0.5
+    x = torch.rand(999, 3, generator=gen)
+    x[:40] = x[:40] * 3.0 - 1.0  # outside the unit cube
+    co = torch.randn(999, L * features, generator=gen)
+    t_ref = table.clone().requires_grad_(True)
+    f_ref = hashgrid.grid_encode(x, t_ref.view(lv.n_entries, features), lv)
+    (f_ref * co).sum().backward()
+    t = table.clone().to(device).requires_grad_(True)
+    f = hash_grid_encode(t, x.to(device), cfg)
+    (f * co.to(device)).sum().backward()
+    assert_close("features", f, f_ref, rtol=1e-5, atol=1e-6)
+    assert_close("table gradient", t.grad, t_ref.grad, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_nerfacto_background_field_fwd_bwd(device, training):
+    """TCNNNerfactoField mirror (fields/nerfacto_field.py:65-332, the "grid" background of BASELINE config 5) against the oracle's
+    restatement (pinned on the reference's own class by test_oracle_nerfacto_background_field_against_reference): density, rgb and
+    every parameter gradient."""
+    from sdfstudio_amd.fields.field_heads import FieldHeadNames
+    from sdfstudio_amd.fields.nerfacto_field import TCNNNerfactoField
+    from sdfstudio_amd.models.neus_facto import SceneContraction
+    from oracle import hashgrid
+
+    torch.manual_seed(11)
+    fld = TCNNNerfactoField(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_images=9, num_levels=5, max_res=48, log2_hashmap_size=9,
+                            spatial_distortion=SceneContraction(order=float("inf")))
+    with torch.no_grad():
+        fld.mlp_base.table.copy_((torch.rand_like(fld.mlp_base.table) * 2 - 1) * 0.4)
+    fld = fld.to(device).train(training)
+    n, s = 23, 7
+    o, d, cam = O.synthetic_rays(n, seed=4)
+    cam = cam % 9
+    starts = torch.sort(torch.rand(n, s) * 6.0 + 0.3, dim=-1).values
+    ends = starts + torch.rand(n, s) * 0.4 + 0.01
+    rs = _bundle(o, d, cam, 0.3, 7.0, device).get_ray_samples(starts.to(device), ends.to(device))
+    out = fld(rs)
+    co = [torch.randn(n, s), torch.randn(n, s, 3)]
+    (out[FieldHeadNames.DENSITY][..., 0] * co[0].to(device)).sum().add((out[FieldHeadNames.RGB] * co[1].to(device)).sum()).backward()
+    names = {"bg.mlp_base.table": "mlp_base.table", "bg.mlp_base.w1": "mlp_base.w1", "bg.mlp_base.w2": "mlp_base.w2",
+             "bg.mlp_head.w1": "mlp_head.w1", "bg.mlp_head.w2": "mlp_head.w2", "bg.mlp_head.w3": "mlp_head.w3",
+             "bg.embedding_appearance.embedding.weight": "embedding_appearance.embedding.weight"}
+    sd = {k: v.detach().cpu() for k, v in fld.state_dict().items()}
+    p = {k: sd[v].clone().requires_grad_(True) for k, v in names.items()}
+    growth = math.exp((math.log(48) - math.log(16)) / 4)
+    lv = hashgrid.make_levels(5, 2, 9, 16, growth, False)
+    ref = O.nerfacto_field(o, d, starts, ends, cam, p, "bg.", lv, training=training)
+    ((ref["density"] * co[0]).sum() + (ref["rgb"] * co[1]).sum()).backward()
+    assert_close("density", out[FieldHeadNames.DENSITY][..., 0], ref["density"], rtol=1e-4, atol=1e-6)
+    assert_close("rgb", out[FieldHeadNames.RGB], ref["rgb"], rtol=1e-4, atol=1e-6)
+    grads = dict(fld.named_parameters())
+    for k, v in names.items():
+        if p[k].grad is None or (not training and "embedding" in k):
+            continue
+        assert_close(f"grad {v}", grads[v].grad, p[k].grad, rtol=1e-3, atol=1e-8)
