@@ -204,6 +204,24 @@ int sdfhip_sample_pdf_spacing(int32_t spacing, const float* weights, const float
  * [max(z - (far - near) delta, near), min(z + (far - near) delta, far)] (unchanged where no surface was found: mask = 0). */
 int sdfhip_surface_root(const float* sdf, const float* starts, const float* nears, const float* fars, int64_t n_rays, int32_t n_samples,
                         float delta, int32_t* mask, float* z, float* new_nears, float* new_fars, sdfhip_stream_t stream);
+/* VolSDF's compositing in one launch per direction (models/volsdf.py:62-79): Laplace density of the SDF with
+ * beta = LaplaceDensity.get_beta() (fields/sdf_field.py:48-76) -> weights (cameras/rays.py:146-192) -> rgb + background (1 - acc),
+ * expected depth clipped to the batch's sample range, normal = sum w normalize(grad), accumulation
+ * (model_components/renderers.py:81-92,196,245-259,294), and bg_trans [n_rays] = the transmittance in front of the LAST sample,
+ * which the background model multiplies its colour with (volsdf.py:67-68).  density, weights: [n_rays, n_samples].
+ * Backward: gradients w.r.t. sdf, grad (through the normal), rgb and beta (beta_bar [1] is ACCUMULATED); any upstream gradient may
+ * be NULL. */
+int sdfhip_volsdf_render_forward(const float* sdf, const float* grad, const float* rgb, const float* starts, const float* ends,
+                                 const float* beta, const float* background, int64_t n_rays, int32_t n_samples, float* density,
+                                 float* weights, float* out_rgb, float* out_depth_raw, float* out_depth, float* out_normal, float* out_acc,
+                                 float* bg_trans, float* steps_minmax, sdfhip_stream_t stream);
+int sdfhip_volsdf_render_backward(const float* sdf, const float* grad, const float* rgb, const float* starts, const float* ends,
+                                  const float* beta, const float* background, int64_t n_rays, int32_t n_samples, const float* density,
+                                  const float* weights, const float* out_depth_raw, const float* out_acc, const float* bg_trans,
+                                  const float* steps_minmax, const float* rgb_bar, const float* depth_bar, const float* normal_bar,
+                                  const float* acc_bar, const float* weights_bar, const float* bg_trans_bar, float* sdf_bar, float* grad_bar,
+                                  float* rgbs_bar, float* beta_bar, sdfhip_stream_t stream);
+
 /* ---- packed-sample path of NeuS-acc.  The reference calls three nerfacc (== 0.3.5, CUDA-only) operators; these
  * replace them.  "Packed": the samples of all rays in one array, ray r owning [offsets[r], offsets[r] + counts[r]).
  *

@@ -92,6 +92,8 @@ _SIGNATURES = {
                                           c_f32, c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
     "sdfhip_surface_root": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, c_i64, c_i32, c_f32, ctypes.c_void_p, c_float_p,
                                     c_float_p, c_float_p, ctypes.c_void_p]),
+    "sdfhip_volsdf_render_forward": (c_i32, [c_float_p] * 7 + [c_i64, c_i32] + [c_float_p] * 9 + [ctypes.c_void_p]),
+    "sdfhip_volsdf_render_backward": (c_i32, [c_float_p] * 7 + [c_i64, c_i32] + [c_float_p] * 16 + [ctypes.c_void_p]),
     "sdfhip_march_count": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, c_i64, c_i32,
                                    c_f32, ctypes.c_void_p, ctypes.c_void_p]),
     "sdfhip_march_write": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, c_i64, c_i32,

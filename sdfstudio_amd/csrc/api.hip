@@ -12,6 +12,7 @@
 #include "point_kernels.h"
 #include "ray_kernels.h"
 #include "packed_kernels.h"
+#include "volsdf_render_kernels.h"
 #include "grid_encode_kernels.h"
 
 const FieldKernels* sdfhip_kernels_A();
@@ -1719,6 +1720,82 @@ extern "C" int sdfhip_neus_render_forward(const float* sdf, const float* grad, c
   const unsigned grid = (unsigned)((n_rays + 3) / 4);
   { ProfScope ps_(PS_RENDER_FWD, s); SDFHIP_DISPATCH_C(n_samples, (neus_render_fwd_kernel<C><<<grid, 256, 0, s>>>(a))); }
   depth_clip_kernel<<<(unsigned)((n_rays + 255) / 256), 256, 0, s>>>(out_depth_raw, steps_minmax, (int)n_rays, out_depth);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// VolSDF's compositing (models/volsdf.py:62-79) as one launch per direction: the density-input sibling of neus_render
+static void fill_volsdf_render(VolsdfRenderArgs* a, const float* sdf, const float* grad, const float* rgb, const float* starts, const float* ends,
+                               const float* beta, const float* background, int64_t n_rays, int32_t n_samples) {
+  memset(a, 0, sizeof(*a));
+  a->sdf = sdf;
+  a->grad = grad;
+  a->rgb = rgb;
+  a->starts = starts;
+  a->ends = ends;
+  a->beta = beta;
+  a->bg = background;
+  a->N = (int)n_rays;
+  a->S = n_samples;
+}
+extern "C" int sdfhip_volsdf_render_forward(const float* sdf, const float* grad, const float* rgb, const float* starts, const float* ends,
+                                            const float* beta, const float* background, int64_t n_rays, int32_t n_samples, float* density,
+                                            float* weights, float* out_rgb, float* out_depth_raw, float* out_depth, float* out_normal,
+                                            float* out_acc, float* bg_trans, float* steps_minmax, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(sdf && grad && rgb && starts && ends && beta && density && weights && out_rgb && out_depth_raw && out_depth && out_normal &&
+                     out_acc && bg_trans && steps_minmax, "volsdf_render_forward: null argument");
+  SDFHIP_REQUIRE(n_samples >= 1 && n_samples <= 64 * kMaxPerLane, "volsdf_render: n_samples %d unsupported", n_samples);
+  if (n_rays == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  VolsdfRenderArgs a;
+  fill_volsdf_render(&a, sdf, grad, rgb, starts, ends, beta, background, n_rays, n_samples);
+  a.density = density;
+  a.weights = weights;
+  a.out_rgb = out_rgb;
+  a.out_depth = out_depth_raw;
+  a.out_normal = out_normal;
+  a.out_acc = out_acc;
+  a.bg_trans = bg_trans;
+  a.steps_minmax = steps_minmax;
+  minmax_init_kernel<<<1, 1, 0, s>>>(steps_minmax);
+  const unsigned grid = (unsigned)((n_rays + 3) / 4);
+  { ProfScope ps_(PS_RENDER_FWD, s); SDFHIP_DISPATCH_C(n_samples, (volsdf_render_fwd_kernel<C><<<grid, 256, 0, s>>>(a))); }
+  depth_clip_kernel<<<(unsigned)((n_rays + 255) / 256), 256, 0, s>>>(out_depth_raw, steps_minmax, (int)n_rays, out_depth);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int sdfhip_volsdf_render_backward(const float* sdf, const float* grad, const float* rgb, const float* starts, const float* ends,
+                                             const float* beta, const float* background, int64_t n_rays, int32_t n_samples,
+                                             const float* density, const float* weights, const float* out_depth_raw, const float* out_acc,
+                                             const float* bg_trans, const float* steps_minmax, const float* rgb_bar, const float* depth_bar,
+                                             const float* normal_bar, const float* acc_bar, const float* weights_bar,
+                                             const float* bg_trans_bar, float* sdf_bar, float* grad_bar, float* rgbs_bar, float* beta_bar,
+                                             sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(sdf && grad && rgb && starts && ends && beta && density && weights && out_depth_raw && out_acc && bg_trans && steps_minmax &&
+                     sdf_bar && grad_bar && rgbs_bar, "volsdf_render_backward: null argument");
+  SDFHIP_REQUIRE(n_samples >= 1 && n_samples <= 64 * kMaxPerLane, "volsdf_render: n_samples %d unsupported", n_samples);
+  if (n_rays == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  VolsdfRenderArgs a;
+  fill_volsdf_render(&a, sdf, grad, rgb, starts, ends, beta, background, n_rays, n_samples);
+  a.density = const_cast<float*>(density);
+  a.weights = const_cast<float*>(weights);
+  a.out_depth = const_cast<float*>(out_depth_raw);
+  a.out_acc = const_cast<float*>(out_acc);
+  a.bg_trans = const_cast<float*>(bg_trans);
+  a.steps_minmax = const_cast<float*>(steps_minmax);
+  a.rgbbar = rgb_bar;
+  a.depthbar = depth_bar;
+  a.normalbar = normal_bar;
+  a.accbar = acc_bar;
+  a.weightsbar = weights_bar;
+  a.bgtransbar = bg_trans_bar;
+  a.sdfbar = sdf_bar;
+  a.gradbar = grad_bar;
+  a.rgbsbar = rgbs_bar;
+  a.betabar = beta_bar;
+  const unsigned grid = (unsigned)((n_rays + 3) / 4);
+  { ProfScope ps_(PS_RENDER_BWD, s); SDFHIP_DISPATCH_C(n_samples, (volsdf_render_bwd_kernel<C><<<grid, 256, 0, s>>>(a))); }
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -105,6 +105,51 @@ def neus_render(sdf, gradients, rgb, variance, directions, starts, ends, cos_ann
                              ends.contiguous(), background, cos_anneal_ratio)
 
 
+class _VolsdfRender(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, sdf, grad, rgb, beta, starts, ends, background):
+        lib = _lib.load()
+        n, s = starts.shape
+        dev = starts.device
+        sdf, grad, rgb, beta = sdf.contiguous(), grad.contiguous(), rgb.contiguous(), beta.reshape(1).contiguous()
+        density, weights = torch.empty(n, s, device=dev), torch.empty(n, s, device=dev)
+        out_rgb, normal = torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev)
+        depth_raw, depth, acc, bg_trans = (torch.empty(n, device=dev) for _ in range(4))
+        minmax = torch.empty(2, device=dev)
+        _lib.check(lib.sdfhip_volsdf_render_forward(
+            _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(rgb), _lib.ptr(starts), _lib.ptr(ends), _lib.ptr(beta), _lib.ptr(background), n, s,
+            _lib.ptr(density), _lib.ptr(weights), _lib.ptr(out_rgb), _lib.ptr(depth_raw), _lib.ptr(depth), _lib.ptr(normal), _lib.ptr(acc),
+            _lib.ptr(bg_trans), _lib.ptr(minmax), _lib.stream()), "volsdf_render_forward")
+        ctx.save_for_backward(sdf, grad, rgb, beta, starts, ends, density, weights, depth_raw, acc, bg_trans, minmax)
+        ctx.background = background
+        ctx.mark_non_differentiable(density)
+        return out_rgb, depth, normal, acc, weights, density, bg_trans
+
+    @staticmethod
+    def backward(ctx, rgb_bar, depth_bar, normal_bar, acc_bar, weights_bar, _density_bar, bgt_bar):
+        sdf, grad, rgb, beta, starts, ends, density, weights, depth_raw, acc, bg_trans, minmax = ctx.saved_tensors
+        lib = _lib.load()
+        n, s = starts.shape
+        sdf_bar, grad_bar, rgbs_bar = torch.empty_like(sdf), torch.empty_like(grad), torch.empty_like(rgb)
+        beta_bar = torch.zeros_like(beta)
+        kp = _lib.Keep()
+        _lib.check(lib.sdfhip_volsdf_render_backward(
+            _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(rgb), _lib.ptr(starts), _lib.ptr(ends), _lib.ptr(beta), _lib.ptr(ctx.background), n, s,
+            _lib.ptr(density), _lib.ptr(weights), _lib.ptr(depth_raw), _lib.ptr(acc), _lib.ptr(bg_trans), _lib.ptr(minmax), kp(rgb_bar),
+            kp(depth_bar), kp(normal_bar), kp(acc_bar), kp(weights_bar), kp(bgt_bar), _lib.ptr(sdf_bar), _lib.ptr(grad_bar), _lib.ptr(rgbs_bar),
+            _lib.ptr(beta_bar), _lib.stream()), "volsdf_render_backward")
+        del kp
+        return sdf_bar, grad_bar, rgbs_bar, beta_bar.view(ctx.saved_tensors[3].shape), None, None, None
+
+
+def volsdf_render(sdf, gradients, rgb, beta, starts, ends, background: Optional[torch.Tensor] = None):
+    """VolSDF's compositing in one launch (models/volsdf.py:62-79): LaplaceDensity (sdf_field.py:48-76) with beta [1] =
+    laplace_density.get_beta(), get_weights (rays.py:146-167) and the four renderers.  sdf [N,S], gradients / rgb [N,S,3],
+    starts / ends [N,S].  Returns rgb [N,3], depth [N] (expected, clipped as renderers.py:257), normal [N,3], accumulation [N],
+    weights [N,S], density [N,S] (no gradient flows through this output) and the transmittance in front of the last sample [N]."""
+    return _VolsdfRender.apply(sdf, gradients, rgb, beta, starts.contiguous(), ends.contiguous(), background)
+
+
 class RGBRenderer(nn.Module):
     """renderers.py:42-118 for dense [N,S] samples: sum_s w rgb + bg (1 - sum_s w); clamp to [0,1] in eval.
     background_color: an RGB tensor, "random" (a fresh uniform colour per ray and call, :86-87), "last_sample" (the colour of

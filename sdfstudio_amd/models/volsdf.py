@@ -1,6 +1,6 @@
 """VolSDF model, mirroring nerfstudio/models/volsdf.py (VolSDFModelConfig :30-40, VolSDFModel :43-92) on top of
-models/base_surface_model.py: ErrorBoundedSampler (VolSDF Algorithm 1) -> SDFField -> Laplace density -> density weights ->
-renderers.  BASELINE config 1 is this model with a pure-MLP field (use_grid_feature=False)."""
+models/base_surface_model.py: ErrorBoundedSampler (VolSDF Algorithm 1) -> SDFField -> Laplace density, density weights and the
+four renderers in one kernel (renderers.volsdf_render).  BASELINE config 1 is this model with a pure-MLP field (use_grid_feature=False)."""
 from dataclasses import dataclass, field
 from typing import Dict, List, Type
 
@@ -11,8 +11,7 @@ from torch import nn
 from sdfstudio_amd.cameras.rays import RayBundle
 from sdfstudio_amd.fields.field_heads import FieldHeadNames
 from sdfstudio_amd.model_components.ray_samplers import ErrorBoundedSampler
-from sdfstudio_amd.model_components.renderers import (AccumulationRenderer, DepthRenderer, RGBRenderer, SemanticRenderer,
-                                                      density_to_weights)
+from sdfstudio_amd.model_components.renderers import volsdf_render
 from sdfstudio_amd.models import background as B
 from sdfstudio_amd.models.neus import NeuSModel
 from sdfstudio_amd.models.neus_facto import NeuSFactoModelConfig, SceneContraction
@@ -49,25 +48,21 @@ class VolSDFModel(NeuSModel):
         """volsdf.py:62-79."""
         ray_samples, eik_points = self.sampler(ray_bundle, density_fn=self.field.laplace_density, sdf_fn=self.field.get_sdf)
         sdf, grad, rgb, x = self.field.forward_fused(ray_samples)
-        density = self.field.laplace_density(sdf)  # sdf_field.py:659
-        weights = density_to_weights(density, ray_samples.flat_starts, ray_samples.flat_ends)[..., None]  # rays.py:169-192
-        normals = F.normalize(grad, p=2, dim=-1)
-        out_rgb = self.renderer_rgb(rgb=rgb, weights=weights)
-        depth = self.renderer_depth(weights=weights, ray_samples=ray_samples)[..., 0]
-        normal = self.renderer_normal(semantics=normals, weights=weights)
-        acc = self.renderer_accumulation(weights=weights)[..., 0]
+        bg = None if self.config.background_color == "black" else self.background
+        # density -> weights -> rgb / depth / normal / accumulation and the transmittance the background model needs: one launch
+        out_rgb, depth, normal, acc, weights, density, bg_trans = volsdf_render(
+            sdf, grad, rgb, self.field.laplace_density.get_beta(), ray_samples.flat_starts, ray_samples.flat_ends, bg)
         field_outputs = {
             FieldHeadNames.RGB: rgb, FieldHeadNames.SDF: sdf[..., None], FieldHeadNames.GRADIENT: grad,
-            FieldHeadNames.DENSITY: density[..., None], FieldHeadNames.NORMAL: normals,
+            FieldHeadNames.DENSITY: density[..., None], FieldHeadNames.NORMAL: F.normalize(grad, p=2, dim=-1),
             "points_norm": x.norm(dim=-1, keepdim=True), "sampled_sdf": None,
         }
-        out = {"ray_samples": ray_samples, "eik_points": eik_points, "field_outputs": field_outputs, "weights": weights,
+        out = {"ray_samples": ray_samples, "eik_points": eik_points, "field_outputs": field_outputs, "weights": weights[..., None],
                "rendered": (out_rgb, depth, normal, acc)}
         if B.has_background(self.config):
             # volsdf.py:67-68: transmittance in front of the LAST sample (get_weights_and_transmittance's [:, -1]), i.e. without
             # the last sample's own attenuation - restated, not "fixed"
-            dd = density * (ray_samples.flat_ends - ray_samples.flat_starts)
-            out["bg_transmittance"] = torch.exp(-dd[:, :-1].sum(dim=1, keepdim=True))
+            out["bg_transmittance"] = bg_trans[:, None]
         return out
 
     def get_metrics_dict(self, outputs, batch) -> Dict[str, torch.Tensor]:

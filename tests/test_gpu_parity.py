@@ -1871,3 +1871,48 @@ def test_nerfacto_background_field_fwd_bwd(device, training):
         if p[k].grad is None or (not training and "embedding" in k):
             continue
         assert_close(f"grad {v}", grads[v].grad, p[k].grad, rtol=1e-3, atol=1e-8)
+
+
+@pytest.mark.parametrize("S,white", [(24, False), (96, True), (130, False)])
+def test_volsdf_render_fwd_bwd(device, S, white):
+    """renderers.volsdf_render (models/volsdf.py:62-79 in one launch: Laplace density -> weights -> rgb / depth / normal /
+    accumulation + the transmittance in front of the last sample) against the oracle's per-statement composition, forward and
+    backward w.r.t. sdf, gradients, rgb and beta, with every output carrying a cotangent."""
+    from sdfstudio_amd.model_components.renderers import volsdf_render
+
+    gen = torch.Generator().manual_seed(S)
+    n = 37
+    sdf = torch.randn(n, S, generator=gen) * 0.3
+    sdf[:, 0] = 0.0  # sign(0) = 0 branch
+    grad = torch.randn(n, S, 3, generator=gen)
+    rgb = torch.rand(n, S, 3, generator=gen)
+    starts = torch.sort(torch.rand(n, S, generator=gen) * 4 + 0.5, dim=-1).values
+    ends = torch.cat([starts[:, 1:], starts[:, -1:] + 0.05], dim=-1)
+    beta = torch.tensor([0.07])
+    bg = torch.ones(3) if white else None
+    co = [torch.randn(n, 3, generator=gen), torch.randn(n, generator=gen), torch.randn(n, 3, generator=gen), torch.randn(n, generator=gen),
+          torch.randn(n, S, generator=gen), torch.randn(n, generator=gen)]
+
+    def run(f, dev, dtype):
+        leaves = [t.clone().to(dev, dtype).requires_grad_(True) for t in (sdf, grad, rgb, beta)]
+        outs = f(*leaves, starts.to(dev, dtype), ends.to(dev, dtype), None if bg is None else bg.to(dev, dtype))
+        loss = sum((o * c.to(dev, dtype)).sum() for o, c in zip(outs, co))
+        loss.backward()
+        return [o.detach() for o in outs], [l.grad for l in leaves]
+
+    def oracle(sdf_, grad_, rgb_, beta_, st, en, bg_):
+        density = O.laplace_density(sdf_, beta_)
+        w, trans = O.weights_and_transmittance_from_density(density, en - st)
+        out_rgb, depth, normal, acc = O.render(w, rgb_, F.normalize(grad_, p=2, dim=-1), st, en, bg_)
+        return out_rgb, depth, normal, acc, w, trans[:, -1]
+
+    def product(sdf_, grad_, rgb_, beta_, st, en, bg_):
+        out_rgb, depth, normal, acc, w, density, bgt = volsdf_render(sdf_, grad_, rgb_, beta_, st, en, bg_)
+        return out_rgb, depth, normal, acc, w, bgt
+
+    got, ggot = run(product, device, torch.float32)
+    ref, gref = run(oracle, "cpu", torch.float64)
+    for name, a, b in zip(["rgb", "depth", "normal", "accumulation", "weights", "bg transmittance"], got, ref):
+        assert_close(name, a, b.float(), rtol=1e-4, atol=1e-6)
+    for name, a, b in zip(["d / d sdf", "d / d gradient", "d / d rgb", "d / d beta"], ggot, gref):
+        assert_close(name, a, b.float(), rtol=1e-3, atol=1e-6)
