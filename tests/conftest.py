@@ -19,3 +19,15 @@ def device():
     if not torch.cuda.is_available():
         pytest.skip("no HIP device")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _deterministic_draws(request):
+    """Every test starts from a seed derived from its own id: draws made without an explicit generator (cotangents, perturbations)
+    are the same on every run and every box, so a pass is reproducible and tolerance margins are not a matter of luck."""
+    import zlib
+
+    import torch
+
+    torch.manual_seed(zlib.crc32(request.node.nodeid.encode()) & 0x7FFFFFFF)
+    yield
