@@ -984,3 +984,18 @@ def nerfacto_field(origins, dirs, starts, ends, cam_idx, p: Params, prefix: str,
     hh = torch.cat([d, h[:, 1:1 + geo_feat_dim], emb], dim=-1)
     rgb = torch.sigmoid(torch.relu(torch.relu(hh @ p[f"{prefix}mlp_head.w1"].t()) @ p[f"{prefix}mlp_head.w2"].t()) @ p[f"{prefix}mlp_head.w3"].t())
     return {"density": density.view(n, s), "rgb": rgb.view(n, s, 3)}
+
+
+# ----------------------------------------------------------------------------- optimiser
+def adam_reference(p, g, m, v, lr, beta1, beta2, eps, step, weight_decay=0.0, grad_scale=1.0):
+    """torch.optim.Adam's single-tensor update (torch/optim/adam.py, the optimiser engine/optimizers.py:93-160 instantiates with
+    eps 1e-15) on plain tensors, in place: the statement the adam_kernel restates; grad_scale = 1 / world folds the mean of the
+    gradient all-reduce into the step."""
+    g = g * grad_scale
+    if weight_decay != 0.0:
+        g = g + weight_decay * p
+    m.lerp_(g, 1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-(lr / bc1))

@@ -5,8 +5,8 @@ The reference builds one ``torch.optim.Adam`` per parameter group (eps 1e-15; lr
 and the two Adam moments of ALL groups live in four flat fp32 buffers (parameters become views, like the gradients of
 ``distributed.FlatGradients``), a group is a contiguous slice, and one step of a group is ONE launch of
 ``sdfhip_adam_step`` - with the data-parallel mean folded into the gradient read, so the all-reduce can be a plain SUM.
-There is no PyTorch fallback on the device path (``FusedAdam.step`` raises without the library); ``adam_reference`` is
-the formula as plain torch ops, used by the tests and by CPU-only callers.
+There is no PyTorch fallback (``FusedAdam.step`` raises without the library or on CPU tensors); the formula as plain torch ops
+is ``oracle.sdf_path.adam_reference``, the checker the tests compare with.
 """
 import math
 from typing import Callable, Dict, Iterable, List, Optional
@@ -75,18 +75,6 @@ class FlatParameters:
                 off += n
 
 
-def adam_reference(p, g, m, v, lr, beta1, beta2, eps, step, weight_decay=0.0, grad_scale=1.0):
-    """torch.optim.Adam's single-tensor update (optim/adam.py) on plain tensors, in place; the statement the kernel restates."""
-    g = g * grad_scale
-    if weight_decay != 0.0:
-        g = g + weight_decay * p
-    m.lerp_(g, 1 - beta1)
-    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
-    bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
-    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
-    p.addcdiv_(m, denom, value=-(lr / bc1))
-
-
 class FusedAdam:
     """Adam over flat buffers: ``groups`` maps a name to (parameters, lr); one native launch per group and step.
 
@@ -124,7 +112,7 @@ class FusedAdam:
         self.step_count += 1
         P, G = self.flat_params.flat, self.flat_grads.flat
         if not P.is_cuda:
-            raise _lib.SdfHipError("FusedAdam.step needs HIP device tensors; there is no CPU fallback (adam_reference is the CPU statement)")
+            raise _lib.SdfHipError("FusedAdam.step needs HIP device tensors; there is no CPU fallback")
         for g in self.groups.values():
             a, n = g["start"], g["numel"]
             _lib.check(lib.sdfhip_adam_step(_lib.ptr(P[a:a + n]), _lib.ptr(G[a:a + n]), _lib.ptr(self.exp_avg[a:a + n]),

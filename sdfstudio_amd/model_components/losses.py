@@ -2,27 +2,16 @@
 
 interlevel_loss_zip restates nerfstudio/model_components/losses.py:116-172 (Zip-NeRF proposal loss) on flat
 ``[N,S+1]`` spacing-domain bins.  Only the proposal weights carry gradient (the field's weights are detached, :134).
-On a HIP device each proposal level is ONE kernel launch (sdfhip_interlevel_terms: one wavefront per ray, the blurred
-histogram built by merging the two sorted knot sequences instead of sorting them) plus a mean; the torch formulation below
-(``interlevel_loss_zip_torch``: sort, gathers, cumsums, searchsorted - ~40 launches) remains as the host-side statement
-the CPU tests compare with the oracle.  The mono-prior losses are small torch reductions over rendered per-ray outputs.
+Each proposal level is ONE kernel launch (sdfhip_interlevel_terms: one wavefront per ray, the blurred histogram built by
+merging the two sorted knot sequences instead of sorting them) plus a mean; the reference's formulation (sort, gathers, cumsums,
+searchsorted: ~40 launches) lives in oracle/sdf_path.py as the checker.  There is no CPU path: CPU tensors raise.  The mono-prior
+losses are small torch reductions over rendered per-ray outputs.
 """
 from typing import List
 
 import torch
 
 from sdfstudio_amd import _lib
-
-
-def _blurred_step(bins: torch.Tensor, heights: torch.Tensor, radius: float):
-    """losses.py:116-128 blur_stepfun: piecewise-linear blur of a step function with a box of half-width `radius`."""
-    knots = torch.cat([bins - radius, bins + radius], dim=-1)
-    knots_sorted, order = torch.sort(knots, dim=-1)
-    zero = torch.zeros_like(heights[:, :1])
-    jumps = (torch.cat([heights, zero], dim=-1) - torch.cat([zero, heights], dim=-1)) / (2 * radius)
-    slopes = torch.gather(torch.cat([jumps, -jumps], dim=-1), -1, order[:, :-1])
-    values = torch.cumsum((knots_sorted[:, 1:] - knots_sorted[:, :-1]) * torch.cumsum(slopes, dim=-1), dim=-1)
-    return knots_sorted, torch.cat([zero, values], dim=-1)
 
 
 class _InterlevelLevel(torch.autograd.Function):
@@ -50,37 +39,11 @@ class _InterlevelLevel(torch.autograd.Function):
 
 def interlevel_loss_zip(weights_list: List[torch.Tensor], bins_list: List[torch.Tensor]) -> torch.Tensor:
     """weights_list[i]: [N,S_i] (last = field weights), bins_list[i]: [N,S_i+1] spacing bins (last = field bins)."""
-    if not weights_list[-1].is_cuda:
-        return interlevel_loss_zip_torch(weights_list, bins_list)
     c = bins_list[-1].detach()
     w = weights_list[-1].detach()
     total = 0.0
     for cp, wp, radius in zip(bins_list[:-1], weights_list[:-1], (0.03, 0.003)):
         total = total + _InterlevelLevel.apply(wp, c, w, cp.detach(), radius)
-    return total
-
-
-def interlevel_loss_zip_torch(weights_list: List[torch.Tensor], bins_list: List[torch.Tensor]) -> torch.Tensor:
-    """The same loss as plain torch ops (any device): the formulation of the reference, statement by statement."""
-    c = bins_list[-1].detach()
-    w = weights_list[-1].detach()
-    w_norm = w / (c[:, 1:] - c[:, :-1])
-    total = 0.0
-    for cp, wp, radius in zip(bins_list[:-1], weights_list[:-1], (0.03, 0.003)):
-        xr, yr = _blurred_step(c, w_norm, radius)
-        yr = torch.clip(yr, min=0)
-        area = torch.cumsum((yr[:, 1:] + yr[:, :-1]) * 0.5 * (xr[:, 1:] - xr[:, :-1]), dim=-1)
-        area = torch.cat([torch.zeros_like(area[:, :1]), area], dim=-1)
-        cp = cp.detach().contiguous()
-        idx = torch.searchsorted(xr, cp, side="right")
-        top = xr.shape[-1] - 1
-        lo, hi = torch.clamp(idx - 1, 0, top), torch.clamp(idx, 0, top)
-        x0, x1 = torch.gather(xr, -1, lo), torch.gather(xr, -1, hi)
-        a0, a1 = torch.gather(area, -1, lo), torch.gather(area, -1, hi)
-        t = torch.clip(torch.nan_to_num((cp - x0) / (x1 - x0), 0), 0, 1)
-        cum = a0 + t * (a1 - a0)
-        w_target = cum[:, 1:] - cum[:, :-1]
-        total = total + torch.mean(torch.clip(w_target - wp, min=0) ** 2 / (wp + 1e-5))
     return total
 
 

@@ -264,15 +264,22 @@ def test_host_model_structure_matches_reference_parameter_names():
         getattr(model.field, n).weight_v.numel() + getattr(model.field, n).bias.numel() for n in model.field._lin_names)
 
 
-def test_interlevel_loss_host_matches_oracle():
+def test_product_losses_and_optimizer_have_no_cpu_path():
+    """The product raises on CPU tensors instead of falling back: interlevel_loss_zip is the sdfhip kernel (its torch statement
+    lives in oracle/, the checker), FusedAdam.step is the sdfhip kernel."""
+    from sdfstudio_amd import _lib
+    from sdfstudio_amd.distributed import FlatGradients
+    from sdfstudio_amd.engine.optimizers import FusedAdam
     from sdfstudio_amd.model_components.losses import interlevel_loss_zip
 
-    torch.manual_seed(1)
     bins = [torch.sort(torch.rand(6, s + 1), dim=-1)[0] for s in (32, 24, 16)]
     ws = [torch.rand(6, s).requires_grad_(True) for s in (32, 24, 16)]
-    a = interlevel_loss_zip(ws, bins)
-    b = O.interlevel_loss_zip(ws, bins)
-    assert abs(a.item() - b.item()) <= 1e-6 * abs(b.item())
+    with pytest.raises(_lib.SdfHipError):
+        interlevel_loss_zip(ws, bins)
+    p = torch.nn.Parameter(torch.zeros(5))
+    opt = FusedAdam({"g": {"params": [p], "lr": 1e-3}}, FlatGradients([p]))
+    with pytest.raises(_lib.SdfHipError):
+        opt.step()
 
 
 def test_mono_prior_losses_against_reference():
@@ -502,8 +509,8 @@ def test_neus_facto_training_schedules_against_reference():
 
 
 def test_adam_reference_statement_equals_torch_adam():
-    """engine.optimizers.adam_reference (the formula the HIP kernel restates) against torch.optim.Adam, several steps, eps 1e-15."""
-    from sdfstudio_amd.engine.optimizers import adam_reference
+    """oracle.adam_reference (the formula the HIP kernel restates) against torch.optim.Adam, several steps, eps 1e-15."""
+    adam_reference = O.adam_reference
 
     torch.manual_seed(0)
     p0 = torch.randn(1001)

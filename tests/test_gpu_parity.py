@@ -528,7 +528,7 @@ def test_neus_render_fwd_bwd(device, S, white):
 def test_interlevel_loss_kernel(device, shape):
     """sdfhip_interlevel_terms (one wave per ray, merge instead of sort) against the oracle's statement of losses.py:116-172:
     loss value and the gradient w.r.t. both proposal levels' weights; ragged sizes, empty-weight rays, coincident knots."""
-    from sdfstudio_amd.model_components.losses import interlevel_loss_zip, interlevel_loss_zip_torch
+    from sdfstudio_amd.model_components.losses import interlevel_loss_zip
 
     S, S0, S1 = shape
     n = 67
@@ -549,8 +549,6 @@ def test_interlevel_loss_kernel(device, shape):
     wg = [x.detach().to(device).requires_grad_(True) for x in wl[:2]] + [w.to(device)]
     got = interlevel_loss_zip(wg, [b.to(device) for b in bl])
     got.backward()
-    host = interlevel_loss_zip_torch([x.detach() for x in wl], bl)
-    assert_close("interlevel (torch mirror)", host, ref.detach(), rtol=1e-5, atol=1e-7)
     assert torch.isfinite(ref).item()
     # the blur divides differences of normalised weights by 2 r = 0.006 and the loss differences cumulative sums: fp32 round-off of
     # the reference's own sequential cumsum is ~1e-3 of single gradient entries, so the bar is the fp64 evaluation of the oracle
