@@ -235,6 +235,13 @@ int sdfhip_march_count(const float* origins, const float* dirs, const float* t_m
 int sdfhip_march_write(const float* origins, const float* dirs, const float* t_min, const float* t_max, const float* roi_aabb6_host,
                        const uint8_t* binary, int64_t n_rays, int32_t resolution, float step, const int64_t* offsets,
                        int64_t* ray_indices, float* t_starts, float* t_ends, sdfhip_stream_t stream);
+/* nerfacc.ray_resampling (model_components/ray_samplers.py:1496-1498; NeuSAccSampler(importance_sampling=True)): every ray that has
+ * samples gets n_out new intervals whose n_out + 1 edges are the inverse CDF of its packed weights (padded to a sum >= 1e-5) at
+ * u_j = 1 / (2 (n_out + 1)) + j (1 - 1 / (n_out + 1)) / n_out, linear inside the source intervals.  out_offsets [n_rays]: where
+ * ray r's n_out outputs start (non-empty rays packed in order); rays without samples write nothing. */
+int sdfhip_packed_resample(const float* t_starts, const float* t_ends, const float* weights, const int64_t* offsets,
+                           const int32_t* counts, int64_t n_rays, int32_t n_out, const int64_t* out_offsets, float* out_starts,
+                           float* out_ends, sdfhip_stream_t stream);
 /* nerfacc.render_weight_from_alpha (models/neus_acc.py:103-107): weights_i = alpha_i T_i with T_i = prod_{j<i} (1 - alpha_j)
  * inside each ray's segment; trans receives T (the backward reads it).  Backward: alpha_bar from weights_bar. */
 int sdfhip_packed_weights_forward(const float* alpha, const int64_t* offsets, const int32_t* counts, int64_t n_rays, float* weights,

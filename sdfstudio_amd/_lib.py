@@ -98,6 +98,8 @@ _SIGNATURES = {
                                    c_f32, ctypes.c_void_p, ctypes.c_void_p]),
     "sdfhip_march_write": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, c_i64, c_i32,
                                    c_f32, ctypes.c_void_p, ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_void_p]),
+    "sdfhip_packed_resample": (c_i32, [c_float_p, c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_void_p, c_i64, c_i32, ctypes.c_void_p, c_float_p,
+                                       c_float_p, ctypes.c_void_p]),
     "sdfhip_packed_weights_forward": (c_i32, [c_float_p, ctypes.c_void_p, ctypes.c_void_p, c_i64, c_float_p, c_float_p, ctypes.c_void_p]),
     "sdfhip_packed_weights_backward": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_void_p, c_i64, c_float_p,
                                                ctypes.c_void_p]),

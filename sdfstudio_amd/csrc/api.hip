@@ -1417,6 +1417,28 @@ extern "C" int sdfhip_march_write(const float* origins, const float* dirs, const
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }
+extern "C" int sdfhip_packed_resample(const float* t_starts, const float* t_ends, const float* weights, const int64_t* offsets,
+                                      const int32_t* counts, int64_t n_rays, int32_t n_out, const int64_t* out_offsets, float* out_starts,
+                                      float* out_ends, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(t_starts && t_ends && weights && offsets && counts && out_offsets && out_starts && out_ends && n_out >= 1,
+                 "packed_resample: bad argument");
+  if (n_rays == 0) return 0;
+  ResampleArgs a;
+  memset(&a, 0, sizeof(a));
+  a.offsets = offsets;
+  a.counts = counts;
+  a.t_starts = t_starts;
+  a.t_ends = t_ends;
+  a.weights = weights;
+  a.N = (int)n_rays;
+  a.n_out = n_out;
+  a.out_starts = out_starts;
+  a.out_ends = out_ends;
+  a.out_offsets = out_offsets;
+  packed_resample_kernel<<<(unsigned)((n_rays + 127) / 128), 128, 0, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 extern "C" int sdfhip_packed_weights_forward(const float* alpha, const int64_t* offsets, const int32_t* counts, int64_t n_rays,
                                              float* weights, float* trans, sdfhip_stream_t stream) {
   SDFHIP_REQUIRE(offsets && counts && weights && trans, "packed_weights_forward: null argument");

@@ -89,6 +89,57 @@ __global__ void march_kernel(const MarchArgs a) {
   if constexpr (!WRITE) a.counts[ray] = j;
 }
 
+// nerfacc.ray_resampling (model_components/ray_samplers.py:1496-1498, importance_sampling = True): per ray, n_out new intervals whose
+// edges are the inverse CDF of the packed weights at the n_out + 1 centres u_j = (j + 1/2) / (n_out + 1) ... spaced by
+// (1 - 1 / (n_out + 1)) / n_out, linear inside the source intervals; weights are padded to a sum of at least 1e-5.  Rays without
+// samples stay empty.  Thread per ray (a serial walk over the ray's two short lists).
+struct ResampleArgs {
+  const int64_t* offsets;      // [N] source
+  const int32_t* counts;       // [N]
+  const float* t_starts;       // [P]
+  const float* t_ends;         // [P]
+  const float* weights;        // [P]
+  int32_t N, n_out;
+  float* out_starts;           // [N_nonempty * n_out], ray r at (number of non-empty rays before r) * n_out
+  float* out_ends;
+  const int64_t* out_offsets;  // [N]
+};
+__global__ void packed_resample_kernel(const ResampleArgs a) {
+  const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ray >= a.N) return;
+  const int steps = a.counts[ray];
+  if (steps == 0) return;
+  const float* st = a.t_starts + a.offsets[ray];
+  const float* en = a.t_ends + a.offsets[ray];
+  const float* w = a.weights + a.offsets[ray];
+  float* os = a.out_starts + a.out_offsets[ray];
+  float* oe = a.out_ends + a.out_offsets[ray];
+  float wsum = 0.0f;
+  for (int j = 0; j < steps; ++j) wsum += w[j];
+  const float padding = fmaxf(1e-5f - wsum, 0.0f);
+  const float pad_step = padding / (float)steps;
+  wsum += padding;
+  const int num_bins = a.n_out + 1;
+  const float cdf_step = (1.0f - 1.0f / (float)num_bins) / (float)a.n_out;
+  int idx = 0, j = 0;
+  float cdf_prev = 0.0f, cdf_next = (w[0] + pad_step) / wsum;
+  float cdf_u = 1.0f / (float)(2 * num_bins);
+  while (j < num_bins) {
+    if (cdf_u < cdf_next || idx == steps - 1) {  // (the last interval also takes what round-off leaves above its cdf)
+      const float scaling = (en[idx] - st[idx]) / (cdf_next - cdf_prev);
+      const float t = __builtin_fmaf(cdf_u - cdf_prev, scaling, st[idx]);  // one rounding (the CUDA original contracts as well)
+      if (j < num_bins - 1) os[j] = t;
+      if (j > 0) oe[j - 1] = t;
+      cdf_u += cdf_step;
+      ++j;
+    } else {
+      ++idx;
+      cdf_prev = cdf_next;
+      cdf_next += (w[idx] + pad_step) / wsum;
+    }
+  }
+}
+
 struct PackedArgs {
   const int64_t* offsets;  // [N]
   const int32_t* counts;   // [N]

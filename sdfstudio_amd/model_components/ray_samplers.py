@@ -560,19 +560,39 @@ def march_occupancy_grid(origins, directions, t_min, t_max, roi_aabb, binary, st
     return torch.stack([offsets, counts.long()], dim=-1), counts, ray_indices, t_starts, t_ends
 
 
+def resample_packed(packed_info, counts, t_starts, t_ends, weights, n_samples: int):
+    """nerfacc.ray_resampling as the reference calls it (ray_samplers.py:1496-1498) + nerfacc.unpack_info: every ray with samples
+    gets n_samples new intervals from the inverse CDF of its weights.  Returns (packed_info, counts, ray_indices, t_starts, t_ends)."""
+    lib = _lib.load()
+    dev = t_starts.device
+    n = counts.shape[0]
+    new_counts = (counts > 0).to(torch.int32) * n_samples
+    ends = torch.cumsum(new_counts.long(), dim=0)
+    offsets = ends - new_counts.long()
+    total = int(ends[-1].item()) if n > 0 else 0
+    out_s, out_e = torch.empty(total, 1, device=dev), torch.empty(total, 1, device=dev)
+    kp = _lib.Keep()
+    if total > 0:
+        _lib.check(lib.sdfhip_packed_resample(kp(t_starts.reshape(-1)), kp(t_ends.reshape(-1)), kp(weights.reshape(-1).float()),
+                                              packed_info[:, 0].contiguous().data_ptr(), counts.data_ptr(), n, n_samples, offsets.data_ptr(),
+                                              _lib.ptr(out_s), _lib.ptr(out_e), _lib.stream()), "packed_resample")
+    del kp
+    ray_indices = torch.repeat_interleave(torch.arange(n, device=dev), new_counts.long())  # nerfacc.unpack_info
+    return torch.stack([offsets, new_counts.long()], dim=-1), new_counts, ray_indices, out_s, out_e
+
+
 class NeuSAccSampler(Sampler):
     """ray_samplers.py:1315-1503: the voxel-surface guided sampler of NeuS-acc.  An occupancy grid over the scene box, pruned every
     `steps_per_grid_update` steps from the SDF at the voxel centres (update_binary_grid), drives a fixed-step march that only
     keeps samples in occupied voxels (packed samples: one flat array for all rays); until the first grid update the model runs on
-    the NeuS sampler.  importance_sampling (nerfacc.ray_resampling; off by default, :1326) is not built."""
+    the NeuS sampler.  With importance_sampling (off by default, :1326) the marched samples are re-drawn, 16 per ray, from the pdf of
+    their own alpha-composited weights (nerfacc.ray_resampling -> sdfhip_packed_resample)."""
 
     def __init__(self, aabb, neus_sampler: Optional[NeuSSampler] = None, resolution: int = 128, num_samples: int = 8,
                  num_samples_importance: int = 16, num_samples_boundary: int = 10, steps_warpup: int = 2000,
                  steps_per_grid_update: int = 1000, importance_sampling: bool = False, local_rank: int = 0,
                  single_jitter: bool = False) -> None:
         super().__init__()
-        if importance_sampling:
-            raise NotImplementedError("NeuSAccSampler(importance_sampling=True) (nerfacc.ray_resampling) is not built")
         self.resolution, self.num_samples, self.num_samples_importance = resolution, num_samples, num_samples_importance
         self.num_samples_boundary, self.single_jitter, self.importance_sampling = num_samples_boundary, single_jitter, importance_sampling
         self.steps_warpup, self.steps_per_grid_update, self.local_rank = steps_warpup, steps_per_grid_update, local_rank
@@ -634,5 +654,14 @@ class NeuSAccSampler(Sampler):
         info, counts, ray_indices, t_starts, t_ends = march_occupancy_grid(
             ray_bundle.origins, ray_bundle.directions, ray_bundle.nears[:, 0], ray_bundle.fars[:, 0], self.aabb, self._binary,
             self.step_size)
+        ray_samples = self.create_ray_samples_from_ray_indices(ray_bundle, ray_indices, t_starts, t_ends)
+        if self.importance_sampling and ray_samples.shape[0] > 0:  # :1489-1500
+            from sdfstudio_amd.model_components.renderers import render_weight_from_alpha
+
+            assert alpha_fn is not None
+            alphas = alpha_fn(ray_samples)[:, 0, :]
+            weights = render_weight_from_alpha(alphas, info, counts)
+            info, counts, ray_indices, t_starts, t_ends = resample_packed(info, counts, t_starts, t_ends, weights[:, 0], 16)
+            ray_samples = self.create_ray_samples_from_ray_indices(ray_bundle, ray_indices, t_starts, t_ends)
         self.packed_info, self.packed_counts = info, counts
-        return self.create_ray_samples_from_ray_indices(ray_bundle, ray_indices, t_starts, t_ends), ray_indices
+        return ray_samples, ray_indices

@@ -1798,6 +1798,15 @@ def test_neus_acc_model_packed_path(device):
     far_bundle = _bundle(o + 10.0, d, cam, cfg.near, cfg.far, device)
     out0 = model(far_bundle)
     assert float(out0["rgb"].abs().max()) == 0.0 and out0["eik_grad"].shape == (n, 3)
+    # importance sampling (:1489-1500): 16 samples per ray re-drawn from the pdf of the marched samples' own weights
+    smp.importance_sampling = True
+    out2 = model(_bundle(o, d, cam, cfg.near, cfg.far, device))
+    r_info, r_s, r_e = O.ray_resampling(info, ts, te, w, 16)
+    assert torch.equal(smp.packed_info.cpu(), r_info) and set(smp.packed_counts.cpu().tolist()) <= {0, 16}
+    # (the pdf comes from the product's alphas, which differ from the oracle's by round-off: edges to 1e-4 of the march step count)
+    assert_close("resampled starts", out2["ray_samples"].flat_starts.cpu(), r_s, rtol=0, atol=2e-4)
+    assert_close("resampled ends", out2["ray_samples"].flat_ends.cpu(), r_e, rtol=0, atol=2e-4)
+    assert torch.isfinite(out2["rgb"]).all() and float(out2["accumulation"].max()) <= 1.0 + 1e-4
 
 
 # ------------------------------------------------------------------------------------------------ "grid" background field (config 5)
@@ -1914,3 +1923,31 @@ def test_volsdf_render_fwd_bwd(device, S, white):
         assert_close(name, a, b.float(), rtol=1e-4, atol=1e-6)
     for name, a, b in zip(["d / d sdf", "d / d gradient", "d / d rgb", "d / d beta"], ggot, gref):
         assert_close(name, a, b.float(), rtol=1e-3, atol=1e-6)
+
+
+def test_packed_resampling_against_oracle(device):
+    """sdfhip_packed_resample (nerfacc.ray_resampling as ray_samplers.py:1496-1498 calls it: NeuSAccSampler(importance_sampling=True))
+    against the oracle's fp32 restatement, bit for bit: rays with 0, 1 and many samples, zero weights (padded pdf), and the sampler's
+    own use of it after a grid update."""
+    from sdfstudio_amd.model_components.ray_samplers import resample_packed
+
+    gen = torch.Generator().manual_seed(6)
+    counts = torch.tensor([0, 3, 40, 1, 0, 17, 200, 2])
+    offs = torch.cumsum(counts, 0) - counts
+    info = torch.stack([offs, counts], -1)
+    st, en = [], []
+    for c in counts.tolist():
+        e = torch.sort(torch.rand(c + 1, generator=gen) * 3 + 0.5)[0]
+        st.append(e[:-1])
+        en.append(e[1:])
+    st, en = torch.cat(st)[:, None], torch.cat(en)[:, None]
+    w = torch.rand(int(counts.sum()), generator=gen) * 0.2
+    w[int(offs[3])] = 0.0          # a ray whose only sample has no weight
+    w[int(offs[5]):int(offs[5]) + 17] = 0.0  # a ray of zero weights: uniform through the padding
+    ref_info, ref_s, ref_e = O.ray_resampling(info, st, en, w, 16)
+    g_info, g_counts, g_ri, g_s, g_e = resample_packed(info.to(device), counts.to(torch.int32).to(device), st.to(device), en.to(device),
+                                                       w.to(device), 16)
+    assert torch.equal(g_info.cpu(), ref_info) and torch.equal(g_counts.cpu().long(), ref_info[:, 1])
+    assert torch.equal(g_ri.cpu(), torch.repeat_interleave(torch.arange(len(counts)), ref_info[:, 1]))
+    assert torch.equal(g_s.cpu(), ref_s) and torch.equal(g_e.cpu(), ref_e)
+    assert bool((ref_e >= ref_s).all())
