@@ -727,3 +727,33 @@ def test_oracle_nerfacto_background_field_against_reference(training):
     assert_close("density", out["density"], key["DENSITY"][..., 0], rtol=1e-5, atol=1e-7)
     assert_close("rgb", out["rgb"], key["RGB"], rtol=1e-5, atol=1e-6)
     assert float(out["density"].std()) > 0 and float(out["rgb"].std()) > 1e-3
+
+
+def test_oracle_neus_acc_grid_update_against_reference():
+    """NeuSAccSampler.update_binary_grid / update_step_size (model_components/ray_samplers.py:1379-1432): the oracle's restatement
+    against the reference's own sampler object run on CPU (nerfacc is stubbed: the two methods are plain torch), two successive
+    updates - pruned voxels never come back."""
+    from oracle import ref_harness
+
+    if not ref_harness.reference_available():
+        pytest.skip("needs /root/reference (build container)")
+    ns = ref_harness.import_reference()
+    import nerfstudio.model_components.ray_samplers as rs
+
+    cfg = small_oracle_cfg()
+    p = O.init_field_params(cfg.field, num_images=4, seed=3)
+    aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+    smp = rs.NeuSAccSampler(aabb=aabb, neus_sampler=None, resolution=32, steps_warpup=10, steps_per_grid_update=5)
+    sdf_fn = lambda x: O.geo_network(x, p, cfg.field)[:, 0]
+    binary = torch.ones(32, 32, 32, dtype=torch.bool)
+    for step, var in ((10, 0.45), (15, 0.6)):
+        inv_s = lambda v=var: O.neus_inv_s(torch.tensor([v]))
+        smp.update_step_size(step, inv_s=inv_s)
+        assert abs(smp.step_size - 14.0 / float(inv_s()) / 16) < 1e-12
+        smp.update_binary_grid(step, sdf_fn=sdf_fn, inv_s=inv_s)
+        binary = O.neus_acc_binary_update(binary, smp.cube_coordinate, sdf_fn, inv_s(), float(smp.voxel_size), smp.step_size)
+        assert torch.equal(binary, smp._binary)
+        assert 0.0 < float(binary.float().mean()) < 1.0
+    assert int(smp._update_counter) == 2
+    smp.update_binary_grid(16, sdf_fn=sdf_fn, inv_s=inv_s)  # not a multiple of steps_per_grid_update: nothing happens
+    assert int(smp._update_counter) == 2
