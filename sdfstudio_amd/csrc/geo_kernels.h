@@ -20,7 +20,7 @@
 // that behind the sequential instruction prefetch; on some the fetch rate of code that misses the cache drops from 1.2 to
 // 2.9 cycles per instruction (tools/probe_icache.hip) and exactly the kernels larger than the cache ran 2.4x slower
 // (DESIGN.md section 5).  Each pass below is therefore a RUN-TIME loop over the layers around ONE instance of the
-// hidden -> hidden gemm (~20 KB) and one of the small in0 gemm:
+// hidden -> hidden gemm (~25 KB) and one of the small in0 gemm, and each pass is its own LAUNCH (template parameter PHASE):
 //   * every hidden layer is NBH blocks wide - the layer below the skip concatenation is padded from H - D0 to H rows
 //     (zero weights, NB3 == NBH), so that layer and the skip layer have the regular shape;
 //   * the skip layer's input cat([h, in0]) is two gemms into the same accumulators: the regular one over h and the in0 gemm

@@ -10,21 +10,22 @@
 //       start the LDS-DMA of the next chunk (possibly the first chunk of the NEXT gemm: the stream never drains)
 //       issue the global loads the producer of block kb + 2 needs
 //       produce block kb + 1 (VALU) and split it into bf16 parts, interleaved with
-//       2 x NBO x {3 | 6}  v_mfma_f32_32x32x16_bf16  with A = weight fragments from LDS (ds_read_b128: 8 k per read),
+//       2 x NBO x {3 | 6}  v_mfma_f32_32x32x16_{bf16,f16}  with A = weight fragments from LDS (ds_read_b128: 8 k per read),
 //                                                        B = the parts of block kb (own registers)
 //
-// Numerics: fp32 in, fp32 accumulate, products by SPLIT bf16.  x = x0 + x1 (+ x2) with x0 = bf16(x), x1 = bf16(x - x0), ...
-// (each part carries 8 more mantissa bits; a product of two bf16 is exact in fp32), and
-//   NS = 2:  w x ~ w1 x0 + w0 x1 + w0 x0                                 (3 MFMAs, relative product error ~2^-16)
-//   NS = 3:  w x ~ w1 x1 + w2 x0 + w0 x2 + w1 x0 + w0 x1 + w0 x0        (6 MFMAs, all 24 mantissa bits: fp32-class)
-// The matrix pipe runs bf16 16x faster than fp32 (MI355X: 2.5 PFLOP/s vs 157 TFLOP/s), so even the 6-term form is
-// ~2.7x cheaper than v_mfma_f32_32x32x2_f32.  The forward layers (whose outputs have parity targets: 1e-5 on SDF) use
-// NS = 3; the derivative / gradient passes use NS = 2.  Activations never leave the register file between layers and
+// Numerics: fp32 in, fp32 accumulate, products by SPLIT 16-bit parts.  x = x0 + x1 (+ x2) with x0 = round16(x), x1 = round16(x - x0), ...
+// (a product of two bf16 / fp16 values is exact in fp32), and
+//   NS = 2:  bf16 hi + lo, w x ~ w1 x0 + w0 x1 + w0 x0                      (3 MFMAs, relative product error ~2^-17)
+//   NS = 3:  three bf16 parts, w1 x1 + w2 x0 + w0 x2 + w1 x0 + w0 x1 + w0 x0 (6 MFMAs, all 24 mantissa bits: fp32-class)
+//   NS = 4:  fp16 hi + lo, the same three terms as NS = 2                    (3 MFMAs, 22 mantissa bits: fp32-class for O(1) data)
+// The matrix pipe runs 16-bit inputs 16x faster than fp32 (MI355X: 2.5 PFLOP/s vs 157 TFLOP/s), so the 3-term forms are ~5x cheaper
+// than v_mfma_f32_32x32x2_f32.  The forward passes (whose outputs have parity targets: 1e-5 on SDF) use NS = 4; the derivative /
+// gradient passes, whose operands have arbitrary scale, use NS = 2.  Activations never leave the register file between layers and
 // the weights move L2 -> LDS by DMA (global_load_lds_dwordx4) without passing through registers.
 //
-// Weight chunk layout (pack_kernel), bf16:  Wp[kb][part 0..2][ob][kk 0..1][lane][j 0..7]
+// Weight chunk layout (pack_kernel), 16-bit:  Wp[kb][part 0..4 = bf16 x 3, fp16 x 2][ob][kk 0..1][lane][j 0..7]
 //   = part of  W[out = 32 ob + (lane & 31)][k = 32 kb + tp_row(8 kk + j, lane >> 5)]
-// One ds_read_b128 is the A operand of one MFMA; a gemm that runs NS = 2 streams only parts 0, 1 of every chunk.
+// One ds_read_b128 is the A operand of one MFMA; a gemm streams only the parts of its mode (chunk_part_offset).
 #pragma once
 #include "common.h"
 
