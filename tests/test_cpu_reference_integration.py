@@ -143,18 +143,23 @@ def test_reference_model_runs_with_the_hip_field_plugged_in(ref, which, monkeypa
     assert all(torch.isfinite(v) for v in outs["hybrid"][1].values())
 
 
-@pytest.mark.parametrize("which", ["neus_facto", "neus", "volsdf", "unisurf"])
-@pytest.mark.parametrize("background", ["none", "mlp"])
+@pytest.mark.parametrize("which", ["neus_facto", "neus", "volsdf", "unisurf", "neus_acc"])
+@pytest.mark.parametrize("background", ["none", "mlp", "grid"])
 def test_model_mirrors_have_the_reference_checkpoint_layout(ref, which, background):
     """The MODEL mirrors of this repo (sdfstudio_amd/models/*.py) against the reference's own model classes: same state_dict keys and
     shapes (a reference checkpoint loads strictly), except what INTEGRATION.md documents - the proposal networks' tcnn blob
     (`mlp_base.encoding.params` + its two weight matrices, here `mlp_base.table / w1 / w2`) and the reference-only
-    `device_indicator_param` / proposal `aabb` entries; and the same optimiser parameter groups."""
+    `device_indicator_param` / proposal `aabb` entries, and the "grid" background field's table, which the tinycudann shim of
+    oracle/ref_harness.py names `mlp_base.encoding.params` (real tcnn: one fp16 `params` blob per module); and the same optimiser
+    parameter groups."""
     import nerfstudio.models.unisurf as ru
     import nerfstudio.models.volsdf as rv
 
     from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
+    import nerfstudio.models.neus_acc as rna
+
     from sdfstudio_amd.models.neus import NeuSModel, NeuSModelConfig
+    from sdfstudio_amd.models.neus_acc import NeuSAccModel, NeuSAccModelConfig
     from sdfstudio_amd.models.neus_facto import NeuSFactoModel, NeuSFactoModelConfig, SceneBox
     from sdfstudio_amd.models.unisurf import UniSurfModel, UniSurfModelConfig
     from sdfstudio_amd.models.volsdf import VolSDFModel, VolSDFModelConfig
@@ -170,6 +175,10 @@ def test_model_mirrors_have_the_reference_checkpoint_layout(ref, which, backgrou
         extra = dict(num_samples=16, num_samples_importance=16, num_up_sample_steps=2)
         theirs = ref.rn.NeuSModelConfig(sdf_field=theirs_f, **kw, **extra)
         ours = NeuSModel(NeuSModelConfig(sdf_field=ours_f, **kw, **extra), box, 49)
+    elif which == "neus_acc":
+        extra = dict(num_samples=16, num_samples_importance=16, num_up_sample_steps=2)
+        theirs = rna.NeuSAccModelConfig(sdf_field=theirs_f, **kw, **extra)
+        ours = NeuSAccModel(NeuSAccModelConfig(sdf_field=ours_f, **kw, **extra), box, 49)
     elif which == "volsdf":
         extra = dict(num_samples=16, num_samples_eval=32, num_samples_extra=8)
         theirs = rv.VolSDFModelConfig(sdf_field=theirs_f, **kw, **extra)
@@ -185,14 +194,14 @@ def test_model_mirrors_have_the_reference_checkpoint_layout(ref, which, backgrou
         for k, v in sd.items():
             if k == "device_indicator_param" or (k.startswith("proposal_networks.") and (k.endswith(".aabb") or ".mlp_base." in k)):
                 continue
-            out[k] = tuple(v.shape)
+            out[k.replace("field_background.mlp_base.encoding.params", "field_background.mlp_base.table")] = tuple(v.shape)
         return out
 
     a, b = norm(ours.state_dict()), norm(pure.state_dict())
     assert a == b, {"only ours": sorted(set(a) - set(b)), "only reference": sorted(set(b) - set(a)),
                     "shape": [k for k in a if k in b and a[k] != b[k]]}
     missing, unexpected = ours.load_state_dict({k: v for k, v in pure.state_dict().items() if k in a}, strict=False)
-    assert all(k.startswith("proposal_networks.") for k in missing) and not unexpected
+    assert all(k.startswith("proposal_networks.") or k == "field_background.mlp_base.table" for k in missing) and not unexpected
     go, gp = ours.get_param_groups(), pure.get_param_groups()
     # (the reference lists its frozen dummy background parameter as a group; groups are compared by what an optimiser would train)
     assert {k for k, v in go.items() if any(p.requires_grad for p in v)} == {k for k, v in gp.items() if any(p.requires_grad for p in v)}
