@@ -757,3 +757,30 @@ def test_oracle_neus_acc_grid_update_against_reference():
     assert int(smp._update_counter) == 2
     smp.update_binary_grid(16, sdf_fn=sdf_fn, inv_s=inv_s)  # not a multiple of steps_per_grid_update: nothing happens
     assert int(smp._update_counter) == 2
+
+
+def test_every_kernel_fits_the_instruction_cache():
+    """Regression guard for DESIGN.md section 5: on one class of MI355X boxes code that misses the 64 KB instruction cache is fetched
+    at less than half the rate, which made the (then 330 - 380 KB) fused kernels 2.4x slower there.  Every kernel of the built
+    library must stay below 64 KB of code (tools/kernel_resources.py reads the sizes out of the code object; no GPU needed), and
+    the training launches of the benchmarked shape must not spill registers."""
+    import shutil
+    import subprocess
+    import sys
+
+    lib = os.path.join(ROOT, "sdfstudio_amd", "libsdfhip.so")
+    if not os.path.exists(lib) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf") or shutil.which("objcopy") is None:
+        pytest.skip("needs the built library and the ROCm LLVM tools")
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), lib], text=True)
+    rows = [line for line in out.splitlines()[1:] if line.strip()]
+    assert len(rows) > 100
+    parsed = []
+    for line in rows:
+        name, rest = line.rsplit('",', 1)
+        code, vgpr, agpr, sgpr, scratch, lds = rest.split(",")
+        parsed.append((name.strip('"'), int(code), int(scratch)))
+    worst = max(parsed, key=lambda r: r[1])
+    assert worst[1] < 64 * 1024, f"{worst[0]}: {worst[1]} bytes of code"
+    train = [r for r in parsed if r[0].startswith(("geo_fwd_kernel<GeoDims<8, 3, 8>, true, true, true, 2", "geo_bwd_kernel<GeoDims<8, 3, 8>, true",
+                                                   "col_fwd_kernel<ColDims<8, 3, 8>, true", "col_bwd_kernel<ColDims<8, 3, 8>", "wgrad_bf16x8_kernel"))]
+    assert len(train) >= 8 and all(r[2] == 0 for r in train), [r for r in train if r[2]]
