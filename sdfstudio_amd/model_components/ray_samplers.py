@@ -572,11 +572,12 @@ def resample_packed(packed_info, counts, t_starts, t_ends, weights, n_samples: i
     total = int(ends[-1].item()) if n > 0 else 0
     out_s, out_e = torch.empty(total, 1, device=dev), torch.empty(total, 1, device=dev)
     kp = _lib.Keep()
+    src_offsets = packed_info[:, 0].contiguous()  # bound to a local: the pointer must outlive the launch
     if total > 0:
         _lib.check(lib.sdfhip_packed_resample(kp(t_starts.reshape(-1)), kp(t_ends.reshape(-1)), kp(weights.reshape(-1).float()),
-                                              packed_info[:, 0].contiguous().data_ptr(), counts.data_ptr(), n, n_samples, offsets.data_ptr(),
+                                              src_offsets.data_ptr(), counts.data_ptr(), n, n_samples, offsets.data_ptr(),
                                               _lib.ptr(out_s), _lib.ptr(out_e), _lib.stream()), "packed_resample")
-    del kp
+    del kp, src_offsets
     ray_indices = torch.repeat_interleave(torch.arange(n, device=dev), new_counts.long())  # nerfacc.unpack_info
     return torch.stack([offsets, new_counts.long()], dim=-1), new_counts, ray_indices, out_s, out_e
 
