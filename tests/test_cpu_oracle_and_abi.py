@@ -784,3 +784,20 @@ def test_every_kernel_fits_the_instruction_cache():
     train = [r for r in parsed if r[0].startswith(("geo_fwd_kernel<GeoDims<8, 3, 8>, true, true, true, 2", "geo_bwd_kernel<GeoDims<8, 3, 8>, true",
                                                    "col_fwd_kernel<ColDims<8, 3, 8>, true", "col_bwd_kernel<ColDims<8, 3, 8>", "wgrad_bf16x8_kernel"))]
     assert len(train) >= 8 and all(r[2] == 0 for r in train), [r for r in train if r[2]]
+
+
+def test_no_device_pointer_is_taken_from_a_temporary():
+    """A pointer handed to the library must come from a tensor that stays bound until the launch has been issued (ADVICE round 1:
+    `ptr(x.contiguous())` frees the copy before the next argument is evaluated and the allocator may hand the same block to that
+    argument's copy).  Source-level guard over the product package."""
+    # (.detach() / .view() share the storage of a tensor that lives on: not copies)
+    pat = re.compile(r"(ptr\([^()]*\.(contiguous|float|reshape|clone)\([^()]*\)\s*\))|(\)\s*\.data_ptr\(\))")
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "sdfstudio_amd")):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            for i, line in enumerate(open(os.path.join(dirpath, f)), 1):
+                if pat.search(line.split("#")[0]):
+                    bad.append(f"{os.path.relpath(os.path.join(dirpath, f), ROOT)}:{i}: {line.strip()}")
+    assert not bad, "\n".join(bad)
