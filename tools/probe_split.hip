@@ -1,6 +1,11 @@
-// Dev probe: fused 8 x (256 x 256) stack with split-bf16 products on v_mfma_f32_32x32x16_bf16 (fp32 accumulate).
-//   NS = 2: x = hi + lo,        3 MFMAs per product  (error ~2^-16 per product)
+// Dev probe: fused 8 x (256 x 256) stack with split 16-bit products on v_mfma_f32_32x32x16_{bf16,f16} (fp32 accumulate).
+//   NS = 2: x = hi + lo,        3 MFMAs per product  (bf16: error ~2^-16 per product)
 //   NS = 3: x = hi + mid + lo,  6 MFMAs per product  (fp32-class error)
+//   -DPROBE_F16:   the parts are fp16 instead of bf16 (NS = 2 then carries 22 mantissa bits: fp32-class with 3 MFMAs - the forward
+//                  mode of the product kernels, mlp_core.h NS = 4)
+//   -DPROBE_PKRTZ: (with PROBE_F16) hi parts by v_cvt_pkrtz_f16_f32 on element pairs (round toward zero; the lo part absorbs the
+//                  truncation) - a cheaper producer, to be measured for accuracy and speed
+//   -DPROBE_RELU / -DPROBE_LOOPED / -DABL=n: see main() and the kernel
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
@@ -8,6 +13,7 @@
 #include "common.h"
 void sdfhip_set_error(const char*, ...) {}
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 #ifndef PROBE_L
 #define PROBE_L 8
 #endif
@@ -30,11 +36,33 @@ __device__ __forceinline__ Split<NS> split_block(const f32x16& v) {
       float r = v[kk * 8 + j];
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
+#ifdef PROBE_F16
+        r = __builtin_amdgcn_fmed3f(r, -65504.0f, 65504.0f);
+        const _Float16 h = (_Float16)r;
+        s.p[q][kk][j] = __builtin_bit_cast(__bf16, h);
+#else
         const __bf16 h = (__bf16)r;
         s.p[q][kk][j] = h;
+#endif
         r -= (float)h;
       }
     }
+#if defined(PROBE_F16) && defined(PROBE_PKRTZ)
+  // hi parts of element pairs in one instruction (round toward zero), lo = fp16(x - hi)
+  typedef __fp16 half2_t __attribute__((ext_vector_type(2)));
+  if constexpr (NS == 2)  // hi + lo only (the three-part form keeps the rounding conversions above)
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+      const float r0 = __builtin_amdgcn_fmed3f(v[kk * 8 + j], -65504.0f, 65504.0f), r1 = __builtin_amdgcn_fmed3f(v[kk * 8 + j + 1], -65504.0f, 65504.0f);
+      const half2_t h = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+      s.p[0][kk][j] = __builtin_bit_cast(__bf16, (_Float16)h[0]);
+      s.p[0][kk][j + 1] = __builtin_bit_cast(__bf16, (_Float16)h[1]);
+      s.p[1][kk][j] = __builtin_bit_cast(__bf16, (_Float16)(r0 - (float)h[0]));
+      s.p[1][kk][j + 1] = __builtin_bit_cast(__bf16, (_Float16)(r1 - (float)h[1]));
+    }
+#endif
   return s;
 }
 
@@ -120,7 +148,12 @@ __global__ __launch_bounds__(256, 1) void split_kernel(const float* __restrict__
         for (int t = 0; t < NT; ++t)
 #pragma unroll
           for (int ob = 0; ob < NB; ++ob)
+#ifdef PROBE_F16
+            out[ob] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a[ta[t]][ob]), __builtin_bit_cast(f16x8_t, blk.p[tb[t]][kk]),
+                                                             out[ob], 0, 0, 0);
+#else
             out[ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ta[t]][ob], blk.p[tb[t]][kk], out[ob], 0, 0, 0);
+#endif
       }
       cur = (cur + 1) % NBUF;
       if constexpr (kb + 1 < NB) blk = nxt;
@@ -171,8 +204,16 @@ static void run(const char* name, int64_t P, const float* d_in, float* d_out, un
               const int o = ob * 32 + (lane & 31), k = kb * 32 + tp_row(kk * 8 + j, lane >> 5);
               float r = W[((size_t)l * 256 + o) * 256 + k];
               for (int q = 0; q < NS; ++q) {
+#ifdef PROBE_F16
+                const _Float16 h16 = (_Float16)r;
+                const __bf16 h = __builtin_bit_cast(__bf16, h16);
+                Wp[(size_t)(l * NB + kb) * CH + (((q * NB + ob) * 2 + kk) * 64 + lane) * 8 + j] = h;
+                r -= (float)h16;
+                continue;
+#else
                 const __bf16 h = to_bf16(r);
                 Wp[(size_t)(l * NB + kb) * CH + (((q * NB + ob) * 2 + kk) * 64 + lane) * 8 + j] = h;
+#endif
                 r -= (float)h;
               }
             }
