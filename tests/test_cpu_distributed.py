@@ -127,3 +127,86 @@ def test_bench_parameter_groups_bucketed_allreduce_world2():
     # active prefix: the first 1000 table entries are means (equal on both ranks), the tail kept the local gradient
     assert torch.equal(t0[:1000], t1[:1000]) and not torch.equal(t0[1000:], t1[1000:])
     assert n0 == n1
+
+
+def _order_worker(rank, world, port, ret):
+    """the collective sequence must be the same on every rank even when the autograd graphs differ.  Rank 1 leaves the
+    whole first bucket unused; rank 0 uses everything.  Buckets must leave in index order on both ranks (bucket 1 may not go out
+    from a hook while bucket 0 is still pending), and the unused bucket contributes its zeros."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sdfstudio_amd.distributed import FlatGradients
+
+    a = [torch.nn.Parameter(torch.ones(6)), torch.nn.Parameter(torch.ones(3))]
+    b = [torch.nn.Parameter(torch.ones(4))]
+    flat = FlatGradients(a + b, buckets=[a, b], chunk_numel=4)  # bucket 0 (9 elements) travels as 3 chunks
+    order = []
+    orig = flat._launch
+    flat._launch = lambda bi: (order.append(bi), orig(bi))[1]
+    for step in range(2):
+        flat.zero()
+        loss = (b[0] * 2.0).sum()
+        if rank == 0:
+            loss = loss + (a[0] * 3.0).sum() + (a[1] * 5.0).sum()
+        loss.backward()
+        assert flat.last_overlapped_buckets == (2 if rank == 0 else 0), "bucket 1 must wait for bucket 0 on the rank that never completes it"
+        flat.finish()
+        assert order[-2:] == [0, 1]
+    # protocol violations raise instead of corrupting the buffer
+    errs = []
+    try:
+        (b[0] * 1.0).sum().backward()  # backward without zero() after finish()
+    except RuntimeError as e:
+        errs.append("nozero" if "without zero" in str(e) else str(e))
+    flat.zero()
+    (b[0] * 1.0).sum().backward()
+    try:
+        (b[0] * 1.0).sum().backward()  # second backward before finish()
+    except RuntimeError as e:
+        errs.append("second" if "second backward" in str(e) else str(e))
+    flat.finish()
+    ret[rank] = (flat.flat.clone(), errs, flat.last_collectives)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_order_is_fixed_when_one_rank_skips_a_bucket_world2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_order_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    (g0, e0, n0), (g1, e1, n1) = ret[0], ret[1]
+    assert e0 == ["nozero", "second"] and e1 == ["nozero", "second"]
+    assert torch.equal(g0, g1) and n0 == n1 == 3 + 1
+    # last step: only b[0] was differentiated on both ranks (twice: the refused second backward had already accumulated when the
+    # post-accumulate hook raised - the exception is the signal); a's gradients are the zeros zero() left
+    assert torch.equal(g0, torch.cat([torch.zeros(9), torch.full((4,), 2.0)]))
+
+
+def test_zero_discards_stray_gradients_and_finish_rearms():
+    """zero() after a set_to_none zero_grad + a backward used to copy the stray gradient back into the freshly zeroed
+    buffer (flat = 5 5 5 5, next step's gradient 7 instead of 2)."""
+    from sdfstudio_amd.distributed import FlatGradients
+
+    p = torch.nn.Parameter(torch.ones(4))
+    flat = FlatGradients([p])
+    flat.zero()
+    (p * 5.0).sum().backward()
+    flat.finish()
+    p.grad = None
+    flat.zero()
+    (p * 5.0).sum().backward()   # hook folds the fresh gradient into the view
+    flat.finish()
+    assert torch.equal(flat.flat, torch.full((4,), 5.0)) and p.grad.data_ptr() == flat.flat.data_ptr()
+    p.grad = torch.full((4,), 123.0)  # a stray tensor parked in .grad between steps is discarded, not folded in
+    flat.zero()
+    assert torch.equal(flat.flat, torch.zeros(4)) and p.grad.data_ptr() == flat.flat.data_ptr()
+    (p * 2.0).sum().backward()
+    flat.finish()
+    assert torch.equal(flat.flat, torch.full((4,), 2.0))
+    try:
+        flat.finish()
+        raise AssertionError("finish() twice must raise")
+    except RuntimeError:
+        pass
