@@ -55,6 +55,11 @@ int sdfhip_grid_encode_forward(const SdfHipGridCfg* grid, const float* table, co
                                sdfhip_stream_t stream);
 int sdfhip_grid_encode_backward(const SdfHipGridCfg* grid, const float* x, int64_t n_points, const float* feat_bar, float* table_bar,
                                 sdfhip_stream_t stream);
+/* Test / diagnostic entry: the cell of every (point, level) exactly as every kernel of this library indexes the table (tcnn
+ * grid_index / pos_fract; the hashed branch is the hash of the reference's own HashEncoding.hash_fn, field_components/
+ * encodings.py:338-355, for power-of-two tables).  idx: [n_points, n_levels, 8] entry indices INCLUDING the level offset, corner k =
+ * bit 0 -> +x, bit 1 -> +y, bit 2 -> +z; w: [n_points, n_levels, 3] interpolation weights (after Smoothstep where configured). */
+int sdfhip_grid_cell_dump(const SdfHipGridCfg* grid, const float* x, int64_t n_points, uint32_t* idx, float* w, sdfhip_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------- SDF field
  * Replaces nerfstudio.fields.sdf_field.SDFField's compute: forward_geonetwork (:380-410), get_sdf (:412-418),

@@ -111,25 +111,35 @@ def _fma_half(x: torch.Tensor, scale: float) -> torch.Tensor:
     return pos
 
 
+def level_cell(x: torch.Tensor, lv: GridLevels, lvl: int):
+    """Cell of every point on level lvl: (idx [P,8] int64 table-entry indices INCLUDING the level offset, corner k = bit 0 -> +x,
+    bit 1 -> +y, bit 2 -> +z; w [P,3] interpolation weight along each axis after the optional smoothstep)."""
+    scale = float(lv.scale[lvl])
+    res, size, off = int(lv.resolution[lvl]), int(lv.size[lvl]), int(lv.offset[lvl])
+    pos = _fma_half(x, scale)
+    cell = torch.floor(pos)
+    w = pos - cell
+    if lv.smoothstep:
+        w = w * w * (3.0 - 2.0 * w)
+    c = cell.detach().to(torch.int64)
+    idx = []
+    for corner in range(8):
+        bx, by, bz = corner & 1, (corner >> 1) & 1, (corner >> 2) & 1
+        idx.append(off + corner_index(c[:, 0] + bx, c[:, 1] + by, c[:, 2] + bz, res, size, bool(lv.hashed[lvl])))
+    return torch.stack(idx, dim=-1), w
+
+
 def grid_encode(x: torch.Tensor, table: torch.Tensor, lv: GridLevels) -> torch.Tensor:
     """x: [P,3] in [0,1]; table: [n_entries, F]; returns [P, L*F]."""
     outs: List[torch.Tensor] = []
     for lvl in range(lv.n_levels):
-        scale = float(lv.scale[lvl])
-        res, size, off = int(lv.resolution[lvl]), int(lv.size[lvl]), int(lv.offset[lvl])
-        pos = _fma_half(x, scale)
-        cell = torch.floor(pos)
-        w = pos - cell
-        if lv.smoothstep:
-            w = w * w * (3.0 - 2.0 * w)
-        c = cell.detach().to(torch.int64)
+        idx, w = level_cell(x, lv, lvl)
         acc = 0.0
         for corner in range(8):
             bx, by, bz = corner & 1, (corner >> 1) & 1, (corner >> 2) & 1
             wx = w[:, 0] if bx else 1.0 - w[:, 0]
             wy = w[:, 1] if by else 1.0 - w[:, 1]
             wz = w[:, 2] if bz else 1.0 - w[:, 2]
-            idx = corner_index(c[:, 0] + bx, c[:, 1] + by, c[:, 2] + bz, res, size, bool(lv.hashed[lvl]))
-            acc = acc + (wx * wy * wz)[:, None] * table[off + idx]
+            acc = acc + (wx * wy * wz)[:, None] * table[idx[:, corner]]
         outs.append(acc)
     return torch.cat(outs, dim=-1)

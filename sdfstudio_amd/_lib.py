@@ -74,6 +74,7 @@ _SIGNATURES = {
                                       c_float_p, c_float_p, ctypes.c_void_p]),
     "sdfhip_grid_encode_forward": (c_i32, [ctypes.POINTER(GridCfg), c_float_p, c_float_p, c_i64, c_float_p, ctypes.c_void_p]),
     "sdfhip_grid_encode_backward": (c_i32, [ctypes.POINTER(GridCfg), c_float_p, c_i64, c_float_p, c_float_p, ctypes.c_void_p]),
+    "sdfhip_grid_cell_dump": (c_i32, [ctypes.POINTER(GridCfg), c_float_p, c_i64, ctypes.c_void_p, c_float_p, ctypes.c_void_p]),
     "sdfhip_proposal_forward": (c_i32, [ctypes.POINTER(GridCfg), c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
                                         c_float_p, c_float_p, c_i64, c_i32, c_i32, c_float_p, ctypes.c_void_p]),
     "sdfhip_proposal_workspace_size": (c_i64, []),

@@ -1371,6 +1371,23 @@ extern "C" int sdfhip_grid_encode_backward(const SdfHipGridCfg* grid, const floa
   return 0;
 }
 
+extern "C" int sdfhip_grid_cell_dump(const SdfHipGridCfg* grid, const float* x, int64_t n_points, uint32_t* idx, float* w,
+                                    sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(grid && x && idx && w, "grid_cell_dump: null argument");
+  if (n_points == 0) return 0;
+  GridDumpArgs a;
+  memset(&a, 0, sizeof(a));
+  const int rc = make_grid_dev(grid, &a.grid);
+  if (rc != 0) return rc;
+  a.x = x;
+  a.n_points = n_points;
+  a.idx = idx;
+  a.w = w;
+  grid_cell_dump_kernel<<<dim3((unsigned)((n_points + 255) / 256), grid->n_levels), 256, 0, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---- packed-sample path (NeuS-acc): occupancy-grid marching, segmented compositing
 static void fill_march(MarchArgs* a, const float* origins, const float* dirs, const float* t_min, const float* t_max, const float* roi_aabb6,
                        const uint8_t* binary, int64_t n_rays, int32_t resolution, float step) {

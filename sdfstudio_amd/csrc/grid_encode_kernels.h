@@ -50,3 +50,27 @@ __global__ __launch_bounds__(256) void grid_encode_kernel(const GridEncodeArgs a
     }
   }
 }
+
+// ---- test / diagnostic entry: the cell of every (point, level) exactly as the fused kernels index the table - the 8 corner entry
+// indices (level offset included; corner k: bit 0 -> +x, bit 1 -> +y, bit 2 -> +z) and the three interpolation weights.  The GPU
+// parity test compares the indices BIT FOR BIT with oracle/hashgrid.py level_cell, whose hashed branch is pinned on the
+// reference's own HashEncoding.hash_fn (field_components/encodings.py:338-355) by the CPU suite.
+struct GridDumpArgs {
+  GridDev grid;
+  const float* x;   // [P,3]
+  int64_t n_points;
+  uint32_t* idx;    // [P][L][8]
+  float* w;         // [P][L][3]
+};
+__global__ __launch_bounds__(256) void grid_cell_dump_kernel(const GridDumpArgs a) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.n_points) return;
+  const int level = blockIdx.y, L = a.grid.n_levels;
+  const float pp[3] = {a.x[p * 3], a.x[p * 3 + 1], a.x[p * 3 + 2]};
+  GridCell c;
+  grid_cell(a.grid.lv[level], a.grid.smoothstep != 0, pp, c);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) a.idx[(p * L + level) * 8 + k] = c.idx[k];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) a.w[(p * L + level) * 3 + d] = c.w[d];
+}

@@ -1,0 +1,154 @@
+"""north_star parity bars at BASELINE shape (-m gpu).
+
+BASELINE.json: "outputs match the reference CPU/PyTorch path on identical rays within 1e-4 rel on rendered RGB/depth and 1e-5 on
+SDF values".  tests/test_gpu_parity.py::test_field_and_render_on_reference_samples holds those bars on the reference's own
+samples for the small golden network; the tests here hold them at the FULL network and sampling shape of BASELINE configs 2, 4
+(NeuS-facto: 16 x 2 x 2^19 smoothstep grid, 8 x 256 + 4 x 256 MLPs, 128 samples per ray) and 1 (VolSDF, pure MLP, 64 + 32 samples),
+on IDENTICAL rays and samples: the oracle runs its own sampler, and the HIP field + compositing kernels are evaluated on the
+oracle's starts / ends (the end-to-end tests of test_gpu_parity.py let both sides sample for themselves and therefore carry the
+drift of three fp32 resamplings).  The last test pushes the real 4096 x 128 batch of the benchmark through the kernels and compares a
+64-ray subset (first, last and scattered rows) with the oracle: tail, stride and 64-bit index bugs cannot hide in small batches.
+
+Reference lines: fields/sdf_field.py:380-410,476-525,614-689, model_components/renderers.py:81-92,245-259, cameras/rays.py:146-208.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import assert_close, product_model_from_params
+from oracle import sdf_path as O
+from test_gpu_parity import _bundle, _full_shape_params
+
+pytestmark = pytest.mark.gpu
+
+SDF_ATOL = 1e-5      # north_star: 1e-5 on SDF values
+RENDER_RTOL = 1e-4   # north_star: 1e-4 relative on rendered RGB / depth (relative to the largest rendered value, plus the
+#                      element-wise gate of helpers.report: 1e-3 relative on every element above 1 % of the maximum)
+
+
+def _neus_facto_case(config):
+    inside = config == 4
+    cfg = O.ModelCfg(field=O.FieldCfg(bias=0.8 if inside else 0.5, inside_outside=inside, beta_init=0.3), num_neus_samples=128,
+                     near=0.05 if inside else 0.5, far=4.0 if inside else 4.5)
+    p = _full_shape_params(cfg)
+    n = 64
+    gen = torch.Generator().manual_seed(23)
+    if inside:
+        o = (torch.rand(n, 3, generator=gen) - 0.5) * 0.6
+        d = F.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+        cam = torch.randint(0, 49, (n,), generator=gen)
+    else:
+        o, d, cam = O.synthetic_rays(n, seed=12)
+    rand = [torch.rand(n, 1, generator=gen) for _ in range(3)]
+    return cfg, p, o, d, cam, rand
+
+
+@pytest.mark.parametrize("config", [2, 4])
+def test_northstar_bars_full_shape_neus_facto_on_oracle_samples(device, config):
+    from sdfstudio_amd.model_components.renderers import neus_render
+
+    cfg, p, o, d, cam, rand = _neus_facto_case(config)
+    cos_anneal = 0.4
+    with torch.no_grad():
+        ref = O.neus_facto_forward(o, d, cam, p, cfg, anneal=0.8, cos_anneal_ratio=cos_anneal, rand=rand, training=True)
+    assert ref["starts"].shape == (64, 128)
+    model = product_model_from_params(p, cfg, device).train()
+    model.field.set_cos_anneal_ratio(cos_anneal)
+    rb = _bundle(o, d, cam, cfg.near, cfg.far, device)
+    rs = rb.get_ray_samples(ref["starts"].to(device), ref["ends"].to(device))
+    with torch.no_grad():
+        sdf, grad, rgb, _ = model.field.forward_fused(rs)
+        out_rgb, depth, normal, acc, weights, alpha = neus_render(
+            sdf, grad, rgb, model.field.deviation_network.variance, rs.flat_directions, rs.flat_starts, rs.flat_ends, cos_anneal, None)
+    fo = ref["field"]
+    assert_close("sdf", sdf, fo["sdf"], rtol=0, atol=SDF_ATOL)
+    assert_close("alpha", alpha, fo["alpha"], rtol=RENDER_RTOL, atol=1e-6)
+    assert_close("weights", weights, ref["weights"], rtol=RENDER_RTOL, atol=1e-6)
+    assert_close("rendered rgb", out_rgb, ref["rgb"], rtol=RENDER_RTOL, atol=1e-6)
+    assert_close("accumulation", acc, ref["accumulation"], rtol=RENDER_RTOL, atol=1e-6)
+    hit = ref["accumulation"] > 0.05
+    assert int(hit.sum()) >= 16, "the case must have rays that hit the surface"
+    assert_close("rendered depth", depth[hit.to(device)], ref["depth"][hit], rtol=RENDER_RTOL, atol=1e-6)
+    assert_close("rendered normal", normal, ref["normal"], rtol=RENDER_RTOL, atol=2e-6)
+
+
+def test_northstar_bars_full_shape_volsdf_on_oracle_samples(device):
+    """BASELINE config 1: VolSDF, pure-MLP field (grid features off), ErrorBoundedSampler's 64 + 32 samples, eval mode."""
+    from helpers import load_params
+    from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
+    from sdfstudio_amd.model_components.renderers import volsdf_render
+    from sdfstudio_amd.models.neus_facto import SceneBox
+    from sdfstudio_amd.models.volsdf import VolSDFModel, VolSDFModelConfig
+
+    cfg = O.ModelCfg(field=O.FieldCfg(bias=0.5, inside_outside=False, beta_init=0.1, use_grid_feature=False), proposals=())
+    gen = torch.Generator().manual_seed(8)
+    p = O.init_field_params(cfg.field, seed=2)
+    for k in list(p):
+        if k.endswith("weight_v"):
+            p[k] = p[k] + 0.02 * torch.randn(p[k].shape, generator=gen)
+    fcfg = SDFFieldConfig(bias=0.5, inside_outside=False, use_grid_feature=False, beta_init=0.1)
+    box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=cfg.near, far=cfg.far)
+    model = VolSDFModel(VolSDFModelConfig(sdf_field=fcfg), box, num_train_data=49)
+    load_params(model, p)
+    model = model.to(device).eval()
+    n = 96
+    o, d, cam = O.synthetic_rays(n, seed=9)
+    with torch.no_grad():
+        ref = O.volsdf_forward(o, d, cam, p, cfg, rand=None, training=False)
+    assert ref["starts"].shape == (n, 96)
+    rb = _bundle(o, d, cam, cfg.near, cfg.far, device)
+    rs = rb.get_ray_samples(ref["starts"].to(device), ref["ends"].to(device))
+    with torch.no_grad():
+        sdf, grad, rgb, _ = model.field.forward_fused(rs)
+        out_rgb, depth, normal, acc, weights, density, _ = volsdf_render(sdf, grad, rgb, model.field.laplace_density.get_beta(),
+                                                                         rs.flat_starts, rs.flat_ends, None)
+    fo = ref["field"]
+    assert_close("sdf", sdf, fo["sdf"], rtol=0, atol=SDF_ATOL)
+    assert_close("density", density, fo["density"], rtol=RENDER_RTOL, atol=1e-6)
+    assert_close("weights", weights, ref["weights"], rtol=RENDER_RTOL, atol=1e-6)
+    assert_close("rendered rgb", out_rgb, ref["rgb"], rtol=RENDER_RTOL, atol=1e-6)
+    assert_close("accumulation", acc, ref["accumulation"], rtol=RENDER_RTOL, atol=1e-6)
+    hit = ref["accumulation"] > 0.05
+    assert int(hit.sum()) >= 16
+    assert_close("rendered depth", depth[hit.to(device)], ref["depth"][hit], rtol=RENDER_RTOL, atol=1e-6)
+    assert_close("rendered normal", normal, ref["normal"], rtol=RENDER_RTOL, atol=2e-6)
+
+
+def test_real_benchmark_batch_subset_against_oracle(device):
+    """The benchmark's real 4096 x 128 batch (524 288 points, one launch per stage) through the HIP field and compositing kernels;
+    64 of its rays - the first and last rows of the batch, rows around the 32- / 128-point tile seams, scattered rows - are
+    compared with the oracle on the same samples at the north_star bars."""
+    from sdfstudio_amd.model_components.renderers import neus_render
+
+    cfg = O.ModelCfg(field=O.FieldCfg(bias=0.5, inside_outside=False, beta_init=0.3), num_neus_samples=128)
+    p = _full_shape_params(cfg, seed=7)
+    n, s = 4096, 128
+    o, d, cam = O.synthetic_rays(n, seed=31)
+    gen = torch.Generator().manual_seed(32)
+    # samples concentrated where the unit sphere is (near 2.73 - 1 .. 2.73 + 1), sorted, with a little per-ray structure
+    bins = torch.sort(1.2 + 3.0 * torch.rand(n, s + 1, generator=gen), dim=-1)[0]
+    starts, ends = bins[:, :-1].contiguous(), bins[:, 1:].contiguous()
+    model = product_model_from_params(p, cfg, device).train()
+    cos_anneal = 0.7
+    model.field.set_cos_anneal_ratio(cos_anneal)
+    rb = _bundle(o, d, cam, cfg.near, cfg.far, device)
+    rs = rb.get_ray_samples(starts.to(device), ends.to(device))
+    with torch.no_grad():
+        sdf, grad, rgb, _ = model.field.forward_fused(rs)
+        out_rgb, depth, normal, acc, weights, alpha = neus_render(
+            sdf, grad, rgb, model.field.deviation_network.variance, rs.flat_directions, rs.flat_starts, rs.flat_ends, cos_anneal, None)
+    assert sdf.shape == (n, s) and bool(torch.isfinite(out_rgb).all())
+    rows = sorted(set([0, 1, 31, 32, 33, 127, 128, 4095, 4094, 4064, 4063, 3968, 3967] +
+                      torch.randint(0, n, (51,), generator=gen).tolist()))[:64]
+    idx = torch.tensor(rows)
+    with torch.no_grad():
+        fo = O.field_outputs(o[idx], d[idx], starts[idx], (ends - starts)[idx], cam[idx], p, cfg.field, None, cos_anneal, True)
+        w_ref, _ = O.weights_from_alphas(fo["alpha"])
+        rgb_ref, _, normal_ref, acc_ref = O.render(w_ref, fo["rgb"], fo["normal"], starts[idx], ends[idx])
+    di = idx.to(device)
+    assert_close("sdf (rows of the 4096 x 128 batch)", sdf[di], fo["sdf"], rtol=0, atol=SDF_ATOL)
+    assert_close("alpha", alpha[di], fo["alpha"], rtol=RENDER_RTOL, atol=1e-6)
+    assert_close("weights", weights[di], w_ref, rtol=RENDER_RTOL, atol=1e-6)
+    assert_close("rendered rgb", out_rgb[di], rgb_ref, rtol=RENDER_RTOL, atol=1e-6)
+    assert_close("accumulation", acc[di], acc_ref, rtol=RENDER_RTOL, atol=1e-6)
+    assert_close("rendered normal", normal[di], normal_ref, rtol=RENDER_RTOL, atol=2e-6)
