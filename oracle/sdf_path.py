@@ -740,11 +740,13 @@ def interlevel_loss_zip(weights_list: List[torch.Tensor], bins_list: List[torch.
 
 # ----------------------------------------------------------------------------- full model step
 def neus_facto_forward(origins, dirs, cam_idx, p: Params, cfg: ModelCfg, anneal: float = 1.0,
-                       cos_anneal_ratio: float = 1.0, rand=None, mask=None, training=True):
-    """models/neus_facto.py:282-302 + base_surface_model.py:292-365 with background_model == 'none', black bg."""
+                       cos_anneal_ratio: float = 1.0, rand=None, mask=None, training=True, nears=None, fars=None):
+    """models/neus_facto.py:282-302 + base_surface_model.py:292-365 with background_model == 'none', black bg.  nears / fars [N]:
+    per-ray planes from a box / sphere collider (scene_colliders.py:47-109,132-170); default: the NearFarCollider's constants."""
     n = origins.shape[0]
-    nears = torch.full((n,), cfg.near, dtype=origins.dtype)  # scene_colliders.py:124-129
-    fars = torch.full((n,), cfg.far, dtype=origins.dtype)
+    if nears is None:
+        nears = torch.full((n,), cfg.near, dtype=origins.dtype)  # scene_colliders.py:124-129
+        fars = torch.full((n,), cfg.far, dtype=origins.dtype)
     bins, starts, ends, weights_list, bins_list = proposal_sampler(origins, dirs, nears, fars, p, cfg, anneal, rand)
     deltas = ends - starts
     fo = field_outputs(origins, dirs, starts, deltas, cam_idx, p, cfg.field, mask, cos_anneal_ratio, training)

@@ -21,6 +21,7 @@ from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
 from sdfstudio_amd.model_components.losses import interlevel_loss_zip, monosdf_depth_loss, monosdf_normal_loss
 from sdfstudio_amd.model_components.ray_samplers import ProposalNetworkSampler
 from sdfstudio_amd.model_components.renderers import neus_render
+from sdfstudio_amd.model_components.scene_colliders import build_collider
 from sdfstudio_amd.models import background as B
 
 
@@ -50,7 +51,8 @@ class NeuSFactoModelConfig:
     mono_normal_loss_mult: float = 0.0
     mono_depth_loss_mult: float = 0.0
     sdf_field: SDFFieldConfig = field(default_factory=SDFFieldConfig)
-    background_model: str = "none"   # the reference's default is "mlp" (base_surface_model.py:123); "grid" is not built
+    overwrite_near_far_plane: bool = False  # base_surface_model.py:75: fixed planes replace the scene box's collider
+    background_model: str = "none"   # the reference's default is "mlp" (base_surface_model.py:123); "mlp", "grid", "none" are built
     far_plane_bg: float = 1000.0
     num_samples_outside: int = 32
     num_proposal_samples_per_ray: Tuple[int, ...] = (256, 96)
@@ -140,8 +142,7 @@ class NeuSFactoModel(nn.Module):
         c = self.config
         if c.scene_contraction_norm not in ("inf", "l2"):
             raise ValueError("Invalid scene contraction norm")  # base_surface_model.py:148-155
-        if self.scene_box.collider_type != "near_far":
-            raise NotImplementedError("only the near/far collider is on the path this round")
+        self.collider = build_collider(self.scene_box, c)  # base_surface_model.py:165-176: near_far / box / sphere
         self.scene_contraction = SceneContraction(order=float("inf") if c.scene_contraction_norm == "inf" else None)
         self.field = c.sdf_field.setup(aabb=self.scene_box.aabb, spatial_distortion=self.scene_contraction,
                                        num_images=self.num_train_data, use_average_appearance_embedding=False)
@@ -208,11 +209,8 @@ class NeuSFactoModel(nn.Module):
         self.proposal_sampler.step_cb(step)
 
     def collide(self, ray_bundle: RayBundle) -> RayBundle:
-        """scene_colliders.py:111-129 NearFarCollider."""
-        ones = torch.ones_like(ray_bundle.origins[..., 0:1])
-        ray_bundle.nears = ones * self.scene_box.near
-        ray_bundle.fars = ones * self.scene_box.far
-        return ray_bundle
+        """Model.forward (models/base_model.py:139-140): the collider sets nears / fars unless the bundle already carries them."""
+        return self.collider(ray_bundle)
 
     def _render_per_head(self, ray_samples, field_outputs, weights):
         """The four renderers of SurfaceModel.get_outputs (base_surface_model.py:298-310) on explicit weights (the background

@@ -152,3 +152,45 @@ def test_real_benchmark_batch_subset_against_oracle(device):
     assert_close("rendered rgb", out_rgb[di], rgb_ref, rtol=RENDER_RTOL, atol=1e-6)
     assert_close("accumulation", acc[di], acc_ref, rtol=RENDER_RTOL, atol=1e-6)
     assert_close("rendered normal", normal[di], normal_ref, rtol=RENDER_RTOL, atol=2e-6)
+
+
+def test_config4_indoor_box_collider_step_against_oracle(device):
+    """BASELINE config 4's scene type: an indoor scene (cameras INSIDE the box, inside_outside = True) whose near / far planes come
+    from the AABB box collider (scene_colliders.py:47-109; the reference's indoor conversions write collider_type "box",
+    scripts/datasets/process_nerfstudio_to_sdfstudio.py:103), full network shape, 64 rays, training mode: planes, samples and rendered
+    outputs of the product model against the oracle fed with the planes of the reference-pinned collider mirror."""
+    from sdfstudio_amd.fields.field_heads import FieldHeadNames as H
+    from sdfstudio_amd.model_components.scene_colliders import AABBBoxCollider
+    from sdfstudio_amd.models.neus_facto import SceneBox
+    from test_gpu_parity import _inject_facto_draws
+
+    cfg, p, o, d, cam, rand = _neus_facto_case(4)
+    model = product_model_from_params(p, cfg, device)
+    aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+    model.scene_box = SceneBox(aabb=aabb, near=0.05, far=4.0, collider_type="box")
+    from sdfstudio_amd.model_components.scene_colliders import build_collider
+
+    model.collider = build_collider(model.scene_box, model.config)
+    assert isinstance(model.collider, AABBBoxCollider)
+    model = model.to(device).train()
+    n = o.shape[0]
+    nears, fars = AABBBoxCollider(model.scene_box, near_plane=0.05).train()._intersect_with_aabb(o, d, aabb)
+    assert float(fars.max()) < 3.5 and float(nears.max()) == pytest.approx(0.05)  # every camera is inside: the near plane, the far wall
+    cos_anneal, anneal = 0.4, 0.8
+    with torch.no_grad():
+        ref = O.neus_facto_forward(o, d, cam, p, cfg, anneal=anneal, cos_anneal_ratio=cos_anneal, rand=rand, training=True, nears=nears, fars=fars)
+    model.field.set_cos_anneal_ratio(cos_anneal)
+    model.proposal_sampler.set_anneal(anneal)
+    _inject_facto_draws(model, rand, device)
+    from sdfstudio_amd.cameras.rays import RayBundle
+
+    rb = RayBundle(origins=o.to(device), directions=d.to(device), pixel_area=torch.ones(n, 1, device=device),
+                   directions_norm=torch.ones(n, 1, device=device), camera_indices=cam[:, None].to(device))  # no planes: the collider sets them
+    with torch.no_grad():
+        out = model(rb)
+    assert_close("bins", out["ray_samples"].flat_bins, ref["bins"], rtol=0, atol=5e-5)
+    assert_close("euclidean sample ends", out["ray_samples"].flat_ends, ref["ends"], rtol=0, atol=1e-4)
+    assert bool((out["ray_samples"].flat_ends.cpu() <= fars[:, None] + 1e-4).all()), "samples beyond the far wall of the box"
+    assert_close("sdf", out["field_outputs"][H.SDF][..., 0], ref["field"]["sdf"], rtol=0, atol=1e-4)
+    assert_close("rgb", out["rgb"], ref["rgb"], rtol=1e-3, atol=2e-4)
+    assert_close("accumulation", out["accumulation"][..., 0], ref["accumulation"], rtol=1e-3, atol=2e-4)
