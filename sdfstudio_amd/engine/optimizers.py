@@ -122,6 +122,31 @@ class FusedAdam:
     def zero_grad(self):
         self.flat_grads.zero()
 
+    # ---- checkpointing (the trainer's checkpoint holds {"optimizers": {group: optimizer.state_dict()}}, engine/trainer.py:351-360,
+    # and Optimizers.load_optimizers (optimizers.py:157-160) restores it: without this a resumed run would restart Adam's bias
+    # correction and the warm-up)
+    def state_dict(self) -> Dict:
+        out = {"step_count": self.step_count, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "groups": {}}
+        for name, g in self.groups.items():
+            a, n = g["start"], g["numel"]
+            out["groups"][name] = {"lr": g["lr"], "lr_init": g["lr_init"], "numel": n,
+                                   "exp_avg": self.exp_avg[a:a + n].detach().clone(), "exp_avg_sq": self.exp_avg_sq[a:a + n].detach().clone()}
+        return out
+
+    def load_state_dict(self, state: Dict) -> None:
+        if set(state["groups"]) != set(self.groups):
+            raise KeyError(f"optimizer groups differ: checkpoint {sorted(state['groups'])}, model {sorted(self.groups)}")
+        for name, g in self.groups.items():
+            sg = state["groups"][name]
+            if int(sg["numel"]) != g["numel"]:
+                raise ValueError(f"group {name!r}: {sg['numel']} parameters in the checkpoint, {g['numel']} in the model")
+            a, n = g["start"], g["numel"]
+            self.exp_avg[a:a + n].copy_(sg["exp_avg"])
+            self.exp_avg_sq[a:a + n].copy_(sg["exp_avg_sq"])
+            g["lr"], g["lr_init"] = float(sg["lr"]), float(sg["lr_init"])
+        self.step_count = int(state["step_count"])
+        self.betas, self.eps, self.weight_decay = tuple(state["betas"]), float(state["eps"]), float(state["weight_decay"])
+
 
 class Optimizers:
     """engine/optimizers.py:93-160: the trainer-facing wrapper (zero_grad_all / optimizer_step_all / scheduler_step_all)."""
@@ -145,3 +170,17 @@ class Optimizers:
 
     def scheduler_step_all(self, step: int = 0):
         self.adam.scheduler_step()
+
+    def state_dict(self) -> Dict:
+        """What the trainer stores under "optimizers" (engine/trainer.py:351-360).  One difference from per-group torch.optim.Adam
+        is documented here rather than hidden: the fused step updates EVERY element of a group, also parameters whose gradient
+        is None in torch terms (their flat gradient is the zero zero() left, so moments decay and the bias-corrected update is
+        0 while they were never used; once a parameter has been used, torch would freeze its moments in steps that skip it,
+        this keeps decaying them)."""
+        return self.adam.state_dict()
+
+    def load_optimizers(self, loaded_state: Dict) -> None:
+        """optimizers.py:157-160."""
+        self.adam.load_state_dict(loaded_state)
+
+    load_state_dict = load_optimizers

@@ -134,8 +134,8 @@ class UniformLinDispPiecewiseSampler(SpacedSampler):
 
     spacing = "piecewise"
 
-    def __init__(self, num_samples: Optional[int] = None, train_stratified=True, single_jitter=True) -> None:
-        # (the reference's default is single_jitter=False; every caller on the path passes single_jitter, neus_facto.py:145)
+    def __init__(self, num_samples: Optional[int] = None, train_stratified=True, single_jitter=False) -> None:
+        # defaults as the reference's (ray_samplers.py:235-240); every caller on the path passes single_jitter (neus_facto.py:145)
         super().__init__(num_samples=num_samples, train_stratified=train_stratified, single_jitter=single_jitter)
 
 
@@ -343,8 +343,8 @@ class PDFSampler(Sampler):
     incoming samples, for both jitter modes; with include_original=True (the reference's default, though every caller on the
     SDF path passes False: :525, :835, :601) the new bins are merged with the existing ones by a sort, as the reference does (:355)."""
 
-    def __init__(self, num_samples: Optional[int] = None, train_stratified: bool = True, single_jitter: bool = True,
-                 include_original: bool = False, histogram_padding: float = 0.01, spacing: str = "piecewise") -> None:
+    def __init__(self, num_samples: Optional[int] = None, train_stratified: bool = True, single_jitter: bool = False,
+                 include_original: bool = True, histogram_padding: float = 0.01, spacing: str = "piecewise") -> None:
         super().__init__(num_samples=num_samples)
         if spacing not in _SPACINGS:
             raise ValueError(f"unknown spacing {spacing!r}; built: {sorted(_SPACINGS)}")

@@ -37,8 +37,12 @@ def build_background(model, config) -> None:
     else:
         raise ValueError(f"background_model={config.background_model!r}: 'grid', 'mlp' or 'none' (base_surface_model.py:122-123)")
     model.sampler_bg = LinearDisparitySampler(num_samples=config.num_samples_outside)
-    bg = {"black": torch.zeros(3), "white": torch.ones(3)}.get(config.background_color)
-    model.renderer_rgb = RGBRenderer(background_color=None if config.background_color == "black" else bg)
+    # "black" / "white" become colours; "random" and "last_sample" travel through to the renderer unchanged, as in the reference
+    # (base_surface_model.py:206, renderers.py:81-92); the FUSED field -> render path of the models refuses those two loudly
+    bc = config.background_color
+    if bc not in ("black", "white", "random", "last_sample"):
+        raise ValueError(f"background_color={bc!r}: 'random', 'last_sample', 'white' or 'black' (base_surface_model.py:80)")
+    model.renderer_rgb = RGBRenderer(background_color=None if bc == "black" else (torch.ones(3) if bc == "white" else bc))
     model.renderer_depth = DepthRenderer(method="expected")
     model.renderer_normal = SemanticRenderer()
     model.renderer_accumulation = AccumulationRenderer()

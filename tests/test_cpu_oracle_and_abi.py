@@ -801,3 +801,31 @@ def test_no_device_pointer_is_taken_from_a_temporary():
                 if pat.search(line.split("#")[0]):
                     bad.append(f"{os.path.relpath(os.path.join(dirpath, f), ROOT)}:{i}: {line.strip()}")
     assert not bad, "\n".join(bad)
+
+
+def test_optimizers_state_dict_round_trip_restores_moments_step_and_schedule():
+    """Optimizers.state_dict / load_optimizers (engine/optimizers.py:157-160, trainer.py:351-360).  Host logic only: the
+    moments, the step counter (Adam's bias correction) and every group's lr / lr_init survive a save -> new object -> load."""
+    from sdfstudio_amd.engine.optimizers import Optimizers, neus_scheduler
+
+    def make():
+        torch.manual_seed(0)
+        a = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+        b = [torch.nn.Parameter(torch.randn(4))]
+        return a, b, Optimizers({"fields": {"lr": 5e-4, "scheduler": neus_scheduler(3, 0.05, 10)}, "proposal_networks": {"lr": 1e-2, "scheduler": None}},
+                                {"fields": a, "field_background": [], "proposal_networks": b})
+
+    _, _, o1 = make()
+    o1.adam.exp_avg.copy_(torch.arange(26.0))
+    o1.adam.exp_avg_sq.copy_(torch.arange(26.0) * 2)
+    o1.adam.step_count = 5
+    o1.scheduler_step_all(5)
+    sd = o1.state_dict()
+    assert set(sd["groups"]) == {"fields", "proposal_networks"} and sd["groups"]["fields"]["numel"] == 22
+    _, _, o2 = make()
+    o2.load_optimizers(sd)
+    assert torch.equal(o2.adam.exp_avg, o1.adam.exp_avg) and torch.equal(o2.adam.exp_avg_sq, o1.adam.exp_avg_sq)
+    assert o2.adam.step_count == 5 and o2.adam.groups["fields"]["lr"] == o1.adam.groups["fields"]["lr"] != 5e-4
+    bad = dict(sd, groups={"fields": sd["groups"]["fields"]})
+    with pytest.raises(KeyError):
+        o2.load_optimizers(bad)

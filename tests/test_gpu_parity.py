@@ -39,7 +39,7 @@ def test_spaced_sampler(device, training, S):
     o, d, cam = O.synthetic_rays(n)
     rb = _bundle(o, d, cam, 0.5, 4.5, device)
     jit = torch.rand(n, 1)
-    smp = UniformLinDispPiecewiseSampler().train(training)
+    smp = UniformLinDispPiecewiseSampler(single_jitter=True).train(training)
     smp.jitter_override = jit.to(device)
     rs = smp(rb, num_samples=S)
     bins = O.initial_bins(n, S, jit if training else None)
@@ -60,11 +60,11 @@ def test_pdf_sampler(device, training, shape):
     n = 67
     o, d, cam = O.synthetic_rays(n)
     rb = _bundle(o, d, cam, 0.5, 4.5, device)
-    rs0 = UniformLinDispPiecewiseSampler().eval()(rb, num_samples=s_in)
+    rs0 = UniformLinDispPiecewiseSampler(single_jitter=True).eval()(rb, num_samples=s_in)
     w = torch.rand(n, s_in) ** 4
     w[3] = 0.0  # a ray with zero weight exercises the eps padding (ray_samplers.py:307-310)
     jit = torch.rand(n, 1)
-    pdf = PDFSampler().train(training)
+    pdf = PDFSampler(single_jitter=True, include_original=False).train(training)
     pdf.jitter_override = jit.to(device)
     rs = pdf(rb, rs0, w.to(device)[..., None], num_samples=s_out, anneal=0.7)
     bins_in = O.initial_bins(n, s_in, None)
