@@ -9,6 +9,11 @@ One "step" = one full training iteration of BASELINE config 2 on every rank: dra
 (including the second-order terms), one RCCL all-reduce of the flat gradient buffer when N > 1, Adam step.
 Inputs are synthetic (DTU-scan65-like cameras) and already resident in HBM.
 
+`--config 5` runs BASELINE config 5 instead (neus-facto-angelo, method_configs.py:381-450: 2048 rays x 48 samples, 16 x 8 x 2^22 linear
+hash grid = 2.1 GB table, numerical SDF gradients (7 geometry evaluations per sample), progressive levels from level_init = 8, "grid"
+background model, curvature loss); its roofline is the hash-grid gather of geo_encode_kernel, the HBM-bound stage SURVEY 8(d) names K1.
+The default (config 2) is the headline the driver records.
+
 Rank 0 prints ONE JSON line.  `value` = whole-job field ray-samples per second (N * 4096 * 128 / step time).
 `roofline` is for the dominant kernel (geo_bwd_kernel: tangent + data backward of the geometry MLP), with its launch
 time measured live by HIP events recorded on the launch stream inside the timed region (sdfhip_profile_*).  With the
@@ -93,6 +98,23 @@ def draw_rays(centers, rot, n, gen):
     return centers[cam].contiguous(), (d / norm).contiguous(), norm, cam
 
 
+def build_model_config5(device):
+    """BASELINE config 5: the neus-facto-angelo preset (method_configs.py:381-450) at its own sizes."""
+    from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
+    from sdfstudio_amd.models.neus_facto import NeuSFactoModel, NeuSFactoModelConfig, SceneBox
+
+    torch.manual_seed(0)
+    fcfg = SDFFieldConfig(use_grid_feature=True, num_layers=1, num_layers_color=4, hidden_dim=256, hidden_dim_color=256, geometric_init=True,
+                          bias=0.5, beta_init=0.3, inside_outside=False, use_appearance_embedding=True, use_numerical_gradients=True,
+                          base_res=64, max_res=4096, log2_hashmap_size=22, hash_features_per_level=8, hash_smoothstep=False,
+                          use_position_encoding=False)
+    mcfg = NeuSFactoModelConfig(near_plane=0.01, far_plane=1000.0, overwrite_near_far_plane=True, sdf_field=fcfg, background_model="grid",
+                                level_init=8, eikonal_loss_mult=0.01, use_anneal_beta=True, enable_progressive_hash_encoding=True,
+                                enable_numerical_gradients_schedule=True, enable_curvature_loss_schedule=True, curvature_loss_multi=5e-4)
+    box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=0.5, far=4.5)
+    return NeuSFactoModel(mcfg, box, num_train_data=49).to(device).train()
+
+
 def build_model(device, small=False):
     """BASELINE config 2 (default), or the small parity configuration of tests/golden (8x64 networks, 8x2x2^11 grid, 32/24
     proposal + 16 field samples): the latter only drives the N > 1 control-flow test, never a reported number."""
@@ -159,6 +181,9 @@ def cpu_baseline():
         iters += 1
     dt = (time.perf_counter() - t0) / iters
     return {"value": n * N_SAMPLES / dt, "unit": "ray-samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "note": "the oracle (a PyTorch port of the reference's path, pinned on the reference's own Python by the CPU tests) timed on THIS "
+                    "host; the reference tree itself does not exist on the GPU box - its own Python was timed in the build container on 8 "
+                    "vCPU: cpu_baseline_reference",
             "sample": f"{iters} training iterations of {n} rays x {N_SAMPLES} samples (same networks, samplers, losses, Adam); "
                       f"{dt * 1e3:.0f} ms/iter"}
 
@@ -184,6 +209,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 5], help="BASELINE config: 2 (default, the headline) or 5 (neus-facto-angelo)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--small", action="store_true", help="small parity configuration (control-flow tests only, not a benchmark)")
     ap.add_argument("--no-forward-only", action="store_true", help="skip the eval-mode leg (PMC passes: per-step launch counts stay clean)")
@@ -202,6 +228,9 @@ def run(args):
     global N_RAYS, N_SAMPLES
     if args.small:
         N_RAYS, N_SAMPLES = 512, 16
+    cfg5 = getattr(args, "config", 2) == 5
+    if cfg5:
+        N_RAYS, N_SAMPLES = 2048, 48  # method_configs.py:396 train_num_rays_per_batch, neus_facto.py:51 num_neus_samples_per_ray
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -230,23 +259,35 @@ def run(args):
     from sdfstudio_amd.cameras.rays import RayBundle
     from sdfstudio_amd.distributed import FlatGradients, broadcast_parameters
 
-    model = build_model(device, small=args.small)
+    model = build_model_config5(device) if cfg5 else build_model(device, small=args.small)
     broadcast_parameters(model)
     groups = {k: v for k, v in model.get_param_groups().items() if v}  # "field_background" is empty with background_model="none"
     # one flat gradient buffer; one exchange bucket per parameter group, all-reduced (RCCL) as soon as backward has produced it
     flat = FlatGradients([p for g in groups.values() for p in g], buckets=list(groups.values()))
     # optimizers and schedulers as method_configs.py:485-500 (neus-facto): Adam eps 1e-15, lr 5e-4 with NeuS warm-up / cosine
     # (fields), 1e-2 with MultiStepLR (proposal networks): one fused Adam launch per group over the flat buffers
-    from sdfstudio_amd.engine.optimizers import Optimizers, multi_step_scheduler, neus_scheduler
+    from sdfstudio_amd.engine.optimizers import Optimizers, multi_step_scheduler, multi_step_warmup_scheduler, neus_scheduler
 
-    opts = Optimizers({"fields": {"lr": 5e-4, "scheduler": neus_scheduler(500, 0.05, 20000)},
-                       "proposal_networks": {"lr": 1e-2, "scheduler": multi_step_scheduler(20000)}}, groups, flat_grads=flat)
+    flat.time_waits = world > 1
+    if cfg5:
+        # method_configs.py:434-447: Adam 1e-3 with MultiStepWarmup (fields; AdamW with weight_decay 0 = Adam for field_background),
+        # Adam 1e-2 with MultiStepLR (proposal networks)
+        opts = Optimizers({"fields": {"lr": 1e-3, "scheduler": multi_step_warmup_scheduler(5000, (600000, 800000), 0.1)},
+                           "field_background": {"lr": 1e-3, "scheduler": multi_step_warmup_scheduler(5000, (300000, 400000), 0.1)},
+                           "proposal_networks": {"lr": 1e-2, "scheduler": multi_step_scheduler(1000000)}}, groups, flat_grads=flat)
+    else:
+        opts = Optimizers({"fields": {"lr": 5e-4, "scheduler": neus_scheduler(500, 0.05, 20000)},
+                           "proposal_networks": {"lr": 1e-2, "scheduler": multi_step_scheduler(20000)}}, groups, flat_grads=flat)
     centers, rot = synthetic_cameras(device)
     gen = torch.Generator(device=device)
     gen.manual_seed(42 + rank)  # base_config.py:74 + scripts/train.py:86: seed + global rank
 
+    table = model.field.encoding.params
+
     def step(i):
         model.before_train_iteration(i)
+        if cfg5:  # progressive levels: the masked levels' table rows have exactly zero gradient on every rank
+            flat.set_active_numel(table, model.active_table_floats())
         o, d, norm, cam = draw_rays(centers, rot, N_RAYS, gen)
         image = torch.rand(N_RAYS, 3, device=device, generator=gen)
         rb = RayBundle(origins=o, directions=d, directions_norm=norm, camera_indices=cam[:, None])
@@ -293,8 +334,14 @@ def run(args):
         fwd_ms = (time.perf_counter() - t1) / 5 * 1e3
         model.train()
     t = torch.tensor([dt], device=device, dtype=torch.float64)
+    exposed_by_rank = None
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ex = flat.exposed_ms()[-args.steps:]  # the timed steps
+        allr = torch.zeros(world, device=device, dtype=torch.float64)  # all_reduce of a one-hot vector: works on RCCL and on gloo alike
+        allr[rank] = sum(ex) / max(len(ex), 1)
+        dist.all_reduce(allr)
+        exposed_by_rank = [round(float(v), 4) for v in allr.tolist()]
     dt = float(t.item())
 
     if rank == 0:
@@ -302,42 +349,80 @@ def run(args):
         samples = world * N_RAYS * N_SAMPLES
         value = samples / (dt / args.steps)
         g, c = flops_per_sample()
+        train_flops = 6 * g + 3 * c  # fwd G, analytic-normal chain G, its double backward 2G, backward 2G; colour C + 2C
+        if cfg5:  # 1-hidden-layer geometry net on 167 inputs, evaluated 7 x per sample (numerical gradients), no double backward
+            g = 2 * (167 * 256 + 256 * 257)
+            train_flops = 7 * 3 * g + 3 * c
         P = N_RAYS * N_SAMPLES
-        # dominant kernel: geo_bwd_kernel = tangent pass (G) + data backward (G), one launch per step
+        # dominant kernel: geo_bwd_kernel = tangent pass (G) + data backward (G) of the geometry MLP, two launches per step.
+        # the MLP kernels (K3) are priced against the MATRIX roofline: algorithmic flops (2G per ray-sample for this
+        # kernel) x the 3 split-precision terms actually issued per product, against the dense 16-bit MFMA peak.  The HBM view of
+        # the same launches (the kernel streams saved per-layer tensors) is reported beside it under "hbm", not as `frac`.
         kt_ms, kn = prof.get("geo_bwd_kernel", (0.0, 0))
         roof = None
-        if kn > 0:
+        pm_dir = os.path.join(ROOT, "profiles")
+        if kn > 0 and not cfg5:
             avg_s = kt_ms / kn * 1e-3
-            alg_bytes = geo_bwd_algorithmic_bytes() * P
-            achieved = alg_bytes / avg_s / 1e9
+            flow_bytes = geo_bwd_algorithmic_bytes() * P
             traffic, traffic_source = None, None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the bench)
-            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json"))
-            tpath = os.path.join(ROOT, "profiles", cands[-1]) if cands else ""  # newest committed PMC pass (r1 < r1c < r2 ...)
+            cands = sorted(f for f in os.listdir(pm_dir) if f.endswith("_pmc_traffic.json"))
             if cands:
-                with open(tpath) as fh:
+                with open(os.path.join(pm_dir, cands[-1])) as fh:  # newest committed PMC pass (r1 < r2 < r3 ...)
                     tj = json.load(fh)
-                traffic = tj["hbm_read_bytes"] + tj["hbm_write_bytes"]  # HBM bytes per launch
+                traffic = tj["hbm_read_bytes"] + tj["hbm_write_bytes"]
                 traffic_source = tj["source"]
             flops = 2 * g * P
             io_bytes = geo_bwd_io_bytes() * P
-            roof = {"kernel": "geo_bwd_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS,
-                    "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_unit": "bytes per launch",
-                    "traffic_source": traffic_source, "dataflow_bytes": alg_bytes,
+            issued = 3 * flops / avg_s / 1e12
+            roof = {"kernel": "geo_bwd_kernel", "bound": "mfma", "achieved": round(issued, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(issued / PEAK_BF16_MFMA_TFLOPS, 4),
+                    "achieved_is": "SURVEY 8(d) algorithmic flops of the kernel (2G = 2.098 MFLOP per ray-sample: tangent pass + data backward) x 3 "
+                                   "issued 16-bit MFMA terms per fp32-class product / launch time (HIP events on the launch stream)",
+                    "algorithmic_tflops": round(flops / avg_s / 1e12, 1), "terms_per_product": 3,
+                    "frac_algorithmic_of_16bit_peak": round(flops / avg_s / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                    "frac_algorithmic_of_fp32_matrix_peak": round(flops / avg_s / 1e12 / 157.3, 4),
+                    "traffic": traffic, "traffic_unit": "HBM bytes per step of this kernel (sum of its two launches)", "traffic_source": traffic_source,
                     "avg_launch_ms": round(kt_ms / kn, 4), "launches": kn,
-                    "achieved_is": f"data-flow bytes / launch time: {geo_bwd_algorithmic_bytes()} B per ray-sample (the per-layer tensors the "
-                                   f"kernel reads and writes, DESIGN.md section 4) x {P} ray-samples; the PMC traffic agrees to 2 %",
-                    # SURVEY 8(d)'s definition: only what must cross the kernel boundary (inputs + outputs); traffic / this = waste
-                    "algorithmic_bytes": io_bytes,
-                    "waste_ratio": round((traffic if traffic else alg_bytes) / io_bytes, 1),
-                    "frac_at_algorithmic_bytes": round(io_bytes / avg_s / 1e9 / PEAK_HBM_GBS, 4),
-                    # the matrix side of the same kernel: 2G algorithmic flop per sample, each product issued as 3 bf16 MFMA terms
-                    "mfma": {"algorithmic_tflops": round(flops / avg_s / 1e12, 1), "issued_bf16_tflops": round(3 * flops / avg_s / 1e12, 1),
-                             "peak_bf16_tflops": PEAK_BF16_MFMA_TFLOPS, "frac_issued": round(3 * flops / avg_s / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}}
+                    # the memory side of the same launches
+                    "hbm": {"algorithmic_bytes": io_bytes, "frac_at_algorithmic_bytes": round(io_bytes / avg_s / 1e9 / PEAK_HBM_GBS, 4),
+                            "waste_ratio": round((traffic if traffic else flow_bytes) / io_bytes, 1),
+                            "dataflow_bytes": flow_bytes, "dataflow_GBps": round(flow_bytes / avg_s / 1e9, 1),
+                            "dataflow_frac": round(flow_bytes / avg_s / 1e9 / PEAK_HBM_GBS, 4),
+                            "note": "algorithmic_bytes = what must cross the kernel boundary (SURVEY 8d); dataflow_bytes = the saved per-layer "
+                                    "tensors this data flow reads and writes (DESIGN.md section 4); measured streaming ceilings of this pool: "
+                                    "read 5.5, write 4.0, mixed 5.2 TB/s (profiles/r3_hbm_ceiling.txt)"}}
+        # K1 of SURVEY 8(d), the stage north_star asks rocprof HBM GB/s for: the hash-grid gather of geo_encode_kernel
+        enc_ms, enc_n = prof.get("geo_encode_kernel", (0.0, 0))
+        enc = None
+        if enc_n > 0:
+            if cfg5:  # 7 evaluations per ray-sample (centre + 6 taps), 16 levels x 8 corners x 8 features x 4 B + position in + 6 in0 blocks out
+                per_sample, what = 7 * (16 * 8 * 8 * 4 + 12 + 6 * 128), "7 x (4096 B gather + 12 B position + 768 B tile-packed in0) per ray-sample"
+            else:
+                per_sample, what = 16 * 8 * 2 * 4 + 12 + 128, "1024 B gather + 12 B position + 128 B of features per ray-sample (SURVEY 8d: 1164 B)"
+            eb = per_sample * P
+            es = enc_ms / args.steps * 1e-3
+            enc = {"kernel": "geo_encode_kernel", "bound": "hbm", "achieved": round(eb / es / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                   "frac": round(eb / es / 1e9 / PEAK_HBM_GBS, 4), "algorithmic_bytes": eb, "achieved_is": what + " / its time per step",
+                   "ms_per_step": round(enc_ms / args.steps, 4), "traffic": None}
+            for f in sorted((f for f in os.listdir(pm_dir) if f.endswith("_pmc_summary.csv")), reverse=True):
+                if ("cfg5" in f) != cfg5:
+                    continue
+                import csv
+
+                with open(os.path.join(pm_dir, f)) as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("kernel", "").startswith("geo_encode_kernel") and row.get("hbm_write_GB"):
+                            per_launch = (float(row["hbm_read_GB_corrected_x2"]) + float(row["hbm_write_GB"])) * 1e9
+                            enc["traffic"] = per_launch * enc_n / args.steps  # HBM bytes per step (PMC, average launch x launches per step)
+                            enc["traffic_source"] = f"profiles/{f} (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc passes)"
+                break
+            if cfg5:
+                roof = enc
         kernels = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] / args.steps} for k, v in prof.items()}
         mfma_ms = sum(prof.get(k, (0.0, 0))[0] for k in ("geo_fwd_kernel", "geo_bwd_kernel", "col_fwd_kernel", "col_bwd_kernel",
                                                          "wgrad_kernel")) / args.steps
         line = {
-            "metric": "ray-samples/sec (NeuS-facto train step, 4096 rays x 128 samples per GPU)",
+            "metric": f"ray-samples/sec (NeuS-facto train step, {N_RAYS} rays x {N_SAMPLES} samples per GPU)",
             "value": round(value, 1), "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "dtype_note": "fp32 tensors and accumulators; matrix products as three 16-bit MFMA terms of hi + lo operand parts: fp16 parts "
@@ -345,17 +430,26 @@ def run(args):
                           "range) in the backward kernels and weight-gradient GEMMs",
             "data": "synthetic", "iters_per_sec": round(1e3 / ms, 3), "per_gpu": round(value / world, 1),
             "config": {"workload": "SMALL parity configuration (control-flow test only, NOT a benchmark)" if args.small else
-                                   "BASELINE config 2: NeuS-facto hash-grid 16x2x2^19 smoothstep + 8x256 geo MLP + 4x256 colour MLP, "
-                                   "4096 rays x 128 samples (+256/96 proposal samples) per GPU per step, full train step incl. Adam",
+                                   ("BASELINE config 5: neus-facto-angelo preset - hash grid 16x8x2^22 linear (2.1 GB table), 1x256 geo MLP with "
+                                    "numerical SDF gradients (7 evaluations per sample), 4x256 colour MLP, 'grid' background field, progressive "
+                                    "levels (level_init 8), curvature loss; 2048 rays x 48 samples (+256/96 proposal samples) per GPU per step, "
+                                    "full train step incl. Adam" if cfg5 else
+                                    "BASELINE config 2: NeuS-facto hash-grid 16x2x2^19 smoothstep + 8x256 geo MLP + 4x256 colour MLP, "
+                                    "4096 rays x 128 samples (+256/96 proposal samples) per GPU per step, full train step incl. Adam"),
                        "rays_per_gpu": N_RAYS, "samples_per_ray": N_SAMPLES,
                        "parallelism": f"dp{world} (flat-gradient RCCL all-reduce)" if world > 1 else "single GPU"},
             "roofline": roof,
+            "encode_roofline": enc,
             "collective": None if world == 1 else {"backend": dist.get_backend(), "buckets": len(groups),
                                                     "bytes_per_step_per_rank": 4 * flat.exchanged_numel(),
-                                                    "overlap": "bucket all-reduce launched from post-accumulate-grad hooks during backward"},
+                                                    "collectives_per_step": flat.last_collectives,
+                                                    "buckets_launched_during_backward": flat.last_overlapped_buckets,
+                                                    "exposed_ms_per_step_by_rank": exposed_by_rank,
+                                                    "overlap": "bucket all-reduces leave in fixed index order from post-accumulate-grad hooks during "
+                                                               "backward; exposed = GPU time the compute stream stalled in finish()"},
             "forward_only": {"value": round(N_RAYS * N_SAMPLES / (fwd_ms * 1e-3), 1), "unit": "ray-samples/s per GPU (eval-mode render, no grad)",
                              "ms_per_batch": round(fwd_ms, 3)},
-            "model_tflops": round((6 * g + 3 * c) * P / (ms * 1e-3) / 1e12, 2),
+            "model_tflops": round(train_flops * P / (ms * 1e-3) / 1e12, 2),
             "mfma_kernels_ms_per_step": round(mfma_ms, 3),
             "kernels": kernels,
         }
@@ -363,11 +457,11 @@ def run(args):
         # bound by, the issued 16-bit MFMA terms (3 per product in every pass) against the dense bf16 / fp16 peak, and the whole
         # step's HBM bytes from the committed PMC passes
         step_bytes = None
-        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_step_traffic.json"))
+        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_step_traffic.json") and ("cfg5" in f) == cfg5)
         if cands:
             with open(os.path.join(ROOT, "profiles", cands[-1])) as fh:
                 step_bytes = json.load(fh).get("hbm_GB_per_training_step")
-        model_tf = (6 * g + 3 * c) * P / (ms * 1e-3) / 1e12
+        model_tf = train_flops * P / (ms * 1e-3) / 1e12
         line["step_roofline"] = {
             "model_tflops": round(model_tf, 1), "fp32_matrix_peak_tflops": 157.3, "frac_of_fp32_matrix_peak": round(model_tf / 157.3, 3),
             "issued_16bit_mfma_tflops": round(3 * model_tf, 1), "frac_of_dense_bf16_peak": round(3 * model_tf / PEAK_BF16_MFMA_TFLOPS, 4),
@@ -379,7 +473,7 @@ def run(args):
         if os.path.exists(ref_path):
             with open(ref_path) as fh:
                 line["cpu_baseline_reference"] = json.load(fh)  # the reference's own Python, timed in the build container (no GPU box has it)
-        if world == 1 and not args.no_cpu_baseline and not args.small:
+        if world == 1 and not args.no_cpu_baseline and not args.small and not cfg5:
             print("[bench] GPU leg done: " + json.dumps(line), file=sys.stderr, flush=True)
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

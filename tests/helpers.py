@@ -77,6 +77,9 @@ def report(name, got, ref, rtol, atol, elem_rtol=None):
 def assert_close(name, got, ref, rtol=1e-4, atol=1e-6, elem_rtol=None):
     ok, msg = report(name, got, ref, rtol, atol, elem_rtol)
     print(("PASS " if ok else "FAIL ") + msg)
+    if os.environ.get("SDFHIP_TEST_LOG"):  # every comparison of a run in one file (with KEEP_GOING: a census of what would fail)
+        with open(os.environ["SDFHIP_TEST_LOG"], "a") as fh:
+            fh.write(("PASS " if ok else "FAIL ") + os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0] + " :: " + msg + "\n")
     if os.environ.get("SDFHIP_TEST_KEEP_GOING"):  # debugging aid: print every comparison of a failing test
         return
     assert ok, msg
