@@ -77,7 +77,13 @@ typedef struct {
   int32_t appearance_dim;        /* appearance_embedding_dim */
   int32_t contract;              /* SceneContraction on the sample positions: 0 none, 1 order = inf, 2 order = None (L2) */
   float rgb_padding;
-  SdfHipGridCfg grid;
+  SdfHipGridCfg grid;            /* n_levels = 0: no grid features (NeRFField) */
+  /* The same fused kernels serve the background fields of the surface models (NeRFField, fields/
+   * vanilla_nerf_field.py:37-114; TCNNNerfactoField's two MLPs, fields/nerfacto_field.py:128-156,211-225) through the first-order
+   * entries sdfhip_geo_forward / _backward and sdfhip_color_forward / _backward: */
+  int32_t activation;            /* hidden activation of the geometry-type network: 0 Softplus(beta = 100) (sdf_field.py:290), 1 ReLU */
+  int32_t skip_style;            /* 0: cat([h, in0]) / sqrt(2), the layer below the skip H - in0 wide (sdf_field.py:280,403-404);
+                                    1: cat([in0, h]), every layer H wide (field_components/mlp.py:86-88) */
 } SdfHipFieldCfg;
 
 typedef struct SdfHipField SdfHipField;

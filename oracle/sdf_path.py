@@ -1035,6 +1035,41 @@ def nerfacto_field(origins, dirs, starts, ends, cam_idx, p: Params, prefix: str,
     return {"density": density.view(n, s), "rgb": rgb.view(n, s, 3)}
 
 
+# ----------------------------------------------------------------------------- "mlp" background field (the reference's default)
+def nerf_field(origins, dirs, starts, ends, p: Params, prefix: str = "", contraction: Optional[str] = "inf", skip: int = 4) -> Dict[str, torch.Tensor]:
+    """NeRFField.forward (fields/vanilla_nerf_field.py:91-114, fields/base_field.py:111-126) as base_surface_model.py:189-200 builds
+    it: contracted frustum MID points -> NeRFEncoding (10 frequencies, input appended; encodings.py:167-208) -> ReLU MLP whose layer
+    `skip` takes cat([encoding, x]) (field_components/mlp.py:76-100, ReLU after every layer incl. the last) -> Softplus density head
+    (field_heads.py:99-107); cat([NeRFEncoding(view dir, 4 frequencies, input appended), base output]) -> ReLU MLP -> Sigmoid rgb head.
+    Parameters under `prefix` with the reference's state_dict names: mlp_base.layers.N.{weight,bias}, mlp_head.layers.N.*,
+    field_output_density.net.*, field_heads.0.net.*."""
+    n, s = starts.shape
+    mid = (starts + ends) / 2
+    pos = (origins[:, None, :] + dirs[:, None, :] * mid[..., None]).reshape(-1, 3)
+    x = pos if contraction is None else (contract_inf if contraction == "inf" else contract_l2)(pos)
+
+    def enc(v, nf):
+        freqs = 2.0 ** torch.arange(nf, dtype=v.dtype)
+        sc = (v[..., None] * freqs).reshape(v.shape[0], -1)
+        return torch.cat([torch.sin(torch.cat([sc, sc + torch.pi / 2.0], dim=-1)), v], dim=-1)
+
+    def mlp(name, inp, skip_at):
+        h, l = inp, 0
+        while f"{prefix}{name}.layers.{l}.weight" in p:
+            if l == skip_at:
+                h = torch.cat([inp, h], dim=-1)
+            h = torch.relu(F.linear(h, p[f"{prefix}{name}.layers.{l}.weight"], p[f"{prefix}{name}.layers.{l}.bias"]))
+            l += 1
+        return h
+
+    base = mlp("mlp_base", enc(x, 10), skip)
+    density = F.softplus(F.linear(base, p[f"{prefix}field_output_density.net.weight"], p[f"{prefix}field_output_density.net.bias"]))
+    d = dirs[:, None, :].expand(n, s, 3).reshape(-1, 3)
+    head = mlp("mlp_head", torch.cat([enc(d, 4), base], dim=-1), -1)
+    rgb = torch.sigmoid(F.linear(head, p[f"{prefix}field_heads.0.net.weight"], p[f"{prefix}field_heads.0.net.bias"]))
+    return {"density": density.view(n, s), "rgb": rgb.view(n, s, 3)}
+
+
 # ----------------------------------------------------------------------------- optimiser (SURVEY f1)
 def adam_reference(p, g, m, v, lr, beta1, beta2, eps, step, weight_decay=0.0, grad_scale=1.0):
     """torch.optim.Adam's single-tensor update (torch/optim/adam.py, the optimiser engine/optimizers.py:93-160 instantiates with

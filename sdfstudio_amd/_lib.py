@@ -37,6 +37,7 @@ class FieldCfg(ctypes.Structure):
         ("num_layers", c_i32), ("hidden_dim", c_i32), ("geo_feat_dim", c_i32), ("num_layers_color", c_i32),
         ("hidden_dim_color", c_i32), ("skip_layer", c_i32), ("pe_degree", c_i32), ("use_position_encoding", c_i32),
         ("appearance_dim", c_i32), ("contract", c_i32), ("rgb_padding", c_f32), ("grid", GridCfg),
+        ("activation", c_i32), ("skip_style", c_i32),  # background fields: ReLU network, MLP-style skip (zero = the SDF field)
     ]
 
 

@@ -18,6 +18,8 @@
 const FieldKernels* sdfhip_kernels_A();
 const FieldKernels* sdfhip_kernels_B();
 const FieldKernels* sdfhip_kernels_C();
+const FieldKernels* sdfhip_kernels_D();
+const FieldKernels* sdfhip_kernels_E();
 
 static thread_local char g_err[1024] = "";
 void sdfhip_set_error(const char* fmt, ...) {
@@ -216,13 +218,18 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
   SDFHIP_REQUIRE(cfg != nullptr && out != nullptr, "null argument");
   SdfHipField* f = new SdfHipField();
   f->cfg = *cfg;
-  int rc = make_grid_dev(&cfg->grid, &f->grid);
-  if (rc != 0) {
-    delete f;
-    return rc;
-  }
   int64_t entries = 0;
-  sdfhip_grid_levels(&cfg->grid, nullptr, &entries);
+  if (cfg->grid.n_levels == 0) {  // no grid features (NeRFField): in0 = position + encoding only; the table pointer is never read
+    memset(&f->grid, 0, sizeof(f->grid));
+    f->grid.n_features = 2;
+  } else {
+    const int rc = make_grid_dev(&cfg->grid, &f->grid);
+    if (rc != 0) {
+      delete f;
+      return rc;
+    }
+    sdfhip_grid_levels(&cfg->grid, nullptr, &entries);
+  }
   f->table_floats = entries * cfg->grid.n_features;
   f->n_feat = cfg->grid.n_levels * cfg->grid.n_features;
   const int H = cfg->hidden_dim, GF = cfg->geo_feat_dim, HC = cfg->hidden_dim_color, NL = cfg->num_layers,
@@ -230,6 +237,7 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
   const int D0 = 3 + 6 * cfg->pe_degree + f->n_feat;
   f->d0 = D0;
   const int skip = cfg->skip_layer;
+  const bool mlp_skip = cfg->skip_style == 1;  // cat([in0, h]) with every layer H wide (field_components/mlp.py) instead of the SDF field's
   auto fail = [&](const char* why) {
     sdfhip_set_error("unsupported field configuration: %s (hidden %d, layers %d, in0 %d, geo_feat %d, colour %dx%d, skip %d)", why, H,
                      NL, D0, GF, NLC, HC, skip);
@@ -237,15 +245,20 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
     return -1;
   };
   if (H % 32 || GF % 32 || HC % 32) return fail("dims must be multiples of 32");
-  if (skip >= 0 && (skip < 1 || skip >= NL || H - D0 <= 0)) return fail("bad skip layer");
+  if (skip >= 0 && (skip < 1 || skip >= NL || (!mlp_skip && H - D0 <= 0))) return fail("bad skip layer");
+  if (cfg->activation != 0 && cfg->activation != 1) return fail("activation must be 0 (Softplus 100) or 1 (ReLU)");
+  if (cfg->skip_style != 0 && cfg->skip_style != 1) return fail("skip_style must be 0 or 1");
   if (NL + 1 > kMaxLayers || NLC + 1 > kMaxLayers) return fail("too many layers");
   // nb3: width (blocks) of the layer below the skip concatenation.  Its H - D0 real rows are padded to the FULL hidden width,
   // so that every hidden layer has the same shape and the fused kernels can loop over them (geo_kernels.h)
   const int nb0 = (D0 + 31) / 32, nb3 = skip >= 0 ? H / 32 : 0, nbs = (33 + E + 31) / 32;
-  const FieldKernels* cands[] = {sdfhip_kernels_A(), sdfhip_kernels_B(), sdfhip_kernels_C()};
+  const FieldKernels* cands[] = {sdfhip_kernels_A(), sdfhip_kernels_B(), sdfhip_kernels_C(), sdfhip_kernels_D(), sdfhip_kernels_E()};
   f->k = nullptr;
   for (const FieldKernels* k : cands) {
-    if (k->nbh == H / 32 && k->nb0 == nb0 && k->nbf == GF / 32 && k->nbs == nbs && k->nbc == HC / 32)
+    // in0 may be narrower than the instantiation's in0 blocks (the encode kernel zero-fills the rest, the packed weights have zero
+    // columns there): the narrowest instantiation that holds it wins
+    if (k->nbh == H / 32 && k->nb0 >= nb0 && k->nbf == GF / 32 && k->nbs == nbs && k->nbc == HC / 32 && k->act == cfg->activation &&
+        (f->k == nullptr || k->nb0 < f->k->nb0))
       f->k = k;
   }
   if (f->k == nullptr) return fail("no kernel instantiation was built for this shape");
@@ -261,8 +274,8 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
   int64_t off = 0;
   for (int l = 0; l <= NL; ++l) {
     LinearInfo li;
-    li.in_dim = l == 0 ? D0 : H;
-    li.out_dim = l == NL ? 1 + GF : ((skip >= 0 && l + 1 == skip) ? H - D0 : H);
+    li.in_dim = l == 0 ? D0 : ((mlp_skip && l == skip) ? H + D0 : H);
+    li.out_dim = l == NL ? 1 + GF : ((skip >= 0 && l + 1 == skip && !mlp_skip) ? H - D0 : H);
     li.w_off = off;
     off += (int64_t)li.out_dim * li.in_dim;
     li.b_off = off;
@@ -336,9 +349,14 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
       } else if (l == skip) {
         // layer input = cat([h, in0]) / sqrt(2)  (sdf_field.py:403-404): h occupies nb3 blocks, in0 nb0 blocks
         colmap.assign(kb * 32, -1);
-        for (int i = 0; i < H - D0; ++i) colmap[i] = i;
-        for (int j = 0; j < D0; ++j) colmap[f->nb3 * 32 + j] = (H - D0) + j;
-        scale = (float)(1.0 / std::sqrt(2.0));
+        if (mlp_skip) {  // layer input = cat([in0, h]) (field_components/mlp.py:86-88), no scaling
+          for (int i = 0; i < H; ++i) colmap[i] = D0 + i;
+          for (int j = 0; j < D0; ++j) colmap[f->nb3 * 32 + j] = j;
+        } else {
+          for (int i = 0; i < H - D0; ++i) colmap[i] = i;
+          for (int j = 0; j < D0; ++j) colmap[f->nb3 * 32 + j] = (H - D0) + j;
+          scale = (float)(1.0 / std::sqrt(2.0));
+        }
       } else {
         colmap = ident(kb * 32, li.in_dim);
       }
@@ -555,6 +573,9 @@ extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, c
   SDFHIP_REQUIRE(mode >= SDFHIP_MODE_SDF && mode <= SDFHIP_MODE_FULL, "field_forward: bad mode %d", mode);
   SDFHIP_REQUIRE(n_samples >= 1 && n_rays >= 0, "field_forward: bad shape");
   SDFHIP_REQUIRE(mode != SDFHIP_MODE_FULL || (dirs && starts && grad && rgb), "field_forward: MODE_FULL needs dirs, starts, grad, rgb");
+  SDFHIP_REQUIRE(mode != SDFHIP_MODE_FULL || f->k->geo_bwd != nullptr,
+                 "field_forward: MODE_FULL (analytic normal, second-order backward) exists for Softplus networks only; ReLU background fields "
+                 "go through sdfhip_geo_forward / sdfhip_color_forward");
   if (n_rays == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const FieldKernels* k = f->k;
@@ -722,6 +743,7 @@ static TpOperand seg2(const float* p0, int nb0, int xf0, const float* p1, int nb
 static void run_geo_wgrads(const SdfHipField* f, const FieldWs& w, const bool tangent, const int64_t n_tiles, float* theta_bar,
                            hipStream_t s) {
   const FieldKernels* k = f->k;
+  const int xf = f->cfg.activation == 1 ? 2 : 1;  // u_l = act(z_{l-1}) applied as the saved pre-activation is loaded (wgrad_kernels.h)
   for (int l = 0; l < f->nl; ++l) {
     const LinearInfo& li = f->lin[l];
     WgradArgs a;
@@ -736,10 +758,10 @@ static void run_geo_wgrads(const SdfHipField* f, const FieldWs& w, const bool ta
       a.B[0] = seg1(w.in0, k->nb0, 0);
       a.B[1] = seg1(w.ebar, k->nb0, 0);
     } else if (l == f->skip) {
-      a.B[0] = seg2(w.z[l - 1], f->nb3, 1, w.in0, k->nb0, 0);
+      a.B[0] = seg2(w.z[l - 1], f->nb3, xf, w.in0, k->nb0, 0);
       a.B[1] = seg1(w.qb[l], a.nbb, 0);
     } else {
-      a.B[0] = seg1(w.z[l - 1], a.nbb, 1);
+      a.B[0] = seg1(w.z[l - 1], a.nbb, xf);
       a.B[1] = seg1(w.qb[l], a.nbb, 0);
     }
     run_wgrad(f, w, a, f->g_rowmap[l], f->g_colmap[l], li.w_off, li.in_dim, f->g_scale[l], li.b_off, theta_bar, s);
@@ -754,7 +776,7 @@ static void run_geo_wgrads(const SdfHipField* f, const FieldWs& w, const bool ta
     a.nbb = k->nbh;
     a.n_tiles = n_tiles;
     a.A[0] = seg1(w.featbar, k->nbf, 0);
-    a.B[0] = seg1(w.z[f->nl - 1], k->nbh, 1);
+    a.B[0] = seg1(w.z[f->nl - 1], k->nbh, xf);
     run_wgrad(f, w, a, f->g_rowmap[f->nl], f->g_colmap[f->nl], li.w_off, li.in_dim, 1.0f, li.b_off, theta_bar, s);
     const int tps = (int)((n_tiles + w.n_split - 1) / w.n_split);
     { ProfScope ps_(PS_WGRAD, s); k->sdfrow(w.z[f->nl - 1], tangent ? w.qb[f->nl] : nullptr, w.sdfbar, n_tiles, tps, w.partial, (unsigned)w.n_split, s); }
@@ -921,7 +943,10 @@ extern "C" int sdfhip_geo_backward(const SdfHipField* f, const float* packed, co
   ga.pe_degree = f->cfg.pe_degree;
   ga.nb0 = k->nb0;
   ga.tablebar = table_bar;
-  { ProfScope ps_(PS_GRID_BWD, s); grid_bwd_kernel<<<dim3((unsigned)((P + 255) / 256), f->grid.n_levels * (f->grid.n_features / 2)), 256, 0, s>>>(ga); }
+  if (f->grid.n_levels > 0) {  // NeRFField has no grid
+    ProfScope ps_(PS_GRID_BWD, s);
+    grid_bwd_kernel<<<dim3((unsigned)((P + 255) / 256), f->grid.n_levels * (f->grid.n_features / 2)), 256, 0, s>>>(ga);
+  }
 
   run_geo_wgrads(f, w, false, NP / 32, theta_bar, s);
   SDFHIP_CHECK_HIP(hipGetLastError());
@@ -1059,6 +1084,7 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
                                      sdfhip_stream_t stream) {
   (void)table;
   SDFHIP_REQUIRE(f && packed && level_mask && workspace && theta_bar && table_bar, "field_backward: null argument");
+  SDFHIP_REQUIRE(f->k->geo_bwd != nullptr, "field_backward: no second-order kernels for this (ReLU) field");
   if (n_rays == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const FieldKernels* k = f->k;

@@ -70,6 +70,21 @@ SDFHIP_D float softplus100_h(float z) {
   return t > 20.0f ? z : hs;
 }
 
+// Hidden activation of a fused geometry-type network, selected at compile time by the network's dims class (GeoDims::ACT):
+//   0  Softplus(beta = 100)   the SDF field (sdf_field.py:290, 409)
+//   1  ReLU                   the background fields (field_components/mlp.py:93 of NeRFField; tcnn's FullyFusedMLP in TCNNNerfactoField)
+// act_d1 is the derivative the first-order backward multiplies with; second-order passes exist for ACT = 0 only.
+template <int ACT>
+SDFHIP_D float act_h(const float z) {
+  if constexpr (ACT == 1) return fmaxf(z, 0.0f);
+  else return softplus100_h(z);
+}
+template <int ACT>
+SDFHIP_D float act_d1(const float z) {
+  if constexpr (ACT == 1) return z > 0.0f ? 1.0f : 0.0f;
+  else return softplus100_d1(z);
+}
+
 // thread-local last-error string (extern "C" API returns 0 or a negative code)
 void sdfhip_set_error(const char* fmt, ...);
 #define SDFHIP_CHECK_HIP(expr)                                                            \

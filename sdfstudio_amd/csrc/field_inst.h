@@ -13,6 +13,8 @@ struct FieldKernels {
   void (*col_bwd)(const ColBwdArgs&, unsigned grid, hipStream_t);
   void (*sdfrow)(const float* z_last, const float* qb_last, const float* sdfbar, int64_t n_tiles, int tiles_per_split,
                  float* partial, unsigned grid, hipStream_t);
+  int act;  // hidden activation of the geometry-type network (common.h act_h): 0 Softplus(100); 1 ReLU - first-order entries only
+            // (geo_fwd modes 1 - 3, geo_bwd1; geo_bwd is null)
 };
 
 // Kernels that want more than 64 KiB of dynamic LDS must raise the per-function limit first.
@@ -106,3 +108,41 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
   SDFHIP_DEFINE_GEO_FWD_INFER(NAME, NBH, NB0, NBF)                 \
   SDFHIP_DEFINE_GEO_BWD(NAME, NBH, NB0, NBF)                       \
   SDFHIP_DEFINE_COL_AND_TABLE(NAME, NBH, NB0, NBF, NBS, NBC)
+
+// ---- first-order kernel family with a ReLU geometry-type network: the background fields.  NeRFField
+// (fields/vanilla_nerf_field.py:37-114: 8 x 256 ReLU MLP with a skip, two 128-wide head layers) and TCNNNerfactoField's two 64-wide
+// bias-free ReLU MLPs (fields/nerfacto_field.py:128-156, 211-225) run on the same fused kernels as the SDF field - geo_fwd_kernel
+// without the analytic-normal chain (modes 1 - 3), geo_bwd_kernel<TANGENT = false>, the colour kernels, the split-K weight
+// gradients - instantiated with ACT = 1.  No second-order entries: nothing differentiates these fields' outputs w.r.t. position.
+#define SDFHIP_DEFINE_FIRST_ORDER_FIELD_KERNELS(NAME, NBH, NB0, NBF, NBS, NBC)                                            \
+  namespace NAME##_ns {                                                                                                   \
+  using GD = GeoDims<NBH, NB0, NBF, 1>;                                                                                    \
+  using CD = ColDims<NBF, NBS, NBC>;                                                                                      \
+  static void geo_fwd(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s) {                                      \
+    const size_t lds = GD::lds_floats(kNsFwd, a.p.nl) * sizeof(float);                                                     \
+    if (mode == 1) launch_lds(geo_fwd_kernel<GD, false, false, true>, a, grid, 256, lds, s);                              \
+    else if (mode == 3) launch_lds(geo_fwd_kernel<GD, false, true, true>, a, grid, 256, lds, s);                          \
+    else if (mode == 2) launch_lds(geo_fwd_kernel<GD, false, false, false>, a, grid, 256, lds, s);                        \
+    else abort(); /* second-order modes are refused in sdfhip_field_forward before they get here */                      \
+  }                                                                                                                       \
+  static void geo_bwd1(const GeoBwdArgs& a, unsigned grid, hipStream_t s) {                                               \
+    launch_lds(geo_bwd_kernel<GD, false>, a, grid, 256, GD::lds_floats(kNsGrad, a.p.nl) * sizeof(float), s);              \
+  }                                                                                                                       \
+  static void col_fwd(const ColFwdArgs& a, int save, unsigned grid, hipStream_t s) {                                      \
+    const size_t lds = CD::lds_floats(kNsCol, a.p.nlc) * sizeof(float);                                                   \
+    if (save) launch_lds(col_fwd_kernel<CD, true>, a, grid, 256, lds, s);                                                 \
+    else launch_lds(col_fwd_kernel<CD, false>, a, grid, 256, lds, s);                                                     \
+  }                                                                                                                       \
+  static void col_bwd(const ColBwdArgs& a, unsigned grid, hipStream_t s) {                                                \
+    launch_lds(col_bwd_kernel<CD>, a, grid, 256, CD::lds_floats(kNsGrad, a.p.nlc) * sizeof(float), s);                    \
+  }                                                                                                                       \
+  static void sdfrow(const float* z, const float* q, const float* sb, int64_t nt, int tps, float* part,                  \
+                     unsigned grid, hipStream_t s) {                                                                      \
+    sdfrow_grad_kernel<NBH, 1><<<grid, 256, 0, s>>>(z, q, sb, nt, tps, part);                                             \
+  }                                                                                                                       \
+  }                                                                                                                       \
+  const FieldKernels* sdfhip_kernels_##NAME() {                                                                           \
+    static const FieldKernels k = {NBH, NB0, NBF, NBS, NBC, NAME##_ns::geo_fwd, nullptr, NAME##_ns::geo_bwd1,             \
+                                   NAME##_ns::col_fwd, NAME##_ns::col_bwd, NAME##_ns::sdfrow, 1};                         \
+    return &k;                                                                                                            \
+  }

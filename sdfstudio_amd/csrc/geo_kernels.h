@@ -46,9 +46,10 @@ constexpr int kNsMax = ns_parts(kNsFwd) > ns_parts(kNsGrad) ? kNsFwd : kNsGrad; 
 
 // Block widths of a geometry network (32 features per block): hidden, in0 (position + encodings + grid features), geometry
 // feature.  The DEPTH (hidden layers NL, skip layer SKIP or -1) is a run-time property carried in GeoPtrs: the kernels loop.
-template <int NBH_, int NB0_, int NBF_>
+template <int NBH_, int NB0_, int NBF_, int ACT_ = 0>
 struct GeoDims {
   static constexpr int NBH = NBH_, NB0 = NB0_, NBF = NBF_;
+  static constexpr int ACT = ACT_;  // hidden activation (common.h act_h / act_d1): 0 Softplus(100), 1 ReLU (first-order kernels only)
   static constexpr int cmax(int a, int b) { return a > b ? a : b; }
   static constexpr int MAXO = cmax(NBH, NBF);                            // widest chunk (out-blocks) any gemm streams
   static constexpr int buf_floats(int ns) { return chunk_pieces(MAXO, ns) * 256; }  // one weight chunk buffer
@@ -115,6 +116,7 @@ SDFHIP_D const float* geo_skip_in0(const float* wp_skip) {
 template <class D, bool GRAD, bool SAVE, bool FEAT, int PHASE = 0>
 __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
   static_assert(PHASE == 0 || GRAD, "the chain only exists with GRAD");
+  static_assert(!GRAD || D::ACT == 0, "the analytic-normal chain is written for Softplus(100) networks");
   constexpr bool CHAIN = GRAD && PHASE != 1;  // this launch runs (and prefetches for) the chain
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, hf = lane >> 5;
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
         constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
         const float z = accIn[kb][e];
         if constexpr (SAVE || GRAD) *tp_elem(zprev, tile, D::NBH, kb, e, lane) = z;
-        return softplus100_h(z);
+        return act_h<D::ACT>(z);
       };
       const float* nxt = l == SKIP ? geo_skip_in0<D>(a.p.wp[l]) : (l + 1 < NL ? a.p.wp[l + 1] : after_last);
       tp_gemm<D::NBH, D::NBH, Stores<ZS>, NS, PCS>(accOut, carry, NoFetch{}, make, in0_blk0, ws, a.p.wp[l], nxt);
@@ -185,7 +187,7 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
       constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
       const float z = accIn[kb][e];
       if constexpr (SAVE || GRAD) *tp_elem(zlast, tile, D::NBH, kb, e, lane) = z;
-      const float h = softplus100_h(z);
+      const float h = act_h<D::ACT>(z);
       part = fmaf(wsdf[kb * 32 + tp_row(e, hf)], h, part);
       return h;
     };
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
       auto fetch = [&](auto bc) __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(zl, tile, D::NBH, decltype(bc)::value)}}; };
       auto make = [&](auto bc, const Raw& raw, auto ec) __attribute__((always_inline)) {
         constexpr int b = decltype(bc)::value, e = decltype(ec)::value;
-        const float r = accIn[b][e] * softplus100_d1(raw.a[e]);
+        const float r = accIn[b][e] * act_d1<D::ACT>(raw.a[e]);
         if constexpr (SAVE) *tp_elem(rl, tile, D::NBH, b, e, lane) = r;
         return r;
       };
@@ -274,6 +276,7 @@ struct GeoBwdArgs {
 template <class D, bool TANGENT = true, int PHASE = 0>
 __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
   static_assert(PHASE == 0 || TANGENT, "phases split the second-order kernel");
+  static_assert(!TANGENT || D::ACT == 0, "the tangent pass uses Softplus(100)'s second derivative");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, hf = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -315,7 +318,7 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
         auto make = [&](auto kbc, const Raw& raw, auto ec) __attribute__((always_inline)) {
           constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
           const float v = accIn[kb][e];
-          const float d1 = softplus100_d1(raw.a[e]);
+          const float d1 = act_d1<D::ACT>(raw.a[e]);
           *tp_elem(zbp, tile, D::NBH, kb, e, lane) = v * raw.b[e] * (100.0f * (1.0f - d1));
           const float qn = d1 * v;
           *tp_elem(qbl, tile, qb_nb, kb, e, lane) = qn;
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
         static_for<0, 16>([&](auto ec) __attribute__((always_inline)) {
           constexpr int e = decltype(ec)::value;
           const float v = accIn[b][e];
-          const float d1 = softplus100_d1(raw.a[e]);
+          const float d1 = act_d1<D::ACT>(raw.a[e]);
           *tp_elem(zblast, tile, D::NBH, b, e, lane) = v * raw.b[e] * (100.0f * (1.0f - d1));
           *tp_elem(qblast, tile, D::NBH, b, e, lane) = d1 * v;
         });
@@ -403,7 +406,7 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
     if (l == 0 || l == SKIP) {
       auto make = [&](auto bc, const Raw& raw, auto ec) __attribute__((always_inline)) {
         constexpr int b = decltype(bc)::value, e = decltype(ec)::value;
-        const float zb = TANGENT ? fmaf(accIn[b][e], softplus100_d1(raw.a[e]), raw.b[e]) : accIn[b][e] * softplus100_d1(raw.a[e]);
+        const float zb = TANGENT ? fmaf(accIn[b][e], act_d1<D::ACT>(raw.a[e]), raw.b[e]) : accIn[b][e] * act_d1<D::ACT>(raw.a[e]);
         *tp_elem(zbl, tile, D::NBH, b, e, lane) = zb;
         return zb;
       };
@@ -424,8 +427,8 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
       auto make = [&](auto bc, const Raw& raw, auto ec) __attribute__((always_inline)) {
         constexpr int b = decltype(bc)::value, e = decltype(ec)::value;
         float zb;
-        if constexpr (TANGENT) zb = done ? raw.b[e] : fmaf(accIn[b][e], softplus100_d1(raw.a[e]), raw.b[e]);
-        else zb = accIn[b][e] * softplus100_d1(raw.a[e]);
+        if constexpr (TANGENT) zb = done ? raw.b[e] : fmaf(accIn[b][e], act_d1<D::ACT>(raw.a[e]), raw.b[e]);
+        else zb = accIn[b][e] * act_d1<D::ACT>(raw.a[e]);
         *tp_elem(zbl, tile, D::NBH, b, e, lane) = zb;
         return zb;
       };

@@ -8,7 +8,7 @@
 // (qb_last == nullptr: first-order backward, no tangent term)
 // grid = n_split, block = 256 (the 4 waves interleave over the split's tiles, then sum through LDS).
 // partial: [n_split][NBH*32 + 32]  (last 32-slot holds b_sdf_bar in [0])
-template <int NBH>
+template <int NBH, int ACT = 0>
 __global__ __launch_bounds__(256) void sdfrow_grad_kernel(const float* __restrict__ z_last, const float* __restrict__ qb_last,
                                                             const float* __restrict__ sdfbar, const int64_t n_tiles,
                                                             const int tiles_per_split, float* __restrict__ partial) {
@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void sdfrow_grad_kernel(const float* __restric
       const float* qp = qb_last + ((size_t)tile * NBH + b) * 1024 + lane;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        acc[b][r] += fmaf(sb, softplus100_h(zp[r * 64]), qb_last != nullptr ? qp[r * 64] : 0.0f);
+        acc[b][r] += fmaf(sb, act_h<ACT>(zp[r * 64]), qb_last != nullptr ? qp[r * 64] : 0.0f);
       }
     }
   }

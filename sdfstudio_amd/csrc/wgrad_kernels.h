@@ -90,7 +90,7 @@ static __global__ void packvec_kernel(const float* __restrict__ theta, const Vec
 struct TpOperand {
   const float* ptr[2];  // up to two concatenated TP arrays
   int32_t nb[2];        // blocks in each
-  int32_t xf[2];        // 0: as stored, 1: softplus(beta=100) applied on load
+  int32_t xf[2];        // 0: as stored, 1: softplus(beta=100) applied on load, 2: ReLU applied on load
 };
 struct WgradArgs {
   TpOperand A[2], B[2];  // up to two (A, B) pairs accumulated into the same C
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
   const float* src0[4];
   const float* src1[4];
   int stride0[4], stride1[4];
-  bool xf0[4], xf1[4];
+  int xf0[4], xf1[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int blk = slot[q] < 8 ? ob_base + slot[q] : ib_base + slot[q] - 8;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
       const int lb = blk - (seg ? op.nb[0] : 0);
       const float* base = op.ptr[seg] + (size_t)lb * 1024;
       const int stride = op.nb[seg] * 1024;
-      const bool xf = op.xf[seg] == 1;
+      const int xf = op.xf[seg];
       if (pr == 0) {
         src0[q] = base;
         stride0[q] = stride;
@@ -192,15 +192,18 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (!valid[q]) continue;
-      const bool xf = p1 ? xf1[q] : xf0[q];
+      const int xf = p1 ? xf1[q] : xf0[q];
       // lane holds, for i = 0..3, TP row r = 4 i + (lane >> 4), half (lane >> 3) & 1, points 4 (lane & 7) .. + 3
       float* dst = lds + slot[q] * kWgBlk + (lane & 7) * 4;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         f32x4 v = pre[q][i];
-        if (xf) {
+        if (xf == 1) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = softplus100_h(v[e]);
+        } else if (xf == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
         }
         const int f = tp_row(i * 4 + (lane >> 4), (lane >> 3) & 1);
         *reinterpret_cast<f32x4*>(dst + f * kWgRow) = v;
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
   const float* src0[4];
   const float* src1[4];
   int stride0[4], stride1[4];
-  bool xf0[4], xf1[4];
+  int xf0[4], xf1[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int blk = slot[q] < 8 ? ob_base + slot[q] : ib_base + slot[q] - 8;
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
       const int lb = blk - (seg ? op.nb[0] : 0);
       const float* base = op.ptr[seg] + (size_t)lb * 1024;
       const int stride = op.nb[seg] * 1024;
-      const bool xf = op.xf[seg] == 1;
+      const int xf = op.xf[seg];
       if (pr == 0) {
         src0[q] = base;
         stride0[q] = stride;
@@ -355,15 +358,18 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (!valid[q]) continue;
-      const bool xf = p1 ? xf1[q] : xf0[q];
+      const int xf = p1 ? xf1[q] : xf0[q];
       // lane holds, for i = 0..3, TP row r = 4 i + (lane >> 4), half (lane >> 3) & 1, points 4 (lane & 7) .. + 3
       __bf16* dst = ldsb + slot[q] * kWbSlot + (lane & 7) * 4;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         f32x4 v = pre[q][i];
-        if (xf) {
+        if (xf == 1) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = softplus100_h(v[e]);
+        } else if (xf == 2) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
         }
         if (q < 2 && !p1) colsum[q][i] += (v[0] + v[1]) + (v[2] + v[3]);
         bf16x4 hi, lo;
@@ -487,7 +493,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16x8_kernel(const WgradArgs a)
   const float* src0[2];
   const float* src1[2];
   int stride0[2], stride1[2];
-  bool xf0[2], xf1[2];
+  int xf0[2], xf1[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int blk = q == 0 ? ob_base + wave : ib_base + wave;
@@ -498,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16x8_kernel(const WgradArgs a)
       const int lb = blk - (seg ? op.nb[0] : 0);
       const float* base = op.ptr[seg] + (size_t)lb * 1024;
       const int stride = op.nb[seg] * 1024;
-      const bool xf = op.xf[seg] == 1;
+      const int xf = op.xf[seg];
       if (pr == 0) {
         src0[q] = base;
         stride0[q] = stride;
@@ -533,13 +539,16 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16x8_kernel(const WgradArgs a)
     constexpr int q = decltype(qc)::value, i = decltype(ic)::value;
     if (!valid[q]) return;
     const bool p1 = st >= n_t;
-    const bool xf = p1 ? xf1[q] : xf0[q];
+    const int xf = p1 ? xf1[q] : xf0[q];
     // lane holds, for i = 0..3, TP row r = 4 i + (lane >> 4), half (lane >> 3) & 1, points 4 (lane & 7) .. + 3
     __bf16* dst = ldsb + (st & 1) * kWbBuf + slot[q] * kWbSlot + (lane & 7) * 4;
     f32x4 v = pre[q][i];
-    if (xf) {
+    if (xf == 1) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = softplus100_h(v[e]);
+    } else if (xf == 2) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
     }
     if (q == 0 && !p1) colsum[i] += (v[0] + v[1]) + (v[2] + v[3]);
     bf16x4 hi, lo;

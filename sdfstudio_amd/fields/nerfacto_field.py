@@ -4,9 +4,13 @@ base_surface_model.py:181-187 builds it for BASELINE config 5 (neus-facto-angelo
 + features + appearance embedding -> 3-layer 64-wide ReLU MLP -> sigmoid rgb.
 
 The reference builds every piece from tiny-cuda-nn (HashGrid, FullyFusedMLP without biases, SphericalHarmonics degree 4); here the
-hash-grid encoding is the sdfhip operator (sdfhip_grid_encode_forward / _backward, csrc/grid_encode_kernels.h), the two small MLPs
-and the harmonics are torch ops on device tensors (rocBLAS) - NOT hand-written kernels, stated plainly; this field is off BASELINE
-config 2's path.  Optional heads of the reference (transients, semantics, predicted normals: all off in the surface models) raise.
+whole field runs on the fused sdfhip kernels instantiated with a ReLU activation (csrc/inst_e.hip): hash-grid gather +
+base MLP + density row are one ``geo_fwd_kernel`` launch (``sdfhip_geo_forward``; backward: ``geo_bwd_kernel<TANGENT = false>``,
+``grid_bwd_kernel``, split-K weight gradients), the colour MLP one ``col_fwd_kernel`` launch (``sdfhip_color_forward``) that takes the
+16 spherical harmonics of the view direction and the appearance embedding - both per-ray quantities - in the per-ray embedding slots
+of its small-input block.  The harmonics themselves are 16 polynomials per RAY (torch, [N, 16]).  No torch matmul, no rocBLAS, no CPU
+path.  Optional heads of the reference (transients, semantics, predicted normals: all off in the surface models) raise.
+``hash_grid_encode`` below is the encoding as a standalone operator (tcnn.Encoding("HashGrid")), kept for callers that want features.
 tcnn keeps each network's weights in one fp16 ``params`` vector in an internal padded layout, so reference checkpoints of THIS field do
 not load (fp32 ``mlp_base.{table, w1, w2}``, ``mlp_head.{w1, w2, w3}`` here), as for the proposal networks.
 """
@@ -124,40 +128,74 @@ class TCNNNerfactoField(nn.Module):
         _, n_entries = _lib.grid_levels(self.grid_cfg)
         self.mlp_base = _BaseParams(n_entries * features_per_level, num_levels * features_per_level, hidden_dim, 1 + geo_feat_dim)
         self.mlp_head = _HeadParams(16 + geo_feat_dim + appearance_embedding_dim, hidden_dim_color, 3)
+        # ---- native descriptor: a ReLU geometry-type network on in0 = [x (zero weights) | grid features], 1 hidden layer, output =
+        # [density ; geometry features padded to one 32-wide block]; colour-type network with 2 hidden layers whose per-ray embedding
+        # slots carry [SH(16) | appearance embedding]
+        from sdfstudio_amd.fields.vanilla_nerf_field import NativeBackgroundNet
+
+        if geo_feat_dim > 32 or hidden_dim % 32 or hidden_dim_color % 32:
+            raise NotImplementedError("geo_feat_dim <= 32 and hidden widths that are multiples of 32")
+        self._gf_pad = 32
+        n_in, e_dim = num_levels * features_per_level, 16 + appearance_embedding_dim
+        cfg_c = _lib.FieldCfg(1, hidden_dim, self._gf_pad, 2, hidden_dim_color, -1, 0, 0, e_dim, 0, 0.0, self.grid_cfg, 1, 0)
+        expect = [(hidden_dim, 3 + n_in), (1 + self._gf_pad, hidden_dim), (hidden_dim_color, 33 + self._gf_pad + e_dim),
+                  (hidden_dim_color, hidden_dim_color), (3, hidden_dim_color)]
+        self._native = NativeBackgroundNet(cfg_c, self._gf_pad, e_dim, expect)
+
+    def _theta(self) -> torch.Tensor:
+        """Flat parameter vector in the library's layout (differentiable torch indexing).  tcnn's FullyFusedMLP has no biases: they
+        are zeros here and their gradients are dropped."""
+        b, h = self.mlp_base, self.mlp_head
+        dev, dt = b.w1.device, b.w1.dtype
+        z = lambda *shape: torch.zeros(*shape, device=dev, dtype=dt)  # noqa: E731
+        H, HC, G, GP, E = b.w1.shape[0], h.w1.shape[0], self.geo_feat_dim, self._gf_pad, self.appearance_embedding_dim
+        parts = [torch.cat([z(H, 3), b.w1], dim=1).reshape(-1), z(H),
+                 torch.cat([b.w2, z(1 + GP - b.w2.shape[0], H)], dim=0).reshape(-1), z(1 + GP),
+                 # colour layer 0 columns: x(3) d-PE(27) normal(3) [all unused] | features (GP) | embedding slots = SH(16) + appearance (E)
+                 torch.cat([z(HC, 33), h.w1[:, 16:16 + G], z(HC, GP - G), h.w1[:, :16], h.w1[:, 16 + G:16 + G + E]], dim=1).reshape(-1), z(HC),
+                 h.w2.reshape(-1), z(HC), h.w3.reshape(-1), z(3)]
+        return torch.cat(parts)
 
     def get_density(self, ray_samples):
-        """:225-246: contracted frustum MID points -> (x + 2) / 4 -> hash grid -> MLP -> trunc_exp of the first output."""
-        positions = ray_samples.frustums.get_positions()
-        if self.spatial_distortion is not None:
-            positions = (self.spatial_distortion(positions) + 2.0) / 4.0
-        else:
-            positions = (positions - self.aabb[0]) / (self.aabb[1] - self.aabb[0])  # SceneBox.get_normalized_positions
-        shape = positions.shape[:-1]
-        feat = hash_grid_encode(self.mlp_base.table, positions.reshape(-1, 3).detach().float(), self.grid_cfg)
-        h = torch.relu(feat @ self.mlp_base.w1.t()) @ self.mlp_base.w2.t()
-        h = h.view(*shape, -1)
-        density = _TruncExp.apply(h[..., :1])
-        return density, h[..., 1:]
+        """:225-246: contracted frustum MID points -> (x + 2) / 4 -> hash grid -> MLP -> trunc_exp of the first output.  The second
+        return value carries what get_outputs needs from this call (features + the packed parameter vector + positions)."""
+        from sdfstudio_amd.fields.sdf_field import _GeoNetFunction
 
-    def get_outputs(self, ray_samples, density_embedding: Optional[torch.Tensor] = None) -> Dict:
+        positions = ray_samples.frustums.get_positions()
+        shape = tuple(positions.shape[:-1])
+        if self.spatial_distortion is not None:
+            positions = self.spatial_distortion(positions)  # the kernel applies (x + 2) / 4 itself (sdf_field.py:384, same map)
+        else:
+            positions = (positions - self.aabb[0]) / (self.aabb[1] - self.aabb[0]) * 4.0 - 2.0  # SceneBox.get_normalized_positions
+        x = positions.reshape(-1, 3).detach().float().contiguous()
+        if not x.is_cuda:
+            raise _lib.SdfHipError("TCNNNerfactoField runs on the sdfhip kernels: HIP device tensors required (no CPU fallback)")
+        theta = self._theta()
+        mask = torch.ones(self.grid_cfg.n_levels * self.grid_cfg.n_features, device=x.device)
+        pre, feat = _GeoNetFunction.apply(theta, self.mlp_base.table, self._native, x, mask)
+        density = _TruncExp.apply(pre.view(*shape, 1))
+        return density, (feat, theta, x)
+
+    def get_outputs(self, ray_samples, density_embedding=None) -> Dict:
         """:248-330."""
+        from sdfstudio_amd.cameras.rays import unpack_ray_samples
+        from sdfstudio_amd.fields.sdf_field import _ColorFunction
+
         assert density_embedding is not None
         if ray_samples.camera_indices is None:
             raise AttributeError("Camera indices are not provided.")
-        shape = density_embedding.shape[:-1]
-        directions = (ray_samples.frustums.directions.expand(*shape, 3) + 1.0) / 2.0  # get_normalized_directions
-        d = sh_degree4(directions.reshape(-1, 3))
+        feat, theta, x = density_embedding
+        _, d, st, _ = unpack_ray_samples(ray_samples)
+        n, s = st.shape
+        sh = sh_degree4((d + 1.0) / 2.0)  # get_normalized_directions; per ray
         if self.training:
-            emb = self.embedding_appearance(ray_samples.camera_indices.reshape(shape[0], -1)[:, 0])
-            emb = emb[:, None, :].expand(*shape, -1) if len(shape) == 2 else emb
+            emb = self.embedding_appearance(ray_samples.camera_indices.reshape(n, -1)[:, 0])
         elif self.use_average_appearance_embedding:
-            emb = self.embedding_appearance.mean(dim=0).expand(*shape, -1)
+            emb = self.embedding_appearance.mean(dim=0)[None, :].expand(n, -1)
         else:
-            emb = torch.zeros(*shape, self.appearance_embedding_dim, device=d.device)
-        h = torch.cat([d, density_embedding.reshape(-1, self.geo_feat_dim), emb.reshape(-1, self.appearance_embedding_dim)], dim=-1)
-        p = self.mlp_head
-        rgb = torch.sigmoid(torch.relu(torch.relu(h @ p.w1.t()) @ p.w2.t()) @ p.w3.t())
-        return {FieldHeadNames.RGB: rgb.view(*shape, 3)}
+            emb = torch.zeros(n, self.appearance_embedding_dim, device=d.device)
+        rgb = _ColorFunction.apply(theta, feat, torch.zeros_like(x), torch.cat([sh, emb], dim=-1), self._native, x, d.contiguous(), n, s)
+        return {FieldHeadNames.RGB: rgb.view(n, s, 3)}
 
     def forward(self, ray_samples) -> Dict:
         """fields/base_field.py:111-126."""

@@ -829,3 +829,34 @@ def test_optimizers_state_dict_round_trip_restores_moments_step_and_schedule():
     bad = dict(sd, groups={"fields": sd["groups"]["fields"]})
     with pytest.raises(KeyError):
         o2.load_optimizers(bad)
+
+
+def test_oracle_nerf_background_field_against_reference():
+    """The "mlp" background field (the reference's default, base_surface_model.py:189-200): oracle.nerf_field against the reference's own
+    NeRFField (fields/vanilla_nerf_field.py, pure torch: fully pinned) on the same parameters, with and without scene contraction."""
+    from oracle import ref_harness
+
+    if not ref_harness.reference_available():
+        pytest.skip("needs /root/reference (build container)")
+    ns = ref_harness.import_reference()
+    from nerfstudio.field_components.encodings import NeRFEncoding
+    from nerfstudio.field_components.spatial_distortions import SceneContraction
+    from nerfstudio.fields.vanilla_nerf_field import NeRFField
+
+    torch.manual_seed(5)
+    for contraction in ("inf", None):
+        fld = NeRFField(position_encoding=NeRFEncoding(in_dim=3, num_frequencies=10, min_freq_exp=0.0, max_freq_exp=9.0, include_input=True),
+                        direction_encoding=NeRFEncoding(in_dim=3, num_frequencies=4, min_freq_exp=0.0, max_freq_exp=3.0, include_input=True),
+                        spatial_distortion=SceneContraction(order=float("inf")) if contraction else None)
+        n, s = 19, 6
+        o, d, cam = O.synthetic_rays(n, seed=4)
+        starts = torch.sort(torch.rand(n, s) * 6.0 + 0.3, dim=-1).values
+        ends = starts + torch.rand(n, s) * 0.4 + 0.01
+        rb = ns.rays.RayBundle(origins=o, directions=d, pixel_area=torch.ones(n, 1), directions_norm=torch.ones(n, 1), camera_indices=cam[:, None])
+        rs = rb.get_ray_samples(bin_starts=starts[..., None], bin_ends=ends[..., None])
+        with torch.no_grad():
+            ref = {str(k).split(".")[-1]: v for k, v in fld(rs).items()}
+            out = O.nerf_field(o, d, starts, ends, dict(fld.state_dict()), "", contraction)
+        assert_close("density", out["density"], ref["DENSITY"][..., 0], rtol=1e-5, atol=1e-7)
+        assert_close("rgb", out["rgb"], ref["RGB"], rtol=1e-5, atol=1e-6)
+        assert float(out["rgb"].std()) > 1e-3

@@ -1371,11 +1371,15 @@ def test_background_mlp_models_against_reference_golden(device, name):
     # amplifies it (same 5e-3 bar as test_neus_model_against_reference_golden); the other two models follow the reference's
     # samples to ~1e-6
     tol = 5e-3 if name == "neus" else 5e-4
-    assert_close("weights", out["weights"], o["weights"], rtol=tol, atol=2e-6)
-    assert_close("rgb", out["rgb"], o["rgb"], rtol=tol, atol=1e-6)
-    assert_close("depth", out["depth"], o["depth"], rtol=tol, atol=1e-5)
-    assert_close("normal", out["normal"], o["normal"], rtol=tol, atol=1e-5)
-    assert_close("accumulation", out["accumulation"], o["accumulation"], rtol=tol, atol=1e-6)
+    # END-TO-END comparison (both sides run their own samplers): sample positions differ by fp32 round-off, so single elements move
+    # by more than the tensor-level bars suggest and the element-wise gate of helpers.report does not apply (inf); element-wise
+    # parity of the background fields on IDENTICAL samples: test_nerf_background_field_fwd_bwd, test_nerfacto_background_field_fwd_bwd
+    E = float("inf")
+    assert_close("weights", out["weights"], o["weights"], rtol=tol, atol=2e-6, elem_rtol=E)
+    assert_close("rgb", out["rgb"], o["rgb"], rtol=tol, atol=1e-6, elem_rtol=E)
+    assert_close("depth", out["depth"], o["depth"], rtol=tol, atol=1e-5, elem_rtol=E)
+    assert_close("normal", out["normal"], o["normal"], rtol=tol, atol=1e-5, elem_rtol=E)
+    assert_close("accumulation", out["accumulation"], o["accumulation"], rtol=tol, atol=1e-6, elem_rtol=E)
     assert_close("rgb_loss", loss, g["loss"]["rgb_loss"], rtol=1e-4, atol=1e-7)
     got = {k.replace("mlp_base.table", "mlp_base.encoding.params") if k.startswith(("proposal_networks.", "field_background.")) else k: p.grad
            for k, p in model.named_parameters() if p.grad is not None}
@@ -1388,10 +1392,9 @@ def test_background_mlp_models_against_reference_golden(device, name):
         # (|z| ~ 1e-6, helpers.relu_flip_basis) moves single entries by up to ~1e-2 of the maximum; their tight comparison is the
         # job of the train-mode goldens (test_*_model_against_reference_golden), here they get the loose bar.
         # (the hash table's finest level is the extreme case: an entry sees a handful of samples, its gradient here is ~1e-4)
-        # background: 2e-3 on the heads / head MLP; the 8 x 256 base MLP's gradients (scale ~5e-5 here, sums of 256-term products
-        # through rocBLAS on the device vs the CPU reference) get 1e-2
+        # background: 2e-3 on the heads / head MLP; the 8 x 256 base MLP's gradients (scale ~5e-5 here) get 1e-2
         rt = (1e-2 if "mlp_base" in k else 2e-3) if k.startswith("field_background") else (1e-1 if k == "field.encoding.params" else 2e-2)
-        assert_close(f"grad {k}", got[k], ref, rtol=rt, atol=1e-9)
+        assert_close(f"grad {k}", got[k], ref, rtol=rt, atol=1e-9, elem_rtol=E)
         checked += 1
     assert checked >= (44 if grid else 50)
     assert any(k.startswith("field_background.mlp_base") for k in g["grad"])
@@ -1835,6 +1838,53 @@ def test_standalone_hash_grid_encode(device, features, smooth):
     (f * co.to(device)).sum().backward()
     assert_close("features", f, f_ref, rtol=1e-5, atol=1e-6)
     assert_close("table gradient", t.grad, t_ref.grad, rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("contraction", ["inf", None])
+def test_nerf_background_field_fwd_bwd(device, contraction):
+    """NeRFField, the reference's default background model (fields/vanilla_nerf_field.py:37-114; 8 x 256 ReLU MLP with a skip + 2 x 128
+    head), on the fused sdfhip kernels (csrc/inst_d.hip) against the oracle's restatement (pinned on the reference's own class by
+    test_oracle_nerf_background_field_against_reference) on IDENTICAL samples: density, rgb and every parameter gradient, with the
+    element-wise gate.  n * s = 161 points: padded tail of the 128-point tiles."""
+    from sdfstudio_amd.fields.field_heads import FieldHeadNames
+    from sdfstudio_amd.fields.vanilla_nerf_field import NeRFField
+    from sdfstudio_amd.models.neus_facto import SceneContraction
+
+    torch.manual_seed(13)
+    fld = NeRFField(spatial_distortion=SceneContraction(order=float("inf")) if contraction else None)
+    with torch.no_grad():  # biases away from zero so that every ReLU pattern occurs
+        for prm in fld.parameters():
+            if prm.dim() == 1:
+                prm.add_(0.1 * torch.randn_like(prm))
+    fld = fld.to(device).train()
+    n, s = 23, 7
+    o, d, cam = O.synthetic_rays(n, seed=4)
+    starts = torch.sort(torch.rand(n, s) * (6.0 if contraction else 1.5) + 0.3, dim=-1).values
+    ends = starts + torch.rand(n, s) * 0.4 + 0.01
+    rs = _bundle(o, d, cam, 0.3, 7.0, device).get_ray_samples(starts.to(device), ends.to(device))
+    out = fld(rs)
+    co = [torch.randn(n, s), torch.randn(n, s, 3)]
+    (out[FieldHeadNames.DENSITY][..., 0] * co[0].to(device)).sum().add((out[FieldHeadNames.RGB] * co[1].to(device)).sum()).backward()
+
+    def oracle(dtype):
+        p = {k: v.detach().cpu().to(dtype).requires_grad_(True) for k, v in fld.state_dict().items()}
+        ref = O.nerf_field(o.to(dtype), d.to(dtype), starts.to(dtype), ends.to(dtype), p, "", contraction)
+        ((ref["density"] * co[0].to(dtype)).sum() + (ref["rgb"] * co[1].to(dtype)).sum()).backward()
+        return ref, p
+
+    ref, p = oracle(torch.float32)
+    _, p64 = oracle(torch.float64)
+    assert out[FieldHeadNames.DENSITY].shape == (n, s, 1) and out[FieldHeadNames.RGB].shape == (n, s, 3)
+    assert_close("density", out[FieldHeadNames.DENSITY][..., 0], ref["density"], rtol=1e-4, atol=1e-6)
+    assert_close("rgb", out[FieldHeadNames.RGB], ref["rgb"], rtol=1e-4, atol=1e-6)
+    checked = 0
+    for k, prm in fld.named_parameters():
+        assert prm.grad is not None, k
+        # 10-frequency encodings (2^9 x) amplify position round-off: the fp32 oracle itself is ~1e-4 from its fp64 evaluation on the
+        # first layer; the bar is the fp32 round-off class of the reference path, or 1e-3 of the maximum
+        assert_fp32_class(f"grad {k}", prm.grad, p[k].grad, p64[k].grad, factor=3.0, atol=1e-3 * p64[k].grad.abs().max().item())
+        checked += 1
+    assert checked == 2 * (8 + 2 + 1 + 1)
 
 
 @pytest.mark.parametrize("training", [True, False])
