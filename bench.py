@@ -93,7 +93,7 @@ def draw_rays(centers, rot, n, gen):
     y = (u[:, 1] * 384).floor() + 0.5
     x = (u[:, 2] * 384).floor() + 0.5
     d_cam = torch.stack([(x - 199.4) / 925.5, (y - 198.1) / 922.6, torch.ones_like(x)], dim=-1)
-    d = torch.einsum("nij,nj->ni", rot[cam], d_cam)
+    d = (rot[cam] * d_cam[:, None, :]).sum(dim=-1)  # rot @ d_cam per ray, elementwise (a bmm would put a rocBLAS kernel into the trace)
     norm = d.norm(dim=-1, keepdim=True)
     return centers[cam].contiguous(), (d / norm).contiguous(), norm, cam
 

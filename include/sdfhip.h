@@ -107,6 +107,18 @@ int64_t sdfhip_field_workspace_size(const SdfHipField* f, int64_t n_points, int3
 /* theta -> MFMA operand order: every weight as five 16-bit parts (bf16 w0 + w1 + w2, fp16 hi + lo; a kernel streams the two of its
  * precision mode), W and W^T chunked per 32-wide k block (once per optimiser step). */
 int sdfhip_field_pack(const SdfHipField* f, const float* theta, float* packed, sdfhip_stream_t stream);
+/* Weight-normalised parameters -> theta and back, one launch each.  Every Linear of the SDF field is nn.utils.weight_norm'ed
+ * (fields/sdf_field.py:314-317, 362): W = g v / ||v|| per output row; theta is the flat [W_0 | b_0 | W_1 | b_1 ...] vector of
+ * sdfhip_field_theta_layout.  v / g / b: HOST arrays of n_lin = sdfhip_field_num_linear(f) DEVICE pointers (weight_v [out, in],
+ * weight_g [out, 1], bias [out]).  inv_norm: [sdfhip_field_weightnorm_rows(f)] scratch the backward needs.  Backward: v_bar / g_bar /
+ * b_bar are host arrays of device pointers the gradients are written to (accumulate = 1: added to) - e.g. straight into the
+ * flat gradient buffer of a data-parallel exchange; a null entry skips that output. */
+int64_t sdfhip_field_weightnorm_rows(const SdfHipField* f);
+int sdfhip_field_theta_from_weightnorm(const SdfHipField* f, const float* const* v, const float* const* g, const float* const* b,
+                                       int32_t n_lin, float* theta, float* inv_norm, sdfhip_stream_t stream);
+int sdfhip_field_theta_backward_weightnorm(const SdfHipField* f, const float* const* v, const float* const* g, const float* const* b,
+                                           int32_t n_lin, const float* inv_norm, const float* theta_bar, float* const* v_bar,
+                                           float* const* g_bar, float* const* b_bar, int32_t accumulate, sdfhip_stream_t stream);
 
 enum {
   SDFHIP_MODE_SDF = 0,     /* get_sdf: sdf only                                  */
@@ -263,6 +275,22 @@ int sdfhip_packed_weights_backward(const float* alpha, const float* weights, con
  * (values NULL: of weights_i, dim = 1); rays without samples get zeros.  Deterministic (one wavefront per ray, no atomics). */
 int sdfhip_packed_accumulate(const float* weights, const float* values, const int64_t* offsets, const int32_t* counts, int64_t n_rays,
                              int32_t dim, float* out, sdfhip_stream_t stream);
+/* Scalar losses behind the renderer, fused: loss4 = { L1 colour loss F.l1_loss(image, rgb) (models/
+ * base_surface_model.py:402), eikonal ((|grad| - 1)^2).mean() (:406), curvature |(tap sums - 2 sdf) / delta^2|.mean() (models/
+ * neus_facto.py:313-325), MonoSDF normal loss (model_components/losses.py:264-275: L1 + cosine of the normalised normals) }, each
+ * multiplied by scale4_host[k] (HOST array: multiplier / element count; 0 for a loss that is off).  grad [P,3], sdf [P] + taps [P,6],
+ * n_pred + n_gt [N,3] may be NULL (those losses are then 0).  workspace: sdfhip_surface_loss_workspace_floats() floats.  Deterministic
+ * (per-block partial sums, fixed-order finish).  Backward: loss_bar4 = HOST array of 4 DEVICE scalar pointers (NULL: not
+ * differentiated); outputs may be NULL. */
+int64_t sdfhip_surface_loss_workspace_floats(void);
+int sdfhip_surface_loss_forward(const float* rgb, const float* image, int64_t n_rays, const float* grad, const float* sdf, const float* taps,
+                                float delta, int64_t n_points, const float* n_pred, const float* n_gt, const float* scale4_host,
+                                float* workspace, float* loss4, sdfhip_stream_t stream);
+int sdfhip_surface_loss_backward(const float* rgb, const float* image, int64_t n_rays, const float* grad, const float* sdf, const float* taps,
+                                 float delta, int64_t n_points, const float* n_pred, const float* n_gt, const float* scale4_host,
+                                 const float* const* loss_bar4, float* rgb_bar, float* grad_bar, float* sdf_bar, float* taps_bar,
+                                 float* n_pred_bar, sdfhip_stream_t stream);
+
 /* interlevel_loss_zip (model_components/losses.py:116-172), the part per proposal level: the field histogram (c [n_rays, s+1]
  * spacing bins, w [n_rays, s] weights; both constants) blurred with half-width `radius` (0.03 / 0.003 for the two levels, :138)
  * and resampled at the proposal bins cp [n_rays, s_p+1]; against the proposal weights wp [n_rays, s_p]:

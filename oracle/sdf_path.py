@@ -769,6 +769,14 @@ def neus_facto_loss(out, image, cfg: ModelCfg) -> Dict[str, torch.Tensor]:
     }
 
 
+def monosdf_normal_loss(normal_pred: torch.Tensor, normal_gt: torch.Tensor) -> torch.Tensor:
+    """model_components/losses.py:264-275 (checker of the fused surface_losses operator; pinned on the reference's own function by the CPU suite): L1 + cosine between the rendered normal and the monocular normal prior."""
+    n_gt = F.normalize(normal_gt, p=2, dim=-1)
+    n_pr = F.normalize(normal_pred, p=2, dim=-1)
+    return torch.abs(n_pr - n_gt).sum(dim=-1).mean() + (1.0 - torch.sum(n_pr * n_gt, dim=-1)).mean()
+
+
+
 # ----------------------------------------------------------------------------- parameter init
 def init_field_params(cfg: FieldCfg, num_images: int = 49, seed: int = 0, dtype=torch.float32) -> Params:
     """Geometric init of fields/sdf_field.py:286-313, colour init :354-363, grid U(-1e-4,1e-4) (tcnn default)."""

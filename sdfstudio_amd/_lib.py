@@ -58,6 +58,15 @@ _SIGNATURES = {
     "sdfhip_field_packed_size": (c_i64, [ctypes.c_void_p]),
     "sdfhip_field_workspace_size": (c_i64, [ctypes.c_void_p, c_i64, c_i32]),
     "sdfhip_field_pack": (c_i32, [ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_void_p]),
+    "sdfhip_field_weightnorm_rows": (c_i64, [ctypes.c_void_p]),
+    "sdfhip_field_theta_from_weightnorm": (c_i32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_i32, c_float_p, c_float_p, ctypes.c_void_p]),
+    "sdfhip_field_theta_backward_weightnorm": (c_i32, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_i32, c_float_p, c_float_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), c_i32,
+                                                       ctypes.c_void_p]),
+    "sdfhip_surface_loss_workspace_floats": (c_i64, []),
+    "sdfhip_surface_loss_forward": (c_i32, [c_float_p, c_float_p, c_i64, c_float_p, c_float_p, c_float_p, c_f32, c_i64, c_float_p, c_float_p,
+                                            ctypes.POINTER(c_f32), c_float_p, c_float_p, ctypes.c_void_p]),
+    "sdfhip_surface_loss_backward": (c_i32, [c_float_p, c_float_p, c_i64, c_float_p, c_float_p, c_float_p, c_f32, c_i64, c_float_p, c_float_p,
+                                             ctypes.POINTER(c_f32), ctypes.POINTER(ctypes.c_void_p), c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
     "sdfhip_field_forward": (c_i32, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
                                      c_i64, c_i32, c_float_p, c_i32, c_i32, ctypes.c_void_p, c_float_p, c_float_p,
                                      c_float_p, c_float_p, ctypes.c_void_p]),
@@ -194,6 +203,15 @@ class Keep:
         t = t.contiguous()
         self._refs.append(t)
         return ptr(t)
+
+
+def ptr_array(tensors):
+    """HOST array of device pointers (NULL for None) for the entry points that take `const float* const*`; the tensors must stay
+    alive (and contiguous fp32 on the device) until the launch has been issued - keep them in a local."""
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else ptr(t)
+    return arr
 
 
 def stream():

@@ -14,6 +14,7 @@
 #include "packed_kernels.h"
 #include "volsdf_render_kernels.h"
 #include "grid_encode_kernels.h"
+#include "theta_kernels.h"
 
 const FieldKernels* sdfhip_kernels_A();
 const FieldKernels* sdfhip_kernels_B();
@@ -716,7 +717,8 @@ static void run_wgrad(const SdfHipField* f, const FieldWs& w, const WgradArgs& b
   r.b_off = b_off;
   r.accumulate = 0;
   const int total = r.rows * r.cols;
-  { ProfScope ps_(PS_WREDUCE, s); wreduce_kernel<<<(unsigned)((total + 63) / 64), 256, 0, s>>>(r); }
+  // 256 elements per block; the bias rows (64 per block) need ceil(rows / 64) blocks, which rows * cols / 256 covers for cols >= 4
+  { ProfScope ps_(PS_WREDUCE, s); wreduce_kernel<<<(unsigned)std::max((total + 255) / 256, (r.rows + 63) / 64), 256, 0, s>>>(r); }
 }
 
 static TpOperand seg1(const float* p, int nb, int xf) {
@@ -1410,6 +1412,117 @@ extern "C" int sdfhip_grid_cell_dump(const SdfHipGridCfg* grid, const float* x, 
   a.idx = idx;
   a.w = w;
   grid_cell_dump_kernel<<<dim3((unsigned)((n_points + 255) / 256), grid->n_levels), 256, 0, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- weight-normalised parameters -> theta (and back), scalar losses of the surface models (theta_kernels.h)
+static int fill_theta_layers(const SdfHipField* f, const float* const* v, const float* const* g, const float* const* b, int32_t n_lin,
+                             ThetaLayers* L) {
+  SDFHIP_REQUIRE(f && v && g && b, "weightnorm_theta: null argument");
+  SDFHIP_REQUIRE(n_lin == (int32_t)f->lin.size() && n_lin <= kThetaMaxLin, "weightnorm_theta: %d layers given, the field has %d (max %d)", n_lin,
+                 (int)f->lin.size(), kThetaMaxLin);
+  memset(L, 0, sizeof(*L));
+  L->n_lin = n_lin;
+  int rows = 0;
+  for (int l = 0; l < n_lin; ++l) {
+    SDFHIP_REQUIRE(v[l] && g[l] && b[l], "weightnorm_theta: null parameter pointer for layer %d", l);
+    L->row_start[l] = rows;
+    L->out_dim[l] = f->lin[l].out_dim;
+    L->in_dim[l] = f->lin[l].in_dim;
+    L->w_off[l] = f->lin[l].w_off;
+    L->b_off[l] = f->lin[l].b_off;
+    L->v[l] = v[l];
+    L->g[l] = g[l];
+    L->b[l] = b[l];
+    rows += f->lin[l].out_dim;
+  }
+  L->row_start[n_lin] = rows;
+  L->total_rows = rows;
+  return 0;
+}
+extern "C" int64_t sdfhip_field_weightnorm_rows(const SdfHipField* f) {
+  int64_t rows = 0;
+  for (const LinearInfo& li : f->lin) rows += li.out_dim;
+  return rows;
+}
+extern "C" int sdfhip_field_theta_from_weightnorm(const SdfHipField* f, const float* const* v, const float* const* g, const float* const* b,
+                                                  int32_t n_lin, float* theta, float* inv_norm, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(theta && inv_norm, "theta_from_weightnorm: null output");
+  ThetaLayers L;
+  const int rc = fill_theta_layers(f, v, g, b, n_lin, &L);
+  if (rc != 0) return rc;
+  weightnorm_theta_fwd_kernel<<<(unsigned)((L.total_rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(L, theta, inv_norm);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int sdfhip_field_theta_backward_weightnorm(const SdfHipField* f, const float* const* v, const float* const* g, const float* const* b,
+                                                      int32_t n_lin, const float* inv_norm, const float* theta_bar, float* const* v_bar,
+                                                      float* const* g_bar, float* const* b_bar, int32_t accumulate, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(theta_bar && inv_norm && v_bar && g_bar && b_bar, "theta_backward_weightnorm: null argument");
+  ThetaLayers L;
+  const int rc = fill_theta_layers(f, v, g, b, n_lin, &L);
+  if (rc != 0) return rc;
+  for (int l = 0; l < n_lin; ++l) {
+    L.v_bar[l] = v_bar[l];
+    L.g_bar[l] = g_bar[l];
+    L.b_bar[l] = b_bar[l];
+  }
+  weightnorm_theta_bwd_kernel<<<(unsigned)((L.total_rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(L, theta_bar, inv_norm, accumulate);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+static const int kSurfaceLossBlocks = 512;
+extern "C" int64_t sdfhip_surface_loss_workspace_floats(void) { return (int64_t)kSurfaceLossBlocks * SL_COUNT; }
+static void fill_surface_loss(SurfaceLossArgs* a, const float* rgb, const float* image, int64_t n_rays, const float* grad, const float* sdf,
+                              const float* taps, float delta, int64_t n_points, const float* n_pred, const float* n_gt, const float* scale4) {
+  memset(a, 0, sizeof(*a));
+  a->rgb = rgb;
+  a->image = image;
+  a->grad = grad;
+  a->sdf = sdf;
+  a->taps = taps;
+  a->n_pred = n_pred;
+  a->n_gt = n_gt;
+  a->n_rays = n_rays;
+  a->n_points = (grad || taps) ? n_points : 0;
+  a->inv_delta2 = taps ? 1.0f / (delta * delta) : 0.0f;
+  for (int k = 0; k < SL_COUNT; ++k) a->scale[k] = scale4[k];
+}
+extern "C" int sdfhip_surface_loss_forward(const float* rgb, const float* image, int64_t n_rays, const float* grad, const float* sdf,
+                                           const float* taps, float delta, int64_t n_points, const float* n_pred, const float* n_gt,
+                                           const float* scale4_host, float* workspace, float* loss4, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(rgb && image && scale4_host && workspace && loss4 && n_rays >= 1, "surface_loss_forward: bad argument");
+  SDFHIP_REQUIRE((taps == nullptr) == (sdf == nullptr) && (n_pred == nullptr) == (n_gt == nullptr), "surface_loss_forward: taps need sdf, n_pred needs n_gt");
+  SurfaceLossArgs a;
+  fill_surface_loss(&a, rgb, image, n_rays, grad, sdf, taps, delta, n_points, n_pred, n_gt, scale4_host);
+  const int64_t items = std::max<int64_t>(n_rays, a.n_points);
+  a.n_blocks = (int)std::min<int64_t>(kSurfaceLossBlocks, (items + 255) / 256);
+  a.partial = workspace;
+  a.loss = loss4;
+  surface_loss_partial_kernel<<<(unsigned)a.n_blocks, 256, 0, (hipStream_t)stream>>>(a);
+  surface_loss_finish_kernel<<<1, 64, 0, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int sdfhip_surface_loss_backward(const float* rgb, const float* image, int64_t n_rays, const float* grad, const float* sdf,
+                                            const float* taps, float delta, int64_t n_points, const float* n_pred, const float* n_gt,
+                                            const float* scale4_host, const float* const* loss_bar4, float* rgb_bar, float* grad_bar,
+                                            float* sdf_bar, float* taps_bar, float* n_pred_bar, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(rgb && image && scale4_host && loss_bar4 && n_rays >= 1, "surface_loss_backward: bad argument");
+  SDFHIP_REQUIRE((grad_bar == nullptr || grad) && (taps_bar == nullptr || (taps && sdf && sdf_bar)) && (n_pred_bar == nullptr || (n_pred && n_gt)),
+                 "surface_loss_backward: an output gradient was asked for without its input");
+  SurfaceLossArgs a;
+  fill_surface_loss(&a, rgb, image, n_rays, grad, sdf, taps, delta, n_points, n_pred, n_gt, scale4_host);
+  for (int k = 0; k < SL_COUNT; ++k) a.loss_bar[k] = loss_bar4[k];
+  a.rgb_bar = rgb_bar;
+  a.grad_bar = grad_bar;
+  a.sdf_bar = sdf_bar;
+  a.taps_bar = taps_bar;
+  a.n_pred_bar = n_pred_bar;
+  const int64_t items = std::max<int64_t>(n_rays, a.n_points);
+  surface_loss_bwd_kernel<<<(unsigned)std::min<int64_t>(4096, (items + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }

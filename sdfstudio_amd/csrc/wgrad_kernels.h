@@ -697,50 +697,58 @@ struct WreduceArgs {
   int64_t b_off;   // bias gradient destination (index by natural row), or -1
   int32_t accumulate;
 };
-// block = 256 threads = 64 consecutive elements x 4 interleaved split groups (each thread sums n_split / 4 partials, 8 loads
-// in flight), combined through LDS; grid = ceil(rows * cols / 64)
+// block = 256 threads = 64 x 4 consecutive elements (one 16-byte load per thread and split: a wave reads 1 KiB per instruction; with
+// 4-byte loads the kernel was bound by the latency of 256-byte requests, PMC: 83 % of its wave cycles parked) x 4 interleaved split
+// groups (each thread sums n_split / 4 partials, 8 loads in flight), combined through LDS; grid = ceil(rows * cols / 256)
 static __global__ __launch_bounds__(256) void wreduce_kernel(const WreduceArgs a) {
-  __shared__ float red[4][64];
+  __shared__ f32x4 red[4][64];
   const int ix = threadIdx.x & 63, sg = threadIdx.x >> 6;
-  const int total = a.rows * a.cols;
-  const int idx = blockIdx.x * 64 + ix;
-  float s = 0.0f;
+  const int total = a.rows * a.cols;  // a multiple of 1024 (both are multiples of 32)
+  const int idx = (blockIdx.x * 64 + ix) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (idx < total) {
     const float* p = a.partial + idx;
     int k = sg;
     for (; k + 28 < a.n_split; k += 32) {
-      float v[8];
+      f32x4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + 4 * u) * total];
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 4 * u) * total);
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += v[u];
     }
-    for (; k < a.n_split; k += 4) s += p[(size_t)k * total];
+    for (; k < a.n_split; k += 4) s += *reinterpret_cast<const f32x4*>(p + (size_t)k * total);
   }
   red[sg][ix] = s;
   __syncthreads();
   if (sg == 0 && idx < total) {
     s = (red[0][ix] + red[1][ix]) + (red[2][ix] + red[3][ix]);
-    const int o = idx / a.cols, i = idx % a.cols;
-    const int nr = a.rowmap[o], nc = a.colmap[i];
-    if (nr >= 0 && nc >= 0) {
-      float* dst = a.theta_bar + a.w_off + (int64_t)nr * a.ld + nc;
-      *dst = (a.accumulate ? *dst : 0.0f) + s * a.scale;
+    const int o = idx / a.cols, i0 = idx % a.cols;  // cols is a multiple of 4: the four elements share the row
+    const int nr = a.rowmap[o];
+    if (nr >= 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int nc = a.colmap[i0 + e];
+        if (nc >= 0) {
+          float* dst = a.theta_bar + a.w_off + (int64_t)nr * a.ld + nc;
+          *dst = (a.accumulate ? *dst : 0.0f) + s[e] * a.scale;
+        }
+      }
     }
   }
-  // bias gradients: rows elements, handled by the first ceil(rows / 64) blocks
+  // bias gradients: rows elements, 64 per block, handled by the first ceil(rows / 64) blocks
   if (a.bpartial != nullptr && a.b_off >= 0 && blockIdx.x * 64 < a.rows) {  // block-uniform condition (barriers inside)
+    const int row = blockIdx.x * 64 + ix;
     float t = 0.0f;
-    if (idx < a.rows)
-      for (int k = sg; k < a.n_split; k += 4) t += a.bpartial[(size_t)k * a.rows + idx];
+    if (row < a.rows)
+      for (int k = sg; k < a.n_split; k += 4) t += a.bpartial[(size_t)k * a.rows + row];
     __syncthreads();
-    red[sg][ix] = t;
+    red[sg][ix][0] = t;
     __syncthreads();
-    if (sg == 0 && idx < a.rows) {
-      const int nr = a.rowmap[idx];
+    if (sg == 0 && row < a.rows) {
+      const int nr = a.rowmap[row];
       if (nr >= 0) {
         float* dst = a.theta_bar + a.b_off + nr;
-        *dst = (a.accumulate ? *dst : 0.0f) + ((red[0][ix] + red[1][ix]) + (red[2][ix] + red[3][ix]));
+        *dst = (a.accumulate ? *dst : 0.0f) + ((red[0][ix][0] + red[1][ix][0]) + (red[2][ix][0] + red[3][ix][0]));
       }
     }
   }

@@ -28,6 +28,8 @@ from typing import Dict, Iterable, List, Optional, Sequence
 import torch
 import torch.distributed as dist
 
+from sdfstudio_amd.grad_slots import CLAIM_ATTR, SLOT_ATTR  # noqa: F401
+
 
 def _dist_on(group=None) -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
@@ -92,6 +94,9 @@ class FlatGradients:
     def _attach(self):
         for p in self.params:
             p.grad = self._view(p)
+            # native backward kernels write this parameter's gradient straight into its slice (grad_slots.py)
+            setattr(p, SLOT_ATTR, (lambda q=p: self._view(q)))
+            setattr(p, CLAIM_ATTR, False)
 
     def _is_view(self, p) -> bool:
         return p.grad is not None and p.grad.data_ptr() == self.flat.data_ptr() + 4 * self._offset[id(p)]
@@ -105,8 +110,10 @@ class FlatGradients:
             raise RuntimeError("FlatGradients.zero() while all-reduces of the previous backward are in flight: call finish() first")
         self.flat.zero_()
         for p in self.params:
-            if not self._is_view(p):
-                p.grad = self._view(p)
+            # None, not a view: AccumulateGrad then ADOPTS the first incoming gradient instead of adding it into .grad - and the native
+            # backward kernels hand it a view of this buffer they have already written (grad_slots.py): no launch per parameter
+            p.grad = None
+            setattr(p, CLAIM_ATTR, False)
         self._arm()
 
     zero_grad = zero
@@ -178,9 +185,12 @@ class FlatGradients:
             raise RuntimeError("FlatGradients: a second backward reached a parameter before finish() - its bucket may already be "
                                "in flight (accumulate micro-batches into one loss, or call finish() / zero() between backwards)")
         if not self._is_view(p):
-            # autograd allocated a fresh gradient (someone set .grad = None after zero()): fold it in before the bucket can leave
+            # AccumulateGrad runs once per leaf and backward with the SUM of everything that reached the parameter.  It adopted an
+            # ordinary tensor: a torch op produced the gradient, or several producers did and the engine summed them out of place (a
+            # native kernel's slice is then one of the summands, already inside this total), or it cloned the view it was handed.
+            # In every case p.grad is the whole gradient of this pass: it REPLACES the slice.
             v = self._view(p)
-            v.add_(p.grad)
+            v.copy_(p.grad)
             p.grad = v
         if self._overlap:
             self._launch_ready(from_hook=True)
@@ -195,7 +205,7 @@ class FlatGradients:
         for p in self.params:
             if not self._is_view(p):
                 if p.grad is None:
-                    p.grad = self._view(p)
+                    p.grad = self._view(p)  # unused in this step: its gradient is the zeros zero() left
                     continue
                 if self._launched[self._bucket_of[id(p)]]:
                     raise RuntimeError("FlatGradients: a gradient outside the flat buffer appeared after its bucket was launched")

@@ -13,6 +13,7 @@ from torch import nn
 
 from sdfstudio_amd import _lib
 from sdfstudio_amd.cameras.rays import unpack_ray_samples
+from sdfstudio_amd.grad_slots import grad_target
 
 
 class _ProposalDensity(torch.autograd.Function):
@@ -31,6 +32,7 @@ class _ProposalDensity(torch.autograd.Function):
                                                int(contract), _lib.ptr(density), _lib.stream()), "proposal_forward")
         ctx.save_for_backward(table, w1, w2, origins, dirs, starts, ends)
         ctx.grid_cfg, ctx.contract, ctx.shape = grid_cfg, int(contract), (n, s)
+        ctx.param_objs = (table, w1, w2)  # the Parameters themselves: their gradient slots (grad_slots.py) are looked up in backward
         return density
 
     @staticmethod
@@ -42,9 +44,10 @@ class _ProposalDensity(torch.autograd.Function):
         n, s = ctx.shape
         dev = table.device
         ws = torch.empty(lib.sdfhip_proposal_workspace_size(), dtype=torch.uint8, device=dev)
-        table_bar = torch.zeros_like(table)
-        w1_bar = torch.empty_like(w1)
-        w2_bar = torch.empty_like(w2)
+        # straight into the flat gradient buffer when a FlatGradients owns it (the table gradient is accumulated into: zero start)
+        table_bar = grad_target(ctx.param_objs[0], zero_init=True)[0]
+        w1_bar = grad_target(ctx.param_objs[1])[0]
+        w2_bar = grad_target(ctx.param_objs[2])[0]
         kp = _lib.Keep()
         _lib.check(lib.sdfhip_proposal_backward(ctypes.byref(ctx.grid_cfg), _lib.ptr(table), _lib.ptr(w1), _lib.ptr(w2),
                                                 _lib.ptr(origins), _lib.ptr(dirs), _lib.ptr(starts), _lib.ptr(ends), n, s,

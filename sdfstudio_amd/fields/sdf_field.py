@@ -18,6 +18,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from sdfstudio_amd import _lib
+from sdfstudio_amd.grad_slots import grad_target
 from sdfstudio_amd.cameras.rays import unpack_ray_samples
 from sdfstudio_amd.fields.field_heads import FieldHeadNames
 
@@ -128,6 +129,42 @@ def _contig(t):
     return None if t is None else t.contiguous()
 
 
+class _ThetaFunction(torch.autograd.Function):
+    """weight_v / weight_g / bias of every Linear -> the flat parameter vector theta of the native layout, W = g v / ||v|| per row
+    (nn.utils.weight_norm, sdf_field.py:314-317, 362), as ONE launch; backward: ONE launch producing every (v_bar, g_bar, bias_bar),
+    written straight into the parameters' gradient slots when a FlatGradients owns them (grad_slots.py) - the reference's
+    per-layer torch._weight_norm + cat cost 14 + 14 + 1 launches and three AccumulateGrad adds per layer and step."""
+
+    @staticmethod
+    def forward(ctx, fld, *params):
+        lib = _lib.load()
+        h = fld._handle
+        n_lin = len(params) // 3
+        dev = params[0].device
+        theta = torch.empty(lib.sdfhip_field_theta_size(h), device=dev)
+        inv_norm = torch.empty(lib.sdfhip_field_weightnorm_rows(h), device=dev)
+        flat = [t.detach().contiguous() for t in params]  # bound to a local until the launch has been issued
+        _lib.check(lib.sdfhip_field_theta_from_weightnorm(h, _lib.ptr_array(flat[0::3]), _lib.ptr_array(flat[1::3]), _lib.ptr_array(flat[2::3]),
+                                                          n_lin, _lib.ptr(theta), _lib.ptr(inv_norm), _lib.stream()), "theta_from_weightnorm")
+        ctx.save_for_backward(inv_norm, *flat)
+        ctx.fld, ctx.params = fld, params  # the Parameter objects themselves: their gradient slots are looked up in backward
+        return theta
+
+    @staticmethod
+    def backward(ctx, theta_bar):
+        inv_norm, *flat = ctx.saved_tensors
+        lib = _lib.load()
+        n_lin = len(flat) // 3
+        outs = [grad_target(p)[0] if ctx.needs_input_grad[1 + i] else None for i, p in enumerate(ctx.params)]
+        theta_bar_c = theta_bar.contiguous()
+        _lib.check(lib.sdfhip_field_theta_backward_weightnorm(
+            ctx.fld._handle, _lib.ptr_array(flat[0::3]), _lib.ptr_array(flat[1::3]), _lib.ptr_array(flat[2::3]), n_lin, _lib.ptr(inv_norm),
+            _lib.ptr(theta_bar_c), _lib.ptr_array(outs[0::3]), _lib.ptr_array(outs[1::3]), _lib.ptr_array(outs[2::3]), 0, _lib.stream()),
+            "theta_backward_weightnorm")
+        del theta_bar_c
+        return (None, *outs)
+
+
 class _FieldFunction(torch.autograd.Function):
     """One autograd node for the whole field: (theta, table[, emb]) -> (sdf, d sdf/dx, rgb, contracted x)."""
 
@@ -157,7 +194,7 @@ class _FieldFunction(torch.autograd.Function):
         x = ws[: NP * 12].view(torch.float32).view(NP, 3)[:P].view(n, s, 3)  # contracted positions live first in the workspace
         if train:
             ctx.save_for_backward(packed, table, mask, ws)
-            ctx.fld, ctx.shape, ctx.has_emb = fld, (n, s), emb is not None
+            ctx.fld, ctx.shape, ctx.has_emb, ctx.table_param = fld, (n, s), emb is not None, table
         else:
             x = x.clone()  # lets the workspace go
         ctx.mark_non_differentiable(x)
@@ -172,7 +209,9 @@ class _FieldFunction(torch.autograd.Function):
         dev = packed.device
         h = fld._handle
         theta_bar = torch.empty(lib.sdfhip_field_theta_size(h), device=dev)
-        table_bar = torch.zeros_like(table)
+        # the scatter kernel ACCUMULATES into the table gradient: straight into the (zeroed) slice of the flat gradient buffer when
+        # there is one (no 49 MB fill, no 49 MB AccumulateGrad add), else into a fresh zero tensor
+        table_bar = grad_target(ctx.table_param, zero_init=True)[0].view(-1)
         emb_bar = torch.zeros(n, fld.config.appearance_embedding_dim, device=dev) if ctx.has_emb else None
 
         # incoming cotangents may be stride-0 expands (e.g. from .sum()): materialise them into locals that outlive the call, a
@@ -205,7 +244,7 @@ class _GeoNetFunction(torch.autograd.Function):
         _lib.check(lib.sdfhip_geo_forward(h, _lib.ptr(packed), _lib.ptr(table), _lib.ptr(mask), _lib.ptr(positions), P,
                                           ctypes.c_void_p(ws.data_ptr()), _lib.ptr(sdf), _lib.ptr(feat), _lib.stream()), "geo_forward")
         ctx.save_for_backward(packed, table, mask, ws)
-        ctx.fld, ctx.P = fld, P
+        ctx.fld, ctx.P, ctx.table_param = fld, P, table
         return sdf[:P], feat
 
     @staticmethod
@@ -214,7 +253,7 @@ class _GeoNetFunction(torch.autograd.Function):
         lib = _lib.load()
         h = ctx.fld._handle
         theta_bar = torch.zeros(lib.sdfhip_field_theta_size(h), device=packed.device)  # colour entries stay zero
-        table_bar = torch.zeros_like(table)
+        table_bar = grad_target(ctx.table_param, zero_init=True)[0].view(-1)  # accumulated into; the flat gradient slice when there is one
 
         sdf_bar_c, feat_bar_c = _contig(sdf_bar), _contig(feat_bar)
         _lib.check(lib.sdfhip_geo_backward(h, _lib.ptr(packed), _lib.ptr(mask), ctx.P, ctypes.c_void_p(ws.data_ptr()),
@@ -399,10 +438,14 @@ class SDFField(nn.Module):
                 pass
 
     def _theta(self) -> torch.Tensor:
-        """Flat effective parameter vector in the ABI's layout: per linear layer W = g * v / ||v|| (weight_norm, dim 0), b."""
+        """Flat effective parameter vector in the ABI's layout: per linear layer W = g * v / ||v|| (weight_norm, dim 0), b - one native
+        launch (and one for its backward).  On CPU tensors (host-side inspection of the layout only: no kernel takes them) the same
+        vector is assembled with torch ops."""
+        lins = [getattr(self, name) for name in self._lin_names]
+        if lins[0].weight_v.is_cuda:
+            return _ThetaFunction.apply(self, *[t for lin in lins for t in (lin.weight_v, lin.weight_g, lin.bias)])
         parts = []
-        for name in self._lin_names:
-            lin = getattr(self, name)
+        for lin in lins:
             parts.append(torch._weight_norm(lin.weight_v, lin.weight_g, 0).reshape(-1))
             parts.append(lin.bias)
         return torch.cat(parts)

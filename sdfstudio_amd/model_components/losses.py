@@ -4,14 +4,87 @@ interlevel_loss_zip restates nerfstudio/model_components/losses.py:116-172 (Zip-
 ``[N,S+1]`` spacing-domain bins.  Only the proposal weights carry gradient (the field's weights are detached, :134).
 Each proposal level is ONE kernel launch (sdfhip_interlevel_terms: one wavefront per ray, the blurred histogram built by
 merging the two sorted knot sequences instead of sorting them) plus a mean; the reference's formulation (sort, gathers, cumsums,
-searchsorted: ~40 launches) lives in oracle/sdf_path.py as the checker.  There is no CPU path: CPU tensors raise.  The mono-prior
-losses are small torch reductions over rendered per-ray outputs.
+searchsorted: ~40 launches) lives in oracle/sdf_path.py as the checker.  There is no CPU path: CPU tensors raise.
+
+surface_losses: the scalar losses behind the renderer - L1 colour (base_surface_model.py:402), eikonal (:406), curvature
+(neus_facto.py:313-325), MonoSDF normal (losses.py:264-275) - as one fused operator: two launches forward (per-block partial sums,
+deterministic finish), one elementwise launch backward (sdfhip_surface_loss_forward / _backward), instead of ~25 reductions and
+elementwise launches.  The MonoSDF scale-and-shift depth loss (a 2 x 2 least-squares fit + multi-scale gradient matching on the
+ray batch viewed as an image, losses.py:278-409) stays a handful of torch reductions: it is off in BASELINE configs 1 - 3 and 5.
 """
-from typing import List
+import ctypes
+from typing import Dict, List, Optional
 
 import torch
 
 from sdfstudio_amd import _lib
+
+
+class _SurfaceLosses(torch.autograd.Function):
+    """(rgb, eik_grad, sdf, taps, n_pred) -> (rgb_loss, eikonal_loss, curvature_loss, normal_loss), each already multiplied by its
+    weight; absent inputs are None and their loss is 0."""
+
+    @staticmethod
+    def forward(ctx, rgb, grad, sdf, taps, n_pred, image, n_gt, delta, mults):
+        lib = _lib.load()
+        if not rgb.is_cuda:
+            raise _lib.SdfHipError("surface_losses runs on the sdfhip kernels: HIP device tensors required (no CPU fallback)")
+        dev = rgb.device
+        n = rgb.shape[0]
+        P = grad.numel() // 3 if grad is not None else (sdf.numel() if sdf is not None else 0)
+        scale = (ctypes.c_float * 4)(mults[0] / (3.0 * n), (mults[1] / P) if grad is not None else 0.0,
+                                     (mults[2] / (3.0 * P)) if taps is not None else 0.0, (mults[3] / n) if n_pred is not None else 0.0)
+        kp = _lib.Keep()
+        ws = torch.empty(lib.sdfhip_surface_loss_workspace_floats(), device=dev)
+        loss4 = torch.empty(4, device=dev)
+        args = (kp(rgb.detach().float()), kp(image.float()), n, kp(None if grad is None else grad.detach()), kp(None if sdf is None else sdf.detach()),
+                kp(None if taps is None else taps.detach()), float(delta), P, kp(None if n_pred is None else n_pred.detach()),
+                kp(None if n_gt is None else n_gt.float()))
+        _lib.check(lib.sdfhip_surface_loss_forward(*args, scale, _lib.ptr(ws), _lib.ptr(loss4), _lib.stream()), "surface_loss_forward")
+        ctx.kp, ctx.args, ctx.scale = kp, args, scale  # the marshalled inputs stay alive for the backward
+        ctx.shapes = (rgb.shape, None if grad is None else grad.shape, None if sdf is None else sdf.shape, None if taps is None else taps.shape,
+                      None if n_pred is None else n_pred.shape)
+        return loss4[0:1].view(()), loss4[1:2].view(()), loss4[2:3].view(()), loss4[3:4].view(())
+
+    @staticmethod
+    def backward(ctx, *lbar):
+        lib = _lib.load()
+        dev = lbar[0].device if lbar[0] is not None else next(t for t in lbar if t is not None).device
+        shp = ctx.shapes
+        need = ctx.needs_input_grad
+        lb = [None if t is None else t.contiguous().float() for t in lbar]
+        outs = [torch.empty(shp[i], device=dev) if (shp[i] is not None and need[i]) else None for i in range(5)]
+        if outs[2] is None and outs[3] is not None:  # the curvature stencil differentiates sdf and taps together
+            outs[2] = torch.empty(shp[2], device=dev)
+        _lib.check(lib.sdfhip_surface_loss_backward(*ctx.args, ctx.scale, _lib.ptr_array(lb), _lib.ptr(outs[0]), _lib.ptr(outs[1]),
+                                                    _lib.ptr(outs[2]) if outs[3] is not None else None, _lib.ptr(outs[3]), _lib.ptr(outs[4]),
+                                                    _lib.stream()), "surface_loss_backward")
+        del lb
+        if outs[3] is None:
+            outs[2] = None
+        return outs[0], outs[1], outs[2] if need[2] else None, outs[3], outs[4], None, None, None, None
+
+
+def surface_losses(rgb: torch.Tensor, image: torch.Tensor, eik_grad: Optional[torch.Tensor] = None, eikonal_mult: float = 0.0,
+                   sdf: Optional[torch.Tensor] = None, sampled_sdf: Optional[torch.Tensor] = None, delta: float = 1.0, curvature_mult: float = 0.0,
+                   normal_pred: Optional[torch.Tensor] = None, normal_gt: Optional[torch.Tensor] = None, normal_mult: float = 0.0) -> Dict[str, torch.Tensor]:
+    """The fused scalar losses of SurfaceModel.get_loss_dict (base_surface_model.py:399-424, neus_facto.py:312-325).  rgb / image
+    [N,3]; eik_grad [N,S,3]; sdf [N,S,1] + sampled_sdf [N,S,6] (numerical-gradient taps); normal_pred / normal_gt [N,3].  Returns
+    the entries that are switched on, multiplied by their weights: rgb_loss always, eikonal_loss / curvature_loss / normal_loss."""
+    use_curv = sampled_sdf is not None and curvature_mult > 0.0
+    use_nrm = normal_pred is not None and normal_mult > 0.0
+    l_rgb, l_eik, l_cur, l_nrm = _SurfaceLosses.apply(
+        rgb.contiguous(), None if eik_grad is None else eik_grad.contiguous(), sdf.contiguous() if use_curv else None,
+        sampled_sdf.contiguous() if use_curv else None, normal_pred.contiguous() if use_nrm else None, image, normal_gt if use_nrm else None,
+        delta, (1.0, eikonal_mult, curvature_mult, normal_mult))
+    out = {"rgb_loss": l_rgb}
+    if eik_grad is not None:
+        out["eikonal_loss"] = l_eik
+    if use_curv:
+        out["curvature_loss"] = l_cur
+    if use_nrm:
+        out["normal_loss"] = l_nrm
+    return out
 
 
 class _InterlevelLevel(torch.autograd.Function):
@@ -45,13 +118,6 @@ def interlevel_loss_zip(weights_list: List[torch.Tensor], bins_list: List[torch.
     for cp, wp, radius in zip(bins_list[:-1], weights_list[:-1], (0.03, 0.003)):
         total = total + _InterlevelLevel.apply(wp, c, w, cp.detach(), radius)
     return total
-
-
-def monosdf_normal_loss(normal_pred: torch.Tensor, normal_gt: torch.Tensor) -> torch.Tensor:
-    """losses.py:264-275: L1 + cosine between the rendered normal and the monocular normal prior."""
-    n_gt = torch.nn.functional.normalize(normal_gt, p=2, dim=-1)
-    n_pr = torch.nn.functional.normalize(normal_pred, p=2, dim=-1)
-    return torch.abs(n_pr - n_gt).sum(dim=-1).mean() + (1.0 - torch.sum(n_pr * n_gt, dim=-1)).mean()
 
 
 def scale_and_shift_invariant_loss(prediction: torch.Tensor, target: torch.Tensor, mask: torch.Tensor, alpha: float = 0.5,

