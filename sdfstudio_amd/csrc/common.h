@@ -47,27 +47,30 @@ SDFHIP_D void static_for(F&& f) {
 // log(1 + e) is formed as log2(1 + e) ln2: for tiny e the rounding of 1 + e bounds the ABSOLUTE error of h by 6e-10, far
 // below the fp32 resolution of the next layer's accumulation.  A libm expf + log1pf + IEEE division here costs ~150 VALU
 // instructions per element and made the fused kernels instruction-fetch bound (profiles/r1_notes.md).
+// The exponent's argument is NOT clamped: for t > 20 the linear branch is selected and whatever the other branch holds (inf, or
+// inf * 0 = NaN in the derivative) is discarded by the select; z * (100 log2 e) is one multiply and the threshold test is on z
+// itself (t > 20 <=> z > 0.2): two VALU instructions fewer per element than "t = 100 z; min(t, 20) * log2 e" in the producers of
+// the fused kernels, which are VALU-bound in the forward launch.
+constexpr float kSp100Log2e = 144.269504088896340736f;  // 100 / ln 2
+constexpr float kSp100Thr = 0.2f;                       // threshold 20 / beta 100
 SDFHIP_D void softplus100(float z, float& h, float& d1) {
-  const float t = 100.0f * z;
-  const float e = __builtin_amdgcn_exp2f(fminf(t, 20.0f) * 1.44269504088896340736f);
+  const float e = __builtin_amdgcn_exp2f(z * kSp100Log2e);
   const float u = 1.0f + e;
   const float hs = __builtin_amdgcn_logf(u) * (0.69314718055994530942f * 0.01f);
   const float ds = e * __builtin_amdgcn_rcpf(u);
-  const bool lin = t > 20.0f;
+  const bool lin = z > kSp100Thr;
   h = lin ? z : hs;
   d1 = lin ? 1.0f : ds;
 }
 SDFHIP_D float softplus100_d1(float z) {
-  const float t = 100.0f * z;
-  const float e = __builtin_amdgcn_exp2f(fminf(t, 20.0f) * 1.44269504088896340736f);
+  const float e = __builtin_amdgcn_exp2f(z * kSp100Log2e);
   const float ds = e * __builtin_amdgcn_rcpf(1.0f + e);
-  return t > 20.0f ? 1.0f : ds;
+  return z > kSp100Thr ? 1.0f : ds;
 }
 SDFHIP_D float softplus100_h(float z) {
-  const float t = 100.0f * z;
-  const float e = __builtin_amdgcn_exp2f(fminf(t, 20.0f) * 1.44269504088896340736f);
+  const float e = __builtin_amdgcn_exp2f(z * kSp100Log2e);
   const float hs = __builtin_amdgcn_logf(1.0f + e) * (0.69314718055994530942f * 0.01f);
-  return t > 20.0f ? z : hs;
+  return z > kSp100Thr ? z : hs;
 }
 
 // Hidden activation of a fused geometry-type network, selected at compile time by the network's dims class (GeoDims::ACT):

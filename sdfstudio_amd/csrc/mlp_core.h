@@ -92,6 +92,7 @@ struct WStream {
 template <int NS>
 struct SplitBlk {
   bf16x8 p[ns_parts(NS)][2];
+  float pend;  // the even element of a pair, waiting for its odd neighbour (split_put converts element pairs with packed conversions)
 };
 // one product term of mode NS: acc += A * B
 template <int NS>
@@ -160,20 +161,41 @@ constexpr int gemm_group(const int nbo, const int ns) {
   return nbo <= 5 ? nbo : 1;
 }
 
-// element e (TP register index) of a block under construction -> its slot in the split operand
+// element e (TP register index) of a block under construction -> its slot in the split operand.  Elements arrive in order
+// e = 0 .. 15; an even element waits in `pend` and is converted TOGETHER with its odd neighbour: the two share one dword of the
+// operand vector, so hi and lo parts are one packed conversion each (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32, round to nearest even
+// like the scalar conversions: same numbers) instead of two scalar conversions and a pack apiece.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 template <int NS, int E>
 SDFHIP_D void split_put(SplitBlk<NS>& s, float r) {
-  if constexpr (NS == 4) {
-    r = __builtin_amdgcn_fmed3f(r, -65504.0f, 65504.0f);  // fp16 has no exponent headroom: saturate instead of inf
-    const _Float16 h = (_Float16)r;
-    s.p[0][E >> 3][E & 7] = __builtin_bit_cast(__bf16, h);
-    s.p[1][E >> 3][E & 7] = __builtin_bit_cast(__bf16, (_Float16)(r - (float)h));
+  if constexpr (NS == 4) r = __builtin_amdgcn_fmed3f(r, -65504.0f, 65504.0f);  // fp16 has no exponent headroom: saturate instead of inf
+  if constexpr ((E & 1) == 0) {
+    s.pend = r;
   } else {
+    constexpr int kk = E >> 3, j = (E & 7) - 1;
+    f32x2_t v = {s.pend, r};
+    // the pair (j, j + 1), j even, is dword j / 2 of the 8-element operand vector: the packed conversion's result goes in whole
+    // (element-wise _Float16 -> __bf16 bit casts of the pair miscompile on this toolchain: tools/probe_splitput.hip)
+    auto put = [&](bf16x8& dst, const uint32_t w) __attribute__((always_inline)) {
+      u32x4_t t = __builtin_bit_cast(u32x4_t, dst);
+      t[j >> 1] = w;
+      dst = __builtin_bit_cast(bf16x8, t);
+    };
+    if constexpr (NS == 4) {
+      const f16x2_t h = __builtin_convertvector(v, f16x2_t);
+      const f16x2_t l = __builtin_convertvector(v - __builtin_convertvector(h, f32x2_t), f16x2_t);
+      put(s.p[0][kk], __builtin_bit_cast(uint32_t, h));
+      put(s.p[1][kk], __builtin_bit_cast(uint32_t, l));
+    } else {
 #pragma unroll
-    for (int q = 0; q < NS; ++q) {
-      const __bf16 h = (__bf16)r;
-      s.p[q][E >> 3][E & 7] = h;
-      if (q + 1 < NS) r -= (float)h;
+      for (int q = 0; q < NS; ++q) {
+        const bf16x2_t h = __builtin_convertvector(v, bf16x2_t);
+        put(s.p[q][kk], __builtin_bit_cast(uint32_t, h));
+        if (q + 1 < NS) v -= __builtin_convertvector(h, f32x2_t);
+      }
     }
   }
 }

@@ -644,8 +644,11 @@ def _check_field_grads(model, po, rtol=1e-3, truth=None, min_checked=28):
         else:
             # ReLU / clip masks make the gradient piecewise: one unit flipping at one point is a discrete jump, so the
             # bar is max(3 x the fp32 oracle's own distance from fp64, rtol x scale)
-            assert_fp32_class(f"grad {k}", got[k], ref.grad, truth[k].grad, factor=3.0,
-                              atol=rtol * truth[k].grad.abs().max().item())
+            # colour network: a single ReLU unit whose pre-activation the two fp32 evaluations put on opposite sides of zero moves one
+            # row of a clin* gradient by a discrete amount (helpers.relu_flip_basis; up to ~1e-2 of the maximum at 8192 samples, see
+            # test_full_shape_training_step_against_oracle): 5e-3 of the maximum for those tensors
+            rt = max(rtol, 5e-3) if k.startswith("clin") else rtol
+            assert_fp32_class(f"grad {k}", got[k], ref.grad, truth[k].grad, factor=3.0, atol=rt * truth[k].grad.abs().max().item())
         checked += 1
     assert checked >= min_checked
 
