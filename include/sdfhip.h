@@ -158,6 +158,14 @@ int sdfhip_geo_forward(const SdfHipField* f, const float* packed, const float* t
  * are overwritten (the colour-network entries are left untouched: the caller zeroes the vector); table_bar is accumulated into. */
 int sdfhip_geo_backward(const SdfHipField* f, const float* packed, const float* level_mask, int64_t n_points, void* workspace,
                         const float* sdf_bar, const float* feat_bar, float* theta_bar, float* table_bar, sdfhip_stream_t stream);
+/* The same pair when only the first n_feat_points points' geometry feature is taken (feat [n_feat_points, geo_feat_dim], feat_bar
+ * likewise; the rest contribute through sdf only): the numerical-gradient branch (sdf_field.py:433-453, 639-644) evaluates 7 P points
+ * and uses the feature of the P centre points - no layout conversion of the other 6 P x geo_feat_dim values in either direction. */
+int sdfhip_geo_forward_n(const SdfHipField* f, const float* packed, const float* table, const float* level_mask, const float* positions,
+                         int64_t n_points, int64_t n_feat_points, void* workspace, float* sdf, float* feat, sdfhip_stream_t stream);
+int sdfhip_geo_backward_n(const SdfHipField* f, const float* packed, const float* level_mask, int64_t n_points, void* workspace,
+                          int64_t n_feat_points, const float* sdf_bar, const float* feat_bar, float* theta_bar, float* table_bar,
+                          sdfhip_stream_t stream);
 
 /* Colour network as its own operator: SDFField.get_colors (sdf_field.py:532-612, ref-nerf options off) with every input supplied
  * by the caller - the numerical-gradient path (sdf_field.py:639-644) feeds it the finite-difference d sdf / dx.

@@ -867,10 +867,11 @@ __global__ void pad_copy_kernel(const float* __restrict__ in, const int64_t n, c
   if (i < n_padded) out[i] = (in != nullptr && i < n) ? in[i] : 0.0f;
 }
 
-extern "C" int sdfhip_geo_forward(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
-                                  const float* positions, int64_t n_points, void* workspace, float* sdf, float* feat,
-                                  sdfhip_stream_t stream) {
+extern "C" int sdfhip_geo_forward_n(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
+                                    const float* positions, int64_t n_points, int64_t n_feat_points, void* workspace, float* sdf,
+                                    float* feat, sdfhip_stream_t stream) {
   SDFHIP_REQUIRE(f && packed && table && level_mask && positions && workspace && sdf, "geo_forward: null argument");
+  SDFHIP_REQUIRE(n_feat_points >= 0 && n_feat_points <= n_points, "geo_forward: n_feat_points out of range");
   if (n_points == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const FieldKernels* k = f->k;
@@ -900,18 +901,24 @@ extern "C" int sdfhip_geo_forward(const SdfHipField* f, const float* packed, con
   ga.feat_tp = w.feat;
   ga.sdf = sdf;
   { ProfScope ps_(PS_GEO_FWD, s); k->geo_fwd(3, ga, (unsigned)(NP / 128), s); }
-  if (feat != nullptr) {
-    const int64_t total = P * f->cfg.geo_feat_dim;
-    untp_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(w.feat, k->nbf, f->cfg.geo_feat_dim, P, feat);
+  if (feat != nullptr && n_feat_points > 0) {
+    const int64_t total = n_feat_points * f->cfg.geo_feat_dim;
+    untp_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(w.feat, k->nbf, f->cfg.geo_feat_dim, n_feat_points, feat);
   }
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }
+extern "C" int sdfhip_geo_forward(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
+                                  const float* positions, int64_t n_points, void* workspace, float* sdf, float* feat,
+                                  sdfhip_stream_t stream) {
+  return sdfhip_geo_forward_n(f, packed, table, level_mask, positions, n_points, n_points, workspace, sdf, feat, stream);
+}
 
-extern "C" int sdfhip_geo_backward(const SdfHipField* f, const float* packed, const float* level_mask, int64_t n_points, void* workspace,
-                                   const float* sdf_bar, const float* feat_bar, float* theta_bar, float* table_bar,
+extern "C" int sdfhip_geo_backward_n(const SdfHipField* f, const float* packed, const float* level_mask, int64_t n_points, void* workspace,
+                                     int64_t n_feat_points, const float* sdf_bar, const float* feat_bar, float* theta_bar, float* table_bar,
                                    sdfhip_stream_t stream) {
   SDFHIP_REQUIRE(f && packed && level_mask && workspace && theta_bar && table_bar, "geo_backward: null argument");
+  SDFHIP_REQUIRE(n_feat_points >= 0 && n_feat_points <= n_points, "geo_backward: n_feat_points out of range");
   if (n_points == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const FieldKernels* k = f->k;
@@ -921,7 +928,8 @@ extern "C" int sdfhip_geo_backward(const SdfHipField* f, const float* packed, co
   const unsigned pg = (unsigned)((NP + 255) / 256);
   pad_copy_kernel<<<pg, 256, 0, s>>>(sdf_bar, P, NP, w.sdfbar);
   const int64_t fw = NP * k->nbf * 32;
-  totp_kernel<<<(unsigned)((fw + 255) / 256), 256, 0, s>>>(feat_bar, k->nbf, f->cfg.geo_feat_dim, P, NP, w.featbar);
+  // rows >= n_feat_points (points whose feature the caller never took: the six taps of the numerical gradient) get zeros
+  totp_kernel<<<(unsigned)((fw + 255) / 256), 256, 0, s>>>(feat_bar, k->nbf, f->cfg.geo_feat_dim, n_feat_points, NP, w.featbar);
 
   GeoBwdArgs gb;
   memset(&gb, 0, sizeof(gb));
@@ -953,6 +961,12 @@ extern "C" int sdfhip_geo_backward(const SdfHipField* f, const float* packed, co
   run_geo_wgrads(f, w, false, NP / 32, theta_bar, s);
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+extern "C" int sdfhip_geo_backward(const SdfHipField* f, const float* packed, const float* level_mask, int64_t n_points, void* workspace,
+                                   const float* sdf_bar, const float* feat_bar, float* theta_bar, float* table_bar,
+                                   sdfhip_stream_t stream) {
+  return sdfhip_geo_backward_n(f, packed, level_mask, n_points, workspace, n_points, sdf_bar, feat_bar, theta_bar, table_bar, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ colour network as its own operator

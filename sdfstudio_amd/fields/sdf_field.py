@@ -229,10 +229,13 @@ class _GeoNetFunction(torch.autograd.Function):
     """forward_geonetwork under autograd (first order): (theta, table) -> (sdf [P], geometry feature [P, F]) at explicit positions."""
 
     @staticmethod
-    def forward(ctx, theta, table, fld, positions, mask):
+    def forward(ctx, theta, table, fld, positions, mask, n_feat=None):
+        """n_feat: the geometry feature is returned for the first n_feat points only (default: all) - the numerical-gradient branch
+        evaluates the six taps for their sdf alone."""
         lib = _lib.load()
         dev = theta.device
         P = positions.shape[0]
+        n_feat = P if n_feat is None else int(n_feat)
         NP = _lib.padded_points(P)
         h = fld._handle
         packed = torch.empty(lib.sdfhip_field_packed_size(h), device=dev)
@@ -240,11 +243,11 @@ class _GeoNetFunction(torch.autograd.Function):
         _lib.check(lib.sdfhip_field_pack(h, _lib.ptr(theta_c), _lib.ptr(packed), _lib.stream()), "field_pack")
         ws = torch.empty(lib.sdfhip_geo_workspace_size(h, P), dtype=torch.uint8, device=dev)
         sdf = torch.empty(NP, device=dev)
-        feat = torch.empty(P, fld.config.geo_feat_dim, device=dev)
-        _lib.check(lib.sdfhip_geo_forward(h, _lib.ptr(packed), _lib.ptr(table), _lib.ptr(mask), _lib.ptr(positions), P,
-                                          ctypes.c_void_p(ws.data_ptr()), _lib.ptr(sdf), _lib.ptr(feat), _lib.stream()), "geo_forward")
+        feat = torch.empty(n_feat, fld.config.geo_feat_dim, device=dev)
+        _lib.check(lib.sdfhip_geo_forward_n(h, _lib.ptr(packed), _lib.ptr(table), _lib.ptr(mask), _lib.ptr(positions), P, n_feat,
+                                            ctypes.c_void_p(ws.data_ptr()), _lib.ptr(sdf), _lib.ptr(feat), _lib.stream()), "geo_forward")
         ctx.save_for_backward(packed, table, mask, ws)
-        ctx.fld, ctx.P, ctx.table_param = fld, P, table
+        ctx.fld, ctx.P, ctx.table_param, ctx.n_feat = fld, P, table, n_feat
         return sdf[:P], feat
 
     @staticmethod
@@ -256,11 +259,11 @@ class _GeoNetFunction(torch.autograd.Function):
         table_bar = grad_target(ctx.table_param, zero_init=True)[0].view(-1)  # accumulated into; the flat gradient slice when there is one
 
         sdf_bar_c, feat_bar_c = _contig(sdf_bar), _contig(feat_bar)
-        _lib.check(lib.sdfhip_geo_backward(h, _lib.ptr(packed), _lib.ptr(mask), ctx.P, ctypes.c_void_p(ws.data_ptr()),
-                                           _lib.ptr(sdf_bar_c), _lib.ptr(feat_bar_c), _lib.ptr(theta_bar), _lib.ptr(table_bar),
-                                           _lib.stream()), "geo_backward")
+        _lib.check(lib.sdfhip_geo_backward_n(h, _lib.ptr(packed), _lib.ptr(mask), ctx.P, ctypes.c_void_p(ws.data_ptr()), ctx.n_feat,
+                                             _lib.ptr(sdf_bar_c), _lib.ptr(feat_bar_c), _lib.ptr(theta_bar), _lib.ptr(table_bar),
+                                             _lib.stream()), "geo_backward")
         del sdf_bar_c, feat_bar_c
-        return theta_bar, table_bar, None, None, None
+        return theta_bar, table_bar, None, None, None, None
 
 
 class _ColorFunction(torch.autograd.Function):
@@ -566,9 +569,16 @@ class SDFField(nn.Module):
         P = x.shape[0]
         delta = self.numerical_gradients_delta
         pts = torch.cat([x[None], x[None, :, :] + self._tap_offsets(x)[:, None, :]], dim=0).reshape(-1, 3)
-        h = self.forward_geonetwork(pts)
-        sdf, feat = h[:P, 0], h[:P, 1:]
-        taps = h[P:, 0].view(6, P)
+        # one differentiable call over the 7 P points; the geometry feature is only taken (and converted out of the kernels' tile
+        # layout, and back in the backward) for the P centre points
+        if torch.is_grad_enabled():
+            sdf_all, feat = _GeoNetFunction.apply(self._theta(), self.encoding.params, self, pts.detach().contiguous().float(),
+                                                  self._mask(x.device), P)
+        else:  # rendering: the inference variant of the kernels (nothing saved)
+            h = self.forward_geonetwork(pts)
+            sdf_all, feat = h[:, 0], h[:P, 1:]
+        sdf = sdf_all[:P]
+        taps = sdf_all[P:].view(6, P)
         grad = torch.stack([0.5 * (taps[0] - taps[1]) / delta, 0.5 * (taps[2] - taps[3]) / delta, 0.5 * (taps[4] - taps[5]) / delta], dim=-1)
         rgb = _ColorFunction.apply(self._theta(), feat, grad, emb, self, x.detach(), d, n, s)
         sampled_sdf = taps.view(6, n, s).permute(1, 2, 0).contiguous()  # :644
