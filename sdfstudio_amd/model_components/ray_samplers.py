@@ -607,6 +607,7 @@ class NeuSAccSampler(Sampler):
         self.register_buffer("aabb", aabb.clone().float(), persistent=False)
         self.register_buffer("_binary", torch.ones((self.grid_size,) * 3, dtype=torch.bool))
         self.register_buffer("_update_counter", torch.zeros(1, dtype=torch.int32))
+        self._updates_host: Optional[int] = 0  # host mirror of _update_counter (None: unknown, e.g. after a checkpoint load)
         lo, hi = float(aabb[0, 0]) + self.voxel_size / 2.0, float(aabb[1, 0]) - self.voxel_size / 2.0
         off = torch.linspace(lo, hi, self.grid_size)
         x, y, z = torch.meshgrid(off, off, off, indexing="ij")
@@ -636,6 +637,19 @@ class NeuSAccSampler(Sampler):
             mask[mask.clone()] = alpha > self.alpha_thres
             self._binary = mask.reshape([self.grid_size] * 3).contiguous()
             self._update_counter += 1
+            if self._updates_host is not None:
+                self._updates_host += 1
+
+    def num_grid_updates(self) -> int:
+        """The reference reads `_update_counter.item()` in every forward (ray_samplers.py:1467, models/neus_acc.py:93): a device -> host
+        synchronisation per call.  The counter only changes in update_binary_grid and on a checkpoint load, so a host mirror answers."""
+        if self._updates_host is None:
+            self._updates_host = int(self._update_counter.item())
+        return self._updates_host
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._updates_host = None  # re-read from the loaded buffer on next use
 
     def create_ray_samples_from_ray_indices(self, ray_bundle: RayBundle, ray_indices, t_starts, t_ends) -> RaySamples:
         """:1434-1455.  Packed samples are [P,1] here (every sample its own one-sample ray), the layout the field kernels take."""
@@ -650,7 +664,7 @@ class NeuSAccSampler(Sampler):
         """:1457-1503.  After the first grid update: (ray_samples [P,1], ray_indices [P]); `packed_info` / `counts` of the call are
         kept on the sampler for the compositing kernels."""
         assert ray_bundle is not None and sdf_fn is not None
-        if int(self._update_counter.item()) <= 0:
+        if self.num_grid_updates() <= 0:
             return self.neus_sampler(ray_bundle, sdf_fn=sdf_fn)
         info, counts, ray_indices, t_starts, t_ends = march_occupancy_grid(
             ray_bundle.origins, ray_bundle.directions, ray_bundle.nears[:, 0], ray_bundle.fars[:, 0], self.aabb, self._binary,

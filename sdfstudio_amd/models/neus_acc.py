@@ -41,7 +41,7 @@ class NeuSAccModel(NeuSModel):
 
     def get_outputs(self, ray_bundle: RayBundle) -> Dict[str, torch.Tensor]:
         """:92-143."""
-        if int(self.sampler._update_counter.item()) <= 0:  # bootstrap with plain NeuS
+        if self.sampler.num_grid_updates() <= 0:  # bootstrap with plain NeuS (host mirror of the counter: no device sync per forward)
             return super().get_outputs(ray_bundle)
         ray_samples, ray_indices = self.sampler(ray_bundle, sdf_fn=self.field.get_sdf, alpha_fn=self.field.get_alpha)
         n_rays = len(ray_bundle)
@@ -51,11 +51,13 @@ class NeuSAccModel(NeuSModel):
             field_outputs = self.field(ray_samples, return_alphas=True)  # [P,1,*]
             alphas = field_outputs[FieldHeadNames.ALPHA][:, 0, :]
             weights = render_weight_from_alpha(alphas, info, counts)
-            rgb = accumulate_along_rays(weights, ray_indices, field_outputs[FieldHeadNames.RGB][:, 0, :], info, counts)
-            normal = accumulate_along_rays(weights, ray_indices, field_outputs[FieldHeadNames.NORMAL][:, 0, :], info, counts)
-            accumulation = accumulate_along_rays(weights, ray_indices, None, info, counts)
+            # the four renderers (rgb, normal, accumulation, depth: models/neus_acc.py:106-126) as ONE segmented accumulation over
+            # the packed samples: values = [rgb | normal | 1 | mid], 8 columns
             mids = (ray_samples.frustums.starts + ray_samples.frustums.ends)[:, 0, :] / 2
-            depth = accumulate_along_rays(weights, ray_indices, mids, info, counts)
+            vals = torch.cat([field_outputs[FieldHeadNames.RGB][:, 0, :], field_outputs[FieldHeadNames.NORMAL][:, 0, :],
+                              torch.ones_like(mids), mids], dim=-1)
+            acc8 = accumulate_along_rays(weights, ray_indices, vals, info, counts)
+            rgb, normal, accumulation, depth = acc8[:, 0:3], acc8[:, 3:6], acc8[:, 6:7], acc8[:, 7:8]
             if ray_bundle.directions_norm is not None:
                 depth = depth / ray_bundle.directions_norm  # point-to-point distance -> depth (:127-128)
             # the reference's dictionary has no "weights" entry on this path (the dense-sample losses that read it do not apply);

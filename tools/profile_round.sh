@@ -1,12 +1,14 @@
 #!/bin/bash
 # Evidence run on the GPU box (via gpurun): kernel-trace stats of the default bench command, then the PMC passes the guide
 # prescribes for HBM traffic (FETCH_SIZE and WRITE_SIZE in SEPARATE passes; no sys/hip/hsa trace domains next to --pmc),
-# then SQ busy / wait counters.   tools/profile_round.sh <tag>   ->  gpurun_out/<tag>/{kt,pmc_fetch,pmc_write,pmc_sq}
+# then SQ busy / wait counters.   tools/profile_round.sh <tag> [bench.py args]   ->  gpurun_out/<tag>/{kt,pmc_fetch,pmc_write,pmc_sq}
 TAG=${1:-r1}
+shift
+EXTRA="$@"   # extra bench.py arguments, e.g. --config 5 (tag it r3_cfg5: bench.py picks the cfg5 summaries for its config-5 line)
 R=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $R
 cd /tmp && export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline"
+B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline $EXTRA"
 BP="$B --no-forward-only"  # PMC passes: training steps only, so launches / steps = launches per step
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/kt -o kt -- $B --steps 10 --warmup 3 > $R/kt.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/pmc_fetch -o p -- $BP --steps 2 --warmup 1 > $R/pmc_fetch.log 2>&1
