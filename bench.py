@@ -365,7 +365,7 @@ def run(args):
             avg_s = kt_ms / kn * 1e-3
             flow_bytes = geo_bwd_algorithmic_bytes() * P
             traffic, traffic_source = None, None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the bench)
-            cands = sorted(f for f in os.listdir(pm_dir) if f.endswith("_pmc_traffic.json"))
+            cands = sorted(f for f in os.listdir(pm_dir) if f.endswith("_pmc_traffic.json") and "cfg5" not in f)
             if cands:
                 with open(os.path.join(pm_dir, cands[-1])) as fh:  # newest committed PMC pass (r1 < r2 < r3 ...)
                     tj = json.load(fh)
