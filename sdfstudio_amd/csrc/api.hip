@@ -928,8 +928,14 @@ extern "C" int sdfhip_geo_backward_n(const SdfHipField* f, const float* packed, 
   const unsigned pg = (unsigned)((NP + 255) / 256);
   pad_copy_kernel<<<pg, 256, 0, s>>>(sdf_bar, P, NP, w.sdfbar);
   const int64_t fw = NP * k->nbf * 32;
-  // rows >= n_feat_points (points whose feature the caller never took: the six taps of the numerical gradient) get zeros
-  totp_kernel<<<(unsigned)((fw + 255) / 256), 256, 0, s>>>(feat_bar, k->nbf, f->cfg.geo_feat_dim, n_feat_points, NP, w.featbar);
+  // rows >= n_feat_points (points whose feature the caller never took: the six taps of the numerical gradient) get zeros: the
+  // tile-packed layout is tile-major, so everything behind the last tile with a live row is ONE contiguous memset
+  {
+    const int64_t n_conv = std::min<int64_t>(NP, (n_feat_points + 31) / 32 * 32);
+    const int64_t cw = n_conv * k->nbf * 32;
+    if (cw > 0) totp_kernel<<<(unsigned)((cw + 255) / 256), 256, 0, s>>>(feat_bar, k->nbf, f->cfg.geo_feat_dim, n_feat_points, n_conv, w.featbar);
+    if (fw > cw) SDFHIP_CHECK_HIP(hipMemsetAsync(w.featbar + cw, 0, (size_t)(fw - cw) * sizeof(float), s));
+  }
 
   GeoBwdArgs gb;
   memset(&gb, 0, sizeof(gb));
@@ -1047,16 +1053,24 @@ extern "C" int sdfhip_color_forward(const SdfHipField* f, const float* packed, c
 }
 
 // d L / d (normal input) [P,3] and d L / d (appearance embedding) [N, emb_dim] out of the colour backward's small-input block
-__global__ void color_unpack_kernel(const float* __restrict__ csmallbar_tp, const int nbs, const int64_t n_points, const int S,
-                                    const int emb_dim, float* __restrict__ grad_bar, float* __restrict__ emb_bar) {
+__global__ void color_unpack_kernel(const float* __restrict__ csmallbar_tp, const int nbs, const int64_t n_points,
+                                    float* __restrict__ grad_bar) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_points) return;
-  if (grad_bar != nullptr) {
 #pragma unroll
-    for (int d = 0; d < 3; ++d) grad_bar[p * 3 + d] = csmallbar_tp[tp_index(p, 30 + d, nbs)];
-  }
-  if (emb_bar != nullptr)
-    for (int j = 0; j < emb_dim; ++j) atomicAdd(emb_bar + (p / S) * emb_dim + j, csmallbar_tp[tp_index(p, 33 + j, nbs)]);
+  for (int d = 0; d < 3; ++d) grad_bar[p * 3 + d] = csmallbar_tp[tp_index(p, 30 + d, nbs)];
+}
+// d L / d (per-ray embedding) [N, emb_dim] += sum over the ray's S consecutive points: one thread per (ray, slot), no atomics (the
+// caller's buffer is zero or holds an earlier contribution)
+__global__ void color_emb_reduce_kernel(const float* __restrict__ csmallbar_tp, const int nbs, const int64_t n_rays, const int S,
+                                        const int emb_dim, float* __restrict__ emb_bar) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_rays * emb_dim) return;
+  const int64_t ray = idx / emb_dim;
+  const int j = (int)(idx % emb_dim);
+  float s = 0.0f;
+  for (int i = 0; i < S; ++i) s += csmallbar_tp[tp_index(ray * S + i, 33 + j, nbs)];
+  emb_bar[idx] += s;
 }
 
 extern "C" int sdfhip_color_backward(const SdfHipField* f, const float* packed, int64_t n_rays, int32_t n_samples, void* workspace,
@@ -1087,8 +1101,11 @@ extern "C" int sdfhip_color_backward(const SdfHipField* f, const float* packed, 
     const int64_t total = P * f->cfg.geo_feat_dim;
     untp_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(w.featbar, k->nbf, f->cfg.geo_feat_dim, P, feat_bar);
   }
-  color_unpack_kernel<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(w.csmallbar, k->nbs, P, n_samples, f->cfg.appearance_dim, grad_bar,
-                                                                  emb_bar);
+  if (grad_bar != nullptr) color_unpack_kernel<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(w.csmallbar, k->nbs, P, grad_bar);
+  if (emb_bar != nullptr && f->cfg.appearance_dim > 0) {
+    const int64_t ne = n_rays * f->cfg.appearance_dim;
+    color_emb_reduce_kernel<<<(unsigned)((ne + 255) / 256), 256, 0, s>>>(w.csmallbar, k->nbs, n_rays, n_samples, f->cfg.appearance_dim, emb_bar);
+  }
   run_col_wgrads(f, w, NP / 32, theta_bar, s);
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
