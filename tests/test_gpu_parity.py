@@ -628,7 +628,7 @@ def _product_field(model, o, d, cam, starts, coefs, device):
 FIELD_KEYS = ["glin0", "glin3", "glin4", "glin5", "glin8", "clin0", "clin2", "clin4"]
 
 
-def _check_field_grads(model, po, rtol=1e-3, truth=None, min_checked=28):
+def _check_field_grads(model, po, rtol=1e-3, truth=None, min_checked=28, clin_rtol=5e-3):
     """Parameter gradients against the fp32 oracle (|d| <= rtol * max|ref|); with `truth` (the oracle evaluated in
     fp64) the bar is the fp32-round-off class of the reference path instead (helpers.assert_fp32_class)."""
     got = product_grads(model)
@@ -647,7 +647,7 @@ def _check_field_grads(model, po, rtol=1e-3, truth=None, min_checked=28):
             # colour network: a single ReLU unit whose pre-activation the two fp32 evaluations put on opposite sides of zero moves one
             # row of a clin* gradient by a discrete amount (helpers.relu_flip_basis; up to ~1e-2 of the maximum at 8192 samples, see
             # test_full_shape_training_step_against_oracle): 5e-3 of the maximum for those tensors
-            rt = max(rtol, 5e-3) if k.startswith("clin") else rtol
+            rt = max(rtol, clin_rtol) if k.startswith("clin") else rtol
             assert_fp32_class(f"grad {k}", got[k], ref.grad, truth[k].grad, factor=3.0, atol=rt * truth[k].grad.abs().max().item())
         checked += 1
     assert checked >= min_checked
@@ -969,7 +969,11 @@ def test_field_depth_sweep_fwd_bwd(device, shape):
     f64, p64 = _oracle_field(cfg.field, to_double(p), o.double(), d.double(), cam, starts.double(), [c.double() for c in coefs])
     assert_fp32_class(f"gradient {tag}", grad, fo["gradient"], f64["gradient"], factor=3.0, atol=2e-5)
     assert_fp32_class(f"rgb {tag}", rgb, fo["rgb"], f64["rgb"], factor=3.0, atol=2e-5)
-    _check_field_grads(model, po, rtol=1e-3, truth=p64, min_checked=2 * (nl + 1) + 2 * (nlc + 1))
+    # 1320 points: ONE colour-network ReLU unit that the two fp32 evaluations put on opposite sides of zero at ONE point changes an
+    # entry of a clin* gradient by one term of a ~1320-term sum of random-sign terms, i.e. by a few percent of the tensor's maximum
+    # (seen: 1.9 % on clin4.weight_v of the 9 + 5 shape, with the fp32 oracle 2e-6 from fp64).  The geometry network (Softplus, no
+    # knife edges) keeps the 1e-3 bar; a wrong colour kernel would be off by O(1) in every tensor and in rgb above.
+    _check_field_grads(model, po, rtol=1e-3, truth=p64, min_checked=2 * (nl + 1) + 2 * (nlc + 1), clin_rtol=3e-2)
 
 
 def test_full_size_properties(device):
