@@ -338,13 +338,14 @@ int sdfhip_volsdf_bound_step(const float* bins_in, const float* sdf_a, const flo
  *   alpha = rendering_sdf_with_fixed_inv_s(bins_in, sdf, inv_s) (:899-944) -> weights (rays.py:194-208) with a trailing 0 (:873)
  *   new samples = PDFSampler(histogram_padding = 1e-5, include_original = False)(weights, n_new) (:875-880, :303-358)
  *   merged = merge_ray_samples(current, new) (:757-786): sorted bins + the index into cat(starts_current, starts_new)
- * bins_in [N,S+1] (S = s_a + s_b), jitter [N] or NULL.  Outputs: sdf_merged [N,S]; new_bins [N,n_new+1]; new_starts /
+ * bins_in [N,S+1] (S = s_a + s_b); jitter NULL (eval: bin centres), [N] (single_jitter, :825, 836-840) or, with
+ * jitter_per_sample != 0, [N,n_new+1] (one draw per new bin edge, :321-330).  Outputs: sdf_merged [N,S]; new_bins [N,n_new+1]; new_starts /
  * new_ends [N,n_new] euclidean (the caller evaluates get_sdf there and passes the result as the next step's sdf_b);
  * merged_bins [N,S+n_new+1]; merged_index [N,S+n_new] (int32); merged_starts / merged_ends [N,S+n_new] euclidean.
  * All outputs are constants w.r.t. autograd (bins.detach(), :771). */
 int sdfhip_neus_upsample(const float* bins_in, const float* sdf_a, const float* sdf_b, const int32_t* index, const float* nears,
-                         const float* fars, const float* jitter, int64_t n_rays, int32_t s_a, int32_t s_b, int32_t n_new,
-                         float inv_s, float* sdf_merged, float* new_bins, float* new_starts, float* new_ends, float* merged_bins,
+                         const float* fars, const float* jitter, int32_t jitter_per_sample, int64_t n_rays, int32_t s_a, int32_t s_b,
+                         int32_t n_new, float inv_s, float* sdf_merged, float* new_bins, float* new_starts, float* new_ends, float* merged_bins,
                          int32_t* merged_index, float* merged_starts, float* merged_ends, sdfhip_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------- weights + renderers

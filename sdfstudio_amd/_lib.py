@@ -128,7 +128,7 @@ _SIGNATURES = {
     "sdfhip_volsdf_bound_step": (c_i32, [c_float_p, c_float_p, c_float_p, ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p,
                                          c_i64, c_i32, c_i32, c_f32, c_i32, c_float_p, c_float_p, c_float_p, c_float_p,
                                          ctypes.c_void_p, ctypes.c_void_p]),
-    "sdfhip_neus_upsample": (c_i32, [c_float_p, c_float_p, c_float_p, ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_i64, c_i32,
+    "sdfhip_neus_upsample": (c_i32, [c_float_p, c_float_p, c_float_p, ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_i32, c_i64, c_i32,
                                      c_i32, c_i32, c_f32, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_void_p,
                                      c_float_p, c_float_p, ctypes.c_void_p]),
     "sdfhip_sample_pdf": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_i64, c_i32, c_i32, c_f32, c_f32,

@@ -461,7 +461,7 @@ extern "C" int64_t sdfhip_field_packed_size(const SdfHipField* f) { return f->pa
 
 // ---- workspace carving
 struct FieldWs {
-  float *x, *in0, *dydp, *z[kMaxLayers], *r[kMaxLayers], *feat, *e, *csmall, *h[kMaxLayers];
+  float *x, *in0, *dydp, *u[kMaxLayers], *r[kMaxLayers], *feat, *e, *csmall, *h[kMaxLayers];
   float *rgb;
   float *gtot, *ebar, *sdfbar, *qb[kMaxLayers + 1], *zb[kMaxLayers], *in0bar, *d[kMaxLayers], *dout, *featbar, *csmallbar;
   float *partial, *bpartial;
@@ -488,7 +488,7 @@ static void carve(const SdfHipField* f, int64_t n_points, int level, void* base,
   if (full) {
     w->dydp = take(np * f->n_feat * 3);
     for (int l = 0; l < f->nl; ++l) {
-      w->z[l] = take(np * f->nbo_geo(l) * 32);
+      w->u[l] = take(np * f->nbo_geo(l) * 32);
       if (train) w->r[l] = take(np * f->nbo_geo(l) * 32);
     }
     w->e = take(np * k->nb0 * 32);
@@ -612,7 +612,7 @@ extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, c
   fill_geo_ptrs(f, packed, &ga.p, kNsFwd);
   ga.in0_tp = w.in0;
   for (int l = 0; l < f->nl; ++l) {
-    ga.z_tp[l] = w.z[l];
+    ga.u_tp[l] = w.u[l];
     ga.r_tp[l] = w.r[l];
   }
   ga.feat_tp = w.feat;
@@ -721,23 +721,20 @@ static void run_wgrad(const SdfHipField* f, const FieldWs& w, const WgradArgs& b
   { ProfScope ps_(PS_WREDUCE, s); wreduce_kernel<<<(unsigned)std::max((total + 255) / 256, (r.rows + 63) / 64), 256, 0, s>>>(r); }
 }
 
-static TpOperand seg1(const float* p, int nb, int xf) {
+static TpOperand seg1(const float* p, int nb) {
   TpOperand o;
   memset(&o, 0, sizeof(o));
   o.ptr[0] = p;
   o.nb[0] = nb;
-  o.xf[0] = xf;
   return o;
 }
-static TpOperand seg2(const float* p0, int nb0, int xf0, const float* p1, int nb1, int xf1) {
+static TpOperand seg2(const float* p0, int nb0, const float* p1, int nb1) {
   TpOperand o;
   memset(&o, 0, sizeof(o));
   o.ptr[0] = p0;
   o.nb[0] = nb0;
-  o.xf[0] = xf0;
   o.ptr[1] = p1;
   o.nb[1] = nb1;
-  o.xf[1] = xf1;
   return o;
 }
 
@@ -745,7 +742,6 @@ static TpOperand seg2(const float* p0, int nb0, int xf0, const float* p1, int nb
 static void run_geo_wgrads(const SdfHipField* f, const FieldWs& w, const bool tangent, const int64_t n_tiles, float* theta_bar,
                            hipStream_t s) {
   const FieldKernels* k = f->k;
-  const int xf = f->cfg.activation == 1 ? 2 : 1;  // u_l = act(z_{l-1}) applied as the saved pre-activation is loaded (wgrad_kernels.h)
   for (int l = 0; l < f->nl; ++l) {
     const LinearInfo& li = f->lin[l];
     WgradArgs a;
@@ -754,17 +750,17 @@ static void run_geo_wgrads(const SdfHipField* f, const FieldWs& w, const bool ta
     a.nba = f->nbo_geo(l);
     a.nbb = f->kb_geo(l);
     a.n_tiles = n_tiles;
-    a.A[0] = seg1(w.zb[l], a.nba, 0);
-    a.A[1] = seg1(w.r[l], a.nba, 0);
+    a.A[0] = seg1(w.zb[l], a.nba);
+    a.A[1] = seg1(w.r[l], a.nba);
     if (l == 0) {
-      a.B[0] = seg1(w.in0, k->nb0, 0);
-      a.B[1] = seg1(w.ebar, k->nb0, 0);
+      a.B[0] = seg1(w.in0, k->nb0);
+      a.B[1] = seg1(w.ebar, k->nb0);
     } else if (l == f->skip) {
-      a.B[0] = seg2(w.z[l - 1], f->nb3, xf, w.in0, k->nb0, 0);
-      a.B[1] = seg1(w.qb[l], a.nbb, 0);
+      a.B[0] = seg2(w.u[l - 1], f->nb3, w.in0, k->nb0);
+      a.B[1] = seg1(w.qb[l], a.nbb);
     } else {
-      a.B[0] = seg1(w.z[l - 1], a.nbb, xf);
-      a.B[1] = seg1(w.qb[l], a.nbb, 0);
+      a.B[0] = seg1(w.u[l - 1], a.nbb);
+      a.B[1] = seg1(w.qb[l], a.nbb);
     }
     run_wgrad(f, w, a, f->g_rowmap[l], f->g_colmap[l], li.w_off, li.in_dim, f->g_scale[l], li.b_off, theta_bar, s);
   }
@@ -777,11 +773,11 @@ static void run_geo_wgrads(const SdfHipField* f, const FieldWs& w, const bool ta
     a.nba = k->nbf;
     a.nbb = k->nbh;
     a.n_tiles = n_tiles;
-    a.A[0] = seg1(w.featbar, k->nbf, 0);
-    a.B[0] = seg1(w.z[f->nl - 1], k->nbh, xf);
+    a.A[0] = seg1(w.featbar, k->nbf);
+    a.B[0] = seg1(w.u[f->nl - 1], k->nbh);
     run_wgrad(f, w, a, f->g_rowmap[f->nl], f->g_colmap[f->nl], li.w_off, li.in_dim, 1.0f, li.b_off, theta_bar, s);
     const int tps = (int)((n_tiles + w.n_split - 1) / w.n_split);
-    { ProfScope ps_(PS_WGRAD, s); k->sdfrow(w.z[f->nl - 1], tangent ? w.qb[f->nl] : nullptr, w.sdfbar, n_tiles, tps, w.partial, (unsigned)w.n_split, s); }
+    { ProfScope ps_(PS_WGRAD, s); k->sdfrow(w.u[f->nl - 1], tangent ? w.qb[f->nl] : nullptr, w.sdfbar, n_tiles, tps, w.partial, (unsigned)w.n_split, s); }
     const int stride = k->nbh * 32 + 32;
     sdfrow_reduce_kernel<<<(stride + 255) / 256, 256, 0, s>>>(w.partial, w.n_split, stride, f->cfg.hidden_dim, theta_bar + li.w_off,
                                                               theta_bar + li.b_off);
@@ -799,8 +795,8 @@ static void run_col_wgrads(const SdfHipField* f, const FieldWs& w, const int64_t
     a.nba = k->nbc;
     a.nbb = f->kb_col(l);
     a.n_tiles = n_tiles;
-    a.A[0] = seg1(w.d[l], k->nbc, 0);
-    a.B[0] = l == 0 ? seg2(w.feat, k->nbf, 0, w.csmall, k->nbs, 0) : seg1(w.h[l - 1], k->nbc, 0);
+    a.A[0] = seg1(w.d[l], k->nbc);
+    a.B[0] = l == 0 ? seg2(w.feat, k->nbf, w.csmall, k->nbs) : seg1(w.h[l - 1], k->nbc);
     run_wgrad(f, w, a, f->c_rowmap[l], f->c_colmap[l], li.w_off, li.in_dim, 1.0f, li.b_off, theta_bar, s);
   }
   {
@@ -811,8 +807,8 @@ static void run_col_wgrads(const SdfHipField* f, const FieldWs& w, const int64_t
     a.nba = 1;
     a.nbb = k->nbc;
     a.n_tiles = n_tiles;
-    a.A[0] = seg1(w.dout, 1, 0);
-    a.B[0] = seg1(w.h[f->nlc - 1], k->nbc, 0);
+    a.A[0] = seg1(w.dout, 1);
+    a.B[0] = seg1(w.h[f->nlc - 1], k->nbc);
     run_wgrad(f, w, a, f->c_rowmap[f->nlc], f->c_colmap[f->nlc], li.w_off, li.in_dim, 1.0f, li.b_off, theta_bar, s);
   }
 }
@@ -834,7 +830,7 @@ static void carve_geo(const SdfHipField* f, int64_t n_points, void* base, FieldW
   w->x = take(np * 3);
   w->in0 = take(np * k->nb0 * 32);
   w->feat = take(np * k->nbf * 32);
-  for (int l = 0; l < f->nl; ++l) w->z[l] = take(np * f->nbo_geo(l) * 32);
+  for (int l = 0; l < f->nl; ++l) w->u[l] = take(np * f->nbo_geo(l) * 32);
   w->sdfbar = take(np);
   for (int l = 0; l < f->nl; ++l) w->zb[l] = take(np * f->nbo_geo(l) * 32);
   w->in0bar = take(np * k->nb0 * 32);
@@ -897,7 +893,7 @@ extern "C" int sdfhip_geo_forward_n(const SdfHipField* f, const float* packed, c
   memset(&ga, 0, sizeof(ga));
   fill_geo_ptrs(f, packed, &ga.p, kNsFwd);
   ga.in0_tp = w.in0;
-  for (int l = 0; l < f->nl; ++l) ga.z_tp[l] = w.z[l];
+  for (int l = 0; l < f->nl; ++l) ga.u_tp[l] = w.u[l];
   ga.feat_tp = w.feat;
   ga.sdf = sdf;
   { ProfScope ps_(PS_GEO_FWD, s); k->geo_fwd(3, ga, (unsigned)(NP / 128), s); }
@@ -943,7 +939,7 @@ extern "C" int sdfhip_geo_backward_n(const SdfHipField* f, const float* packed, 
   gb.featbar_tp = w.featbar;
   gb.sdfbar = w.sdfbar;
   for (int l = 0; l < f->nl; ++l) {
-    gb.z_tp[l] = w.z[l];
+    gb.u_tp[l] = w.u[l];
     gb.zb_tp[l] = w.zb[l];
   }
   gb.in0bar_tp = w.in0bar;
@@ -1175,7 +1171,7 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
   gb.featbar_tp = w.featbar;
   gb.sdfbar = w.sdfbar;
   for (int l = 0; l < f->nl; ++l) {
-    gb.z_tp[l] = w.z[l];
+    gb.u_tp[l] = w.u[l];
     gb.r_tp[l] = w.r[l];
     gb.zb_tp[l] = w.zb[l];
   }
@@ -1804,8 +1800,8 @@ extern "C" int sdfhip_volsdf_bound_step(const float* bins_in, const float* sdf_a
 }
 
 extern "C" int sdfhip_neus_upsample(const float* bins_in, const float* sdf_a, const float* sdf_b, const int32_t* index, const float* nears,
-                                    const float* fars, const float* jitter, int64_t n_rays, int32_t s_a, int32_t s_b, int32_t n_new,
-                                    float inv_s, float* sdf_merged, float* new_bins, float* new_starts, float* new_ends,
+                                    const float* fars, const float* jitter, int32_t jitter_per_sample, int64_t n_rays, int32_t s_a,
+                                    int32_t s_b, int32_t n_new, float inv_s, float* sdf_merged, float* new_bins, float* new_starts, float* new_ends,
                                     float* merged_bins, int32_t* merged_index, float* merged_starts, float* merged_ends,
                                     sdfhip_stream_t stream) {
   SDFHIP_REQUIRE(bins_in && sdf_a && nears && fars && sdf_merged && new_bins && new_starts && new_ends && merged_bins && merged_index &&
@@ -1823,6 +1819,7 @@ extern "C" int sdfhip_neus_upsample(const float* bins_in, const float* sdf_a, co
   a.nears = nears;
   a.fars = fars;
   a.jitter = jitter;
+  a.jitter_stride = jitter != nullptr && jitter_per_sample ? n_new + 1 : 0;
   a.N = (int)n_rays;
   a.Sa = s_a;
   a.Sb = s_b;

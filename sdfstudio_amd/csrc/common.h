@@ -73,6 +73,14 @@ SDFHIP_D float softplus100_h(float z) {
   return z > kSp100Thr ? z : hs;
 }
 
+// s'(z) recovered from the SAVED ACTIVATION h = softplus(z) (round 3: the fused kernels save h_l, not z_l): e^{100 h} = 1 + e^{100 z}, so
+//   s'(z) = e^{100 z} / (1 + e^{100 z}) = 1 - e^{-100 h}
+// one transcendental (quarter rate on the VALU) and two full-rate instructions in place of exp + rcp + five; above the threshold h = z
+// and e^{-100 h} < 2e-9 rounds the result to 1 like aten's linear branch.  For h -> 0 the subtraction is exact to half an ulp of 1
+// (6e-8 ABSOLUTE, where exp / (1 + exp) is 6e-8 relative): the same error class as the rounding of every s' near 1, which is what the
+// sums these derivatives enter are made of; parity is held by the fp64-anchored gradient tests of tests/test_gpu_parity.py.
+SDFHIP_D float softplus100_d1_from_h(float h) { return 1.0f - __builtin_amdgcn_exp2f(-h * kSp100Log2e); }
+
 // Hidden activation of a fused geometry-type network, selected at compile time by the network's dims class (GeoDims::ACT):
 //   0  Softplus(beta = 100)   the SDF field (sdf_field.py:290, 409)
 //   1  ReLU                   the background fields (field_components/mlp.py:93 of NeRFField; tcnn's FullyFusedMLP in TCNNNerfactoField)
@@ -86,6 +94,12 @@ template <int ACT>
 SDFHIP_D float act_d1(const float z) {
   if constexpr (ACT == 1) return z > 0.0f ? 1.0f : 0.0f;
   else return softplus100_d1(z);
+}
+// the same derivative from the saved activation h = act(z) (what the training kernels keep per layer; the weight gradient reads it as is)
+template <int ACT>
+SDFHIP_D float act_d1h(const float h) {
+  if constexpr (ACT == 1) return h > 0.0f ? 1.0f : 0.0f;
+  else return softplus100_d1_from_h(h);
 }
 
 // thread-local last-error string (extern "C" API returns 0 or a negative code)

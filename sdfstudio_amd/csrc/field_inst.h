@@ -11,7 +11,7 @@ struct FieldKernels {
   void (*geo_bwd1)(const GeoBwdArgs&, unsigned grid, hipStream_t);  // first-order data backward only (after sdfhip_geo_forward)
   void (*col_fwd)(const ColFwdArgs&, int save_activations, unsigned grid, hipStream_t);
   void (*col_bwd)(const ColBwdArgs&, unsigned grid, hipStream_t);
-  void (*sdfrow)(const float* z_last, const float* qb_last, const float* sdfbar, int64_t n_tiles, int tiles_per_split,
+  void (*sdfrow)(const float* u_last, const float* qb_last, const float* sdfbar, int64_t n_tiles, int tiles_per_split,
                  float* partial, unsigned grid, hipStream_t);
   int act;  // hidden activation of the geometry-type network (common.h act_h): 0 Softplus(100); 1 ReLU - first-order entries only
             // (geo_fwd modes 1 - 3, geo_bwd1; geo_bwd is null)
@@ -138,7 +138,7 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
   }                                                                                                                       \
   static void sdfrow(const float* z, const float* q, const float* sb, int64_t nt, int tps, float* part,                  \
                      unsigned grid, hipStream_t s) {                                                                      \
-    sdfrow_grad_kernel<NBH, 1><<<grid, 256, 0, s>>>(z, q, sb, nt, tps, part);                                             \
+    sdfrow_grad_kernel<NBH><<<grid, 256, 0, s>>>(z, q, sb, nt, tps, part);                                             \
   }                                                                                                                       \
   }                                                                                                                       \
   const FieldKernels* sdfhip_kernels_##NAME() {                                                                           \

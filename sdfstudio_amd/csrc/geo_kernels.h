@@ -61,7 +61,7 @@ struct GeoDims {
   static constexpr int pieces(int ns) { return chunk_pieces(MAXO, ns); }
 };
 // tensor layouts that depend on the depth: qb_tp[l] has kb(l) blocks per tile (NB0 / NBH + NB0 at the skip layer / NBH),
-// z_tp[l], r_tp[l], zb_tp[l] have NBH (every hidden layer is NBH wide: the one below the skip concatenation is padded)
+// u_tp[l], r_tp[l], zb_tp[l] have NBH (every hidden layer is NBH wide: the one below the skip concatenation is padded)
 
 struct GeoPtrs {
   int32_t nl, skip;               // hidden layers (the output layer is layer nl), skip layer (-1: none; 1 <= skip < nl)
@@ -76,7 +76,8 @@ struct GeoPtrs {
 struct GeoFwdArgs {
   GeoPtrs p;
   const float* in0_tp;  // [T][NB0]
-  float* z_tp[kMaxLayers];  // [T][nbo(l)]   (training only)
+  float* u_tp[kMaxLayers];  // [T][nbo(l)]   saved ACTIVATIONS act(z_l) (training only): what the next layer and the weight gradient
+                            // consume as they are; the backward-type passes recover s'(z_l) from them (common.h act_d1h)
   float* r_tp[kMaxLayers];  // [T][nbo(l)]   (training only)
   float* feat_tp;           // [T][NBF]
   float* sdf;               // [T*32]
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
 
   // first gemm of the chain: the in0 part if the last hidden layer is the skip layer, the hidden part otherwise; its operands
   // are block 0 of z_{NL-1} either way
-  auto chain_first_src = [&]() __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(a.z_tp[NL - 1], tile, D::NBH, 0)}}; };
+  auto chain_first_src = [&]() __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(a.u_tp[NL - 1], tile, D::NBH, 0)}}; };
   const float* chain_first_w = SKIP == NL - 1 ? a.p.wpT_in0 : a.p.wpT[NL - 1];
 
   WStream ws{lds, D::buf_floats(NS), 0, wave, lane};
@@ -156,12 +157,12 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
     }
     if (l > 0) {
       // hidden -> hidden: u_l = softplus(z_{l-1}) made from the accumulators of the layer below, z_{l-1} saved on the way
-      float* zprev = a.z_tp[l - 1];
+      float* uprev = a.u_tp[l - 1];
       auto make = [&](auto kbc, const Raw&, auto ec) __attribute__((always_inline)) {
         constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
-        const float z = accIn[kb][e];
-        if constexpr (SAVE || GRAD) *tp_elem(zprev, tile, D::NBH, kb, e, lane) = z;
-        return act_h<D::ACT>(z);
+        const float h = act_h<D::ACT>(accIn[kb][e]);
+        if constexpr (SAVE || GRAD) *tp_elem(uprev, tile, D::NBH, kb, e, lane) = h;
+        return h;
       };
       const float* nxt = l == SKIP ? geo_skip_in0<D>(a.p.wp[l]) : (l + 1 < NL ? a.p.wp[l + 1] : after_last);
       tp_gemm<D::NBH, D::NBH, Stores<ZS>, NS, PCS>(accOut, carry, NoFetch{}, make, in0_blk0, ws, a.p.wp[l], nxt);
@@ -181,13 +182,12 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
   // ---- output layer: the sdf row as a lane-local dot product riding in the producer, feature rows on the MFMA path
   {
     float part = 0.0f;
-    float* zlast = a.z_tp[NL - 1];
+    float* ulast = a.u_tp[NL - 1];
     const float* wsdf = cvec + (NL + 1) * W;
     auto make = [&](auto kbc, const Raw&, auto ec) __attribute__((always_inline)) {
       constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
-      const float z = accIn[kb][e];
-      if constexpr (SAVE || GRAD) *tp_elem(zlast, tile, D::NBH, kb, e, lane) = z;
-      const float h = act_h<D::ACT>(z);
+      const float h = act_h<D::ACT>(accIn[kb][e]);
+      if constexpr (SAVE || GRAD) *tp_elem(ulast, tile, D::NBH, kb, e, lane) = h;
       part = fmaf(wsdf[kb * 32 + tp_row(e, hf)], h, part);
       return h;
     };
@@ -219,12 +219,12 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
     for (int b = 0; b < D::NBH; ++b) accIn[b] = tp_rowvec_blk(cvec + (NL + 1) * W, b, hf);
 #pragma unroll 1
     for (int l = NL - 1; l >= 0; --l) {
-      const float* zl = a.z_tp[l];
+      const float* ul = a.u_tp[l];
       float* rl = a.r_tp[l];
-      auto fetch = [&](auto bc) __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(zl, tile, D::NBH, decltype(bc)::value)}}; };
+      auto fetch = [&](auto bc) __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(ul, tile, D::NBH, decltype(bc)::value)}}; };
       auto make = [&](auto bc, const Raw& raw, auto ec) __attribute__((always_inline)) {
         constexpr int b = decltype(bc)::value, e = decltype(ec)::value;
-        const float r = accIn[b][e] * act_d1<D::ACT>(raw.a[e]);
+        const float r = accIn[b][e] * act_d1h<D::ACT>(raw.a[e]);
         if constexpr (SAVE) *tp_elem(rl, tile, D::NBH, b, e, lane) = r;
         return r;
       };
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
         f32x16 accE[D::NB0];
 #pragma unroll
         for (int b = 0; b < D::NB0; ++b) accE[b] = f32x16_zero();
-        auto next_fetch = [&]() __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(zl, tile, D::NBH, 0)}}; };
+        auto next_fetch = [&]() __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(ul, tile, D::NBH, 0)}}; };
         tp_gemm<D::NBH, D::NB0, Stores<(SAVE ? 16 : 0)>, NS, PCS>(accE, carry, fetch, make, next_fetch, ws, l == 0 ? a.p.wpT[0] : a.p.wpT_in0,
                                                                   a.p.wpT[l]);
         if (l == 0 && SKIP > 0) {
@@ -247,8 +247,8 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
       if (l > 0) {
 #pragma unroll
         for (int b = 0; b < D::NBH; ++b) accOut[b] = f32x16_zero();
-        const float* zbelow = a.z_tp[l - 1];
-        auto next_fetch = [&]() __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(zbelow, tile, D::NBH, 0)}}; };
+        const float* ubelow = a.u_tp[l - 1];
+        auto next_fetch = [&]() __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(ubelow, tile, D::NBH, 0)}}; };
         tp_gemm<D::NBH, D::NBH, Stores<(SAVE ? 16 : 0)>, NS, PCS>(accOut, carry, fetch, make, next_fetch, ws, a.p.wpT[l],
                                                                   l - 1 == SKIP ? a.p.wpT_in0 : a.p.wpT[l - 1]);
         acc_copy_n(accIn, accOut);
@@ -262,7 +262,7 @@ struct GeoBwdArgs {
   const float* ebar_tp;     // [T][NB0]   tangent seed  J_in0 gbar
   const float* featbar_tp;  // [T][NBF]
   const float* sdfbar;      // [T*32]
-  const float* z_tp[kMaxLayers];
+  const float* u_tp[kMaxLayers];
   const float* r_tp[kMaxLayers];
   float* qb_tp[kMaxLayers + 1];  // [T][kb(l)]  tangent entering layer l  (l == NL: the tangent reaching the sdf row); qb_tp[0] == ebar_tp
   float* zb_tp[kMaxLayers];      // [T][nbo(l)] holds zc_l after the tangent pass, zbar_l after the backward pass
@@ -308,24 +308,24 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
       if (l > 0) {
         // hidden -> hidden.  The producer is the tangent epilogue of the layer below on element e of block kb:
         //   qb_l = s'(z_{l-1}) v_{l-1} ;  zc_{l-1} = v_{l-1} r_{l-1} 100 (1 - s'(z_{l-1}))  (-> zb_tp[l-1])
-        const float* zp = a.z_tp[l - 1];
+        const float* up = a.u_tp[l - 1];
         const float* rp = a.r_tp[l - 1];
         float* zbp = a.zb_tp[l - 1];
         auto fetch = [&](auto kbc) __attribute__((always_inline)) {
           constexpr int kb = decltype(kbc)::value;
-          return BlkSrc<2>{{tp_block_ptr(zp, tile, D::NBH, kb), tp_block_ptr(rp, tile, D::NBH, kb)}};
+          return BlkSrc<2>{{tp_block_ptr(up, tile, D::NBH, kb), tp_block_ptr(rp, tile, D::NBH, kb)}};
         };
         auto make = [&](auto kbc, const Raw& raw, auto ec) __attribute__((always_inline)) {
           constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
           const float v = accIn[kb][e];
-          const float d1 = act_d1<D::ACT>(raw.a[e]);
+          const float d1 = act_d1h<D::ACT>(raw.a[e]);
           *tp_elem(zbp, tile, D::NBH, kb, e, lane) = v * raw.b[e] * (100.0f * (1.0f - d1));
           const float qn = d1 * v;
           *tp_elem(qbl, tile, qb_nb, kb, e, lane) = qn;
           return qn;
         };
         // what follows: the in0 part of this layer (operands: seed block 0), or the next layer (operands: (z_l, r_l) block 0)
-        const float* na = l == SKIP ? a.ebar_tp : a.z_tp[l];
+        const float* na = l == SKIP ? a.ebar_tp : a.u_tp[l];
         const float* nb = l == SKIP ? a.ebar_tp : a.r_tp[l];
         const int nnb = l == SKIP ? D::NB0 : D::NBH;
         auto next_fetch = [&]() __attribute__((always_inline)) { return BlkSrc<2>{{tp_block_ptr(na, tile, nnb, 0), tp_block_ptr(nb, tile, nnb, 0)}}; };
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
           return raw.a[e];
         };
         auto next_fetch = [&]() __attribute__((always_inline)) {
-          return BlkSrc<2>{{tp_block_ptr(a.z_tp[l], tile, D::NBH, 0), tp_block_ptr(a.r_tp[l], tile, D::NBH, 0)}};
+          return BlkSrc<2>{{tp_block_ptr(a.u_tp[l], tile, D::NBH, 0), tp_block_ptr(a.r_tp[l], tile, D::NBH, 0)}};
         };
         const float* w = l == 0 ? a.p.wp[0] : geo_skip_in0<D>(a.p.wp[l]);
         tp_gemm<D::NB0, D::NBH, Stores<16>, NS, PCS>(accOut, carry, fetch, make, next_fetch, ws, w,
@@ -354,17 +354,17 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
     }
     {
       // epilogue of the last hidden layer: qb_NL (tangent reaching the sdf row; only the weight gradient needs it) and zc_{NL-1}
-      const float* zlast = a.z_tp[NL - 1];
+      const float* ulast = a.u_tp[NL - 1];
       const float* rlast = a.r_tp[NL - 1];
       float* zblast = a.zb_tp[NL - 1];
       float* qblast = a.qb_tp[NL];
       static_for<0, D::NBH>([&](auto bc) __attribute__((always_inline)) {
         constexpr int b = decltype(bc)::value;
-        const Raw raw = load_src(BlkSrc<2>{{tp_block_ptr(zlast, tile, D::NBH, b), tp_block_ptr(rlast, tile, D::NBH, b)}}, lane);
+        const Raw raw = load_src(BlkSrc<2>{{tp_block_ptr(ulast, tile, D::NBH, b), tp_block_ptr(rlast, tile, D::NBH, b)}}, lane);
         static_for<0, 16>([&](auto ec) __attribute__((always_inline)) {
           constexpr int e = decltype(ec)::value;
           const float v = accIn[b][e];
-          const float d1 = act_d1<D::ACT>(raw.a[e]);
+          const float d1 = act_d1h<D::ACT>(raw.a[e]);
           *tp_elem(zblast, tile, D::NBH, b, e, lane) = v * raw.b[e] * (100.0f * (1.0f - d1));
           *tp_elem(qblast, tile, D::NBH, b, e, lane) = d1 * v;
         });
@@ -373,8 +373,8 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
   }
 
   auto bwd_src = [&](const int l, const int b) __attribute__((always_inline)) {
-    if constexpr (TANGENT) return BlkSrc<2>{{tp_block_ptr(a.z_tp[l], tile, D::NBH, b), tp_block_ptr(a.zb_tp[l], tile, D::NBH, b)}};
-    else return BlkSrc<1>{{tp_block_ptr(a.z_tp[l], tile, D::NBH, b)}};
+    if constexpr (TANGENT) return BlkSrc<2>{{tp_block_ptr(a.u_tp[l], tile, D::NBH, b), tp_block_ptr(a.zb_tp[l], tile, D::NBH, b)}};
+    else return BlkSrc<1>{{tp_block_ptr(a.u_tp[l], tile, D::NBH, b)}};
   };
 
   if constexpr (PHASE == 1) return;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
     if (l == 0 || l == SKIP) {
       auto make = [&](auto bc, const Raw& raw, auto ec) __attribute__((always_inline)) {
         constexpr int b = decltype(bc)::value, e = decltype(ec)::value;
-        const float zb = TANGENT ? fmaf(accIn[b][e], act_d1<D::ACT>(raw.a[e]), raw.b[e]) : accIn[b][e] * act_d1<D::ACT>(raw.a[e]);
+        const float zb = TANGENT ? fmaf(accIn[b][e], act_d1h<D::ACT>(raw.a[e]), raw.b[e]) : accIn[b][e] * act_d1h<D::ACT>(raw.a[e]);
         *tp_elem(zbl, tile, D::NBH, b, e, lane) = zb;
         return zb;
       };
@@ -427,8 +427,8 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
       auto make = [&](auto bc, const Raw& raw, auto ec) __attribute__((always_inline)) {
         constexpr int b = decltype(bc)::value, e = decltype(ec)::value;
         float zb;
-        if constexpr (TANGENT) zb = done ? raw.b[e] : fmaf(accIn[b][e], act_d1<D::ACT>(raw.a[e]), raw.b[e]);
-        else zb = accIn[b][e] * act_d1<D::ACT>(raw.a[e]);
+        if constexpr (TANGENT) zb = done ? raw.b[e] : fmaf(accIn[b][e], act_d1h<D::ACT>(raw.a[e]), raw.b[e]);
+        else zb = accIn[b][e] * act_d1h<D::ACT>(raw.a[e]);
         *tp_elem(zbl, tile, D::NBH, b, e, lane) = zb;
         return zb;
       };

@@ -572,7 +572,8 @@ struct NeusUpArgs {
   const int32_t* index;   // [N,S] into cat(sdf_a, sdf_b) or null (identity)
   const float* nears;
   const float* fars;
-  const float* jitter;    // [N] or null
+  const float* jitter;    // [N], [N,n_new+1] (jitter_stride = n_new+1) or null
+  int32_t jitter_stride;
   int32_t N, Sa, Sb, n_new;
   float inv_s, histogram_padding, eps, u_end, u_center;
   float* sdf_merged;      // [N,S]
@@ -678,7 +679,7 @@ __global__ __launch_bounds__(256) void neus_upsample_kernel(const NeusUpArgs a) 
     const float end = a.u_end;
     const float step = end / (float)(nbins - 1);
     float u = j < nbins / 2 ? step * (float)j : end - step * (float)(nbins - 1 - j);  // torch.linspace
-    u += a.jitter != nullptr ? a.jitter[ray] / (float)nbins : a.u_center;
+    u += a.jitter != nullptr ? a.jitter[a.jitter_stride ? (int64_t)ray * a.jitter_stride + j : ray] / (float)nbins : a.u_center;
     int lo = 0, hi = S + 1;
     while (lo < hi) {  // searchsorted(side = "right")
       const int m = (lo + hi) >> 1;

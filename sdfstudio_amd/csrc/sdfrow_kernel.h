@@ -4,12 +4,12 @@
 #include "common.h"
 
 // Gradient of the sdf output row (lane-local dot product in geo_fwd_kernel):
-//   w_sdf_bar[k] = sum_p ( sdfbar_p * softplus(z_last[p][k]) + qb_last[p][k] ),   b_sdf_bar = sum_p sdfbar_p
+//   w_sdf_bar[k] = sum_p ( sdfbar_p * u_last[p][k] + qb_last[p][k] ),   b_sdf_bar = sum_p sdfbar_p      u_last = act(z_last), as saved
 // (qb_last == nullptr: first-order backward, no tangent term)
 // grid = n_split, block = 256 (the 4 waves interleave over the split's tiles, then sum through LDS).
 // partial: [n_split][NBH*32 + 32]  (last 32-slot holds b_sdf_bar in [0])
-template <int NBH, int ACT = 0>
-__global__ __launch_bounds__(256) void sdfrow_grad_kernel(const float* __restrict__ z_last, const float* __restrict__ qb_last,
+template <int NBH>
+__global__ __launch_bounds__(256) void sdfrow_grad_kernel(const float* __restrict__ u_last, const float* __restrict__ qb_last,
                                                             const float* __restrict__ sdfbar, const int64_t n_tiles,
                                                             const int tiles_per_split, float* __restrict__ partial) {
   __shared__ float red[4][NBH * 32 + 32];
@@ -28,11 +28,11 @@ __global__ __launch_bounds__(256) void sdfrow_grad_kernel(const float* __restric
     bsum += sb;
 #pragma unroll
     for (int b = 0; b < NBH; ++b) {
-      const float* zp = z_last + ((size_t)tile * NBH + b) * 1024 + lane;
+      const float* up = u_last + ((size_t)tile * NBH + b) * 1024 + lane;
       const float* qp = qb_last + ((size_t)tile * NBH + b) * 1024 + lane;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        acc[b][r] += fmaf(sb, act_h<ACT>(zp[r * 64]), qb_last != nullptr ? qp[r * 64] : 0.0f);
+        acc[b][r] += fmaf(sb, up[r * 64], qb_last != nullptr ? qp[r * 64] : 0.0f);
       }
     }
   }

@@ -80,8 +80,8 @@ static __global__ void packvec_kernel(const float* __restrict__ theta, const Vec
 // C[o][i] = sum over points of A[p][o] * B[p][i]: a GEMM whose contraction runs over the 524 288 points, with both
 // operands stored tile-packed (lane <-> point).  The MFMA wants lane <-> feature, so every 32-point tile is transposed
 // through LDS: the workgroup (4 waves) loads the <= 8 A blocks and <= 8 B blocks of one tile with coalesced 1 KiB
-// dwordx4 wave loads (each HBM byte is read once per macro tile, softplus applied once where the operand is a saved
-// pre-activation), writes them as [block][feature 0..31][point 0..31] rows of 36 floats (ds_write_b128, conflict free),
+// dwordx4 wave loads (each HBM byte is read once per macro tile; every operand is used as stored - the layer kernels save
+// activations, not pre-activations), writes them as [block][feature 0..31][point 0..31] rows of 36 floats (ds_write_b128, conflict free),
 // and each wave reads its 4 + 4 blocks back with ds_read_b128 (4 consecutive points of "its" feature; the 36-float row
 // stride spreads a 16-lane read group over all 64 banks).  Each wave owns a 4x4-block (128 x 128) quadrant of the
 // 256 x 256 macro tile: 256 accumulator registers, 256 MFMAs per tile against 32 LDS reads.  The next tile's global loads
@@ -90,7 +90,6 @@ static __global__ void packvec_kernel(const float* __restrict__ theta, const Vec
 struct TpOperand {
   const float* ptr[2];  // up to two concatenated TP arrays
   int32_t nb[2];        // blocks in each
-  int32_t xf[2];        // 0: as stored, 1: softplus(beta=100) applied on load, 2: ReLU applied on load
 };
 struct WgradArgs {
   TpOperand A[2], B[2];  // up to two (A, B) pairs accumulated into the same C
@@ -145,11 +144,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) valid[q] = slot[q] < 8 ? (ob_base + slot[q] < a.nba) : (ib_base + slot[q] - 8 < a.nbb);
 
-  // per-slot source description, resolved once (wave-uniform -> scalar registers): base pointer, floats per tile, softplus flag
+  // per-slot source description, resolved once (wave-uniform -> scalar registers): base pointer, floats per tile
   const float* src0[4];
   const float* src1[4];
   int stride0[4], stride1[4];
-  int xf0[4], xf1[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int blk = slot[q] < 8 ? ob_base + slot[q] : ib_base + slot[q] - 8;
@@ -160,15 +158,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
       const int lb = blk - (seg ? op.nb[0] : 0);
       const float* base = op.ptr[seg] + (size_t)lb * 1024;
       const int stride = op.nb[seg] * 1024;
-      const int xf = op.xf[seg];
       if (pr == 0) {
         src0[q] = base;
         stride0[q] = stride;
-        xf0[q] = xf;
       } else {
         src1[q] = base;
         stride1[q] = stride;
-        xf1[q] = xf;
       }
     }
   }
@@ -192,19 +187,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (!valid[q]) continue;
-      const int xf = p1 ? xf1[q] : xf0[q];
       // lane holds, for i = 0..3, TP row r = 4 i + (lane >> 4), half (lane >> 3) & 1, points 4 (lane & 7) .. + 3
       float* dst = lds + slot[q] * kWgBlk + (lane & 7) * 4;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         f32x4 v = pre[q][i];
-        if (xf == 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = softplus100_h(v[e]);
-        } else if (xf == 2) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
-        }
         const int f = tp_row(i * 4 + (lane >> 4), (lane >> 3) & 1);
         *reinterpret_cast<f32x4*>(dst + f * kWgRow) = v;
       }
@@ -315,7 +302,6 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
   const float* src0[4];
   const float* src1[4];
   int stride0[4], stride1[4];
-  int xf0[4], xf1[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int blk = slot[q] < 8 ? ob_base + slot[q] : ib_base + slot[q] - 8;
@@ -326,15 +312,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
       const int lb = blk - (seg ? op.nb[0] : 0);
       const float* base = op.ptr[seg] + (size_t)lb * 1024;
       const int stride = op.nb[seg] * 1024;
-      const int xf = op.xf[seg];
       if (pr == 0) {
         src0[q] = base;
         stride0[q] = stride;
-        xf0[q] = xf;
       } else {
         src1[q] = base;
         stride1[q] = stride;
-        xf1[q] = xf;
       }
     }
   }
@@ -358,19 +341,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (!valid[q]) continue;
-      const int xf = p1 ? xf1[q] : xf0[q];
       // lane holds, for i = 0..3, TP row r = 4 i + (lane >> 4), half (lane >> 3) & 1, points 4 (lane & 7) .. + 3
       __bf16* dst = ldsb + slot[q] * kWbSlot + (lane & 7) * 4;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         f32x4 v = pre[q][i];
-        if (xf == 1) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = softplus100_h(v[e]);
-        } else if (xf == 2) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
-        }
         if (q < 2 && !p1) colsum[q][i] += (v[0] + v[1]) + (v[2] + v[3]);
         bf16x4 hi, lo;
 #pragma unroll
@@ -453,7 +428,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
 }
 
 // ---- 8-wave version (default).  The 4-wave kernel above is bound by the VALU work of the staging pass (bf16 split of 256 values
-// per wave and tile, softplus where the operand is a saved pre-activation: ~1500 VALU instructions against 96 MFMAs, with the
+// per wave and tile (until round 3 also the softplus of saved pre-activations): ~1500 VALU instructions against 96 MFMAs, with the
 // matrix pipe idle meanwhile and two barriers per tile).  Here the macro tile is shared by 8 waves (two per SIMD: their VALU
 // streams issue side by side), each wave stages two blocks instead of four and owns a 2 x 4 block patch (128 accumulator
 // registers), and LDS is double buffered so that tile t + 1 is split and written while tile t is multiplied: one barrier
@@ -493,7 +468,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16x8_kernel(const WgradArgs a)
   const float* src0[2];
   const float* src1[2];
   int stride0[2], stride1[2];
-  int xf0[2], xf1[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int blk = q == 0 ? ob_base + wave : ib_base + wave;
@@ -504,15 +478,12 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16x8_kernel(const WgradArgs a)
       const int lb = blk - (seg ? op.nb[0] : 0);
       const float* base = op.ptr[seg] + (size_t)lb * 1024;
       const int stride = op.nb[seg] * 1024;
-      const int xf = op.xf[seg];
       if (pr == 0) {
         src0[q] = base;
         stride0[q] = stride;
-        xf0[q] = xf;
       } else {
         src1[q] = base;
         stride1[q] = stride;
-        xf1[q] = xf;
       }
     }
   }
@@ -533,30 +504,32 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16x8_kernel(const WgradArgs a)
       for (int i = 0; i < 4; ++i) pre[q][i] = src[i * 64];
     }
   };
-  // one staging unit = one f32x4 (4 consecutive points of one TP row) of slot q: softplus where the operand is a saved
-  // pre-activation, bias column sums, bf16 hi / lo split, two 8-byte LDS writes
+  // one staging unit = one f32x4 (4 consecutive points of one TP row) of slot q: bias column sums, bf16 hi / lo split, two 8-byte LDS writes
   auto store_unit = [&](const int st, auto qc, auto ic) __attribute__((always_inline)) {
     constexpr int q = decltype(qc)::value, i = decltype(ic)::value;
     if (!valid[q]) return;
     const bool p1 = st >= n_t;
-    const int xf = p1 ? xf1[q] : xf0[q];
     // lane holds, for i = 0..3, TP row r = 4 i + (lane >> 4), half (lane >> 3) & 1, points 4 (lane & 7) .. + 3
     __bf16* dst = ldsb + (st & 1) * kWbBuf + slot[q] * kWbSlot + (lane & 7) * 4;
     f32x4 v = pre[q][i];
-    if (xf == 1) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = softplus100_h(v[e]);
-    } else if (xf == 2) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
-    }
     if (q == 0 && !p1) colsum[i] += (v[0] + v[1]) + (v[2] + v[3]);
     bf16x4 hi, lo;
+#ifdef SDFHIP_ABL_WGRAD_NOSPLIT  // timing ablation (wrong numerics): what the staging pass would cost if the operands arrived split
+    {
+      typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+      u32x2_t t;
+      t[0] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, v[1]), __builtin_bit_cast(uint32_t, v[0]), 0x07060302u);
+      t[1] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, v[3]), __builtin_bit_cast(uint32_t, v[2]), 0x07060302u);
+      hi = __builtin_bit_cast(bf16x4, t);
+      lo = hi;
+    }
+#else
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       hi[e] = (__bf16)v[e];
       lo[e] = (__bf16)(v[e] - (float)hi[e]);
     }
+#endif
     const int f = tp_row(i * 4 + (lane >> 4), (lane >> 3) & 1);
     *reinterpret_cast<bf16x4*>(dst + f * kWbRow) = hi;
     *reinterpret_cast<bf16x4*>(dst + kWbTile + f * kWbRow) = lo;

@@ -333,8 +333,6 @@ class SDFField(nn.Module):
             unsupported.append("ref-nerf colour options")
         if c.off_axis:
             unsupported.append("off_axis")
-        if not c.weight_norm:
-            unsupported.append("weight_norm=False")
         if unsupported:
             raise NotImplementedError("sdfhip does not build: " + ", ".join(unsupported))
         self.aabb = nn.Parameter(torch.as_tensor(aabb, dtype=torch.float32), requires_grad=False)
@@ -385,7 +383,7 @@ class SDFField(nn.Module):
                     else:
                         lin.bias.zero_()
                         lin.weight.normal_(0.0, math.sqrt(2) / math.sqrt(out_dim))
-            setattr(self, f"glin{l}", nn.utils.weight_norm(lin))
+            setattr(self, f"glin{l}", nn.utils.weight_norm(lin) if c.weight_norm else lin)
 
         self.laplace_density = LaplaceDensity(init_val=c.beta_init)
         self.deviation_network = SingleVarianceNetwork(init_val=c.beta_init)
@@ -398,7 +396,7 @@ class SDFField(nn.Module):
             lin = nn.Linear(cdims[l], cdims[l + 1])
             torch.nn.init.kaiming_uniform_(lin.weight.data)
             torch.nn.init.zeros_(lin.bias.data)
-            setattr(self, f"clin{l}", nn.utils.weight_norm(lin))
+            setattr(self, f"clin{l}", nn.utils.weight_norm(lin) if c.weight_norm else lin)
 
         self._cos_anneal_ratio = 1.0
         self.numerical_gradients_delta = 0.0001
@@ -428,7 +426,8 @@ class SDFField(nn.Module):
             lib.sdfhip_field_theta_layout(h, w_off, b_off, od, idim)
             for i, name in enumerate(self._lin_names):
                 lin = getattr(self, name)
-                assert tuple(lin.weight_v.shape) == (od[i], idim[i]), (name, tuple(lin.weight_v.shape), od[i], idim[i])
+                shape = tuple((lin.weight_v if self.config.weight_norm else lin.weight).shape)
+                assert shape == (od[i], idim[i]), (name, shape, od[i], idim[i])
             self._handle_v = h
         return self._handle_v
 
@@ -445,6 +444,9 @@ class SDFField(nn.Module):
         launch (and one for its backward).  On CPU tensors (host-side inspection of the layout only: no kernel takes them) the same
         vector is assembled with torch ops."""
         lins = [getattr(self, name) for name in self._lin_names]
+        if not self.config.weight_norm:
+            # plain Linear layers (sdf_field.py:312-313, 360-361 with weight_norm=False): theta IS the concatenation of the parameters
+            return torch.cat([t.reshape(-1) for lin in lins for t in (lin.weight, lin.bias)])
         if lins[0].weight_v.is_cuda:
             return _ThetaFunction.apply(self, *[t for lin in lins for t in (lin.weight_v, lin.weight_g, lin.bias)])
         parts = []

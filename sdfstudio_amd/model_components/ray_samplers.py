@@ -147,15 +147,14 @@ class NeuSSampler(Sampler):
     def __init__(self, num_samples: int = 64, num_samples_importance: int = 64, num_samples_outside: int = 32,
                  num_upsample_steps: int = 4, base_variance: float = 64, single_jitter: bool = True) -> None:
         super().__init__()
-        if not single_jitter:
-            raise NotImplementedError("only single_jitter=True is built")
+        self.single_jitter = single_jitter
         self.num_samples = num_samples
         self.num_samples_importance = num_samples_importance
         self.num_samples_outside = num_samples_outside  # unused by the reference as well (ray_samplers.py:888-893)
         self.num_upsample_steps = num_upsample_steps
         self.base_variance = base_variance
-        self.uniform_sampler = UniformSampler(single_jitter=True)
-        self.jitter_overrides: Optional[List[torch.Tensor]] = None  # tests: one draw per up-sampling step
+        self.uniform_sampler = UniformSampler(single_jitter=single_jitter)
+        self.jitter_overrides: Optional[List[torch.Tensor]] = None  # tests: one draw per up-sampling step ([N], or [N, n_new + 1])
 
     def upsample_step(self, ray_bundle: RayBundle, bins, sdf_a, sdf_b, index, n_new: int, inv_s: float, jitter):
         """One reference loop iteration; returns (sdf_merged, new_bins, new_starts, new_ends, merged_bins, merged_index,
@@ -180,7 +179,8 @@ class NeuSSampler(Sampler):
         kp = _lib.Keep()
         _lib.check(lib.sdfhip_neus_upsample(
             kp(bins), kp(sdf_a), kp(sdf_b),
-            None if index is None else index.data_ptr(), _lib.ptr(nears), _lib.ptr(fars), _lib.ptr(jitter), n, s_a, s_b, n_new,
+            None if index is None else index.data_ptr(), _lib.ptr(nears), _lib.ptr(fars), _lib.ptr(jitter),
+            0 if jitter is None or jitter.dim() == 1 else 1, n, s_a, s_b, n_new,
             float(inv_s), _lib.ptr(sdf_m), _lib.ptr(new_bins), _lib.ptr(new_starts), _lib.ptr(new_ends), _lib.ptr(m_bins),
             m_index.data_ptr(), _lib.ptr(m_starts), _lib.ptr(m_ends), _lib.stream()), "neus_upsample")
         del kp
@@ -203,8 +203,9 @@ class NeuSSampler(Sampler):
                 new_sdf = sdf_fn(new_samples)[..., 0]
             jitter = None
             if self.training:
-                jitter = (self.jitter_overrides[it] if self.jitter_overrides is not None else torch.rand(n, device=dev))
-                jitter = jitter.reshape(-1).contiguous()
+                shape = (n,) if self.single_jitter else (n, n_new + 1)  # PDFSampler's draw, ray_samplers.py:321-330
+                jitter = (self.jitter_overrides[it] if self.jitter_overrides is not None else torch.rand(shape, device=dev))
+                jitter = jitter.reshape(shape).contiguous()
             if sdf is None:
                 sdf_a, sdf_b = new_sdf, None
             else:
@@ -396,16 +397,19 @@ class ProposalNetworkSampler(Sampler):
                  num_proposal_network_iterations: int = 2, use_uniform_sampler: bool = False, single_jitter: bool = True,
                  update_sched: Callable = lambda x: 1) -> None:
         super().__init__()
-        if use_uniform_sampler:
-            raise NotImplementedError("neus-facto uses the piecewise initial sampler (neus_facto.py:140-147)")
         if num_proposal_network_iterations < 1:
             raise ValueError("num_proposal_network_iterations must be >= 1")
         self.num_proposal_samples_per_ray = num_proposal_samples_per_ray
         self.num_nerf_samples_per_ray = num_nerf_samples_per_ray
         self.num_proposal_network_iterations = num_proposal_network_iterations
         self.update_sched = update_sched
-        self.initial_sampler = UniformLinDispPiecewiseSampler(single_jitter=single_jitter)
-        self.pdf_sampler = PDFSampler(include_original=False, single_jitter=single_jitter)
+        # ray_samplers.py:517-522; the PDF kernel resamples in the spacing domain of the initial sampler's bins
+        if use_uniform_sampler:
+            self.initial_sampler = UniformSampler(single_jitter=single_jitter)
+        else:
+            self.initial_sampler = UniformLinDispPiecewiseSampler(single_jitter=single_jitter)
+        self.pdf_sampler = PDFSampler(include_original=False, single_jitter=single_jitter,
+                                      spacing="uniform" if use_uniform_sampler else "piecewise")
         self._anneal = 1.0
         self._steps_since_update = 0
         self._step = 0

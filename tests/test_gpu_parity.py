@@ -145,6 +145,39 @@ def test_pdf_sampler_general(device, kind, single_jitter, include_original):
 
 
 @pytest.mark.parametrize("training", [True, False])
+def test_proposal_sampler_with_uniform_initial_sampler(device, training):
+    """ProposalNetworkSampler(use_uniform_sampler=True) (ray_samplers.py:517-522): UniformSampler bins, then PDF resampling in the SAME
+    (uniform) spacing domain, twice; against the oracle's statements composed the same way, with analytic density functions."""
+    from sdfstudio_amd.model_components.ray_samplers import ProposalNetworkSampler
+
+    n, counts, s_final = 37, (48, 24), 16
+    o, d, cam = O.synthetic_rays(n, seed=4)
+    near, far = 0.5, 4.5
+    rb = _bundle(o, d, cam, near, far, device)
+    peaks = [1.7, 2.4]
+    smp = ProposalNetworkSampler(num_proposal_samples_per_ray=counts, num_nerf_samples_per_ray=s_final, num_proposal_network_iterations=2,
+                                 use_uniform_sampler=True, single_jitter=True).train(training)
+    gen = torch.Generator().manual_seed(17)
+    t0, u = torch.rand(n, 1, generator=gen), torch.rand(n, 1, generator=gen)
+    smp.initial_sampler.jitter_override = t0.to(device)
+    smp.pdf_sampler.jitter_override = u.to(device)
+    fns = [lambda rs, c=c: 6.0 * torch.exp(-4.0 * ((rs.frustums.starts + rs.frustums.ends) / 2 - c) ** 2) for c in peaks]
+    rs, weights_list, samples_list = smp(rb, density_fns=fns)
+    nears, fars = torch.full((n,), near), torch.full((n,), far)
+    bins = O.initial_bins(n, counts[0], t0 if training else None)
+    for lvl, c in enumerate(peaks):
+        eu = O.uniform_to_euclidean(bins, nears, fars)
+        assert_close(f"level {lvl} bins", samples_list[lvl].flat_bins, bins, rtol=0, atol=1e-5)
+        dens = 6.0 * torch.exp(-4.0 * ((eu[:, :-1] + eu[:, 1:]) / 2 - c) ** 2)
+        w = O.weights_from_density(dens, eu[:, 1:] - eu[:, :-1])
+        assert_close(f"level {lvl} weights", weights_list[lvl][..., 0], w, rtol=1e-4, atol=1e-6)
+        bins = O.pdf_sample(w, bins, counts[1] if lvl == 0 else s_final, u if training else None)
+    eu = O.uniform_to_euclidean(bins, nears, fars)
+    assert_close("final bins", rs.flat_bins, bins, rtol=0, atol=2e-5)
+    assert_close("final starts", rs.flat_starts, eu[:, :-1], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("training", [True, False])
 def test_uniform_sampler(device, training):
     from sdfstudio_amd.model_components.ray_samplers import UniformSampler
 
@@ -283,6 +316,36 @@ def test_neus_model_against_reference_golden(device, mode):
 
         _, basis = relu_flip_basis(oracle_backward, margin=3e-5)
         assert_grads_close_mod_relu_flips(got, g["grad"], basis, rtol=5e-3)
+
+
+def test_neus_sampler_per_sample_jitter(device):
+    """NeuSSampler(single_jitter=False) (ray_samplers.py:825, 836-840): the initial UniformSampler draws one offset per bin edge
+    (:107-110) and every PDF resampling one per NEW bin edge (:321-330).  Whole sampler against the oracle's, on a sphere sdf
+    that both sides evaluate at the frustum start positions."""
+    from sdfstudio_amd.model_components.ray_samplers import NeuSSampler
+
+    n, S, n_imp, steps = 41, 24, 32, 4
+    o, d, cam = O.synthetic_rays(n, seed=8)
+    rb = _bundle(o, d, cam, 0.5, 4.5, device)
+    gen = torch.Generator().manual_seed(3)
+    rand = [torch.rand(n, S + 1, generator=gen)] + [torch.rand(n, n_imp // steps + 1, generator=gen) for _ in range(steps)]
+    smp = NeuSSampler(num_samples=S, num_samples_importance=n_imp, num_upsample_steps=steps, single_jitter=False).train(True)
+    smp.uniform_sampler.jitter_override = rand[0].to(device)
+    smp.jitter_overrides = [r.to(device) for r in rand[1:]]
+    rs = smp(rb, sdf_fn=lambda r: r.frustums.get_start_positions().norm(dim=-1, keepdim=True) - 1.0)
+    nears, fars = torch.full((n,), 0.5), torch.full((n,), 4.5)
+    bins, starts, ends = O.neus_sampler(o, d, nears, fars, lambda t: (o[:, None, :] + d[:, None, :] * t[..., None]).norm(dim=-1) - 1.0,
+                                        num_samples=S, num_samples_importance=n_imp, num_upsample_steps=steps, rand=rand)
+    # histogram_padding 1e-5: cdf increments down to ~1e-6, one fp32 ulp of the cdf moves an edge by 1e-4 of a bin (see the step test)
+    assert_close("bins", rs.flat_bins, bins, rtol=0, atol=1e-4)
+    assert_close("starts", rs.flat_starts, starts, rtol=0, atol=5e-4)
+    assert float((rs.flat_bins[:, 1:] - rs.flat_bins[:, :-1]).min()) >= 0.0
+    # and the draws really are per sample: a single-jitter run with the first column of every draw gives different bins
+    smp1 = NeuSSampler(num_samples=S, num_samples_importance=n_imp, num_upsample_steps=steps, single_jitter=True).train(True)
+    smp1.uniform_sampler.jitter_override = rand[0][:, :1].to(device)
+    smp1.jitter_overrides = [r[:, 0].to(device) for r in rand[1:]]
+    rs1 = smp1(rb, sdf_fn=lambda r: r.frustums.get_start_positions().norm(dim=-1, keepdim=True) - 1.0)
+    assert float((rs1.flat_bins - rs.flat_bins).abs().max()) > 1e-3
 
 
 # ------------------------------------------------------------------------------------------------ VolSDF sampler
@@ -686,6 +749,33 @@ def test_field_small_expanded_cotangents(device):
     model.zero_grad()
     (scales[0] * sdf.sum() + scales[1] * grad.sum() + scales[2] * rgb.sum()).backward()  # all three cotangents are expands
     _check_field_grads(model, po)
+
+
+def test_field_without_weight_norm(device):
+    """SDFFieldConfig(weight_norm=False) (sdf_field.py:146, 312-313, 360-361): plain nn.Linear layers named glin{l}.weight / .bias.  The
+    golden network with its weight-norm folded (W = g v / |v|) must give the same outputs, and the gradients arrive on .weight."""
+    g = load_golden("train")
+    cfg = small_oracle_cfg()
+    plain = {}
+    for k, v in g["param"].items():
+        if k.endswith(".weight_g"):
+            continue
+        if k.endswith(".weight_v"):
+            plain[k[: -len("_v")]] = O.fold_weight_norm(v, g["param"][k[: -len("_v")] + "_g"])
+        else:
+            plain[k] = v
+    model = product_model_from_params(plain, cfg, device, field_kwargs={"weight_norm": False}).train()
+    names = dict(model.field.named_parameters())
+    assert "glin0.weight" in names and "glin0.weight_v" not in names and "clin2.weight" in names
+    n, s = 23, 9
+    o, d, cam, starts = _field_case(cfg, plain, n, s, seed=21)
+    coefs = [torch.randn(n, s), torch.randn(n, s, 3) * 0.3, torch.randn(n, s, 3)]
+    fo, po = _oracle_field(cfg.field, plain, o, d, cam, starts, coefs)
+    sdf, grad, rgb, _ = _product_field(model, o, d, cam, starts, coefs, device)
+    assert_close("sdf", sdf, fo["sdf"], rtol=0, atol=1e-5)
+    assert_close("gradient", grad, fo["gradient"], rtol=1e-4, atol=1e-5)
+    assert_close("rgb", rgb, fo["rgb"], rtol=0, atol=2e-5)
+    _check_field_grads(model, po, min_checked=19)
 
 
 def test_field_small_level_mask_and_reference_style_outputs(device):
