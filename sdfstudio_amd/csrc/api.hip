@@ -661,14 +661,23 @@ extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, c
   return 0;
 }
 
-__global__ void sdfrow_reduce_kernel(const float* __restrict__ partial, const int n_split, const int stride, const int hidden,
-                                     float* __restrict__ w_row, float* __restrict__ b0) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= stride) return;
+// block = 32 columns x 32 split lanes (a thread sums n_split / 32 partials, the lanes combine through LDS); grid = ceil(stride / 32).
+// (One thread per column over all 256 splits was 256 dependent round trips: 0.10 ms for 288 sums.)
+__global__ __launch_bounds__(1024) void sdfrow_reduce_kernel(const float* __restrict__ partial, const int n_split, const int stride,
+                                                             const int hidden, float* __restrict__ w_row, float* __restrict__ b0) {
+  __shared__ float red[32][33];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), r0 = threadIdx.x >> 5;
   float s = 0.0f;
-  for (int k = 0; k < n_split; ++k) s += partial[(size_t)k * stride + i];
-  if (i < hidden) w_row[i] = s;
-  if (i == stride - 32) b0[0] = s;
+  if (c < stride)
+    for (int k = r0; k < n_split; k += 32) s += partial[(size_t)k * stride + c];
+  red[r0][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (r0 == 0 && c < stride) {
+#pragma unroll
+    for (int r = 1; r < 32; ++r) s += red[r][threadIdx.x & 31];
+    if (c < hidden) w_row[c] = s;
+    if (c == stride - 32) b0[0] = s;
+  }
 }
 
 static void run_wgrad(const SdfHipField* f, const FieldWs& w, const WgradArgs& base, int rowmap, int colmap, int64_t w_off, int ld,
@@ -718,7 +727,7 @@ static void run_wgrad(const SdfHipField* f, const FieldWs& w, const WgradArgs& b
   r.accumulate = 0;
   const int total = r.rows * r.cols;
   // 256 elements per block; the bias rows (64 per block) need ceil(rows / 64) blocks, which rows * cols / 256 covers for cols >= 4
-  { ProfScope ps_(PS_WREDUCE, s); wreduce_kernel<<<(unsigned)std::max((total + 255) / 256, (r.rows + 63) / 64), 256, 0, s>>>(r); }
+  { ProfScope ps_(PS_WREDUCE, s); wreduce_kernel<<<(unsigned)std::max((total + 255) / 256, (r.rows + 63) / 64), 64 * kWrG, 0, s>>>(r); }
 }
 
 static TpOperand seg1(const float* p, int nb) {
@@ -779,7 +788,7 @@ static void run_geo_wgrads(const SdfHipField* f, const FieldWs& w, const bool ta
     const int tps = (int)((n_tiles + w.n_split - 1) / w.n_split);
     { ProfScope ps_(PS_WGRAD, s); k->sdfrow(w.u[f->nl - 1], tangent ? w.qb[f->nl] : nullptr, w.sdfbar, n_tiles, tps, w.partial, (unsigned)w.n_split, s); }
     const int stride = k->nbh * 32 + 32;
-    sdfrow_reduce_kernel<<<(stride + 255) / 256, 256, 0, s>>>(w.partial, w.n_split, stride, f->cfg.hidden_dim, theta_bar + li.w_off,
+    sdfrow_reduce_kernel<<<(stride + 31) / 32, 1024, 0, s>>>(w.partial, w.n_split, stride, f->cfg.hidden_dim, theta_bar + li.w_off,
                                                               theta_bar + li.b_off);
   }
 }
@@ -1271,7 +1280,7 @@ extern "C" int sdfhip_proposal_backward(const SdfHipGridCfg* grid, const float* 
   a.tablebar = table_bar;
   a.wpartial = (float*)workspace;
   { ProfScope ps_(PS_PROP_BWD, s); prop_bwd_kernel<<<kPropBwdBlocks, 256, 0, s>>>(a); }
-  colsum_kernel<<<(176 + 31) / 32, 256, 0, s>>>(a.wpartial, kPropBwdBlocks, 176, 176, w1_bar, 160, w2_bar);
+  colsum_kernel<<<(176 + 31) / 32, 1024, 0, s>>>(a.wpartial, kPropBwdBlocks, 176, 176, w1_bar, 160, w2_bar);
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1529,7 +1538,7 @@ extern "C" int sdfhip_surface_loss_forward(const float* rgb, const float* image,
   a.partial = workspace;
   a.loss = loss4;
   surface_loss_partial_kernel<<<(unsigned)a.n_blocks, 256, 0, (hipStream_t)stream>>>(a);
-  surface_loss_finish_kernel<<<1, 64, 0, (hipStream_t)stream>>>(a);
+  surface_loss_finish_kernel<<<1, 256, 0, (hipStream_t)stream>>>(a);
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }

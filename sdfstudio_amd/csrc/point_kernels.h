@@ -611,19 +611,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
 }
 
 // Column sums of the per-block partials: out1[i] = sum_k partial[k][i] (i < n1), out2[i - n1] = sum_k partial[k][i] (i >= n1).
-// Block = 32 columns x 8 row lanes (coalesced 128-byte row segments), rows strided by 8, LDS tree over the row lanes.
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ partial, const int n_rows, const int n_cols, const int row_stride,
-                                                     float* __restrict__ out1, const int n1, float* __restrict__ out2) {
-  __shared__ float red[8][33];
+// Block = 32 columns x 32 row lanes (coalesced 128-byte row segments), rows strided by 32 (1024 rows: 32 dependent loads per thread, where
+// 8 row lanes made 128), LDS sum over the row lanes.
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ partial, const int n_rows, const int n_cols, const int row_stride,
+                                                      float* __restrict__ out1, const int n1, float* __restrict__ out2) {
+  __shared__ float red[32][33];
   const int c = blockIdx.x * 32 + (threadIdx.x & 31), r0 = threadIdx.x >> 5;
   float s = 0.0f;
   if (c < n_cols)
-    for (int k = r0; k < n_rows; k += 8) s += partial[(size_t)k * row_stride + c];
+    for (int k = r0; k < n_rows; k += 32) s += partial[(size_t)k * row_stride + c];
   red[r0][threadIdx.x & 31] = s;
   __syncthreads();
   if (r0 == 0 && c < n_cols) {
 #pragma unroll
-    for (int r = 1; r < 8; ++r) s += red[r][threadIdx.x & 31];
+    for (int r = 1; r < 32; ++r) s += red[r][threadIdx.x & 31];
     if (c < n1) out1[c] = s;
     else out2[c - n1] = s;
   }

@@ -157,12 +157,21 @@ __global__ __launch_bounds__(256) void surface_loss_partial_kernel(const Surface
   if (threadIdx.x < SL_COUNT) a.partial[(size_t)blockIdx.x * SL_COUNT + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 // one block: loss_k = scale_k * sum over blocks (double accumulation, fixed order)
-__global__ __launch_bounds__(64) void surface_loss_finish_kernel(const SurfaceLossArgs a) {
-  const int k = threadIdx.x;
-  if (k >= SL_COUNT) return;
+// one block of 256: thread t sums the partials of loss t % SL_COUNT over blocks t / SL_COUNT, + 64, ... in double, the 64 lanes of a loss
+// combine through LDS (one thread per loss over all blocks was ~1000 dependent round trips: 45 us for four numbers)
+__global__ __launch_bounds__(256) void surface_loss_finish_kernel(const SurfaceLossArgs a) {
+  __shared__ double red[256];
+  static_assert(256 % SL_COUNT == 0, "lanes per loss");
+  const int k = threadIdx.x % SL_COUNT, g = threadIdx.x / SL_COUNT;
   double s = 0.0;
-  for (int b = 0; b < a.n_blocks; ++b) s += (double)a.partial[(size_t)b * SL_COUNT + k];
-  a.loss[k] = (float)(s * (double)a.scale[k]);
+  for (int b = g; b < a.n_blocks; b += 256 / SL_COUNT) s += (double)a.partial[(size_t)b * SL_COUNT + k];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x < SL_COUNT) {
+    double t = 0.0;
+    for (int j = 0; j < 256 / SL_COUNT; ++j) t += red[j * SL_COUNT + threadIdx.x];
+    a.loss[threadIdx.x] = (float)(t * (double)a.scale[threadIdx.x]);
+  }
 }
 // elementwise backward; grid-stride over max(N, P)
 __global__ __launch_bounds__(256) void surface_loss_bwd_kernel(const SurfaceLossArgs a) {

@@ -462,15 +462,19 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16x8_kernel(const WgradArgs a)
 
   for (int i = tid; i < kW8LdsBytes / 16; i += 512) reinterpret_cast<f32x4*>(ldsb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // staging role: slot `wave` (A block ob_base + wave) and slot 8 + wave (B block ib_base + wave)
+  // staging role: slot `wave` (A block ob_base + wave) and slot 8 + wave (B block ib_base + wave).  A slot beyond the operand's extent
+  // stages a copy of the operand's LAST block (clamped index: the loads hit the cache behind the wave that owns that block) - it feeds
+  // accumulator blocks that are never written back.  That keeps the whole pipeline below free of branches, which is what lets the
+  // compiler's s_waitcnt insertion count the loads in flight exactly (see the loop).
   const int slot[2] = {wave, 8 + wave};
-  const bool valid[2] = {ob_base + wave < a.nba, ib_base + wave < a.nbb};
+  const bool valid0 = ob_base + wave < a.nba;
   const float* src0[2];
   const float* src1[2];
   int stride0[2], stride1[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
-    const int blk = q == 0 ? ob_base + wave : ib_base + wave;
+    const int want = q == 0 ? ob_base + wave : ib_base + wave;
+    const int blk = min(want, (q == 0 ? a.nba : a.nbb) - 1);
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
       const TpOperand& op = q == 0 ? a.A[pr] : a.B[pr];
@@ -487,32 +491,37 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16x8_kernel(const WgradArgs a)
       }
     }
   }
+  if (a.n_pairs < 2) {  // pair 1 absent: never selected below (p1 is false for every stage), but keep the pointers valid
+    src1[0] = src0[0], src1[1] = src0[1];
+    stride1[0] = stride0[0], stride1[1] = stride0[1];
+  }
 
-  // operand tile in flight from HBM, one stage ahead of its split (a second stage in flight measured no faster and its 32
-  // registers push the 2 x 4 patch kernel into spills)
+  // Operand tile in flight from HBM: 8 staging units per wave and stage (unit u = 16-byte piece u & 3 of slot u >> 2), each in its own
+  // four registers.  The load of unit u of stage st + 2 is issued the moment unit u of stage st + 1 has been consumed, so every load has
+  // a whole stage to return and 8 are in flight per wave at all times; its consumer waits with vmcnt(7) - the seven younger loads stay
+  // in flight.  (Until round 3 the eight loads of a stage were issued together at the end of the previous one, behind validity branches:
+  // the compiler had to wait for five of them before the FIRST unit and the HBM latency was exposed once per stage.)
   f32x4 pre[2][4];
-  auto load_stage = [&](const int st) __attribute__((always_inline)) {
+  auto load_unit = [&](const int st_want, auto qc, auto ic) __attribute__((always_inline)) {
+    constexpr int q = decltype(qc)::value, i = decltype(ic)::value;
+    const int st = min(st_want, n_stage - 1);  // past the end: re-load the last stage (never consumed into a buffer that is read)
     const bool p1 = st >= n_t;
     const int64_t tile = t0 + (p1 ? st - n_t : st);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (!valid[q]) continue;
-      const float* base = p1 ? src1[q] : src0[q];
-      const int stride = p1 ? stride1[q] : stride0[q];
-      const f32x4* src = reinterpret_cast<const f32x4*>(base + (size_t)tile * stride) + lane;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) pre[q][i] = src[i * 64];
-    }
+    const float* base = p1 ? src1[q] : src0[q];
+    const int stride = p1 ? stride1[q] : stride0[q];
+    pre[q][i] = reinterpret_cast<const f32x4*>(base + (size_t)tile * stride)[lane + i * 64];
   };
   // one staging unit = one f32x4 (4 consecutive points of one TP row) of slot q: bias column sums, bf16 hi / lo split, two 8-byte LDS writes
   auto store_unit = [&](const int st, auto qc, auto ic) __attribute__((always_inline)) {
     constexpr int q = decltype(qc)::value, i = decltype(ic)::value;
-    if (!valid[q]) return;
     const bool p1 = st >= n_t;
     // lane holds, for i = 0..3, TP row r = 4 i + (lane >> 4), half (lane >> 3) & 1, points 4 (lane & 7) .. + 3
     __bf16* dst = ldsb + (st & 1) * kWbBuf + slot[q] * kWbSlot + (lane & 7) * 4;
-    f32x4 v = pre[q][i];
-    if (q == 0 && !p1) colsum[i] += (v[0] + v[1]) + (v[2] + v[3]);
+    const f32x4 v = pre[q][i];
+    if (q == 0) {
+      const float t = (v[0] + v[1]) + (v[2] + v[3]);
+      colsum[i] += p1 ? 0.0f : t;  // pair 0 only; "stage n_stage" (staged behind the last one, never multiplied) has st >= n_t as well
+    }
     bf16x4 hi, lo;
 #ifdef SDFHIP_ABL_WGRAD_NOSPLIT  // timing ablation (wrong numerics): what the staging pass would cost if the operands arrived split
     {
@@ -534,29 +543,29 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16x8_kernel(const WgradArgs a)
     *reinterpret_cast<bf16x4*>(dst + f * kWbRow) = hi;
     *reinterpret_cast<bf16x4*>(dst + kWbTile + f * kWbRow) = lo;
   };
-  auto store_stage = [&](const int st) __attribute__((always_inline)) {
+
+  if (n_stage > 0) {
     static_for<0, 8>([&](auto uc) __attribute__((always_inline)) {
       constexpr int u = decltype(uc)::value;
-      store_unit(st, std::integral_constant<int, (u >> 2)>{}, std::integral_constant<int, (u & 3)>{});
+      load_unit(0, std::integral_constant<int, (u >> 2)>{}, std::integral_constant<int, (u & 3)>{});
     });
-  };
-
-  if (n_stage > 0) load_stage(0);
-  __syncthreads();  // the zero fill has landed (slots without a block stay zero)
-  if (n_stage > 0) {
-    store_stage(0);
-    if (n_stage > 1) load_stage(1);
+    __syncthreads();  // the zero fill has landed
+    static_for<0, 8>([&](auto uc) __attribute__((always_inline)) {
+      constexpr int u = decltype(uc)::value;
+      store_unit(0, std::integral_constant<int, (u >> 2)>{}, std::integral_constant<int, (u & 3)>{});
+      load_unit(1, std::integral_constant<int, (u >> 2)>{}, std::integral_constant<int, (u & 3)>{});
+    });
   }
   // lane (row = lane & 31, k half = lane >> 5) reads 8 consecutive points of "its" feature row
   const int frag = (lane & 31) * kWbRow + 8 * (lane >> 5);
   // One stage: 6 NA NB MFMAs on buffer st & 1 with the eight staging units of stage st + 1 (VALU + ds_write into the other
-  // buffer) placed between them at equal distances and pinned there.  The two waves of a SIMD share its matrix pipe: whichever
-  // loses the arbitration for a run of MFMAs falls behind by that run and from then on does its VALU unit while the partner
-  // multiplies - the pattern settles into complementary phases instead of both waves sitting in their VALU part together.
+  // buffer, then the global load of the same unit of stage st + 2) placed between them at equal distances and pinned there.  The two
+  // waves of a SIMD share its matrix pipe: whichever loses the arbitration for a run of MFMAs falls behind by that run and from then
+  // on does its VALU unit while the partner multiplies - the pattern settles into complementary phases instead of both waves sitting
+  // in their VALU part together.  The last iteration stages a "stage n_stage" nobody reads (no branch: see above).
   constexpr int M = 6 * NA * NB;
   for (int st = 0; st < n_stage; ++st) {
     __syncthreads();  // stage st is complete in buffer st & 1; everybody is done reading the other buffer (stage st - 1)
-    const bool more = st + 1 < n_stage;
     const __bf16* la = ldsb + (st & 1) * kWbBuf + qi * kWbSlot + frag;
     const __bf16* lb = ldsb + (st & 1) * kWbBuf + (8 + qj) * kWbSlot + frag;
     static_for<0, 2>([&](auto kc) __attribute__((always_inline)) {
@@ -579,17 +588,15 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16x8_kernel(const WgradArgs a)
         constexpr int ulo = (m * 8) / M, uhi = ((m + 1) * 8) / M;      // staging units due after this MFMA
         if constexpr (ulo < uhi) {
           __builtin_amdgcn_sched_barrier(0);
-          if (more) {
-            static_for<ulo, uhi>([&](auto uc) __attribute__((always_inline)) {
-              constexpr int u = decltype(uc)::value;
-              store_unit(st + 1, std::integral_constant<int, (u >> 2)>{}, std::integral_constant<int, (u & 3)>{});
-            });
-          }
+          static_for<ulo, uhi>([&](auto uc) __attribute__((always_inline)) {
+            constexpr int u = decltype(uc)::value;
+            store_unit(st + 1, std::integral_constant<int, (u >> 2)>{}, std::integral_constant<int, (u & 3)>{});
+            load_unit(st + 2, std::integral_constant<int, (u >> 2)>{}, std::integral_constant<int, (u & 3)>{});
+          });
           __builtin_amdgcn_sched_barrier(0);
         }
       });
     });
-    if (st + 2 < n_stage) load_stage(st + 2);
   }
 
   const int ldc = a.nbb * 32;
@@ -614,7 +621,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16x8_kernel(const WgradArgs a)
       t += __shfl_xor(t, 2);
       t += __shfl_xor(t, 4);
       const int ob = ob_base + wave;
-      if (valid[0] && (lane & 7) == 0 && ob < a.nba)
+      if (valid0 && (lane & 7) == 0 && ob < a.nba)
         a.bpartial[(size_t)split * a.nba * 32 + ob * 32 + tp_row(i * 4 + (lane >> 4), (lane >> 3) & 1)] = t;
     }
   }
@@ -670,11 +677,14 @@ struct WreduceArgs {
   int64_t b_off;   // bias gradient destination (index by natural row), or -1
   int32_t accumulate;
 };
-// block = 256 threads = 64 x 4 consecutive elements (one 16-byte load per thread and split: a wave reads 1 KiB per instruction; with
-// 4-byte loads the kernel was bound by the latency of 256-byte requests, PMC: 83 % of its wave cycles parked) x 4 interleaved split
-// groups (each thread sums n_split / 4 partials, 8 loads in flight), combined through LDS; grid = ceil(rows * cols / 256)
-static __global__ __launch_bounds__(256) void wreduce_kernel(const WreduceArgs a) {
-  __shared__ f32x4 red[4][64];
+// block = 64 x kWrG threads: 64 x 4 consecutive elements (one 16-byte load per thread and split: a wave reads 1 KiB per instruction; with
+// 4-byte loads the kernel was bound by the latency of 256-byte requests, PMC: 83 % of its wave cycles parked) x kWrG interleaved split
+// groups, combined through LDS; grid = ceil(rows * cols / 256).  The partials of one element are 256 KiB apart (one per split), so the
+// kernel lives on loads in flight: with 16 groups a thread sums n_split / 16 partials in batches of 8 (256 splits: two round trips to
+// the Infinity Cache where the 4-group version of round 2 made eight).
+constexpr int kWrG = 16;
+static __global__ __launch_bounds__(64 * kWrG) void wreduce_kernel(const WreduceArgs a) {
+  __shared__ f32x4 red[kWrG][64];
   const int ix = threadIdx.x & 63, sg = threadIdx.x >> 6;
   const int total = a.rows * a.cols;  // a multiple of 1024 (both are multiples of 32)
   const int idx = (blockIdx.x * 64 + ix) * 4;
@@ -682,19 +692,21 @@ static __global__ __launch_bounds__(256) void wreduce_kernel(const WreduceArgs a
   if (idx < total) {
     const float* p = a.partial + idx;
     int k = sg;
-    for (; k + 28 < a.n_split; k += 32) {
+    for (; k + 7 * kWrG < a.n_split; k += 8 * kWrG) {
       f32x4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 4 * u) * total);
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(k + kWrG * u) * total);
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += v[u];
     }
-    for (; k < a.n_split; k += 4) s += *reinterpret_cast<const f32x4*>(p + (size_t)k * total);
+    for (; k < a.n_split; k += kWrG) s += *reinterpret_cast<const f32x4*>(p + (size_t)k * total);
   }
   red[sg][ix] = s;
   __syncthreads();
   if (sg == 0 && idx < total) {
-    s = (red[0][ix] + red[1][ix]) + (red[2][ix] + red[3][ix]);
+    s = red[0][ix];
+#pragma unroll
+    for (int g = 1; g < kWrG; ++g) s += red[g][ix];
     const int o = idx / a.cols, i0 = idx % a.cols;  // cols is a multiple of 4: the four elements share the row
     const int nr = a.rowmap[o];
     if (nr >= 0) {
@@ -713,15 +725,18 @@ static __global__ __launch_bounds__(256) void wreduce_kernel(const WreduceArgs a
     const int row = blockIdx.x * 64 + ix;
     float t = 0.0f;
     if (row < a.rows)
-      for (int k = sg; k < a.n_split; k += 4) t += a.bpartial[(size_t)k * a.rows + row];
+      for (int k = sg; k < a.n_split; k += kWrG) t += a.bpartial[(size_t)k * a.rows + row];
     __syncthreads();
     red[sg][ix][0] = t;
     __syncthreads();
     if (sg == 0 && row < a.rows) {
       const int nr = a.rowmap[row];
       if (nr >= 0) {
+        float tot = red[0][ix][0];
+#pragma unroll
+        for (int g = 1; g < kWrG; ++g) tot += red[g][ix][0];
         float* dst = a.theta_bar + a.b_off + nr;
-        *dst = (a.accumulate ? *dst : 0.0f) + ((red[0][ix][0] + red[1][ix][0]) + (red[2][ix][0] + red[3][ix][0]));
+        *dst = (a.accumulate ? *dst : 0.0f) + tot;
       }
     }
   }
