@@ -377,7 +377,8 @@ int sdfhip_neus_render_backward(const float* sdf, const float* grad, const float
  * Optional HIP-event timing of the library's own launches, recorded on the stream each kernel is launched on.
  * enable(1) resets and starts recording; read() waits for the recorded events of a slot and returns the total
  * milliseconds and the number of timed launches.  Off by default; not thread safe. */
-int sdfhip_profile_enable(int enable);          /* returns the number of slots */
+int sdfhip_profile_enable(int enable);          /* every slot on / off; returns the number of slots */
+int sdfhip_profile_enable_slots(uint64_t slot_mask); /* only the slots whose bit is set record (0: off); returns the number of slots */
 const char* sdfhip_profile_name(int slot);
 int sdfhip_profile_read(int slot, double* total_ms, int64_t* count);
 

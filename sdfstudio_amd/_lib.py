@@ -139,6 +139,7 @@ _SIGNATURES = {
     "sdfhip_neus_render_forward": (c_i32, [c_float_p] * 8 + [c_f32, c_i64, c_i32] + [c_float_p] * 8 + [ctypes.c_void_p]),
     "sdfhip_neus_render_backward": (c_i32, [c_float_p] * 8 + [c_f32, c_i64, c_i32] + [c_float_p] * 14 + [ctypes.c_void_p]),
     "sdfhip_profile_enable": (c_i32, [c_i32]),
+    "sdfhip_profile_enable_slots": (c_i32, [ctypes.c_uint64]),
     "sdfhip_profile_name": (ctypes.c_char_p, [c_i32]),
     "sdfhip_profile_read": (c_i32, [c_i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64)]),
 }
@@ -237,6 +238,19 @@ def grid_levels(cfg: GridCfg):
 
 def profile_enable(on: bool) -> int:
     return load().sdfhip_profile_enable(1 if on else 0)
+
+
+def profile_enable_only(names) -> int:
+    """HIP events on the launches of the named slots only (sdfhip_profile_name); every other launch runs un-instrumented."""
+    lib = load()
+    mask = 0
+    n_slots = lib.sdfhip_profile_enable(0)
+    for slot in range(n_slots):
+        if lib.sdfhip_profile_name(slot).decode() in names:
+            mask |= 1 << slot
+    if not mask:
+        raise ValueError(f"no profile slot named any of {list(names)}")
+    return lib.sdfhip_profile_enable_slots(mask)
 
 
 def profile_collect():

@@ -47,6 +47,7 @@ static const char* kProfNames[PS_COUNT] = {
     "prop_bwd_kernel", "neus_render_fwd_kernel", "neus_render_bwd_kernel", "density_weights_kernels", "sampler_kernels"};
 struct ProfState {
   bool enabled = false;
+  uint64_t mask = ~0ull;  // slots that record (sdfhip_profile_enable_slots)
   std::vector<hipEvent_t> start[PS_COUNT], stop[PS_COUNT];
   size_t used[PS_COUNT] = {};
 };
@@ -55,7 +56,7 @@ struct ProfScope {
   int slot;
   hipStream_t s;
   bool on;
-  ProfScope(int slot_, hipStream_t s_) : slot(slot_), s(s_), on(g_prof.enabled) {
+  ProfScope(int slot_, hipStream_t s_) : slot(slot_), s(s_), on(g_prof.enabled && ((g_prof.mask >> slot_) & 1ull)) {
     if (!on) return;
     if (g_prof.used[slot] == g_prof.start[slot].size()) {
       hipEvent_t a, b;
@@ -74,6 +75,17 @@ struct ProfScope {
 };
 extern "C" int sdfhip_profile_enable(int enable) {
   g_prof.enabled = enable != 0;
+  g_prof.mask = ~0ull;
+  for (int i = 0; i < PS_COUNT; ++i) g_prof.used[i] = 0;
+  return PS_COUNT;
+}
+// Events on the launches of the selected slots only (bit i = slot i).  An event pair serialises the command stream around its launch
+// (the next dispatch cannot be set up under the tail of the previous kernel), ~10 - 40 us per pair on MI355X: with every launch of a
+// training step instrumented that is ~1 ms per step of measurement overhead, so bench.py times the step with events on the dominant
+// kernel alone and fills its per-kernel table from a separate pass.
+extern "C" int sdfhip_profile_enable_slots(uint64_t slot_mask) {
+  g_prof.enabled = slot_mask != 0;
+  g_prof.mask = slot_mask;
   for (int i = 0; i < PS_COUNT; ++i) g_prof.used[i] = 0;
   return PS_COUNT;
 }

@@ -140,7 +140,11 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
   f32x16 accIn[D::NBH], accOut[D::MAXO];
   Raw carry;
   auto in0_blk0 = [&]() __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(a.in0_tp, tile, D::NB0, 0)}}; };
-  constexpr int ZS = (SAVE || GRAD) ? 16 : 0;  // z stores per produced block
+#ifdef SDFHIP_ABL_FWD_NOSTORE
+  constexpr int ZS = 0;
+#else
+  constexpr int ZS = (SAVE || GRAD) ? 16 : 0;  // activation stores per produced block
+#endif
 
   if constexpr (PHASE == 2) carry = load_src(chain_first_src(), lane);
   if constexpr (PHASE != 2) {
@@ -161,7 +165,9 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
       auto make = [&](auto kbc, const Raw&, auto ec) __attribute__((always_inline)) {
         constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
         const float h = act_h<D::ACT>(accIn[kb][e]);
+#ifndef SDFHIP_ABL_FWD_NOSTORE  // timing ablation: the forward launch without its activation stores
         if constexpr (SAVE || GRAD) *tp_elem(uprev, tile, D::NBH, kb, e, lane) = h;
+#endif
         return h;
       };
       const float* nxt = l == SKIP ? geo_skip_in0<D>(a.p.wp[l]) : (l + 1 < NL ? a.p.wp[l + 1] : after_last);

@@ -225,7 +225,12 @@ SDFHIP_D void tp_gemm(f32x16 (&acc)[MAXA], Raw& carry, Fetch&& fetch, Make&& mak
     constexpr bool more = kb + 1 < KB;
     {
       // vector-memory operations issued after the DMA of chunk kb: the loads of fetch(kb + 1), then the stores of make(kb)
-      constexpr int newer = ST::at(kb) + (more ? 16 * decltype(fetch(IC<(more ? kb + 1 : 0)>{}))::n : 0);
+      constexpr int newer_ = ST::at(kb) + (more ? 16 * decltype(fetch(IC<(more ? kb + 1 : 0)>{}))::n : 0);
+#ifdef SDFHIP_ABL_WAIT_SLACK  // timing ablation (RACY: the chunk may not have landed): what the wait for the weight DMA costs through the
+      constexpr int newer = newer_ + SDFHIP_ABL_WAIT_SLACK;  // older stores it also waits for (vmcnt retires in issue order)
+#else
+      constexpr int newer = newer_;
+#endif
       ws.template wait_sync<(newer < 63 ? newer : 63)>();
     }
     r1 = r2;

@@ -102,6 +102,15 @@ struct WgradArgs {
   float* bpartial;       // [n_split][nba*32]   column sums of pair 0's A   (may be null)
 };
 
+// Split-K partials are stored chunk-major: element idx = row * cols + col of split s lives at  P[idx / 256][s][idx % 256], so the
+// 256 partials of 256 consecutive elements are ONE contiguous 256 KiB run that a wreduce block streams (split-major [s][rows][cols]
+// put them 256 KiB apart: every load of the reduction opened a new page, 62 us for 64 MB out of the Infinity Cache).  A wave of the
+// GEMM still writes whole 128-byte segments (32 consecutive columns of a row never straddle a chunk).
+SDFHIP_D size_t wg_partial_index(const int split, const int n_split, const int row, const int col, const int ldc) {
+  const int idx = row * ldc + col;
+  return ((size_t)(idx >> 8) * n_split + split) * 256 + (idx & 255);
+}
+
 constexpr int kWgRow = 36;              // floats per LDS row (32 points + 4 pad: 16-byte aligned, bank-spreading)
 constexpr int kWgBlk = 32 * kWgRow;     // floats per staged block
 constexpr int kWgLdsBytes = 16 * kWgBlk * 4;
@@ -228,7 +237,6 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
   }
 
   const int ldc = a.nbb * 32;
-  float* C = a.partial + (size_t)split * a.nba * 32 * ldc;
   const int hf = lane >> 5;
 #pragma unroll
   for (int i = 0; i < NA; ++i)
@@ -237,7 +245,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_kernel(const WgradArgs a) {
       const int ob = ob_base + qi + 2 * i, ib = ib_base + qj + 2 * j;
       if (qi + 2 * i < 8 && qj + 2 * j < 8 && ob < a.nba && ib < a.nbb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) C[(size_t)(ob * 32 + tp_row(r, hf)) * ldc + ib * 32 + (lane & 31)] = acc[i][j][r];
+        for (int r = 0; r < 16; ++r)
+          a.partial[wg_partial_index(split, (int)gridDim.x, ob * 32 + tp_row(r, hf), ib * 32 + (lane & 31), ldc)] = acc[i][j][r];
       }
     }
   if (a.bpartial != nullptr && ib_base == 0 && qj == 0) {
@@ -398,7 +407,6 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
   }
 
   const int ldc = a.nbb * 32;
-  float* C = a.partial + (size_t)split * a.nba * 32 * ldc;
   const int hf = lane >> 5;
 #pragma unroll
   for (int i = 0; i < NA; ++i)
@@ -407,7 +415,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16_kernel(const WgradArgs a) {
       const int ob = ob_base + qi + 2 * i, ib = ib_base + qj + 2 * j;
       if (qi + 2 * i < 8 && qj + 2 * j < 8 && ob < a.nba && ib < a.nbb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) C[(size_t)(ob * 32 + tp_row(r, hf)) * ldc + ib * 32 + (lane & 31)] = acc[i][j][r];
+        for (int r = 0; r < 16; ++r)
+          a.partial[wg_partial_index(split, (int)gridDim.x, ob * 32 + tp_row(r, hf), ib * 32 + (lane & 31), ldc)] = acc[i][j][r];
       }
     }
   if (a.bpartial != nullptr && ib_base == 0) {
@@ -600,7 +609,6 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16x8_kernel(const WgradArgs a)
   }
 
   const int ldc = a.nbb * 32;
-  float* C = a.partial + (size_t)split * a.nba * 32 * ldc;
   const int hf = lane >> 5;
 #pragma unroll
   for (int i = 0; i < NA; ++i)
@@ -609,7 +617,8 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16x8_kernel(const WgradArgs a)
       const int ob = ob_base + qi + 4 * i, ib = ib_base + qj + 2 * j;
       if (qi + 4 * i < 8 && qj + 2 * j < 8 && ob < a.nba && ib < a.nbb) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) C[(size_t)(ob * 32 + tp_row(r, hf)) * ldc + ib * 32 + (lane & 31)] = acc[i][j][r];
+        for (int r = 0; r < 16; ++r)
+          a.partial[wg_partial_index(split, (int)gridDim.x, ob * 32 + tp_row(r, hf), ib * 32 + (lane & 31), ldc)] = acc[i][j][r];
       }
     }
   if (a.bpartial != nullptr && ib_base == 0) {
@@ -679,9 +688,8 @@ struct WreduceArgs {
 };
 // block = 64 x kWrG threads: 64 x 4 consecutive elements (one 16-byte load per thread and split: a wave reads 1 KiB per instruction; with
 // 4-byte loads the kernel was bound by the latency of 256-byte requests, PMC: 83 % of its wave cycles parked) x kWrG interleaved split
-// groups, combined through LDS; grid = ceil(rows * cols / 256).  The partials of one element are 256 KiB apart (one per split), so the
-// kernel lives on loads in flight: with 16 groups a thread sums n_split / 16 partials in batches of 8 (256 splits: two round trips to
-// the Infinity Cache where the 4-group version of round 2 made eight).
+// groups, combined through LDS; grid = ceil(rows * cols / 256): one block streams the contiguous [n_split][256] run of its chunk
+// (wg_partial_index), a thread sums n_split / 16 partials in batches of 8.
 constexpr int kWrG = 16;
 static __global__ __launch_bounds__(64 * kWrG) void wreduce_kernel(const WreduceArgs a) {
   __shared__ f32x4 red[kWrG][64];
@@ -690,16 +698,16 @@ static __global__ __launch_bounds__(64 * kWrG) void wreduce_kernel(const Wreduce
   const int idx = (blockIdx.x * 64 + ix) * 4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (idx < total) {
-    const float* p = a.partial + idx;
+    const float* p = a.partial + (size_t)(idx >> 8) * a.n_split * 256 + (idx & 255);  // chunk-major (wg_partial_index): split stride 256
     int k = sg;
     for (; k + 7 * kWrG < a.n_split; k += 8 * kWrG) {
       f32x4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(k + kWrG * u) * total);
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(k + kWrG * u) * 256);
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += v[u];
     }
-    for (; k < a.n_split; k += kWrG) s += *reinterpret_cast<const f32x4*>(p + (size_t)k * total);
+    for (; k < a.n_split; k += kWrG) s += *reinterpret_cast<const f32x4*>(p + (size_t)k * 256);
   }
   red[sg][ix] = s;
   __syncthreads();

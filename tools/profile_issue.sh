@@ -5,7 +5,7 @@ TAG=${1:-r1}
 R=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $R
 cd /tmp && export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 2 --warmup 1"
+B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-kernel-table --steps 2 --warmup 1"
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT \
   --output-format csv -d $R/pmc_issue -o p -- $B > $R/pmc_issue.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_ACTIVE_INST_MISC \

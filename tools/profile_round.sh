@@ -9,7 +9,7 @@ R=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $R
 cd /tmp && export TMPDIR=/tmp
 B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline $EXTRA"
-BP="$B --no-forward-only"  # PMC passes: training steps only, so launches / steps = launches per step
+BP="$B --no-forward-only --no-kernel-table"  # PMC passes: training steps only, so launches / steps = launches per step
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/kt -o kt -- $B --steps 10 --warmup 3 > $R/kt.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/pmc_fetch -o p -- $BP --steps 2 --warmup 1 > $R/pmc_fetch.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/pmc_write -o p -- $BP --steps 2 --warmup 1 > $R/pmc_write.log 2>&1
