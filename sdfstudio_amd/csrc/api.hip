@@ -978,7 +978,8 @@ extern "C" int sdfhip_geo_backward_n(const SdfHipField* f, const float* packed, 
   ga.tablebar = table_bar;
   if (f->grid.n_levels > 0) {  // NeRFField has no grid
     ProfScope ps_(PS_GRID_BWD, s);
-    grid_bwd_kernel<<<dim3((unsigned)((P + 255) / 256), f->grid.n_levels * (f->grid.n_features / 2)), 256, 0, s>>>(ga);
+    if (f->grid.n_features == 8) grid_bwd8_kernel<<<dim3((unsigned)((P + 255) / 256), f->grid.n_levels), 256, 0, s>>>(ga);
+    else grid_bwd_kernel<<<dim3((unsigned)((P + 255) / 256), f->grid.n_levels * (f->grid.n_features / 2)), 256, 0, s>>>(ga);
   }
 
   run_geo_wgrads(f, w, false, NP / 32, theta_bar, s);
@@ -1222,7 +1223,11 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
     SDFHIP_CHECK_HIP(hipStreamWaitEvent(g_side.stream, g_side.fork, 0));
     gs = g_side.stream;
   }
-  { ProfScope ps_(PS_GRID_BWD, gs); grid_bwd_kernel<<<dim3((unsigned)((P + 255) / 256), f->grid.n_levels * (f->grid.n_features / 2)), 256, 0, gs>>>(ga); }
+  {
+    ProfScope ps_(PS_GRID_BWD, gs);
+    if (f->grid.n_features == 8) grid_bwd8_kernel<<<dim3((unsigned)((P + 255) / 256), f->grid.n_levels), 256, 0, gs>>>(ga);
+    else grid_bwd_kernel<<<dim3((unsigned)((P + 255) / 256), f->grid.n_levels * (f->grid.n_features / 2)), 256, 0, gs>>>(ga);
+  }
   if (forked) SDFHIP_CHECK_HIP(hipEventRecord(g_side.join, gs));
 
   // 5. weight gradients: split-K GEMMs over points

@@ -443,6 +443,107 @@ __global__ __launch_bounds__(256) void grid_bwd_kernel(const GridBwdArgs a) {
   scatter_stage_flush(st, lane, a.tablebar, F, pair * 2);
 }
 
+// ---- 8 features per entry (BASELINE config 5: 16 x 8 x 2^22): one entry is 32 bytes, an x-pair of entries one 64-byte line.  With one
+// feature PAIR per block (the kernel above) the four pair-blocks of a level each touch every line of the level again - 4 lanes per line
+// and instruction.  Here one block scatters all 8 features of a level: an instruction carries, in lanes 16 i .. 16 i + 15, the x-pair x
+// 8 features of one corner pair of point 4 q + i - whole lines, 4 per instruction instead of 16, a quarter of the (instruction, line)
+// pairs the memory-side atomic unit is priced by (tools/probe_atomic.hip: 84 -> 334 G adds/s).
+template <int NV>
+SDFHIP_D bool wave_run_reduce_n(const uint32_t idx, const bool active, float (&v)[NV]) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t key = active ? idx : 0xffffffffu;
+  const uint32_t prev = __shfl_up(key, 1);
+  const uint32_t next = __shfl_down(key, 1);
+  int head = (lane == 0) || (prev != key);
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    float u[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) u[i] = __shfl_up(v[i], d);
+    const int uh = __shfl_up(head, d);
+    if (lane >= d && !head) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] += u[i];
+      head |= uh;
+    }
+  }
+  return active && ((lane == 63) || (next != key));
+}
+struct ScatterStage8 {
+  float v[64][33];     // [point of the wave][(corner & 3) * 8 + feature]: four corners at a time, row padded against bank conflicts
+  uint32_t e[64][5];   // [point][corner & 3] table entry, or kNoEntry
+};
+// grid = (ceil(P/256), n_levels): all 8 features of one level per y
+__global__ __launch_bounds__(256) void grid_bwd8_kernel(const GridBwdArgs a) {
+  __shared__ ScatterStage8 stage[4];
+  const int lane = threadIdx.x & 63;
+  ScatterStage8& st = stage[threadIdx.x >> 6];
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = p < a.n_points;
+  const int level = blockIdx.y, c0 = level * 8;
+  float m[8];
+  bool any = false;
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    m[f] = a.mask[c0 + f];
+    any |= m[f] != 0.0f;
+  }
+  if (!any) return;  // block-uniform: a level that is still switched off (progressive levels)
+  const int feat0 = 3 + 6 * a.pe_degree;
+  float yb[8], e8[8], gb[3] = {0.f, 0.f, 0.f}, pp[3] = {0.5f, 0.5f, 0.5f};
+  const bool second = a.e_tp != nullptr && a.gtot != nullptr;
+#pragma unroll
+  for (int f = 0; f < 8; ++f) yb[f] = e8[f] = 0.0f;
+  if (live) {
+#pragma unroll
+    for (int f = 0; f < 8; ++f) yb[f] = a.in0bar_tp[tp_index(p, feat0 + c0 + f, a.nb0)] * m[f];
+    if (second) {
+#pragma unroll
+      for (int f = 0; f < 8; ++f) e8[f] = a.e_tp[tp_index(p, feat0 + c0 + f, a.nb0)] * m[f] * 0.25f;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) gb[d] = a.gtot[p * 3 + d];
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) pp[d] = (a.x[p * 3 + d] + 2.0f) * 0.25f;
+  }
+  GridCell c;
+  grid_cell(a.grid.lv[level], a.grid.smoothstep != 0, pp, c);
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int k = half * 4 + kk;
+      const float w = corner_w(c, k);
+      float t[8];
+      float s = 0.0f;
+      if (second) {
+        float dw[3];
+        corner_dw(c, k, dw);
+        s = dw[0] * gb[0] + dw[1] * gb[1] + dw[2] * gb[2];
+      }
+#pragma unroll
+      for (int f = 0; f < 8; ++f) t[f] = fmaf(s, e8[f], w * yb[f]);
+      const bool issue = wave_run_reduce_n<8>(c.idx[k], live, t);
+#pragma unroll
+      for (int f = 0; f < 8; ++f) st.v[lane][kk * 8 + f] = t[f];
+      st.e[lane][kk] = issue ? c.idx[k] : kNoEntry;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int cp = 0; cp < 2; ++cp)
+#pragma unroll 4
+      for (int q = 0; q < 16; ++q) {
+        const int pt = q * 4 + (lane >> 4), kk = cp * 2 + ((lane >> 3) & 1), f = lane & 7;
+        const uint32_t entry = st.e[pt][kk];
+        const float v = st.v[pt][kk * 8 + f];
+        if (entry != kNoEntry) atomicAdd(a.tablebar + (size_t)entry * 8 + f, v);
+      }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ proposal field
 constexpr int kPropLevels = 5, kPropIn = 10, kPropHidden = 16;
 struct PropArgs {

@@ -54,6 +54,10 @@ class FlatGradients:
             self._offset[id(p)] = off
             off += p.numel()
         self._active: Dict[int, int] = {}
+        # high-water mark of set_active_numel per parameter: elements beyond it have NEVER carried a gradient, so they are still the
+        # zeros the buffer was created with (zero() need not rewrite them, Adam need not visit them: live_ranges())
+        self._hwm: Dict[int, int] = {}
+        self._finished_steps = 0
         self._attach()
         if buckets is None:
             buckets = [self.params]
@@ -108,7 +112,8 @@ class FlatGradients:
         tensor sat in .grad is DISCARDED - this call means "all gradients are zero now"."""
         if self._work:
             raise RuntimeError("FlatGradients.zero() while all-reduces of the previous backward are in flight: call finish() first")
-        self.flat.zero_()
+        for a, b in self.live_ranges():  # one range (the whole buffer) unless a parameter has a never-active suffix
+            self.flat[a:b].zero_()
         for p in self.params:
             # None, not a view: AccumulateGrad then ADOPTS the first incoming gradient instead of adding it into .grad - and the native
             # backward kernels hand it a view of this buffer they have already written (grad_slots.py): no launch per parameter
@@ -122,8 +127,36 @@ class FlatGradients:
         """Exchange only param.view(-1)[:numel] (None: all of it); the rest must be identically zero on every rank."""
         if numel is None or numel >= param.numel():
             self._active.pop(id(param), None)
+            self._hwm.pop(id(param), None)
         else:
-            self._active[id(param)] = max(int(numel), 0)
+            n = max(int(numel), 0)
+            self._active[id(param)] = n
+            # a restriction that arrives after unrestricted steps finds gradients (and Adam moments) beyond it: nothing to skip then
+            first = param.numel() if (id(param) not in self._hwm and self._finished_steps > 0) else 0
+            self._hwm[id(param)] = max(self._hwm.get(id(param), first), n)
+
+    def mark_all_live(self):
+        """Forget the never-active suffixes (e.g. after loading optimizer moments from a checkpoint)."""
+        for k in list(self._hwm):
+            self._hwm[k] = 1 << 62
+
+    def live_ranges(self):
+        """Contiguous [start, end) ranges of the flat buffer that may hold a non-zero gradient: everything except the suffix of a
+        parameter that set_active_numel has kept inactive since the first step (progressive hash levels: the table rows of levels
+        that have not been switched on yet - BASELINE config 5 starts with 8 of 16 levels of a 2.1 GB table).  zero() rewrites and
+        the fused Adam step visits only these: beyond them gradient, moments and update are exactly zero."""
+        out = []
+        for p in self.params:
+            off = self._offset[id(p)]
+            n = min(self._hwm.get(id(p), p.numel()), p.numel())
+            if n > 0:
+                if out and out[-1][1] == off:
+                    out[-1][1] = off + n
+                else:
+                    out.append([off, off + n])
+            if n < p.numel():
+                out.append([off + p.numel(), off + p.numel()])  # break the run: the next parameter starts a new range
+        return [(a, b) for a, b in out if b > a]
 
     # ---- exchange
     def _arm(self):
@@ -234,6 +267,7 @@ class FlatGradients:
                 self._wait_events.append(ev)
         self._work = []
         self._armed = False
+        self._finished_steps += 1
         return 1.0 if average else scale
 
     all_reduce_mean = finish

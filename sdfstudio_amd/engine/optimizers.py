@@ -113,11 +113,17 @@ class FusedAdam:
         P, G = self.flat_params.flat, self.flat_grads.flat
         if not P.is_cuda:
             raise _lib.SdfHipError("FusedAdam.step needs HIP device tensors; there is no CPU fallback")
+        # Elements that have never carried a gradient (FlatGradients.live_ranges: table rows of hash levels that are still switched
+        # off) have zero gradient and zero moments: their update is exactly 0 unless weight decay moves them, so they are skipped.
+        live = self.flat_grads.live_ranges() if self.weight_decay == 0.0 else [(0, P.numel())]
         for g in self.groups.values():
-            a, n = g["start"], g["numel"]
-            _lib.check(lib.sdfhip_adam_step(_lib.ptr(P[a:a + n]), _lib.ptr(G[a:a + n]), _lib.ptr(self.exp_avg[a:a + n]),
-                                            _lib.ptr(self.exp_avg_sq[a:a + n]), n, g["lr"], self.betas[0], self.betas[1], self.eps,
-                                            self.weight_decay, self.step_count, float(grad_scale), _lib.stream()), "adam_step")
+            for la, lb in live:
+                a, b = max(g["start"], la), min(g["start"] + g["numel"], lb)
+                if b <= a:
+                    continue
+                _lib.check(lib.sdfhip_adam_step(_lib.ptr(P[a:b]), _lib.ptr(G[a:b]), _lib.ptr(self.exp_avg[a:b]),
+                                                _lib.ptr(self.exp_avg_sq[a:b]), b - a, g["lr"], self.betas[0], self.betas[1], self.eps,
+                                                self.weight_decay, self.step_count, float(grad_scale), _lib.stream()), "adam_step")
 
     def zero_grad(self):
         self.flat_grads.zero()
@@ -144,6 +150,7 @@ class FusedAdam:
             self.exp_avg[a:a + n].copy_(sg["exp_avg"])
             self.exp_avg_sq[a:a + n].copy_(sg["exp_avg_sq"])
             g["lr"], g["lr_init"] = float(sg["lr"]), float(sg["lr_init"])
+        self.flat_grads.mark_all_live()  # loaded moments may be non-zero anywhere
         self.step_count = int(state["step_count"])
         self.betas, self.eps, self.weight_decay = tuple(state["betas"]), float(state["eps"]), float(state["weight_decay"])
 

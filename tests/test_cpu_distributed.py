@@ -244,3 +244,38 @@ def test_gradient_slots_are_adopted_without_an_add():
         assert p.grad.data_ptr() == flat.flat.data_ptr() and q.grad.data_ptr() == flat.flat.data_ptr() + 4 * 6
         flat.finish()
         assert torch.equal(flat.flat, torch.cat([torch.full((6,), 5.0), torch.full((5,), 4.0)]))
+
+
+def test_live_ranges_skip_a_never_active_suffix():
+    """Progressive hash levels (BASELINE config 5): the table rows of levels that have not been switched on never carry a gradient.
+    live_ranges() - what zero() rewrites and the fused Adam step visits - leaves that suffix out while it has never been active, grows
+    with it, and covers everything when the restriction arrives after unrestricted steps or after a checkpoint load."""
+    from sdfstudio_amd.distributed import FlatGradients
+
+    a, table, c = (torch.nn.Parameter(torch.randn(n)) for n in (6, 40, 5))
+    flat = FlatGradients([a, table, c])
+    assert flat.live_ranges() == [(0, 51)]
+    flat.set_active_numel(table, 16)
+    assert flat.live_ranges() == [(0, 22), (46, 51)]
+    flat.flat[22:46] = 7.0  # sentinel: zero() must not touch the never-active suffix
+    flat.flat[:22] = 3.0
+    flat.zero()
+    assert float(flat.flat[:22].abs().max()) == 0.0 and torch.equal(flat.flat[22:46], torch.full((24,), 7.0))
+    flat.flat[22:46] = 0.0
+    (a.sum() + (table[:16] * 2).sum() + c.sum()).backward()
+    flat.finish()
+    assert torch.equal(flat.flat[6:22], torch.full((16,), 2.0)) and float(flat.flat[22:46].abs().max()) == 0.0
+    flat.set_active_numel(table, 24)  # a level is switched on: the range grows, never shrinks
+    assert flat.live_ranges() == [(0, 30), (46, 51)]
+    flat.set_active_numel(table, 8)
+    assert flat.live_ranges() == [(0, 30), (46, 51)] and flat._ranges(0) == [(0, 14), (46, 51)]  # the exchange follows the current prefix
+    flat.mark_all_live()
+    assert flat.live_ranges() == [(0, 51)]
+    # a restriction that arrives after unrestricted steps: gradients (and moments) exist beyond it, nothing is skipped
+    a2, table2, c2 = (torch.nn.Parameter(torch.randn(n)) for n in (6, 40, 5))
+    flat2 = FlatGradients([a2, table2, c2])
+    flat2.zero()
+    (a2.sum() + table2.sum() + c2.sum()).backward()
+    flat2.finish()
+    flat2.set_active_numel(table2, 16)
+    assert flat2.live_ranges() == [(0, 51)]

@@ -660,6 +660,36 @@ def test_fused_adam_against_torch_adam(device, world):
     assert ga[0].data_ptr() == opts.adam.flat_params.flat.data_ptr()  # parameters really live in the flat buffer
 
 
+def test_fused_adam_skips_never_active_table_rows_exactly(device):
+    """Progressive hash levels: FlatGradients.set_active_numel keeps the table rows of switched-off levels out of zero() and of the
+    Adam step (FlatGradients.live_ranges).  torch.optim.Adam with explicit zero gradients there must end at the same parameters: the
+    skipped rows stay bit-for-bit where they started, rows switched on later start from zero moments with the GLOBAL step count."""
+    from sdfstudio_amd.engine.optimizers import Optimizers
+
+    torch.manual_seed(2)
+    head, table, tail = (torch.nn.Parameter(torch.randn(n, device=device)) for n in (33, 1000, 7))
+    refs = [torch.nn.Parameter(p.detach().clone()) for p in (head, table, tail)]
+    start = table.detach().clone()
+    opts = Optimizers({"fields": {"lr": 1e-3, "scheduler": None}}, {"fields": [head, table, tail]})
+    t = torch.optim.Adam(refs, lr=1e-3, eps=1e-15)
+    for step, active in enumerate([301, 301, 301, 640, 640, 1000]):
+        opts.flat_grads.set_active_numel(table, active)
+        launches = len(opts.flat_grads.live_ranges())
+        assert launches == (1 if active == 1000 else 2)
+        opts.zero_grad_all()
+        for p, r in zip((head, table, tail), refs):
+            g = torch.randn_like(p)
+            if p is table:
+                g[active:] = 0.0
+            opts.flat_grads._view(p).add_(g)
+            r.grad = g.clone()
+        opts.optimizer_step_all()
+        t.step()
+        for i, (p, r) in enumerate(zip((head, table, tail), refs)):
+            assert_close(f"step {step} param {i}", p, r, rtol=2e-6, atol=1e-7)
+        assert torch.equal(table.detach()[active:], start[active:])
+
+
 # ------------------------------------------------------------------------------------------------ field (small golden net)
 def _field_case(cfg, params, n, s, seed, use_emb=False):
     torch.manual_seed(seed)
