@@ -413,8 +413,11 @@ def run(args):
         enc_ms, enc_n = prof.get("geo_encode_kernel", (0.0, 0))
         enc = None
         if enc_n > 0:
-            if cfg5:  # 7 evaluations per ray-sample (centre + 6 taps), 16 levels x 8 corners x 8 features x 4 B + position in + 6 in0 blocks out
-                per_sample, what = 7 * (16 * 8 * 8 * 4 + 12 + 6 * 128), "7 x (4096 B gather + 12 B position + 768 B tile-packed in0) per ray-sample"
+            if cfg5:  # 7 evaluations per ray-sample (centre + 6 taps); ACTIVE levels x 8 corners x 8 features x 4 B + position in + 6 in0 blocks out
+                # (progressive levels: the kernel skips the levels the mask has switched off, so they are not counted either)
+                lv_on = int(getattr(model.field, "_active_levels", model.field.num_levels))
+                per_sample = 7 * (lv_on * 8 * 8 * 4 + 12 + 6 * 128)
+                what = f"7 x ({lv_on} active levels x 256 B gather + 12 B position + 768 B tile-packed in0) per ray-sample"
             else:
                 per_sample, what = 16 * 8 * 2 * 4 + 12 + 128, "1024 B gather + 12 B position + 128 B of features per ray-sample (SURVEY 8d: 1164 B)"
             eb = per_sample * P
@@ -429,7 +432,7 @@ def run(args):
 
                 with open(os.path.join(pm_dir, f)) as fh:
                     for row in csv.DictReader(fh):
-                        if row.get("kernel", "").startswith("geo_encode_kernel") and row.get("hbm_write_GB"):
+                        if row.get("kernel", "").startswith("geo_encode") and row.get("hbm_write_GB"):
                             per_launch = (float(row["hbm_read_GB_corrected_x2"]) + float(row["hbm_write_GB"])) * 1e9
                             enc["traffic"] = per_launch * enc_n / args.steps  # HBM bytes per step (PMC, average launch x launches per step)
                             enc["traffic_source"] = f"profiles/{f} (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc passes)"

@@ -617,7 +617,12 @@ extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, c
   ea.x_out = w.x;
   ea.in0_tp = w.in0;
   ea.dydp = full ? w.dydp : nullptr;
-  { ProfScope ps_(PS_ENCODE, s); geo_encode_kernel<<<dim3((unsigned)(NP / 256 + (NP % 256 != 0)), f->grid.n_levels * (f->grid.n_features / 2) + 1), 256, 0, s>>>(ea); }
+  {
+    ProfScope ps_(PS_ENCODE, s);
+    const unsigned gx = (unsigned)(NP / 256 + (NP % 256 != 0));
+    if (f->grid.n_features == 8) geo_encode8_kernel<<<dim3(gx, f->grid.n_levels + 1), 256, 0, s>>>(ea);
+    else geo_encode_kernel<<<dim3(gx, f->grid.n_levels * (f->grid.n_features / 2) + 1), 256, 0, s>>>(ea);
+  }
 
   GeoFwdArgs ga;
   memset(&ga, 0, sizeof(ga));
@@ -909,7 +914,12 @@ extern "C" int sdfhip_geo_forward_n(const SdfHipField* f, const float* packed, c
   ea.mask = level_mask;
   ea.x_out = w.x;
   ea.in0_tp = w.in0;
-  { ProfScope ps_(PS_ENCODE, s); geo_encode_kernel<<<dim3((unsigned)(NP / 256 + (NP % 256 != 0)), f->grid.n_levels * (f->grid.n_features / 2) + 1), 256, 0, s>>>(ea); }
+  {
+    ProfScope ps_(PS_ENCODE, s);
+    const unsigned gx = (unsigned)(NP / 256 + (NP % 256 != 0));
+    if (f->grid.n_features == 8) geo_encode8_kernel<<<dim3(gx, f->grid.n_levels + 1), 256, 0, s>>>(ea);
+    else geo_encode_kernel<<<dim3(gx, f->grid.n_levels * (f->grid.n_features / 2) + 1), 256, 0, s>>>(ea);
+  }
   GeoFwdArgs ga;
   memset(&ga, 0, sizeof(ga));
   fill_geo_ptrs(f, packed, &ga.p, kNsFwd);

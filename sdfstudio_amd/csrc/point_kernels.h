@@ -218,6 +218,88 @@ __global__ __launch_bounds__(256) void geo_encode_kernel(const EncodeArgs a) {
   }
 }
 
+// ---- 8 features per entry (BASELINE config 5): one block gathers WHOLE 32-byte entries (two 16-byte loads per corner) and produces all 8
+// features of a level.  With one feature pair per block (above) the four pair-blocks of a level visit every entry again, each for 8 of
+// its 32 bytes: on a 2.1 GB table those visits are HBM sectors fetched four times (PMC: 7.3 GB per step for 3.4 GB of entries).
+// grid = (n_padded / 256, n_levels + 1), block = 256; the last y writes position / positional encoding / padding like the kernel above.
+__global__ __launch_bounds__(256) void geo_encode8_kernel(const EncodeArgs a) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.n_padded) return;
+  const bool live = p < a.n_points;
+  float x[3] = {0.f, 0.f, 0.f};
+  if (live) {
+    start_position(a.origins, a.dirs, a.starts, p, a.S, x);
+    if (a.contract) contract_inf(x, a.contract);
+  }
+  const int L = a.grid.n_levels;
+  const int level = blockIdx.y;
+  const int pe_dims = 6 * a.pe_degree;
+  const int feat0 = 3 + pe_dims;
+  if (level == L) {
+    a.x_out[p * 3 + 0] = x[0];
+    a.x_out[p * 3 + 1] = x[1];
+    a.x_out[p * 3 + 2] = x[2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) a.in0_tp[tp_index(p, d, a.nb0)] = x[d];
+    for (int d = 0; d < 3; ++d)
+      for (int f = 0; f < a.pe_degree; ++f) {
+        const float u = x[d] * (float)(1 << f);
+        const float s1 = (live && a.use_pe) ? sinf(u) : 0.0f;
+        const float s2 = (live && a.use_pe) ? sinf(u + 1.57079632679489661923f) : 0.0f;
+        a.in0_tp[tp_index(p, 3 + d * a.pe_degree + f, a.nb0)] = s1;
+        a.in0_tp[tp_index(p, 3 + 3 * a.pe_degree + d * a.pe_degree + f, a.nb0)] = s2;
+      }
+    for (int c = feat0 + L * 8; c < a.nb0 * 32; ++c) a.in0_tp[tp_index(p, c, a.nb0)] = 0.0f;
+    return;
+  }
+  const int c0 = level * 8;
+  float m[8], y[8], dy[8][3];
+  bool any = false;
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    m[f] = a.mask[c0 + f];
+    any |= m[f] != 0.0f;
+    y[f] = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) dy[f][d] = 0.0f;
+  }
+  if (live && any) {
+    const float pp[3] = {(x[0] + 2.0f) * 0.25f, (x[1] + 2.0f) * 0.25f, (x[2] + 2.0f) * 0.25f};
+    GridCell c;
+    grid_cell(a.grid.lv[level], a.grid.smoothstep != 0, pp, c);
+    const f32x4* tab = reinterpret_cast<const f32x4*>(a.table);
+    f32x4 v[8][2];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      v[k][0] = tab[(size_t)c.idx[k] * 2];
+      v[k][1] = tab[(size_t)c.idx[k] * 2 + 1];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float w = corner_w(c, k);
+      float dw[3] = {0.f, 0.f, 0.f};
+      if (a.dydp != nullptr) corner_dw(c, k, dw);
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        const float t = v[k][f >> 2][f & 3];
+        y[f] = fmaf(w, t, y[f]);
+        if (a.dydp != nullptr) {
+#pragma unroll
+          for (int d = 0; d < 3; ++d) dy[f][d] = fmaf(dw[d], t, dy[f][d]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int f = 0; f < 8; ++f) a.in0_tp[tp_index(p, feat0 + c0 + f, a.nb0)] = y[f] * m[f];
+  if (a.dydp != nullptr) {
+#pragma unroll
+    for (int f = 0; f < 8; ++f)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) a.dydp[(size_t)((c0 + f) * 3 + d) * a.n_padded + p] = dy[f][d];
+  }
+}
+
 struct AssembleArgs {
   const float* e_tp;    // [T][nb0]  d sdf / d in0
   const float* x;       // [n_padded][3]

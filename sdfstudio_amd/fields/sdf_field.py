@@ -464,6 +464,7 @@ class SDFField(nn.Module):
         """sdf_field.py:376-378 (progressive hash levels)."""
         self.hash_encoding_mask[:] = 1.0
         self.hash_encoding_mask[level * self.features_per_level:] = 0
+        self._active_levels = max(0, min(int(level), self.num_levels))  # host copy: nobody has to read the device mask back
 
     def set_numerical_gradients_delta(self, delta: float) -> None:
         self.numerical_gradients_delta = delta

@@ -198,8 +198,9 @@ class NeuSFactoModel(nn.Module):
         the features of the levels above; their table rows get exactly zero gradient): what a data-parallel exchange has to move
         (sdfstudio_amd/distributed.py FlatGradients.set_active_numel)."""
         f = self.field
-        mask = f.hash_encoding_mask
-        n_active = int((mask.reshape(f.num_levels, -1).amax(dim=1) > 0).sum().item())
+        n_active = getattr(f, "_active_levels", None)  # what update_mask was last called with (no device read-back per step)
+        if n_active is None:
+            n_active = int((f.hash_encoding_mask.reshape(f.num_levels, -1).amax(dim=1) > 0).sum().item())
         levels = f.encoding.levels
         if n_active >= len(levels):
             return f.encoding.params.numel()
