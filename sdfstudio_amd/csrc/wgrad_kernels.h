@@ -689,8 +689,14 @@ struct WreduceArgs {
 // block = 64 x kWrG threads: 64 x 4 consecutive elements (one 16-byte load per thread and split: a wave reads 1 KiB per instruction; with
 // 4-byte loads the kernel was bound by the latency of 256-byte requests, PMC: 83 % of its wave cycles parked) x kWrG interleaved split
 // groups, combined through LDS; grid = ceil(rows * cols / 256): one block streams the contiguous [n_split][256] run of its chunk
-// (wg_partial_index), a thread sums n_split / 16 partials in batches of 8.
-constexpr int kWrG = 16;
+// (wg_partial_index), a thread sums n_split / kWrG partials in batches of 8.  The group count moves time between this kernel and the
+// GEMM that follows it, not their sum (same-box kernel durations, tools/ab_rocprof.sh: 4 / 8 / 16 groups -> wreduce 67 / 43 / 107 us per
+// launch, wgrad + wreduce 5.38 / 5.36 / 5.38 ms per step): what the pair costs is the write-back of the 64 MB of partials and their
+// read, wherever the counters book it.
+#ifndef SDFHIP_WREDUCE_GROUPS
+#define SDFHIP_WREDUCE_GROUPS 8
+#endif
+constexpr int kWrG = SDFHIP_WREDUCE_GROUPS;
 static __global__ __launch_bounds__(64 * kWrG) void wreduce_kernel(const WreduceArgs a) {
   __shared__ f32x4 red[kWrG][64];
   const int ix = threadIdx.x & 63, sg = threadIdx.x >> 6;
