@@ -431,11 +431,15 @@ def run(args):
                 import csv
 
                 with open(os.path.join(pm_dir, f)) as fh:
-                    for row in csv.DictReader(fh):
-                        if row.get("kernel", "").startswith("geo_encode") and row.get("hbm_write_GB"):
-                            per_launch = (float(row["hbm_read_GB_corrected_x2"]) + float(row["hbm_write_GB"])) * 1e9
-                            enc["traffic"] = per_launch * enc_n / args.steps  # HBM bytes per step (PMC, average launch x launches per step)
-                            enc["traffic_source"] = f"profiles/{f} (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc passes)"
+                    prows = list(csv.DictReader(fh))
+                # the slot covers every encode launch of a step (config 5: the 8-feature kernel of the SDF grid and the 2-feature one of
+                # the background grid); the PMC passes sample whole training steps, geo_bwd_kernel runs once per step and phase
+                sampled = min([int(r["launches_sampled"]) for r in prows if r.get("kernel", "").startswith("geo_bwd_kernel")] or [0])
+                tot = sum((float(r["hbm_read_GB_corrected_x2"]) + float(r["hbm_write_GB"])) * 1e9 * int(r["launches_sampled"])
+                          for r in prows if r.get("kernel", "").startswith("geo_encode") and r.get("hbm_write_GB"))
+                if sampled > 0 and tot > 0:
+                    enc["traffic"] = tot / sampled  # HBM bytes per training step (PMC: average launch x launches, over the steps sampled)
+                    enc["traffic_source"] = f"profiles/{f} (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc passes; all geo_encode* launches)"
                 break
             if cfg5:
                 roof = enc
