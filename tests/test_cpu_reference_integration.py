@@ -205,3 +205,20 @@ def test_model_mirrors_have_the_reference_checkpoint_layout(ref, which, backgrou
     go, gp = ours.get_param_groups(), pure.get_param_groups()
     # (the reference lists its frozen dummy background parameter as a group; groups are compared by what an optimiser would train)
     assert {k for k, v in go.items() if any(p.requires_grad for p in v)} == {k for k, v in gp.items() if any(p.requires_grad for p in v)}
+
+
+@pytest.mark.parametrize("enc", ["periodic", "tensorf_vm"])
+def test_reference_cannot_run_its_non_hash_encodings(ref, enc):
+    """Why `SDFField(encoding_type="periodic" | "tensorf_vm")` is refused here instead of built: the reference itself cannot evaluate
+    them with grid features.  forward_geonetwork (sdf_field.py:380-390) multiplies the encoding by self.hash_encoding_mask, which only
+    the "hash" branch of the constructor creates (:228-245).  If this test ever fails the reference has been fixed and DESIGN.md
+    section 1 ("Not built") is out of date."""
+    from nerfstudio.fields.sdf_field import SDFField as RefField, SDFFieldConfig as RefCfg
+    from sdfstudio_amd.fields.sdf_field import SDFField, SDFFieldConfig
+
+    cfg = RefCfg(encoding_type=enc, use_grid_feature=True, num_layers=2, hidden_dim=64, geo_feat_dim=16, hidden_dim_color=64, num_layers_color=2)
+    fld = RefField(cfg, aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_images=3)
+    with pytest.raises(AttributeError, match="hash_encoding_mask"):
+        fld.forward_geonetwork(torch.rand(5, 3))
+    with pytest.raises(NotImplementedError, match="encoding_type"):
+        SDFField(SDFFieldConfig(encoding_type=enc), torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_images=3)
