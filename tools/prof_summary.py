@@ -2,7 +2,7 @@
 
   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (verbatim)
   profiles/<tag>_pmc_summary.csv    per kernel (average per launch): FETCH_SIZE / WRITE_SIZE [KB], HBM read GB (FETCH_SIZE x 2: gfx950's
-                                    counter reports half of a coalesced stream, MI355X_MICROARCH.md), HBM write GB, SQ ratios
+                                    counter reports half of a coalesced stream, MI355X_MICROARCH.md), HBM write GB, SQ ratios, LDS bank-conflict fraction
   profiles/<tag>_pmc_traffic.json   the dominant kernel's HBM bytes per launch (read by bench.py -> roofline.traffic)
 """
 import csv, json, os, shutil, sys
@@ -33,7 +33,7 @@ def counters(sub):
 ks = os.path.join(src, "kt", "kt_kernel_stats.csv")
 if os.path.exists(ks):
     shutil.copy(ks, os.path.join(dst, f"{tag}_kernel_stats.csv"))
-fetch, write, sq = counters("pmc_fetch"), counters("pmc_write"), counters("pmc_sq")
+fetch, write, sq, lds = counters("pmc_fetch"), counters("pmc_write"), counters("pmc_sq"), counters("pmc_lds")
 mean = lambda v: sum(v) / len(v) if v else float("nan")
 rows = []
 for k in sorted(fetch, key=lambda n: -mean(fetch[n]["FETCH_SIZE"]) - mean(write.get(n, {}).get("WRITE_SIZE", [0.0]))):
@@ -48,7 +48,10 @@ for k in sorted(fetch, key=lambda n: -mean(fetch[n]["FETCH_SIZE"]) - mean(write.
                  # matrix-pipe busy cycles over (cycles x 1024 SIMDs): GRBM_GUI_ACTIVE is summed over the 8 XCDs
                  "mfma_busy_frac": round(mean(s["SQ_VALU_MFMA_BUSY_CYCLES"]) / (mean(s["GRBM_GUI_ACTIVE"]) * 128), 3) if s else "",
                  "wait_any_frac": ratio("SQ_WAIT_ANY"),
-                 "wait_inst_frac": ratio("SQ_WAIT_INST_ANY"), "valu_frac": ratio("SQ_ACTIVE_INST_VALU")})
+                 "wait_inst_frac": ratio("SQ_WAIT_INST_ANY"), "valu_frac": ratio("SQ_ACTIVE_INST_VALU"),
+                 # LDS: extra cycles lost to bank conflicts over all cycles the LDS arrays were busy (MI355X_MICROARCH.md)
+                 "lds_bank_conflict_frac": (round(mean(lds[k]["SQ_LDS_BANK_CONFLICT"]) / mean(lds[k]["SQ_LDS_IDX_ACTIVE"]), 4)
+                                            if k in lds and mean(lds[k].get("SQ_LDS_IDX_ACTIVE", [])) > 0 else "")})
 if rows:
     with open(os.path.join(dst, f"{tag}_pmc_summary.csv"), "w", newline="") as fh:
         w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
