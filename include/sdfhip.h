@@ -299,6 +299,23 @@ int sdfhip_surface_loss_backward(const float* rgb, const float* image, int64_t n
                                  const float* const* loss_bar4, float* rgb_bar, float* grad_bar, float* sdf_bar, float* taps_bar,
                                  float* n_pred_bar, sdfhip_stream_t stream);
 
+/* MonoSDF depth prior: ScaleAndShiftInvariantLoss(alpha, scales = 1) (model_components/losses.py:278-409) exactly as the surface models
+ * call it (models/base_surface_model.py:227,427-437): the N rays viewed as ONE rows x (N / rows) image (rows = 32), all-ones mask,
+ * target = depth_gt * gt_scale + gt_shift (50, 0.5): closed-form scale / shift fit (:278-301), MSE / 2 + alpha * gradient matching,
+ * batch-based reduction.  loss[1]; state10 carries the fit and the sums the backward needs to differentiate THROUGH it (as autograd
+ * does in the reference).  One deterministic launch each way.  n_rays must be a multiple of rows. */
+int sdfhip_mono_depth_loss_forward(const float* depth_pred, const float* depth_gt, int64_t n_rays, int32_t rows, float gt_scale,
+                                   float gt_shift, float alpha, float* loss, float* state10, sdfhip_stream_t stream);
+int sdfhip_mono_depth_loss_backward(const float* depth_pred, const float* depth_gt, int64_t n_rays, int32_t rows, float gt_scale,
+                                    float gt_shift, float alpha, const float* state10, const float* loss_bar, float* pred_bar,
+                                    sdfhip_stream_t stream);
+
+/* Foreground-mask loss (models/base_surface_model.py:415-420): mult * binary_cross_entropy(clip(acc, 1e-3, 1 - 1e-3), label) with
+ * acc[N] = the per-ray sum of the rendering weights; loss[1]; acc_bar[N].  One deterministic launch each way. */
+int sdfhip_fg_mask_loss_forward(const float* acc, const float* label, int64_t n_rays, float mult, float* loss, sdfhip_stream_t stream);
+int sdfhip_fg_mask_loss_backward(const float* acc, const float* label, int64_t n_rays, float mult, const float* loss_bar, float* acc_bar,
+                                 sdfhip_stream_t stream);
+
 /* interlevel_loss_zip (model_components/losses.py:116-172), the part per proposal level: the field histogram (c [n_rays, s+1]
  * spacing bins, w [n_rays, s] weights; both constants) blurred with half-width `radius` (0.03 / 0.003 for the two levels, :138)
  * and resampled at the proposal bins cp [n_rays, s_p+1]; against the proposal weights wp [n_rays, s_p]:

@@ -1536,6 +1536,75 @@ extern "C" int sdfhip_field_theta_backward_weightnorm(const SdfHipField* f, cons
   return 0;
 }
 
+// MonoSDF depth prior (ScaleAndShiftInvariantLoss as base_surface_model.py:427-437 calls it) and the foreground-mask BCE (:415-420)
+static int fill_depth_loss(DepthLossArgs* a, const float* pred, const float* gt, int64_t n, int32_t rows, float gt_scale, float gt_shift,
+                           float alpha) {
+  SDFHIP_REQUIRE(pred && gt && n >= 1 && rows >= 1 && n % rows == 0 && n < (1 << 30), "mono_depth_loss: %lld rays do not form a %d-row image",
+                 (long long)n, rows);
+  memset(a, 0, sizeof(*a));
+  a->pred = pred;
+  a->gt = gt;
+  a->n = (int)n;
+  a->rows = rows;
+  a->width = (int)(n / rows);
+  a->gt_scale = gt_scale;
+  a->gt_shift = gt_shift;
+  a->alpha = alpha;
+  return 0;
+}
+extern "C" int sdfhip_mono_depth_loss_forward(const float* depth_pred, const float* depth_gt, int64_t n_rays, int32_t rows, float gt_scale,
+                                              float gt_shift, float alpha, float* loss, float* state10, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(loss && state10, "mono_depth_loss_forward: null output");
+  DepthLossArgs a;
+  if (int rc = fill_depth_loss(&a, depth_pred, depth_gt, n_rays, rows, gt_scale, gt_shift, alpha)) return rc;
+  a.loss = loss;
+  a.state = state10;
+  depth_loss_fwd_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int sdfhip_mono_depth_loss_backward(const float* depth_pred, const float* depth_gt, int64_t n_rays, int32_t rows, float gt_scale,
+                                               float gt_shift, float alpha, const float* state10, const float* loss_bar, float* pred_bar,
+                                               sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(state10 && loss_bar && pred_bar, "mono_depth_loss_backward: null argument");
+  DepthLossArgs a;
+  if (int rc = fill_depth_loss(&a, depth_pred, depth_gt, n_rays, rows, gt_scale, gt_shift, alpha)) return rc;
+  a.state = const_cast<float*>(state10);
+  a.loss_bar = loss_bar;
+  a.pred_bar = pred_bar;
+  depth_loss_bwd_kernel<<<(unsigned)std::min<int64_t>((n_rays + 255) / 256, 1024), 256, 0, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int sdfhip_fg_mask_loss_forward(const float* acc, const float* label, int64_t n_rays, float mult, float* loss, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(acc && label && loss && n_rays >= 1 && n_rays < (1 << 30), "fg_mask_loss_forward: bad argument");
+  FgLossArgs a;
+  memset(&a, 0, sizeof(a));
+  a.acc = acc;
+  a.label = label;
+  a.n = (int)n_rays;
+  a.scale = mult / (float)n_rays;
+  a.loss = loss;
+  fg_loss_fwd_kernel<<<1, 1024, 0, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int sdfhip_fg_mask_loss_backward(const float* acc, const float* label, int64_t n_rays, float mult, const float* loss_bar,
+                                            float* acc_bar, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(acc && label && loss_bar && acc_bar && n_rays >= 1 && n_rays < (1 << 30), "fg_mask_loss_backward: bad argument");
+  FgLossArgs a;
+  memset(&a, 0, sizeof(a));
+  a.acc = acc;
+  a.label = label;
+  a.n = (int)n_rays;
+  a.scale = mult / (float)n_rays;
+  a.loss_bar = loss_bar;
+  a.acc_bar = acc_bar;
+  fg_loss_bwd_kernel<<<(unsigned)std::min<int64_t>((n_rays + 255) / 256, 1024), 256, 0, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 static const int kSurfaceLossBlocks = 512;
 extern "C" int64_t sdfhip_surface_loss_workspace_floats(void) { return (int64_t)kSurfaceLossBlocks * SL_COUNT; }
 static void fill_surface_loss(SurfaceLossArgs* a, const float* rgb, const float* image, int64_t n_rays, const float* grad, const float* sdf,

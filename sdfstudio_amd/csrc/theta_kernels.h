@@ -222,3 +222,143 @@ __global__ __launch_bounds__(256) void surface_loss_bwd_kernel(const SurfaceLoss
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------------ MonoSDF depth prior + foreground mask
+// ScaleAndShiftInvariantLoss(alpha, scales = 1) (model_components/losses.py:278-409) as the surface models call it
+// (base_surface_model.py:427-437): the ray batch viewed as ONE rows x (N / rows) image, all-ones mask, target = gt * gt_scale + gt_shift.
+//   (s, t) = argmin sum (s p + t - y)^2                          closed form 2 x 2 system, (0, 0) when singular      (:278-301)
+//   loss   = sum d^2 / (2 N) + alpha * sum_edges |d_j - d_k| / N          d = s p + t - y, edges = horizontal + vertical neighbours
+// One block: the batch is a few thousand rays, and one block makes the sums deterministic.  state (out): s, t, det, a00, a01, b0, b1, N as
+// float, then G_s = sum g p and G_t = sum g with g = d loss / d d - what the backward needs to go THROUGH the fit (the reference
+// differentiates compute_scale_and_shift too).
+struct DepthLossArgs {
+  const float* pred;  // [N]
+  const float* gt;    // [N]
+  int32_t n, rows, width;
+  float gt_scale, gt_shift, alpha;
+  float* loss;         // [1]
+  float* state;        // [10]
+  const float* loss_bar;  // device scalar (backward)
+  float* pred_bar;        // [N]      (backward)
+};
+SDFHIP_D float depth_sign(const float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+template <int NV>
+SDFHIP_D void block_sum_double(double (&v)[NV], double* red /* [NV][blockDim / 64] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double t = v[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) t += __shfl_xor(t, m);
+    if (lane == 0) red[i * nw + wave] = t;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double t = 0.0;
+    for (int w = 0; w < nw; ++w) t += red[i * nw + w];
+    v[i] = t;
+  }
+  __syncthreads();
+}
+// g_i = d loss / d d_i (without the 1 / N): d_i + alpha * sum over the up-to-four neighbours of sign(d_i - d_nb)
+SDFHIP_D float depth_loss_g(const DepthLossArgs& a, const int i, const float s, const float t) {
+  auto d_at = [&](const int j) { return fmaf(s, a.pred[j], t) - fmaf(a.gt[j], a.gt_scale, a.gt_shift); };
+  const int r = i / a.width, c = i - r * a.width;
+  const float d = d_at(i);
+  float e = 0.0f;
+  if (c + 1 < a.width) e += depth_sign(d - d_at(i + 1));
+  if (c > 0) e += depth_sign(d - d_at(i - 1));
+  if (r + 1 < a.rows) e += depth_sign(d - d_at(i + a.width));
+  if (r > 0) e += depth_sign(d - d_at(i - a.width));
+  return fmaf(a.alpha, e, d);
+}
+__global__ __launch_bounds__(1024) void depth_loss_fwd_kernel(const DepthLossArgs a) {
+  __shared__ double red[4 * 16];
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < a.n; i += blockDim.x) {
+    const double p = a.pred[i], y = fmaf(a.gt[i], a.gt_scale, a.gt_shift);
+    v[0] += p * p;
+    v[1] += p;
+    v[2] += p * y;
+    v[3] += y;
+  }
+  block_sum_double<4>(v, red);
+  const double a00 = v[0], a01 = v[1], b0 = v[2], b1 = v[3], a11 = (double)a.n;
+  // the reference forms the determinant and the solution in fp32 from fp32 sums (:288-299); the sums here are exact to double, the
+  // 2 x 2 solve as well, rounded once
+  const double det = a00 * a11 - a01 * a01;
+  const float s = det != 0.0 ? (float)((a11 * b0 - a01 * b1) / det) : 0.0f;
+  const float t = det != 0.0 ? (float)((-a01 * b0 + a00 * b1) / det) : 0.0f;
+  double w[4] = {0.0, 0.0, 0.0, 0.0};  // sum d^2, sum |edge|, G_s, G_t
+  for (int i = threadIdx.x; i < a.n; i += blockDim.x) {
+    const int r = i / a.width, c = i - r * a.width;
+    const float p = a.pred[i];
+    const float d = fmaf(s, p, t) - fmaf(a.gt[i], a.gt_scale, a.gt_shift);
+    w[0] += (double)d * d;
+    if (c + 1 < a.width) w[1] += fabsf(d - (fmaf(s, a.pred[i + 1], t) - fmaf(a.gt[i + 1], a.gt_scale, a.gt_shift)));
+    if (r + 1 < a.rows) w[1] += fabsf(d - (fmaf(s, a.pred[i + a.width], t) - fmaf(a.gt[i + a.width], a.gt_scale, a.gt_shift)));
+    const float g = depth_loss_g(a, i, s, t);
+    w[2] += (double)g * p;
+    w[3] += (double)g;
+  }
+  block_sum_double<4>(w, red);
+  if (threadIdx.x == 0) {
+    a.loss[0] = (float)(w[0] / (2.0 * a11) + (double)a.alpha * w[1] / a11);
+    a.state[0] = s;
+    a.state[1] = t;
+    a.state[2] = (float)det;
+    a.state[3] = (float)a00;
+    a.state[4] = (float)a01;
+    a.state[5] = (float)b0;
+    a.state[6] = (float)b1;
+    a.state[7] = (float)a11;
+    a.state[8] = (float)(w[2] / a11);
+    a.state[9] = (float)(w[3] / a11);
+  }
+}
+// d loss / d p_i = lb * ( g_i s / N  +  G_s ds/dp_i  +  G_t dt/dp_i ),  the fit differentiated through a00' = 2 p_i, a01' = 1, b0' = y_i
+__global__ __launch_bounds__(256) void depth_loss_bwd_kernel(const DepthLossArgs a) {
+  const float s = a.state[0], t = a.state[1], det = a.state[2], a00 = a.state[3], a01 = a.state[4], b0 = a.state[5], b1 = a.state[6];
+  const float n = a.state[7], gs = a.state[8], gt_ = a.state[9], lb = a.loss_bar[0];
+  const float inv_det = det != 0.0f ? 1.0f / det : 0.0f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) {
+    const float p = a.pred[i], y = fmaf(a.gt[i], a.gt_scale, a.gt_shift);
+    const float ddet = 2.0f * (p * n - a01);
+    const float ds = ((n * y - b1) - s * ddet) * inv_det;
+    const float dt = ((-b0 - a01 * y + 2.0f * p * b1) - t * ddet) * inv_det;
+    (void)a00;
+    a.pred_bar[i] = lb * (depth_loss_g(a, i, s, t) * s / n + gs * ds + gt_ * dt);
+  }
+}
+
+// Foreground-mask loss (base_surface_model.py:415-420): binary_cross_entropy(clip(sum_s weights, 1e-3, 1 - 1e-3), fg_label), mean over rays.
+// acc = the per-ray weight sum.  One block, deterministic; the log terms are clamped at -100 like aten's.
+struct FgLossArgs {
+  const float* acc;    // [N]
+  const float* label;  // [N]
+  int32_t n;
+  float scale;         // loss multiplier / N
+  float* loss;         // [1]
+  const float* loss_bar;
+  float* acc_bar;      // [N]
+};
+__global__ __launch_bounds__(1024) void fg_loss_fwd_kernel(const FgLossArgs a) {
+  __shared__ double red[16];
+  double v[1] = {0.0};
+  for (int i = threadIdx.x; i < a.n; i += blockDim.x) {
+    const float c = fminf(fmaxf(a.acc[i], 1e-3f), 1.0f - 1e-3f), y = a.label[i];
+    v[0] -= (double)(y * fmaxf(logf(c), -100.0f) + (1.0f - y) * fmaxf(logf(1.0f - c), -100.0f));
+  }
+  block_sum_double<1>(v, red);
+  if (threadIdx.x == 0) a.loss[0] = (float)(v[0] * (double)a.scale);
+}
+__global__ __launch_bounds__(256) void fg_loss_bwd_kernel(const FgLossArgs a) {
+  const float lb = a.loss_bar[0] * a.scale;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n; i += gridDim.x * 256) {
+    const float x = a.acc[i], y = a.label[i];
+    const bool inside = x >= 1e-3f && x <= 1.0f - 1e-3f;  // clip passes the gradient on its closed interval like aten's clamp backward
+    const float c = fminf(fmaxf(x, 1e-3f), 1.0f - 1e-3f);
+    a.acc_bar[i] = inside ? lb * (c - y) / (c * (1.0f - c)) : 0.0f;
+  }
+}

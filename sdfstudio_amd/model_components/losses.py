@@ -9,8 +9,10 @@ searchsorted: ~40 launches) lives in oracle/sdf_path.py as the checker.  There i
 surface_losses: the scalar losses behind the renderer - L1 colour (base_surface_model.py:402), eikonal (:406), curvature
 (neus_facto.py:313-325), MonoSDF normal (losses.py:264-275) - as one fused operator: two launches forward (per-block partial sums,
 deterministic finish), one elementwise launch backward (sdfhip_surface_loss_forward / _backward), instead of ~25 reductions and
-elementwise launches.  The MonoSDF scale-and-shift depth loss (a 2 x 2 least-squares fit + multi-scale gradient matching on the
-ray batch viewed as an image, losses.py:278-409) stays a handful of torch reductions: it is off in BASELINE configs 1 - 3 and 5.
+elementwise launches.  The MonoSDF scale-and-shift depth loss (a 2 x 2 least-squares fit + gradient matching on the ray batch viewed
+as an image, losses.py:278-409; BASELINE config 4) and the foreground-mask BCE are one native launch each way as well
+(sdfhip_mono_depth_loss_*, sdfhip_fg_mask_loss_*); scale_and_shift_invariant_loss below is the general statement (any mask, any number of
+scales) for callers outside the surface models.
 """
 import ctypes
 from typing import Dict, List, Optional
@@ -159,7 +161,73 @@ def scale_and_shift_invariant_loss(prediction: torch.Tensor, target: torch.Tenso
     return total
 
 
+class _MonoDepthLoss(torch.autograd.Function):
+    """ScaleAndShiftInvariantLoss(alpha = 0.5, scales = 1) on the ray batch viewed as one 32-row image with an all-ones mask: one native
+    launch forward (fit, loss and the sums the backward needs), one backward - the gradient goes THROUGH the scale / shift fit as it
+    does under autograd in the reference."""
+
+    @staticmethod
+    def forward(ctx, depth_pred, depth_gt, rows, gt_scale, gt_shift, alpha):
+        lib = _lib.load()
+        p = depth_pred.detach().reshape(-1).contiguous().float()
+        g = depth_gt.detach().reshape(-1).contiguous().float()
+        loss = torch.empty(1, device=p.device)
+        state = torch.empty(10, device=p.device)
+        _lib.check(lib.sdfhip_mono_depth_loss_forward(_lib.ptr(p), _lib.ptr(g), p.numel(), int(rows), float(gt_scale), float(gt_shift),
+                                                      float(alpha), _lib.ptr(loss), _lib.ptr(state), _lib.stream()), "mono_depth_loss_forward")
+        ctx.save_for_backward(p, g, state)
+        ctx.cfg, ctx.shape = (int(rows), float(gt_scale), float(gt_shift), float(alpha)), depth_pred.shape
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, lbar):
+        lib = _lib.load()
+        p, g, state = ctx.saved_tensors
+        rows, gt_scale, gt_shift, alpha = ctx.cfg
+        lb = lbar.reshape(1).contiguous().float()
+        out = torch.empty_like(p)
+        _lib.check(lib.sdfhip_mono_depth_loss_backward(_lib.ptr(p), _lib.ptr(g), p.numel(), rows, gt_scale, gt_shift, alpha, _lib.ptr(state),
+                                                       _lib.ptr(lb), _lib.ptr(out), _lib.stream()), "mono_depth_loss_backward")
+        return out.view(ctx.shape), None, None, None, None, None
+
+
 def monosdf_depth_loss(depth_pred: torch.Tensor, depth_gt: torch.Tensor) -> torch.Tensor:
-    """base_surface_model.py:427-437: the ray batch is viewed as a 32 x (N/32) patch, the prior is rescaled (x 50 + 0.5)."""
+    """base_surface_model.py:427-437: the ray batch is viewed as a 32 x (N/32) patch, the prior is rescaled (x 50 + 0.5).  On the device:
+    the fused operator (sdfhip_mono_depth_loss_*); CPU tensors (host-side checks against the reference's class) take the statement."""
+    if depth_pred.is_cuda:
+        return _MonoDepthLoss.apply(depth_pred, depth_gt, 32, 50.0, 0.5, 0.5)
     mask = torch.ones_like(depth_gt).reshape(1, 32, -1).bool()
     return scale_and_shift_invariant_loss(depth_pred.reshape(1, 32, -1), (depth_gt * 50 + 0.5).reshape(1, 32, -1), mask, 0.5, 1)
+
+
+class _FgMaskLoss(torch.autograd.Function):
+    """mult * binary_cross_entropy(clip(acc, 1e-3, 1 - 1e-3), label) over the rays: one native launch each way."""
+
+    @staticmethod
+    def forward(ctx, acc, label, mult):
+        lib = _lib.load()
+        a = acc.detach().reshape(-1).contiguous().float()
+        y = label.detach().reshape(-1).contiguous().float()
+        loss = torch.empty(1, device=a.device)
+        _lib.check(lib.sdfhip_fg_mask_loss_forward(_lib.ptr(a), _lib.ptr(y), a.numel(), float(mult), _lib.ptr(loss), _lib.stream()),
+                   "fg_mask_loss_forward")
+        ctx.save_for_backward(a, y)
+        ctx.mult, ctx.shape = float(mult), acc.shape
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, lbar):
+        lib = _lib.load()
+        a, y = ctx.saved_tensors
+        lb = lbar.reshape(1).contiguous().float()
+        out = torch.empty_like(a)
+        _lib.check(lib.sdfhip_fg_mask_loss_backward(_lib.ptr(a), _lib.ptr(y), a.numel(), ctx.mult, _lib.ptr(lb), _lib.ptr(out), _lib.stream()),
+                   "fg_mask_loss_backward")
+        return out.view(ctx.shape), None, None
+
+
+def fg_mask_loss(weights_sum: torch.Tensor, fg_label: torch.Tensor, mult: float) -> torch.Tensor:
+    """base_surface_model.py:415-420: mult * BCE(clip(sum of the rendering weights per ray, 1e-3, 1 - 1e-3), foreground mask)."""
+    if weights_sum.is_cuda:
+        return _FgMaskLoss.apply(weights_sum, fg_label, mult)
+    return torch.nn.functional.binary_cross_entropy(weights_sum.clip(1e-3, 1.0 - 1e-3), fg_label) * mult

@@ -18,7 +18,7 @@ from sdfstudio_amd.cameras.rays import RayBundle
 from sdfstudio_amd.fields.density_fields import HashMLPDensityField
 from sdfstudio_amd.fields.field_heads import FieldHeadNames
 from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
-from sdfstudio_amd.model_components.losses import interlevel_loss_zip, monosdf_depth_loss, surface_losses
+from sdfstudio_amd.model_components.losses import fg_mask_loss, interlevel_loss_zip, monosdf_depth_loss, surface_losses
 from sdfstudio_amd.model_components.ray_samplers import ProposalNetworkSampler
 from sdfstudio_amd.model_components.renderers import neus_render
 from sdfstudio_amd.model_components.scene_colliders import build_collider
@@ -300,8 +300,7 @@ class NeuSFactoModel(nn.Module):
             normal_mult=c.mono_normal_loss_mult)
         if "fg_mask" in batch and c.fg_mask_loss_mult > 0.0:
             fg = batch["fg_mask"].float().to(image.device)
-            wsum = outputs["weights"].sum(dim=1).clip(1e-3, 1.0 - 1e-3)
-            loss["fg_mask_loss"] = F.binary_cross_entropy(wsum, fg) * c.fg_mask_loss_mult
+            loss["fg_mask_loss"] = fg_mask_loss(outputs["weights"].sum(dim=1), fg, c.fg_mask_loss_mult)  # clip + BCE + mean: one launch
         if "depth" in batch and c.mono_depth_loss_mult > 0.0:  # base_surface_model.py:427-437
             loss["depth_loss"] = monosdf_depth_loss(outputs["depth"], batch["depth"].to(image.device)[..., None]) * c.mono_depth_loss_mult
         weights = [w[..., 0] for w in outputs["weights_list"]]

@@ -290,6 +290,41 @@ def test_surface_losses_operator_against_torch(device):
     assert set(surface_losses(leaves[0].detach(), image.to(device))) == {"rgb_loss"}
 
 
+@pytest.mark.parametrize("n", [4096, 32 * 37])
+def test_mono_depth_and_fg_mask_losses_against_torch(device, n):
+    """The MonoSDF depth prior (ScaleAndShiftInvariantLoss as base_surface_model.py:427-437 calls it) and the foreground-mask BCE
+    (:415-420) as native operators against their torch statements in fp64 - scale_and_shift_invariant_loss is pinned on the reference's
+    class by the CPU suite: value, and the gradient w.r.t. the rendered depth INCLUDING its path through the scale / shift fit."""
+    from sdfstudio_amd.model_components.losses import fg_mask_loss, monosdf_depth_loss, scale_and_shift_invariant_loss
+
+    gen = torch.Generator().manual_seed(n)
+    depth = (1.5 + torch.rand(n, 1, generator=gen) * 2.0 + 0.3 * torch.sin(torch.arange(n)[:, None] * 0.01))
+    gt = (0.02 * depth + 0.004 * torch.randn(n, 1, generator=gen)).clamp_min(1e-3)  # a monocular prior: affine in the depth + noise
+    ref_in = depth.clone().double().requires_grad_(True)
+    mask = torch.ones(1, 32, n // 32, dtype=torch.bool)
+    ref = scale_and_shift_invariant_loss(ref_in.reshape(1, 32, -1), (gt.double() * 50 + 0.5).reshape(1, 32, -1), mask, 0.5, 1)
+    (ref * 1.7).backward()
+    got_in = depth.clone().to(device).requires_grad_(True)
+    got = monosdf_depth_loss(got_in, gt.to(device))
+    (got * 1.7).backward()
+    assert_close("depth loss", got, ref.float(), rtol=2e-5, atol=1e-8)
+    assert_close("d depth loss / d depth", got_in.grad, ref_in.grad.float(), rtol=2e-4, atol=1e-9, elem_rtol=float("inf"))  # |x| kinks: sign flips of near-ties
+    # foreground mask: weights sums on both sides of the clip, hard and soft labels
+    acc = torch.rand(n, 1, generator=gen) * 1.2 - 0.1
+    acc[:4, 0] = torch.tensor([0.0, 1.0, 1e-3, 1.0 - 1e-3])
+    label = (torch.rand(n, 1, generator=gen) > 0.5).float()
+    label[7:11] = torch.rand(4, 1, generator=gen)
+    r_in = acc.clone().double().requires_grad_(True)
+    r = F.binary_cross_entropy(r_in.clip(1e-3, 1.0 - 1e-3), label.double()) * 0.01
+    (r * 3.0).backward()
+    g_in = acc.clone().to(device).requires_grad_(True)
+    gl = fg_mask_loss(g_in, label.to(device), 0.01)
+    (gl * 3.0).backward()
+    assert_close("fg mask loss", gl, r.float(), rtol=1e-5, atol=1e-9)
+    inside = ((acc > 1e-3 + 1e-6) & (acc < 1.0 - 1e-3 - 1e-6)) | (acc < 1e-3 - 1e-6) | (acc > 1.0 - 1e-3 + 1e-6)  # fp32 / fp64 disagree AT the clip bounds
+    assert_close("d fg loss / d acc", g_in.grad[inside], r_in.grad.float()[inside], rtol=1e-5, atol=1e-9)
+
+
 def test_gradient_slots_give_the_same_gradients_as_plain_autograd(device):
     """grad_slots.py end to end on the golden NeuS-facto model: with a FlatGradients the native backward kernels write parameter
     gradients straight into the flat buffer (no AccumulateGrad launch); the flat buffer must equal what plain autograd leaves in
