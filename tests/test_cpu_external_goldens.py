@@ -57,3 +57,57 @@ def test_oracle_march_and_resampling_against_real_nerfacc(path):
     assert torch.equal(rinfo[:, 1], t("resampled_packed_info")[:, 1].long())
     assert (rs.view(-1) - t("resampled_starts").view(-1)).abs().max().item() <= 2e-6
     assert (re.view(-1) - t("resampled_ends").view(-1)).abs().max().item() <= 2e-6
+
+
+def test_tcnn_state_dict_layout_round_trip():
+    """utils/tcnn_state_dict.py (UNVERIFIED against a real tcnn until tests/golden/tcnn_net_*.npz exist): the statement of the layout is at
+    least self-consistent - sizes, padding, order (network before encoding), and the model-level conversion is an exact round trip."""
+    from sdfstudio_amd.utils import tcnn_state_dict as T
+
+    # the proposal network: 10 inputs -> 16 -> 1: two 16 x 16 matrices in params, then the table
+    assert T.mlp_matrix_shapes(10, 16, 1, 1) == [(16, 10, 16, 16), (1, 16, 16, 16)]
+    assert T.mlp_param_count(32, 64, 1, 16) == 64 * 32 + 16 * 64 and T.mlp_param_count(63, 64, 2, 3) == 64 * 64 + 64 * 64 + 16 * 64
+    gen = torch.Generator().manual_seed(0)
+    params = torch.randn(512 + 40, generator=gen)
+    (w1, w2), table = T.split_params(params, 10, 16, 1, 1, n_grid=40)
+    assert w1.shape == (16, 10) and w2.shape == (1, 16) and torch.equal(table, params[512:])
+    assert torch.equal(w1, params[:256].view(16, 16)[:, :10]) and torch.equal(w2[0], params[256:272])
+    back = T.join_params([w1, w2], 10, 16, 1, 1, table)
+    keep = torch.zeros(512 + 40, dtype=torch.bool)
+    keep[:256].view(16, 16)[:, :10] = True
+    keep[256:272] = True
+    keep[512:] = True
+    assert torch.equal(back[keep], params[keep]) and float(back[~keep].abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        T.split_params(params[:-1], 10, 16, 1, 1, n_grid=40)
+
+
+def test_tcnn_state_dict_model_round_trip():
+    from sdfstudio_amd.fields.density_fields import HashMLPDensityField
+    from sdfstudio_amd.fields.nerfacto_field import TCNNNerfactoField
+    from sdfstudio_amd.models.neus_facto import SceneContraction
+    from sdfstudio_amd.utils import tcnn_state_dict as T
+
+    class Holder(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
+            self.proposal_networks = torch.nn.ModuleList([
+                HashMLPDensityField(aabb, spatial_distortion=SceneContraction(order=float("inf")), log2_hashmap_size=9, max_res=32)])
+            self.field_background = TCNNNerfactoField(aabb, num_images=3, num_levels=4, max_res=32, log2_hashmap_size=8,
+                                                      spatial_distortion=SceneContraction(order=float("inf")))
+            self.other = torch.nn.Linear(3, 2)
+
+    m = Holder()
+    sd = m.state_dict()
+    ref = T.to_reference_state_dict(sd, m)
+    assert "proposal_networks.0.mlp_base.params" in ref and "proposal_networks.0.mlp_base.w1" not in ref
+    assert "field_background.mlp_head.params" in ref and "field_background.mlp_base.params" in ref and "other.weight" in ref
+    n_table = m.proposal_networks[0].mlp_base.table.numel()
+    assert ref["proposal_networks.0.mlp_base.params"].numel() == 2 * 16 * 16 + n_table
+    assert ref["field_background.mlp_head.params"].numel() == 64 * 64 + 64 * 64 + 16 * 64  # 63 inputs padded to 64, 3 outputs to 16
+    again = T.from_reference_state_dict(ref, m)
+    assert set(again) == set(sd)
+    for k in sd:
+        assert torch.equal(again[k].cpu(), sd[k].cpu()), k
+    m.load_state_dict(again)  # strict

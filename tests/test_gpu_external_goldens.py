@@ -46,3 +46,31 @@ def test_hip_march_and_resampling_against_real_nerfacc(device, path):
     _, _, _, rs, re = resample_packed(info, counts, ts, te, t("weights"), 16)
     assert (rs.view(-1).cpu() - torch.from_numpy(z["resampled_starts"]).view(-1)).abs().max().item() <= 2e-6
     assert (re.view(-1).cpu() - torch.from_numpy(z["resampled_ends"]).view(-1)).abs().max().item() <= 2e-6
+
+
+TCNN_NET = sorted(glob.glob(os.path.join(GOLDEN, "tcnn_net_proposal*.npz")))
+
+
+@pytest.mark.skipif(not TCNN_NET, reason="no tests/golden/tcnn_net_*.npz: utils/tcnn_state_dict.py stays unverified")
+@pytest.mark.parametrize("path", TCNN_NET or ["absent"])
+def test_converted_tcnn_params_against_real_tcnn(device, path):
+    """A real tcnn NetworkWithInputEncoding's flat `params`, converted by utils/tcnn_state_dict.py and loaded into HashMLPDensityField,
+    must reproduce the real module's outputs (tcnn computes in fp16: 2e-2 absolute on the pre-activation; a wrong layout gives noise)."""
+    import math
+
+    from sdfstudio_amd.fields.density_fields import HashMLPDensityField
+    from sdfstudio_amd.models.neus_facto import SceneContraction
+    from sdfstudio_amd.utils import tcnn_state_dict as T
+
+    z = np.load(path)
+    L, F, log2_t, base, max_res, hidden = [int(v) for v in z["cfg"]]
+    fld = HashMLPDensityField(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), hidden_dim=hidden, num_levels=L, max_res=max_res, base_res=base,
+                              log2_hashmap_size=log2_t, features_per_level=F, spatial_distortion=SceneContraction(order=float("inf")))
+    sd = T.from_reference_state_dict({"mlp_base.params": torch.from_numpy(z["params"])}, fld)
+    fld.load_state_dict(sd, strict=True)
+    fld = fld.to(device)
+    x01 = torch.from_numpy(z["x"]).to(device)
+    dens = fld.density_fn(4.0 * x01 - 2.0)[..., 0]  # the field maps contracted positions to (x + 2) / 4 and applies trunc_exp
+    got = torch.log(dens).cpu()
+    ref = torch.from_numpy(z["y"]).view(-1)
+    assert (got - ref).abs().max().item() <= 2e-2 + 1e-2 * ref.abs().max().item(), "converted parameters do not reproduce tcnn's outputs"

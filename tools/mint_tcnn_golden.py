@@ -54,5 +54,32 @@ def main():
         print("wrote", name, y.shape)
 
 
+def mint_networks(out_dir):
+    """tests/golden/tcnn_net_*.npz: a real NetworkWithInputEncoding's flat `params`, inputs and outputs - pins the parameter LAYOUT that
+    sdfstudio_amd/utils/tcnn_state_dict.py restates (network before encoding, row-major matrices, 16-padding)."""
+    import tinycudann as tcnn  # noqa: PLC0415
+
+    dev = torch.device("cuda")
+    # HashMLPDensityField(num_levels=5, max_res=64, log2_hashmap_size=17, hidden_dim=16, num_layers=2) - fields/density_fields.py:75-94
+    L, F, log2_t, base, max_res, hidden = 5, 2, 17, 16, 64, 16
+    growth = math.exp((math.log(max_res) - math.log(base)) / (L - 1))
+    net = tcnn.NetworkWithInputEncoding(n_input_dims=3, n_output_dims=1, encoding_config={
+        "otype": "HashGrid", "n_levels": L, "n_features_per_level": F, "log2_hashmap_size": log2_t, "base_resolution": base,
+        "per_level_scale": growth}, network_config={
+        "otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": hidden, "n_hidden_layers": 1})
+    gen = torch.Generator().manual_seed(5)
+    params = (torch.rand(net.params.numel(), generator=gen) * 2 - 1) * 0.5
+    x = 0.25 + 0.5 * torch.rand(2048, 3, generator=gen)  # inside the cube the scene contraction leaves alone
+    with torch.no_grad():
+        net.params.copy_(params.to(dev))
+        y = net(x.to(dev)).float().cpu()
+    np.savez_compressed(os.path.join(out_dir, "tcnn_net_proposal0.npz"), params=params.numpy(), x=x.numpy(), y=y.numpy(),
+                        cfg=np.array([L, F, log2_t, base, max_res, hidden], np.int64), growth=np.float64(growth),
+                        params_dtype=str(net.params.dtype), tcnn_version=str(getattr(tcnn, "__version__", "unknown")),
+                        device=torch.cuda.get_device_name(0))
+    print("wrote tcnn_net_proposal0", y.shape, net.params.dtype)
+
+
 if __name__ == "__main__":
     main()
+    mint_networks(sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
