@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libsdfhip.so")
-SOURCES = ["inst_a_inf.hip", "inst_c_inf.hip", "inst_a_bwd.hip", "inst_c_bwd.hip", "inst_a_fwd.hip", "inst_c_fwd.hip", "inst_b.hip", "api.hip", "inst_d.hip", "inst_e.hip",
+SOURCES = ["inst_a_inf.hip", "inst_c_inf.hip", "inst_a_bwd.hip", "inst_c_bwd.hip", "inst_a_fwd.hip", "inst_c_fwd.hip", "inst_b.hip", "api.hip", "inst_w.hip", "inst_d.hip", "inst_e.hip",
            "inst_a.hip", "inst_c.hip"]  # slowest first
 # -fno-slp-vectorize: the SLP pass packs adjacent scalar fp32 adds / muls of the producers into v_pk_* instructions, which cost
 # MORE issue time beside MFMAs than the scalar forms (MI355X_MICROARCH.md, "price of one filler"), and it is ~20 % of the compile time

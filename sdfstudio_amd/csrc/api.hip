@@ -21,6 +21,7 @@ const FieldKernels* sdfhip_kernels_B();
 const FieldKernels* sdfhip_kernels_C();
 const FieldKernels* sdfhip_kernels_D();
 const FieldKernels* sdfhip_kernels_E();
+const FieldKernels* sdfhip_kernels_W();
 
 static thread_local char g_err[1024] = "";
 void sdfhip_set_error(const char* fmt, ...) {
@@ -265,7 +266,8 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
   // nb3: width (blocks) of the layer below the skip concatenation.  Its H - D0 real rows are padded to the FULL hidden width,
   // so that every hidden layer has the same shape and the fused kernels can loop over them (geo_kernels.h)
   const int nb0 = (D0 + 31) / 32, nb3 = skip >= 0 ? H / 32 : 0, nbs = (33 + E + 31) / 32;
-  const FieldKernels* cands[] = {sdfhip_kernels_A(), sdfhip_kernels_B(), sdfhip_kernels_C(), sdfhip_kernels_D(), sdfhip_kernels_E()};
+  const FieldKernels* cands[] = {sdfhip_kernels_A(), sdfhip_kernels_B(), sdfhip_kernels_C(), sdfhip_kernels_D(), sdfhip_kernels_E(),
+                                 sdfhip_kernels_W()};
   f->k = nullptr;
   for (const FieldKernels* k : cands) {
     // in0 may be narrower than the instantiation's in0 blocks (the encode kernel zero-fills the rest, the packed weights have zero
@@ -497,11 +499,13 @@ static void carve(const SdfHipField* f, int64_t n_points, int level, void* base,
   w->x = take(np * 3);
   w->in0 = take(np * k->nb0 * 32);
   w->feat = take(np * k->nbf * 32);
+  if (!full && k->layerwise)  // point modes of the layer-at-a-time kernels: the activations are the hand-over between launches
+    for (int l = 0; l < f->nl; ++l) w->u[l] = take(np * f->nbo_geo(l) * 32);
   if (full) {
     w->dydp = take(np * f->n_feat * 3);
     for (int l = 0; l < f->nl; ++l) {
       w->u[l] = take(np * f->nbo_geo(l) * 32);
-      if (train) w->r[l] = take(np * f->nbo_geo(l) * 32);
+      if (train || k->layerwise) w->r[l] = take(np * f->nbo_geo(l) * 32);
     }
     w->e = take(np * k->nb0 * 32);
     w->csmall = take(np * k->nbs * 32);

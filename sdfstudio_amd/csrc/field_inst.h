@@ -15,6 +15,8 @@ struct FieldKernels {
                  float* partial, unsigned grid, hipStream_t);
   int act;  // hidden activation of the geometry-type network (common.h act_h): 0 Softplus(100); 1 ReLU - first-order entries only
             // (geo_fwd modes 1 - 3, geo_bwd1; geo_bwd is null)
+  int layerwise = 0;  // 1: the geometry network runs one layer per launch (wide_kernels.h): the per-layer tensors are its inter-layer
+                      // storage, so the workspace holds them in EVERY mode
 };
 
 // Kernels that want more than 64 KiB of dynamic LDS must raise the per-function limit first.

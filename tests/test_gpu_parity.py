@@ -1061,6 +1061,45 @@ def test_field_full_size_fwd_bwd(device):
     _check_field_grads(model, po, rtol=1e-3, truth=p64)
 
 
+@pytest.mark.parametrize("nl", [8, 2, 5])
+def test_field_hidden_512_layer_by_layer(device, nl):
+    """Hidden width 512 (neus-facto-bigmlp, method_configs.py:503-523: num_layers 8, hidden_dim 512, colour 4 x 256; also a shallow
+    network without the skip connection and a 5-layer one whose skip layer is the last hidden layer): two 16-block accumulator sets do
+    not fit a wave, the geometry network runs layer by layer (csrc/wide_kernels.h) on the per-layer tensors of the training data flow.
+    Same bars as the fused shapes: sdf 1e-5, everything else fp64-anchored; plus the inference entries (get_sdf, forward_geonetwork,
+    the no-grad forward) that run the same launches without a backward."""
+    fcfg = O.FieldCfg(num_layers=nl, hidden_dim=512, num_layers_color=4, bias=0.5, inside_outside=False, beta_init=0.3)
+    cfg = O.ModelCfg(field=fcfg)
+    p = _full_shape_params(cfg, seed=31 + nl)
+    model = product_model_from_params(p, cfg, device).train()
+    n, s = 33, 40
+    o, d, cam, starts = _field_case(cfg, p, n, s, seed=23)
+    coefs = [torch.randn(n, s), torch.randn(n, s, 3) * 0.3, torch.randn(n, s, 3)]
+    fo, po = _oracle_field(cfg.field, p, o, d, cam, starts, coefs)
+    sdf, grad, rgb, x = _product_field(model, o, d, cam, starts, coefs, device)
+    tag = f"({nl}x512 + 4x256)"
+    assert_close(f"sdf {tag}", sdf, fo["sdf"], rtol=0, atol=1e-5)
+    f64, p64 = _oracle_field(cfg.field, to_double(p), o.double(), d.double(), cam, starts.double(), [c.double() for c in coefs])
+    assert_fp32_class(f"gradient {tag}", grad, fo["gradient"], f64["gradient"], factor=3.0, atol=2e-5)
+    assert_fp32_class(f"rgb {tag}", rgb, fo["rgb"], f64["rgb"], factor=3.0, atol=2e-5)
+    _check_field_grads(model, po, rtol=1e-3, truth=p64, min_checked=2 * (nl + 1) + 2 * 5, clin_rtol=3e-2)
+    # inference entries: nothing differentiated, same launches
+    model.eval()
+    rb = _bundle(o, d, cam, 0.5, 4.5, device)
+    st = starts.to(device)
+    rs = rb.get_ray_samples(st, st + 1.0)
+    with torch.no_grad():
+        sdf_e, grad_e, rgb_e, _ = model.field.forward_fused(rs)
+    assert_close("eval-mode sdf == training sdf", sdf_e, sdf.detach(), rtol=0, atol=0)
+    assert_close("eval-mode gradient", grad_e, grad.detach(), rtol=0, atol=0)
+    pos = (o[:, None, :] + d[:, None, :] * starts[..., None]).reshape(-1, 3)
+    with torch.no_grad():
+        h = O.geo_network(pos, p, cfg.field)
+    assert_close("get_sdf", model.field.get_sdf(rs)[..., 0], h[:, 0].view(n, s), rtol=0, atol=1e-5)
+    out = model.field.forward_geonetwork(pos.to(device))
+    assert_close("forward_geonetwork feat", out[:, 1:], h[:, 1:], rtol=1e-4, atol=1e-5)
+
+
 @pytest.mark.parametrize("shape", [(2, 2, 256), (1, 1, 256), (5, 2, 256), (6, 3, 256), (7, 4, 256), (9, 5, 256), (5, 1, 64), (2, 3, 64), (9, 2, 64)],
                          ids=lambda t: f"{t[0]}x{t[2]}+{t[1]}x{t[2]}")
 def test_field_depth_sweep_fwd_bwd(device, shape):
