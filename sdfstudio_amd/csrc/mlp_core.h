@@ -74,8 +74,8 @@ struct WStream {
                                      (__attribute__((address_space(3))) void*)(dst + piece * 256), 16, 0, 0);
   }
   // The weight chunk about to be consumed has landed in LDS for every wave, and every wave is done reading the other
-  // buffer.  NEWER = number of vector-memory operations this wave issued AFTER the chunk's DMA (the producer's stores):
-  // vmcnt retires in issue order, so waiting for "at most NEWER outstanding" covers the DMA without draining those stores.
+  // buffer.  NEWER = vector-memory operations allowed to stay outstanding: 0 since round 3 (tp_gemm explains why the counted form -
+  // "the operations issued after the chunk's DMA may stay in flight" - was not safe).
   // A bare s_barrier (no workgroup release fence) keeps the compiler from adding its own vmcnt(0) in front of it.
   template <int NEWER>
   SDFHIP_D void wait_sync() {
@@ -226,10 +226,20 @@ SDFHIP_D void tp_gemm(f32x16 (&acc)[MAXA], Raw& carry, Fetch&& fetch, Make&& mak
     {
       // vector-memory operations issued after the DMA of chunk kb: the loads of fetch(kb + 1), then the stores of make(kb)
       constexpr int newer_ = ST::at(kb) + (more ? 16 * decltype(fetch(IC<(more ? kb + 1 : 0)>{}))::n : 0);
-#ifdef SDFHIP_ABL_WAIT_SLACK  // timing ablation (RACY: the chunk may not have landed): what the wait for the weight DMA costs through the
-      constexpr int newer = newer_ + SDFHIP_ABL_WAIT_SLACK;  // older stores it also waits for (vmcnt retires in issue order)
-#else
+      // Round 3: the wait DRAINS the wave's vector-memory queue (vmcnt(0)).  Rounds 1 - 2 waited with the count above ("at most
+      // `newer_` operations outstanding": the loads / stores issued after the chunk's DMA may stay in flight), on the premise that
+      // vmcnt retires strictly in issue order.  That premise does not hold between an LDS-DMA and the ordinary loads / stores behind it:
+      // on the 64-wide golden network one no-grad forward in five came back with a workgroup's (or a few waves') colour outputs off by
+      // ~5e-5 - a gemm had started on a weight chunk that was still landing (tools/debug_fwd.py: 60 / 60 calls bit-identical with the
+      // drain, sdf and normals were never affected; the full-size shapes never showed it, their steps are long enough).  The drain costs
+      // 0.2 ms per config-2 step (22.67 -> 22.89 ms, same box).  -DSDFHIP_COUNTED_WAIT restores the counted form for experiments.
+#ifdef SDFHIP_ABL_WAIT_SLACK  // timing ablation (RACY on purpose): what the wait costs through the older stores it also covers
+      constexpr int newer = newer_ + SDFHIP_ABL_WAIT_SLACK;
+#elif defined(SDFHIP_COUNTED_WAIT)
       constexpr int newer = newer_;
+#else
+      constexpr int newer = 0;
+      (void)newer_;
 #endif
       ws.template wait_sync<(newer < 63 ? newer : 63)>();
     }

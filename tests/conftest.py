@@ -31,3 +31,25 @@ def _deterministic_draws(request):
 
     torch.manual_seed(zlib.crc32(request.node.nodeid.encode()) & 0x7FFFFFFF)
     yield
+
+
+@pytest.fixture(autouse=True)
+def _poisoned_allocator(request):
+    """SDFHIP_TEST_POISON=1 (debugging aid): before every GPU test the caching allocator's free blocks are filled with NaN, so that a
+    kernel which reads memory nobody wrote (workspace padding, rows beyond the last point, a forgotten zero fill) turns its result
+    into NaN instead of depending on what an earlier test left there."""
+    if os.environ.get("SDFHIP_TEST_POISON") != "1" or request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    import torch
+
+    if torch.cuda.is_available():
+        blocks = []
+        try:
+            for n in (1 << 28, 1 << 26, 1 << 24, 1 << 22, 1 << 20, 1 << 18, 1 << 16):  # 1 GiB ... 256 KiB: large and small pools
+                for _ in range(3):
+                    blocks.append(torch.full((n,), float("nan"), device="cuda"))
+        except RuntimeError:
+            pass
+        del blocks
+    yield
