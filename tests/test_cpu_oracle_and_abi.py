@@ -861,3 +861,127 @@ def test_oracle_nerf_background_field_against_reference():
         assert_close("density", out["density"], ref["DENSITY"][..., 0], rtol=1e-5, atol=1e-7)
         assert_close("rgb", out["rgb"], ref["RGB"], rtol=1e-5, atol=1e-6)
         assert float(out["rgb"].std()) > 1e-3
+
+
+def _replay_rand(n, queue):
+    """torch.rand replacement that replays `queue` (in call order) for every [n, k] request and passes anything else through."""
+    real_rand = torch.rand
+
+    def fake(*size, **kw):
+        shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else size
+        if len(shape) == 2 and shape[0] == n and queue:
+            t = queue.pop(0)
+            assert tuple(t.shape) == tuple(shape), (tuple(t.shape), shape)
+            return t.clone()
+        return real_rand(*size, **kw)
+
+    return real_rand, fake
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/nerfstudio"), reason="the reference tree only exists in the build container")
+@pytest.mark.parametrize("single_jitter", [True, False])
+def test_neus_sampler_oracle_against_reference_both_jitter_modes(single_jitter):
+    """oracle.neus_sampler pinned LIVE on the reference's NeuSSampler (ray_samplers.py:815-897) for single_jitter True and False (one
+    draw per ray / one per bin edge: :107-110, :321-330), with an analytic sdf and the draws replayed in call order.  The GPU test
+    test_neus_sampler_per_sample_jitter compares the kernels with this oracle."""
+    from oracle import ref_harness
+
+    ns = ref_harness.import_reference()
+    torch.manual_seed(6)
+    n, S, n_imp, steps = 19, 24, 32, 4
+    o, d, _ = O.synthetic_rays(n, seed=8)
+    nears, fars = torch.full((n, 1), 0.5), torch.full((n, 1), 4.5)
+    k0, k1 = (1, 1) if single_jitter else (S + 1, n_imp // steps + 1)
+    draws = [torch.rand(n, k0)] + [torch.rand(n, k1) for _ in range(steps)]
+    rb = ns.rays.RayBundle(origins=o, directions=d, pixel_area=torch.ones(n, 1), nears=nears.clone(), fars=fars.clone())
+    smp = ns.rs.NeuSSampler(num_samples=S, num_samples_importance=n_imp, num_samples_outside=0, num_upsample_steps=steps,
+                            base_variance=64, single_jitter=single_jitter).train()
+    real_rand, fake = _replay_rand(n, [t.clone() for t in draws])
+    torch.rand = fake
+    try:
+        rs = smp(rb, sdf_fn=lambda r: r.frustums.get_start_positions().norm(dim=-1, keepdim=True) - 1.0)
+    finally:
+        torch.rand = real_rand
+    bins, starts, ends = O.neus_sampler(o, d, nears[:, 0], fars[:, 0], lambda t: (o[:, None, :] + d[:, None, :] * t[..., None]).norm(dim=-1) - 1.0,
+                                        num_samples=S, num_samples_importance=n_imp, num_upsample_steps=steps, rand=draws)
+    assert rs.frustums.starts.shape == (n, S + n_imp, 1)
+    # inverse CDF with histogram_padding 1e-5: one fp32 ulp of the cdf moves an edge by ~1e-4 of a bin; identical statement on both sides
+    assert torch.allclose(rs.frustums.starts[..., 0], starts, rtol=0, atol=2e-5), (rs.frustums.starts[..., 0] - starts).abs().max()
+    assert torch.allclose(rs.frustums.ends[..., 0], ends, rtol=0, atol=2e-5)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/nerfstudio"), reason="the reference tree only exists in the build container")
+@pytest.mark.parametrize("training", [True, False])
+def test_proposal_sampler_with_uniform_initial_sampler_against_reference(training):
+    """ProposalNetworkSampler(use_uniform_sampler=True) (ray_samplers.py:517-522) of the REFERENCE against the oracle statements composed the
+    way tests/test_gpu_parity.py::test_proposal_sampler_with_uniform_initial_sampler composes them (initial_bins -> weights_from_density ->
+    pdf_sample in the uniform spacing domain, twice): pins that composition."""
+    from oracle import ref_harness
+
+    ns = ref_harness.import_reference()
+    torch.manual_seed(12)
+    n, counts, s_final = 17, (48, 24), 16
+    o, d, _ = O.synthetic_rays(n, seed=4)
+    nears, fars = torch.full((n, 1), 0.5), torch.full((n, 1), 4.5)
+    peaks = [1.7, 2.4]
+    rb = ns.rays.RayBundle(origins=o, directions=d, pixel_area=torch.ones(n, 1), nears=nears.clone(), fars=fars.clone())
+    smp = ns.rs.ProposalNetworkSampler(num_proposal_samples_per_ray=counts, num_nerf_samples_per_ray=s_final, num_proposal_network_iterations=2,
+                                       use_uniform_sampler=True, single_jitter=True).train(training)
+    t0, u = torch.rand(n, 1), torch.rand(n, 1)
+    real_rand, fake = _replay_rand(n, [t0.clone(), u.clone(), u.clone()])
+    fns = [lambda pos, c=c: None for c in peaks]  # replaced below: the reference hands POSITIONS to density_fns (ray_samplers.py:566-571)
+
+    def density_of(c):
+        def fn(positions):
+            t = ((positions - o[:, None, :]) * d[:, None, :]).sum(-1, keepdim=True)  # |d| = 1: distance along the ray of the frustum centre
+            return 6.0 * torch.exp(-4.0 * (t - c) ** 2)
+        return fn
+
+    fns = [density_of(c) for c in peaks]
+    torch.rand = fake
+    try:
+        rs, weights_list, samples_list = smp(rb, density_fns=fns)
+    finally:
+        torch.rand = real_rand
+    bins = O.initial_bins(n, counts[0], t0 if training else None)
+    for lvl, c in enumerate(peaks):
+        eu = O.uniform_to_euclidean(bins, nears[:, 0], fars[:, 0])
+        ref_lvl = samples_list[lvl]
+        assert torch.allclose(ref_lvl.frustums.starts[..., 0], eu[:, :-1], rtol=1e-6, atol=2e-5), lvl
+        dens = 6.0 * torch.exp(-4.0 * ((eu[:, :-1] + eu[:, 1:]) / 2 - c) ** 2)
+        w = O.weights_from_density(dens, eu[:, 1:] - eu[:, :-1])
+        assert torch.allclose(weights_list[lvl][..., 0], w, rtol=1e-4, atol=1e-6), lvl
+        bins = O.pdf_sample(w, bins, counts[1] if lvl == 0 else s_final, u if training else None)
+    eu = O.uniform_to_euclidean(bins, nears[:, 0], fars[:, 0])
+    assert torch.allclose(rs.frustums.starts[..., 0], eu[:, :-1], rtol=1e-5, atol=5e-5), (rs.frustums.starts[..., 0] - eu[:, :-1]).abs().max()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/nerfstudio"), reason="the reference tree only exists in the build container")
+def test_geo_network_without_weight_norm_against_reference():
+    """SDFFieldConfig(weight_norm=False) (sdf_field.py:146, 312-313, 360-361): the reference's plain nn.Linear layers against
+    oracle.geo_network / color_network fed the same `glin{l}.weight` / `.bias` tensors - the oracle side of test_field_without_weight_norm."""
+    from oracle import ref_harness
+
+    ref_harness.import_reference()
+    from nerfstudio.fields.sdf_field import SDFField as RefField, SDFFieldConfig as RefCfg
+
+    torch.manual_seed(5)
+    fc = small_oracle_cfg().field
+    cfg = RefCfg(num_layers=fc.num_layers, hidden_dim=fc.hidden_dim, geo_feat_dim=fc.geo_feat_dim, num_layers_color=fc.num_layers_color,
+                 hidden_dim_color=fc.hidden_dim_color, bias=fc.bias, inside_outside=fc.inside_outside, use_grid_feature=True,
+                 beta_init=fc.beta_init, num_levels=fc.num_levels, max_res=fc.max_res, base_res=fc.base_res,
+                 log2_hashmap_size=fc.log2_hashmap_size, hash_features_per_level=fc.hash_features_per_level, hash_smoothstep=fc.hash_smoothstep,
+                 use_appearance_embedding=fc.use_appearance_embedding, weight_norm=False)
+    fld = RefField(cfg, aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_images=49)
+    names = dict(fld.named_parameters())
+    assert "glin0.weight" in names and "glin0.weight_v" not in names
+    with torch.no_grad():
+        for k, v in names.items():
+            if k.startswith(("glin", "clin")) and k.endswith("weight"):
+                v.add_(0.05 * torch.randn_like(v))
+    p = {k: v.detach().clone() for k, v in fld.state_dict().items()}
+    x = torch.rand(257, 3) * 2 - 1
+    with torch.no_grad():
+        ref = fld.forward_geonetwork(x)
+        got = O.geo_network(x, p, fc)
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6), (got - ref).abs().max()
