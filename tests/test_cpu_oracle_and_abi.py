@@ -985,3 +985,54 @@ def test_geo_network_without_weight_norm_against_reference():
         ref = fld.forward_geonetwork(x)
         got = O.geo_network(x, p, fc)
     assert torch.allclose(got, ref, rtol=1e-5, atol=1e-6), (got - ref).abs().max()
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/nerfstudio"), reason="the reference tree only exists in the build container")
+@pytest.mark.parametrize("grid", [False, True], ids=["pure-mlp (the preset: use_grid_feature defaults to False)", "with the hash grid"])
+def test_oracle_field_at_the_bigmlp_width_against_reference(grid):
+    """The oracle's field at the neus-facto-bigmlp shape (method_configs.py:503-523: 8 x 512 geometry MLP, 4 x 256 colour MLP, everything else
+    default) against the reference's SDFField LIVE - sdf, analytic gradient (autograd.grad through the network), rgb and two parameter
+    gradients on a handful of samples.  Anchors tests/test_gpu_parity.py::test_field_hidden_512_layer_by_layer, which compares the
+    layer-at-a-time HIP kernels with this oracle."""
+    from oracle import ref_harness
+
+    ns = ref_harness.import_reference()
+    H = ns.FieldHeadNames
+    torch.manual_seed(9)
+    fc = O.FieldCfg(num_layers=8, hidden_dim=512, num_layers_color=4, bias=0.5, inside_outside=False, beta_init=0.3, log2_hashmap_size=12,
+                    use_grid_feature=grid)
+    p = O.init_field_params(fc, num_images=49, seed=3)
+    for k in list(p):
+        if k.endswith("weight_v"):
+            p[k] = p[k] + 0.02 * torch.randn(p[k].shape)
+        elif k == "encoding.params":
+            p[k] = (torch.rand(p[k].shape) * 2 - 1) * 0.1
+    rcfg = ns.sf.SDFFieldConfig(num_layers=8, hidden_dim=512, num_layers_color=4, bias=0.5, inside_outside=False, beta_init=0.3, log2_hashmap_size=12,
+                                use_grid_feature=grid)
+    fld = ns.sf.SDFField(rcfg, torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_images=49, spatial_distortion=ns.sd.SceneContraction(order=float("inf")))
+    sd = fld.state_dict()
+    for k in sd:
+        if k in p:
+            assert sd[k].shape == p[k].shape, (k, tuple(sd[k].shape), tuple(p[k].shape))
+            sd[k] = p[k].clone()
+    fld.load_state_dict(sd)
+    fld.train()
+    n, s = 7, 5
+    o, d, cam = O.synthetic_rays(n, seed=2)
+    starts = torch.sort(torch.rand(n, s) * 4.0 + 0.5, dim=-1)[0]
+    rb = ns.rays.RayBundle(origins=o, directions=d, pixel_area=torch.ones(n, 1), directions_norm=torch.ones(n, 1), camera_indices=cam[:, None],
+                           nears=torch.full((n, 1), 0.5), fars=torch.full((n, 1), 4.5))
+    rs = rb.get_ray_samples(bin_starts=starts[..., None], bin_ends=starts[..., None] + 1.0)
+    out = fld(rs, return_alphas=True)
+    coef = [torch.randn(n, s), torch.randn(n, s, 3) * 0.3, torch.randn(n, s, 3)]
+    ((out[H.SDF][..., 0] * coef[0]).sum() + (out[H.GRADIENT] * coef[1]).sum() + (out[H.RGB] * coef[2]).sum()).backward()
+    po = {k: v.clone().requires_grad_(v.is_floating_point() and k != "laplace_density.beta_min") for k, v in p.items()}
+    fo = O.field_outputs(o, d, starts, torch.ones(n, s), cam, po, fc)
+    ((fo["sdf"] * coef[0]).sum() + (fo["gradient"] * coef[1]).sum() + (fo["rgb"] * coef[2]).sum()).backward()
+    assert torch.allclose(fo["sdf"], out[H.SDF][..., 0], rtol=0, atol=2e-6)
+    assert torch.allclose(fo["gradient"], out[H.GRADIENT], rtol=1e-5, atol=1e-5)
+    assert torch.allclose(fo["rgb"], out[H.RGB], rtol=0, atol=2e-6)
+    ref_grads = dict(fld.named_parameters())
+    for k in ("glin4.weight_v", "glin8.weight_g", "clin0.weight_v", "glin0.bias"):
+        g_ref, g_or = ref_grads[k].grad, po[k].grad
+        assert g_ref is not None and (g_or - g_ref).abs().max().item() <= 1e-4 * g_ref.abs().max().item() + 1e-8, k
