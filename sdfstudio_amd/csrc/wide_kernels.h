@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, 1) void wide_tan_kernel(const GeoBwdArgs a, co
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
   constexpr int NS = kNsGrad, PCS = chunk_pieces(D::NBH, NS);
-  const int NL = a.p.nl, SKIP = a.p.skip;
+  const int SKIP = a.p.skip;
   const float* w_h = a.p.wp[l];
   const float* w_i = HID ? geo_skip_in0<D>(a.p.wp[l]) : a.p.wp[l];
   WStream ws{lds, D::buf_floats(NS), 0, wave, lane};
@@ -230,7 +230,6 @@ __global__ __launch_bounds__(256, 1) void wide_tan_kernel(const GeoBwdArgs a, co
   float* zbl = a.zb_tp[l];
   float* qbn = a.qb_tp[l + 1];
   const int qbn_nb = (l + 1 == SKIP) ? D::NBH + D::NB0 : D::NBH;  // l + 1 == NL: the tangent reaching the sdf row, NBH blocks
-  (void)NL;
 #pragma unroll
   for (int b = 0; b < D::NBH; ++b) {
     const f32x16 u = tp_load_blk(ul, tile, D::NBH, b, lane), r = tp_load_blk(rl, tile, D::NBH, b, lane);
