@@ -237,6 +237,8 @@ SDFHIP_D void tp_gemm(f32x16 (&acc)[MAXA], Raw& carry, Fetch&& fetch, Make&& mak
       constexpr int newer = newer_ + SDFHIP_ABL_WAIT_SLACK;
 #elif defined(SDFHIP_COUNTED_WAIT)
       constexpr int newer = newer_;
+#elif defined(SDFHIP_LOADS_ONLY_WAIT)  // UNTESTED candidate for the next round: the younger LOADS may stay in
+      constexpr int newer = newer_ - ST::at(kb);  // flight, the stores are not counted on (safe if loads and LDS-DMA retire in order among themselves)
 #else
       constexpr int newer = 0;
       (void)newer_;
