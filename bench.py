@@ -210,6 +210,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, choices=[2, 5], help="BASELINE config: 2 (default, the headline) or 5 (neus-facto-angelo)")
+    ap.add_argument("--levels", type=int, default=8, choices=[8, 16],
+                    help="--config 5 only: hash levels the progressive mask has switched on in the timed steps - 8 = the preset's level_init "
+                         "(steps 0 .. 80 k of its 1 M iterations), 16 = the steady state (steps >= 150 k: 85 %% of the schedule); the timed steps "
+                         "start at step 5 resp. 200 000 of the preset's schedules")
+    ap.add_argument("--no-config5", action="store_true", help="default (config 2) run: skip the two short config-5 legs appended as \"config5\"")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--small", action="store_true", help="small parity configuration (control-flow tests only, not a benchmark)")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the second (untimed) pass that times every launch")
@@ -223,6 +228,135 @@ def main():
         mp.spawn(_spawned, args=(args, _free_port()), nprocs=args.gpus, join=True)
         return
     run(args)
+
+
+def fence(world):
+    import torch.distributed as dist
+
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def make_job(config, device, world, rank, small=False):
+    """Model, flat gradient buffer, optimizers and the step function of one benchmark configuration (2 or 5) on this rank."""
+    from sdfstudio_amd.cameras.rays import RayBundle
+    from sdfstudio_amd.distributed import FlatGradients, broadcast_parameters
+    from sdfstudio_amd.engine.optimizers import Optimizers, multi_step_scheduler, multi_step_warmup_scheduler, neus_scheduler
+
+    cfg5 = config == 5
+    n_rays = 2048 if cfg5 else (512 if small else 4096)  # method_configs.py:396 train_num_rays_per_batch (config 5)
+    model = build_model_config5(device) if cfg5 else build_model(device, small=small)
+    broadcast_parameters(model)
+    groups = {k: v for k, v in model.get_param_groups().items() if v}  # "field_background" is empty with background_model="none"
+    # one flat gradient buffer; one exchange bucket per parameter group, all-reduced (RCCL) as soon as backward has produced it
+    flat = FlatGradients([p for g in groups.values() for p in g], buckets=list(groups.values()))
+    flat.time_waits = world > 1
+    if cfg5:
+        # method_configs.py:434-447: Adam 1e-3 with MultiStepWarmup (fields; AdamW with weight_decay 0 = Adam for field_background),
+        # Adam 1e-2 with MultiStepLR (proposal networks)
+        opts = Optimizers({"fields": {"lr": 1e-3, "scheduler": multi_step_warmup_scheduler(5000, (600000, 800000), 0.1)},
+                           "field_background": {"lr": 1e-3, "scheduler": multi_step_warmup_scheduler(5000, (300000, 400000), 0.1)},
+                           "proposal_networks": {"lr": 1e-2, "scheduler": multi_step_scheduler(1000000)}}, groups, flat_grads=flat)
+        # progressive levels: the masked levels' table rows have exactly zero gradient on every rank; zero() asks the model
+        flat.track_active(model.field.encoding.params, model.active_table_floats)
+    else:
+        # optimizers and schedulers as method_configs.py:485-500 (neus-facto): Adam eps 1e-15, lr 5e-4 with NeuS warm-up / cosine
+        # (fields), 1e-2 with MultiStepLR (proposal networks): one fused Adam launch per group over the flat buffers
+        opts = Optimizers({"fields": {"lr": 5e-4, "scheduler": neus_scheduler(500, 0.05, 20000)},
+                           "proposal_networks": {"lr": 1e-2, "scheduler": multi_step_scheduler(20000)}}, groups, flat_grads=flat)
+    centers, rot = synthetic_cameras(device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(42 + rank)  # base_config.py:74 + scripts/train.py:86: seed + global rank
+
+    def step(i):
+        model.before_train_iteration(i)
+        o, d, norm, cam = draw_rays(centers, rot, n_rays, gen)
+        image = torch.rand(n_rays, 3, device=device, generator=gen)
+        rb = RayBundle(origins=o, directions=d, directions_norm=norm, camera_indices=cam[:, None])
+        out = model(rb)
+        loss = sum(model.get_loss_dict(out, {"image": image}).values())
+        flat.zero(loss)  # the loss's graph tells the buckets which gradients to wait for (unused parameters: distributed.py)
+        loss.backward()
+        opts.optimizer_step_all(grad_scale=flat.finish(average=False))  # SUM all-reduce; the 1 / world mean rides in the Adam read
+        opts.scheduler_step_all(i)
+        model.after_train_iteration(i)
+        return loss
+
+    return {"model": model, "flat": flat, "groups": groups, "opts": opts, "step": step, "centers": centers, "rot": rot, "gen": gen,
+            "n_rays": n_rays}
+
+
+def timed_steps(job, first, warmup, steps, dominant, world):
+    """`warmup` untimed steps, then EXACTLY `steps` timed ones between fences (barrier + synchronize on both sides); the schedules'
+    step counter starts at `first`.  Returns (seconds on this rank, events of the dominant kernel inside the timed region, last loss)."""
+    from sdfstudio_amd import _lib
+
+    step = job["step"]
+    for i in range(warmup):
+        step(first + i)
+    fence(world)
+    _lib.profile_enable_only([dominant])
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = step(first + warmup + i)
+    fence(world)
+    dt = time.perf_counter() - t0
+    prof = _lib.profile_collect()
+    _lib.profile_enable(False)
+    return dt, prof, loss
+
+
+def max_over_ranks(dt, device, world):
+    import torch.distributed as dist
+
+    t = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def encode_roofline_config5(model, prof, steps, P):
+    """K1 of SURVEY 8(d) for config 5: 7 evaluations per ray-sample (centre + 6 taps); ACTIVE levels x 8 corners x 8 features x 4 B +
+    position in + 6 in0 blocks out (progressive levels: the kernel skips the levels the mask has switched off: not counted either)."""
+    enc_ms, enc_n = prof.get("geo_encode_kernel", (0.0, 0))
+    if enc_n <= 0:
+        return None
+    lv_on = int(getattr(model.field, "_active_levels", model.field.num_levels))
+    per_sample = 7 * (lv_on * 8 * 8 * 4 + 12 + 6 * 128)
+    eb = per_sample * P
+    es = enc_ms / steps * 1e-3
+    return {"kernel": "geo_encode_kernel", "bound": "hbm", "achieved": round(eb / es / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(eb / es / 1e9 / PEAK_HBM_GBS, 4), "algorithmic_bytes": eb,
+            "achieved_is": f"7 x ({lv_on} active levels x 256 B gather + 12 B position + 768 B tile-packed in0) per ray-sample / its time per step",
+            "ms_per_step": round(enc_ms / steps, 4), "levels_active": lv_on, "traffic": None}
+
+
+def config5_legs(device, world, rank, steps=10, warmup=3):
+    """BASELINE config 5 (neus-facto-angelo at its own sizes) as two short legs inside the default run, so that the driver's record
+    carries a config-5 figure: the preset's level_init state (8 of 16 hash levels on: steps 0 .. 80 k of its 1 M iterations) and the
+    steady state (all 16 on, schedules at step 200 000: 85 % of the run) - twice the gather / scatter bytes, 2.5 x the Adam rows and
+    twice the all-reduce of the first.  Same model object, same timing discipline as the headline leg."""
+    job = make_job(5, device, world, rank)
+    P = job["n_rays"] * 48
+    out = {"workload": "BASELINE config 5: neus-facto-angelo preset (16x8x2^22 linear grid = 2.1 GB table, 1x256 geo MLP evaluated 7 x per sample, "
+                       "4x256 colour MLP, 'grid' background, curvature loss), 2048 rays x 48 samples per GPU per step, full train step incl. Adam",
+           "steps": steps, "warmup": warmup}
+    for name, first in (("levels8", 0), ("levels16", 200000)):
+        dt, prof, loss = timed_steps(job, first, warmup, steps, "geo_encode_kernel", world)
+        dt = max_over_ranks(dt, device, world)
+        assert math.isfinite(float(loss.detach())), f"config 5 ({name}) diverged"
+        ms = dt / steps * 1e3
+        flat = job["flat"]
+        out[name] = {"ms_per_step": round(ms, 3), "value": round(world * P / (dt / steps), 1), "unit": "ray-samples/s",
+                     "levels_active": int(job["model"].field._active_levels), "first_step": first,
+                     "exchanged_bytes_per_rank": 4 * flat.exchanged_numel(),
+                     "adam_rows_visited": sum(b - a for a, b in flat.live_ranges()),
+                     "roofline": encode_roofline_config5(job["model"], prof, steps, P)}
+    del job
+    torch.cuda.empty_cache()
+    return out
 
 
 def run(args):
@@ -257,79 +391,25 @@ def run(args):
               f"device {local_rank} {torch.cuda.get_device_name(local_rank)}", file=sys.stderr, flush=True)
 
     from sdfstudio_amd import _lib
-    from sdfstudio_amd.cameras.rays import RayBundle
-    from sdfstudio_amd.distributed import FlatGradients, broadcast_parameters
 
-    model = build_model_config5(device) if cfg5 else build_model(device, small=args.small)
-    broadcast_parameters(model)
-    groups = {k: v for k, v in model.get_param_groups().items() if v}  # "field_background" is empty with background_model="none"
-    # one flat gradient buffer; one exchange bucket per parameter group, all-reduced (RCCL) as soon as backward has produced it
-    flat = FlatGradients([p for g in groups.values() for p in g], buckets=list(groups.values()))
-    # optimizers and schedulers as method_configs.py:485-500 (neus-facto): Adam eps 1e-15, lr 5e-4 with NeuS warm-up / cosine
-    # (fields), 1e-2 with MultiStepLR (proposal networks): one fused Adam launch per group over the flat buffers
-    from sdfstudio_amd.engine.optimizers import Optimizers, multi_step_scheduler, multi_step_warmup_scheduler, neus_scheduler
-
-    flat.time_waits = world > 1
-    if cfg5:
-        # method_configs.py:434-447: Adam 1e-3 with MultiStepWarmup (fields; AdamW with weight_decay 0 = Adam for field_background),
-        # Adam 1e-2 with MultiStepLR (proposal networks)
-        opts = Optimizers({"fields": {"lr": 1e-3, "scheduler": multi_step_warmup_scheduler(5000, (600000, 800000), 0.1)},
-                           "field_background": {"lr": 1e-3, "scheduler": multi_step_warmup_scheduler(5000, (300000, 400000), 0.1)},
-                           "proposal_networks": {"lr": 1e-2, "scheduler": multi_step_scheduler(1000000)}}, groups, flat_grads=flat)
-    else:
-        opts = Optimizers({"fields": {"lr": 5e-4, "scheduler": neus_scheduler(500, 0.05, 20000)},
-                           "proposal_networks": {"lr": 1e-2, "scheduler": multi_step_scheduler(20000)}}, groups, flat_grads=flat)
-    centers, rot = synthetic_cameras(device)
-    gen = torch.Generator(device=device)
-    gen.manual_seed(42 + rank)  # base_config.py:74 + scripts/train.py:86: seed + global rank
-
-    table = model.field.encoding.params
-
-    def step(i):
-        model.before_train_iteration(i)
-        if cfg5:  # progressive levels: the masked levels' table rows have exactly zero gradient on every rank
-            flat.set_active_numel(table, model.active_table_floats())
-        o, d, norm, cam = draw_rays(centers, rot, N_RAYS, gen)
-        image = torch.rand(N_RAYS, 3, device=device, generator=gen)
-        rb = RayBundle(origins=o, directions=d, directions_norm=norm, camera_indices=cam[:, None])
-        out = model(rb)
-        loss = sum(model.get_loss_dict(out, {"image": image}).values())
-        flat.zero()
-        loss.backward()
-        opts.optimizer_step_all(grad_scale=flat.finish(average=False))  # SUM all-reduce; the 1 / world mean rides in the Adam read
-        opts.scheduler_step_all(i)
-        model.after_train_iteration(i)
-        return loss
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    fence()
+    job = make_job(5 if cfg5 else 2, device, world, rank, small=args.small)
+    model, flat, groups = job["model"], job["flat"], job["groups"]
+    step = job["step"]
+    first = (200000 if args.levels == 16 else 0) if cfg5 else 0  # config 5: where in the preset's schedules the timed steps sit
     # Timed region: HIP events on the launches of the DOMINANT kernel only (the roofline figure must come from these steps).  An event
     # pair serialises the command stream around its launch; with every launch instrumented the step measured ~1 ms longer, so the
     # per-kernel table comes from a second, untimed pass with events everywhere (its step time is reported beside the table).
     dominant = "geo_encode_kernel" if cfg5 else "geo_bwd_kernel"
-    _lib.profile_enable_only([dominant])
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        loss = step(args.warmup + i)
-    fence()
-    dt = time.perf_counter() - t0
-    prof_timed = _lib.profile_collect()
-    _lib.profile_enable(False)
+    dt_local, prof_timed, loss = timed_steps(job, first, args.warmup, args.steps, dominant, world)
+    dt = dt_local
     table_steps = 0 if args.no_kernel_table else min(args.steps, 10)
     prof, instrumented_ms = dict(prof_timed), None
     if table_steps:
         _lib.profile_enable(True)
         t1 = time.perf_counter()
         for i in range(table_steps):
-            step(args.warmup + args.steps + i)
-        fence()
+            step(first + args.warmup + args.steps + i)
+        fence(world)
         instrumented_ms = (time.perf_counter() - t1) / table_steps * 1e3
         for k, v in _lib.profile_collect().items():  # scaled to the timed region's step count: the code below divides by args.steps
             prof.setdefault(k, (v[0] * args.steps / table_steps, v[1] * args.steps / table_steps))
@@ -339,7 +419,10 @@ def run(args):
     # forward-only leg (eval-mode render, reported separately; outside the timed training region)
     fwd_ms = float("nan")
     if not args.no_forward_only:
+        from sdfstudio_amd.cameras.rays import RayBundle
+
         model.eval()
+        centers, rot, gen = job["centers"], job["rot"], job["gen"]
         o, d, norm, cam = draw_rays(centers, rot, N_RAYS, gen)
         rb_eval = RayBundle(origins=o, directions=d, directions_norm=norm, camera_indices=cam[:, None])
         with torch.no_grad():
@@ -361,6 +444,10 @@ def run(args):
         dist.all_reduce(allr)
         exposed_by_rank = [round(float(v), 4) for v in allr.tolist()]
     dt = float(t.item())
+    cfg5_extra = None
+    if not cfg5 and not args.small and not args.no_config5:
+        del loss  # the last step's graph (and its 25 GB field workspace) goes back to the allocator
+        cfg5_extra = config5_legs(device, world, rank)
 
     if rank == 0:
         ms = dt / args.steps * 1e3
@@ -413,18 +500,15 @@ def run(args):
         enc_ms, enc_n = prof.get("geo_encode_kernel", (0.0, 0))
         enc = None
         if enc_n > 0:
-            if cfg5:  # 7 evaluations per ray-sample (centre + 6 taps); ACTIVE levels x 8 corners x 8 features x 4 B + position in + 6 in0 blocks out
-                # (progressive levels: the kernel skips the levels the mask has switched off, so they are not counted either)
-                lv_on = int(getattr(model.field, "_active_levels", model.field.num_levels))
-                per_sample = 7 * (lv_on * 8 * 8 * 4 + 12 + 6 * 128)
-                what = f"7 x ({lv_on} active levels x 256 B gather + 12 B position + 768 B tile-packed in0) per ray-sample"
+            if cfg5:
+                enc = encode_roofline_config5(model, prof, args.steps, P)
             else:
                 per_sample, what = 16 * 8 * 2 * 4 + 12 + 128, "1024 B gather + 12 B position + 128 B of features per ray-sample (SURVEY 8d: 1164 B)"
-            eb = per_sample * P
-            es = enc_ms / args.steps * 1e-3
-            enc = {"kernel": "geo_encode_kernel", "bound": "hbm", "achieved": round(eb / es / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                   "frac": round(eb / es / 1e9 / PEAK_HBM_GBS, 4), "algorithmic_bytes": eb, "achieved_is": what + " / its time per step",
-                   "ms_per_step": round(enc_ms / args.steps, 4), "traffic": None}
+                eb = per_sample * P
+                es = enc_ms / args.steps * 1e-3
+                enc = {"kernel": "geo_encode_kernel", "bound": "hbm", "achieved": round(eb / es / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                       "frac": round(eb / es / 1e9 / PEAK_HBM_GBS, 4), "algorithmic_bytes": eb, "achieved_is": what + " / its time per step",
+                       "ms_per_step": round(enc_ms / args.steps, 4), "traffic": None}
             for f in sorted((f for f in os.listdir(pm_dir) if f.endswith("_pmc_summary.csv")), reverse=True):
                 if ("cfg5" in f) != cfg5:
                     continue
@@ -457,7 +541,8 @@ def run(args):
             "config": {"workload": "SMALL parity configuration (control-flow test only, NOT a benchmark)" if args.small else
                                    ("BASELINE config 5: neus-facto-angelo preset - hash grid 16x8x2^22 linear (2.1 GB table), 1x256 geo MLP with "
                                     "numerical SDF gradients (7 evaluations per sample), 4x256 colour MLP, 'grid' background field, progressive "
-                                    "levels (level_init 8), curvature loss; 2048 rays x 48 samples (+256/96 proposal samples) per GPU per step, "
+                                    f"levels ({'all 16 on: steady state, schedules at step 200 000' if args.levels == 16 else 'level_init 8: schedules at step 0'}), "
+                                    "curvature loss; 2048 rays x 48 samples (+256/96 proposal samples) per GPU per step, "
                                     "full train step incl. Adam" if cfg5 else
                                     "BASELINE config 2: NeuS-facto hash-grid 16x2x2^19 smoothstep + 8x256 geo MLP + 4x256 colour MLP, "
                                     "4096 rays x 128 samples (+256/96 proposal samples) per GPU per step, full train step incl. Adam"),
@@ -465,10 +550,12 @@ def run(args):
                        "parallelism": f"dp{world} (flat-gradient RCCL all-reduce)" if world > 1 else "single GPU"},
             "roofline": roof,
             "encode_roofline": enc,
+            "config5": cfg5_extra,
             "collective": None if world == 1 else {"backend": dist.get_backend(), "buckets": len(groups),
                                                     "bytes_per_step_per_rank": 4 * flat.exchanged_numel(),
                                                     "collectives_per_step": flat.last_collectives,
                                                     "buckets_launched_during_backward": flat.last_overlapped_buckets,
+                                                    "parameters_outside_the_graph": flat.last_unused,
                                                     "exposed_ms_per_step_by_rank": exposed_by_rank,
                                                     "overlap": "bucket all-reduces leave in fixed index order from post-accumulate-grad hooks during "
                                                                "backward; exposed = GPU time the compute stream stalled in finish()"},

@@ -194,12 +194,15 @@ def sdf_and_gradient(x: torch.Tensor, p: Params, cfg: FieldCfg, mask=None, creat
 # implementations whose pre-activations differ by round-off can legitimately disagree on the gradient contribution of a
 # (point, unit) pair with |z| ~ 1e-7.  relu_hook(record={}) captures the colour network's pre-activations; relu_hook(flip=
 # {layer: bool mask}) evaluates the other branch at the flagged pairs (tests/helpers.py: assert_grads_close_mod_relu_flips).
+# Key -1 is the curvature loss's |c| (neus_facto_loss): same mechanism, same reason.  relu_hook(force={layer: bool mask}) imposes a
+# whole branch pattern: PyTorch's multi-threaded CPU reductions are not run-to-run reproducible at the last ulp, so "the other branch
+# than this run's" is not a well-defined request at a knife edge - "this pattern" is.
 RELU_HOOK = None
 
 
 class relu_hook:
-    def __init__(self, record=None, flip=None):
-        self.cfg = {"record": record, "flip": flip}
+    def __init__(self, record=None, flip=None, force=None):
+        self.cfg = {"record": record, "flip": flip, "force": force}
 
     def __enter__(self):
         global RELU_HOOK
@@ -239,6 +242,9 @@ def color_network(x, dirs, grad, feat, emb, p: Params, cfg: FieldCfg) -> torch.T
                 flip = (RELU_HOOK.get("flip") or {}).get(l)
                 if flip is not None:  # the OTHER branch of the ReLU at the flagged (point, unit) pairs
                     h = torch.where(flip, z - h, h)
+                force = (RELU_HOOK.get("force") or {}).get(l)
+                if force is not None:  # a GIVEN branch pattern (True: the linear branch) whatever round-off makes of sign(z) in this run
+                    h = torch.where(force, z, torch.zeros_like(z))
     rgb = torch.sigmoid(h)
     return rgb * (1 + 2 * cfg.rgb_padding) - cfg.rgb_padding
 
@@ -740,18 +746,34 @@ def interlevel_loss_zip(weights_list: List[torch.Tensor], bins_list: List[torch.
 
 # ----------------------------------------------------------------------------- full model step
 def neus_facto_forward(origins, dirs, cam_idx, p: Params, cfg: ModelCfg, anneal: float = 1.0,
-                       cos_anneal_ratio: float = 1.0, rand=None, mask=None, training=True, nears=None, fars=None):
-    """models/neus_facto.py:282-302 + base_surface_model.py:292-365 with background_model == 'none', black bg.  nears / fars [N]:
-    per-ray planes from a box / sphere collider (scene_colliders.py:47-109,132-170); default: the NearFarCollider's constants."""
+                       cos_anneal_ratio: float = 1.0, rand=None, mask=None, training=True, nears=None, fars=None,
+                       numerical_delta: Optional[float] = None, background: Optional[Dict] = None):
+    """models/neus_facto.py:282-302 + base_surface_model.py:292-365, black bg.  nears / fars [N]:
+    per-ray planes from a box / sphere collider (scene_colliders.py:47-109,132-170); default: the NearFarCollider's constants.
+    numerical_delta: the field's use_numerical_gradients branch (sdf_field.py:638-644; neus-facto-angelo, BASELINE config 5).
+    background: None (background_model == 'none'), or {"prefix": "field_background.", "lv": GridLevels, "geo_feat_dim": 15} for
+    background_model == 'grid' (neus_facto.py:289-290 -> forward_background_field_and_merge, base_surface_model.py:266-290: the
+    background field is evaluated on the SDF samples themselves and replaces alpha and colour of the samples whose START position
+    lies outside the unit sphere; a NeuS-facto model has no 'bg_transmittance', so :314-329 never runs for it)."""
     n = origins.shape[0]
     if nears is None:
         nears = torch.full((n,), cfg.near, dtype=origins.dtype)  # scene_colliders.py:124-129
         fars = torch.full((n,), cfg.far, dtype=origins.dtype)
     bins, starts, ends, weights_list, bins_list = proposal_sampler(origins, dirs, nears, fars, p, cfg, anneal, rand)
     deltas = ends - starts
-    fo = field_outputs(origins, dirs, starts, deltas, cam_idx, p, cfg.field, mask, cos_anneal_ratio, training)
-    weights, trans = weights_from_alphas(fo["alpha"])
-    rgb, depth, normal, acc = render(weights, fo["rgb"], fo["normal"], starts, ends)
+    fo = field_outputs(origins, dirs, starts, deltas, cam_idx, p, cfg.field, mask, cos_anneal_ratio, training, numerical_delta=numerical_delta)
+    alpha, rgb_s = fo["alpha"], fo["rgb"]
+    if background is not None:
+        pos = origins[:, None, :] + dirs[:, None, :] * starts[..., None]
+        inside = (pos.norm(dim=-1) < 1.0).to(alpha.dtype)  # get_foreground_mask, base_surface_model.py:256-264
+        bg = nerfacto_field(origins, dirs, starts, ends, cam_idx, p, background["prefix"], background["lv"],
+                            geo_feat_dim=background.get("geo_feat_dim", 15), training=training)
+        bg_alpha = 1.0 - torch.exp(-deltas * bg["density"])  # RaySamples.get_alphas, cameras/rays.py:131-144
+        alpha = alpha * inside + (1.0 - inside) * bg_alpha
+        rgb_s = rgb_s * inside[..., None] + (1.0 - inside[..., None]) * bg["rgb"]
+        fo = dict(fo, alpha=alpha, rgb=rgb_s, inside=inside)
+    weights, trans = weights_from_alphas(alpha)
+    rgb, depth, normal, acc = render(weights, rgb_s, fo["normal"], starts, ends)
     return {
         "rgb": rgb, "depth": depth, "normal": normal, "accumulation": acc, "weights": weights,
         "field": fo, "starts": starts, "ends": ends, "bins": bins,
@@ -759,14 +781,32 @@ def neus_facto_forward(origins, dirs, cam_idx, p: Params, cfg: ModelCfg, anneal:
     }
 
 
-def neus_facto_loss(out, image, cfg: ModelCfg) -> Dict[str, torch.Tensor]:
-    """base_surface_model.py:399-406 (L1 rgb, eikonal) + neus_facto.py:304-310 (interlevel)."""
+def neus_facto_loss(out, image, cfg: ModelCfg, curvature: Optional[Tuple[float, float]] = None) -> Dict[str, torch.Tensor]:
+    """base_surface_model.py:399-406 (L1 rgb, eikonal) + neus_facto.py:304-310 (interlevel).  curvature = (delta, multiplier incl. the
+    schedule's factor): neus_facto.py:312-325 on the six tap values of the numerical-gradient field."""
     g = out["field"]["gradient"]
-    return {
+    loss = {
         "rgb_loss": F.l1_loss(out["rgb"], image),
         "eikonal_loss": ((g.norm(2, dim=-1) - 1) ** 2).mean() * cfg.eikonal_loss_mult,
         "interlevel_loss": cfg.interlevel_loss_mult * interlevel_loss_zip(out["weights_list"], out["bins_list"]),
     }
+    if curvature is not None:
+        delta, mult = curvature
+        sdf, taps = out["field"]["sdf"], out["field"]["sampled_sdf"]
+        curv = (taps.reshape(sdf.shape + (3, 2)).sum(dim=-1) - 2 * sdf[..., None]) / (delta * delta)
+        a = curv.abs()
+        if RELU_HOOK is not None:  # test instrumentation (relu_hook): |c| is the path's other knife edge - the second difference divides
+            # the sdf's round-off by delta^2, so two fp32 evaluations may disagree on sign(c) where |c| is below that noise
+            if RELU_HOOK.get("record") is not None:
+                RELU_HOOK["record"][-1] = curv.detach().reshape(-1, 3)
+            flip = (RELU_HOOK.get("flip") or {}).get(-1)
+            if flip is not None:  # the OTHER branch of |c| at the flagged elements
+                a = torch.where(flip.view_as(a), -a, a)
+            force = (RELU_HOOK.get("force") or {}).get(-1)
+            if force is not None:  # a GIVEN branch pattern (True: +c)
+                a = torch.where(force.view_as(a), curv, -curv)
+        loss["curvature_loss"] = a.mean() * mult
+    return loss
 
 
 def monosdf_normal_loss(normal_pred: torch.Tensor, normal_gt: torch.Tensor) -> torch.Tensor:

@@ -19,8 +19,19 @@ field no ray hits) therefore still matches its peers, as DDP's fixed bucket orde
 level mask of neus-facto-angelo (sdf_field.py:376-378) the hash-table rows of the masked levels have exactly zero
 gradient on every rank, so BASELINE config 5's 1.8 GB table moves only its active prefix.
 
-Protocol per step: ``zero()`` -> one backward -> ``finish()``.  Anything else raises: a second backward before ``finish()`` would
-accumulate into slices that are being reduced, a backward without ``zero()`` would mix last step's means with new local sums.
+Unused parameters.  A bucket leaves from a hook when the LAST of its gradients has arrived, so it has to know how many will arrive.
+Not every parameter of a group is in every step's autograd graph: ``laplace_density.beta`` never is under the NeuS family (no Laplace
+density on the path to the loss), ``deviation_network.variance`` never is under VolSDF, the appearance embedding is not when it is
+switched off, a background field is not in a step whose rays stay inside the unit sphere.  Their hooks never fire; counted as pending
+they keep their bucket - and, with the fixed order, every bucket behind it - from leaving before ``finish()``: no overlap at all, on
+every model of the family.  ``zero(loss)`` therefore walks the graph below ``loss`` once per step, exactly what DDP does
+with ``find_unused_parameters=True`` (pipelines/base_pipeline.py:242), and arms every bucket with the parameters that are REACHABLE;
+the unreachable ones contribute the zeros ``zero()`` left.  (The walk visits ~10^2 nodes: the whole field is one autograd node.)
+
+Protocol per step: ``zero(loss)`` -> one backward of that loss -> ``finish()``.  Anything else raises: a second backward before
+``finish()`` would accumulate into slices that are being reduced, a backward without ``zero()`` would mix last step's means with new
+local sums.  (``zero()`` without the loss keeps the conservative count - every parameter pending - which is correct and overlaps only
+when every parameter of a bucket receives a gradient.)
 """
 import time
 from typing import Dict, Iterable, List, Optional, Sequence
@@ -54,6 +65,8 @@ class FlatGradients:
             self._offset[id(p)] = off
             off += p.numel()
         self._active: Dict[int, int] = {}
+        self._active_fn = {}  # id(param) -> (param, callable): the active size is re-read at every zero() (track_active)
+        self._all_live = False  # sticky: set by mark_all_live() (optimizer state loaded): never skip a suffix again
         # high-water mark of set_active_numel per parameter: elements beyond it have NEVER carried a gradient, so they are still the
         # zeros the buffer was created with (zero() need not rewrite them, Adam need not visit them: live_ranges())
         self._hwm: Dict[int, int] = {}
@@ -72,6 +85,8 @@ class FlatGradients:
         self._bucket_of = {id(p): bi for bi, b in enumerate(self._buckets) for p in b}
         self._pending = [0] * len(self._buckets)
         self._launched = [False] * len(self._buckets)
+        self._used: Optional[set] = None
+        self.last_unused = 0    # parameters the last zero(loss) found outside the graph
         self._next = 0          # first bucket that has not been launched: launches happen in index order only
         self._armed = False
         self._work = []
@@ -105,13 +120,17 @@ class FlatGradients:
     def _is_view(self, p) -> bool:
         return p.grad is not None and p.grad.data_ptr() == self.flat.data_ptr() + 4 * self._offset[id(p)]
 
-    def zero(self):
+    def zero(self, loss: Optional[torch.Tensor] = None):
         """Clear every gradient (the ONLY way gradients of these parameters should be cleared) and re-arm the buckets.
+        loss: the tensor backward() is about to be called on - its graph tells which parameters will receive a gradient in this step, so
+        that a bucket leaves as soon as the last of THOSE has arrived (module docstring: unused parameters).
         optimizer.zero_grad() / module.zero_grad() default to set_to_none=True, which drops the views (autograd would then
         allocate fresh gradients and the flat buffer would go stale): the views are re-attached here, and whatever stray
         tensor sat in .grad is DISCARDED - this call means "all gradients are zero now"."""
         if self._work:
             raise RuntimeError("FlatGradients.zero() while all-reduces of the previous backward are in flight: call finish() first")
+        for prm, fn in self._active_fn.values():  # progressive hash levels: the model is asked, the caller cannot forget (track_active)
+            self.set_active_numel(prm, fn())
         for a, b in self.live_ranges():  # one range (the whole buffer) unless a parameter has a never-active suffix
             self.flat[a:b].zero_()
         for p in self.params:
@@ -119,7 +138,7 @@ class FlatGradients:
             # backward kernels hand it a view of this buffer they have already written (grad_slots.py): no launch per parameter
             p.grad = None
             setattr(p, CLAIM_ATTR, False)
-        self._arm()
+        self._arm(None if loss is None else self.reachable(loss))
 
     zero_grad = zero
 
@@ -127,16 +146,27 @@ class FlatGradients:
         """Exchange only param.view(-1)[:numel] (None: all of it); the rest must be identically zero on every rank."""
         if numel is None or numel >= param.numel():
             self._active.pop(id(param), None)
-            self._hwm.pop(id(param), None)
+            if id(param) in self._hwm:
+                self._hwm[id(param)] = param.numel()  # everything has been live from here on (a later restriction skips nothing)
         else:
             n = max(int(numel), 0)
             self._active[id(param)] = n
-            # a restriction that arrives after unrestricted steps finds gradients (and Adam moments) beyond it: nothing to skip then
-            first = param.numel() if (id(param) not in self._hwm and self._finished_steps > 0) else 0
+            # a restriction that arrives after unrestricted steps (or after mark_all_live: loaded moments) finds gradients / Adam
+            # moments beyond it: nothing to skip then
+            first = param.numel() if (id(param) not in self._hwm and (self._finished_steps > 0 or self._all_live)) else 0
             self._hwm[id(param)] = max(self._hwm.get(id(param), first), n)
 
+    def track_active(self, param: torch.nn.Parameter, numel_fn):
+        """set_active_numel(param, numel_fn()) at every zero(): the model's own statement of how much of the parameter can carry a
+        gradient in the coming step (NeuSFactoModel.active_table_floats under the progressive level mask).  Why this matters: zero()
+        clears only live_ranges() and the native backward kernels ACCUMULATE into the slots, so a level that is switched on without
+        the restriction being widened would pile stale gradient into rows that are neither exchanged nor stepped."""
+        self._active_fn[id(param)] = (param, numel_fn)
+
     def mark_all_live(self):
-        """Forget the never-active suffixes (e.g. after loading optimizer moments from a checkpoint)."""
+        """Forget the never-active suffixes for good (e.g. after loading optimizer moments from a checkpoint: the moments beyond the
+        current restriction may be non-zero).  Sticky: restrictions set later still bound the EXCHANGE, never what zero() / Adam visit."""
+        self._all_live = True
         for k in list(self._hwm):
             self._hwm[k] = 1 << 62
 
@@ -159,15 +189,35 @@ class FlatGradients:
         return [(a, b) for a, b in out if b > a]
 
     # ---- exchange
-    def _arm(self):
+    def reachable(self, loss: torch.Tensor) -> set:
+        """ids of the parameters whose AccumulateGrad node hangs below `loss` in the autograd graph, i.e. whose post-accumulate hook
+        can fire in loss.backward() (DDP's find_unused_parameters walk, torch/nn/parallel/distributed.py; the reference enables it:
+        pipelines/base_pipeline.py:242)."""
+        seen, out = set(), set()
+        stack = [loss.grad_fn]
+        while stack:
+            fn = stack.pop()
+            if fn is None or fn in seen:
+                continue
+            seen.add(fn)
+            var = getattr(fn, "variable", None)  # AccumulateGrad
+            if var is not None:
+                out.add(id(var))
+                continue
+            stack.extend(f for f, _ in fn.next_functions)
+        return out
+
+    def _arm(self, used: Optional[set] = None):
         for bi, b in enumerate(self._buckets):
-            self._pending[bi] = len(b)
+            self._pending[bi] = len(b) if used is None else sum(1 for p in b if id(p) in used)
             self._launched[bi] = False
+        self._used = used
         self._next = 0
         self._work = []
         self._armed = True
         self.last_overlapped_buckets = 0
         self.last_collectives = 0
+        self.last_unused = 0 if used is None else sum(1 for p in self.params if id(p) not in used)
 
     def _ranges(self, bi):
         """Contiguous [start, end) element ranges of bucket bi that have to travel, cut into chunks of at most chunk_numel."""
@@ -213,6 +263,9 @@ class FlatGradients:
             raise RuntimeError("FlatGradients: backward without zero() since the last finish() - the flat buffer still holds the "
                                "reduced gradients of the previous step")
         bi = self._bucket_of[id(p)]
+        if self._used is not None and id(p) not in self._used:
+            raise RuntimeError("FlatGradients: a gradient arrived for a parameter that is not in the graph of the loss zero() was given "
+                               "(zero(loss) and backward() must see the same loss)")
         self._pending[bi] -= 1
         if self._pending[bi] < 0 or self._launched[bi]:
             raise RuntimeError("FlatGradients: a second backward reached a parameter before finish() - its bucket may already be "

@@ -1036,3 +1036,65 @@ def test_oracle_field_at_the_bigmlp_width_against_reference(grid):
     for k in ("glin4.weight_v", "glin8.weight_g", "clin0.weight_v", "glin0.bias"):
         g_ref, g_or = ref_grads[k].grad, po[k].grad
         assert g_ref is not None and (g_or - g_ref).abs().max().item() <= 1e-4 * g_ref.abs().max().item() + 1e-8, k
+
+
+def _angelo_oracle_step(g, dtype=torch.float32):
+    """The oracle's config-5 step (numerical gradients, level mask, "grid" background merge, curvature loss) on a golden's inputs.
+    Returns (outputs, losses, run_backward) - run_backward() -> {oracle name: gradient} re-evaluates everything (helpers.relu_flip_basis)."""
+    from helpers import angelo_bg_levels, angelo_oracle_cfg, oracle_params_from_reference_state
+
+    cfg = angelo_oracle_cfg()
+    i = g["in"]
+    cast = (lambda t: t.to(dtype) if t.is_floating_point() else t)
+    p = {k: cast(v) for k, v in oracle_params_from_reference_state(g["param"]).items()}
+    level, delta, curv_mult = int(i["level"]), float(i["delta"]), float(i["curv_mult"])
+    mask = torch.ones(16 * 8, dtype=dtype)
+    mask[level * 8:] = 0  # sdf_field.py:376-378
+    rand = [cast(i[f"rand{k}"]) for k in range(3)]
+
+    def step():
+        po = {k: v.clone().requires_grad_(v.is_floating_point() and k != "laplace_density.beta_min") for k, v in p.items()}
+        out = O.neus_facto_forward(cast(i["origins"]), cast(i["dirs"]), i["cam"], po, cfg, anneal=float(i["anneal"]),
+                                   cos_anneal_ratio=float(i["cos_anneal"]), rand=rand, mask=mask, training=True, numerical_delta=delta,
+                                   background={"prefix": "field_background.", "lv": angelo_bg_levels()})
+        losses = O.neus_facto_loss(out, cast(i["image"]), cfg, curvature=(delta, curv_mult))
+        sum(losses.values()).backward()
+        return out, losses, {k: v.grad for k, v in po.items() if v.grad is not None}
+
+    out, losses, _ = step()
+    return out, losses, (lambda: step()[2])
+
+
+@pytest.mark.parametrize("level", [8, 16])
+def test_oracle_angelo_step_against_reference_golden(level):
+    """BASELINE config 5 end to end: the oracle's neus_facto_forward(numerical_delta, background) + neus_facto_loss(curvature) against
+    the reference's own NeuSFactoModel set up as the neus-facto-angelo preset (tests/golden/make_golden_angelo.py: train mode,
+    injected draws, level mask 8 and 16, its own get_loss_dict): samples, field and rendered outputs, the four losses, every
+    parameter gradient (SDF field incl. the 8-feature table and the embedding, background field, proposal networks) - the gradients
+    up to the branch choices at the path's knife edges (colour ReLUs, sign of noise-level curvature elements)."""
+    from helpers import assert_grads_close_mod_relu_flips, oracle_params_from_reference_state, relu_flip_basis
+
+    g = load_golden_file(f"neus_facto_angelo_small_train_l{level}.npz")
+    out, losses, run_backward = _angelo_oracle_step(g)
+    delta = float(g["in"]["delta"])
+    omap = {"starts": out["starts"], "ends": out["ends"], "bins": out["bins"], "sdf": out["field"]["sdf"], "gradient": out["field"]["gradient"],
+            "field_rgb": out["field"]["rgb"], "alpha": out["field"]["alpha"], "sampled_sdf": out["field"]["sampled_sdf"],
+            "points_norm": out["field"]["points_norm"], "weights": out["weights"], "rgb": out["rgb"], "depth": out["depth"],
+            "normal": out["normal"], "accumulation": out["accumulation"], "prop_weights0": out["weights_list"][0],
+            "prop_weights1": out["weights_list"][1]}
+    fd = 5e-7 / delta  # the finite-difference normal divides the sdf's fp32 round-off by 2 delta; alpha and everything rendered see it
+    exact = ("starts", "ends", "bins", "sdf", "sampled_sdf", "points_norm", "prop_weights0", "prop_weights1")
+    for k, v in g["out"].items():
+        tol = max(1e-4, 4 * fd) if k in ("depth", "gradient", "normal") else (2e-5 if k in exact else max(2e-5, fd))
+        assert_close(k, omap[k], v, rtol=tol, atol=1e-6, elem_rtol=float("inf"))
+    assert set(losses) == set(g["loss"]) == {"rgb_loss", "eikonal_loss", "interlevel_loss", "curvature_loss"}
+    for k, v in g["loss"].items():
+        assert_close(f"loss {k}", losses[k], v, rtol=2e-5, atol=1e-8)
+    ref = oracle_params_from_reference_state(g["grad"])
+    assert len(ref) == 37 and any(k.startswith("field_background.") for k in ref) and "encoding.params" in ref
+    base, basis = relu_flip_basis(run_backward, margin=2e-5, curv_margin=1e-6 / (delta * delta), max_flips=64)
+    assert_grads_close_mod_relu_flips({k: v for k, v in base.items() if k in ref}, ref, basis, rtol=2e-3)
+    if level < 16:  # masked levels: exactly zero gradient on both sides (what lets the exchange and Adam skip them)
+        lv = O.FieldCfg(num_levels=16, max_res=4096, base_res=64, log2_hashmap_size=10, hash_features_per_level=8, hash_smoothstep=False).grid_levels()
+        first = int(lv.offset[level]) * 8
+        assert base["encoding.params"][first:].abs().max().item() == 0.0 and ref["encoding.params"][first:].abs().max().item() == 0.0

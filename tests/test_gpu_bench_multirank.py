@@ -25,3 +25,7 @@ def test_bench_self_spawns_two_ranks():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0
     assert d["collective"]["backend"] == "gloo" and d["collective"]["bytes_per_step_per_rank"] > 0
     assert "rank 1/2" in r.stderr and "rank 0/2" in r.stderr
+    # the exchange must OVERLAP with backward on the real model: laplace_density.beta and the (switched-off) appearance embedding are
+    # outside a NeuS-facto step's graph and must not keep the "fields" bucket waiting for finish()
+    assert d["collective"]["parameters_outside_the_graph"] >= 1, d["collective"]
+    assert d["collective"]["buckets_launched_during_backward"] >= 1, d["collective"]
