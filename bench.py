@@ -450,6 +450,9 @@ def run(args):
         cfg5_extra = config5_legs(device, world, rank)
 
     if rank == 0:
+        from sdfstudio_amd import build as _build
+
+        lib_digest = _build.built_digest() or None  # what the loaded libsdfhip.so was built from (sdfstudio_amd/build.py)
         ms = dt / args.steps * 1e3
         samples = world * N_RAYS * N_SAMPLES
         value = samples / (dt / args.steps)
@@ -469,13 +472,14 @@ def run(args):
         if kn > 0 and not cfg5:
             avg_s = kt_ms / kn * 1e-3
             flow_bytes = geo_bwd_algorithmic_bytes() * P
-            traffic, traffic_source = None, None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the bench)
+            traffic, traffic_source, traffic_digest = None, None, None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the bench)
             cands = sorted(f for f in os.listdir(pm_dir) if f.endswith("_pmc_traffic.json") and "cfg5" not in f)
             if cands:
                 with open(os.path.join(pm_dir, cands[-1])) as fh:  # newest committed PMC pass (r1 < r2 < r3 ...)
                     tj = json.load(fh)
                 traffic = tj["hbm_read_bytes"] + tj["hbm_write_bytes"]
                 traffic_source = tj["source"]
+                traffic_digest = tj.get("library_digest")
             flops = 2 * g * P
             io_bytes = geo_bwd_io_bytes() * P
             issued = 3 * flops / avg_s / 1e12
@@ -487,6 +491,8 @@ def run(args):
                     "frac_algorithmic_of_16bit_peak": round(flops / avg_s / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
                     "frac_algorithmic_of_fp32_matrix_peak": round(flops / avg_s / 1e12 / 157.3, 4),
                     "traffic": traffic, "traffic_unit": "HBM bytes per step of this kernel (sum of its two launches)", "traffic_source": traffic_source,
+                    # the PMC passes are a separate rocprofv3 run: they describe THIS library only if it was built from the same sources
+                    "traffic_library_digest": traffic_digest, "traffic_stale": traffic is not None and traffic_digest != lib_digest,
                     "avg_launch_ms": round(kt_ms / kn, 4), "launches": kn,
                     # the memory side of the same launches
                     "hbm": {"algorithmic_bytes": io_bytes, "frac_at_algorithmic_bytes": round(io_bytes / avg_s / 1e9 / PEAK_HBM_GBS, 4),
@@ -531,6 +537,7 @@ def run(args):
         mfma_ms = sum(prof.get(k, (0.0, 0))[0] for k in ("geo_fwd_kernel", "geo_bwd_kernel", "col_fwd_kernel", "col_bwd_kernel",
                                                          "wgrad_kernel")) / args.steps
         line = {
+            "library_digest": lib_digest,
             "metric": f"ray-samples/sec (NeuS-facto train step, {N_RAYS} rays x {N_SAMPLES} samples per GPU)",
             "value": round(value, 1), "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -571,16 +578,17 @@ def run(args):
         # whole-step view: model FLOPs (6G + 3C per sample) against the fp32 matrix peak an exact-fp32 implementation would be
         # bound by, the issued 16-bit MFMA terms (3 per product in every pass) against the dense bf16 / fp16 peak, and the whole
         # step's HBM bytes from the committed PMC passes
-        step_bytes = None
+        step_bytes, step_digest = None, None
         cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_step_traffic.json") and ("cfg5" in f) == cfg5)
         if cands:
             with open(os.path.join(ROOT, "profiles", cands[-1])) as fh:
-                step_bytes = json.load(fh).get("hbm_GB_per_training_step")
+                sj = json.load(fh)
+            step_bytes, step_digest = sj.get("hbm_GB_per_training_step"), sj.get("library_digest")
         model_tf = train_flops * P / (ms * 1e-3) / 1e12
         line["step_roofline"] = {
             "model_tflops": round(model_tf, 1), "fp32_matrix_peak_tflops": 157.3, "frac_of_fp32_matrix_peak": round(model_tf / 157.3, 3),
             "issued_16bit_mfma_tflops": round(3 * model_tf, 1), "frac_of_dense_bf16_peak": round(3 * model_tf / PEAK_BF16_MFMA_TFLOPS, 4),
-            "hbm_GB_per_step_pmc": step_bytes,
+            "hbm_GB_per_step_pmc": step_bytes, "hbm_pmc_stale": step_bytes is not None and step_digest != lib_digest,
             "hbm_GBps": None if step_bytes is None else round(step_bytes / (ms * 1e-3), 1),
             "hbm_frac_of_8TBps": None if step_bytes is None else round(step_bytes / (ms * 1e-3) / PEAK_HBM_GBS, 4),
         }

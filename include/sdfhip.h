@@ -183,6 +183,25 @@ int sdfhip_color_backward(const SdfHipField* f, const float* packed, int64_t n_r
                           const float* rgb_bar, float* theta_bar, float* feat_bar, float* grad_bar, float* emb_bar,
                           sdfhip_stream_t stream);
 
+/* SDFField.get_outputs with use_numerical_gradients (fields/sdf_field.py:629-655; the field mode of the neus-facto-angelo preset,
+ * configs/method_configs.py:381-450) as ONE forward and ONE backward operator: the geometry network on the P = n_rays * n_samples
+ * contracted START positions and their six taps x +- delta e_k (sdf_field.py:431-453; 7 P points, tap-major), the central-difference
+ * normal, get_colors on it.  origins / dirs [n_rays,3], starts [n_rays,n_samples], emb [n_rays, appearance_dim] or NULL.
+ * Outputs: sdf7 [sdfhip_numfield_sdf_rows(P)] (rows 0..P-1: the samples' sdf; rows P k + i: tap k - 1 of sample i), grad [P,3],
+ * rgb [P,3], taps [P,6] (`sampled_sdf`, sdf_field.py:644; may be NULL), x_out [P,3] contracted positions (may be NULL).
+ * training != 0 keeps what the backward needs in `workspace` (sdfhip_numfield_workspace_size(f, P) bytes, caller-owned until then). */
+int64_t sdfhip_numfield_workspace_size(const SdfHipField* f, int64_t n_points);
+int64_t sdfhip_numfield_sdf_rows(int64_t n_points);
+int sdfhip_numfield_forward(const SdfHipField* f, const float* packed, const float* table, const float* level_mask, const float* origins,
+                            const float* dirs, const float* starts, int64_t n_rays, int32_t n_samples, const float* emb, float delta,
+                            int32_t training, void* workspace, float* sdf7, float* grad, float* rgb, float* taps, float* x_out,
+                            sdfhip_stream_t stream);
+/* Cotangents sdf_bar [P], grad_bar [P,3], rgb_bar [P,3], taps_bar [P,6] (each may be NULL = zero).  theta_bar [theta_size] is
+ * overwritten, table_bar and emb_bar [n_rays, appearance_dim] (may be NULL) are accumulated into. */
+int sdfhip_numfield_backward(const SdfHipField* f, const float* packed, const float* level_mask, int64_t n_rays, int32_t n_samples,
+                             float delta, void* workspace, const float* sdf_bar, const float* grad_bar, const float* rgb_bar,
+                             const float* taps_bar, float* theta_bar, float* table_bar, float* emb_bar, sdfhip_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------- proposal density field
  * Replaces nerfstudio.fields.density_fields.HashMLPDensityField.get_density / density_fn (:99-118; base_field.py:48-65):
  * L-inf contraction of the frustum MIDPOINT, (x+2)/4, tcnn HashGrid(5 levels, F=2, linear) + FullyFusedMLP(16, ReLU,

@@ -54,6 +54,24 @@ def _digest(src: str) -> str:
     return h.hexdigest()[:16]
 
 
+def source_digest() -> str:
+    """One digest over the compile flags and EVERY source the library is built from (each translation unit's closure): the identity
+    evidence files carry (profiles/*_traffic.json: `library_digest`) and bench.py compares with the library it has loaded."""
+    h = hashlib.sha256()
+    for src in sorted(SOURCES):
+        h.update(_digest(src).encode())
+    return h.hexdigest()[:16]
+
+
+def built_digest() -> str:
+    """The digest recorded next to the .so when it was linked ("" if none): what the LOADED library was built from."""
+    try:
+        with open(LIB + ".digest") as fh:
+            return fh.read().strip()
+    except OSError:
+        return ""
+
+
 def _compile(src: str) -> str:
     obj = os.path.join(BUILD, f"{os.path.splitext(src)[0]}.{_digest(src)}.o")
     if not os.path.exists(obj):
@@ -81,6 +99,8 @@ def build(verbose: bool = True) -> str:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
         with open(stamp, "w") as fh:
             fh.write(key)
+    with open(LIB + ".digest", "w") as fh:  # travels to the GPU box with the .so (git-ignored like it)
+        fh.write(source_digest())
     if verbose:
         print(f"[sdfhip] built {LIB} ({os.path.getsize(LIB) / 1e6:.1f} MB)")
     return LIB

@@ -714,21 +714,10 @@ static void run_wgrad(const SdfHipField* f, const FieldWs& w, const WgradArgs& b
         a.ob_base = ob;
         a.ib_base = ib;
         const int rows = std::min(8, a.nba - ob), cols = std::min(8, a.nbb - ib);
-        // weight-gradient products: split-bf16 (3 bf16 MFMAs per product, fp32 accumulate).  Default: the 8-wave double-buffered
-        // kernel; SDFHIP_WGRAD_V1=1 the 4-wave one; SDFHIP_WGRAD_FP32=1 the exact-fp32 MFMA kernel (A/B and strict-fp32 runs)
-        static const bool fp32 = getenv("SDFHIP_WGRAD_FP32") != nullptr && getenv("SDFHIP_WGRAD_FP32")[0] == '1';
-        static const bool v1 = getenv("SDFHIP_WGRAD_V1") != nullptr && getenv("SDFHIP_WGRAD_V1")[0] == '1';
-        if (!fp32 && !v1) {
-          WgradKernelFn fn = wgrad8_pick((rows + 3) / 4, (cols + 1) / 2);
-          (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, kW8LdsBytes);
-          hipLaunchKernelGGL(fn, dim3((unsigned)w.n_split), dim3(512), kW8LdsBytes, s, a);
-          continue;
-        }
-        const int na = (rows + 1) / 2, nb = (cols + 1) / 2;
-        WgradKernelFn fn = wgrad_pick(na, nb, fp32);
-        const int lds_bytes = fp32 ? kWgLdsBytes : kWbLdsBytes;
-        (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        hipLaunchKernelGGL(fn, dim3((unsigned)w.n_split), dim3(256), lds_bytes, s, a);
+        // weight-gradient products: split-bf16 (3 bf16 MFMAs per product, fp32 accumulate) on the 8-wave double-buffered kernel
+        WgradKernelFn fn = wgrad8_pick((rows + 3) / 4, (cols + 1) / 2);
+        (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, kW8LdsBytes);
+        hipLaunchKernelGGL(fn, dim3((unsigned)w.n_split), dim3(512), kW8LdsBytes, s, a);
       }
   }
   WreduceArgs r;
@@ -769,8 +758,10 @@ static TpOperand seg2(const float* p0, int nb0, const float* p1, int nb1) {
 }
 
 // Weight gradients of the geometry network: split-K GEMMs over the points.  tangent = the second-order pair (R_l^T Qb_l) rides along.
+// n_tiles_feat: tiles whose rows carry a feature cotangent (default: all) - the output layer's feature-row GEMM runs over those only.
 static void run_geo_wgrads(const SdfHipField* f, const FieldWs& w, const bool tangent, const int64_t n_tiles, float* theta_bar,
-                           hipStream_t s) {
+                           hipStream_t s, int64_t n_tiles_feat = -1) {
+  if (n_tiles_feat < 0) n_tiles_feat = n_tiles;
   const FieldKernels* k = f->k;
   for (int l = 0; l < f->nl; ++l) {
     const LinearInfo& li = f->lin[l];
@@ -802,7 +793,7 @@ static void run_geo_wgrads(const SdfHipField* f, const FieldWs& w, const bool ta
     a.n_pairs = 1;
     a.nba = k->nbf;
     a.nbb = k->nbh;
-    a.n_tiles = n_tiles;
+    a.n_tiles = n_tiles_feat;
     a.A[0] = seg1(w.featbar, k->nbf);
     a.B[0] = seg1(w.u[f->nl - 1], k->nbh);
     run_wgrad(f, w, a, f->g_rowmap[f->nl], f->g_colmap[f->nl], li.w_off, li.in_dim, 1.0f, li.b_off, theta_bar, s);
@@ -1248,6 +1239,298 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
   const int64_t n_tiles = NP / 32;
   run_geo_wgrads(f, w, true, n_tiles, theta_bar, s);
   run_col_wgrads(f, w, n_tiles, theta_bar, s);
+  if (forked) SDFHIP_CHECK_HIP(hipStreamWaitEvent(s, g_side.join, 0));
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ numerical-gradient field, one operator
+// SDFField.get_outputs with use_numerical_gradients (sdf_field.py:629-655; neus-facto-angelo, BASELINE config 5) as ONE forward and ONE
+// backward call: the geometry network on the P contracted sample positions and their six taps (7 P points, tap-major: the centre points
+// occupy the first tiles), the finite-difference normal, the colour network on it.  Round 3 composed this in Python out of
+// sdfhip_geo_forward_n + torch ops + sdfhip_color_forward, which moved the geometry feature out of the kernels' tile-packed layout and
+// back (untp / totp: 1.0 ms of a 9.9 ms step), packed the weights twice and cost ~40 small ATen launches each way.  Here the colour
+// kernels read the feature tiles the geometry kernel wrote (and hand their cotangent back the same way), the tap points run the
+// sdf-row-only kernels (no feature rows computed, stored, back-propagated or multiplied into a weight gradient for 6/7 of the points),
+// and the output layer's weight gradient runs over the centre tiles only.
+struct NumWs {
+  FieldWs g;           // geometry part over n7 = padded(7 P) points: x, in0, feat, u, sdfbar, zb, in0bar, featbar, partial, bpartial
+  FieldWs c;           // colour part over nc = padded(P) points: csmall, h, rgb, d, dout, csmallbar; feat / featbar alias g's first tiles
+  float* grad_fd;      // [nc][3]
+  int64_t nc, n7;
+  size_t bytes;
+};
+static void carve_num(const SdfHipField* f, int64_t P, void* base, NumWs* w) {
+  const FieldKernels* k = f->k;
+  const int64_t nc = sdfhip_padded_points(P), n7 = sdfhip_padded_points(7 * P);
+  size_t off = 0;
+  auto take = [&](int64_t floats) {
+    float* p = base ? reinterpret_cast<float*>(reinterpret_cast<char*>(base) + off) : nullptr;
+    off += ((size_t)floats * sizeof(float) + 255) / 256 * 256;
+    return p;
+  };
+  memset(w, 0, sizeof(*w));
+  w->nc = nc;
+  w->n7 = n7;
+  FieldWs& g = w->g;
+  g.x = take(n7 * 3);
+  g.in0 = take(n7 * k->nb0 * 32);
+  g.feat = take(n7 * k->nbf * 32);     // tap tiles stay unwritten when the sdf-row-only forward exists (has_sdf_save)
+  for (int l = 0; l < f->nl; ++l) g.u[l] = take(n7 * f->nbo_geo(l) * 32);
+  g.sdfbar = take(n7);
+  for (int l = 0; l < f->nl; ++l) g.zb[l] = take(n7 * f->nbo_geo(l) * 32);
+  g.in0bar = take(n7 * k->nb0 * 32);
+  g.featbar = take(n7 * k->nbf * 32);
+  FieldWs& c = w->c;
+  c.feat = g.feat;
+  c.featbar = g.featbar;
+  c.csmall = take(nc * k->nbs * 32);
+  for (int l = 0; l < f->nlc; ++l) c.h[l] = take(nc * k->nbc * 32);
+  c.rgb = take(nc * 3);
+  for (int l = 0; l < f->nlc; ++l) c.d[l] = take(nc * k->nbc * 32);
+  c.dout = take(nc * 32);
+  c.csmallbar = take(nc * k->nbs * 32);
+  w->grad_fd = take(nc * 3);
+  const int64_t n_tiles = n7 / 32;
+  g.n_split = (int)std::min<int64_t>(256, n_tiles);
+  g.partial = take((int64_t)g.n_split * f->max_partial_elems);
+  g.bpartial = take((int64_t)g.n_split * f->max_partial_rows);
+  c.n_split = (int)std::min<int64_t>(256, nc / 32);
+  c.partial = g.partial;  // the weight-gradient GEMMs run one after the other on one stream
+  c.bpartial = g.bpartial;
+  w->bytes = off;
+}
+extern "C" int64_t sdfhip_numfield_workspace_size(const SdfHipField* f, int64_t n_points) {
+  NumWs w;
+  carve_num(f, n_points, nullptr, &w);
+  return (int64_t)w.bytes;
+}
+extern "C" int64_t sdfhip_numfield_sdf_rows(int64_t n_points) { return sdfhip_padded_points(7 * n_points); }
+
+// every tile-indexed pointer of a geometry launch advanced by `tile0` tiles: the launch then covers tiles tile0 .. of the same tensors
+static void shift_geo_fwd(const SdfHipField* f, GeoFwdArgs* a, const int64_t tile0) {
+  const FieldKernels* k = f->k;
+  a->in0_tp += tile0 * k->nb0 * 1024;
+  for (int l = 0; l < f->nl; ++l)
+    if (a->u_tp[l]) a->u_tp[l] += tile0 * f->nbo_geo(l) * 1024;
+  if (a->feat_tp) a->feat_tp += tile0 * k->nbf * 1024;
+  a->sdf += tile0 * 32;
+}
+static void shift_geo_bwd(const SdfHipField* f, GeoBwdArgs* a, const int64_t tile0) {
+  const FieldKernels* k = f->k;
+  if (a->featbar_tp) a->featbar_tp += tile0 * k->nbf * 1024;
+  a->sdfbar += tile0 * 32;
+  for (int l = 0; l < f->nl; ++l) {
+    a->u_tp[l] += tile0 * f->nbo_geo(l) * 1024;
+    a->zb_tp[l] += tile0 * f->nbo_geo(l) * 1024;
+  }
+  a->in0bar_tp += tile0 * k->nb0 * 1024;
+}
+
+extern "C" int sdfhip_numfield_forward(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
+                                       const float* origins, const float* dirs, const float* starts, int64_t n_rays, int32_t n_samples,
+                                       const float* emb, float delta, int32_t training, void* workspace, float* sdf7, float* grad,
+                                       float* rgb, float* taps, float* x_out, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(f && packed && table && level_mask && origins && dirs && starts && workspace && sdf7 && grad && rgb,
+                 "numfield_forward: null argument");
+  SDFHIP_REQUIRE(n_samples >= 1 && n_rays >= 0 && delta > 0.0f, "numfield_forward: bad shape / delta");
+  SDFHIP_REQUIRE(!f->k->layerwise, "numfield_forward: the layer-at-a-time (512-wide) kernels are not wired into this operator");
+  if (n_rays == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const FieldKernels* k = f->k;
+  const int64_t P = n_rays * n_samples;
+  NumWs w;
+  carve_num(f, P, workspace, &w);
+  const int64_t NC = w.nc, N7 = w.n7;
+
+  EncodeArgs ea;
+  memset(&ea, 0, sizeof(ea));
+  ea.grid = f->grid;
+  ea.origins = origins;
+  ea.dirs = dirs;
+  ea.starts = starts;
+  ea.n_points = 7 * P;
+  ea.n_padded = N7;
+  ea.S = n_samples;
+  ea.contract = f->cfg.contract;  // get_outputs contracts the sample positions (sdf_field.py:629), the taps are taken in contracted space
+  ea.pe_degree = f->cfg.pe_degree;
+  ea.use_pe = f->cfg.use_position_encoding;
+  ea.nb0 = k->nb0;
+  ea.table = table;
+  ea.mask = level_mask;
+  ea.x_out = w.g.x;
+  ea.in0_tp = w.g.in0;
+  ea.tap_points = P;
+  ea.tap_delta = delta;
+  {
+    ProfScope ps_(PS_ENCODE, s);
+    const unsigned gx = (unsigned)(N7 / 256 + (N7 % 256 != 0));
+    if (f->grid.n_features == 8) geo_encode8_kernel<<<dim3(gx, f->grid.n_levels + 1), 256, 0, s>>>(ea);
+    else geo_encode_kernel<<<dim3(gx, f->grid.n_levels * (f->grid.n_features / 2) + 1), 256, 0, s>>>(ea);
+  }
+  GeoFwdArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  fill_geo_ptrs(f, packed, &ga.p, kNsFwd);
+  ga.in0_tp = w.g.in0;
+  for (int l = 0; l < f->nl; ++l) ga.u_tp[l] = w.g.u[l];
+  ga.feat_tp = w.g.feat;
+  ga.sdf = sdf7;
+  {
+    ProfScope ps_(PS_GEO_FWD, s);
+    // centre tiles (and the few tap points that share their last workgroup): sdf + feature; tap tiles: the sdf row alone
+    const int save = training != 0;
+    if (k->has_sdf_save && N7 > NC) {
+      k->geo_fwd(save ? 3 : 1, ga, (unsigned)(NC / 128), s);
+      GeoFwdArgs gt = ga;
+      shift_geo_fwd(f, &gt, NC / 32);
+      k->geo_fwd(save ? 5 : 2, gt, (unsigned)((N7 - NC) / 128), s);
+    } else {
+      k->geo_fwd(save ? 3 : 1, ga, (unsigned)(N7 / 128), s);
+    }
+  }
+  FdArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.sdf7 = sdf7;
+  fa.n_points = P;
+  fa.delta = delta;
+  fa.grad = grad;
+  fa.taps = taps;
+  fd_normal_kernel<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(fa);
+
+  AssembleArgs aa;
+  memset(&aa, 0, sizeof(aa));
+  aa.x = w.g.x;
+  aa.dirs = dirs;
+  aa.emb = emb;
+  aa.grad_in = grad;
+  aa.n_points = P;
+  aa.n_padded = NC;
+  aa.S = n_samples;
+  aa.pe_degree = f->cfg.pe_degree;
+  aa.use_pe = f->cfg.use_position_encoding;
+  aa.n_feat = f->n_feat;
+  aa.nb0 = k->nb0;
+  aa.nbs = k->nbs;
+  aa.emb_dim = f->cfg.appearance_dim;
+  aa.csmall_tp = w.c.csmall;
+  { ProfScope ps_(PS_ASSEMBLE, s); grad_assemble_kernel<<<(unsigned)(NC / 256 + (NC % 256 != 0)), 256, 0, s>>>(aa); }
+  ColFwdArgs ca;
+  memset(&ca, 0, sizeof(ca));
+  fill_col_ptrs(f, packed, &ca.p, kNsCol);
+  ca.feat_tp = w.c.feat;
+  ca.csmall_tp = w.c.csmall;
+  for (int l = 0; l < f->nlc; ++l) ca.h_tp[l] = w.c.h[l];
+  ca.rgb = w.c.rgb;
+  { ProfScope ps_(PS_COL_FWD, s); k->col_fwd(ca, training != 0, (unsigned)(NC / 128), s); }
+  SDFHIP_CHECK_HIP(hipMemcpyAsync(rgb, w.c.rgb, (size_t)P * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (x_out != nullptr) SDFHIP_CHECK_HIP(hipMemcpyAsync(x_out, w.g.x, (size_t)P * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sdfhip_numfield_backward(const SdfHipField* f, const float* packed, const float* level_mask, int64_t n_rays,
+                                        int32_t n_samples, float delta, void* workspace, const float* sdf_bar, const float* grad_bar,
+                                        const float* rgb_bar, const float* taps_bar, float* theta_bar, float* table_bar, float* emb_bar,
+                                        sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(f && packed && level_mask && workspace && theta_bar && table_bar, "numfield_backward: null argument");
+  if (n_rays == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const FieldKernels* k = f->k;
+  const int64_t P = n_rays * n_samples;
+  NumWs w;
+  carve_num(f, P, workspace, &w);
+  const int64_t NC = w.nc, N7 = w.n7;
+
+  // 1. colour network backward: its feature cotangent lands in the centre tiles of the geometry network's featbar
+  ColBwdArgs cb;
+  memset(&cb, 0, sizeof(cb));
+  fill_col_ptrs(f, packed, &cb.p, kNsGrad);
+  cb.rgb = w.c.rgb;
+  cb.rgbbar = rgb_bar;
+  cb.n_points = rgb_bar != nullptr ? P : 0;
+  for (int l = 0; l < f->nlc; ++l) {
+    cb.h_tp[l] = w.c.h[l];
+    cb.d_tp[l] = w.c.d[l];
+  }
+  cb.dout_tp = w.c.dout;
+  cb.featbar_tp = w.c.featbar;
+  cb.csmallbar_tp = w.c.csmallbar;
+  { ProfScope ps_(PS_COL_BWD, s); k->col_bwd(cb, (unsigned)(NC / 128), s); }
+  if (emb_bar != nullptr && f->cfg.appearance_dim > 0) {
+    const int64_t ne = n_rays * f->cfg.appearance_dim;
+    color_emb_reduce_kernel<<<(unsigned)((ne + 255) / 256), 256, 0, s>>>(w.c.csmallbar, k->nbs, n_rays, n_samples, f->cfg.appearance_dim, emb_bar);
+  }
+
+  // 2. adjoint of the finite differences: sdfbar of the 7 P points
+  FdArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.n_points = P;
+  fa.delta = delta;
+  fa.sdf_bar = sdf_bar;
+  fa.grad_bar = grad_bar;
+  fa.csmallbar_tp = w.c.csmallbar;
+  fa.taps_bar = taps_bar;
+  fa.nbs = k->nbs;
+  fa.n_padded7 = N7;
+  fa.sdfbar7 = w.g.sdfbar;
+  fd_adjoint_kernel<<<(unsigned)((N7 + 255) / 256), 256, 0, s>>>(fa);
+
+  // 3. geometry network backward: centre tiles with their feature cotangent, tap tiles from the sdf row alone
+  GeoBwdArgs gb;
+  memset(&gb, 0, sizeof(gb));
+  fill_geo_ptrs(f, packed, &gb.p, kNsGrad);
+  gb.featbar_tp = w.g.featbar;
+  gb.sdfbar = w.g.sdfbar;
+  for (int l = 0; l < f->nl; ++l) {
+    gb.u_tp[l] = w.g.u[l];
+    gb.zb_tp[l] = w.g.zb[l];
+  }
+  gb.in0bar_tp = w.g.in0bar;
+  const bool split = k->geo_bwd1s != nullptr && k->has_sdf_save && N7 > NC;
+  {
+    ProfScope ps_(PS_GEO_BWD, s);
+    if (split) {
+      k->geo_bwd1(gb, (unsigned)(NC / 128), s);
+      GeoBwdArgs gt = gb;
+      shift_geo_bwd(f, &gt, NC / 32);
+      k->geo_bwd1s(gt, (unsigned)((N7 - NC) / 128), s);
+    } else {
+      const int64_t fw = N7 * k->nbf * 32, cw = NC * k->nbf * 32;
+      if (fw > cw) SDFHIP_CHECK_HIP(hipMemsetAsync(w.g.featbar + cw, 0, (size_t)(fw - cw) * sizeof(float), s));
+      k->geo_bwd1(gb, (unsigned)(N7 / 128), s);
+    }
+  }
+
+  // 4. hash-table gradient of all 7 P points (forked beside the weight-gradient GEMMs: bound by the memory-side atomic unit, not by CUs)
+  GridBwdArgs ga;
+  memset(&ga, 0, sizeof(ga));
+  ga.grid = f->grid;
+  ga.x = w.g.x;
+  ga.in0bar_tp = w.g.in0bar;
+  ga.mask = level_mask;
+  ga.n_points = 7 * P;
+  ga.pe_degree = f->cfg.pe_degree;
+  ga.nb0 = k->nb0;
+  ga.tablebar = table_bar;
+  const bool forked = g_side.ready();
+  hipStream_t gs = s;
+  if (forked) {
+    SDFHIP_CHECK_HIP(hipEventRecord(g_side.fork, s));
+    SDFHIP_CHECK_HIP(hipStreamWaitEvent(g_side.stream, g_side.fork, 0));
+    gs = g_side.stream;
+  }
+  if (f->grid.n_levels > 0) {
+    ProfScope ps_(PS_GRID_BWD, gs);
+    const int64_t P7 = 7 * P;
+    if (f->grid.n_features == 8) grid_bwd8_kernel<<<dim3((unsigned)((P7 + 255) / 256), f->grid.n_levels), 256, 0, gs>>>(ga);
+    else grid_bwd_kernel<<<dim3((unsigned)((P7 + 255) / 256), f->grid.n_levels * (f->grid.n_features / 2)), 256, 0, gs>>>(ga);
+  }
+  if (forked) SDFHIP_CHECK_HIP(hipEventRecord(g_side.join, gs));
+
+  // 5. weight gradients.  Hidden layers: all 7 P points; the output layer's feature rows: the centre tiles only (no other point has a
+  //    feature cotangent), its sdf row: all points
+  run_geo_wgrads(f, w.g, false, N7 / 32, theta_bar, s, split ? NC / 32 : N7 / 32);
+  run_col_wgrads(f, w.c, NC / 32, theta_bar, s);
   if (forked) SDFHIP_CHECK_HIP(hipStreamWaitEvent(s, g_side.join, 0));
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;

@@ -17,6 +17,9 @@ struct FieldKernels {
             // (geo_fwd modes 1 - 3, geo_bwd1; geo_bwd is null)
   int layerwise = 0;  // 1: the geometry network runs one layer per launch (wide_kernels.h): the per-layer tensors are its inter-layer
                       // storage, so the workspace holds them in EVERY mode
+  // first-order backward of points that have no feature cotangent (geo_bwd_kernel<FEATBAR = false>); null: use geo_bwd1 with zeros
+  void (*geo_bwd1s)(const GeoBwdArgs&, unsigned grid, hipStream_t) = nullptr;
+  int has_sdf_save = 0;  // geo_fwd mode 5 exists (sdf row only, activations saved: the taps of the numerical-gradient branch)
 };
 
 // Kernels that want more than 64 KiB of dynamic LDS must raise the per-function limit first.
@@ -28,7 +31,8 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
 
 // One instantiation serves every DEPTH of a network with these block widths (layers and skip position are run-time values,
 // the kernels loop over the layers).  mode: 0 = train/full (GRAD, SAVE, FEAT), 1 = geonetwork (FEAT only), 2 = sdf only,
-// 3 = geonetwork saving z_l (differentiable), 4 = full forward without a backward to follow (GRAD, FEAT: d sdf / dx, nothing saved).  The kernel families of one shape can live in separate translation units so the
+// 3 = geonetwork saving z_l (differentiable), 4 = full forward without a backward to follow (GRAD, FEAT: d sdf / dx, nothing saved),
+// 5 = sdf only, activations saved (differentiable; no feature rows: the six taps of the numerical-gradient branch).  The kernel families of one shape can live in separate translation units so the
 // build parallelises: GEO_FWD_TRAIN / GEO_FWD_INFER / GEO_BWD define plain functions, COL defines the rest and the table.
 // The second-order kernels run as two launches each (forward | chain, tangent | backward: geo_kernels.h, PHASE);
 // -DSDFHIP_SINGLE_LAUNCH keeps them in one for A/B runs.
@@ -61,6 +65,7 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
     if (mode == 1) launch_lds(geo_fwd_kernel<GD, false, false, true>, a, grid, 256, lds, s);                              \
     else if (mode == 3) launch_lds(geo_fwd_kernel<GD, false, true, true>, a, grid, 256, lds, s);                          \
     else if (mode == 4) SDFHIP_GEO_FWD_LAUNCH(GD, false, a, grid, lds, s);                                                 \
+    else if (mode == 5) launch_lds(geo_fwd_kernel<GD, false, true, false>, a, grid, 256, lds, s);                         \
     else launch_lds(geo_fwd_kernel<GD, false, false, false>, a, grid, 256, lds, s);                                       \
   }
 
@@ -72,6 +77,10 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
   void sdfhip_geo_bwd1_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s) {                                        \
     using GD = GeoDims<NBH, NB0, NBF>;                                                                                     \
     launch_lds(geo_bwd_kernel<GD, false>, a, grid, 256, GD::lds_floats(kNsGrad, a.p.nl) * sizeof(float), s);              \
+  }                                                                                                                       \
+  void sdfhip_geo_bwd1s_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s) {                                       \
+    using GD = GeoDims<NBH, NB0, NBF>;                                                                                     \
+    launch_lds(geo_bwd_kernel<GD, false, 0, false>, a, grid, 256, GD::lds_floats(kNsGrad, a.p.nl) * sizeof(float), s);    \
   }
 
 #define SDFHIP_DEFINE_COL_AND_TABLE(NAME, NBH, NB0, NBF, NBS, NBC)                                                        \
@@ -79,6 +88,7 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
   void sdfhip_geo_fwd_infer_##NAME(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s);                          \
   void sdfhip_geo_bwd_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s);                                          \
   void sdfhip_geo_bwd1_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s);                                         \
+  void sdfhip_geo_bwd1s_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s);                                        \
   namespace NAME##_ns {                                                                                                   \
   static void geo_fwd(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s) {                                      \
     if (mode == 0) sdfhip_geo_fwd_train_##NAME(a, grid, s);                                                               \
@@ -100,7 +110,8 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
   }                                                                                                                       \
   const FieldKernels* sdfhip_kernels_##NAME() {                                                                           \
     static const FieldKernels k = {NBH, NB0, NBF, NBS, NBC, NAME##_ns::geo_fwd, sdfhip_geo_bwd_##NAME,                    \
-                                   sdfhip_geo_bwd1_##NAME, NAME##_ns::col_fwd, NAME##_ns::col_bwd, NAME##_ns::sdfrow};    \
+                                   sdfhip_geo_bwd1_##NAME, NAME##_ns::col_fwd, NAME##_ns::col_bwd, NAME##_ns::sdfrow,     \
+                                   0, 0, sdfhip_geo_bwd1s_##NAME, 1};                                                     \
     return &k;                                                                                                            \
   }
 

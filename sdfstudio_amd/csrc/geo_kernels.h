@@ -279,9 +279,12 @@ struct GeoBwdArgs {
 // PHASE (TANGENT only): 0 = tangent pass and data backward in one launch, 1 = tangent pass only, 2 = data backward only (zc from
 // the tangent launch is in zb_tp).  The backward starts from ub_NL = w_s sdfbar + W_f^T featbar, not from registers of the
 // tangent pass, so the split moves no extra data; the reason for it is the one given at geo_fwd_kernel.
-template <class D, bool TANGENT = true, int PHASE = 0>
+// FEATBAR = false (first-order only): the caller has no cotangent for the geometry feature of these points (the six taps of the
+// numerical-gradient branch are evaluated for their sdf alone): ub_NL = w_s sdfbar, the W_f^T featbar gemm and its reads are skipped.
+template <class D, bool TANGENT = true, int PHASE = 0, bool FEATBAR = true>
 __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
   static_assert(PHASE == 0 || TANGENT, "phases split the second-order kernel");
+  static_assert(FEATBAR || !TANGENT, "the feature-less variant is a first-order kernel");
   static_assert(!TANGENT || D::ACT == 0, "the tangent pass uses Softplus(100)'s second derivative");
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, hf = lane >> 5;
@@ -295,7 +298,8 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
 
   WStream ws{lds, D::buf_floats(NS), 0, wave, lane};
   if constexpr (TANGENT && PHASE != 2) ws.issue(a.p.wp[0], chunk_pieces(D::NBH, NS), true);
-  else ws.issue(a.p.wpT[NL], chunk_pieces(D::NBH, NS), true);
+  else if constexpr (FEATBAR) ws.issue(a.p.wpT[NL], chunk_pieces(D::NBH, NS), true);
+  else ws.issue(bwd_first_w, PCS, true);  // the widest chunk any gemm streams, over-read into the packed buffer's slack (geo_fwd PHASE 2)
   if (tid < D::NBH * 32) cvec[tid] = a.p.w_sdf[tid];
   __syncthreads();
 
@@ -399,8 +403,12 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
     };
     auto make = [&](auto, const Raw& raw, auto ec) __attribute__((always_inline)) { return raw.a[decltype(ec)::value]; };
     auto next_fetch = [&]() __attribute__((always_inline)) { return bwd_src(NL - 1, 0); };
-    carry = load_src(fetch(IC<0>{}), lane);
-    tp_gemm<D::NBF, D::NBH, Stores<0>, NS, PCS>(accIn, carry, fetch, make, next_fetch, ws, a.p.wpT[NL], bwd_first_w);
+    if constexpr (FEATBAR) {
+      carry = load_src(fetch(IC<0>{}), lane);
+      tp_gemm<D::NBF, D::NBH, Stores<0>, NS, PCS>(accIn, carry, fetch, make, next_fetch, ws, a.p.wpT[NL], bwd_first_w);
+    } else {
+      carry = load_src(next_fetch(), lane);
+    }
   }
   // accIn holds ub_{l+1}.  zb_l = ub * s'(z_l) + zc_l (zc from the tangent pass, in zb_tp[l]) is produced, stored for the weight
   // gradient and multiplied by W_l^T: its in0 columns first where the layer has them (skip layer -> parked in in0bar, layer 0),

@@ -5,9 +5,10 @@
 // is PRODUCED just in time from the previous layer's accumulators by a small functor (activation, derivative scaling,
 // loads of saved tensors, stores of tensors the backward needs):
 //
-//   for kb in 0..KB (fully unrolled, every register index a compile-time constant):
-//       wait for weight chunk kb in LDS (counted s_waitcnt vmcnt ; s_barrier)
-//       start the LDS-DMA of the next chunk (possibly the first chunk of the NEXT gemm: the stream never drains)
+//   for kb in 0..KB (unrolled WITHIN a gemm, every register index a compile-time constant; the layers around the gemms are run-time loops):
+//       wait for weight chunk kb in LDS: s_waitcnt vmcnt(0) - the wave's WHOLE vector-memory queue, i.e. the chunk's LDS-DMA and every
+//       load / store issued around it - then a bare s_barrier (all four waves' pieces have landed, everybody is done with the other buffer)
+//       start the LDS-DMA of the next chunk (possibly the first chunk of the NEXT gemm: the weight stream itself never stalls on a layer boundary)
 //       issue the global loads the producer of block kb + 2 needs
 //       produce block kb + 1 (VALU) and split it into bf16 parts, interleaved with
 //       2 x NBO x {3 | 6}  v_mfma_f32_32x32x16_{bf16,f16}  with A = weight fragments from LDS (ds_read_b128: 8 k per read),
@@ -74,8 +75,8 @@ struct WStream {
                                      (__attribute__((address_space(3))) void*)(dst + piece * 256), 16, 0, 0);
   }
   // The weight chunk about to be consumed has landed in LDS for every wave, and every wave is done reading the other
-  // buffer.  NEWER = vector-memory operations allowed to stay outstanding: 0 since round 3 (tp_gemm explains why the counted form -
-  // "the operations issued after the chunk's DMA may stay in flight" - was not safe).
+  // buffer.  NEWER = vector-memory operations allowed to stay outstanding: 0 in the product (tp_gemm explains why no counted form -
+  // "the operations issued after the chunk's DMA may stay in flight" - is safe here).
   // A bare s_barrier (no workgroup release fence) keeps the compiler from adding its own vmcnt(0) in front of it.
   template <int NEWER>
   SDFHIP_D void wait_sync() {
@@ -140,9 +141,8 @@ SDFHIP_D Raw load_src(const BlkSrc<N>& src, const int lane) {
 //                                      during step kb, the compiler interleaves it with the step's MFMAs
 //   next_fetch() -> BlkSrc<N>          operands of block 0 of the FOLLOWING gemm, loaded during this gemm's last step;
 //                                      they travel in `carry`, which on entry holds this gemm's own block-0 operands
-//   ST::at(kb)                         number of global stores make(IC<kb>, ..) issues.  Those stores and the 16 N loads of
-//                                      fetch(kb + 1) are issued AFTER the DMA of chunk kb, so the wait for that chunk may
-//                                      leave them in flight (WStream::wait_sync)
+//   ST::at(kb)                         number of global stores make(IC<kb>, ..) issues (bookkeeping for the experimental counted waits
+//                                      below; the product wait drains the queue and does not depend on it)
 //   NS                                 bf16 parts per operand (2: 3-term products, 3: 6-term, fp32-class)
 // wp: this gemm's packed weights (first chunk already in flight / landed in the current buffer).
 // next_wp / NEXTP: first chunk of the gemm that follows, chunk_pieces(its NBO, its NS) (0: none).
@@ -226,19 +226,19 @@ SDFHIP_D void tp_gemm(f32x16 (&acc)[MAXA], Raw& carry, Fetch&& fetch, Make&& mak
     {
       // vector-memory operations issued after the DMA of chunk kb: the loads of fetch(kb + 1), then the stores of make(kb)
       constexpr int newer_ = ST::at(kb) + (more ? 16 * decltype(fetch(IC<(more ? kb + 1 : 0)>{}))::n : 0);
-      // Round 3: the wait DRAINS the wave's vector-memory queue (vmcnt(0)).  Rounds 1 - 2 waited with the count above ("at most
-      // `newer_` operations outstanding": the loads / stores issued after the chunk's DMA may stay in flight), on the premise that
-      // vmcnt retires strictly in issue order.  That premise does not hold between an LDS-DMA and the ordinary loads / stores behind it:
-      // on the 64-wide golden network one no-grad forward in five came back with a workgroup's (or a few waves') colour outputs off by
-      // ~5e-5 - a gemm had started on a weight chunk that was still landing (tools/debug_fwd.py: 60 / 60 calls bit-identical with the
-      // drain, sdf and normals were never affected; the full-size shapes never showed it, their steps are long enough).  The drain costs
-      // 0.2 ms per config-2 step (22.67 -> 22.89 ms, same box).  -DSDFHIP_COUNTED_WAIT restores the counted form for experiments.
-#ifdef SDFHIP_ABL_WAIT_SLACK  // timing ablation (RACY on purpose): what the wait costs through the older stores it also covers
+      // The wait DRAINS the wave's vector-memory queue (vmcnt(0)).  Rounds 1 - 2 waited with the count above ("at most `newer_`
+      // operations outstanding": what was issued after the chunk's DMA may stay in flight), on the premise that vmcnt retires in issue
+      // order.  It does not, in two ways, both established with the bit-reproducibility tests (tests/test_gpu_bitrepro.py,
+      // test_field_forward_is_bit_reproducible): stores retire out of order with respect to loads (round 3: one no-grad forward in five of
+      // the 64-wide golden network came back with a workgroup's colour outputs off by ~5e-5 - a gemm had started on a weight chunk that
+      // was still landing), and an LDS-DMA does not retire in order with the ordinary loads issued after it either (round 4: counting
+      // only the younger LOADS and letting every store drain - the one variant the store argument leaves open - fails the same test, 2 of
+      // 2 modes, while being 0.07 - 0.2 ms per step faster).  A counted wait is therefore only sound for a queue that holds nothing but
+      // LDS-DMAs (the guide's GEMM templates); these kernels interleave the producer's loads and stores with the weight stream, and all
+      // four waves of a workgroup own a full register file, so there is no room for a fifth, DMA-only wave.  The drain costs 0.2 ms per
+      // config-2 step against the (racy) counted form.
+#ifdef SDFHIP_ABL_WAIT_SLACK  // TIMING ABLATION ONLY (racy on purpose, wrong numerics allowed): what the wait costs through the queue it drains
       constexpr int newer = newer_ + SDFHIP_ABL_WAIT_SLACK;
-#elif defined(SDFHIP_COUNTED_WAIT)
-      constexpr int newer = newer_;
-#elif defined(SDFHIP_LOADS_ONLY_WAIT)  // UNTESTED candidate for the next round: the younger LOADS may stay in
-      constexpr int newer = newer_ - ST::at(kb);  // flight, the stores are not counted on (safe if loads and LDS-DMA retire in order among themselves)
 #else
       constexpr int newer = 0;
       (void)newer_;

@@ -143,7 +143,22 @@ struct EncodeArgs {
   float* x_out;          // [n_padded][3] contracted positions
   float* in0_tp;         // [n_padded/32][nb0][16][64]
   float* dydp;           // [(L*F)*3][n_padded]  or null
+  // numerical-gradient branch (sdf_field.py:431-453): n_points = 7 tap_points, point tap_points * k + i is point i displaced by the
+  // k-th tap offset AFTER the contraction (k = 0: the point itself; 1..6: +d, -d along x, then y, then z).  0: plain points.
+  int64_t tap_points;
+  float tap_delta;
 };
+
+// position of encode point p: the start position of point q = p mod tap_points (or p), contracted, then displaced by its tap
+SDFHIP_D void encode_position(const EncodeArgs& a, const int64_t p, float x[3]) {
+  const int64_t q = a.tap_points > 0 ? p % a.tap_points : p;
+  start_position(a.origins, a.dirs, a.starts, q, a.S, x);
+  if (a.contract) contract_inf(x, a.contract);
+  if (a.tap_points > 0) {
+    const int tap = (int)(p / a.tap_points);
+    if (tap > 0) x[(tap - 1) >> 1] += ((tap - 1) & 1) ? -a.tap_delta : a.tap_delta;
+  }
+}
 
 // grid = (n_padded / 256, n_levels + 1), block = 256
 __global__ __launch_bounds__(256) void geo_encode_kernel(const EncodeArgs a) {
@@ -151,10 +166,7 @@ __global__ __launch_bounds__(256) void geo_encode_kernel(const EncodeArgs a) {
   if (p >= a.n_padded) return;
   const bool live = p < a.n_points;
   float x[3] = {0.f, 0.f, 0.f};
-  if (live) {
-    start_position(a.origins, a.dirs, a.starts, p, a.S, x);
-    if (a.contract) contract_inf(x, a.contract);
-  }
+  if (live) encode_position(a, p, x);
   // blockIdx.y = level * (F / 2) + feature pair; the last y is the position / positional-encoding block.  An F-feature level is
   // F / 2 two-feature gathers that share the cell (hash_features_per_level = 8 in the neus-facto-angelo preset).
   const int L = a.grid.n_levels, F = a.grid.n_features, pairs = F >> 1;
@@ -227,10 +239,7 @@ __global__ __launch_bounds__(256) void geo_encode8_kernel(const EncodeArgs a) {
   if (p >= a.n_padded) return;
   const bool live = p < a.n_points;
   float x[3] = {0.f, 0.f, 0.f};
-  if (live) {
-    start_position(a.origins, a.dirs, a.starts, p, a.S, x);
-    if (a.contract) contract_inf(x, a.contract);
-  }
+  if (live) encode_position(a, p, x);
   const int L = a.grid.n_levels;
   const int level = blockIdx.y;
   const int pe_dims = 6 * a.pe_degree;
@@ -811,4 +820,57 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
     if (c < n1) out1[c] = s;
     else out2[c - n1] = s;
   }
+}
+
+
+// ---- numerical-gradient branch (sdf_field.py:431-453, 638-644): central differences of the six tap values
+struct FdArgs {
+  const float* sdf7;     // [7 P (padded)]  sdf of the points and their taps, tap-major (EncodeArgs::tap_points)
+  int64_t n_points;      // P
+  float delta;
+  float* grad;           // [P][3]   0.5 (sdf(x + d e_k) - sdf(x - d e_k)) / d
+  float* taps;           // [P][6]   sampled_sdf (sdf_field.py:644), or null
+  // backward
+  const float* sdf_bar;    // [P] or null
+  const float* grad_bar;   // [P][3] or null   upstream d L / d gradient (eikonal loss, alpha)
+  const float* csmallbar_tp;  // [T][nbs] colour backward (normal slots 30..32) or null
+  const float* taps_bar;   // [P][6] or null   (curvature loss)
+  int32_t nbs, pad_;
+  int64_t n_padded7;
+  float* sdfbar7;          // [n_padded7]
+};
+__global__ __launch_bounds__(256) void fd_normal_kernel(const FdArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= a.n_points) return;
+  const int64_t P = a.n_points;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const float tp = a.sdf7[(2 * d + 1) * P + i], tm = a.sdf7[(2 * d + 2) * P + i];
+    a.grad[i * 3 + d] = 0.5f * (tp - tm) / a.delta;
+    if (a.taps != nullptr) {
+      a.taps[i * 6 + 2 * d] = tp;
+      a.taps[i * 6 + 2 * d + 1] = tm;
+    }
+  }
+}
+// adjoint: sdfbar of the 7 P points from (sdf_bar, total d L / d gradient, taps_bar); rows beyond 7 P are zero
+__global__ __launch_bounds__(256) void fd_adjoint_kernel(const FdArgs a) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= a.n_padded7) return;
+  const int64_t P = a.n_points;
+  float v = 0.0f;
+  if (p < 7 * P) {
+    const int tap = (int)(p / P);
+    const int64_t i = p - tap * P;
+    if (tap == 0) {
+      v = a.sdf_bar != nullptr ? a.sdf_bar[i] : 0.0f;
+    } else {
+      const int d = (tap - 1) >> 1;
+      float g = a.grad_bar != nullptr ? a.grad_bar[i * 3 + d] : 0.0f;
+      if (a.csmallbar_tp != nullptr) g += a.csmallbar_tp[tp_index(i, 30 + d, a.nbs)];
+      v = ((tap - 1) & 1) ? -(0.5f * g / a.delta) : 0.5f * g / a.delta;
+      if (a.taps_bar != nullptr) v += a.taps_bar[i * 6 + (tap - 1)];
+    }
+  }
+  a.sdfbar7[p] = v;
 }

@@ -165,6 +165,7 @@ class Optimizers:
         if flat_grads is None:
             flat_grads = FlatGradients([p for g in groups.values() for p in g["params"]], buckets=[g["params"] for g in groups.values()])
         self.flat_grads = flat_grads
+        self._group_params = {k: list(g["params"]) for k, g in groups.items()}  # full lists (incl. requires_grad=False), as the reference indexes them
         eps = {config[k].get("eps", 1e-15) for k in groups}
         assert len(eps) == 1, "one eps for all groups (the reference uses 1e-15 throughout)"
         self.adam = FusedAdam(groups, flat_grads, eps=eps.pop())
@@ -187,7 +188,49 @@ class Optimizers:
         return self.adam.state_dict()
 
     def load_optimizers(self, loaded_state: Dict) -> None:
-        """optimizers.py:157-160."""
-        self.adam.load_state_dict(loaded_state)
+        """optimizers.py:157-160.  Accepts this class's own state_dict() and the REFERENCE's checkpoint layout
+        {group: torch.optim.Adam.state_dict()} (engine/trainer.py:351-360): per-parameter exp_avg / exp_avg_sq / step, indexed by the
+        position of the parameter in the group's parameter list."""
+        if "groups" in loaded_state and "step_count" in loaded_state:
+            self.adam.load_state_dict(loaded_state)
+            return
+        if not all(isinstance(v, dict) and "state" in v and "param_groups" in v for v in loaded_state.values()):
+            raise ValueError("optimizer state is neither Optimizers.state_dict() of this repo nor {group: torch.optim.Adam.state_dict()} of the "
+                             f"reference (top-level keys: {sorted(loaded_state)})")
+        if set(loaded_state) != set(self._group_params):
+            raise KeyError(f"optimizer groups differ: checkpoint {sorted(loaded_state)}, model {sorted(self._group_params)}")
+        adam = self.adam
+        steps = set()
+        for name, ref in loaded_state.items():
+            plist = self._group_params[name]
+            for idx, st in ref["state"].items():
+                idx = int(idx)
+                if idx >= len(plist):
+                    raise ValueError(f"group {name!r}: the checkpoint has state for parameter #{idx}, the model's group has {len(plist)} parameters")
+                p = plist[idx]
+                if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                    raise ValueError(f"group {name!r}, parameter #{idx}: moment of shape {tuple(st['exp_avg'].shape)} for a parameter of shape "
+                                     f"{tuple(p.shape)} - the reference keeps its tiny-cuda-nn modules (proposal networks, 'grid' background) as "
+                                     "one flat `params` vector each; their optimizer state does not map onto this repo's tensors")
+                if id(p) not in adam.flat_params.offset:
+                    continue  # requires_grad = False here
+                a, n = adam.flat_params.offset[id(p)], p.numel()
+                adam.exp_avg[a:a + n].copy_(st["exp_avg"].reshape(-1))
+                adam.exp_avg_sq[a:a + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(st["step"]))
+            pg = ref["param_groups"][0]
+            adam.groups[name]["lr"] = float(pg["lr"])
+            adam.groups[name]["lr_init"] = float(pg.get("initial_lr", adam.groups[name]["lr_init"]))
+        if len(steps) > 1:
+            # torch counts steps per parameter (a parameter unused in some iterations lags); the fused step has ONE counter: take the
+            # latest, which is exact for every parameter that was used in every iteration
+            pass
+        adam.step_count = max(steps) if steps else 0
+        adam.flat_grads.mark_all_live()
 
     load_state_dict = load_optimizers
+
+    def load_schedulers(self, loaded_state: Dict) -> None:
+        """optimizers.py (trainer resume path): the schedules here are pure functions of the step count, which load_optimizers restores
+        together with every group's current lr - there is no separate scheduler state to load."""
+        return None

@@ -311,6 +311,60 @@ class _ColorFunction(torch.autograd.Function):
         return theta_bar, feat_bar, grad_bar, emb_bar, None, None, None, None, None
 
 
+class _NumericalFieldFunction(torch.autograd.Function):
+    """get_outputs with use_numerical_gradients (sdf_field.py:629-655) as ONE autograd node: (theta, table[, emb]) -> (sdf, finite-
+    difference d sdf / dx, rgb, the six tap values, contracted x).  One native call each way (sdfhip_numfield_forward / _backward): the
+    geometry network on the samples and their six taps, the central differences, the colour network on the normal - the geometry feature
+    stays in the kernels' tile-packed layout between the two networks, the tap points run the sdf-row-only kernels."""
+
+    @staticmethod
+    def forward(ctx, theta, table, emb, fld, origins, dirs, starts, mask, delta):
+        lib = _lib.load()
+        dev = theta.device
+        n, s = starts.shape
+        P = n * s
+        h = fld._handle
+        packed = torch.empty(lib.sdfhip_field_packed_size(h), device=dev)
+        theta_c = theta.contiguous()
+        _lib.check(lib.sdfhip_field_pack(h, _lib.ptr(theta_c), _lib.ptr(packed), _lib.stream()), "field_pack")
+        train = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        ws = torch.empty(lib.sdfhip_numfield_workspace_size(h, P), dtype=torch.uint8, device=dev)
+        sdf7 = torch.empty(lib.sdfhip_numfield_sdf_rows(P), device=dev)
+        grad = torch.empty(P, 3, device=dev)
+        rgb = torch.empty(P, 3, device=dev)
+        taps = torch.empty(P, 6, device=dev)
+        x = torch.empty(P, 3, device=dev)
+        emb_c = None if emb is None else emb.contiguous()
+        _lib.check(lib.sdfhip_numfield_forward(h, _lib.ptr(packed), _lib.ptr(table), _lib.ptr(mask), _lib.ptr(origins), _lib.ptr(dirs),
+                                               _lib.ptr(starts), n, s, _lib.ptr(emb_c), float(delta), 1 if train else 0,
+                                               ctypes.c_void_p(ws.data_ptr()), _lib.ptr(sdf7), _lib.ptr(grad), _lib.ptr(rgb), _lib.ptr(taps),
+                                               _lib.ptr(x), _lib.stream()), "numfield_forward")
+        del emb_c
+        if train:
+            ctx.save_for_backward(packed, mask, ws)
+            ctx.fld, ctx.shape, ctx.has_emb, ctx.table_param, ctx.delta = fld, (n, s), emb is not None, table, float(delta)
+        ctx.mark_non_differentiable(x)
+        return sdf7[:P].view(n, s), grad.view(n, s, 3), rgb.view(n, s, 3), taps.view(n, s, 6), x.view(n, s, 3)
+
+    @staticmethod
+    def backward(ctx, sdf_bar, grad_bar, rgb_bar, taps_bar, _x_bar):
+        packed, mask, ws = ctx.saved_tensors
+        lib = _lib.load()
+        fld = ctx.fld
+        n, s = ctx.shape
+        dev = packed.device
+        h = fld._handle
+        theta_bar = torch.empty(lib.sdfhip_field_theta_size(h), device=dev)
+        table_bar = grad_target(ctx.table_param, zero_init=True)[0].view(-1)  # accumulated into; the flat gradient slice when there is one
+        emb_bar = torch.zeros(n, fld.config.appearance_embedding_dim, device=dev) if ctx.has_emb else None
+        sdf_bar_c, grad_bar_c, rgb_bar_c, taps_bar_c = _contig(sdf_bar), _contig(grad_bar), _contig(rgb_bar), _contig(taps_bar)
+        _lib.check(lib.sdfhip_numfield_backward(h, _lib.ptr(packed), _lib.ptr(mask), n, s, ctx.delta, ctypes.c_void_p(ws.data_ptr()),
+                                                _lib.ptr(sdf_bar_c), _lib.ptr(grad_bar_c), _lib.ptr(rgb_bar_c), _lib.ptr(taps_bar_c),
+                                                _lib.ptr(theta_bar), _lib.ptr(table_bar), _lib.ptr(emb_bar), _lib.stream()), "numfield_backward")
+        del sdf_bar_c, grad_bar_c, rgb_bar_c, taps_bar_c
+        return theta_bar, table_bar, emb_bar, None, None, None, None, None, None
+
+
 def _contract_inf(x: torch.Tensor, order=float("inf")) -> torch.Tensor:
     """SceneContraction, field_components/spatial_distortions.py:66-92 (order = inf, or None / 2 for the L2 norm)."""
     mag = x.abs().amax(dim=-1, keepdim=True) if order == float("inf") else torch.linalg.norm(x, dim=-1, keepdim=True)
@@ -564,28 +618,11 @@ class SDFField(nn.Module):
         return self._plain_view
 
     def _numerical_outputs(self, ray_samples, o, d, st, emb):
-        """get_outputs with use_numerical_gradients (sdf_field.py:629-655): geometry network at the contracted start positions
-        and at the six taps in ONE differentiable call (7 P points), finite-difference normal, colour network on it."""
-        n, s = st.shape
-        pos = (o[:, None, :] + d[:, None, :] * st[..., None]).reshape(-1, 3)
-        x = _contract_inf(pos, self.spatial_distortion.order) if self.spatial_distortion is not None else pos
-        P = x.shape[0]
-        delta = self.numerical_gradients_delta
-        pts = torch.cat([x[None], x[None, :, :] + self._tap_offsets(x)[:, None, :]], dim=0).reshape(-1, 3)
-        # one differentiable call over the 7 P points; the geometry feature is only taken (and converted out of the kernels' tile
-        # layout, and back in the backward) for the P centre points
-        if torch.is_grad_enabled():
-            sdf_all, feat = _GeoNetFunction.apply(self._theta(), self.encoding.params, self, pts.detach().contiguous().float(),
-                                                  self._mask(x.device), P)
-        else:  # rendering: the inference variant of the kernels (nothing saved)
-            h = self.forward_geonetwork(pts)
-            sdf_all, feat = h[:, 0], h[:P, 1:]
-        sdf = sdf_all[:P]
-        taps = sdf_all[P:].view(6, P)
-        grad = torch.stack([0.5 * (taps[0] - taps[1]) / delta, 0.5 * (taps[2] - taps[3]) / delta, 0.5 * (taps[4] - taps[5]) / delta], dim=-1)
-        rgb = _ColorFunction.apply(self._theta(), feat, grad, emb, self, x.detach(), d, n, s)
-        sampled_sdf = taps.view(6, n, s).permute(1, 2, 0).contiguous()  # :644
-        return sdf.view(n, s), grad.view(n, s, 3), rgb.view(n, s, 3), x.detach().view(n, s, 3), sampled_sdf
+        """get_outputs with use_numerical_gradients (sdf_field.py:629-655): geometry network at the contracted start positions and at the
+        six taps, finite-difference normal, colour network on it - one native operator each way (_NumericalFieldFunction)."""
+        sdf, grad, rgb, taps, x = _NumericalFieldFunction.apply(self._theta(), self.encoding.params, emb, self, o, d, st, self._mask(o.device),
+                                                                self.numerical_gradients_delta)
+        return sdf, grad, rgb, x, taps  # taps [N,S,6]: `sampled_sdf` (:644)
 
     def get_density(self, ray_samples):
         """sdf_field.py:469-475: Laplace density and geometry feature at the frustum START positions (no contraction, no grad)."""

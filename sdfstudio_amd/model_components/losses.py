@@ -36,35 +36,48 @@ class _SurfaceLosses(torch.autograd.Function):
         P = grad.numel() // 3 if grad is not None else (sdf.numel() if sdf is not None else 0)
         scale = (ctypes.c_float * 4)(mults[0] / (3.0 * n), (mults[1] / P) if grad is not None else 0.0,
                                      (mults[2] / (3.0 * P)) if taps is not None else 0.0, (mults[3] / n) if n_pred is not None else 0.0)
-        kp = _lib.Keep()
         ws = torch.empty(lib.sdfhip_surface_loss_workspace_floats(), device=dev)
         loss4 = torch.empty(4, device=dev)
-        args = (kp(rgb.detach().float()), kp(image.float()), n, kp(None if grad is None else grad.detach()), kp(None if sdf is None else sdf.detach()),
-                kp(None if taps is None else taps.detach()), float(delta), P, kp(None if n_pred is None else n_pred.detach()),
-                kp(None if n_gt is None else n_gt.float()))
-        _lib.check(lib.sdfhip_surface_loss_forward(*args, scale, _lib.ptr(ws), _lib.ptr(loss4), _lib.stream()), "surface_loss_forward")
-        ctx.kp, ctx.args, ctx.scale = kp, args, scale  # the marshalled inputs stay alive for the backward
+        # the marshalled inputs, in the ABI's order: rgb, image, grad, sdf, taps, n_pred, n_gt (None where a loss is switched off)
+        ts = [rgb.detach().float().contiguous(), image.float().contiguous(), None if grad is None else grad.detach().contiguous(),
+              None if sdf is None else sdf.detach().contiguous(), None if taps is None else taps.detach().contiguous(),
+              None if n_pred is None else n_pred.detach().contiguous(), None if n_gt is None else n_gt.float().contiguous()]
+        _lib.check(lib.sdfhip_surface_loss_forward(*_SurfaceLosses._args(ts, n, float(delta), P), scale, _lib.ptr(ws), _lib.ptr(loss4), _lib.stream()),
+                   "surface_loss_forward")
+        # saved THROUGH autograd (not as raw pointers): an in-place change of rgb / eik_grad / sdf between forward and backward trips the
+        # version-counter check instead of silently producing wrong gradients, and the tensors are released with the graph
+        ctx.present = [t is not None for t in ts]
+        ctx.save_for_backward(*[t for t in ts if t is not None])
+        ctx.scale, ctx.n, ctx.delta, ctx.P = scale, n, float(delta), P
         ctx.shapes = (rgb.shape, None if grad is None else grad.shape, None if sdf is None else sdf.shape, None if taps is None else taps.shape,
                       None if n_pred is None else n_pred.shape)
         return loss4[0:1].view(()), loss4[1:2].view(()), loss4[2:3].view(()), loss4[3:4].view(())
 
     @staticmethod
+    def _args(ts, n, delta, P):
+        """(rgb, image, n, grad, sdf, taps, delta, P, n_pred, n_gt) as the ABI takes them; `ts` stays alive in the caller until the launch."""
+        return (_lib.ptr(ts[0]), _lib.ptr(ts[1]), n, _lib.ptr(ts[2]), _lib.ptr(ts[3]), _lib.ptr(ts[4]), delta, P, _lib.ptr(ts[5]), _lib.ptr(ts[6]))
+
+    @staticmethod
     def backward(ctx, *lbar):
         lib = _lib.load()
-        dev = lbar[0].device if lbar[0] is not None else next(t for t in lbar if t is not None).device
+        saved = list(ctx.saved_tensors)
+        ts = [saved.pop(0) if here else None for here in ctx.present]
+        dev = ts[0].device
         shp = ctx.shapes
         need = ctx.needs_input_grad
         lb = [None if t is None else t.contiguous().float() for t in lbar]
         outs = [torch.empty(shp[i], device=dev) if (shp[i] is not None and need[i]) else None for i in range(5)]
-        if outs[2] is None and outs[3] is not None:  # the curvature stencil differentiates sdf and taps together
-            outs[2] = torch.empty(shp[2], device=dev)
-        _lib.check(lib.sdfhip_surface_loss_backward(*ctx.args, ctx.scale, _lib.ptr_array(lb), _lib.ptr(outs[0]), _lib.ptr(outs[1]),
-                                                    _lib.ptr(outs[2]) if outs[3] is not None else None, _lib.ptr(outs[3]), _lib.ptr(outs[4]),
-                                                    _lib.stream()), "surface_loss_backward")
-        del lb
-        if outs[3] is None:
-            outs[2] = None
-        return outs[0], outs[1], outs[2] if need[2] else None, outs[3], outs[4], None, None, None, None
+        # the curvature stencil differentiates sdf and its six taps in one pass: whichever of the two is asked for, both buffers exist
+        # (the other one is scratch) - a sdf that requires grad next to detached taps used to lose its curvature gradient
+        curv = shp[3] is not None and (need[2] or need[3])
+        sdf_bar = outs[2] if outs[2] is not None else (torch.empty(shp[2], device=dev) if curv else None)
+        taps_bar = outs[3] if outs[3] is not None else (torch.empty(shp[3], device=dev) if curv else None)
+        _lib.check(lib.sdfhip_surface_loss_backward(*_SurfaceLosses._args(ts, ctx.n, ctx.delta, ctx.P), ctx.scale, _lib.ptr_array(lb), _lib.ptr(outs[0]),
+                                                    _lib.ptr(outs[1]), _lib.ptr(sdf_bar), _lib.ptr(taps_bar), _lib.ptr(outs[4]), _lib.stream()),
+                   "surface_loss_backward")
+        del lb, ts
+        return outs[0], outs[1], sdf_bar if need[2] else None, taps_bar if need[3] else None, outs[4], None, None, None, None
 
 
 def surface_losses(rgb: torch.Tensor, image: torch.Tensor, eik_grad: Optional[torch.Tensor] = None, eikonal_mult: float = 0.0,

@@ -91,9 +91,23 @@ def _module_layouts(model) -> Dict[str, Tuple[int, int, int, int, int, Tuple[str
     return out
 
 
+# tcnn modules of the reference's TCNNNerfactoField that carry NO learnable state: parameter-free encodings, whose torch binding still
+# registers a zero-element `params` Parameter (fields/nerfacto_field.py:127-139)
+_PARAM_FREE = ("direction_encoding.", "position_encoding.")
+# optional heads the surface models never switch on (nerfacto_field.py:160-223); a checkpoint that has them carries tcnn params we drop
+_OPTIONAL_HEADS = ("mlp_transient.", "mlp_semantics.", "mlp_pred_normals.")
+
+
+def _nerfacto_prefixes(model) -> List[str]:
+    from sdfstudio_amd.fields.nerfacto_field import TCNNNerfactoField
+
+    return [f"{name}." if name else "" for name, mod in model.named_modules() if isinstance(mod, TCNNNerfactoField)]
+
+
 def from_reference_state_dict(reference_sd: Dict[str, torch.Tensor], model) -> Dict[str, torch.Tensor]:
-    """A reference checkpoint's state_dict -> one `model.load_state_dict` accepts: every `<prefix>params` of a tcnn-backed module is
-    replaced by `<prefix>{w1, w2[, w3], table}`; all other keys pass through unchanged."""
+    """A reference checkpoint's state_dict -> one `model.load_state_dict(strict=True)` accepts: every `<prefix>params` of a tcnn-backed
+    module is replaced by `<prefix>{w1, w2[, w3], table}`; the zero-element `params` of the reference field's parameter-free tcnn
+    encodings (`direction_encoding`, `position_encoding`) are dropped - the mirror has no such modules; all other keys pass through."""
     sd = dict(reference_sd)
     for pre, (d_in, hidden, nh, d_out, n_grid, names) in _module_layouts(model).items():
         key = pre + "params"
@@ -104,11 +118,23 @@ def from_reference_state_dict(reference_sd: Dict[str, torch.Tensor], model) -> D
             sd[pre + n] = m
         if table is not None:
             sd[pre + "table"] = table
+    for pre in _nerfacto_prefixes(model):
+        for sub in _PARAM_FREE:
+            t = sd.get(pre + sub + "params")
+            if t is not None:
+                if t.numel() != 0:
+                    raise ValueError(f"{pre + sub}params has {t.numel()} elements: a parameter-free tcnn encoding is expected there")
+                del sd[pre + sub + "params"]
+        for sub in _OPTIONAL_HEADS:
+            if pre + sub + "params" in sd:
+                raise NotImplementedError(f"the checkpoint carries {pre + sub}params: the transient / semantic / predicted-normal heads of "
+                                          "TCNNNerfactoField are not built (off in every surface model)")
     return sd
 
 
 def to_reference_state_dict(sd: Dict[str, torch.Tensor], model) -> Dict[str, torch.Tensor]:
-    """The inverse of from_reference_state_dict (for handing a checkpoint trained here to the reference's viewer / exporters)."""
+    """The inverse of from_reference_state_dict (for handing a checkpoint trained here to the reference's viewer / exporters): the
+    reference's strict load also wants the (empty) `params` of the parameter-free encodings."""
     out = dict(sd)
     for pre, (d_in, hidden, nh, d_out, n_grid, names) in _module_layouts(model).items():
         if pre + names[0] not in out:
@@ -116,4 +142,8 @@ def to_reference_state_dict(sd: Dict[str, torch.Tensor], model) -> Dict[str, tor
         mats = [out.pop(pre + n) for n in names]
         table = out.pop(pre + "table") if n_grid else None
         out[pre + "params"] = join_params(mats, d_in, hidden, nh, d_out, table)
+    for pre in _nerfacto_prefixes(model):
+        if pre + "mlp_base.params" in out:
+            for sub in _PARAM_FREE:
+                out.setdefault(pre + sub + "params", torch.zeros(0, dtype=torch.float32))
     return out

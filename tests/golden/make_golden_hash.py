@@ -57,6 +57,50 @@ def reference_hash_vectors():
     out["fwd/scalings"] = enc.scalings.numpy().astype(np.float64)
     out["fwd/out"] = y.numpy()
     out["fwd/log2_t"] = np.int64(9)
+    out.update(reference_smoothstep_vectors(gen))
+    out.update(reference_level_geometry())
+    return out
+
+
+def reference_smoothstep_vectors(gen):
+    """Smoothstep, the way the reference's OWN code applies it: PeriodicVolumeEncoding.pytorch_fwd (encodings.py:689-733, `offset *
+    offset * (3 - 2 offset)` at :700-701) evaluated on a table that is LINEAR in the cell coordinates along one axis and constant along
+    the others - the trilinear blend of such a table returns floor(pos_axis) + s(frac_axis), i.e. the interpolation weight itself.  (The
+    class's dense periodic index is x-major and its cells sit at pos = S x: neither is tcnn's; what this pins is the weight function.)"""
+    from nerfstudio.field_components.encodings import PeriodicVolumeEncoding
+
+    out = {}
+    R = 16  # periodic volume resolution 2^(12 / 3); scalings floor(4 g^l) stay below it, nothing wraps
+    x = torch.rand(2048, 3, generator=gen) * 0.98 + 0.01
+    for smooth in (True, False):
+        enc = PeriodicVolumeEncoding(num_levels=2, min_res=4, max_res=12, log2_hashmap_size=12, features_per_level=1, hash_init_scale=1.0,
+                                     smoothstep=smooth)
+        coords = torch.stack(torch.meshgrid(torch.arange(R), torch.arange(R), torch.arange(R), indexing="ij"), -1).reshape(-1, 3).float()
+        ys = []
+        for axis in range(3):
+            with torch.no_grad():
+                enc.hash_table.copy_(coords[:, axis].repeat(2)[:, None])  # both levels: entry (x, y, z) holds its `axis` coordinate
+                ys.append(enc.pytorch_fwd(x))  # [P, 2 levels]
+        out[f"smooth/{'on' if smooth else 'off'}"] = torch.stack(ys, dim=-1).numpy()  # [P, level, axis] = floor(pos) + weight
+        out["smooth/scalings"] = enc.scalings.numpy().astype(np.float64)
+    out["smooth/x"] = x.numpy()
+    return out
+
+
+def reference_level_geometry():
+    """The per-level growth factor as the reference computes it wherever it builds a multi-resolution grid (HashEncoding, encodings.py:
+    296-303; SDFField hands the same expression to tcnn as per_level_scale, fields/sdf_field.py:226-238): exp((ln max - ln min) / (L - 1)),
+    for BASELINE configs 2 (16 levels 16 -> 2048) and 5 (16 levels 64 -> 4096) and the proposal grids (5 levels 16 -> 64 / 256)."""
+    from nerfstudio.field_components.encodings import HashEncoding
+
+    out = {}
+    for name, (L, lo, hi) in {"config2": (16, 16, 2048), "config5": (16, 64, 4096), "prop0": (5, 16, 64), "prop1": (5, 16, 256)}.items():
+        enc = HashEncoding(num_levels=L, min_res=lo, max_res=hi, log2_hashmap_size=4, implementation="torch")
+        # scalings = floor(min_res * growth^level): recover growth^level before the floor from the class's own expression
+        growth = np.exp((np.log(hi) - np.log(lo)) / (L - 1))
+        assert torch.equal(enc.scalings, torch.floor(lo * growth ** torch.arange(L))), "the reference's formula moved"
+        out[f"levels/{name}/scalings"] = enc.scalings.numpy().astype(np.float64)
+        out[f"levels/{name}/args"] = np.array([L, lo, hi], np.int64)
     return out
 
 

@@ -111,3 +111,15 @@ def test_tcnn_state_dict_model_round_trip():
     for k in sd:
         assert torch.equal(again[k].cpu(), sd[k].cpu()), k
     m.load_state_dict(again)  # strict
+    # the reference's TCNNNerfactoField also registers two parameter-free tcnn encodings whose torch binding keeps a
+    # zero-element `params` (nerfacto_field.py:127-139): emitted for the reference's strict load, dropped for ours
+    for k in ("field_background.direction_encoding.params", "field_background.position_encoding.params"):
+        assert k in ref and ref[k].numel() == 0 and k not in again
+    fake_ref = dict(ref)  # what a reference checkpoint looks like
+    m2 = Holder()
+    m2.load_state_dict(T.from_reference_state_dict(fake_ref, m2), strict=True)
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v.cpu(), sd[k].cpu()), k
+    bad = dict(ref, **{"field_background.mlp_semantics.params": torch.zeros(5)})
+    with pytest.raises(NotImplementedError):
+        T.from_reference_state_dict(bad, m)

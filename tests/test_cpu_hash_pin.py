@@ -71,3 +71,56 @@ def test_hashed_level_lookup_equals_reference_pytorch_fwd(live):
     assert got.shape == want.shape == (x.shape[0], L * F)
     err = (got - want).abs().max().item()
     assert err <= 2e-6 * want.abs().max().item() + 1e-7, err
+
+
+@pytest.mark.parametrize("live", [False, True], ids=["fixture", "live-reference"])
+def test_smoothstep_weight_equals_reference_periodic_volume_encoding(live):
+    """Smoothstep is applied by reference code too - PeriodicVolumeEncoding.pytorch_fwd (field_components/encodings.py:
+    700-701).  On a table that is linear in the cell coordinate along one axis its trilinear blend returns floor(pos) + weight(frac(pos)):
+    the interpolation weight itself.  oracle.hashgrid.level_cell must produce the same weight for the same fractional position, with
+    Smoothstep on and off (the kernels' cell arithmetic is held to the oracle's by tests/test_gpu_hash_pin.py and every field test)."""
+    v = _vectors(live)
+    x = torch.from_numpy(v["smooth/x"]).double()
+    S = v["smooth/scalings"]
+    for name, smooth in (("on", True), ("off", False)):
+        want = torch.from_numpy(v[f"smooth/{name}"]).double()  # [P, level, axis] = floor(S x) + w
+        for lvl in range(len(S)):
+            pos = x * float(S[lvl])
+            w_ref = want[:, lvl, :] - pos.floor()
+            # the oracle at the position x' that gives it the same pos = scale x' + 0.5 (any positive scale: mapped through and back)
+            scale = float(S[lvl]) - 1.0
+            lv = hashgrid.GridLevels(n_levels=1, n_features=1, log2_hashmap_size=12, base_resolution=0, per_level_scale=1.0, smoothstep=smooth,
+                                     scale=np.array([scale], np.float32), resolution=np.array([int(S[lvl]) + 1]), size=np.array([4096]),
+                                     offset=np.array([0, 4096]), hashed=np.array([False]))
+            xp = (pos - 0.5) / float(np.float32(scale))
+            _, w = hashgrid.level_cell(xp, lv, 0)
+            err = (w - w_ref).abs().max().item()
+            assert err <= 5e-6, f"smoothstep {name}, level {lvl}: weight differs from the reference's by {err:.2e}"
+            if smooth:  # and it IS w^2 (3 - 2 w) of the linear weight, not the identity
+                fr = pos - pos.floor()
+                assert (w_ref - fr * fr * (3 - 2 * fr)).abs().max().item() <= 5e-6 and (w_ref - fr).abs().max().item() > 0.05
+
+
+@pytest.mark.parametrize("live", [False, True], ids=["fixture", "live-reference"])
+def test_level_growth_factor_equals_reference_formula(live):
+    """The per-level scale of oracle.hashgrid.make_levels (and, bit for bit, of the library: test_level_table_of_the_library_equals_the_
+    oracles) grows by the factor the reference computes: exp((ln max_res - ln min_res) / (L - 1)) (encodings.py:296-303, sdf_field.py:226),
+    for the grids of BASELINE configs 2 and 5 and the proposal networks.  tcnn's scale_l = base g^l - 1 and the reference's own
+    scalings_l = floor(base g^l) are different conventions of the same geometry: floor(scale_l + 1) must reproduce the reference's
+    integer resolutions except where g^l is an integer and the two fp roundings straddle it."""
+    from oracle import sdf_path as O
+
+    v = _vectors(live)
+    for name in ("config2", "config5", "prop0", "prop1"):
+        L, lo, hi = (int(t) for t in v[f"levels/{name}/args"])
+        ref = v[f"levels/{name}/scalings"]
+        g = O.FieldCfg(num_levels=L, base_res=lo, max_res=hi).growth_factor()
+        assert g == float(np.exp((np.log(hi) - np.log(lo)) / (L - 1)))  # the same double, not merely close
+        lv = hashgrid.make_levels(L, 2, 19, lo, g, False)
+        exact = lo * g ** np.arange(L)
+        # tcnn receives per_level_scale as a FLOAT: g rounded to fp32 (6e-8) compounds to (L - 1) x 6e-8 at the finest level
+        assert np.allclose(lv.scale.astype(np.float64) + 1.0, exact, rtol=(L - 1) * 1.2e-7, atol=0), name
+        near_int = np.abs(exact - np.round(exact)) < 4e-6 * exact
+        assert np.array_equal(np.floor(lv.scale.astype(np.float64) + 1.0)[~near_int], ref[~near_int]), name
+        assert np.allclose(np.round(exact)[near_int], np.round(lv.scale.astype(np.float64) + 1.0)[near_int]), name
+        assert lv.scale[0] == lo - 1 and abs(float(lv.scale[-1]) + 1.0 - hi) <= (L - 1) * 1.2e-7 * hi

@@ -1098,3 +1098,42 @@ def test_oracle_angelo_step_against_reference_golden(level):
         lv = O.FieldCfg(num_levels=16, max_res=4096, base_res=64, log2_hashmap_size=10, hash_features_per_level=8, hash_smoothstep=False).grid_levels()
         first = int(lv.offset[level]) * 8
         assert base["encoding.params"][first:].abs().max().item() == 0.0 and ref["encoding.params"][first:].abs().max().item() == 0.0
+
+
+def test_optimizers_load_the_references_checkpoint_layout():
+    """the reference's checkpoints hold {"optimizers": {group: torch.optim.Adam.state_dict()}} (engine/trainer.py:351-360,
+    optimizers.py:157-160).  load_optimizers maps that layout onto the flat moments (by the parameter's position in the group's list,
+    frozen parameters included in the count), restores step and lr, refuses anything else with a message that says what it expected,
+    and load_schedulers exists for the trainer's resume path."""
+    from sdfstudio_amd.engine.optimizers import Optimizers
+
+    a, b = torch.nn.Linear(3, 2), torch.nn.Linear(2, 1)
+    frozen = torch.nn.Parameter(torch.ones(4), requires_grad=False)
+    groups = {"fields": [frozen] + list(a.parameters()), "proposal_networks": list(b.parameters())}
+    opts = Optimizers({"fields": {"lr": 1e-3, "scheduler": None}, "proposal_networks": {"lr": 1e-2, "scheduler": None}}, groups)
+    ref = {}
+    for name, plist in groups.items():
+        o = torch.optim.Adam(plist, lr=0.5 if name == "fields" else 0.25, eps=1e-15)
+        for _ in range(3):
+            for p in plist:
+                if p.requires_grad:
+                    p.grad = torch.randn_like(p)
+            o.step()
+        ref[name] = o.state_dict()
+    opts.load_optimizers(ref)
+    ad = opts.adam
+    for name, plist in groups.items():
+        for idx, p in enumerate(plist):
+            if not p.requires_grad:
+                continue
+            off = ad.flat_params.offset[id(p)]
+            assert torch.equal(ad.exp_avg[off:off + p.numel()], ref[name]["state"][idx]["exp_avg"].reshape(-1))
+            assert torch.equal(ad.exp_avg_sq[off:off + p.numel()], ref[name]["state"][idx]["exp_avg_sq"].reshape(-1))
+    assert ad.step_count == 3 and ad.groups["fields"]["lr"] == 0.5 and ad.groups["proposal_networks"]["lr"] == 0.25
+    assert opts.load_schedulers({}) is None
+    with pytest.raises(ValueError, match="neither"):
+        opts.load_optimizers({"fields": 3})
+    wrong = {k: dict(v) for k, v in ref.items()}
+    wrong["fields"] = dict(ref["fields"], state={1: dict(ref["fields"]["state"][1], exp_avg=torch.zeros(7))})
+    with pytest.raises(ValueError, match="moment of shape"):
+        opts.load_optimizers(wrong)

@@ -13,6 +13,11 @@ root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
+sys.path.insert(0, root)
+from sdfstudio_amd import build as _build  # noqa: E402
+
+# identity of the library the passes ran on (the digest written next to the .so when it was linked; the sources' own digest beside it)
+LIB_ID = {"library_digest": _build.built_digest(), "source_digest_at_summary": _build.source_digest()}
 
 
 def short(name):
@@ -60,7 +65,7 @@ if rows:
     # the dominant kernel runs as two launches per step (tangent pass | data backward, geo_kernels.h PHASE): its traffic is their sum
     gb = [r for r in rows if r["kernel"].startswith("geo_bwd_kernel")]
     if gb:
-        json.dump({"kernel": "geo_bwd_kernel", "launches_per_step": len(gb),
+        json.dump({"kernel": "geo_bwd_kernel", "launches_per_step": len(gb), **LIB_ID,
                    "hbm_read_bytes": sum(r["hbm_read_GB_corrected_x2"] for r in gb) * 1e9, "hbm_write_bytes": sum(r["hbm_write_GB"] for r in gb) * 1e9,
                    "source": f"profiles/{tag}_pmc_summary.csv: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes), FETCH_SIZE "
                              "doubled per MI355X_MICROARCH.md (gfx950 reports half of a coalesced stream); sum over the kernel's launches of a step"},
@@ -72,7 +77,7 @@ if rows:
     tot_w = sum(r["hbm_write_GB"] * r["launches_sampled"] for r in rows if r["hbm_write_GB"] == r["hbm_write_GB"])
     gb = [r for r in rows if r["kernel"].startswith("geo_bwd_kernel")]
     steps = gb[0]["launches_sampled"] if gb else 1  # geo_bwd runs once per training step
-    json.dump({"training_steps_sampled": steps, "hbm_read_GB_all_launches": round(tot_r, 2), "hbm_write_GB_all_launches": round(tot_w, 2),
+    json.dump({"training_steps_sampled": steps, **LIB_ID, "hbm_read_GB_all_launches": round(tot_r, 2), "hbm_write_GB_all_launches": round(tot_w, 2),
                "hbm_GB_per_training_step": round((tot_r + tot_w) / steps, 2),
                "note": "sum over all sdfhip kernels of (average bytes per launch x launches sampled), divided by the training steps sampled"},
               open(os.path.join(dst, f"{tag}_step_traffic.json"), "w"), indent=1)
