@@ -409,6 +409,26 @@ int sdfhip_neus_render_backward(const float* sdf, const float* grad, const float
                                 const float* weights_bar,
                                 float* sdf_bar, float* grad_bar, float* rgbs_bar, float* variance_bar, sdfhip_stream_t stream);
 
+/* The same with NeuS-facto's background merge (models/neus_facto.py:289-290 -> base_surface_model.py:256-290,
+ * forward_background_field_and_merge) fused in: samples whose START position origins + dirs * starts lies outside the unit sphere take
+ * alpha = 1 - exp(-(ends - starts) * bg_density) (RaySamples.get_alphas, cameras/rays.py:131-144) and colour bg_rgb of the background
+ * field, the others the SDF field's alpha and colour; the rendered normal is the SDF field's everywhere (field_outputs[NORMAL] is not
+ * merged).  origins [n_rays,3], bg_density [n_rays,n_samples], bg_rgb [n_rays,n_samples,3]; `alpha` returns the MERGED alpha.
+ * Backward: bg_density_bar / bg_rgb_bar are overwritten (zero for inside samples), sdf_bar / rgbs_bar are zero for outside samples. */
+int sdfhip_neus_render_bg_forward(const float* sdf, const float* grad, const float* rgb, const float* dirs, const float* starts,
+                                  const float* ends, const float* variance, const float* background, float cos_anneal, int64_t n_rays,
+                                  int32_t n_samples, const float* origins, const float* bg_density, const float* bg_rgb, float* alpha,
+                                  float* weights, float* out_rgb, float* out_depth_raw, float* out_depth, float* out_normal,
+                                  float* out_acc, float* steps_minmax, float* rgb_merged /* [n_rays,n_samples,3] or NULL */,
+                                  sdfhip_stream_t stream);
+int sdfhip_neus_render_bg_backward(const float* sdf, const float* grad, const float* rgb, const float* dirs, const float* starts,
+                                   const float* ends, const float* variance, const float* background, float cos_anneal, int64_t n_rays,
+                                   int32_t n_samples, const float* origins, const float* bg_density, const float* bg_rgb,
+                                   const float* alpha, const float* weights, const float* out_depth_raw, const float* out_acc,
+                                   const float* steps_minmax, const float* rgb_bar, const float* depth_bar, const float* normal_bar,
+                                   const float* acc_bar, const float* weights_bar, float* sdf_bar, float* grad_bar, float* rgbs_bar,
+                                   float* variance_bar, float* bg_density_bar, float* bg_rgb_bar, sdfhip_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------- measurement (bench.py)
  * Optional HIP-event timing of the library's own launches, recorded on the stream each kernel is launched on.
  * enable(1) resets and starts recording; read() waits for the recorded events of a slot and returns the total

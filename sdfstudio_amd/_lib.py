@@ -145,6 +145,8 @@ _SIGNATURES = {
                                                 ctypes.c_void_p]),
     "sdfhip_neus_render_forward": (c_i32, [c_float_p] * 8 + [c_f32, c_i64, c_i32] + [c_float_p] * 8 + [ctypes.c_void_p]),
     "sdfhip_neus_render_backward": (c_i32, [c_float_p] * 8 + [c_f32, c_i64, c_i32] + [c_float_p] * 14 + [ctypes.c_void_p]),
+    "sdfhip_neus_render_bg_forward": (c_i32, [c_float_p] * 8 + [c_f32, c_i64, c_i32] + [c_float_p] * 12 + [ctypes.c_void_p]),
+    "sdfhip_neus_render_bg_backward": (c_i32, [c_float_p] * 8 + [c_f32, c_i64, c_i32] + [c_float_p] * 19 + [ctypes.c_void_p]),
     "sdfhip_mono_depth_loss_forward": (c_i32, [c_float_p, c_float_p, c_i64, c_i32, c_f32, c_f32, c_f32, c_float_p, c_float_p, ctypes.c_void_p]),
     "sdfhip_mono_depth_loss_backward": (c_i32, [c_float_p, c_float_p, c_i64, c_i32, c_f32, c_f32, c_f32, c_float_p, c_float_p, c_float_p,
                                                 ctypes.c_void_p]),

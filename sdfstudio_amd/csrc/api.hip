@@ -1512,6 +1512,8 @@ extern "C" int sdfhip_numfield_backward(const SdfHipField* f, const float* packe
   ga.pe_degree = f->cfg.pe_degree;
   ga.nb0 = k->nb0;
   ga.tablebar = table_bar;
+  ga.tap_points = P;
+  ga.tap_delta = delta;
   const bool forked = g_side.ready();
   hipStream_t gs = s;
   if (forked) {
@@ -1522,7 +1524,8 @@ extern "C" int sdfhip_numfield_backward(const SdfHipField* f, const float* packe
   if (f->grid.n_levels > 0) {
     ProfScope ps_(PS_GRID_BWD, gs);
     const int64_t P7 = 7 * P;
-    if (f->grid.n_features == 8) grid_bwd8_kernel<<<dim3((unsigned)((P7 + 255) / 256), f->grid.n_levels), 256, 0, gs>>>(ga);
+    // 8 lanes per sample (7 taps + a filler) on the levels that use the tap-adjacent mapping
+    if (f->grid.n_features == 8) grid_bwd8_kernel<<<dim3((unsigned)((8 * P + 255) / 256), f->grid.n_levels), 256, 0, gs>>>(ga);
     else grid_bwd_kernel<<<dim3((unsigned)((P7 + 255) / 256), f->grid.n_levels * (f->grid.n_features / 2)), 256, 0, gs>>>(ga);
   }
   if (forked) SDFHIP_CHECK_HIP(hipEventRecord(g_side.join, gs));
@@ -2283,11 +2286,37 @@ __global__ void minmax_init_kernel(float* mm) {
   mm[1] = 0.0f;
 }
 
+static int neus_render_forward_impl(const float* sdf, const float* grad, const float* rgb, const float* dirs, const float* starts,
+                                    const float* ends, const float* variance, const float* background, float cos_anneal,
+                                    int64_t n_rays, int32_t n_samples, float* alpha, float* weights, float* out_rgb,
+                                    float* out_depth_raw, float* out_depth, float* out_normal, float* out_acc,
+                                    float* steps_minmax, const float* origins, const float* bg_density, const float* bg_rgb,
+                                    float* rgb_merged, sdfhip_stream_t stream);
 extern "C" int sdfhip_neus_render_forward(const float* sdf, const float* grad, const float* rgb, const float* dirs, const float* starts,
                                           const float* ends, const float* variance, const float* background, float cos_anneal,
                                           int64_t n_rays, int32_t n_samples, float* alpha, float* weights, float* out_rgb,
                                           float* out_depth_raw, float* out_depth, float* out_normal, float* out_acc,
                                           float* steps_minmax, sdfhip_stream_t stream) {
+  return neus_render_forward_impl(sdf, grad, rgb, dirs, starts, ends, variance, background, cos_anneal, n_rays, n_samples, alpha, weights,
+                                  out_rgb, out_depth_raw, out_depth, out_normal, out_acc, steps_minmax, nullptr, nullptr, nullptr, nullptr, stream);
+}
+extern "C" int sdfhip_neus_render_bg_forward(const float* sdf, const float* grad, const float* rgb, const float* dirs, const float* starts,
+                                             const float* ends, const float* variance, const float* background, float cos_anneal,
+                                             int64_t n_rays, int32_t n_samples, const float* origins, const float* bg_density,
+                                             const float* bg_rgb, float* alpha, float* weights, float* out_rgb, float* out_depth_raw,
+                                             float* out_depth, float* out_normal, float* out_acc, float* steps_minmax,
+                                             float* rgb_merged, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(origins && bg_density && bg_rgb, "neus_render_bg_forward: null argument");
+  return neus_render_forward_impl(sdf, grad, rgb, dirs, starts, ends, variance, background, cos_anneal, n_rays, n_samples, alpha, weights,
+                                  out_rgb, out_depth_raw, out_depth, out_normal, out_acc, steps_minmax, origins, bg_density, bg_rgb, rgb_merged,
+                                  stream);
+}
+static int neus_render_forward_impl(const float* sdf, const float* grad, const float* rgb, const float* dirs, const float* starts,
+                                    const float* ends, const float* variance, const float* background, float cos_anneal,
+                                    int64_t n_rays, int32_t n_samples, float* alpha, float* weights, float* out_rgb,
+                                    float* out_depth_raw, float* out_depth, float* out_normal, float* out_acc,
+                                    float* steps_minmax, const float* origins, const float* bg_density, const float* bg_rgb,
+                                    float* rgb_merged, sdfhip_stream_t stream) {
   SDFHIP_REQUIRE(sdf && grad && rgb && dirs && starts && ends && variance && alpha && weights && out_rgb && out_depth_raw && out_depth &&
                      out_normal && out_acc && steps_minmax,
                  "neus_render_forward: null argument");
@@ -2313,6 +2342,10 @@ extern "C" int sdfhip_neus_render_forward(const float* sdf, const float* grad, c
   a.out_normal = out_normal;
   a.out_acc = out_acc;
   a.steps_minmax = steps_minmax;
+  a.origins = origins;
+  a.bg_density = bg_density;
+  a.bg_rgb = bg_rgb;
+  a.rgb_merged = rgb_merged;
   if (n_rays == 0) return 0;
   minmax_init_kernel<<<1, 1, 0, s>>>(steps_minmax);
   const unsigned grid = (unsigned)((n_rays + 3) / 4);
@@ -2398,6 +2431,14 @@ extern "C" int sdfhip_volsdf_render_backward(const float* sdf, const float* grad
   return 0;
 }
 
+static int neus_render_backward_impl(const float* sdf, const float* grad, const float* rgb, const float* dirs, const float* starts,
+                                     const float* ends, const float* variance, const float* background, float cos_anneal,
+                                     int64_t n_rays, int32_t n_samples, const float* alpha, const float* weights,
+                                     const float* out_depth_raw, const float* out_acc, const float* steps_minmax,
+                                     const float* rgb_bar, const float* depth_bar, const float* normal_bar, const float* acc_bar,
+                                     const float* weights_bar, float* sdf_bar, float* grad_bar, float* rgbs_bar,
+                                     float* variance_bar, const float* origins, const float* bg_density, const float* bg_rgb,
+                                     float* bg_density_bar, float* bg_rgb_bar, sdfhip_stream_t stream);
 extern "C" int sdfhip_neus_render_backward(const float* sdf, const float* grad, const float* rgb, const float* dirs, const float* starts,
                                            const float* ends, const float* variance, const float* background, float cos_anneal,
                                            int64_t n_rays, int32_t n_samples, const float* alpha, const float* weights,
@@ -2405,6 +2446,31 @@ extern "C" int sdfhip_neus_render_backward(const float* sdf, const float* grad, 
                                            const float* rgb_bar, const float* depth_bar, const float* normal_bar, const float* acc_bar,
                                            const float* weights_bar, float* sdf_bar, float* grad_bar, float* rgbs_bar,
                                            float* variance_bar, sdfhip_stream_t stream) {
+  return neus_render_backward_impl(sdf, grad, rgb, dirs, starts, ends, variance, background, cos_anneal, n_rays, n_samples, alpha, weights,
+                                   out_depth_raw, out_acc, steps_minmax, rgb_bar, depth_bar, normal_bar, acc_bar, weights_bar, sdf_bar,
+                                   grad_bar, rgbs_bar, variance_bar, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+}
+extern "C" int sdfhip_neus_render_bg_backward(const float* sdf, const float* grad, const float* rgb, const float* dirs, const float* starts,
+                                              const float* ends, const float* variance, const float* background, float cos_anneal,
+                                              int64_t n_rays, int32_t n_samples, const float* origins, const float* bg_density,
+                                              const float* bg_rgb, const float* alpha, const float* weights, const float* out_depth_raw,
+                                              const float* out_acc, const float* steps_minmax, const float* rgb_bar, const float* depth_bar,
+                                              const float* normal_bar, const float* acc_bar, const float* weights_bar, float* sdf_bar,
+                                              float* grad_bar, float* rgbs_bar, float* variance_bar, float* bg_density_bar,
+                                              float* bg_rgb_bar, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(origins && bg_density && bg_rgb && bg_density_bar && bg_rgb_bar, "neus_render_bg_backward: null argument");
+  return neus_render_backward_impl(sdf, grad, rgb, dirs, starts, ends, variance, background, cos_anneal, n_rays, n_samples, alpha, weights,
+                                   out_depth_raw, out_acc, steps_minmax, rgb_bar, depth_bar, normal_bar, acc_bar, weights_bar, sdf_bar,
+                                   grad_bar, rgbs_bar, variance_bar, origins, bg_density, bg_rgb, bg_density_bar, bg_rgb_bar, stream);
+}
+static int neus_render_backward_impl(const float* sdf, const float* grad, const float* rgb, const float* dirs, const float* starts,
+                                     const float* ends, const float* variance, const float* background, float cos_anneal,
+                                     int64_t n_rays, int32_t n_samples, const float* alpha, const float* weights,
+                                     const float* out_depth_raw, const float* out_acc, const float* steps_minmax,
+                                     const float* rgb_bar, const float* depth_bar, const float* normal_bar, const float* acc_bar,
+                                     const float* weights_bar, float* sdf_bar, float* grad_bar, float* rgbs_bar,
+                                     float* variance_bar, const float* origins, const float* bg_density, const float* bg_rgb,
+                                     float* bg_density_bar, float* bg_rgb_bar, sdfhip_stream_t stream) {
   SDFHIP_REQUIRE(sdf && grad && rgb && dirs && starts && ends && variance && alpha && weights && out_depth_raw && out_acc && steps_minmax &&
                      sdf_bar && grad_bar && rgbs_bar,
                  "neus_render_backward: null argument");
@@ -2436,6 +2502,11 @@ extern "C" int sdfhip_neus_render_backward(const float* sdf, const float* grad, 
   a.gradbar = grad_bar;
   a.rgbsbar = rgbs_bar;
   a.variancebar = variance_bar;
+  a.origins = origins;
+  a.bg_density = bg_density;
+  a.bg_rgb = bg_rgb;
+  a.bg_density_bar = bg_density_bar;
+  a.bg_rgb_bar = bg_rgb_bar;
   if (n_rays == 0) return 0;
   const unsigned grid = (unsigned)((n_rays + 3) / 4);
   { ProfScope ps_(PS_RENDER_BWD, (hipStream_t)stream); SDFHIP_DISPATCH_C(n_samples, (neus_render_bwd_kernel<C><<<grid, 256, 0, (hipStream_t)stream>>>(a))); }

@@ -452,6 +452,12 @@ struct GridBwdArgs {
   int64_t n_points;
   int32_t pe_degree, nb0;
   float* tablebar;         // [entries][F]  (accumulated)
+  // numerical-gradient branch: the n_points = 7 tap_points points are tap-major (EncodeArgs::tap_points), the taps tap_delta apart (in
+  // contracted space; x 0.25 in the grid's domain).  0: plain points.  grid_bwd8_kernel then puts the 7 taps of a sample into ADJACENT
+  // lanes on every level whose cells are wider than 2 delta, where they mostly share the cell: the run reduction in front of the atomics
+  // merges them (late in neus-facto-angelo's schedule delta is a quarter of the FINEST cell: up to 7 x fewer line updates).
+  int64_t tap_points;
+  float tap_delta;
 };
 
 // ---- line-coalesced issue of the table-gradient atomics
@@ -569,9 +575,19 @@ __global__ __launch_bounds__(256) void grid_bwd8_kernel(const GridBwdArgs a) {
   __shared__ ScatterStage8 stage[4];
   const int lane = threadIdx.x & 63;
   ScatterStage8& st = stage[threadIdx.x >> 6];
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool live = p < a.n_points;
   const int level = blockIdx.y, c0 = level * 8;
+  int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  bool live = p < a.n_points, filler = false;
+  if (a.tap_points > 0 && a.tap_delta * 0.25f * a.grid.lv[level].scale < 0.5f) {
+    // taps of a sample in lanes 8 j .. 8 j + 6; lane 8 j + 7 is a zero-valued filler that repeats its left neighbour's entries, so that
+    // runs still extend from one sample to the next along the ray
+    const int64_t t = p;
+    const int slot = (int)(t & 7);
+    const int64_t i = t >> 3;
+    live = i < a.tap_points && slot < 7;
+    filler = i < a.tap_points && slot == 7;
+    p = slot * a.tap_points + i;
+  }
   float m[8];
   bool any = false;
 #pragma unroll
@@ -614,10 +630,13 @@ __global__ __launch_bounds__(256) void grid_bwd8_kernel(const GridBwdArgs a) {
       }
 #pragma unroll
       for (int f = 0; f < 8; ++f) t[f] = fmaf(s, e8[f], w * yb[f]);
-      const bool issue = wave_run_reduce_n<8>(c.idx[k], live, t);
+      uint32_t idx = c.idx[k];
+      const uint32_t idx_left = __shfl_up(idx, 1);
+      if (filler) idx = idx_left;  // values are zero (yb = e8 = 0 for a lane that is not live)
+      const bool issue = wave_run_reduce_n<8>(idx, live || filler, t);
 #pragma unroll
       for (int f = 0; f < 8; ++f) st.v[lane][kk * 8 + f] = t[f];
-      st.e[lane][kk] = issue ? c.idx[k] : kNoEntry;
+      st.e[lane][kk] = issue ? idx : kNoEntry;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

@@ -70,7 +70,20 @@ struct NeusRenderArgs {
   float* gradbar;  // [N,S,3]
   float* rgbsbar;  // [N,S,3]
   float* variancebar;  // [1] accumulated
+  // background merge of NeuS-facto (neus_facto.py:289-290 -> base_surface_model.py:266-290; null: no background model): samples whose
+  // START position o + d t lies outside the unit sphere take alpha = 1 - exp(-delta sigma_bg) (rays.py:131-144) and colour rgb_bg of
+  // the background field; the normal stays the SDF field's (field_outputs[NORMAL] is not merged)
+  const float* origins;      // [N,3]
+  const float* bg_density;   // [N,S]
+  const float* bg_rgb;       // [N,S,3]
+  float* bg_density_bar;     // [N,S]
+  float* bg_rgb_bar;         // [N,S,3]
+  float* rgb_merged;         // [N,S,3] forward: the merged per-sample colour (field_outputs[RGB] of the reference), or null
 };
+SDFHIP_D bool neus_inside(const NeusRenderArgs& a, const int ray, const float dx, const float dy, const float dz, const float t) {
+  const float px = a.origins[ray * 3 + 0] + dx * t, py = a.origins[ray * 3 + 1] + dy * t, pz = a.origins[ray * 3 + 2] + dz * t;
+  return sqrtf(px * px + py * py + pz * pz) < 1.0f;  // get_foreground_mask, base_surface_model.py:256-264
+}
 
 SDFHIP_D float neus_inv_s(const float variance) {
   return fminf(fmaxf(expf(variance * 10.0f), 1e-6f), 1e6f);  // sdf_field.py:116-118
@@ -102,6 +115,7 @@ __global__ __launch_bounds__(256) void neus_render_fwd_kernel(const NeusRenderAr
       const float nc = sigmoidf_((sd + ic * delta * 0.5f) * inv_s);
       const float v = (pc - nc + 1e-5f) / (pc + 1e-5f);
       al[c] = fminf(fmaxf(v, 0.0f), 1.0f);
+      if (a.bg_density != nullptr && !neus_inside(a, ray, dx, dy, dz, a.starts[i])) al[c] = 1.0f - expf(-(delta * a.bg_density[i]));
       one_m[c] = 1.0f - al[c] + 1e-7f;  // rays.py:205
       a.alpha[i] = al[c];
     }
@@ -120,9 +134,15 @@ __global__ __launch_bounds__(256) void neus_render_fwd_kernel(const NeusRenderAr
       const float w = al[c] * T;
       a.weights[i] = w;
       acc += w;
-      r = fmaf(w, a.rgb[i * 3], r);
-      g = fmaf(w, a.rgb[i * 3 + 1], g);
-      b = fmaf(w, a.rgb[i * 3 + 2], b);
+      const float* col = (a.bg_density != nullptr && !neus_inside(a, ray, dx, dy, dz, a.starts[i])) ? a.bg_rgb : a.rgb;
+      r = fmaf(w, col[i * 3], r);
+      g = fmaf(w, col[i * 3 + 1], g);
+      b = fmaf(w, col[i * 3 + 2], b);
+      if (a.rgb_merged != nullptr) {
+        a.rgb_merged[i * 3 + 0] = col[i * 3];
+        a.rgb_merged[i * 3 + 1] = col[i * 3 + 1];
+        a.rgb_merged[i * 3 + 2] = col[i * 3 + 2];
+      }
       const float mid = 0.5f * (a.starts[i] + a.ends[i]);
       dep = fmaf(w, mid, dep);
       mn = fminf(mn, mid);
@@ -228,14 +248,21 @@ __global__ __launch_bounds__(256) void neus_render_bwd_kernel(const NeusRenderAr
       const float nrm = fmaxf(sqrtf(gx * gx + gy * gy + gz * gz), 1e-12f);
       const float n0 = gx / nrm, n1 = gy / nrm, n2 = gz / nrm;
       float t = ab + (a.weightsbar != nullptr ? a.weightsbar[i] : 0.0f);
-      t += rb[0] * (a.rgb[i * 3] - bg[0]) + rb[1] * (a.rgb[i * 3 + 1] - bg[1]) + rb[2] * (a.rgb[i * 3 + 2] - bg[2]);
+      const bool outside = a.bg_density != nullptr && !neus_inside(a, ray, dx, dy, dz, a.starts[i]);
+      const float* col = outside ? a.bg_rgb : a.rgb;
+      t += rb[0] * (col[i * 3] - bg[0]) + rb[1] * (col[i * 3 + 1] - bg[1]) + rb[2] * (col[i * 3 + 2] - bg[2]);
       t += db * (mid - depth_raw) / (acc + 1e-10f);
       t += nb[0] * n0 + nb[1] * n1 + nb[2] * n2;
       wbar[c] = t;
-      // per-sample outputs that do not need the scan
-      a.rgbsbar[i * 3 + 0] = w * rb[0];
-      a.rgbsbar[i * 3 + 1] = w * rb[1];
-      a.rgbsbar[i * 3 + 2] = w * rb[2];
+      // per-sample outputs that do not need the scan: the colour cotangent goes to whichever field supplied the colour
+      a.rgbsbar[i * 3 + 0] = outside ? 0.0f : w * rb[0];
+      a.rgbsbar[i * 3 + 1] = outside ? 0.0f : w * rb[1];
+      a.rgbsbar[i * 3 + 2] = outside ? 0.0f : w * rb[2];
+      if (a.bg_rgb_bar != nullptr) {
+        a.bg_rgb_bar[i * 3 + 0] = outside ? w * rb[0] : 0.0f;
+        a.bg_rgb_bar[i * 3 + 1] = outside ? w * rb[1] : 0.0f;
+        a.bg_rgb_bar[i * 3 + 2] = outside ? w * rb[2] : 0.0f;
+      }
       local += t * w;
     }
   }
@@ -275,7 +302,9 @@ __global__ __launch_bounds__(256) void neus_render_bwd_kernel(const NeusRenderAr
       const float pc = sigmoidf_(ep * inv_s), nc = sigmoidf_(en * inv_s);
       const float den = pc + 1e-5f;
       const float v = (pc - nc + 1e-5f) / den;
-      const bool pass = v >= 0.0f && v <= 1.0f;  // torch.clip backward mask
+      const bool outside = a.bg_density != nullptr && !neus_inside(a, ray, dx, dy, dz, a.starts[i]);
+      if (a.bg_density_bar != nullptr) a.bg_density_bar[i] = outside ? abar_i * delta * expf(-(delta * a.bg_density[i])) : 0.0f;
+      const bool pass = v >= 0.0f && v <= 1.0f && !outside;  // torch.clip backward mask; outside samples take the background's alpha
       float sdb = 0.f, icb = 0.f;
       if (pass && abar_i != 0.0f) {
         const float pbar = abar_i / den;              // d/d(p) with p = pc - nc

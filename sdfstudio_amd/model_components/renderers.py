@@ -105,6 +105,60 @@ def neus_render(sdf, gradients, rgb, variance, directions, starts, ends, cos_ann
                              ends.contiguous(), background, cos_anneal_ratio)
 
 
+class _NeusRenderBg(torch.autograd.Function):
+    """neus_render with NeuS-facto's background merge fused in (include/sdfhip.h: sdfhip_neus_render_bg_*): one launch each way where
+    the per-head path (get_alpha -> merge -> get_weights_from_alphas -> four renderers, base_surface_model.py:266-310) costs ~50."""
+
+    @staticmethod
+    def forward(ctx, sdf, grad, rgb, variance, bg_density, bg_rgb, origins, dirs, starts, ends, background, cos_anneal):
+        lib = _lib.load()
+        n, s = starts.shape
+        dev = starts.device
+        sdf, grad, rgb, bg_density, bg_rgb = sdf.contiguous(), grad.contiguous(), rgb.contiguous(), bg_density.contiguous(), bg_rgb.contiguous()
+        alpha, weights = torch.empty(n, s, device=dev), torch.empty(n, s, device=dev)
+        out_rgb, normal = torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev)
+        depth_raw, depth, acc = (torch.empty(n, device=dev) for _ in range(3))
+        minmax = torch.empty(2, device=dev)
+        rgb_merged = torch.empty(n, s, 3, device=dev)
+        _lib.check(lib.sdfhip_neus_render_bg_forward(
+            _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(rgb), _lib.ptr(dirs), _lib.ptr(starts), _lib.ptr(ends), _lib.ptr(variance),
+            _lib.ptr(background), float(cos_anneal), n, s, _lib.ptr(origins), _lib.ptr(bg_density), _lib.ptr(bg_rgb), _lib.ptr(alpha),
+            _lib.ptr(weights), _lib.ptr(out_rgb), _lib.ptr(depth_raw), _lib.ptr(depth), _lib.ptr(normal), _lib.ptr(acc), _lib.ptr(minmax),
+            _lib.ptr(rgb_merged), _lib.stream()), "neus_render_bg_forward")
+        ctx.save_for_backward(sdf, grad, rgb, variance, bg_density, bg_rgb, origins, dirs, starts, ends, alpha, weights, depth_raw, acc, minmax)
+        ctx.background = background
+        ctx.cos_anneal = float(cos_anneal)
+        ctx.mark_non_differentiable(alpha, rgb_merged)
+        return out_rgb, depth, normal, acc, weights, alpha, rgb_merged
+
+    @staticmethod
+    def backward(ctx, rgb_bar, depth_bar, normal_bar, acc_bar, weights_bar, _alpha_bar, _merged_bar):
+        sdf, grad, rgb, variance, bg_density, bg_rgb, origins, dirs, starts, ends, alpha, weights, depth_raw, acc, minmax = ctx.saved_tensors
+        lib = _lib.load()
+        n, s = starts.shape
+        sdf_bar, grad_bar, rgbs_bar = torch.empty_like(sdf), torch.empty_like(grad), torch.empty_like(rgb)
+        bgd_bar, bgc_bar = torch.empty_like(bg_density), torch.empty_like(bg_rgb)
+        var_bar = torch.zeros_like(variance)
+        kp = _lib.Keep()
+        _lib.check(lib.sdfhip_neus_render_bg_backward(
+            _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(rgb), _lib.ptr(dirs), _lib.ptr(starts), _lib.ptr(ends), _lib.ptr(variance),
+            _lib.ptr(ctx.background), ctx.cos_anneal, n, s, _lib.ptr(origins), _lib.ptr(bg_density), _lib.ptr(bg_rgb), _lib.ptr(alpha),
+            _lib.ptr(weights), _lib.ptr(depth_raw), _lib.ptr(acc), _lib.ptr(minmax), kp(rgb_bar), kp(depth_bar), kp(normal_bar), kp(acc_bar),
+            kp(weights_bar), _lib.ptr(sdf_bar), _lib.ptr(grad_bar), _lib.ptr(rgbs_bar), _lib.ptr(var_bar), _lib.ptr(bgd_bar), _lib.ptr(bgc_bar),
+            _lib.stream()), "neus_render_bg_backward")
+        del kp
+        return sdf_bar, grad_bar, rgbs_bar, var_bar, bgd_bar, bgc_bar, None, None, None, None, None, None
+
+
+def neus_render_bg(sdf, gradients, rgb, variance, bg_density, bg_rgb, origins, directions, starts, ends, cos_anneal_ratio: float,
+                   background: Optional[torch.Tensor] = None):
+    """neus_render + forward_background_field_and_merge (base_surface_model.py:266-290): samples that start outside the unit sphere take
+    the background field's alpha (from bg_density [N,S]) and colour (bg_rgb [N,S,3]).  Returns neus_render's tuple - `alpha` is the
+    merged alpha - plus the merged per-sample colour [N,S,3] (the reference's field_outputs[RGB]; carried for inspection, no gradient)."""
+    return _NeusRenderBg.apply(sdf, gradients, rgb, variance, bg_density, bg_rgb, origins.contiguous(), directions.contiguous(),
+                               starts.contiguous(), ends.contiguous(), background, cos_anneal_ratio)
+
+
 class _VolsdfRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sdf, grad, rgb, beta, starts, ends, background):

@@ -324,3 +324,60 @@ def test_northstar_bars_config5_on_oracle_samples(device, step):
     assert int(hit.sum()) >= 16, "the case must have rays that hit something"
     bar("rendered depth", depth[hit.to(device)], ref["depth"][hit], depth64[hit])
     bar("rendered normal", normal, ref["normal"], normal64, atol=2e-6)
+
+
+@pytest.mark.parametrize("S,white", [(48, False), (130, True)])
+def test_neus_render_with_background_merge_fwd_bwd(device, S, white):
+    """renderers.neus_render_bg (get_alpha -> forward_background_field_and_merge -> get_weights_from_alphas -> the four renderers,
+    sdf_field.py:476-525, base_surface_model.py:256-310, in ONE launch each way) against the oracle's per-statement composition in fp64:
+    every output, and the gradients w.r.t. sdf, d sdf / dx, rgb, the variance, the background density and the background colour, with
+    every output carrying a cotangent.  Half of the samples start outside the unit sphere."""
+    from sdfstudio_amd.model_components.renderers import neus_render_bg
+
+    gen = torch.Generator().manual_seed(S)
+    n = 41
+    o, d, _ = O.synthetic_rays(n, seed=3)
+    o = o * 0.45
+    bins = torch.sort(torch.rand(n, S + 1, generator=gen) * 2.5 + 0.02, dim=-1)[0]
+    starts, ends = bins[:, :-1].contiguous(), bins[:, 1:].contiguous()
+    sdf = torch.randn(n, S, generator=gen) * 0.2
+    grad = torch.randn(n, S, 3, generator=gen)
+    rgb = torch.rand(n, S, 3, generator=gen)
+    var = torch.tensor([0.31])
+    bgd = torch.rand(n, S, generator=gen) * 6.0
+    bgc = torch.rand(n, S, 3, generator=gen)
+    background = torch.ones(3) if white else None
+    co = [torch.randn(n, 3, generator=gen), torch.randn(n, generator=gen), torch.randn(n, 3, generator=gen), torch.randn(n, generator=gen),
+          torch.randn(n, S, generator=gen) * 0.1]
+    leaves = [t.clone().double().requires_grad_(True) for t in (sdf, grad, rgb, var, bgd, bgc)]
+    rs, rg, rc, rv, rbd, rbc = leaves
+    pos = o.double()[:, None, :] + d.double()[:, None, :] * starts.double()[..., None]
+    inside = (pos.norm(dim=-1) < 1.0).double()
+    assert 0.1 < float(inside.mean()) < 0.9
+    deltas = (ends - starts).double()
+    alpha = O.neus_alpha(rs, rg, d.double(), deltas, O.neus_inv_s(rv), 0.4)
+    alpha = alpha * inside + (1 - inside) * (1.0 - torch.exp(-deltas * rbd))
+    col = rc * inside[..., None] + (1 - inside[..., None]) * rbc
+    w_ref, _ = O.weights_from_alphas(alpha)
+    rgb_ref, depth_ref, normal_ref, acc_ref = O.render(w_ref, col, torch.nn.functional.normalize(rg, dim=-1), starts.double(), ends.double(),
+                                                       None if background is None else background.double())
+    ((rgb_ref * co[0]).sum() + (depth_ref * co[1]).sum() + (normal_ref * co[2]).sum() + (acc_ref * co[3]).sum() + (w_ref * co[4]).sum()).backward()
+    got_leaves = [t.clone().to(device).requires_grad_(True) for t in (sdf, grad, rgb, var, bgd, bgc)]
+    out_rgb, depth, normal, acc, weights, a_got, merged = neus_render_bg(
+        got_leaves[0], got_leaves[1], got_leaves[2], got_leaves[3], got_leaves[4], got_leaves[5], o.to(device), d.to(device), starts.to(device),
+        ends.to(device), 0.4, None if background is None else background.to(device))
+    assert_close("alpha (merged)", a_got, alpha.float(), rtol=1e-5, atol=1e-6)
+    assert_close("weights", weights, w_ref.float(), rtol=1e-5, atol=1e-6)
+    assert_close("rgb", out_rgb, rgb_ref.float(), rtol=1e-5, atol=1e-6)
+    assert_close("depth", depth, depth_ref.float(), rtol=1e-5, atol=1e-6)
+    assert_close("normal", normal, normal_ref.float(), rtol=1e-5, atol=1e-6)
+    assert_close("accumulation", acc, acc_ref.float(), rtol=1e-5, atol=1e-6)
+    assert_close("merged colour", merged, col.float(), rtol=0, atol=0)
+    ((out_rgb * co[0].to(device)).sum() + (depth * co[1].to(device)).sum() + (normal * co[2].to(device)).sum() + (acc * co[3].to(device)).sum()
+     + (weights * co[4].to(device)).sum()).backward()
+    for name, a, b in zip(("sdf", "gradient", "rgb", "variance", "bg density", "bg colour"), got_leaves, leaves):
+        assert_close(f"d / d {name}", a.grad, b.grad.float(), rtol=2e-4, atol=1e-7, elem_rtol=float("inf"))
+    # outside samples: nothing reaches the SDF field's alpha inputs and colour; inside samples: nothing reaches the background's
+    out_m = (inside == 0).to(device)
+    assert float(got_leaves[0].grad[out_m].abs().max()) == 0.0 and float(got_leaves[2].grad[out_m].abs().max()) == 0.0
+    assert float(got_leaves[4].grad[~out_m].abs().max()) == 0.0 and float(got_leaves[5].grad[~out_m].abs().max()) == 0.0
