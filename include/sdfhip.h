@@ -202,6 +202,15 @@ int sdfhip_numfield_backward(const SdfHipField* f, const float* packed, const fl
                              float delta, void* workspace, const float* sdf_bar, const float* grad_bar, const float* rgb_bar,
                              const float* taps_bar, float* theta_bar, float* table_bar, float* emb_bar, sdfhip_stream_t stream);
 
+/* Small per-ray operators of the "grid" background field (fields/nerfacto_field.py:65-332, base_surface_model.py:181-187).
+ * sdfhip_sh4_embed: out [n_rays, 16 + emb_dim] = [tiny-cuda-nn SphericalHarmonics degree 4 of get_normalized_directions(dirs) = (dirs + 1) / 2
+ * (nerfacto_field.py:128-134,283-285) | emb [n_rays, emb_dim] or zeros (NULL)]: the per-ray inputs of the field's colour network.
+ * sdfhip_embedding_backward: backward of rows = weight[idx] (field_components/embedding.py): out [n_rows, dim] (overwritten) = sum of
+ * grad [n, dim] over the n with idx[n] == row (idx: int64 device tensor), fixed summation order, dim <= 64. */
+int sdfhip_sh4_embed(const float* dirs, const float* emb, int64_t n_rays, int32_t emb_dim, float* out, sdfhip_stream_t stream);
+int sdfhip_embedding_backward(const int64_t* idx, const float* grad, int64_t n, int32_t dim, int64_t n_rows, float* out,
+                              sdfhip_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------- proposal density field
  * Replaces nerfstudio.fields.density_fields.HashMLPDensityField.get_density / density_fn (:99-118; base_field.py:48-65):
  * L-inf contraction of the frustum MIDPOINT, (x+2)/4, tcnn HashGrid(5 levels, F=2, linear) + FullyFusedMLP(16, ReLU,

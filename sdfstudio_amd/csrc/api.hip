@@ -1244,6 +1244,73 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ small per-ray operators of the "grid" background
+// tiny-cuda-nn's SphericalHarmonics encoding of degree 4 (16 real harmonics; oracle/sdf_path.py::sh_degree4 is the statement it is held
+// to) of the view direction as fields/nerfacto_field.py:128-134,283-285 feeds it - get_normalized_directions(d) = (d + 1) / 2, mapped back
+// to [-1, 1] inside - next to the per-ray appearance embedding: the colour kernel's per-ray slots [SH(16) | emb] in one launch.
+__global__ void sh4_embed_kernel(const float* __restrict__ dirs, const float* __restrict__ emb, const int64_t n, const int emb_dim,
+                                 float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) v[d] = __fsub_rn(__fmul_rn(__fdiv_rn(__fadd_rn(dirs[i * 3 + d], 1.0f), 2.0f), 2.0f), 1.0f);
+  const float x = v[0], y = v[1], z = v[2];
+  const float xy = x * y, xz = x * z, yz = y * z, x2 = x * x, y2 = y * y, z2 = z * z;
+  float* o = out + i * (16 + emb_dim);
+  o[0] = 0.28209479177387814f;
+  o[1] = -0.48860251190291987f * y;
+  o[2] = 0.48860251190291987f * z;
+  o[3] = -0.48860251190291987f * x;
+  o[4] = 1.0925484305920792f * xy;
+  o[5] = -1.0925484305920792f * yz;
+  o[6] = 0.94617469575755997f * z2 - 0.31539156525251999f;
+  o[7] = -1.0925484305920792f * xz;
+  o[8] = 0.54627421529603959f * x2 - 0.54627421529603959f * y2;
+  o[9] = 0.59004358992664352f * y * (-3.0f * x2 + y2);
+  o[10] = 2.8906114426405538f * xy * z;
+  o[11] = 0.45704579946446572f * y * (1.0f - 5.0f * z2);
+  o[12] = 0.3731763325901154f * z * (5.0f * z2 - 3.0f);
+  o[13] = 0.45704579946446572f * x * (1.0f - 5.0f * z2);
+  o[14] = 1.4453057213202769f * z * (x2 - y2);
+  o[15] = 0.59004358992664352f * x * (-x2 + 3.0f * y2);
+  for (int j = 0; j < emb_dim; ++j) o[16 + j] = emb != nullptr ? emb[i * emb_dim + j] : 0.0f;
+}
+extern "C" int sdfhip_sh4_embed(const float* dirs, const float* emb, int64_t n_rays, int32_t emb_dim, float* out, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(dirs && out && emb_dim >= 0 && n_rays >= 0, "sh4_embed: bad argument");
+  if (n_rays == 0) return 0;
+  sh4_embed_kernel<<<(unsigned)((n_rays + 255) / 256), 256, 0, (hipStream_t)stream>>>(dirs, emb, n_rays, emb_dim, out);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// Backward of an embedding lookup rows = weight[idx] (field_components/embedding.py; per-camera appearance embeddings, 49 rows x 32):
+// out[r] = sum over the n with idx[n] == r of grad[n], one block per table row, a FIXED summation order (torch's
+// embedding_backward_feature_kernel: 0.11 ms per call and atomics).  out is overwritten.
+__global__ void embedding_backward_kernel(const int64_t* __restrict__ idx, const float* __restrict__ grad, const int64_t n, const int dim,
+                                          float* __restrict__ out) {
+  const int64_t row = blockIdx.x;
+  __shared__ float red[8][64];
+  const int c = threadIdx.x & 63, g = threadIdx.x >> 6;  // 8 groups of 64 columns
+  float s = 0.0f;
+  for (int64_t i = g; i < n; i += 8)
+    if (idx[i] == row && c < dim) s += grad[i * dim + c];
+  red[g][c] = s;
+  __syncthreads();
+  if (g == 0 && c < dim) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) s += red[k][c];
+    out[row * dim + c] = s;
+  }
+}
+extern "C" int sdfhip_embedding_backward(const int64_t* idx, const float* grad, int64_t n, int32_t dim, int64_t n_rows, float* out,
+                                         sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(idx && grad && out && dim >= 1 && dim <= 64 && n_rows >= 1 && n >= 0, "embedding_backward: bad argument (dim <= 64)");
+  embedding_backward_kernel<<<(unsigned)n_rows, 512, 0, (hipStream_t)stream>>>(idx, grad, n, dim, out);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ numerical-gradient field, one operator
 // SDFField.get_outputs with use_numerical_gradients (sdf_field.py:629-655; neus-facto-angelo, BASELINE config 5) as ONE forward and ONE
 // backward call: the geometry network on the P contracted sample positions and their six taps (7 P points, tap-major: the centre points

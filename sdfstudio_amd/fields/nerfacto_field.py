@@ -71,6 +71,25 @@ def sh_degree4(d: torch.Tensor) -> torch.Tensor:
     ], dim=-1)
 
 
+class _ShEmbed(torch.autograd.Function):
+    """[SH degree 4 of (d + 1) / 2 | appearance embedding] per ray: the per-ray inputs of the field's colour network in one native
+    launch (sdfhip_sh4_embed); sh_degree4 above is the same statement in torch ops (~40 launches)."""
+
+    @staticmethod
+    def forward(ctx, dirs, emb, emb_dim):
+        lib = _lib.load()
+        n = dirs.shape[0]
+        out = torch.empty(n, 16 + emb_dim, device=dirs.device)
+        emb_c = None if emb is None else emb.contiguous()
+        _lib.check(lib.sdfhip_sh4_embed(_lib.ptr(dirs), _lib.ptr(emb_c), n, emb_dim, _lib.ptr(out), _lib.stream()), "sh4_embed")
+        del emb_c
+        return out
+
+    @staticmethod
+    def backward(ctx, out_bar):
+        return None, (out_bar[:, 16:] if ctx.needs_input_grad[1] else None), None
+
+
 class _TruncExp(torch.autograd.Function):
     """field_components/activations.py:23-39: exp forward, gradient exp(clamp(x, -15, 15))."""
 
@@ -142,19 +161,34 @@ class TCNNNerfactoField(nn.Module):
                   (hidden_dim_color, hidden_dim_color), (3, hidden_dim_color)]
         self._native = NativeBackgroundNet(cfg_c, self._gf_pad, e_dim, expect)
 
-    def _theta(self) -> torch.Tensor:
-        """Flat parameter vector in the library's layout (differentiable torch indexing).  tcnn's FullyFusedMLP has no biases: they
-        are zeros here and their gradients are dropped."""
+    def _theta_layout(self) -> torch.Tensor:
+        """The library's flat parameter vector as cat() statements over the field's tensors (tcnn's FullyFusedMLP has no biases: they are
+        zeros here and their gradients are dropped).  Evaluated ONCE, on tagged stand-ins, to learn where every parameter element lands."""
         b, h = self.mlp_base, self.mlp_head
-        dev, dt = b.w1.device, b.w1.dtype
-        z = lambda *shape: torch.zeros(*shape, device=dev, dtype=dt)  # noqa: E731
         H, HC, G, GP, E = b.w1.shape[0], h.w1.shape[0], self.geo_feat_dim, self._gf_pad, self.appearance_embedding_dim
-        parts = [torch.cat([z(H, 3), b.w1], dim=1).reshape(-1), z(H),
-                 torch.cat([b.w2, z(1 + GP - b.w2.shape[0], H)], dim=0).reshape(-1), z(1 + GP),
+        tags, off = {}, 0
+        for name, t in (("bw1", b.w1), ("bw2", b.w2), ("hw1", h.w1), ("hw2", h.w2), ("hw3", h.w3)):
+            tags[name] = torch.arange(off, off + t.numel(), dtype=torch.int64).view_as(t)
+            off += t.numel()
+        z = lambda *shape: torch.full(shape, off, dtype=torch.int64)  # noqa: E731  ("off" = the slot of an appended zero)
+        bw1, bw2, hw1, hw2, hw3 = (tags[k] for k in ("bw1", "bw2", "hw1", "hw2", "hw3"))
+        parts = [torch.cat([z(H, 3), bw1], dim=1).reshape(-1), z(H),
+                 torch.cat([bw2, z(1 + GP - bw2.shape[0], H)], dim=0).reshape(-1), z(1 + GP),
                  # colour layer 0 columns: x(3) d-PE(27) normal(3) [all unused] | features (GP) | embedding slots = SH(16) + appearance (E)
-                 torch.cat([z(HC, 33), h.w1[:, 16:16 + G], z(HC, GP - G), h.w1[:, :16], h.w1[:, 16 + G:16 + G + E]], dim=1).reshape(-1), z(HC),
-                 h.w2.reshape(-1), z(HC), h.w3.reshape(-1), z(3)]
+                 torch.cat([z(HC, 33), hw1[:, 16:16 + G], z(HC, GP - G), hw1[:, :16], hw1[:, 16 + G:16 + G + E]], dim=1).reshape(-1), z(HC),
+                 hw2.reshape(-1), z(HC), hw3.reshape(-1), z(3)]
         return torch.cat(parts)
+
+    def _theta(self) -> torch.Tensor:
+        """Flat parameter vector in the library's layout: ONE concatenation of the five weight tensors (plus a zero) and ONE gather
+        through the index map of _theta_layout - the cat-of-cats statement itself cost ~60 small launches per step with its backward."""
+        b, h = self.mlp_base, self.mlp_head
+        dev = b.w1.device
+        if getattr(self, "_theta_src", None) is None or self._theta_src.device != dev:
+            self._theta_src = self._theta_layout().to(dev)
+            self._theta_zero = torch.zeros(1, device=dev, dtype=b.w1.dtype)
+        flat = torch.cat([b.w1.reshape(-1), b.w2.reshape(-1), h.w1.reshape(-1), h.w2.reshape(-1), h.w3.reshape(-1), self._theta_zero])
+        return flat.index_select(0, self._theta_src)
 
     def get_density(self, ray_samples):
         """:225-246: contracted frustum MID points -> (x + 2) / 4 -> hash grid -> MLP -> trunc_exp of the first output.  The second
@@ -187,14 +221,14 @@ class TCNNNerfactoField(nn.Module):
         feat, theta, x = density_embedding
         _, d, st, _ = unpack_ray_samples(ray_samples)
         n, s = st.shape
-        sh = sh_degree4((d + 1.0) / 2.0)  # get_normalized_directions; per ray
         if self.training:
             emb = self.embedding_appearance(ray_samples.camera_indices.reshape(n, -1)[:, 0])
         elif self.use_average_appearance_embedding:
             emb = self.embedding_appearance.mean(dim=0)[None, :].expand(n, -1)
         else:
-            emb = torch.zeros(n, self.appearance_embedding_dim, device=d.device)
-        rgb = _ColorFunction.apply(theta, feat, torch.zeros_like(x), torch.cat([sh, emb], dim=-1), self._native, x, d.contiguous(), n, s)
+            emb = None  # zeros
+        slots = _ShEmbed.apply(d.contiguous(), emb, self.appearance_embedding_dim)  # [SH(get_normalized_directions(d)) | emb]: one launch
+        rgb = _ColorFunction.apply(theta, feat, torch.zeros_like(x), slots, self._native, x, d.contiguous(), n, s)
         return {FieldHeadNames.RGB: rgb.view(n, s, 3)}
 
     def forward(self, ray_samples) -> Dict:

@@ -107,6 +107,30 @@ class _HashTable(nn.Module):
         self.params = nn.Parameter((torch.rand(n_entries * grid_cfg.n_features) * 2 - 1) * 1e-4)
 
 
+class _EmbeddingLookup(torch.autograd.Function):
+    """rows = weight[idx] with a native, deterministic backward (sdfhip_embedding_backward: one block per table row, fixed summation
+    order) written straight into the parameter's gradient slot - torch's embedding_backward_feature_kernel costs 0.11 ms per call for a
+    49 x 32 table and accumulates with atomics."""
+
+    @staticmethod
+    def forward(ctx, weight, idx):
+        idx = idx.reshape(-1).long().contiguous()
+        ctx.save_for_backward(idx)
+        ctx.weight_param, ctx.shape = weight, tuple(weight.shape)
+        return weight.detach().index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, rows_bar):
+        (idx,) = ctx.saved_tensors
+        lib = _lib.load()
+        out = grad_target(ctx.weight_param)[0]  # every row is written: no zero fill needed
+        g = rows_bar.contiguous()
+        _lib.check(lib.sdfhip_embedding_backward(ctypes.c_void_p(idx.data_ptr()), _lib.ptr(g), idx.numel(), ctx.shape[1], ctx.shape[0],
+                                                 _lib.ptr(out), _lib.stream()), "embedding_backward")
+        del g
+        return out, None
+
+
 class _Embedding(nn.Module):
     """field_components/embedding.py: appearance embedding table."""
 
@@ -121,7 +145,10 @@ class _Embedding(nn.Module):
         return self.embedding.weight.mean(dim)
 
     def forward(self, idx):
-        return self.embedding(idx)
+        w = self.embedding.weight
+        if w.is_cuda and w.dtype == torch.float32 and w.shape[1] <= 64 and idx.dim() == 1:
+            return _EmbeddingLookup.apply(w, idx)
+        return self.embedding(idx)  # host-side inspection (CPU tensors) and unusual shapes
 
 
 def _contig(t):
