@@ -167,13 +167,16 @@ __global__ __launch_bounds__(256) void geo_encode_kernel(const EncodeArgs a) {
   const bool live = p < a.n_points;
   float x[3] = {0.f, 0.f, 0.f};
   if (live) encode_position(a, p, x);
-  // blockIdx.y = level * (F / 2) + feature pair; the last y is the position / positional-encoding block.  An F-feature level is
-  // F / 2 two-feature gathers that share the cell (hash_features_per_level = 8 in the neus-facto-angelo preset).
+  // An F-feature level is F / 2 two-feature gathers that share the cell (hash_features_per_level = 8 in the neus-facto-angelo preset:
+  // geo_encode8_kernel below).
+  // blockIdx.y = 0: the position / positional-encoding block (36 sinf per point: the longest blocks of the launch - scheduled FIRST, they
+  // overlap with the gathers instead of forming its tail); y - 1 = level * (F / 2) + feature pair
   const int L = a.grid.n_levels, F = a.grid.n_features, pairs = F >> 1;
-  const int level = blockIdx.y / pairs, pair = blockIdx.y % pairs;
+  const int yy = (int)blockIdx.y - 1;
+  const int level = yy / pairs, pair = yy % pairs;
   const int pe_dims = 6 * a.pe_degree;
   const int feat0 = 3 + pe_dims;
-  if ((int)blockIdx.y == L * pairs) {
+  if (yy < 0) {
     // position + positional encoding + zero padding  (encodings.py:167-208: sin(cat[x f, x f + pi/2]))
     a.x_out[p * 3 + 0] = x[0];
     a.x_out[p * 3 + 1] = x[1];
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(256) void geo_encode_kernel(const EncodeArgs a) {
 // ---- 8 features per entry (BASELINE config 5): one block gathers WHOLE 32-byte entries (two 16-byte loads per corner) and produces all 8
 // features of a level.  With one feature pair per block (above) the four pair-blocks of a level visit every entry again, each for 8 of
 // its 32 bytes: on a 2.1 GB table those visits are HBM sectors fetched four times (PMC: 7.3 GB per step for 3.4 GB of entries).
-// grid = (n_padded / 256, n_levels + 1), block = 256; the last y writes position / positional encoding / padding like the kernel above.
+// grid = (n_padded / 256, n_levels + 1), block = 256; y = 0 writes position / positional encoding / padding like the kernel above.
 __global__ __launch_bounds__(256) void geo_encode8_kernel(const EncodeArgs a) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= a.n_padded) return;
@@ -241,10 +244,10 @@ __global__ __launch_bounds__(256) void geo_encode8_kernel(const EncodeArgs a) {
   float x[3] = {0.f, 0.f, 0.f};
   if (live) encode_position(a, p, x);
   const int L = a.grid.n_levels;
-  const int level = blockIdx.y;
+  const int level = (int)blockIdx.y - 1;  // y = 0: the position / positional-encoding block, first (see geo_encode_kernel)
   const int pe_dims = 6 * a.pe_degree;
   const int feat0 = 3 + pe_dims;
-  if (level == L) {
+  if (level < 0) {
     a.x_out[p * 3 + 0] = x[0];
     a.x_out[p * 3 + 1] = x[1];
     a.x_out[p * 3 + 2] = x[2];

@@ -33,6 +33,7 @@ Protocol per step: ``zero(loss)`` -> one backward of that loss -> ``finish()``. 
 local sums.  (``zero()`` without the loss keeps the conservative count - every parameter pending - which is correct and overlaps only
 when every parameter of a bucket receives a gradient.)
 """
+import os
 import time
 from typing import Dict, Iterable, List, Optional, Sequence
 
@@ -40,6 +41,9 @@ import torch
 import torch.distributed as dist
 
 from sdfstudio_amd.grad_slots import CLAIM_ATTR, SLOT_ATTR  # noqa: F401
+
+
+_DEBUG_LIVE = os.environ.get("SDFHIP_DEBUG_GRADS") == "1"
 
 
 def _dist_on(group=None) -> bool:
@@ -298,6 +302,14 @@ class FlatGradients:
                 v = self._view(p)  # stray gradient of a parameter whose hook never fired (grad set by hand): fold it in
                 v.add_(p.grad)
                 p.grad = v
+        if _DEBUG_LIVE:  # SDFHIP_DEBUG_GRADS=1: nothing may have been written beyond a never-active suffix (it is neither zeroed,
+            for p in self.params:  # exchanged nor stepped: a level switched on without widening the restriction would pile up there)
+                n = self._hwm.get(id(p))
+                if n is not None and n < p.numel():
+                    off = self._offset[id(p)]
+                    if float(self.flat[off + n:off + p.numel()].abs().max()) != 0.0:
+                        raise RuntimeError("FlatGradients: gradient beyond the active prefix of a parameter (set_active_numel / track_active "
+                                           "was not widened before a level was switched on)")
         for bi in range(self._next, len(self._buckets)):
             self._launch(bi)
         scale = 1.0
