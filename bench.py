@@ -516,7 +516,8 @@ def run(args):
                        "frac": round(eb / es / 1e9 / PEAK_HBM_GBS, 4), "algorithmic_bytes": eb, "achieved_is": what + " / its time per step",
                        "ms_per_step": round(enc_ms / args.steps, 4), "traffic": None}
             for f in sorted((f for f in os.listdir(pm_dir) if f.endswith("_pmc_summary.csv")), reverse=True):
-                if ("cfg5" in f) != cfg5:
+                # evidence tags: <round>_cfg5 (8 levels), <round>_cfg5l16 (steady state); everything else is config 2
+                if ("cfg5" in f) != cfg5 or (cfg5 and ("cfg5l16" in f) != (args.levels == 16)):
                     continue
                 import csv
 
@@ -579,7 +580,8 @@ def run(args):
         # bound by, the issued 16-bit MFMA terms (3 per product in every pass) against the dense bf16 / fp16 peak, and the whole
         # step's HBM bytes from the committed PMC passes
         step_bytes, step_digest = None, None
-        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_step_traffic.json") and ("cfg5" in f) == cfg5)
+        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_step_traffic.json") and ("cfg5" in f) == cfg5
+                       and (not cfg5 or ("cfg5l16" in f) == (args.levels == 16)))
         if cands:
             with open(os.path.join(ROOT, "profiles", cands[-1])) as fh:
                 sj = json.load(fh)

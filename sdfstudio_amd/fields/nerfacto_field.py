@@ -161,6 +161,14 @@ class TCNNNerfactoField(nn.Module):
                   (hidden_dim_color, hidden_dim_color), (3, hidden_dim_color)]
         self._native = NativeBackgroundNet(cfg_c, self._gf_pad, e_dim, expect)
 
+    def _const(self, name: str, shape, value: float, device) -> torch.Tensor:
+        """Constant device tensors the kernels read every step (level mask of ones, the unused normal input): built once per shape."""
+        cache = self.__dict__.setdefault("_const_cache", {})
+        key = (name, tuple(shape), str(device))
+        if key not in cache:
+            cache[key] = torch.full(tuple(shape), float(value), device=device)
+        return cache[key]
+
     def _theta_layout(self) -> torch.Tensor:
         """The library's flat parameter vector as cat() statements over the field's tensors (tcnn's FullyFusedMLP has no biases: they are
         zeros here and their gradients are dropped).  Evaluated ONCE, on tagged stand-ins, to learn where every parameter element lands."""
@@ -205,7 +213,7 @@ class TCNNNerfactoField(nn.Module):
         if not x.is_cuda:
             raise _lib.SdfHipError("TCNNNerfactoField runs on the sdfhip kernels: HIP device tensors required (no CPU fallback)")
         theta = self._theta()
-        mask = torch.ones(self.grid_cfg.n_levels * self.grid_cfg.n_features, device=x.device)
+        mask = self._const("mask", (self.grid_cfg.n_levels * self.grid_cfg.n_features,), 1.0, x.device)
         pre, feat = _GeoNetFunction.apply(theta, self.mlp_base.table, self._native, x, mask)
         density = _TruncExp.apply(pre.view(*shape, 1))
         return density, (feat, theta, x)
@@ -228,7 +236,8 @@ class TCNNNerfactoField(nn.Module):
         else:
             emb = None  # zeros
         slots = _ShEmbed.apply(d.contiguous(), emb, self.appearance_embedding_dim)  # [SH(get_normalized_directions(d)) | emb]: one launch
-        rgb = _ColorFunction.apply(theta, feat, torch.zeros_like(x), slots, self._native, x, d.contiguous(), n, s)
+        # the colour kernel's normal input is unused by this field (zero weight columns): a cached zero block, not a fill per call
+        rgb = _ColorFunction.apply(theta, feat, self._const("zero_normal", tuple(x.shape), 0.0, x.device), slots, self._native, x, d.contiguous(), n, s)
         return {FieldHeadNames.RGB: rgb.view(n, s, 3)}
 
     def forward(self, ray_samples) -> Dict:
