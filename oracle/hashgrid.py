@@ -130,21 +130,25 @@ def level_cell(x: torch.Tensor, lv: GridLevels, lvl: int):
 
 
 def grid_encode(x: torch.Tensor, table: torch.Tensor, lv: GridLevels) -> torch.Tensor:
-    """x: [P,3] in [0,1]; table: [n_entries, F]; returns [P, L*F].  The 8 L corner entries of every point are fetched by ONE
-    indexing operation: autograd then builds one table-sized gradient per call instead of one per (level, corner) - what makes the
-    2.1 GB table of BASELINE config 5 affordable on the host; the blend below is the same sequence of operations either way."""
+    """x: [P,3] in [0,1]; table: [n_entries, F]; returns [P, L*F].  The blend is the same sequence of operations for every table; how
+    the corner entries are FETCHED depends on the table's size: one indexing operation per (level, corner) normally (fastest on the
+    host: bench.py times this function as its CPU baseline), ONE indexing operation for all 8 L corners when the table is huge -
+    autograd builds a table-sized gradient per indexing operation, and 128 of them for the 2.1 GB table of BASELINE config 5 would
+    cost minutes where one costs seconds."""
     cells = [level_cell(x, lv, lvl) for lvl in range(lv.n_levels)]
-    idx_all = torch.stack([c[0] for c in cells], dim=1)  # [P, L, 8]
-    vals = table[idx_all.reshape(-1)].view(x.shape[0], lv.n_levels, 8, table.shape[-1])
+    one_gather = table.numel() > (1 << 27)
+    if one_gather:
+        idx_all = torch.stack([c[0] for c in cells], dim=1)  # [P, L, 8]
+        vals = table[idx_all.reshape(-1)].view(x.shape[0], lv.n_levels, 8, table.shape[-1])
     outs: List[torch.Tensor] = []
     for lvl in range(lv.n_levels):
-        w = cells[lvl][1]
+        idx, w = cells[lvl]
         acc = 0.0
         for corner in range(8):
             bx, by, bz = corner & 1, (corner >> 1) & 1, (corner >> 2) & 1
             wx = w[:, 0] if bx else 1.0 - w[:, 0]
             wy = w[:, 1] if by else 1.0 - w[:, 1]
             wz = w[:, 2] if bz else 1.0 - w[:, 2]
-            acc = acc + (wx * wy * wz)[:, None] * vals[:, lvl, corner]
+            acc = acc + (wx * wy * wz)[:, None] * (vals[:, lvl, corner] if one_gather else table[idx[:, corner]])
         outs.append(acc)
     return torch.cat(outs, dim=-1)

@@ -647,9 +647,33 @@ class SDFField(nn.Module):
     def _numerical_outputs(self, ray_samples, o, d, st, emb):
         """get_outputs with use_numerical_gradients (sdf_field.py:629-655): geometry network at the contracted start positions and at the
         six taps, finite-difference normal, colour network on it - one native operator each way (_NumericalFieldFunction)."""
+        if self.config.hidden_dim > 256:
+            return self._numerical_outputs_composed(o, d, st, emb)  # layer-at-a-time (512-wide) kernels: not wired into the fused operator
         sdf, grad, rgb, taps, x = _NumericalFieldFunction.apply(self._theta(), self.encoding.params, emb, self, o, d, st, self._mask(o.device),
                                                                 self.numerical_gradients_delta)
         return sdf, grad, rgb, x, taps  # taps [N,S,6]: `sampled_sdf` (:644)
+
+    def _numerical_outputs_composed(self, o, d, st, emb):
+        """The same computation composed of the first-order operators (_GeoNetFunction on the 7 P points, torch finite differences,
+        _ColorFunction): the path of round 3, kept for kernel families the fused operator does not cover (hidden width 512)."""
+        n, s = st.shape
+        pos = (o[:, None, :] + d[:, None, :] * st[..., None]).reshape(-1, 3)
+        x = _contract_inf(pos, self.spatial_distortion.order) if self.spatial_distortion is not None else pos
+        P = x.shape[0]
+        delta = self.numerical_gradients_delta
+        pts = torch.cat([x[None], x[None, :, :] + self._tap_offsets(x)[:, None, :]], dim=0).reshape(-1, 3)
+        if torch.is_grad_enabled():  # sdfhip_geo_forward takes positions as given (contracted on the host above)
+            sdf_all, feat = _GeoNetFunction.apply(self._theta(), self.encoding.params, self, pts.detach().contiguous().float(),
+                                                  self._mask(x.device), P)
+        else:
+            h = self.forward_geonetwork(pts)
+            sdf_all, feat = h[:, 0], h[:P, 1:]
+        sdf = sdf_all[:P]
+        taps = sdf_all[P:].view(6, P)
+        grad = torch.stack([0.5 * (taps[0] - taps[1]) / delta, 0.5 * (taps[2] - taps[3]) / delta, 0.5 * (taps[4] - taps[5]) / delta], dim=-1)
+        rgb = _ColorFunction.apply(self._theta(), feat, grad, emb, self, x.detach(), d, n, s)
+        sampled_sdf = taps.view(6, n, s).permute(1, 2, 0).contiguous()  # :644
+        return sdf.view(n, s), grad.view(n, s, 3), rgb.view(n, s, 3), x.detach().view(n, s, 3), sampled_sdf
 
     def get_density(self, ray_samples):
         """sdf_field.py:469-475: Laplace density and geometry feature at the frustum START positions (no contraction, no grad)."""
