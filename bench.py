@@ -115,9 +115,10 @@ def build_model_config5(device):
     return NeuSFactoModel(mcfg, box, num_train_data=49).to(device).train()
 
 
-def build_model(device, small=False):
+def build_model(device, small=False, hidden=256, samples=None):
     """BASELINE config 2 (default), or the small parity configuration of tests/golden (8x64 networks, 8x2x2^11 grid, 32/24
-    proposal + 16 field samples): the latter only drives the N > 1 control-flow test, never a reported number."""
+    proposal + 16 field samples): the latter only drives the N > 1 control-flow test, never a reported number.  hidden = 512: the
+    geometry network of the neus-facto-bigmlp preset (method_configs.py:503-523) in config 2's model."""
     from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
     from sdfstudio_amd.models.neus_facto import NeuSFactoModel, NeuSFactoModelConfig, SceneBox
 
@@ -130,10 +131,10 @@ def build_model(device, small=False):
                                     background_model="none")
         box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=0.5, far=4.5)
         return NeuSFactoModel(mcfg, box, num_train_data=49).to(device).train()
-    fcfg = SDFFieldConfig(num_layers=8, hidden_dim=256, geo_feat_dim=256, num_layers_color=4, hidden_dim_color=256, bias=0.5,
+    fcfg = SDFFieldConfig(num_layers=8, hidden_dim=hidden, geo_feat_dim=256, num_layers_color=4, hidden_dim_color=256, bias=0.5,
                           inside_outside=False, use_grid_feature=True, beta_init=0.3, num_levels=16, max_res=2048, base_res=16,
                           log2_hashmap_size=19, hash_features_per_level=2, hash_smoothstep=True)
-    mcfg = NeuSFactoModelConfig(sdf_field=fcfg, num_proposal_samples_per_ray=(256, 96), num_neus_samples_per_ray=N_SAMPLES,
+    mcfg = NeuSFactoModelConfig(sdf_field=fcfg, num_proposal_samples_per_ray=(256, 96), num_neus_samples_per_ray=samples or N_SAMPLES,
                                 background_model="none")
     box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=0.5, far=4.5)
     return NeuSFactoModel(mcfg, box, num_train_data=49).to(device).train()
@@ -215,6 +216,7 @@ def main():
                          "(steps 0 .. 80 k of its 1 M iterations), 16 = the steady state (steps >= 150 k: 85 %% of the schedule); the timed steps "
                          "start at step 5 resp. 200 000 of the preset's schedules")
     ap.add_argument("--no-config5", action="store_true", help="default (config 2) run: skip the two short config-5 legs appended as \"config5\"")
+    ap.add_argument("--no-bigmlp", action="store_true", help="default (config 2) run: skip the two short 512-wide legs appended as \"bigmlp\"")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--small", action="store_true", help="small parity configuration (control-flow tests only, not a benchmark)")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the second (untimed) pass that times every launch")
@@ -239,15 +241,15 @@ def fence(world):
     torch.cuda.synchronize()
 
 
-def make_job(config, device, world, rank, small=False):
+def make_job(config, device, world, rank, small=False, hidden=256, rays=None, samples=None):
     """Model, flat gradient buffer, optimizers and the step function of one benchmark configuration (2 or 5) on this rank."""
     from sdfstudio_amd.cameras.rays import RayBundle
     from sdfstudio_amd.distributed import FlatGradients, broadcast_parameters
     from sdfstudio_amd.engine.optimizers import Optimizers, multi_step_scheduler, multi_step_warmup_scheduler, neus_scheduler
 
     cfg5 = config == 5
-    n_rays = 2048 if cfg5 else (512 if small else 4096)  # method_configs.py:396 train_num_rays_per_batch (config 5)
-    model = build_model_config5(device) if cfg5 else build_model(device, small=small)
+    n_rays = rays or (2048 if cfg5 else (512 if small else 4096))  # method_configs.py:396 train_num_rays_per_batch (config 5)
+    model = build_model_config5(device) if cfg5 else build_model(device, small=small, hidden=hidden, samples=samples)
     broadcast_parameters(model)
     groups = {k: v for k, v in model.get_param_groups().items() if v}  # "field_background" is empty with background_model="none"
     # one flat gradient buffer; one exchange bucket per parameter group, all-reduced (RCCL) as soon as backward has produced it
@@ -297,7 +299,7 @@ def timed_steps(job, first, warmup, steps, dominant, world):
     for i in range(warmup):
         step(first + i)
     fence(world)
-    _lib.profile_enable_only([dominant])
+    _lib.profile_enable_only([dominant] if isinstance(dominant, str) else list(dominant))
     t0 = time.perf_counter()
     for i in range(steps):
         loss = step(first + warmup + i)
@@ -356,6 +358,38 @@ def config5_legs(device, world, rank, steps=10, warmup=3):
                      "roofline": encode_roofline_config5(job["model"], prof, steps, P)}
     del job
     torch.cuda.empty_cache()
+    return out
+
+
+def bigmlp_legs(device, world, rank, ms_config2, steps=8, warmup=3):
+    """The geometry network of the reference's neus-facto-bigmlp preset (8 x 512, method_configs.py:503-523; its own batch is 2048 rays x
+    48 samples) as two short legs of the default run: at the preset's batch and at config 2's (4096 x 128), the latter next to the
+    256-wide step just timed.  NOT a BASELINE config.  The 512-wide network runs LAYER BY LAYER (csrc/wide_kernels.h: two accumulator
+    sets of 16 blocks do not fit a wave); its step-level figure is the 16-bit MFMA terms the geometry + colour networks issue per step
+    (forward G, chain G, tangent G, data backward G, two weight-gradient sets 2G; 3 terms per product) over the step time."""
+    g = 2 * (71 * 512 + 2 * 512 * 512 + 512 * 441 + 4 * 512 * 512 + 512 * 257)
+    _, c = flops_per_sample()
+    out = {"workload": "neus-facto-bigmlp geometry network (8 x 512 softplus, skip at 4) in config 2's model (16x2x2^19 grid, 4x256 colour MLP, "
+                       "256/96 proposal samples), full train step incl. Adam; layer-at-a-time kernels (csrc/wide_kernels.h)",
+           "steps": steps, "warmup": warmup, "geo_flops_per_sample": g}
+    for name, rays, samples in (("preset_batch", 2048, 48), ("config2_batch", N_RAYS, N_SAMPLES)):
+        job = make_job(2, device, world, rank, hidden=512, rays=rays, samples=samples)
+        dt, prof, loss = timed_steps(job, 0, warmup, steps, ("geo_fwd_kernel", "geo_bwd_kernel", "wgrad_kernel"), world)
+        dt = max_over_ranks(dt, device, world)
+        assert math.isfinite(float(loss.detach())), f"bigmlp ({name}) diverged"
+        ms, P = dt / steps * 1e3, rays * samples
+        issued = 3 * (6 * g + 3 * c) * P / (dt / steps) / 1e12
+        out[name] = {"ms_per_step": round(ms, 3), "value": round(world * P / (dt / steps), 1), "unit": "ray-samples/s", "rays": rays,
+                     "samples_per_ray": samples,
+                     # HIP events on these launches inside the timed steps (the layer-at-a-time launches record under the fused kernels' slots)
+                     "kernels_ms_per_step": {k: round(v[0] / steps, 3) for k, v in prof.items()},
+                     "step_roofline": {"bound": "mfma", "achieved": round(issued, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": round(issued / PEAK_BF16_MFMA_TFLOPS, 4),
+                                       "achieved_is": "3 issued 16-bit MFMA terms x (6 G512 + 3 C) flops per ray-sample / whole step time"}}
+        if name == "config2_batch" and ms_config2:
+            out[name]["ratio_to_256_wide_step"] = round(ms / ms_config2, 3)
+        del job, loss
+        torch.cuda.empty_cache()
     return out
 
 
@@ -448,6 +482,10 @@ def run(args):
     if not cfg5 and not args.small and not args.no_config5:
         del loss  # the last step's graph (and its 25 GB field workspace) goes back to the allocator
         cfg5_extra = config5_legs(device, world, rank)
+    bigmlp_extra = None
+    if not cfg5 and not args.small and not args.no_bigmlp:
+        loss = None
+        bigmlp_extra = bigmlp_legs(device, world, rank, dt / args.steps * 1e3)
 
     if rank == 0:
         from sdfstudio_amd import build as _build
@@ -559,6 +597,7 @@ def run(args):
             "roofline": roof,
             "encode_roofline": enc,
             "config5": cfg5_extra,
+            "bigmlp": bigmlp_extra,
             "collective": None if world == 1 else {"backend": dist.get_backend(), "buckets": len(groups),
                                                     "bytes_per_step_per_rank": 4 * flat.exchanged_numel(),
                                                     "collectives_per_step": flat.last_collectives,

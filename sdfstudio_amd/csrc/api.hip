@@ -709,16 +709,26 @@ static void run_wgrad(const SdfHipField* f, const FieldWs& w, const WgradArgs& b
   a.bpartial = b_off >= 0 ? w.bpartial : nullptr;
   {
     ProfScope ps_(PS_WGRAD, s);
-    for (int ob = 0; ob < a.nba; ob += 8)
-      for (int ib = 0; ib < a.nbb; ib += 8) {
-        a.ob_base = ob;
-        a.ib_base = ib;
-        const int rows = std::min(8, a.nba - ob), cols = std::min(8, a.nbb - ib);
-        // weight-gradient products: split-bf16 (3 bf16 MFMAs per product, fp32 accumulate) on the 8-wave double-buffered kernel
-        WgradKernelFn fn = wgrad8_pick((rows + 3) / 4, (cols + 1) / 2);
-        (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, kW8LdsBytes);
-        hipLaunchKernelGGL(fn, dim3((unsigned)w.n_split), dim3(512), kW8LdsBytes, s, a);
-      }
+    a.n_split = w.n_split;
+    a.quad = 0;
+    if (a.nba == 16 && a.nbb == 16 && w.n_split % 8 == 0) {
+      // hidden 512: the four 256 x 256 macro tiles in one launch, interleaved so that they share their operand reads in L2 (WgradArgs::quad)
+      a.quad = 1;
+      WgradKernelFn fn = wgrad8_pick(2, 4);
+      (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, kW8LdsBytes);
+      hipLaunchKernelGGL(fn, dim3(4u * (unsigned)w.n_split), dim3(512), kW8LdsBytes, s, a);
+    } else {
+      for (int ob = 0; ob < a.nba; ob += 8)
+        for (int ib = 0; ib < a.nbb; ib += 8) {
+          a.ob_base = ob;
+          a.ib_base = ib;
+          const int rows = std::min(8, a.nba - ob), cols = std::min(8, a.nbb - ib);
+          // weight-gradient products: split-bf16 (3 bf16 MFMAs per product, fp32 accumulate) on the 8-wave double-buffered kernel
+          WgradKernelFn fn = wgrad8_pick((rows + 3) / 4, (cols + 1) / 2);
+          (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, kW8LdsBytes);
+          hipLaunchKernelGGL(fn, dim3((unsigned)w.n_split), dim3(512), kW8LdsBytes, s, a);
+        }
+    }
   }
   WreduceArgs r;
   memset(&r, 0, sizeof(r));

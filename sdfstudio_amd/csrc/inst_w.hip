@@ -79,7 +79,7 @@ static void geo_bwd1(const GeoBwdArgs& a, unsigned grid, hipStream_t s) { bwd_im
 static void col_fwd(const ColFwdArgs& a, int save, unsigned grid, hipStream_t s) { sdfhip_kernels_A()->col_fwd(a, save, grid, s); }
 static void col_bwd(const ColBwdArgs& a, unsigned grid, hipStream_t s) { sdfhip_kernels_A()->col_bwd(a, grid, s); }
 static void sdfrow(const float* u, const float* q, const float* sb, int64_t nt, int tps, float* part, unsigned grid, hipStream_t s) {
-  sdfrow_grad_kernel<16><<<grid, 256, 0, s>>>(u, q, sb, nt, tps, part);
+  sdfrow_grad_kernel<16><<<dim3(grid, 2), 256, 0, s>>>(u, q, sb, nt, tps, part);  // two groups of 8 blocks
 }
 }  // namespace W_ns
 

@@ -96,6 +96,11 @@ struct WgradArgs {
   int32_t n_pairs;
   int32_t nba, nbb;      // total blocks of A (rows of C / 32) and B (cols of C / 32)
   int32_t ob_base, ib_base;  // first row / column block of the macro tile this launch computes
+  // quad != 0: ONE launch computes the 2 x 2 macro tiles of a 16 x 16-block C (hidden 512).  grid = 4 n_split; workgroup L works on macro
+  // tile (L >> 3) & 3 of point split ((L >> 5) << 3) | (L & 7): workgroups go to the 8 XCDs round-robin, so the four macro tiles of a
+  // split are resident TOGETHER on ONE XCD and stream the same point tiles at the same time - each operand block set (8 A or 8 B
+  // blocks) is read by two of them and the second read is an L2 hit.  As four launches, each streamed its 2 KiB per point from HBM.
+  int32_t quad, n_split;
   int64_t n_tiles;       // point tiles
   int32_t tiles_per_split;
   float* partial;        // [n_split][nba*32][nbb*32]
@@ -141,8 +146,9 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16x8_kernel(const WgradArgs a)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qi = wave >> 1, qj = wave & 1;  // row blocks qi + 4 i (i < NA), column blocks qj + 2 j (j < NB)
-  const int split = blockIdx.x;
-  const int ob_base = a.ob_base, ib_base = a.ib_base;
+  const int L = blockIdx.x, macro = (L >> 3) & 3;
+  const int split = a.quad ? (((L >> 5) << 3) | (L & 7)) : L;
+  const int ob_base = a.quad ? (macro >> 1) * 8 : a.ob_base, ib_base = a.quad ? (macro & 1) * 8 : a.ib_base;
 
   f32x16 acc[NA][NB];
 #pragma unroll
@@ -308,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_bf16x8_kernel(const WgradArgs a)
       if (qi + 4 * i < 8 && qj + 2 * j < 8 && ob < a.nba && ib < a.nbb) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          a.partial[wg_partial_index(split, (int)gridDim.x, ob * 32 + tp_row(r, hf), ib * 32 + (lane & 31), ldc)] = acc[i][j][r];
+          a.partial[wg_partial_index(split, a.n_split, ob * 32 + tp_row(r, hf), ib * 32 + (lane & 31), ldc)] = acc[i][j][r];
       }
     }
   if (a.bpartial != nullptr && ib_base == 0) {

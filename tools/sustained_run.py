@@ -60,7 +60,7 @@ def main():
     th.start()
     time.sleep(1.0)  # idle samples first
     t0 = time.time()
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "20", "--no-cpu-baseline", "--no-forward-only", "--no-kernel-table"] + extra
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", "20", "--no-cpu-baseline", "--no-forward-only", "--no-kernel-table", "--no-config5", "--no-bigmlp"] + extra
     res = subprocess.run(cmd, capture_output=True, text=True)
     t1 = time.time()
     time.sleep(1.0)

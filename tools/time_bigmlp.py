@@ -1,7 +1,7 @@
 """Step time of the neus-facto-bigmlp field shape (configs/method_configs.py:503-523: SDFFieldConfig(num_layers=8, hidden_dim=512,
 num_layers_color=4), 2048 rays per batch, the model's default 48 field samples + 256 / 96 proposal samples) next to the same step at
 hidden 256 - the 512-wide geometry network runs layer by layer (csrc/wide_kernels.h).  Not a BASELINE config: a documentation number.
-    python tools/time_bigmlp.py [steps]   ->  one JSON line per width"""
+    python tools/time_bigmlp.py [steps] [HIDDENxRAYSxSAMPLES]   ->  one JSON line per case"""
 import json
 import os
 import sys
@@ -61,6 +61,10 @@ def run(hidden, rays, samples, steps):
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-    for h in (256, 512):
-        run(h, 2048, 48, n)
-    run(512, 4096, 128, n)
+    if len(sys.argv) > 2:  # one case only (profiling):  time_bigmlp.py 5 512x4096x128
+        h, r, s_ = (int(v) for v in sys.argv[2].split("x"))
+        run(h, r, s_, n)
+    else:
+        for h in (256, 512):
+            run(h, 2048, 48, n)
+        run(512, 4096, 128, n)
