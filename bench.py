@@ -86,14 +86,23 @@ def synthetic_cameras(device):
 
 
 def draw_rays(centers, rot, n, gen):
-    """Uniform random (camera, y, x) as pixel_samplers.py:47-50, then pinhole ray directions."""
+    """Uniform random (camera, y, x) as pixel_samplers.py:47-50, then pinhole ray directions (49 cameras of 384 x 384 pixels, DTU-like
+    intrinsics): one torch.rand + one native launch (cameras/rays.py::generate_pinhole_rays)."""
+    from sdfstudio_amd.cameras.rays import generate_pinhole_rays
+
+    u = torch.rand(n, 3, device=centers.device, generator=gen)
+    return generate_pinhole_rays(u, centers, rot, 384, 384, 925.5, 922.6, 199.4, 198.1)
+
+
+def draw_rays_torch(centers, rot, n, gen):
+    """The same batch in plain torch (26 launches): the statement tests/test_gpu_parity.py holds the native generator to."""
     dev = centers.device
     u = torch.rand(n, 3, device=dev, generator=gen)
     cam = (u[:, 0] * 49).long().clamp_(max=48)
     y = (u[:, 1] * 384).floor() + 0.5
     x = (u[:, 2] * 384).floor() + 0.5
     d_cam = torch.stack([(x - 199.4) / 925.5, (y - 198.1) / 922.6, torch.ones_like(x)], dim=-1)
-    d = (rot[cam] * d_cam[:, None, :]).sum(dim=-1)  # rot @ d_cam per ray, elementwise (a bmm would put a rocBLAS kernel into the trace)
+    d = (rot[cam] * d_cam[:, None, :]).sum(dim=-1)  # rot @ d_cam per ray
     norm = d.norm(dim=-1, keepdim=True)
     return centers[cam].contiguous(), (d / norm).contiguous(), norm, cam
 

@@ -166,6 +166,14 @@ int sdfhip_geo_forward_n(const SdfHipField* f, const float* packed, const float*
 int sdfhip_geo_backward_n(const SdfHipField* f, const float* packed, const float* level_mask, int64_t n_points, void* workspace,
                           int64_t n_feat_points, const float* sdf_bar, const float* feat_bar, float* theta_bar, float* table_bar,
                           sdfhip_stream_t stream);
+/* The forward on positions taken from ray frustums - what the density / background fields evaluate (fields/nerfacto_field.py:225-246
+ * get_density: ray_samples.frustums.get_positions() = origins + directions * (starts + ends) / 2, rays.py:46-55, then the field's
+ * spatial distortion, field_components/spatial_distortions.py:66-92, SdfHipFieldCfg.contract).  origins / dirs [n_rays,3], starts / ends
+ * [n_rays, n_samples]; ends == NULL: the frustum START points (rays.py:61-73).  x_out [P,3] or NULL: the contracted positions.  The
+ * workspace and the backward are sdfhip_geo_backward's (P = n_rays * n_samples points). */
+int sdfhip_geo_forward_rays(const SdfHipField* f, const float* packed, const float* table, const float* level_mask, const float* origins,
+                            const float* dirs, const float* starts, const float* ends, int64_t n_rays, int32_t n_samples, void* workspace,
+                            float* sdf, float* feat, float* x_out, sdfhip_stream_t stream);
 
 /* Colour network as its own operator: SDFField.get_colors (sdf_field.py:532-612, ref-nerf options off) with every input supplied
  * by the caller - the numerical-gradient path (sdf_field.py:639-644) feeds it the finite-difference d sdf / dx.
@@ -207,6 +215,15 @@ int sdfhip_numfield_backward(const SdfHipField* f, const float* packed, const fl
  * (nerfacto_field.py:128-134,283-285) | emb [n_rays, emb_dim] or zeros (NULL)]: the per-ray inputs of the field's colour network.
  * sdfhip_embedding_backward: backward of rows = weight[idx] (field_components/embedding.py): out [n_rows, dim] (overwritten) = sum of
  * grad [n, dim] over the n with idx[n] == row (idx: int64 device tensor), fixed summation order, dim <= 64. */
+/* Pinhole rays for a batch of (camera, pixel) draws - the per-batch arithmetic of the reference's PixelSampler + RayGenerator
+ * (data/utils/pixel_samplers.py:47-50; model_components/ray_generators.py:49-63 -> cameras/cameras.py:462-640 for a perspective camera
+ * without distortion).  u [n_rays,3] uniforms in [0,1): camera = floor(u0 n_cams), y = floor(u1 height), x = floor(u2 width); direction
+ * = R_cam [(x + 0.5 - cx) / fx, (y + 0.5 - cy) / fy, 1] with rot [n_cams,3,3] row-major camera-to-world (x right, y down, z forward).
+ * origins [n,3] = centers[cam], dirs [n,3] unit, norm [n] = the direction's length before normalisation (RayBundle.directions_norm),
+ * cam [n] int64. */
+int sdfhip_generate_rays(const float* u, const float* centers, const float* rot, int32_t n_cams, int32_t height, int32_t width, float fx,
+                         float fy, float cx, float cy, int64_t n_rays, float* origins, float* dirs, float* norm, int64_t* cam,
+                         sdfhip_stream_t stream);
 int sdfhip_sh4_embed(const float* dirs, const float* emb, int64_t n_rays, int32_t emb_dim, float* out, sdfhip_stream_t stream);
 int sdfhip_embedding_backward(const int64_t* idx, const float* grad, int64_t n, int32_t dim, int64_t n_rows, float* out,
                               sdfhip_stream_t stream);

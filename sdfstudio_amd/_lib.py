@@ -81,6 +81,10 @@ _SIGNATURES = {
                                      c_float_p, ctypes.c_void_p]),
     "sdfhip_geo_backward_n": (c_i32, [ctypes.c_void_p, c_float_p, c_float_p, c_i64, ctypes.c_void_p, c_i64, c_float_p, c_float_p, c_float_p,
                                       c_float_p, ctypes.c_void_p]),
+    "sdfhip_geo_forward_rays": (c_i32, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_i64,
+                                        c_i32, ctypes.c_void_p, c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
+    "sdfhip_generate_rays": (c_i32, [c_float_p, c_float_p, c_float_p, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_f32, c_i64, c_float_p,
+                                     c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_void_p]),
     "sdfhip_color_workspace_size": (c_i64, [ctypes.c_void_p, c_i64]),
     "sdfhip_color_forward": (c_i32, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_i64, c_i32,
                                      ctypes.c_void_p, c_float_p, ctypes.c_void_p]),

@@ -4,6 +4,7 @@ Same attribute names and tensor shapes as the reference (``[N,S,1]`` per-sample 
 against sdfstudio reads them unchanged; in addition each object carries the flat ``[N,S]`` / ``[N,3]`` tensors the HIP
 kernels consume, so no broadcast views are materialised on the hot path.
 """
+import ctypes
 from dataclasses import dataclass
 from typing import Callable, Dict, Optional
 
@@ -90,6 +91,32 @@ class RaySamples:
         return self.get_weights_and_transmittance_from_alphas(alphas)[0]
 
 
+def _lazy_deltas(self):
+    """deltas = ends - starts [N,S,1] (rays.py:322), computed on first use: the fused kernels take starts and ends themselves."""
+    d = self.__dict__.get("_deltas")
+    if d is None and self.__dict__.get("frustums") is not None:
+        d = self.frustums.ends - self.frustums.starts
+        self.__dict__["_deltas"] = d
+    return d
+
+
+RaySamples.deltas = property(_lazy_deltas, lambda self, v: self.__dict__.__setitem__("_deltas", v))
+
+_CONST_CACHE: Dict = {}
+
+
+def constant_column(n: int, value: float, device) -> torch.Tensor:
+    """A cached [n,1] tensor filled with `value` (default pixel areas, fixed near / far planes): READ-ONLY by convention - one fill per
+    shape instead of one per training step."""
+    key = (int(n), float(value), str(device))
+    t = _CONST_CACHE.get(key)
+    if t is None:
+        if len(_CONST_CACHE) > 64:
+            _CONST_CACHE.clear()
+        t = _CONST_CACHE[key] = torch.full((int(n), 1), float(value), device=device)
+    return t
+
+
 @dataclass
 class RayBundle:
     """A bundle of rays (rays.py:233-339)."""
@@ -113,14 +140,14 @@ class RayBundle:
         if bin_starts.dim() == 2:
             bin_starts, bin_ends = bin_starts[..., None], bin_ends[..., None]
         n = self.origins.shape[0]
-        pa = self.pixel_area if self.pixel_area is not None else torch.ones(n, 1, device=self.origins.device)
+        pa = self.pixel_area if self.pixel_area is not None else constant_column(n, 1.0, self.origins.device)
         fr = Frustums(
             origins=self.origins[:, None, :], directions=self.directions[:, None, :], starts=bin_starts, ends=bin_ends,
             pixel_area=pa[:, None, :],
         )
         cam = None if self.camera_indices is None else self.camera_indices[..., None]
         return RaySamples(
-            frustums=fr, camera_indices=cam, deltas=bin_ends - bin_starts, spacing_starts=spacing_starts,
+            frustums=fr, camera_indices=cam, deltas=None, spacing_starts=spacing_starts,  # deltas: on first use (_lazy_deltas)
             spacing_ends=spacing_ends, spacing_to_euclidean_fn=spacing_to_euclidean_fn, metadata=self.metadata,
             flat_origins=self.origins.contiguous(), flat_directions=self.directions.contiguous(),
             flat_starts=bin_starts[..., 0].contiguous(), flat_ends=bin_ends[..., 0].contiguous(), flat_bins=flat_bins,
@@ -143,3 +170,24 @@ def unpack_ray_samples(rs):
     if not (torch.equal(fr.origins.expand(n, s, 3)[:, -1, :], fr.origins.expand(n, s, 3)[:, 0, :])):
         raise ValueError("ray samples whose origins vary along the sample axis are not supported by the fused path")
     return o, d, starts[..., 0].contiguous().float(), fr.ends[..., 0].contiguous().float()
+
+
+def generate_pinhole_rays(u, centers, rot, height: int, width: int, fx: float, fy: float, cx: float, cy: float):
+    """One batch of training rays from uniform draws u [n,3] in [0,1): (camera, y, x) as data/utils/pixel_samplers.py:47-50, then the
+    pinhole rays of cameras/cameras.py:462-640 for those pixels (perspective camera, no distortion; pixel centres at +0.5) - the
+    PixelSampler + RayGenerator arithmetic of one training iteration in ONE native launch (sdfhip_generate_rays).
+    centers [C,3], rot [C,3,3] camera-to-world (columns x right, y down, z forward).  Returns (origins [n,3], directions [n,3] unit,
+    directions_norm [n,1], camera index [n] int64)."""
+    from sdfstudio_amd import _lib
+
+    lib = _lib.load()
+    n, dev = u.shape[0], u.device
+    o, d = torch.empty(n, 3, device=dev), torch.empty(n, 3, device=dev)
+    norm = torch.empty(n, 1, device=dev)
+    cam = torch.empty(n, dtype=torch.int64, device=dev)
+    kp = _lib.Keep()
+    _lib.check(lib.sdfhip_generate_rays(kp(u), kp(centers), kp(rot), int(centers.shape[0]), int(height), int(width), float(fx), float(fy),
+                                        float(cx), float(cy), n, _lib.ptr(o), _lib.ptr(d), _lib.ptr(norm),
+                                        ctypes.c_void_p(cam.data_ptr()), _lib.stream()), "generate_rays")
+    del kp
+    return o, d, norm, cam

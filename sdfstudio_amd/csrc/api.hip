@@ -894,10 +894,12 @@ __global__ void pad_copy_kernel(const float* __restrict__ in, const int64_t n, c
   if (i < n_padded) out[i] = (in != nullptr && i < n) ? in[i] : 0.0f;
 }
 
-extern "C" int sdfhip_geo_forward_n(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
-                                    const float* positions, int64_t n_points, int64_t n_feat_points, void* workspace, float* sdf,
-                                    float* feat, sdfhip_stream_t stream) {
-  SDFHIP_REQUIRE(f && packed && table && level_mask && positions && workspace && sdf, "geo_forward: null argument");
+// shared by the explicit-position entry (dirs == null: `origins` holds [P,3] positions, used as given) and the ray entry (positions from
+// the rays' frustums: start points, or mid points when `ends` is given; the field's scene contraction applied)
+static int geo_forward_impl(const SdfHipField* f, const float* packed, const float* table, const float* level_mask, const float* origins,
+                            const float* dirs, const float* starts, const float* ends, int32_t n_samples, int64_t n_points,
+                            int64_t n_feat_points, void* workspace, float* sdf, float* feat, float* x_out, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(f && packed && table && level_mask && origins && workspace && sdf, "geo_forward: null argument");
   SDFHIP_REQUIRE(n_feat_points >= 0 && n_feat_points <= n_points, "geo_forward: n_feat_points out of range");
   if (n_points == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
@@ -908,10 +910,14 @@ extern "C" int sdfhip_geo_forward_n(const SdfHipField* f, const float* packed, c
   EncodeArgs ea;
   memset(&ea, 0, sizeof(ea));
   ea.grid = f->grid;
-  ea.origins = positions;  // explicit positions, used as given (forward_geonetwork does not contract)
+  ea.origins = origins;  // explicit positions are used as given (forward_geonetwork does not contract)
+  ea.dirs = dirs;
+  ea.starts = starts;
+  ea.ends = ends;
+  ea.contract = dirs != nullptr ? f->cfg.contract : 0;
   ea.n_points = P;
   ea.n_padded = NP;
-  ea.S = 1;
+  ea.S = dirs != nullptr ? n_samples : 1;
   ea.pe_degree = f->cfg.pe_degree;
   ea.use_pe = f->cfg.use_position_encoding;
   ea.nb0 = k->nb0;
@@ -937,8 +943,22 @@ extern "C" int sdfhip_geo_forward_n(const SdfHipField* f, const float* packed, c
     const int64_t total = n_feat_points * f->cfg.geo_feat_dim;
     untp_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(w.feat, k->nbf, f->cfg.geo_feat_dim, n_feat_points, feat);
   }
+  if (x_out != nullptr) SDFHIP_CHECK_HIP(hipMemcpyAsync(x_out, w.x, (size_t)P * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
+}
+extern "C" int sdfhip_geo_forward_n(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
+                                    const float* positions, int64_t n_points, int64_t n_feat_points, void* workspace, float* sdf,
+                                    float* feat, sdfhip_stream_t stream) {
+  return geo_forward_impl(f, packed, table, level_mask, positions, nullptr, nullptr, nullptr, 1, n_points, n_feat_points, workspace, sdf, feat,
+                          nullptr, stream);
+}
+extern "C" int sdfhip_geo_forward_rays(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
+                                       const float* origins, const float* dirs, const float* starts, const float* ends, int64_t n_rays,
+                                       int32_t n_samples, void* workspace, float* sdf, float* feat, float* x_out, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(dirs && starts && n_rays >= 0 && n_samples > 0, "geo_forward_rays: bad argument");
+  const int64_t P = n_rays * n_samples;
+  return geo_forward_impl(f, packed, table, level_mask, origins, dirs, starts, ends, n_samples, P, P, workspace, sdf, feat, x_out, stream);
 }
 extern "C" int sdfhip_geo_forward(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
                                   const float* positions, int64_t n_points, void* workspace, float* sdf, float* feat,
@@ -1290,6 +1310,55 @@ extern "C" int sdfhip_sh4_embed(const float* dirs, const float* emb, int64_t n_r
   SDFHIP_REQUIRE(dirs && out && emb_dim >= 0 && n_rays >= 0, "sh4_embed: bad argument");
   if (n_rays == 0) return 0;
   sh4_embed_kernel<<<(unsigned)((n_rays + 255) / 256), 256, 0, (hipStream_t)stream>>>(dirs, emb, n_rays, emb_dim, out);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// Pinhole rays for a batch of (camera, pixel) draws: the per-batch work of the reference's PixelSampler + RayGenerator (data/utils/
+// pixel_samplers.py:47-50 uniform (camera, y, x); model_components/ray_generators.py:49-63 -> cameras.py:462-640 _generate_rays_from_coords
+// for a perspective camera without distortion: direction = R [(x + 0.5 - cx) / fx, (y + 0.5 - cy) / fy, 1] with camera-to-world columns
+// (x right, y down, z forward), normalised; directions_norm kept).  u [n,3] uniforms in [0,1): camera = floor(u0 C), y = floor(u1 H),
+// x = floor(u2 W).  One thread per ray.
+struct GenRaysArgs {
+  const float* u;        // [n,3]
+  const float* centers;  // [C,3]
+  const float* rot;      // [C,3,3] row-major camera-to-world
+  float fx, fy, cx, cy;
+  int32_t n_cams, H, W;
+  int64_t n;
+  float* origins;  // [n,3]
+  float* dirs;     // [n,3] unit
+  float* norm;     // [n]   length of the un-normalised direction
+  int64_t* cam;    // [n]
+};
+__global__ void generate_rays_kernel(const GenRaysArgs a) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  int c = (int)(a.u[i * 3 + 0] * (float)a.n_cams);
+  c = c > a.n_cams - 1 ? a.n_cams - 1 : c;
+  const float y = floorf(a.u[i * 3 + 1] * (float)a.H) + 0.5f, x = floorf(a.u[i * 3 + 2] * (float)a.W) + 0.5f;
+  const float dc[3] = {(x - a.cx) / a.fx, (y - a.cy) / a.fy, 1.0f};
+  const float* R = a.rot + (size_t)c * 9;
+  float d[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) d[r] = (R[r * 3 + 0] * dc[0] + R[r * 3 + 1] * dc[1]) + R[r * 3 + 2] * dc[2];
+  const float len = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    a.origins[i * 3 + r] = a.centers[(size_t)c * 3 + r];
+    a.dirs[i * 3 + r] = d[r] / len;
+  }
+  a.norm[i] = len;
+  a.cam[i] = c;
+}
+extern "C" int sdfhip_generate_rays(const float* u, const float* centers, const float* rot, int32_t n_cams, int32_t height, int32_t width,
+                                    float fx, float fy, float cx, float cy, int64_t n_rays, float* origins, float* dirs, float* norm,
+                                    int64_t* cam, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(u && centers && rot && origins && dirs && norm && cam && n_cams > 0 && height > 0 && width > 0 && n_rays >= 0,
+                 "generate_rays: bad argument");
+  if (n_rays == 0) return 0;
+  GenRaysArgs a{u, centers, rot, fx, fy, cx, cy, n_cams, height, width, n_rays, origins, dirs, norm, cam};
+  generate_rays_kernel<<<(unsigned)((n_rays + 255) / 256), 256, 0, (hipStream_t)stream>>>(a);
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -147,12 +147,21 @@ struct EncodeArgs {
   // k-th tap offset AFTER the contraction (k = 0: the point itself; 1..6: +d, -d along x, then y, then z).  0: plain points.
   int64_t tap_points;
   float tap_delta;
+  const float* ends;     // [N,S] or null.  Non-null (with dirs): the frustum MID point o + d (start + end) / 2 (rays.py:46-55, what the
+                         // density / nerfacto fields evaluate) instead of the start point
 };
 
-// position of encode point p: the start position of point q = p mod tap_points (or p), contracted, then displaced by its tap
+// position of encode point p: the start (or mid) position of point q = p mod tap_points (or p), contracted, then displaced by its tap
 SDFHIP_D void encode_position(const EncodeArgs& a, const int64_t p, float x[3]) {
   const int64_t q = a.tap_points > 0 ? p % a.tap_points : p;
-  start_position(a.origins, a.dirs, a.starts, q, a.S, x);
+  if (a.ends != nullptr && a.dirs != nullptr) {
+    const int64_t ray = q / a.S;
+    const float t2 = a.starts[q] + a.ends[q];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) x[d] = a.origins[ray * 3 + d] + a.dirs[ray * 3 + d] * t2 * 0.5f;  // origins + directions * (starts + ends) / 2
+  } else {
+    start_position(a.origins, a.dirs, a.starts, q, a.S, x);
+  }
   if (a.contract) contract_inf(x, a.contract);
   if (a.tap_points > 0) {
     const int tap = (int)(p / a.tap_points);

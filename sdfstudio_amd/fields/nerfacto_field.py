@@ -90,6 +90,30 @@ class _ShEmbed(torch.autograd.Function):
         return None, (out_bar[:, 16:] if ctx.needs_input_grad[1] else None), None
 
 
+class _PermutedTheta(torch.autograd.Function):
+    """theta = cat(parameters..., one zero)[src] where src visits every parameter element exactly once (a permutation with zero padding):
+    forward = one cat + one gather; backward = one gather of theta_bar per parameter through the INVERSE map, written straight into the
+    parameter's slot of the flat gradient buffer (sdfstudio_amd/grad_slots.py).  Autograd's own backward of the same two statements is an
+    index_add_ over the whole vector (0.06 ms), a split, and one copy per parameter into its slot."""
+
+    @staticmethod
+    def forward(ctx, src, zero, invs, *params):
+        ctx.params, ctx.invs = params, invs
+        return torch.cat([p.reshape(-1) for p in params] + [zero]).index_select(0, src)
+
+    @staticmethod
+    def backward(ctx, theta_bar):
+        from sdfstudio_amd.grad_slots import grad_target
+
+        theta_bar = theta_bar.contiguous()
+        outs = []
+        for p, inv in zip(ctx.params, ctx.invs):
+            out = grad_target(p)[0]  # every element is written
+            torch.index_select(theta_bar, 0, inv, out=out.view(-1))
+            outs.append(out)
+        return (None, None, None, *outs)
+
+
 class _TruncExp(torch.autograd.Function):
     """field_components/activations.py:23-39: exp forward, gradient exp(clamp(x, -15, 15))."""
 
@@ -156,7 +180,10 @@ class TCNNNerfactoField(nn.Module):
             raise NotImplementedError("geo_feat_dim <= 32 and hidden widths that are multiples of 32")
         self._gf_pad = 32
         n_in, e_dim = num_levels * features_per_level, 16 + appearance_embedding_dim
-        cfg_c = _lib.FieldCfg(1, hidden_dim, self._gf_pad, 2, hidden_dim_color, -1, 0, 0, e_dim, 0, 0.0, self.grid_cfg, 1, 0)
+        # scene contraction of the frustum mid points: applied by the ray entry of the geometry network (sdfhip_geo_forward_rays)
+        order = getattr(spatial_distortion, "order", None) if spatial_distortion is not None else None
+        self._contract = 0 if spatial_distortion is None else (1 if order == float("inf") else 2 if order in (None, 2) else -1)
+        cfg_c = _lib.FieldCfg(1, hidden_dim, self._gf_pad, 2, hidden_dim_color, -1, 0, 0, e_dim, max(self._contract, 0), 0.0, self.grid_cfg, 1, 0)
         expect = [(hidden_dim, 3 + n_in), (1 + self._gf_pad, hidden_dim), (hidden_dim_color, 33 + self._gf_pad + e_dim),
                   (hidden_dim_color, hidden_dim_color), (3, hidden_dim_color)]
         self._native = NativeBackgroundNet(cfg_c, self._gf_pad, e_dim, expect)
@@ -192,17 +219,41 @@ class TCNNNerfactoField(nn.Module):
         through the index map of _theta_layout - the cat-of-cats statement itself cost ~60 small launches per step with its backward."""
         b, h = self.mlp_base, self.mlp_head
         dev = b.w1.device
+        params = (b.w1, b.w2, h.w1, h.w2, h.w3)
         if getattr(self, "_theta_src", None) is None or self._theta_src.device != dev:
-            self._theta_src = self._theta_layout().to(dev)
+            src = self._theta_layout()
+            n_src = sum(p.numel() for p in params)
+            # inverse map: where in theta does source element j land?  (None when some element is used twice or never: autograd's own path)
+            hits = torch.bincount(src[src < n_src], minlength=n_src)
+            self._theta_invs = None
+            if bool((hits == 1).all()):
+                where = torch.empty(n_src, dtype=torch.int64)
+                where[src[src < n_src]] = torch.nonzero(src < n_src)[:, 0]
+                self._theta_invs, off = [], 0
+                for p in params:
+                    self._theta_invs.append(where[off:off + p.numel()].to(dev))
+                    off += p.numel()
+            self._theta_src = src.to(dev)
             self._theta_zero = torch.zeros(1, device=dev, dtype=b.w1.dtype)
-        flat = torch.cat([b.w1.reshape(-1), b.w2.reshape(-1), h.w1.reshape(-1), h.w2.reshape(-1), h.w3.reshape(-1), self._theta_zero])
+        if self._theta_invs is not None and torch.is_grad_enabled():
+            return _PermutedTheta.apply(self._theta_src, self._theta_zero, self._theta_invs, *params)
+        flat = torch.cat([p.reshape(-1) for p in params] + [self._theta_zero])
         return flat.index_select(0, self._theta_src)
 
     def get_density(self, ray_samples):
         """:225-246: contracted frustum MID points -> (x + 2) / 4 -> hash grid -> MLP -> trunc_exp of the first output.  The second
         return value carries what get_outputs needs from this call (features + the packed parameter vector + positions)."""
-        from sdfstudio_amd.fields.sdf_field import _GeoNetFunction
+        from sdfstudio_amd.cameras.rays import unpack_ray_samples
+        from sdfstudio_amd.fields.sdf_field import _GeoNetFunction, _GeoNetRaysFunction
 
+        if self._contract > 0 and getattr(ray_samples.frustums, "offsets", None) is None and ray_samples.frustums.starts.is_cuda:
+            # positions from the frustums and their contraction inside the kernel
+            o, d, st, en = unpack_ray_samples(ray_samples)
+            theta = self._theta()
+            mask = self._const("mask", (self.grid_cfg.n_levels * self.grid_cfg.n_features,), 1.0, st.device)
+            pre, feat, x = _GeoNetRaysFunction.apply(theta, self.mlp_base.table, self._native, o.detach().float(), d.detach().float(),
+                                                     st.detach().float(), en.detach().float(), mask)
+            return _TruncExp.apply(pre.view(*st.shape, 1)), (feat, theta, x)
         positions = ray_samples.frustums.get_positions()
         shape = tuple(positions.shape[:-1])
         if self.spatial_distortion is not None:

@@ -225,6 +225,7 @@ class _FieldFunction(torch.autograd.Function):
         else:
             x = x.clone()  # lets the workspace go
         ctx.mark_non_differentiable(x)
+        ctx.set_materialize_grads(False)  # no zero fill for x's cotangent or an unused head: None travels as NULL (include/sdfhip.h)
         return sdf[:P].view(n, s), grad[:P].view(n, s, 3), rgb[:P].view(n, s, 3), x
 
     @staticmethod
@@ -291,6 +292,42 @@ class _GeoNetFunction(torch.autograd.Function):
                                              _lib.stream()), "geo_backward")
         del sdf_bar_c, feat_bar_c
         return theta_bar, table_bar, None, None, None, None
+
+
+class _GeoNetRaysFunction(torch.autograd.Function):
+    """_GeoNetFunction on positions taken from ray frustums INSIDE the kernel (sdfhip_geo_forward_rays): mid points origins + directions *
+    (starts + ends) / 2 (ends None: start points), then the field's scene contraction - the ~16 elementwise launches of
+    frustums.get_positions() + SceneContraction on the host.  (theta, table) -> (sdf [P], feature [P, F], contracted positions [P, 3])."""
+
+    @staticmethod
+    def forward(ctx, theta, table, fld, origins, dirs, starts, ends, mask):
+        lib = _lib.load()
+        dev = theta.device
+        n, s = starts.shape
+        P = n * s
+        NP = _lib.padded_points(P)
+        h = fld._handle
+        packed = torch.empty(lib.sdfhip_field_packed_size(h), device=dev)
+        theta_c = theta.contiguous()
+        _lib.check(lib.sdfhip_field_pack(h, _lib.ptr(theta_c), _lib.ptr(packed), _lib.stream()), "field_pack")
+        ws = torch.empty(lib.sdfhip_geo_workspace_size(h, P), dtype=torch.uint8, device=dev)
+        sdf = torch.empty(NP, device=dev)
+        feat = torch.empty(P, fld.config.geo_feat_dim, device=dev)
+        x = torch.empty(P, 3, device=dev)
+        kp = _lib.Keep()
+        _lib.check(lib.sdfhip_geo_forward_rays(h, _lib.ptr(packed), _lib.ptr(table), _lib.ptr(mask), kp(origins), kp(dirs), kp(starts), kp(ends),
+                                               n, s, ctypes.c_void_p(ws.data_ptr()), _lib.ptr(sdf), _lib.ptr(feat), _lib.ptr(x), _lib.stream()),
+                   "geo_forward_rays")
+        del kp
+        ctx.save_for_backward(packed, table, mask, ws)
+        ctx.fld, ctx.P, ctx.table_param, ctx.n_feat = fld, P, table, P
+        ctx.mark_non_differentiable(x)
+        ctx.set_materialize_grads(False)
+        return sdf[:P], feat, x
+
+    @staticmethod
+    def backward(ctx, sdf_bar, feat_bar, _x_bar):
+        return _GeoNetFunction.backward(ctx, sdf_bar, feat_bar) + (None, None)
 
 
 class _ColorFunction(torch.autograd.Function):
@@ -371,6 +408,7 @@ class _NumericalFieldFunction(torch.autograd.Function):
             ctx.save_for_backward(packed, mask, ws)
             ctx.fld, ctx.shape, ctx.has_emb, ctx.table_param, ctx.delta = fld, (n, s), emb is not None, table, float(delta)
         ctx.mark_non_differentiable(x)
+        ctx.set_materialize_grads(False)  # None cotangents (x; the taps without a curvature loss) travel as NULL, not as zero fills
         return sdf7[:P].view(n, s), grad.view(n, s, 3), rgb.view(n, s, 3), taps.view(n, s, 6), x.view(n, s, 3)
 
     @staticmethod
@@ -543,8 +581,13 @@ class SDFField(nn.Module):
 
     def update_mask(self, level: int):
         """sdf_field.py:376-378 (progressive hash levels)."""
-        self.hash_encoding_mask[:] = 1.0
-        self.hash_encoding_mask[level * self.features_per_level:] = 0
+        m = self.hash_encoding_mask
+        state = (int(level), id(m), m._version)
+        if getattr(self, "_mask_state", None) == state:
+            return  # same level as the last call and nobody has written the mask since (the level changes every steps_per_level steps)
+        m[:] = 1.0
+        m[level * self.features_per_level:] = 0
+        self._mask_state = (int(level), id(m), m._version)
         self._active_levels = max(0, min(int(level), self.num_levels))  # host copy: nobody has to read the device mask back
 
     def set_numerical_gradients_delta(self, delta: float) -> None:

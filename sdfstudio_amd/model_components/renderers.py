@@ -11,6 +11,7 @@ import torch
 from torch import nn
 
 from sdfstudio_amd import _lib
+from sdfstudio_amd.grad_slots import grad_target
 
 
 class _DensityWeights(torch.autograd.Function):
@@ -46,6 +47,14 @@ def density_to_weights(density: torch.Tensor, starts: torch.Tensor, ends: torch.
     return _DensityWeights.apply(density, starts.contiguous(), ends.contiguous())
 
 
+def _variance_target(param, variance):
+    """Where the render backward accumulates d L / d variance: the parameter's slot of the flat gradient buffer when there is one (zeroed
+    by FlatGradients.zero; saves the fill and the hook's copy), else a fresh zero tensor."""
+    if param is not None:
+        return grad_target(param, zero_init=True)[0]
+    return torch.zeros_like(variance)
+
+
 class _NeusRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sdf, grad, rgb, variance, dirs, starts, ends, background, cos_anneal):
@@ -69,7 +78,9 @@ class _NeusRender(torch.autograd.Function):
         ctx.save_for_backward(sdf, grad, rgb, variance, dirs, starts, ends, alpha, weights, depth_raw, acc, minmax)
         ctx.background = background
         ctx.cos_anneal = float(cos_anneal)
+        ctx.var_param = variance if (variance.is_leaf and variance.requires_grad) else None
         ctx.mark_non_differentiable(alpha)
+        ctx.set_materialize_grads(False)  # unused heads (depth, normal, accumulation in training) arrive as None = NULL, not as zero fills
         return out_rgb, depth, normal, acc, weights, alpha
 
     @staticmethod
@@ -80,7 +91,7 @@ class _NeusRender(torch.autograd.Function):
         sdf_bar = torch.empty_like(sdf)
         grad_bar = torch.empty_like(grad)
         rgbs_bar = torch.empty_like(rgb)
-        var_bar = torch.zeros_like(variance)
+        var_bar = _variance_target(ctx.var_param, variance)
 
         kp = _lib.Keep()  # cotangents may be stride-0 expands: their contiguous copies must all outlive the launch
         _lib.check(lib.sdfhip_neus_render_backward(
@@ -128,6 +139,8 @@ class _NeusRenderBg(torch.autograd.Function):
         ctx.save_for_backward(sdf, grad, rgb, variance, bg_density, bg_rgb, origins, dirs, starts, ends, alpha, weights, depth_raw, acc, minmax)
         ctx.background = background
         ctx.cos_anneal = float(cos_anneal)
+        ctx.var_param = variance if (variance.is_leaf and variance.requires_grad) else None
+        ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(alpha, rgb_merged)
         return out_rgb, depth, normal, acc, weights, alpha, rgb_merged
 
@@ -138,7 +151,7 @@ class _NeusRenderBg(torch.autograd.Function):
         n, s = starts.shape
         sdf_bar, grad_bar, rgbs_bar = torch.empty_like(sdf), torch.empty_like(grad), torch.empty_like(rgb)
         bgd_bar, bgc_bar = torch.empty_like(bg_density), torch.empty_like(bg_rgb)
-        var_bar = torch.zeros_like(variance)
+        var_bar = _variance_target(ctx.var_param, variance)
         kp = _lib.Keep()
         _lib.check(lib.sdfhip_neus_render_bg_backward(
             _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(rgb), _lib.ptr(dirs), _lib.ptr(starts), _lib.ptr(ends), _lib.ptr(variance),

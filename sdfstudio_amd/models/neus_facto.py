@@ -25,6 +25,58 @@ from sdfstudio_amd.model_components.scene_colliders import build_collider
 from sdfstudio_amd.models import background as B
 
 
+class LazyOutputs(dict):
+    """The model's output dictionary with some entries computed on first use: `ray_points` (contracted sample positions, consumed by the
+    patch-warp / visibility code only) and `normal_vis` (a viewer image) cost a dozen elementwise launches per training step that nothing
+    on the training path reads.  Reads, membership, iteration and len() behave like the reference's plain dict."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._lazy = {}
+
+    def set_lazy(self, key, fn):
+        self._lazy[key] = fn
+
+    def _force(self, key=None):
+        for k in ([key] if key is not None else list(self._lazy)):
+            if k in self._lazy:
+                super().__setitem__(k, self._lazy.pop(k)())
+
+    def __getitem__(self, key):
+        self._force(key)
+        return super().__getitem__(key)
+
+    def get(self, key, default=None):
+        self._force(key)
+        return super().get(key, default)
+
+    def __contains__(self, key):
+        return key in self._lazy or super().__contains__(key)
+
+    def __setitem__(self, key, value):
+        self._lazy.pop(key, None)
+        super().__setitem__(key, value)
+
+    def __iter__(self):
+        self._force()
+        return super().__iter__()
+
+    def __len__(self):
+        return super().__len__() + len(self._lazy)
+
+    def keys(self):
+        self._force()
+        return super().keys()
+
+    def items(self):
+        self._force()
+        return super().items()
+
+    def values(self):
+        self._force()
+        return super().values()
+
+
 class SceneContraction(nn.Module):
     """field_components/spatial_distortions.py:42-92 (order = inf, or None for L2); a marker for the kernels, callable for host code."""
 
@@ -285,16 +337,17 @@ class NeuSFactoModel(nn.Module):
         depth = depth[:, None]
         if ray_bundle.directions_norm is not None:
             depth = depth / ray_bundle.directions_norm  # base_surface_model.py:303
-        outputs = {
+        outputs = LazyOutputs({
             "rgb": rgb, "accumulation": acc[:, None], "depth": depth, "normal": normal, "weights": so["weights"],
             "directions_norm": ray_bundle.directions_norm,
-            "ray_points": self.scene_contraction(so["ray_samples"].frustums.get_start_positions()),  # :337, visibility masks
-        }
+        })
+        frustums = so["ray_samples"].frustums
+        outputs.set_lazy("ray_points", lambda: self.scene_contraction(frustums.get_start_positions()))  # :337, visibility masks
         if self.training:
             outputs.update({"eik_grad": so["field_outputs"][FieldHeadNames.GRADIENT],
                             "points_norm": so["field_outputs"]["points_norm"]})
             outputs.update(so)
-        outputs["normal_vis"] = (normal + 1.0) / 2.0
+        outputs.set_lazy("normal_vis", lambda: (normal + 1.0) / 2.0)  # :364
         return outputs
 
     def forward(self, ray_bundle: RayBundle) -> Dict:

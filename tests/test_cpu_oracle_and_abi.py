@@ -1137,3 +1137,44 @@ def test_optimizers_load_the_references_checkpoint_layout():
     wrong["fields"] = dict(ref["fields"], state={1: dict(ref["fields"]["state"][1], exp_avg=torch.zeros(7))})
     with pytest.raises(ValueError, match="moment of shape"):
         opts.load_optimizers(wrong)
+
+
+def test_lazy_outputs_behave_like_the_plain_dict():
+    """models/neus_facto.py::LazyOutputs: `ray_points` / `normal_vis` are computed on first use (nothing on the training path reads them);
+    every dict access pattern sees them as if they had been stored eagerly (base_surface_model.py:330-365 returns a plain dict)."""
+    from sdfstudio_amd.models.neus_facto import LazyOutputs
+
+    calls = []
+    d = LazyOutputs({"rgb": 1})
+    d.set_lazy("ray_points", lambda: calls.append("rp") or 7)
+    d.set_lazy("normal_vis", lambda: calls.append("nv") or 9)
+    assert "ray_points" in d and "normal_vis" in d and "missing" not in d and len(d) == 3 and calls == []
+    assert d["rgb"] == 1 and calls == []
+    assert d["ray_points"] == 7 and calls == ["rp"] and d["ray_points"] == 7 and calls == ["rp"]
+    assert d.get("normal_vis") == 9 and calls == ["rp", "nv"]
+    e = LazyOutputs({"a": 0})
+    e.set_lazy("b", lambda: 5)
+    assert sorted(e.keys()) == ["a", "b"] and dict(e) == {"a": 0, "b": 5} and sorted(e.items()) == [("a", 0), ("b", 5)]
+    f = LazyOutputs()
+    f.set_lazy("b", lambda: calls.append("never") or 1)
+    f["b"] = 2  # an explicit store wins and the thunk never runs
+    assert f["b"] == 2 and "never" not in calls and list(f) == ["b"]
+
+
+def test_ray_samples_deltas_on_first_use_and_cached_constants():
+    """cameras/rays.py: RaySamples.deltas = ends - starts (rays.py:322) is computed when somebody reads it; the collider's fixed near / far
+    columns and the default pixel areas are cached read-only constants."""
+    from sdfstudio_amd.cameras.rays import RayBundle, constant_column
+
+    o, d = torch.zeros(5, 3), torch.nn.functional.normalize(torch.randn(5, 3), dim=-1)
+    starts = torch.rand(5, 4).cumsum(-1)
+    ends = starts + 0.1
+    rs = RayBundle(origins=o, directions=d).get_ray_samples(starts, ends)
+    assert "_deltas" not in rs.__dict__ or rs.__dict__["_deltas"] is None
+    assert torch.equal(rs.deltas, (ends - starts)[..., None]) and rs.deltas is rs.deltas
+    assert torch.allclose(rs.get_alphas(torch.ones(5, 4, 1)), 1 - torch.exp(-(ends - starts))[..., None])
+    rs.deltas = torch.zeros(5, 4, 1)
+    assert float(rs.deltas.abs().sum()) == 0.0
+    a, b = constant_column(5, 0.25, "cpu"), constant_column(5, 0.25, "cpu")
+    assert a is b and a.shape == (5, 1) and float(a.min()) == 0.25 == float(a.max())
+    assert constant_column(5, 0.5, "cpu") is not a

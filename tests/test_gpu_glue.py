@@ -1,0 +1,112 @@
+"""Host-side glue that moved into native launches (round 4: config 5's per-step ATen launches): the pinhole ray generator, the geometry
+network's ray entry (frustum positions + scene contraction inside the kernel) and the permuted parameter vector of the background field."""
+import math
+
+import pytest
+import torch
+
+from tests.helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def device():
+    assert torch.cuda.is_available(), "the -m gpu tests need a HIP device"
+    return torch.device("cuda:0")
+
+
+def test_generate_pinhole_rays_against_the_torch_statement(device):
+    """sdfhip_generate_rays (PixelSampler + RayGenerator arithmetic, pixel_samplers.py:47-50 / cameras.py:462-640) against the per-statement
+    torch version bench.py used until round 4: same uniforms -> same cameras and pixels (exact), unit directions and their norms to 1 ulp."""
+    import bench
+
+    centers, rot = bench.synthetic_cameras(device)
+    for n, seed in ((4096, 3), (1, 5), (257, 7)):
+        g1, g2 = torch.Generator(device=device), torch.Generator(device=device)
+        g1.manual_seed(seed)
+        g2.manual_seed(seed)
+        o, d, norm, cam = bench.draw_rays(centers, rot, n, g1)
+        o2, d2, norm2, cam2 = bench.draw_rays_torch(centers, rot, n, g2)
+        assert torch.equal(cam, cam2) and cam.dtype == torch.int64
+        assert torch.equal(o, o2)
+        assert_close("directions", d, d2, rtol=0, atol=3e-7)
+        assert_close("directions_norm", norm, norm2, rtol=3e-7, atol=0)
+        assert_close("unit length", d.norm(dim=-1), torch.ones(n, device=device), rtol=0, atol=3e-7)
+    # edge draws: u = 0 and u just below 1 (last camera, last pixel)
+    from sdfstudio_amd.cameras.rays import generate_pinhole_rays
+
+    u = torch.tensor([[0.0, 0.0, 0.0], [0.999999, 0.999999, 0.999999]], device=device)
+    o, d, norm, cam = generate_pinhole_rays(u, centers, rot, 384, 384, 925.5, 922.6, 199.4, 198.1)
+    assert cam.tolist() == [0, 48]
+    exp = torch.tensor([[(0.5 - 199.4) / 925.5, (0.5 - 198.1) / 922.6, 1.0], [(383.5 - 199.4) / 925.5, (383.5 - 198.1) / 922.6, 1.0]], device=device)
+    dw = torch.einsum("nij,nj->ni", rot[cam], exp)
+    assert_close("corner pixel directions", d * norm, dw, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("order", [float("inf"), None])
+def test_background_field_ray_entry_equals_the_host_composed_positions(device, order):
+    """TCNNNerfactoField.get_density through sdfhip_geo_forward_rays (frustum mid points + SceneContraction inside the kernel) against the
+    same field fed host-computed positions (frustums.get_positions() -> SceneContraction.forward -> sdfhip_geo_forward): density, colour
+    and every parameter gradient.  Positions agree to an ulp, so the grid features do to ~1e-5 of their scale."""
+    from sdfstudio_amd.cameras.rays import RayBundle
+    from sdfstudio_amd.fields.field_heads import FieldHeadNames
+    from sdfstudio_amd.fields.nerfacto_field import TCNNNerfactoField
+    from sdfstudio_amd.models.neus_facto import SceneContraction
+
+    torch.manual_seed(5)
+    fld = TCNNNerfactoField(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_images=7, num_levels=6, max_res=64, log2_hashmap_size=10,
+                            spatial_distortion=SceneContraction(order=order))
+    with torch.no_grad():
+        fld.mlp_base.table.copy_((torch.rand_like(fld.mlp_base.table) * 2 - 1) * 0.4)
+    fld = fld.to(device).train()
+    n, s = 61, 9
+    o = torch.randn(n, 3, device=device) * 0.4
+    d = torch.nn.functional.normalize(torch.randn(n, 3, device=device), dim=-1)
+    starts = torch.sort(torch.rand(n, s, device=device) * 7.0, dim=-1).values  # inside and far outside the unit ball
+    ends = starts + torch.rand(n, s, device=device) * 0.5 + 0.01
+    cam = torch.randint(0, 7, (n, 1), device=device)
+    co = [torch.randn(n, s, device=device), torch.randn(n, s, 3, device=device)]
+
+    def run(native_positions):
+        fld.zero_grad(set_to_none=True)
+        fld._contract = (1 if order == float("inf") else 2) if native_positions else 0  # 0: the host-composed path
+        rs = RayBundle(origins=o, directions=d, camera_indices=cam).get_ray_samples(starts, ends)
+        out = fld(rs)
+        ((out[FieldHeadNames.DENSITY][..., 0] * co[0]).sum() + (out[FieldHeadNames.RGB] * co[1]).sum()).backward()
+        return out, {k: p.grad.clone() for k, p in fld.named_parameters() if p.grad is not None}
+
+    out_n, g_n = run(True)
+    out_h, g_h = run(False)
+    assert_close("density", out_n[FieldHeadNames.DENSITY], out_h[FieldHeadNames.DENSITY], rtol=2e-4, atol=1e-6)
+    assert_close("rgb", out_n[FieldHeadNames.RGB], out_h[FieldHeadNames.RGB], rtol=0, atol=2e-5)
+    assert set(g_n) == set(g_h) and len(g_n) >= 7
+    for k in g_n:
+        assert_close(f"grad {k}", g_n[k], g_h[k], rtol=2e-3, atol=1e-7 + 2e-4 * float(g_h[k].abs().max()))
+
+
+def test_permuted_theta_writes_gradient_slots(device):
+    """The background field's parameter vector (_PermutedTheta): same forward as cat + index_select, and under a flat gradient buffer the
+    five weight gradients land in their slots without autograd's index_add_ / split / copy chain - equal to autograd's own result."""
+    from sdfstudio_amd.distributed import FlatGradients
+    from sdfstudio_amd.fields.nerfacto_field import TCNNNerfactoField
+    from sdfstudio_amd.models.neus_facto import SceneContraction
+
+    torch.manual_seed(2)
+    fld = TCNNNerfactoField(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_images=3, num_levels=4, max_res=32, log2_hashmap_size=8,
+                            spatial_distortion=SceneContraction()).to(device).train()
+    params = [fld.mlp_base.w1, fld.mlp_base.w2, fld.mlp_head.w1, fld.mlp_head.w2, fld.mlp_head.w3]
+    theta = fld._theta()
+    assert fld._theta_invs is not None and theta.grad_fn is not None and "PermutedTheta" in type(theta.grad_fn).__name__
+    w = torch.randn_like(theta)
+    ref = torch.cat([p.reshape(-1) for p in params] + [fld._theta_zero]).index_select(0, fld._theta_src)
+    assert torch.equal(theta.detach(), ref.detach())
+    want = torch.autograd.grad((ref * w).sum(), params)
+    flat = FlatGradients(list(fld.parameters()))
+    loss = (theta * w).sum()
+    flat.zero(loss)
+    loss.backward()
+    flat.finish()
+    for p, g in zip(params, want):
+        assert torch.equal(p.grad, g)
+        assert p.grad.data_ptr() >= flat.flat.data_ptr() and p.grad.data_ptr() < flat.flat.data_ptr() + flat.flat.numel() * 4
