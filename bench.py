@@ -24,8 +24,10 @@ whole step.  `cpu_baseline` times the CPU oracle (a port of the reference's PyTo
 `cpu_baseline_reference` quotes the reference's own Python timed in the build container (profiles/cpu_reference_r2.json).
 """
 import argparse
+import functools
 import json
 import math
+import operator
 import os
 import sys
 import time
@@ -287,7 +289,7 @@ def make_job(config, device, world, rank, small=False, hidden=256, rays=None, sa
         image = torch.rand(n_rays, 3, device=device, generator=gen)
         rb = RayBundle(origins=o, directions=d, directions_norm=norm, camera_indices=cam[:, None])
         out = model(rb)
-        loss = sum(model.get_loss_dict(out, {"image": image}).values())
+        loss = functools.reduce(operator.add, model.get_loss_dict(out, {"image": image}).values())  # (sum() would start with 0 + a tensor: a launch)
         flat.zero(loss)  # the loss's graph tells the buckets which gradients to wait for (unused parameters: distributed.py)
         loss.backward()
         opts.optimizer_step_all(grad_scale=flat.finish(average=False))  # SUM all-reduce; the 1 / world mean rides in the Adam read

@@ -102,37 +102,66 @@ def surface_losses(rgb: torch.Tensor, image: torch.Tensor, eik_grad: Optional[to
     return out
 
 
-class _InterlevelLevel(torch.autograd.Function):
-    """mean over rays and samples of clip(w_gt - wp, 0)^2 / (wp + 1e-5) for one proposal level (losses.py:156-171)."""
+class _Interlevel(torch.autograd.Function):
+    """interlevel_loss_zip (losses.py:116-172) as ONE autograd node over all proposal levels: sum over levels of the mean over rays and
+    samples of clip(w_gt - wp, 0)^2 / (wp + 1e-5).  One native launch per level writes the terms and their derivatives into slices of two
+    flat buffers; the means of all levels are ONE weighted sum with a cached vector of 1 / numel per element, and the backward is one
+    multiply of the (pre-scaled) derivatives by the incoming gradient - four ATen launches where a node per level, its mean and the
+    running sum took ten."""
+
+    _scale_cache = {}
 
     @staticmethod
-    def forward(ctx, wp, c, w, cp, radius):
+    def forward(ctx, c, w, radii, *levels):  # levels = cp_0, wp_0, cp_1, wp_1, ...
         lib = _lib.load()
-        n, s_p = wp.shape
-        s = w.shape[1]
+        n, s = w.shape
+        dev = w.device
+        shapes = [tuple(levels[2 * i + 1].shape) for i in range(len(levels) // 2)]
+        sizes = [a * b for a, b in shapes]
+        key = (tuple(sizes), str(dev))
+        scale = _Interlevel._scale_cache.get(key)
+        if scale is None:
+            if len(_Interlevel._scale_cache) > 16:
+                _Interlevel._scale_cache.clear()
+            scale = torch.cat([torch.full((m,), 1.0 / m, device=dev) for m in sizes])
+            _Interlevel._scale_cache[key] = scale
+        term = torch.empty(sum(sizes), device=dev)
+        dterm = torch.empty(sum(sizes), device=dev)
         kp = _lib.Keep()
-        term = torch.empty(n, s_p, device=wp.device)
-        dterm = torch.empty(n, s_p, device=wp.device)
-        _lib.check(lib.sdfhip_interlevel_terms(kp(c), kp(w), kp(cp), kp(wp.detach()), n, s, s_p, float(radius), _lib.ptr(term),
-                                               _lib.ptr(dterm), None, _lib.stream()), "interlevel_terms")
+        c_p, w_p = kp(c), kp(w)
+        off = 0
+        for i, (m, (_, s_p)) in enumerate(zip(sizes, shapes)):
+            cp, wp = levels[2 * i], levels[2 * i + 1]
+            _lib.check(lib.sdfhip_interlevel_terms(c_p, w_p, kp(cp), kp(wp.detach()), n, s, s_p, float(radii[i]), _lib.ptr(term[off:off + m]),
+                                                   _lib.ptr(dterm[off:off + m]), None, _lib.stream()), "interlevel_terms")
+            off += m
         del kp
-        ctx.save_for_backward(dterm)
-        return term.mean()
+        ctx.save_for_backward(dterm.mul_(scale))  # d (sum of means) / d wp, all levels
+        ctx.shapes = shapes
+        return term.mul_(scale).sum()  # (not torch.dot: that is a rocBLAS call with its own workspace and launches)
 
     @staticmethod
     def backward(ctx, g):
-        (dterm,) = ctx.saved_tensors
-        return dterm * (g / dterm.numel()), None, None, None, None
+        (dscaled,) = ctx.saved_tensors
+        out = dscaled * g
+        grads, off = [None, None, None], 0
+        for a, b in ctx.shapes:
+            grads += [None, out[off:off + a * b].view(a, b)]
+            off += a * b
+        return tuple(grads)
 
 
 def interlevel_loss_zip(weights_list: List[torch.Tensor], bins_list: List[torch.Tensor]) -> torch.Tensor:
     """weights_list[i]: [N,S_i] (last = field weights), bins_list[i]: [N,S_i+1] spacing bins (last = field bins)."""
     c = bins_list[-1].detach()
     w = weights_list[-1].detach()
-    total = 0.0
-    for cp, wp, radius in zip(bins_list[:-1], weights_list[:-1], (0.03, 0.003)):
-        total = total + _InterlevelLevel.apply(wp, c, w, cp.detach(), radius)
-    return total
+    radii = (0.03, 0.003)  # losses.py:138: one blur half-width per proposal level
+    levels = []
+    for cp, wp in zip(bins_list[:-1][:len(radii)], weights_list[:-1][:len(radii)]):
+        levels += [cp.detach(), wp]
+    if not w.is_cuda:
+        raise _lib.SdfHipError("interlevel_loss_zip runs on the sdfhip kernels: HIP device tensors required (no CPU fallback)")
+    return _Interlevel.apply(c, w, radii[:len(levels) // 2], *levels)
 
 
 def scale_and_shift_invariant_loss(prediction: torch.Tensor, target: torch.Tensor, mask: torch.Tensor, alpha: float = 0.5,
