@@ -1178,3 +1178,41 @@ def test_ray_samples_deltas_on_first_use_and_cached_constants():
     a, b = constant_column(5, 0.25, "cpu"), constant_column(5, 0.25, "cpu")
     assert a is b and a.shape == (5, 1) and float(a.min()) == 0.25 == float(a.max())
     assert constant_column(5, 0.5, "cpu") is not a
+
+
+def test_ray_and_position_vectors_of_the_reference():
+    """tests/golden/rays_reference.npz (minted by the reference's own PixelSampler arithmetic, Cameras.generate_rays, Frustums and
+    SceneContraction: tests/golden/make_golden_rays.py) against the host-side statements of this repo - the per-statement ray generation
+    the bench used before sdfhip_generate_rays, and models/neus_facto.py::SceneContraction - bit for bit; re-minted live and compared
+    with the committed file when the reference tree is present.  The GPU suite holds the kernels to the same vectors (tests/test_gpu_glue.py)."""
+    from oracle import ref_harness
+    from sdfstudio_amd.models.neus_facto import SceneContraction
+
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "rays_reference.npz")))
+    u, rot, cen = torch.tensor(g["rays/u"]), torch.tensor(g["rays/rot"]), torch.tensor(g["rays/centers"])
+    fx, fy, cx, cy, H, W, C = g["rays/intrinsics"]
+    cam = (u[:, 0] * C).long().clamp_(max=int(C) - 1)
+    y, x = (u[:, 1] * H).floor() + 0.5, (u[:, 2] * W).floor() + 0.5
+    dc = torch.stack([(x - cx) / fx, (y - cy) / fy, torch.ones_like(x)], -1).float()
+    d = (rot[cam] * dc[:, None, :]).sum(-1)
+    norm = d.norm(dim=-1, keepdim=True)
+    assert np.array_equal(cam.numpy(), g["rays/indices"][:, 0]) and g["rays/indices"][1].tolist() == [int(C) - 1, int(H) - 1, int(W) - 1]
+    assert torch.equal(cen[cam], torch.tensor(g["rays/origins"]))
+    assert torch.allclose(d / norm, torch.tensor(g["rays/directions"]), rtol=0, atol=2e-7)
+    assert torch.allclose(norm, torch.tensor(g["rays/directions_norm"]), rtol=2e-7, atol=0)
+    o, dd, st, en = (torch.tensor(g[f"pos/{k}"]) for k in ("origins", "directions", "starts", "ends"))
+    mid = o[:, None, :] + dd[:, None, :] * (st + en)[..., None] / 2
+    start = o[:, None, :] + dd[:, None, :] * st[..., None]
+    for name, order in (("inf", float("inf")), ("l2", None)):
+        assert torch.allclose(SceneContraction(order)(mid), torch.tensor(g[f"pos/mid_{name}"]), rtol=0, atol=3e-7)
+        assert torch.allclose(SceneContraction(order)(start), torch.tensor(g[f"pos/start_{name}"]), rtol=0, atol=3e-7)
+    if ref_harness.reference_available():
+        import sys
+
+        sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+        import make_golden_rays
+
+        live = make_golden_rays.reference_vectors()
+        assert set(live) == set(g)
+        for k in g:
+            assert np.array_equal(live[k], g[k]), k

@@ -110,3 +110,48 @@ def test_permuted_theta_writes_gradient_slots(device):
     for p, g in zip(params, want):
         assert torch.equal(p.grad, g)
         assert p.grad.data_ptr() >= flat.flat.data_ptr() and p.grad.data_ptr() < flat.flat.data_ptr() + flat.flat.numel() * 4
+
+
+def _ray_vectors():
+    import os
+
+    import numpy as np
+
+    return dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rays_reference.npz")))
+
+
+def test_generate_rays_against_the_references_cameras(device):
+    """sdfhip_generate_rays against vectors minted by the REFERENCE's own data path (tests/golden/make_golden_rays.py: the PixelSampler's
+    floor(rand * [C, H, W]), image_coords + 0.5 and Cameras.generate_rays for perspective cameras): same cameras and origins exactly, unit
+    directions and directions_norm to an ulp."""
+    from sdfstudio_amd.cameras.rays import generate_pinhole_rays
+
+    g = _ray_vectors()
+    fx, fy, cx, cy, H, W, C = g["rays/intrinsics"]
+    t = lambda k: torch.tensor(g[k]).to(device)  # noqa: E731
+    o, d, norm, cam = generate_pinhole_rays(t("rays/u"), t("rays/centers"), t("rays/rot"), int(H), int(W), fx, fy, cx, cy)
+    assert torch.equal(cam.cpu(), torch.tensor(g["rays/indices"][:, 0]))
+    assert torch.equal(o, t("rays/origins"))
+    assert_close("directions", d, t("rays/directions"), rtol=0, atol=3e-7)
+    assert_close("directions_norm", norm, t("rays/directions_norm"), rtol=3e-7, atol=0)
+
+
+@pytest.mark.parametrize("name,order", [("inf", float("inf")), ("l2", None)])
+def test_ray_entry_positions_against_the_references_frustums_and_contraction(device, name, order):
+    """The positions sdfhip_geo_forward_rays forms inside the encode kernel (x_out) against the reference's Frustums.get_positions() /
+    get_start_positions() followed by its SceneContraction (vectors of tests/golden/make_golden_rays.py), both norms, mid and start points."""
+    from sdfstudio_amd.fields.nerfacto_field import TCNNNerfactoField
+    from sdfstudio_amd.fields.sdf_field import _GeoNetRaysFunction
+    from sdfstudio_amd.models.neus_facto import SceneContraction
+
+    g = _ray_vectors()
+    fld = TCNNNerfactoField(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_images=3, num_levels=4, max_res=32, log2_hashmap_size=8,
+                            spatial_distortion=SceneContraction(order=order)).to(device)
+    t = lambda k: torch.tensor(g[k]).to(device)  # noqa: E731
+    o, d, st, en = t("pos/origins"), t("pos/directions"), t("pos/starts"), t("pos/ends")
+    mask = torch.ones(fld.grid_cfg.n_levels * fld.grid_cfg.n_features, device=device)
+    with torch.no_grad():
+        theta = fld._theta()
+        for ends, key in ((en, f"pos/mid_{name}"), (None, f"pos/start_{name}")):
+            _, _, x = _GeoNetRaysFunction.apply(theta, fld.mlp_base.table, fld._native, o, d, st, ends, mask)
+            assert_close(key, x.view(*st.shape, 3), t(key), rtol=0, atol=4e-7)
