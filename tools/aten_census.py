@@ -39,6 +39,7 @@ class Census(TorchDispatchMode):
 
 config = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+eval_mode = len(sys.argv) > 3 and sys.argv[3] == "eval"  # the forward-only leg of bench.py: eval-mode render of one batch, no grad
 dev = torch.device("cuda:0")
 if config == 5:
     bench.N_RAYS, bench.N_SAMPLES = 2048, 48
@@ -48,9 +49,31 @@ for i in range(4):
 torch.cuda.synchronize()
 N = 3
 census = Census()
-with census:
-    for i in range(N):
-        job["step"](first + 4 + i)
+if eval_mode:
+    import time
+
+    from sdfstudio_amd.cameras.rays import RayBundle
+
+    model = job["model"].eval()
+    o, d, norm, cam = bench.draw_rays(job["centers"], job["rot"], job["n_rays"], job["gen"])
+    rb = RayBundle(origins=o, directions=d, directions_norm=norm, camera_indices=cam[:, None])
+    with torch.no_grad():
+        model(rb)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            model(rb)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print(f"eval batch: host enqueue {(t1 - t0) / 20 * 1e3:.3f} ms, total {(t2 - t0) / 20 * 1e3:.3f} ms")
+        with census:
+            for i in range(N):
+                model(rb)
+else:
+    with census:
+        for i in range(N):
+            job["step"](first + 4 + i)
 torch.cuda.synchronize()
 tot = 0
 for (where, op), n in sorted(census.rows.items(), key=lambda kv: (kv[0][0], -kv[1])):
