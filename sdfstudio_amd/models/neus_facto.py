@@ -50,6 +50,14 @@ class LazyOutputs(dict):
         self._force(key)
         return super().get(key, default)
 
+    def pop(self, key, *default):
+        self._force(key)
+        return super().pop(key, *default)
+
+    def copy(self):
+        self._force()
+        return dict(super().items())
+
     def __contains__(self, key):
         return key in self._lazy or super().__contains__(key)
 

@@ -1159,6 +1159,9 @@ def test_lazy_outputs_behave_like_the_plain_dict():
     f.set_lazy("b", lambda: calls.append("never") or 1)
     f["b"] = 2  # an explicit store wins and the thunk never runs
     assert f["b"] == 2 and "never" not in calls and list(f) == ["b"]
+    h = LazyOutputs({"a": 1})
+    h.set_lazy("b", lambda: 3)
+    assert h.copy() == {"a": 1, "b": 3} and h.pop("b") == 3 and "b" not in h and h.pop("zz", None) is None
 
 
 def test_ray_samples_deltas_on_first_use_and_cached_constants():
