@@ -15,7 +15,7 @@ tcnn keeps each network's weights in one fp16 ``params`` vector in an internal p
 not load (fp32 ``mlp_base.{table, w1, w2}``, ``mlp_head.{w1, w2, w3}`` here), as for the proposal networks.
 """
 import math
-from typing import Dict, Optional
+from typing import Dict
 
 import torch
 from torch import nn

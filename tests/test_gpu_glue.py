@@ -1,7 +1,5 @@
 """Host-side glue that moved into native launches (round 4: config 5's per-step ATen launches): the pinhole ray generator, the geometry
 network's ray entry (frustum positions + scene contraction inside the kernel) and the permuted parameter vector of the background field."""
-import math
-
 import pytest
 import torch
 
