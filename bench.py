@@ -228,6 +228,9 @@ def main():
                          "start at step 5 resp. 200 000 of the preset's schedules")
     ap.add_argument("--no-config5", action="store_true", help="default (config 2) run: skip the two short config-5 legs appended as \"config5\"")
     ap.add_argument("--no-bigmlp", action="store_true", help="default (config 2) run: skip the two short 512-wide legs appended as \"bigmlp\"")
+    ap.add_argument("--no-dense-sdf", action="store_true", help="default (config 2) run: skip the dense-SDF (mesh extraction) leg appended as \"dense_sdf\"")
+    ap.add_argument("--only", default=None, choices=["inference"],
+                    help="inference: only the forward-only and dense-SDF legs on config 2's model (no training steps; tools/ A/B and PMC runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--small", action="store_true", help="small parity configuration (control-flow tests only, not a benchmark)")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the second (untimed) pass that times every launch")
@@ -263,8 +266,18 @@ def make_job(config, device, world, rank, small=False, hidden=256, rays=None, sa
     model = build_model_config5(device) if cfg5 else build_model(device, small=small, hidden=hidden, samples=samples)
     broadcast_parameters(model)
     groups = {k: v for k, v in model.get_param_groups().items() if v}  # "field_background" is empty with background_model="none"
-    # one flat gradient buffer; one exchange bucket per parameter group, all-reduced (RCCL) as soon as backward has produced it
-    flat = FlatGradients([p for g in groups.values() for p in g], buckets=list(groups.values()))
+    # Gradient exchange (distributed.py).  N > 1 default: SHARDED - reduce-scatter of the flat gradient, fused Adam on this rank's 1 / N
+    # slice of parameters and moments, all-gather of the updated slices (the SDF table's last: it overlaps the next step's ray
+    # generation and proposal sampling); the big tables are buckets of their own.  SDFHIP_BENCH_EXCHANGE=allreduce: one bucket per
+    # parameter group, all-reduced (RCCL) as soon as backward has produced it, replicated Adam (rounds 1 - 4).
+    shard = world > 1 and os.environ.get("SDFHIP_BENCH_EXCHANGE", "shard") == "shard"
+    if shard:
+        from sdfstudio_amd.distributed import plan_buckets
+
+        params, buckets, late = plan_buckets(groups, big_numel=(1 << 14) if small else (1 << 22))
+        flat = FlatGradients(params, buckets=buckets, shard=True, late_buckets=late)
+    else:
+        flat = FlatGradients([p for g in groups.values() for p in g], buckets=list(groups.values()))
     flat.time_waits = world > 1
     if cfg5:
         # method_configs.py:434-447: Adam 1e-3 with MultiStepWarmup (fields; AdamW with weight_decay 0 = Adam for field_background),
@@ -283,7 +296,11 @@ def make_job(config, device, world, rank, small=False, hidden=256, rays=None, sa
     gen = torch.Generator(device=device)
     gen.manual_seed(42 + rank)  # base_config.py:74 + scripts/train.py:86: seed + global rank
 
+    if shard:
+        model.before_field = lambda: opts.wait_parameters(late=True)
+
     def step(i):
+        opts.wait_parameters(late=False)  # sharded exchange: everything but the SDF table has to be back before the callbacks touch parameters
         model.before_train_iteration(i)
         o, d, norm, cam = draw_rays(centers, rot, n_rays, gen)
         image = torch.rand(n_rays, 3, device=device, generator=gen)
@@ -292,13 +309,15 @@ def make_job(config, device, world, rank, small=False, hidden=256, rays=None, sa
         loss = functools.reduce(operator.add, model.get_loss_dict(out, {"image": image}).values())  # (sum() would start with 0 + a tensor: a launch)
         flat.zero(loss)  # the loss's graph tells the buckets which gradients to wait for (unused parameters: distributed.py)
         loss.backward()
-        opts.optimizer_step_all(grad_scale=flat.finish(average=False))  # SUM all-reduce; the 1 / world mean rides in the Adam read
+        # closes the exchange chunk by chunk (SUM collectives; the 1 / world mean rides in the Adam read) and, sharded, sends the updated
+        # slices back asynchronously
+        opts.optimizer_step_all(grad_scale=None)
         opts.scheduler_step_all(i)
         model.after_train_iteration(i)
         return loss
 
     return {"model": model, "flat": flat, "groups": groups, "opts": opts, "step": step, "centers": centers, "rot": rot, "gen": gen,
-            "n_rays": n_rays}
+            "n_rays": n_rays, "shard": shard}
 
 
 def timed_steps(job, first, warmup, steps, dominant, world):
@@ -307,17 +326,24 @@ def timed_steps(job, first, warmup, steps, dominant, world):
     from sdfstudio_amd import _lib
 
     step = job["step"]
+    flat, opts = job["flat"], job["opts"]
     for i in range(warmup):
         step(first + i)
+    opts.wait_parameters()
     fence(world)
+    if flat.time_waits:
+        flat.exposed_ms(), flat.exposed_gather_ms()  # reset: what follows belongs to the timed steps
     _lib.profile_enable_only([dominant] if isinstance(dominant, str) else list(dominant))
     t0 = time.perf_counter()
     for i in range(steps):
         loss = step(first + warmup + i)
+    opts.wait_parameters()  # sharded exchange: the last step is complete when its parameters are back on every rank
     fence(world)
     dt = time.perf_counter() - t0
     prof = _lib.profile_collect()
     _lib.profile_enable(False)
+    if flat.time_waits:  # GPU time the compute stream stalled on the exchange, per phase, per step (this rank)
+        job["exposed"] = {"reduce_ms_per_step": sum(flat.exposed_ms()) / steps, "gather_ms_per_step": sum(flat.exposed_gather_ms()) / steps}
     return dt, prof, loss
 
 
@@ -365,7 +391,10 @@ def config5_legs(device, world, rank, steps=10, warmup=3):
         out[name] = {"ms_per_step": round(ms, 3), "value": round(world * P / (dt / steps), 1), "unit": "ray-samples/s",
                      "levels_active": int(job["model"].field._active_levels), "first_step": first,
                      "exchanged_bytes_per_rank": 4 * flat.exchanged_numel(),
-                     "adam_rows_visited": sum(b - a for a, b in flat.live_ranges()),
+                     "gathered_bytes_per_rank": flat.gathered_bytes(),  # sharded exchange only (N > 1)
+                     "exchange_exposed_ms_rank0": job.get("exposed"),
+                     "adam_rows_live": sum(b - a for a, b in flat.live_ranges()),
+                     "adam_rows_visited": job["opts"].adam.last_elements_visited,  # this rank: 1 / N of the live rows when sharded
                      "roofline": encode_roofline_config5(job["model"], prof, steps, P)}
     del job
     torch.cuda.empty_cache()
@@ -404,6 +433,142 @@ def bigmlp_legs(device, world, rank, ms_config2, steps=8, warmup=3):
     return out
 
 
+def collective_report(job, backend, exposed_reduce_by_rank, exposed_gather_by_rank):
+    """The data-parallel exchange of the timed steps, phase by phase: bytes per step per rank and the GPU time the compute stream stalled
+    on each phase (HIP events around the waits, one value per rank)."""
+    flat = job["flat"]
+    shard = job["shard"]
+    n_in = 4 * flat.exchanged_numel()
+    w = flat.world
+    native = backend == "nccl"
+    rep = {"backend": backend, "exchange": "sharded: reduce-scatter -> fused Adam on the owned 1 / N slice -> all-gather" if shard else
+                                          "all-reduce of the flat gradient, replicated Adam",
+           "buckets": len(flat._buckets), "chunk_bytes": None if flat._chunk is None else 4 * flat._chunk,
+           "buckets_launched_during_backward": flat.last_overlapped_buckets, "parameters_outside_the_graph": flat.last_unused,
+           "adam_elements_visited_per_rank": job["opts"].adam.last_elements_visited,
+           "phases": {
+               "reduce": {"collective": ("reduce_scatter" if native else "all_reduce of the grid chunk (gloo has no reduce-scatter: same sum in the owned slice)") if shard else "all_reduce",
+                          "collectives_per_step": flat.last_collectives, "buffer_bytes_per_step_per_rank": n_in,
+                          # ring / direct algorithms move (W - 1) / W of the buffer out of (and into) every rank per reduce-scatter; an all-reduce twice that
+                          "wire_bytes_out_per_rank": int(n_in * (w - 1) / w * (1 if shard else 2)),
+                          "exposed_ms_per_step_by_rank": exposed_reduce_by_rank,
+                          "overlap": "bucket collectives leave in fixed index order from post-accumulate-grad hooks during backward; exposed = GPU "
+                                     "time the compute stream stalled in the chunk waits before the owned slices' Adam"},
+               "gather": None if not shard else {
+                   "collective": "all_gather_into_tensor" if native else "all_gather (list of views)",
+                   "collectives_per_step": flat.last_gather_collectives // max(flat._finished_steps, 1),
+                   "buffer_bytes_per_step_per_rank": flat.gathered_bytes(),
+                   "wire_bytes_out_per_rank": int(flat.gathered_bytes() * (w - 1) / w),
+                   "exposed_ms_per_step_by_rank": exposed_gather_by_rank,
+                   "overlap": "issued after the step's Adam, small buckets first, the SDF table last; the next step waits for the small ones "
+                              "before its callbacks and for the table after its proposal sampling has been enqueued"}}}
+    return rep
+
+
+def sdf_flops_per_point():
+    """2 x MACs of the geometry network of config 2 evaluated for its sdf row alone (SDFHIP_MODE_SDF: the 256 feature rows of the output
+    layer are not computed): 71->256, 2 x 256->256, 256->185, skip layer (185 + 71)->256, 3 x 256->256, 256->1."""
+    return 2 * (71 * 256 + 2 * 256 * 256 + 256 * 185 + 256 * 256 + 3 * 256 * 256 + 256)
+
+
+def dense_sdf_leg(model, device, resolution=(512, 512, 256), reps=3):
+    """SURVEY row f4, the compute-bound inference path: `utils/marching_cubes.sdf_on_grid` (the device side of scripts/extract_mesh.py:94-133
+    / utils/marching_cubes.py:15-168) over a 2^26-point lattice on config 2's network - hash-grid encode + the sdf row of the 8 x 256 geometry
+    MLP, nothing saved, nothing read back but the sdf.  `roofline` is the MFMA kernel (geo_fwd_kernel, inference instantiation): algorithmic
+    flops of the sdf row x the 3 split-precision terms issued per product / its launch time (HIP events on the launch stream, all launches of
+    the timed repetitions), against the dense 16-bit MFMA peak."""
+    from sdfstudio_amd import _lib
+    from sdfstudio_amd.utils.marching_cubes import sdf_on_grid
+
+    field = model.field
+    lo, hi = (-1.0, -1.0, -1.0), (1.0, 1.0, 1.0)
+    P = resolution[0] * resolution[1] * resolution[2]
+    with torch.no_grad():
+        sdf_on_grid(field, lo, hi, (64, 64, 64), device=device)  # sizes the allocator
+        sdf_on_grid(field, lo, hi, resolution, device=device)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            vol = sdf_on_grid(field, lo, hi, resolution, device=device)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / reps
+        # a second, instrumented pass: events on the two kernels of the path
+        _lib.profile_enable_only(["geo_fwd_kernel", "geo_encode_kernel"])
+        for _ in range(reps):
+            sdf_on_grid(field, lo, hi, resolution, device=device)
+        torch.cuda.synchronize()
+        prof = _lib.profile_collect()
+        _lib.profile_enable(False)
+    assert bool(torch.isfinite(vol).all()), "dense sdf: non-finite values"
+    g = sdf_flops_per_point()
+    k_ms, k_n = prof.get("geo_fwd_kernel", (0.0, 0))
+    e_ms, _ = prof.get("geo_encode_kernel", (0.0, 0))
+    k_s = k_ms / reps * 1e-3
+    issued = 3 * g * P / k_s / 1e12 if k_s > 0 else 0.0
+    enc_bytes = (16 * 8 * 2 * 4 + 12 + 3 * 128) * P  # gather + position in + the tile-packed in0 (3 blocks) out
+    return {"workload": f"sdf_on_grid: {resolution[0]} x {resolution[1]} x {resolution[2]} = 2^{int(math.log2(P))} lattice points, config 2's field "
+                        "(16x2x2^19 smoothstep grid + 8x256 geometry MLP, sdf row only), no grad, nothing saved",
+            "points": P, "ms": round(wall * 1e3, 3), "value": round(P / wall, 1), "unit": "points/s",
+            "kernels_ms": {"geo_fwd_kernel": round(k_ms / reps, 3), "geo_encode_kernel": round(e_ms / reps, 3)},
+            "launches": k_n // reps if reps else 0,
+            "roofline": {"kernel": "geo_fwd_kernel<..., GRAD = false, SAVE = false, FEAT = false> (SDFHIP_MODE_SDF)", "bound": "mfma",
+                         "achieved": round(issued, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(issued / PEAK_BF16_MFMA_TFLOPS, 4),
+                         "achieved_is": f"sdf-row flops {g / 1e6:.3f} MFLOP per point x 3 issued 16-bit MFMA terms per fp32-class product x "
+                                        "points / the kernel's launch time (HIP events)",
+                         "flops_per_point": g, "terms_per_product": 3, "points_per_s_kernel_only": round(P / k_s, 1) if k_s > 0 else None,
+                         "traffic": None},
+            "encode": {"GBps_on_gather_bytes": round(enc_bytes / (e_ms / reps * 1e-3) / 1e9, 1) if e_ms > 0 else None,
+                       "bytes_per_point": enc_bytes // P}}
+
+
+def forward_only_leg(job, device, n_rays, n_samples, reps=10):
+    """the eval-mode render (no grad, nothing saved for a backward) of one batch, timed as a whole and - in a second,
+    instrumented pass - per kernel.  Its MFMA roofline: forward G, analytic-normal chain G, colour C per ray-sample, 3 issued terms."""
+    from sdfstudio_amd import _lib
+    from sdfstudio_amd.cameras.rays import RayBundle
+
+    model = job["model"]
+    model.eval()
+    o, d, norm, cam = draw_rays(job["centers"], job["rot"], n_rays, job["gen"])
+    rb_eval = RayBundle(origins=o, directions=d, directions_norm=norm, camera_indices=cam[:, None])
+    with torch.no_grad():
+        for _ in range(2):  # the first calls size the caching allocator for the forward-only workspace
+            model(rb_eval)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            model(rb_eval)
+        torch.cuda.synchronize()
+        fwd_ms = (time.perf_counter() - t1) / reps * 1e3
+        _lib.profile_enable(True)
+        for _ in range(reps):
+            model(rb_eval)
+        torch.cuda.synchronize()
+        prof = _lib.profile_collect()
+        _lib.profile_enable(False)
+    model.train()
+    P = n_rays * n_samples
+    g, c = flops_per_sample()
+    kernels = {k: round(v[0] / reps, 4) for k, v in prof.items()}
+    mfma_ms = sum(prof.get(k, (0.0, 0))[0] for k in ("geo_fwd_kernel", "col_fwd_kernel")) / reps
+    issued = 3 * (2 * g + c) * P / (mfma_ms * 1e-3) / 1e12 if mfma_ms > 0 else 0.0
+    # bytes of the forward -> chain hand-over: the chain runs top-down over s'(z_l) of EVERY layer, 8 x 256 floats per point, which no
+    # on-chip store of a 128-point workgroup holds (1 MB): written by the forward launch, read by the chain launch
+    handover = 2 * 8 * 256 * 4 * P
+    return {"value": round(P / (fwd_ms * 1e-3), 1), "unit": "ray-samples/s per GPU (eval-mode render, no grad)", "ms_per_batch": round(fwd_ms, 3),
+            "kernels_ms_per_batch": kernels,
+            "roofline": {"kernel": "geo_fwd_kernel (forward launch + chain launch, nothing saved) + col_fwd_kernel", "bound": "mfma",
+                         "achieved": round(issued, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(issued / PEAK_BF16_MFMA_TFLOPS, 4),
+                         "achieved_is": "(2G + C) flops per ray-sample x 3 issued 16-bit MFMA terms / the three launches' time (HIP events, "
+                                        "instrumented pass)",
+                         "mfma_kernels_ms": round(mfma_ms, 3), "traffic": None,
+                         "forward_to_chain_handover_bytes": handover,
+                         "handover_note": "u_l = s(z_l) of all 8 layers, 8 KiB per point: written by the forward launch, read by the chain "
+                                          "launch (DESIGN.md section 4.1: why no on-chip store holds it)"}}
+
+
 def run(args):
     global N_RAYS, N_SAMPLES
     if args.small:
@@ -440,6 +605,17 @@ def run(args):
     job = make_job(5 if cfg5 else 2, device, world, rank, small=args.small)
     model, flat, groups = job["model"], job["flat"], job["groups"]
     step = job["step"]
+    if getattr(args, "only", None) == "inference":
+        # the two inference legs alone (same functions, same model as the default run): same-box A/Bs of library variants and the PMC
+        # passes of profiles/r5_eval_* run this, so that every launch they see belongs to an inference path
+        from sdfstudio_amd import build as _build
+
+        out = {"library_digest": _build.built_digest() or None, "library": _lib.LIB_PATH,
+               "forward_only": None if args.no_forward_only else forward_only_leg(job, device, N_RAYS, N_SAMPLES),
+               "dense_sdf": None if args.no_dense_sdf else dense_sdf_leg(model, device, reps=args.steps if args.steps < 20 else 3)}
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        return
     first = (200000 if args.levels == 16 else 0) if cfg5 else 0  # config 5: where in the preset's schedules the timed steps sit
     # Timed region: HIP events on the launches of the DOMINANT kernel only (the roofline figure must come from these steps).  An event
     # pair serialises the command stream around its launch; with every launch instrumented the step measured ~1 ms longer, so the
@@ -461,33 +637,24 @@ def run(args):
         _lib.profile_enable(False)
     # SDFHIP_BENCH_ALLOW_NONFINITE=1: timing ablation builds (tools/build_variant.sh -DSDFHIP_ABL_*) compute wrong numbers on purpose
     assert math.isfinite(float(loss.detach())) or os.environ.get("SDFHIP_BENCH_ALLOW_NONFINITE") == "1", "training diverged"
+    final_loss = float(loss.detach())
     # forward-only leg (eval-mode render, reported separately; outside the timed training region)
-    fwd_ms = float("nan")
+    fwd_only = None
     if not args.no_forward_only:
-        from sdfstudio_amd.cameras.rays import RayBundle
-
-        model.eval()
-        centers, rot, gen = job["centers"], job["rot"], job["gen"]
-        o, d, norm, cam = draw_rays(centers, rot, N_RAYS, gen)
-        rb_eval = RayBundle(origins=o, directions=d, directions_norm=norm, camera_indices=cam[:, None])
-        with torch.no_grad():
-            for _ in range(2):  # the first calls size the caching allocator for the forward-only workspace
-                model(rb_eval)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(10):
-                model(rb_eval)
-            torch.cuda.synchronize()
-        fwd_ms = (time.perf_counter() - t1) / 10 * 1e3
-        model.train()
+        fwd_only = forward_only_leg(job, device, N_RAYS, N_SAMPLES)
+    dense = None
+    if not cfg5 and not args.small and not args.no_dense_sdf:
+        dense = dense_sdf_leg(model, device)
     t = torch.tensor([dt], device=device, dtype=torch.float64)
-    exposed_by_rank = None
+    exposed_by_rank = exposed_gather_by_rank = None
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ex = flat.exposed_ms()[-args.steps:]  # the timed steps
-        allr = torch.zeros(world, device=device, dtype=torch.float64)  # all_reduce of a one-hot vector: works on RCCL and on gloo alike
-        allr[rank] = sum(ex) / max(len(ex), 1)
+        ex = job.get("exposed", {"reduce_ms_per_step": 0.0, "gather_ms_per_step": 0.0})
+        allr = torch.zeros(2, world, device=device, dtype=torch.float64)  # all_reduce of one-hot rows: works on RCCL and on gloo alike
+        allr[0, rank], allr[1, rank] = ex["reduce_ms_per_step"], ex["gather_ms_per_step"]
         dist.all_reduce(allr)
+        exposed_gather_by_rank = [round(float(v), 4) for v in allr[1].tolist()]
+        allr = allr[0]
         exposed_by_rank = [round(float(v), 4) for v in allr.tolist()]
     dt = float(t.item())
     cfg5_extra = None
@@ -610,16 +777,10 @@ def run(args):
             "encode_roofline": enc,
             "config5": cfg5_extra,
             "bigmlp": bigmlp_extra,
-            "collective": None if world == 1 else {"backend": dist.get_backend(), "buckets": len(groups),
-                                                    "bytes_per_step_per_rank": 4 * flat.exchanged_numel(),
-                                                    "collectives_per_step": flat.last_collectives,
-                                                    "buckets_launched_during_backward": flat.last_overlapped_buckets,
-                                                    "parameters_outside_the_graph": flat.last_unused,
-                                                    "exposed_ms_per_step_by_rank": exposed_by_rank,
-                                                    "overlap": "bucket all-reduces leave in fixed index order from post-accumulate-grad hooks during "
-                                                               "backward; exposed = GPU time the compute stream stalled in finish()"},
-            "forward_only": {"value": round(N_RAYS * N_SAMPLES / (fwd_ms * 1e-3), 1), "unit": "ray-samples/s per GPU (eval-mode render, no grad)",
-                             "ms_per_batch": round(fwd_ms, 3)},
+            "collective": None if world == 1 else collective_report(job, dist.get_backend(), exposed_by_rank, exposed_gather_by_rank),
+            "forward_only": fwd_only,
+            "dense_sdf": dense,
+            "final_loss": float(final_loss),
             "model_tflops": round(train_flops * P / (ms * 1e-3) / 1e12, 2),
             "mfma_kernels_ms_per_step": round(mfma_ms, 3),
             "kernels": kernels,

@@ -80,9 +80,9 @@ __global__ __launch_bounds__(256, 1) void col_fwd_kernel(const ColFwdArgs a) {
     float* hprev = a.h_tp[l - 1];
     auto make = [&](auto kbc, const Raw&, auto ec) __attribute__((always_inline)) {
       constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
-      const float h = fmaxf(accIn[kb][e], 0.0f);
+      const float h = act_h<1, NS == 4>(accIn[kb][e]);  // ReLU, bounded for fp16 operand parts by the same v_med3_f32
       if constexpr (SAVE) *tp_elem(hprev, tile, D::NBC, kb, e, lane) = h;
-      return h;
+      return InRange{h};
     };
     tp_gemm<D::NBC, D::NBC, Stores<(SAVE ? 16 : 0)>, NS, PCS>(accOut, carry, NoFetch{}, make, NoFetch{}, ws, a.p.wp[l],
                                                               a.p.wp[l + 1 < NLC ? l + 1 : l]);

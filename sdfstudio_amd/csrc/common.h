@@ -67,11 +67,28 @@ SDFHIP_D float softplus100_d1(float z) {
   const float ds = e * __builtin_amdgcn_rcpf(1.0f + e);
   return z > kSp100Thr ? 1.0f : ds;
 }
+// h alone, in the overflow-free form  softplus(z) = max(z, 0) + log(1 + e^{-|100 z|}) / 100  (round 5): the exponential's argument is never
+// positive, so no branch has to be discarded - multiply (the |.| and the sign ride in the instruction's source modifiers), exp, add, log, one
+// clamp, one fma: six vector instructions where the select form took seven, and for 0 < 100 z < 20 the sum z + (small) is closer to aten's
+// log1p(exp(.)) than log2(1 + e^{100 z}) ln2 / 100 was.  Above the threshold (100 z > 20) the correction is < 2.1e-11, below half an ulp of
+// z >= 0.2: the result is z exactly, like aten's linear branch.  HI bounds the result from above in the same instruction as the max with 0
+// (v_med3_f32): producers that hand the value to fp16 operand parts pass 65504 (mlp_core.h InRange) and need no clamp of their own.
+#ifndef SDFHIP_OLD_SOFTPLUS
+template <bool CLAMP16 = false>
+SDFHIP_D float softplus100_h(float z) {
+  const float e = __builtin_amdgcn_exp2f(__builtin_fabsf(z) * -kSp100Log2e);
+  const float l = __builtin_amdgcn_logf(1.0f + e);
+  return __builtin_fmaf(l, 0.69314718055994530942f * 0.01f, __builtin_amdgcn_fmed3f(z, 0.0f, CLAMP16 ? 65504.0f : __builtin_inff()));
+}
+#else  // the select form of rounds 1 - 4 (A/B builds)
+template <bool CLAMP16 = false>
 SDFHIP_D float softplus100_h(float z) {
   const float e = __builtin_amdgcn_exp2f(z * kSp100Log2e);
   const float hs = __builtin_amdgcn_logf(1.0f + e) * (0.69314718055994530942f * 0.01f);
-  return z > kSp100Thr ? z : hs;
+  const float h = z > kSp100Thr ? z : hs;
+  return CLAMP16 ? __builtin_amdgcn_fmed3f(h, -65504.0f, 65504.0f) : h;
 }
+#endif
 
 // s'(z) recovered from the SAVED ACTIVATION h = softplus(z) (round 3: the fused kernels save h_l, not z_l): e^{100 h} = 1 + e^{100 z}, so
 //   s'(z) = e^{100 z} / (1 + e^{100 z}) = 1 - e^{-100 h}
@@ -85,10 +102,12 @@ SDFHIP_D float softplus100_d1_from_h(float h) { return 1.0f - __builtin_amdgcn_e
 //   0  Softplus(beta = 100)   the SDF field (sdf_field.py:290, 409)
 //   1  ReLU                   the background fields (field_components/mlp.py:93 of NeRFField; tcnn's FullyFusedMLP in TCNNNerfactoField)
 // act_d1 is the derivative the first-order backward multiplies with; second-order passes exist for ACT = 0 only.
-template <int ACT>
+// CLAMP16: the result is handed to fp16 operand parts (precision mode 4) - bound it by fp16's largest finite value in the activation's own
+// max / min instruction (v_med3_f32), so that the split needs no clamp of its own (mlp_core.h: InRange)
+template <int ACT, bool CLAMP16 = false>
 SDFHIP_D float act_h(const float z) {
-  if constexpr (ACT == 1) return fmaxf(z, 0.0f);
-  else return softplus100_h(z);
+  if constexpr (ACT == 1) return __builtin_amdgcn_fmed3f(z, 0.0f, CLAMP16 ? 65504.0f : __builtin_inff());
+  else return softplus100_h<CLAMP16>(z);
 }
 template <int ACT>
 SDFHIP_D float act_d1(const float z) {

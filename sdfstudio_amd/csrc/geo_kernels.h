@@ -164,11 +164,11 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
       float* uprev = a.u_tp[l - 1];
       auto make = [&](auto kbc, const Raw&, auto ec) __attribute__((always_inline)) {
         constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
-        const float h = act_h<D::ACT>(accIn[kb][e]);
+        const float h = act_h<D::ACT, NS == 4>(accIn[kb][e]);  // bounded for fp16 operand parts in the activation's own clamp
 #ifndef SDFHIP_ABL_FWD_NOSTORE  // timing ablation: the forward launch without its activation stores
         if constexpr (SAVE || GRAD) *tp_elem(uprev, tile, D::NBH, kb, e, lane) = h;
 #endif
-        return h;
+        return InRange{h};
       };
       const float* nxt = l == SKIP ? geo_skip_in0<D>(a.p.wp[l]) : (l + 1 < NL ? a.p.wp[l + 1] : after_last);
       tp_gemm<D::NBH, D::NBH, Stores<ZS>, NS, PCS>(accOut, carry, NoFetch{}, make, in0_blk0, ws, a.p.wp[l], nxt);
@@ -192,10 +192,10 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
     const float* wsdf = cvec + (NL + 1) * W;
     auto make = [&](auto kbc, const Raw&, auto ec) __attribute__((always_inline)) {
       constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
-      const float h = act_h<D::ACT>(accIn[kb][e]);
+      const float h = act_h<D::ACT, NS == 4>(accIn[kb][e]);
       if constexpr (SAVE || GRAD) *tp_elem(ulast, tile, D::NBH, kb, e, lane) = h;
       part = fmaf(wsdf[kb * 32 + tp_row(e, hf)], h, part);
-      return h;
+      return InRange{h};
     };
     if constexpr (FEAT) {
 #pragma unroll

@@ -169,9 +169,23 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-template <int NS, int E>
+// A producer whose value is known to lie inside fp16's finite range (an activation bounded on the way: common.h act_h<ACT, true>)
+// returns it wrapped in InRange: the split then skips the saturation (one v_med3_f32 per element).
+struct InRange {
+  float v;
+};
+// lo parts of an fp16 hi / lo pair:  lo_i = fp16(x_i - hi_i).  The difference is formed and rounded by ONE instruction per element,
+// v_fma_mix{lo,hi}_f16 (hi_i (f16) * -1 + x_i in fp32 - exact here - rounded to nearest even into the low / high half of the result):
+// the same numbers as "convert hi back to fp32, subtract, packed conversion" (rounds 1 - 4: 2 + 2 + 1 instructions per pair).
+SDFHIP_D uint32_t f16_lo_pair(const uint32_t hpk, const float x0, const float x1) {
+  uint32_t l;
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(hpk), "v"(x0));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(hpk), "v"(x1));
+  return l;
+}
+template <int NS, int E, bool CLAMP = true>
 SDFHIP_D void split_put(SplitBlk<NS>& s, float r) {
-  if constexpr (NS == 4) r = __builtin_amdgcn_fmed3f(r, -65504.0f, 65504.0f);  // fp16 has no exponent headroom: saturate instead of inf
+  if constexpr (NS == 4 && CLAMP) r = __builtin_amdgcn_fmed3f(r, -65504.0f, 65504.0f);  // fp16 has no exponent headroom: saturate instead of inf
   if constexpr ((E & 1) == 0) {
     s.pend = r;
   } else {
@@ -185,10 +199,14 @@ SDFHIP_D void split_put(SplitBlk<NS>& s, float r) {
       dst = __builtin_bit_cast(bf16x8, t);
     };
     if constexpr (NS == 4) {
-      const f16x2_t h = __builtin_convertvector(v, f16x2_t);
-      const f16x2_t l = __builtin_convertvector(v - __builtin_convertvector(h, f32x2_t), f16x2_t);
-      put(s.p[0][kk], __builtin_bit_cast(uint32_t, h));
+      const uint32_t h = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+      put(s.p[0][kk], h);
+#ifndef SDFHIP_OLD_SPLIT
+      put(s.p[1][kk], f16_lo_pair(h, v[0], v[1]));
+#else
+      const f16x2_t l = __builtin_convertvector(v - __builtin_convertvector(__builtin_bit_cast(f16x2_t, h), f32x2_t), f16x2_t);
       put(s.p[1][kk], __builtin_bit_cast(uint32_t, l));
+#endif
     } else {
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
@@ -198,6 +216,10 @@ SDFHIP_D void split_put(SplitBlk<NS>& s, float r) {
       }
     }
   }
+}
+template <int NS, int E>
+SDFHIP_D void split_put(SplitBlk<NS>& s, const InRange r) {
+  split_put<NS, E, false>(s, r.v);
 }
 
 template <int KB, int NBO, class ST, int NS, int NEXTP, int MAXA, class Fetch, class Make, class NextFetch>

@@ -28,6 +28,17 @@ every model of the family.  ``zero(loss)`` therefore walks the grap
 with ``find_unused_parameters=True`` (pipelines/base_pipeline.py:242), and arms every bucket with the parameters that are REACHABLE;
 the unreachable ones contribute the zeros ``zero()`` left.  (The walk visits ~10^2 nodes: the whole field is one autograd node.)
 
+Sharded mode (``shard=True``, round 5; SURVEY 8(e): "reduce-scatter + all-gather over all 7 links"): the exchange sized for BASELINE
+config 5, whose 1.8 GB table cannot hide an all-reduce behind a 10 ms step.  The flat buffer is cut into a FIXED grid of chunks (per
+bucket, anchored at the bucket's start, every chunk a multiple of the world size W); rank r OWNS elements [r n / W, (r + 1) n / W) of
+every chunk of n elements.  A chunk's gradients are reduce-scattered (RCCL, in place: each rank receives the sum of its own slice), the
+fused Adam step runs on the owned slices only - moments exist for 1 / W of the parameters - and the updated slices are all-gathered
+into every rank's parameter buffer (``gather_parameters`` / ``wait_parameters``), which may overlap the start of the next step.  Same
+bytes over xGMI as the all-reduce (which IS a reduce-scatter followed by an all-gather), but the optimiser's HBM traffic and state
+divide by W and the second half of the exchange moves off the critical path.  The ownership grid never depends on the active prefix:
+a level that is switched on later finds its moments where they will always be.  Backends without reduce-scatter (gloo: the CPU tests
+and the single-GPU control-flow runs) emulate it with an all-reduce of the chunk - the owned slice then holds the same sum.
+
 Protocol per step: ``zero(loss)`` -> one backward of that loss -> ``finish()``.  Anything else raises: a second backward before
 ``finish()`` would accumulate into slices that are being reduced, a backward without ``zero()`` would mix last step's means with new
 local sums.  (``zero()`` without the loss keeps the conservative count - every parameter pending - which is correct and overlaps only
@@ -52,22 +63,55 @@ def _dist_on(group=None) -> bool:
 
 class FlatGradients:
     def __init__(self, params: Iterable[torch.nn.Parameter], buckets: Optional[Sequence[Sequence[torch.nn.Parameter]]] = None,
-                 group=None, overlap: bool = True, chunk_numel: Optional[int] = 32 * 1024 * 1024):
+                 group=None, overlap: bool = True, chunk_numel: Optional[int] = 32 * 1024 * 1024, shard: bool = False,
+                 late_buckets: Sequence[int] = ()):
         """params: every parameter whose gradient lives in the flat buffer, in buffer order.  buckets: a partition of them
         into exchange units (default: one bucket); each bucket's parameters must be contiguous in `params`.  chunk_numel: a
         bucket's ranges travel in pieces of at most this many elements (128 MB by default: config 2's 50 MB field bucket is one
         collective, config 5's 1.8 GB table is 14, so the ring starts delivering finished pieces while later ones are in
-        flight and no single collective monopolises the links); None: one collective per contiguous range."""
+        flight and no single collective monopolises the links); None: one collective per contiguous range.
+        shard: reduce-scatter / owned-slice optimiser / all-gather instead of all-reduce (module docstring); the buckets must then be
+        listed in buffer order, and every bucket is padded to a multiple of 64 W elements (zeros: no parameter lives there).
+        late_buckets (sharded mode): indices of buckets whose parameters the next step needs LAST (the big hash table: after the proposal
+        sampling): their all-gathers are issued after everybody else's and wait_parameters(late=False) leaves them in flight."""
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
-        total = sum(p.numel() for p in self.params)
+        self.shard = bool(shard)
+        self.world = dist.get_world_size(group) if _dist_on(group) else 1
+        self.rank = dist.get_rank(group) if _dist_on(group) else 0
+        if buckets is None:
+            buckets = [self.params]
+        self._buckets: List[List[torch.nn.Parameter]] = [[p for p in b if p.requires_grad] for b in buckets]
+        self._buckets = [b for b in self._buckets if b]
+        assert sorted(id(p) for b in self._buckets for p in b) == sorted(id(p) for p in self.params), "buckets must partition the parameters"
+        if self.shard:
+            assert [id(p) for b in self._buckets for p in b] == [id(p) for p in self.params], \
+                "shard=True: list the buckets in buffer order (the ownership grid is anchored at every bucket's start)"
+        # layout: parameters back to back; in sharded mode every bucket ends on a multiple of the quantum (64 W elements: every owned
+        # slice is a whole number of 256-byte lines) so that each chunk of the grid divides evenly among the ranks
+        self._quantum = 64 * self.world if self.shard else 1
+        self._offset: Dict[int, int] = {}
+        self._span: List[List[int]] = [[0, 0] for _ in self._buckets]  # [start, end) of every bucket incl. its padding (sharded mode)
+        if self.shard:
+            off = 0
+            for bi, b in enumerate(self._buckets):
+                self._span[bi][0] = off
+                for p in b:
+                    self._offset[id(p)] = off
+                    off += p.numel()
+                off = (off + self._quantum - 1) // self._quantum * self._quantum
+                self._span[bi][1] = off
+            total = off
+        else:
+            off = 0
+            for p in self.params:
+                self._offset[id(p)] = off
+                off += p.numel()
+            total = off
+            for bi, b in enumerate(self._buckets):
+                self._span[bi] = [self._offset[id(b[0])], self._offset[id(b[-1])] + b[-1].numel()]
         dev = self.params[0].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
-        self._offset: Dict[int, int] = {}
-        off = 0
-        for p in self.params:
-            self._offset[id(p)] = off
-            off += p.numel()
         self._active: Dict[int, int] = {}
         self._active_fn = {}  # id(param) -> (param, callable): the active size is re-read at every zero() (track_active)
         self._all_live = False  # sticky: set by mark_all_live() (optimizer state loaded): never skip a suffix again
@@ -76,12 +120,6 @@ class FlatGradients:
         self._hwm: Dict[int, int] = {}
         self._finished_steps = 0
         self._attach()
-        if buckets is None:
-            buckets = [self.params]
-        self._buckets: List[List[torch.nn.Parameter]] = [[p for p in b if p.requires_grad] for b in buckets]
-        self._buckets = [b for b in self._buckets if b]
-        seen = [id(p) for b in self._buckets for p in b]
-        assert sorted(seen) == sorted(self._offset), "buckets must partition the parameters"
         for b in self._buckets:
             offs = [self._offset[id(p)] for p in b]
             assert offs == sorted(offs) and all(offs[i] + b[i].numel() == offs[i + 1] for i in range(len(b) - 1)), \
@@ -96,6 +134,12 @@ class FlatGradients:
         self._work = []
         self._overlap = overlap
         self._chunk = None if chunk_numel is None else max(int(chunk_numel), 1)
+        if self.shard:  # the grid's chunk: a multiple of the quantum (None: one chunk per bucket)
+            self._chunk = None if self._chunk is None else max(self._chunk // self._quantum, 1) * self._quantum
+        self._late = set(int(i) for i in late_buckets)
+        self._gather_work = []   # in-flight parameter all-gathers (sharded mode): (work, a, b, late)
+        self._gather_events = []
+        self.last_gather_collectives = 0
         # diagnostics of the last step (bench.py prints them per rank): seconds finish() spent blocked in work.wait(), collectives
         # issued, buckets that left from the autograd hooks (i.e. overlapped with the rest of backward)
         self.last_wait_s = 0.0
@@ -223,8 +267,8 @@ class FlatGradients:
         self.last_collectives = 0
         self.last_unused = 0 if used is None else sum(1 for p in self.params if id(p) not in used)
 
-    def _ranges(self, bi):
-        """Contiguous [start, end) element ranges of bucket bi that have to travel, cut into chunks of at most chunk_numel."""
+    def _raw_ranges(self, bi):
+        """Contiguous [start, end) element ranges of bucket bi that can carry a gradient in this step (the active prefixes)."""
         out = []
         for p in self._buckets[bi]:
             off = self._offset[id(p)]
@@ -237,14 +281,67 @@ class FlatGradients:
                 out.append([off, off + n])
             if n < p.numel():  # a gap follows: the next parameter starts a new range
                 out.append([off + p.numel(), off + p.numel()])
+        return [(a, b) for a, b in out if b > a]
+
+    def _grid(self, bi):
+        """Sharded mode: the FIXED chunks [start, end) of bucket bi (anchored at the bucket's start; every length a multiple of W)."""
+        a0, b0 = self._span[bi]
+        step = (b0 - a0) if self._chunk is None else self._chunk
+        return [(s, min(s + step, b0)) for s in range(a0, b0, max(step, 1))]
+
+    def _ranges(self, bi):
+        """What travels for bucket bi.  All-reduce mode: the active ranges, cut into chunks of at most chunk_numel.  Sharded mode: the
+        chunks of the fixed grid that intersect an active range, WHOLE (what lies beyond the active prefix inside such a chunk is zero
+        on every rank; the grid - and with it the ownership of every element - never moves)."""
+        raw = self._raw_ranges(bi)
+        if self.shard:
+            return [(a, b) for a, b in self._grid(bi) if any(ra < b and a < rb for ra, rb in raw)]
         cut = []
-        for a, b in out:
-            if b <= a:
-                continue
+        for a, b in raw:
             step = (b - a) if self._chunk is None else self._chunk
             for s in range(a, b, step):
                 cut.append((s, min(s + step, b)))
         return cut
+
+    def owned(self, a: int, b: int):
+        """The slice [oa, ob) of grid chunk [a, b) this rank owns (sharded mode; everything otherwise)."""
+        if not self.shard or self.world == 1:
+            return a, b
+        n = (b - a) // self.world
+        return a + self.rank * n, a + (self.rank + 1) * n
+
+    def owned_slices(self):
+        """Every slice of the flat buffer this rank owns, with its offset in the rank-local moment buffers: [(a, b, local_offset)], in
+        buffer order over the WHOLE grid (independent of the active prefix).  All-reduce mode: one slice, the buffer itself."""
+        if not self.shard or self.world == 1:
+            return [(0, self.flat.numel(), 0)]
+        out, loc = [], 0
+        for bi in range(len(self._buckets)):
+            for a, b in self._grid(bi):
+                oa, ob = self.owned(a, b)
+                out.append((oa, ob, loc))
+                loc += ob - oa
+        return out
+
+    def local_numel(self) -> int:
+        """Elements of optimiser state this rank keeps (sharded mode: 1 / W of the padded buffer)."""
+        return sum(b - a for a, b, _ in self.owned_slices())
+
+    def owned_live(self):
+        """owned_slices() intersected with live_ranges(): what the optimiser step of THIS rank visits."""
+        live = self.live_ranges()
+        out = []
+        for a, b, loc in self.owned_slices():
+            for la, lb in live:
+                x, y = max(a, la), min(b, lb)
+                if y > x:
+                    out.append((x, y, loc + (x - a)))
+        return out
+
+    def _use_reduce_scatter(self) -> bool:
+        # gloo has no reduce_scatter_tensor: an all-reduce of the chunk leaves the same sum in the owned slice (CPU tests, and the
+        # single-GPU control-flow runs of bench.py with SDFHIP_BENCH_BACKEND=gloo)
+        return self.shard and dist.get_backend(self.group) == "nccl" and os.environ.get("SDFHIP_SHARD_EMULATE") != "1"
 
     def _launch(self, bi):
         assert bi == self._next and not self._launched[bi], "buckets leave in index order"
@@ -252,8 +349,14 @@ class FlatGradients:
         self._next = bi + 1
         if not _dist_on(self.group):
             return
+        rs = self._use_reduce_scatter()
         for a, b in self._ranges(bi):
-            self._work.append((dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True), a, b))
+            if rs:  # in place: this rank's slice of the chunk receives the sum over the ranks (ncclReduceScatter with recv = send + rank * count)
+                oa, ob = self.owned(a, b)
+                work = dist.reduce_scatter_tensor(self.flat[oa:ob], self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            else:
+                work = dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._work.append((work, a, b))
             self.last_collectives += 1
 
     def _launch_ready(self, from_hook: bool):
@@ -285,7 +388,7 @@ class FlatGradients:
         if self._overlap:
             self._launch_ready(from_hook=True)
 
-    def finish(self, average: bool = True) -> float:
+    def finish(self, average: bool = True, wait: bool = True) -> float:
         """Wait for the outstanding bucket all-reduces (launching, in index order, every bucket that has not left yet: e.g. one
         behind a bucket with parameters unused in this step).  average=True turns the sums into means in place; average=False
         leaves the SUMS and returns the scale (1 / world_size) for the consumer to apply - the fused Adam step multiplies the
@@ -317,6 +420,12 @@ class FlatGradients:
         if _dist_on(self.group):
             w = dist.get_world_size(self.group)
             scale = 1.0 / w
+            if not wait:
+                # the consumer (FusedAdam.step in sharded mode) takes the collectives chunk by chunk: pop_work()
+                assert not average, "finish(wait=False) hands over SUMS"
+                self._armed = False
+                self._finished_steps += 1
+                return scale
             ev = None
             if self.time_waits and self.flat.is_cuda:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -335,15 +444,98 @@ class FlatGradients:
         self._finished_steps += 1
         return 1.0 if average else scale
 
+    def pop_work(self):
+        """After finish(wait=False): the in-flight gradient collectives [(work, a, b)] in launch order; the caller waits for each before it
+        reads the chunk (its owned slice, in sharded mode).  wait_chunk() does the wait with the exposed-time bookkeeping of finish()."""
+        work, self._work = self._work, []
+        return work
+
+    def wait_chunk(self, work):
+        ev = None
+        if self.time_waits and self.flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        t0 = time.perf_counter()
+        work.wait()
+        self.last_wait_s += time.perf_counter() - t0
+        if ev is not None:
+            ev[1].record()
+            self._wait_events.append(ev)
+
+    # ---- sharded mode: parameters travel back
+    def gather_chunks(self, with_late: bool = False):
+        """Grid chunks whose parameters an optimiser step may have changed on SOME rank: those that intersect live_ranges(), in buffer
+        order (everything else has zero gradient and zero moments everywhere: no update, nothing to send)."""
+        live = self.live_ranges()
+        out = []
+        for bi in range(len(self._buckets)):
+            for a, b in self._grid(bi):
+                if any(la < b and a < lb for la, lb in live):
+                    out.append((a, b, bi in self._late) if with_late else (a, b))
+        return out
+
+    def gather_parameters(self, flat_params: torch.Tensor):
+        """All-gather the owned slices of gather_chunks() of the flat PARAMETER buffer (same layout as the gradient buffer) into every
+        rank's copy, asynchronously, in the order the next step needs them - the late buckets (the big table) last: wait_parameters()
+        before anything reads the parameters again.  In place (RCCL: ncclAllGather with send = recv + rank * count); gloo takes a list of
+        views of the chunk."""
+        if not (self.shard and _dist_on(self.group)):
+            return
+        assert flat_params.numel() == self.flat.numel(), "the parameter buffer must mirror the gradient buffer's layout"
+        native = dist.get_backend(self.group) == "nccl" and os.environ.get("SDFHIP_SHARD_EMULATE") != "1"
+        chunks = self.gather_chunks(with_late=True)
+        for a, b, late in sorted(chunks, key=lambda c: c[2]):  # stable: buffer order within each class
+            oa, ob = self.owned(a, b)
+            if native:
+                work = dist.all_gather_into_tensor(flat_params[a:b], flat_params[oa:ob], group=self.group, async_op=True)
+            else:
+                n = ob - oa
+                views = [flat_params[a + r * n:a + (r + 1) * n] for r in range(self.world)]
+                work = dist.all_gather(views, flat_params[oa:ob].clone(), group=self.group, async_op=True)
+            self._gather_work.append((work, a, b, late))
+            self.last_gather_collectives += 1
+
+    def wait_parameters(self, late: bool = True):
+        """Wait for the in-flight parameter all-gathers: all of them, or (late=False) all but the late buckets', which stay in flight until
+        a later call.  The wait is a stream wait: GPU work enqueued BEFORE this call overlaps the gathers."""
+        if not self._gather_work:
+            return
+        keep, ev = [], None
+        if self.time_waits and self.flat.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        for item in self._gather_work:
+            if item[3] and not late:
+                keep.append(item)
+            else:
+                item[0].wait()
+        if ev is not None:
+            ev[1].record()
+            self._gather_events.append(ev)
+        self._gather_work = keep
+
+    def gathered_bytes(self) -> int:
+        return 4 * sum(b - a for a, b in self.gather_chunks()) if self.shard else 0
+
     all_reduce_mean = finish
 
     def exposed_ms(self, reset: bool = True) -> List[float]:
-        """GPU milliseconds the compute stream stalled on the exchange in every finish() since the last reset (time_waits)."""
+        """GPU milliseconds the compute stream stalled on the gradient exchange in every wait since the last reset (time_waits): one
+        entry per finish(), or per chunk wait in sharded mode (sum them per step)."""
         if self._wait_events:
             torch.cuda.synchronize(self.flat.device)
         out = [a.elapsed_time(b) for a, b in self._wait_events]
         if reset:
             self._wait_events = []
+        return out
+
+    def exposed_gather_ms(self, reset: bool = True) -> List[float]:
+        """The same for the parameter all-gathers of sharded mode: one entry per wait_parameters() that had something to wait for."""
+        if self._gather_events:
+            torch.cuda.synchronize(self.flat.device)
+        out = [a.elapsed_time(b) for a, b in self._gather_events]
+        if reset:
+            self._gather_events = []
         return out
 
     def exchanged_numel(self) -> int:
@@ -355,3 +547,24 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0):
     if _dist_on():
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t.data, src=src)
+
+
+def plan_buckets(param_groups: Dict[str, Sequence[torch.nn.Parameter]], big_numel: int = 1 << 22, late_groups: Sequence[str] = ("fields",)):
+    """Buffer order and buckets for the sharded exchange from the model's parameter groups: within every group the big tensors (hash
+    tables: >= big_numel elements) come first, each as a bucket of its own - a table's gradient is complete long before the weight
+    gradients of its group - then one bucket with the rest of the group.  The big buckets of `late_groups` (the SDF field's table: read
+    only after the proposal sampling of the next step) are the ones whose parameters travel back last.
+    Returns (params in buffer order, buckets, indices of the late buckets = FlatGradients(late_buckets=...))."""
+    params, buckets, late = [], [], []
+    for name, plist in param_groups.items():
+        plist = [p for p in plist if p.requires_grad]
+        big = [p for p in plist if p.numel() >= big_numel]
+        rest = [p for p in plist if p.numel() < big_numel]
+        for p in big:
+            if name in late_groups:
+                late.append(len(buckets))
+            buckets.append([p])
+        if rest:
+            buckets.append(rest)
+        params += big + rest
+    return params, buckets, late

@@ -168,6 +168,7 @@ class NeuSFactoModel(nn.Module):
         self.config = config
         self.scene_box = scene_box
         self.num_train_data = num_train_data
+        self.before_field = None  # optional callable, run after the proposal sampling and before the SDF field (sample_and_forward_field)
         self.populate_modules()
 
     def populate_modules(self):
@@ -285,6 +286,10 @@ class NeuSFactoModel(nn.Module):
     def sample_and_forward_field(self, ray_bundle: RayBundle) -> Dict:
         """neus_facto.py:282-302 (+ get_weights_from_alphas and the renderers, fused)."""
         ray_samples, weights_list, ray_samples_list = self.proposal_sampler(ray_bundle, density_fns=self.density_fns)
+        if self.before_field is not None:
+            # data-parallel runs with the sharded optimiser (distributed.py): the SDF field's table is the last thing the previous step's
+            # all-gather delivers; the proposal sampling above has been enqueued beside it, the field may only follow it
+            self.before_field()
         if B.has_background(self.config) and self.config.background_color in ("black", "white"):
             # neus_facto.py:286-292 (forward_background_field_and_merge, base_surface_model.py:266-290) FUSED into the compositing
             # kernel: the background field is evaluated on the SDF samples, samples that start outside the unit sphere take its alpha

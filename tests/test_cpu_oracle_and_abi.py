@@ -1139,6 +1139,50 @@ def test_optimizers_load_the_references_checkpoint_layout():
         opts.load_optimizers(wrong)
 
 
+def test_optimizers_load_a_reference_checkpoint_with_its_placeholder_groups_and_never_half_load():
+    """ADVICE r4.  (1) The reference creates an optimizer for every key of get_param_groups(), also for the placeholder
+    "field_background" = [Parameter(ones(1))] of background_model = "none" (base_surface_model.py:241-244, optimizers.py:104-107); this
+    repo drops empty groups, so such a checkpoint must load.  (2) A failure in a LATER group (here: a tcnn-style flat `params` vector in
+    proposal_networks) must leave moments, step count and lr untouched.  (3) betas / eps of the checkpoint are checked, not ignored."""
+    from sdfstudio_amd.engine.optimizers import Optimizers
+
+    a, b = torch.nn.Linear(3, 2), torch.nn.Linear(2, 1)
+    groups = {"fields": list(a.parameters()), "field_background": [], "proposal_networks": list(b.parameters())}
+    cfg = {"fields": {"lr": 1e-3, "scheduler": None}, "field_background": {"lr": 1e-3, "scheduler": None},
+           "proposal_networks": {"lr": 1e-2, "scheduler": None}}
+    opts = Optimizers(cfg, groups)
+    ref_groups = {"fields": groups["fields"], "field_background": [torch.nn.Parameter(torch.ones(1))], "proposal_networks": groups["proposal_networks"]}
+    ref = {}
+    for name, plist in ref_groups.items():
+        o = torch.optim.Adam(plist, lr=0.5, eps=1e-15)
+        if name != "field_background":  # the placeholder never receives a gradient: its optimizer state stays empty
+            for _ in range(2):
+                for p in plist:
+                    p.grad = torch.randn_like(p)
+                o.step()
+        ref[name] = o.state_dict()
+    assert ref["field_background"]["state"] == {}
+    opts.load_optimizers(ref)
+    assert opts.adam.step_count == 2 and float(opts.adam.exp_avg.abs().sum()) > 0
+    # a checkpoint group with real moments that the model has no parameters for is still refused
+    bad = dict(ref, field_background=ref["fields"])
+    with pytest.raises(KeyError, match="no parameters for"):
+        opts.load_optimizers(bad)
+    with pytest.raises(KeyError, match="missing from the checkpoint"):
+        opts.load_optimizers({k: v for k, v in ref.items() if k != "proposal_networks"})
+    # (2) nothing is written when a later group fails
+    fresh = Optimizers(cfg, groups)
+    broken = dict(ref, proposal_networks=dict(ref["proposal_networks"],
+                                              state={0: dict(ref["proposal_networks"]["state"][0], exp_avg=torch.zeros(5), exp_avg_sq=torch.zeros(5))}))
+    with pytest.raises(ValueError, match="moment of shape"):
+        fresh.load_optimizers(broken)
+    assert float(fresh.adam.exp_avg.abs().sum()) == 0.0 and fresh.adam.step_count == 0 and fresh.adam.groups["fields"]["lr"] == 1e-3
+    # (3) hyper-parameters
+    other_eps = {k: dict(v, param_groups=[dict(v["param_groups"][0], eps=1e-8)]) for k, v in ref.items()}
+    with pytest.raises(ValueError, match="eps"):
+        fresh.load_optimizers(other_eps)
+
+
 def test_lazy_outputs_behave_like_the_plain_dict():
     """models/neus_facto.py::LazyOutputs: `ray_points` / `normal_vis` are computed on first use (nothing on the training path reads them);
     every dict access pattern sees them as if they had been stored eagerly (base_surface_model.py:330-365 returns a plain dict)."""

@@ -11,21 +11,46 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.gpu
-def test_bench_self_spawns_two_ranks():
-    env = dict(os.environ, SDFHIP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _run_bench(extra_env, *args):
+    env = dict(os.environ, SDFHIP_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--small"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--small", *args],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
-    d = json.loads(lines[0])
+    return json.loads(lines[0]), r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_self_spawns_two_ranks():
+    """Default N > 1 exchange: SHARDED (reduce-scatter -> Adam on the owned half -> all-gather; over gloo the reduce-scatter is
+    emulated by an all-reduce of the same grid chunk).  The line carries bytes and exposed time PER PHASE."""
+    d, err = _run_bench({})
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0
-    assert d["collective"]["backend"] == "gloo" and d["collective"]["bytes_per_step_per_rank"] > 0
-    assert "rank 1/2" in r.stderr and "rank 0/2" in r.stderr
+    c = d["collective"]
+    assert c["backend"] == "gloo" and c["exchange"].startswith("sharded")
+    red, gat = c["phases"]["reduce"], c["phases"]["gather"]
+    assert red["buffer_bytes_per_step_per_rank"] > 0 and gat["buffer_bytes_per_step_per_rank"] > 0
+    assert len(red["exposed_ms_per_step_by_rank"]) == 2 and len(gat["exposed_ms_per_step_by_rank"]) == 2
+    assert red["wire_bytes_out_per_rank"] * 2 == red["buffer_bytes_per_step_per_rank"]  # (W - 1) / W at W = 2
+    # every rank's Adam visited about half of the parameters
+    n_params = red["buffer_bytes_per_step_per_rank"] // 4
+    assert 0.4 * n_params < c["adam_elements_visited_per_rank"] < 0.6 * n_params, c
+    assert "rank 1/2" in err and "rank 0/2" in err
     # the exchange must OVERLAP with backward on the real model: laplace_density.beta and the (switched-off) appearance embedding are
     # outside a NeuS-facto step's graph and must not keep the "fields" bucket waiting for finish() (VERDICT r3 item 10)
-    assert d["collective"]["parameters_outside_the_graph"] >= 1, d["collective"]
-    assert d["collective"]["buckets_launched_during_backward"] >= 1, d["collective"]
+    assert c["parameters_outside_the_graph"] >= 1, c
+    assert c["buckets_launched_during_backward"] >= 1, c
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_allreduce_exchange_reaches_the_same_loss():
+    """SDFHIP_BENCH_EXCHANGE=allreduce (rounds 1 - 4's exchange) and the sharded default run the same three steps on the same rays:
+    the same training, up to the summation order of the exchange."""
+    a, _ = _run_bench({"SDFHIP_BENCH_EXCHANGE": "allreduce"})
+    b, _ = _run_bench({})
+    assert a["collective"]["exchange"].startswith("all-reduce") and a["collective"]["phases"]["gather"] is None
+    assert a["collective"]["buckets_launched_during_backward"] >= 1
+    assert a["final_loss"] == pytest.approx(b["final_loss"], rel=1e-4), (a["final_loss"], b["final_loss"])

@@ -9,6 +9,7 @@ import csv, json, os, shutil, sys
 from collections import defaultdict
 
 tag = sys.argv[1]
+inference = "--inference" in sys.argv[2:]  # tools/profile_eval.sh: no training steps in the passes - per-kernel tables only
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 src = os.path.join(root, "gpurun_out", tag)
 dst = os.path.join(root, "profiles")
@@ -41,14 +42,18 @@ if os.path.exists(ks):
 fetch, write, sq, lds = counters("pmc_fetch"), counters("pmc_write"), counters("pmc_sq"), counters("pmc_lds")
 mean = lambda v: sum(v) / len(v) if v else float("nan")
 rows = []
-for k in sorted(fetch, key=lambda n: -mean(fetch[n]["FETCH_SIZE"]) - mean(write.get(n, {}).get("WRITE_SIZE", [0.0]))):
+names = fetch if fetch else sq  # EVAL_SQ_ONLY passes have no traffic counters
+for k in sorted(names, key=lambda n: (-mean(fetch[n]["FETCH_SIZE"]) - mean(write.get(n, {}).get("WRITE_SIZE", [0.0]))) if fetch else n):
     if "rocclr" in k or k.startswith("at::") or "elementwise" in k:
         continue
-    f_kb, w_kb = mean(fetch[k]["FETCH_SIZE"]), mean(write[k]["WRITE_SIZE"]) if k in write else float("nan")
+    f_kb = mean(fetch[k]["FETCH_SIZE"]) if k in fetch else float("nan")
+    w_kb = mean(write[k]["WRITE_SIZE"]) if k in write else float("nan")
     s = sq.get(k, {})
     wave = mean(s.get("SQ_WAVE_CYCLES", []))
     ratio = lambda c: round(mean(s.get(c, [])) / wave, 3) if s and wave == wave and wave > 0 else ""
-    rows.append({"kernel": k, "launches_sampled": len(fetch[k]["FETCH_SIZE"]), "FETCH_SIZE_KB": round(f_kb), "WRITE_SIZE_KB": round(w_kb),
+    rnd = lambda v: round(v) if v == v else ""
+    rows.append({"kernel": k, "launches_sampled": len(fetch[k]["FETCH_SIZE"]) if k in fetch else len(sq[k].get("SQ_WAVE_CYCLES", [])),
+                 "FETCH_SIZE_KB": rnd(f_kb), "WRITE_SIZE_KB": rnd(w_kb),
                  "hbm_read_GB_corrected_x2": round(2 * f_kb * 1024 / 1e9, 3), "hbm_write_GB": round(w_kb * 1024 / 1e9, 3),
                  # matrix-pipe busy cycles over (cycles x 1024 SIMDs): GRBM_GUI_ACTIVE is summed over the 8 XCDs
                  "mfma_busy_frac": round(mean(s["SQ_VALU_MFMA_BUSY_CYCLES"]) / (mean(s["GRBM_GUI_ACTIVE"]) * 128), 3) if s else "",
@@ -62,8 +67,10 @@ if rows:
         w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
         w.writeheader()
         w.writerows(rows[:24])
+    json.dump({"tag": tag, **LIB_ID, "passes": sorted(d for d in os.listdir(src) if os.path.isdir(os.path.join(src, d)))},
+              open(os.path.join(dst, f"{tag}_pmc_meta.json"), "w"), indent=1)
     # the dominant kernel runs as two launches per step (tangent pass | data backward, geo_kernels.h PHASE): its traffic is their sum
-    gb = [r for r in rows if r["kernel"].startswith("geo_bwd_kernel")]
+    gb = [] if inference else [r for r in rows if r["kernel"].startswith("geo_bwd_kernel")]
     if gb:
         json.dump({"kernel": "geo_bwd_kernel", "launches_per_step": len(gb), **LIB_ID,
                    "hbm_read_bytes": sum(r["hbm_read_GB_corrected_x2"] for r in gb) * 1e9, "hbm_write_bytes": sum(r["hbm_write_GB"] for r in gb) * 1e9,
@@ -72,7 +79,7 @@ if rows:
                   open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 # whole-step HBM bytes: every kernel's average launch traffic x its launches in the sampled steps (the PMC passes run
 # bench.py --steps 2 --warmup 1 --no-forward-only: 3 training steps and nothing else)
-if rows:
+if rows and not inference:
     tot_r = sum(r["hbm_read_GB_corrected_x2"] * r["launches_sampled"] for r in rows if r["hbm_read_GB_corrected_x2"] == r["hbm_read_GB_corrected_x2"])
     tot_w = sum(r["hbm_write_GB"] * r["launches_sampled"] for r in rows if r["hbm_write_GB"] == r["hbm_write_GB"])
     gb = [r for r in rows if r["kernel"].startswith("geo_bwd_kernel")]
