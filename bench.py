@@ -228,6 +228,8 @@ def main():
                          "start at step 5 resp. 200 000 of the preset's schedules")
     ap.add_argument("--no-config5", action="store_true", help="default (config 2) run: skip the two short config-5 legs appended as \"config5\"")
     ap.add_argument("--no-bigmlp", action="store_true", help="default (config 2) run: skip the two short 512-wide legs appended as \"bigmlp\"")
+    ap.add_argument("--no-preset", action="store_true", help="default (config 2) run: skip the neus-facto preset leg appended as \"preset\"")
+    ap.add_argument("--no-neus-acc", action="store_true", help="default (config 2) run: skip the packed-sample (NeuS-acc) leg appended as \"neus_acc\"")
     ap.add_argument("--no-dense-sdf", action="store_true", help="default (config 2) run: skip the dense-SDF (mesh extraction) leg appended as \"dense_sdf\"")
     ap.add_argument("--only", default=None, choices=["inference"],
                     help="inference: only the forward-only and dense-SDF legs on config 2's model (no training steps; tools/ A/B and PMC runs)")
@@ -255,7 +257,7 @@ def fence(world):
     torch.cuda.synchronize()
 
 
-def make_job(config, device, world, rank, small=False, hidden=256, rays=None, samples=None):
+def make_job(config, device, world, rank, small=False, hidden=256, rays=None, samples=None, model_factory=None):
     """Model, flat gradient buffer, optimizers and the step function of one benchmark configuration (2 or 5) on this rank."""
     from sdfstudio_amd.cameras.rays import RayBundle
     from sdfstudio_amd.distributed import FlatGradients, broadcast_parameters
@@ -263,7 +265,8 @@ def make_job(config, device, world, rank, small=False, hidden=256, rays=None, sa
 
     cfg5 = config == 5
     n_rays = rays or (2048 if cfg5 else (512 if small else 4096))  # method_configs.py:396 train_num_rays_per_batch (config 5)
-    model = build_model_config5(device) if cfg5 else build_model(device, small=small, hidden=hidden, samples=samples)
+    model = model_factory(device) if model_factory is not None else (
+        build_model_config5(device) if cfg5 else build_model(device, small=small, hidden=hidden, samples=samples))
     broadcast_parameters(model)
     groups = {k: v for k, v in model.get_param_groups().items() if v}  # "field_background" is empty with background_model="none"
     # Gradient exchange (distributed.py).  N > 1 default: SHARDED - reduce-scatter of the flat gradient, fused Adam on this rank's 1 / N
@@ -430,6 +433,146 @@ def bigmlp_legs(device, world, rank, ms_config2, steps=8, warmup=3):
             out[name]["ratio_to_256_wide_step"] = round(ms / ms_config2, 3)
         del job, loss
         torch.cuda.empty_cache()
+    return out
+
+
+def enqueue_vs_gpu(step_fn, first, steps, device):
+    """Host time to ENQUEUE `steps` training steps (no synchronisation inside) against the GPU time they take (events around the run):
+    when the first is not clearly below the second, the step is launch / host bound (tools/enqueue_vs_gpu.py, inside the bench)."""
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step_fn(first + i)
+    host = time.perf_counter() - t0
+    e1.record()
+    torch.cuda.synchronize(device)
+    wall = time.perf_counter() - t0
+    return {"host_enqueue_ms_per_step": round(host / steps * 1e3, 3), "gpu_ms_per_step": round(e0.elapsed_time(e1) / steps, 3),
+            "wall_ms_per_step": round(wall / steps * 1e3, 3), "host_bound": host > 0.9 * wall}
+
+
+def preset_leg(device, world, rank, steps=30, warmup=5):
+    """The reference's ONE published operating point (README.md:83: ~22 it/s on an RTX 3090): the `neus-facto` preset
+    exactly as shipped (method_configs.py:452-500) - 2 x 256 geometry + 2 x 256 colour layers on the default 16 x 2 x 2^19 smoothstep
+    grid, no appearance embedding, no background model, 2048 rays x 48 field samples (+ 256 / 96 proposal samples), Adam 5e-4 with the
+    NeuS warm-up / cosine schedule (fields), 1e-2 with MultiStepLR (proposal networks).  ~98 k points per step: the launch / latency
+    regime, which config 2 says nothing about."""
+    from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
+    from sdfstudio_amd.models.neus_facto import NeuSFactoModel, NeuSFactoModelConfig, SceneBox
+
+    def build(dev):
+        torch.manual_seed(0)
+        fcfg = SDFFieldConfig(use_grid_feature=True, num_layers=2, num_layers_color=2, hidden_dim=256, bias=0.5, beta_init=0.3,
+                              use_appearance_embedding=False)
+        mcfg = NeuSFactoModelConfig(sdf_field=fcfg, background_model="none")
+        box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=0.5, far=4.5)
+        return NeuSFactoModel(mcfg, box, num_train_data=49).to(dev).train()
+
+    job = make_job(2, device, world, rank, rays=2048, model_factory=build)
+    rays, samples = 2048, int(job["model"].config.num_neus_samples_per_ray)
+    assert samples == 48
+    dt, prof, loss = timed_steps(job, 0, warmup, steps, ("geo_fwd_kernel", "geo_bwd_kernel", "wgrad_kernel"), world)
+    dt = max_over_ranks(dt, device, world)
+    assert math.isfinite(float(loss.detach())), "preset leg diverged"
+    ms = dt / steps * 1e3
+    _lib_mod = __import__("sdfstudio_amd._lib", fromlist=["_lib"])
+    # per-kernel table (untimed, instrumented pass) and the host-enqueue / GPU split (un-instrumented)
+    _lib_mod.profile_enable(True)
+    for i in range(10):
+        job["step"](warmup + steps + i)
+    job["opts"].wait_parameters()
+    torch.cuda.synchronize(device)
+    table = {k: round(v[0] / 10, 4) for k, v in _lib_mod.profile_collect().items()}
+    _lib_mod.profile_enable(False)
+    split = enqueue_vs_gpu(job["step"], warmup + steps + 10, 20, device)
+    job["opts"].wait_parameters()
+    out = {"workload": "the reference's neus-facto preset as shipped (method_configs.py:452-500): 2x256 geo + 2x256 colour MLP, 16x2x2^19 smoothstep "
+                       f"grid, {rays} rays x {samples} samples (+256/96 proposal samples) per GPU per step, full train step incl. Adam and schedulers",
+           "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 3), "iters_per_sec": round(1e3 / ms, 2),
+           "value": round(world * rays * samples / (dt / steps), 1), "unit": "ray-samples/s",
+           "published": {"iters_per_sec": 22.0, "hardware": "RTX 3090", "source": "reference README.md:83 (BASELINE.md section 2)"},
+           "vs_published": round(1e3 / ms / 22.0, 2),
+           "kernels_ms_per_step": table, "native_kernel_ms_per_step": round(sum(table.values()), 3), "enqueue_vs_gpu": split}
+    del job, loss
+    torch.cuda.empty_cache()
+    return out
+
+
+def neus_acc_leg(device, steps=20, warmup=5):
+    """SURVEY row f2, the packed-sample path (ray_samplers.py:1315-1503, models/neus_acc.py:88-148): the reference's `neus-acc` preset
+    (method_configs.py:937-970: NeuSAccModelConfig defaults - 8 x 256 geometry + 4 x 256 colour MLP, positional encoding only, 2048 rays
+    per step) AFTER its first occupancy-grid update: the march through the pruned 128^3 grid, NeuS up-sampling inside it, packed alpha
+    compositing, losses, backward, Adam.  The field is a geometric-init sphere with a trained-looking sharpness (inv_s = e^5) so that the
+    pruning removes what a trained scene's would; background_model "none" (the preset's default NeRFField background is a separate
+    dense path, BASELINE configs do not use it)."""
+    from sdfstudio_amd import _lib
+    from sdfstudio_amd.cameras.rays import RayBundle
+    from sdfstudio_amd.distributed import FlatGradients
+    from sdfstudio_amd.engine.optimizers import Optimizers, neus_scheduler
+    from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
+    from sdfstudio_amd.models.neus_acc import NeuSAccModel, NeuSAccModelConfig
+    from sdfstudio_amd.models.neus_facto import SceneBox
+
+    torch.manual_seed(0)
+    rays = 2048
+    fcfg = SDFFieldConfig(bias=0.5, beta_init=0.3, inside_outside=False)  # the preset's SDFFieldConfig(): 8x256 + 4x256, no feature grid
+    box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=0.5, far=4.5)
+    model = NeuSAccModel(NeuSAccModelConfig(sdf_field=fcfg, background_model="none"), box, 49).to(device).train()
+    with torch.no_grad():
+        model.field.deviation_network.variance.fill_(0.5)
+    groups = {k: v for k, v in model.get_param_groups().items() if v}
+    flat = FlatGradients([p for g in groups.values() for p in g], buckets=list(groups.values()))
+    opts = Optimizers({k: {"lr": 5e-4, "scheduler": neus_scheduler(500, 0.05, 20000)} for k in groups}, groups, flat_grads=flat)
+    centers, rot = synthetic_cameras(device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(42)
+    model.before_train_iteration(2000)
+    model.after_train_iteration(2000)  # the first occupancy-grid update (ray_samplers.py:1383-1432): from here on the packed path runs
+    occupied = float(model.sampler._binary.float().mean())
+    kept = []
+
+    def step(i):
+        model.before_train_iteration(i)
+        o, d, norm, cam = draw_rays(centers, rot, rays, gen)
+        image = torch.rand(rays, 3, device=device, generator=gen)
+        out = model(RayBundle(origins=o, directions=d, directions_norm=norm, camera_indices=cam[:, None]))
+        kept.append(out["ray_samples"].shape[0] if "ray_indices" in out else -1)
+        loss = functools.reduce(operator.add, model.get_loss_dict(out, {"image": image}).values())
+        flat.zero(loss)
+        loss.backward()
+        opts.optimizer_step_all(grad_scale=None)
+        opts.scheduler_step_all(i)
+        return loss
+
+    for i in range(warmup):
+        step(2001 + i)
+    torch.cuda.synchronize(device)
+    kept.clear()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        loss = step(2001 + warmup + i)
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    assert math.isfinite(float(loss.detach())) and min(kept) > 0, "neus-acc leg: no packed samples / diverged"
+    n_kept = sum(kept) / len(kept)
+    _lib.profile_enable(True)
+    for i in range(5):
+        step(2001 + warmup + steps + i)
+    torch.cuda.synchronize(device)
+    table = {k: round(v[0] / 5, 4) for k, v in _lib.profile_collect().items()}
+    _lib.profile_enable(False)
+    split = enqueue_vs_gpu(step, 2001 + warmup + steps + 5, 10, device)
+    out = {"workload": "the reference's neus-acc preset (method_configs.py:937-970: 8x256 geo + 4x256 colour MLP, PE only) after its first occupancy-grid "
+                       f"update, {rays} rays per step, packed samples; full train step incl. Adam", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(dt * 1e3, 3), "iters_per_sec": round(1.0 / dt, 2), "rays_per_step": rays,
+           "samples_kept_per_ray": round(n_kept / rays, 2), "packed_samples_per_step": round(n_kept, 1), "occupied_voxel_fraction": round(occupied, 5),
+           "march_step_size": float(model.sampler.step_size), "value": round(n_kept / dt, 1), "unit": "packed ray-samples/s",
+           "dense_equivalent": "NeuS samples 64 + 64 per ray on every ray (models/neus.py:34-47): 128 samples per ray",
+           "kernels_ms_per_step": table, "enqueue_vs_gpu": split}
+    del model, flat, opts, loss
+    torch.cuda.empty_cache()
     return out
 
 
@@ -665,6 +808,13 @@ def run(args):
     if not cfg5 and not args.small and not args.no_bigmlp:
         loss = None
         bigmlp_extra = bigmlp_legs(device, world, rank, dt / args.steps * 1e3)
+    preset_extra = None
+    if not cfg5 and not args.small and not args.no_preset:
+        loss = None
+        preset_extra = preset_leg(device, world, rank)
+    acc_extra = None
+    if not cfg5 and not args.small and not args.no_neus_acc and world == 1:
+        acc_extra = neus_acc_leg(device)
 
     if rank == 0:
         from sdfstudio_amd import build as _build
@@ -777,6 +927,8 @@ def run(args):
             "encode_roofline": enc,
             "config5": cfg5_extra,
             "bigmlp": bigmlp_extra,
+            "preset": preset_extra,
+            "neus_acc": acc_extra,
             "collective": None if world == 1 else collective_report(job, dist.get_backend(), exposed_by_rank, exposed_gather_by_rank),
             "forward_only": fwd_only,
             "dense_sdf": dense,

@@ -197,8 +197,11 @@ int sdfhip_color_backward(const SdfHipField* f, const float* packed, int64_t n_r
  * normal, get_colors on it.  origins / dirs [n_rays,3], starts [n_rays,n_samples], emb [n_rays, appearance_dim] or NULL.
  * Outputs: sdf7 [sdfhip_numfield_sdf_rows(P)] (rows 0..P-1: the samples' sdf; rows P k + i: tap k - 1 of sample i), grad [P,3],
  * rgb [P,3], taps [P,6] (`sampled_sdf`, sdf_field.py:644; may be NULL), x_out [P,3] contracted positions (may be NULL).
- * training != 0 keeps what the backward needs in `workspace` (sdfhip_numfield_workspace_size(f, P) bytes, caller-owned until then). */
+ * training != 0 keeps what the backward needs in `workspace` (sdfhip_numfield_workspace_size(f, P) bytes, caller-owned until then);
+ * training == 0 needs sdfhip_numfield_inference_workspace_size(f, P) bytes only (nothing saved: eval renders of config 5 in chunks).
+ * Below delta = 2e-3 the seven sdf evaluations use 24-bit products where the field's shape has such kernels. */
 int64_t sdfhip_numfield_workspace_size(const SdfHipField* f, int64_t n_points);
+int64_t sdfhip_numfield_inference_workspace_size(const SdfHipField* f, int64_t n_points);
 int64_t sdfhip_numfield_sdf_rows(int64_t n_points);
 int sdfhip_numfield_forward(const SdfHipField* f, const float* packed, const float* table, const float* level_mask, const float* origins,
                             const float* dirs, const float* starts, int64_t n_rays, int32_t n_samples, const float* emb, float delta,

@@ -93,6 +93,7 @@ _SIGNATURES = {
     "sdfhip_sh4_embed": (c_i32, [c_float_p, c_float_p, c_i64, c_i32, c_float_p, ctypes.c_void_p]),
     "sdfhip_embedding_backward": (c_i32, [ctypes.c_void_p, c_float_p, c_i64, c_i32, c_i64, c_float_p, ctypes.c_void_p]),
     "sdfhip_numfield_workspace_size": (c_i64, [ctypes.c_void_p, c_i64]),
+    "sdfhip_numfield_inference_workspace_size": (c_i64, [ctypes.c_void_p, c_i64]),
     "sdfhip_numfield_sdf_rows": (c_i64, [c_i64]),
     "sdfhip_numfield_forward": (c_i32, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_i64, c_i32,
                                         c_float_p, ctypes.c_float, c_i32, ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,

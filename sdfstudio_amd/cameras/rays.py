@@ -106,14 +106,23 @@ _CONST_CACHE: Dict = {}
 
 
 def constant_column(n: int, value: float, device) -> torch.Tensor:
-    """A cached [n,1] tensor filled with `value` (default pixel areas, fixed near / far planes): READ-ONLY by convention - one fill per
-    shape instead of one per training step."""
+    """A cached [n,1] tensor filled with `value` (default pixel areas, fixed near / far planes): READ-ONLY - one fill per shape instead
+    of one per training step.  The rule is enforced where it can be: every hand-out checks the tensor's autograd version counter against
+    the one it was created with, so an in-place write by any consumer (a collider's clamp_, a masked assignment in user code) fails
+    loudly at the NEXT batch of that size instead of silently corrupting every later one."""
     key = (int(n), float(value), str(device))
-    t = _CONST_CACHE.get(key)
-    if t is None:
-        if len(_CONST_CACHE) > 64:
-            _CONST_CACHE.clear()
-        t = _CONST_CACHE[key] = torch.full((int(n), 1), float(value), device=device)
+    hit = _CONST_CACHE.get(key)
+    if hit is not None:
+        t, version = hit
+        if t._version != version:
+            del _CONST_CACHE[key]
+            raise RuntimeError(f"a cached constant column ({n} x 1, value {value}) was written in place by one of its consumers: ray_bundle.nears / "
+                               "fars / pixel_area handed out by the default paths are shared, read-only tensors - clone before modifying")
+        return t
+    if len(_CONST_CACHE) > 64:
+        _CONST_CACHE.clear()
+    t = torch.full((int(n), 1), float(value), device=device)
+    _CONST_CACHE[key] = (t, t._version)
     return t
 
 

@@ -2,6 +2,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -1406,7 +1407,10 @@ struct NumWs {
   int64_t nc, n7;
   size_t bytes;
 };
-static void carve_num(const SdfHipField* f, int64_t P, void* base, NumWs* w) {
+constexpr float kHpDelta = 2e-3f;  // numerical-gradient delta (contracted units) below which sdfhip_numfield_forward evaluates with 24-bit products
+// training = false: what a forward WITHOUT a backward to follow touches - positions, in0, the geometry feature, the colour network's
+// inputs and rgb (no saved activations, no cotangent staging, no split-K partials: ~1 / 6 of the training carve)
+static void carve_num(const SdfHipField* f, int64_t P, void* base, NumWs* w, const bool training = true) {
   const FieldKernels* k = f->k;
   const int64_t nc = sdfhip_padded_points(P), n7 = sdfhip_padded_points(7 * P);
   size_t off = 0;
@@ -1419,36 +1423,49 @@ static void carve_num(const SdfHipField* f, int64_t P, void* base, NumWs* w) {
   w->nc = nc;
   w->n7 = n7;
   FieldWs& g = w->g;
+  FieldWs& c = w->c;
   g.x = take(n7 * 3);
   g.in0 = take(n7 * k->nb0 * 32);
   g.feat = take(n7 * k->nbf * 32);     // tap tiles stay unwritten when the sdf-row-only forward exists (has_sdf_save)
-  for (int l = 0; l < f->nl; ++l) g.u[l] = take(n7 * f->nbo_geo(l) * 32);
-  g.sdfbar = take(n7);
-  for (int l = 0; l < f->nl; ++l) g.zb[l] = take(n7 * f->nbo_geo(l) * 32);
-  g.in0bar = take(n7 * k->nb0 * 32);
-  g.featbar = take(n7 * k->nbf * 32);
-  FieldWs& c = w->c;
+  if (training || k->layerwise)        // (the layer-at-a-time kernels hand their activations over through these in every mode)
+    for (int l = 0; l < f->nl; ++l) g.u[l] = take(n7 * f->nbo_geo(l) * 32);
+  if (training) {
+    g.sdfbar = take(n7);
+    for (int l = 0; l < f->nl; ++l) g.zb[l] = take(n7 * f->nbo_geo(l) * 32);
+    g.in0bar = take(n7 * k->nb0 * 32);
+    g.featbar = take(n7 * k->nbf * 32);
+  }
   c.feat = g.feat;
   c.featbar = g.featbar;
   c.csmall = take(nc * k->nbs * 32);
-  for (int l = 0; l < f->nlc; ++l) c.h[l] = take(nc * k->nbc * 32);
+  if (training)
+    for (int l = 0; l < f->nlc; ++l) c.h[l] = take(nc * k->nbc * 32);
   c.rgb = take(nc * 3);
-  for (int l = 0; l < f->nlc; ++l) c.d[l] = take(nc * k->nbc * 32);
-  c.dout = take(nc * 32);
-  c.csmallbar = take(nc * k->nbs * 32);
+  if (training) {
+    for (int l = 0; l < f->nlc; ++l) c.d[l] = take(nc * k->nbc * 32);
+    c.dout = take(nc * 32);
+    c.csmallbar = take(nc * k->nbs * 32);
+  }
   w->grad_fd = take(nc * 3);
-  const int64_t n_tiles = n7 / 32;
-  g.n_split = (int)std::min<int64_t>(256, n_tiles);
-  g.partial = take((int64_t)g.n_split * f->max_partial_elems);
-  g.bpartial = take((int64_t)g.n_split * f->max_partial_rows);
-  c.n_split = (int)std::min<int64_t>(256, nc / 32);
-  c.partial = g.partial;  // the weight-gradient GEMMs run one after the other on one stream
-  c.bpartial = g.bpartial;
+  if (training) {
+    const int64_t n_tiles = n7 / 32;
+    g.n_split = (int)std::min<int64_t>(256, n_tiles);
+    g.partial = take((int64_t)g.n_split * f->max_partial_elems);
+    g.bpartial = take((int64_t)g.n_split * f->max_partial_rows);
+    c.n_split = (int)std::min<int64_t>(256, nc / 32);
+    c.partial = g.partial;  // the weight-gradient GEMMs run one after the other on one stream
+    c.bpartial = g.bpartial;
+  }
   w->bytes = off;
 }
 extern "C" int64_t sdfhip_numfield_workspace_size(const SdfHipField* f, int64_t n_points) {
   NumWs w;
   carve_num(f, n_points, nullptr, &w);
+  return (int64_t)w.bytes;
+}
+extern "C" int64_t sdfhip_numfield_inference_workspace_size(const SdfHipField* f, int64_t n_points) {
+  NumWs w;
+  carve_num(f, n_points, nullptr, &w, false);
   return (int64_t)w.bytes;
 }
 extern "C" int64_t sdfhip_numfield_sdf_rows(int64_t n_points) { return sdfhip_padded_points(7 * n_points); }
@@ -1486,7 +1503,7 @@ extern "C" int sdfhip_numfield_forward(const SdfHipField* f, const float* packed
   const FieldKernels* k = f->k;
   const int64_t P = n_rays * n_samples;
   NumWs w;
-  carve_num(f, P, workspace, &w);
+  carve_num(f, P, workspace, &w, training != 0);
   const int64_t NC = w.nc, N7 = w.n7;
 
   EncodeArgs ea;
@@ -1514,6 +1531,12 @@ extern "C" int sdfhip_numfield_forward(const SdfHipField* f, const float* packed
     if (f->grid.n_features == 8) geo_encode8_kernel<<<dim3(gx, f->grid.n_levels + 1), 256, 0, s>>>(ea);
     else geo_encode_kernel<<<dim3(gx, f->grid.n_levels * (f->grid.n_features / 2) + 1), 256, 0, s>>>(ea);
   }
+  // The numerical normal divides DIFFERENCES of sdf values by 2 delta: an sdf error eps becomes eps / delta in the normal.  At the small
+  // deltas of neus-facto-angelo's schedule (down to 2.4e-4 in contracted units) the 22-bit products of the default forward (eps ~ 3e-7)
+  // show; below kHpDelta the seven evaluations run with all 24 bits (precision mode 3: six bf16 terms per product - the error class of the
+  // fp32 GEMM the reference runs) where the shape has such kernels (FieldKernels::has_hp; SDFHIP_NUMFIELD_HP=0/1 overrides for A/B runs).
+  static const int hp_env = [] { const char* e = getenv("SDFHIP_NUMFIELD_HP"); return e ? atoi(e) : -1; }();
+  const bool hp = k->has_hp && k->has_sdf_save && (hp_env >= 0 ? hp_env != 0 : delta < kHpDelta);
   GeoFwdArgs ga;
   memset(&ga, 0, sizeof(ga));
   fill_geo_ptrs(f, packed, &ga.p, kNsFwd);
@@ -1525,7 +1548,14 @@ extern "C" int sdfhip_numfield_forward(const SdfHipField* f, const float* packed
     ProfScope ps_(PS_GEO_FWD, s);
     // centre tiles (and the few tap points that share their last workgroup): sdf + feature; tap tiles: the sdf row alone
     const int save = training != 0;
-    if (k->has_sdf_save && N7 > NC) {
+    if (hp) {
+      // feature rows of the centre tiles at the default precision, then the sdf rows of ALL seven evaluations with 24-bit products: the
+      // second pass rewrites the centre's sdf and saved activations, so every sdf value and every u_l the backward reads is the 24-bit one
+      k->geo_fwd(save ? 3 : 1, ga, (unsigned)(NC / 128), s);
+      GeoFwdArgs gh = ga;
+      fill_geo_ptrs(f, packed, &gh.p, 3);
+      k->geo_fwd((save ? 5 : 2) | kGeoHp, gh, (unsigned)(N7 / 128), s);
+    } else if (k->has_sdf_save && N7 > NC) {
       k->geo_fwd(save ? 3 : 1, ga, (unsigned)(NC / 128), s);
       GeoFwdArgs gt = ga;
       shift_geo_fwd(f, &gt, NC / 32);

@@ -41,6 +41,12 @@ SDFHIP_D void static_for(F&& f) {
   }
 }
 
+// A value that is only CONSUMED at the end of a long unrolled region (the lane-local sdf-row dot product of the output layer: 128 - 256
+// fused multiply-adds riding in the producers of as many MFMA steps) is fair game for LLVM's code sinking: the whole chain is moved
+// behind the region and its operands stay live across it - wide_out_kernel kept 2 x 256 of them in scratch (884 B per lane).  An empty
+// volatile asm that reads and writes the accumulator pins each step of the chain where it is written.
+SDFHIP_D void pin_here(float& x) { asm volatile("" : "+v"(x)); }
+
 // ---- softplus(beta=100, threshold=20) and its derivatives (aten softplus / softplus_backward / softplus_double_backward,
 // used at sdf_field.py:365,409) on the hardware transcendental unit: v_exp_f32 / v_log_f32 (base 2, 1 ulp) and v_rcp_f32.
 //   t = 100 z ; e = exp(t) ; h = log(1 + e) / 100 ; s'(z) = e / (1 + e) ; s''(z) = 100 s' (1 - s')

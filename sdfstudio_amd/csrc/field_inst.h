@@ -20,6 +20,7 @@ struct FieldKernels {
   // first-order backward of points that have no feature cotangent (geo_bwd_kernel<FEATBAR = false>); null: use geo_bwd1 with zeros
   void (*geo_bwd1s)(const GeoBwdArgs&, unsigned grid, hipStream_t) = nullptr;
   int has_sdf_save = 0;  // geo_fwd mode 5 exists (sdf row only, activations saved: the taps of the numerical-gradient branch)
+  int has_hp = 0;        // geo_fwd honours mode | kGeoHp (24-bit products in the first-order modes)
 };
 
 // Kernels that want more than 64 KiB of dynamic LDS must raise the per-function limit first.
@@ -58,9 +59,22 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
     SDFHIP_GEO_FWD_LAUNCH(GD, true, a, grid, GD::lds_floats(kNsFwd, a.p.nl) * sizeof(float), s);                          \
   }
 
-#define SDFHIP_DEFINE_GEO_FWD_INFER(NAME, NBH, NB0, NBF)                                                                  \
-  void sdfhip_geo_fwd_infer_##NAME(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s) {                         \
+// mode | kGeoHp selects the 24-bit (six-term, precision mode 3) instantiation of the SDF-ROW modes (2 and 5) where the shape has one
+// (HP = 1): the feature-row modes with six terms are 66 - 68 KB of code, over the 64 KB instruction cache, and nothing needs 24-bit
+// feature rows (the caller runs the feature pass at the default precision and the sdf rows again: sdfhip_numfield_forward)
+constexpr int kGeoHp = 0x100;
+#define SDFHIP_DEFINE_GEO_FWD_INFER_(NAME, NBH, NB0, NBF, HP)                                                             \
+  void sdfhip_geo_fwd_infer_##NAME(int mode_, const GeoFwdArgs& a, unsigned grid, hipStream_t s) {                        \
     using GD = GeoDims<NBH, NB0, NBF>;                                                                                     \
+    const int mode = mode_ & 0xff;                                                                                         \
+    if constexpr (HP != 0) {                                                                                               \
+      if ((mode_ & kGeoHp) != 0 && (mode == 2 || mode == 5)) {                                                             \
+        const size_t lds3 = GD::lds_floats(3, a.p.nl) * sizeof(float);                                                     \
+        if (mode == 5) launch_lds(geo_fwd_kernel<GD, false, true, false, 0, 3>, a, grid, 256, lds3, s);                   \
+        else launch_lds(geo_fwd_kernel<GD, false, false, false, 0, 3>, a, grid, 256, lds3, s);                            \
+        return;                                                                                                            \
+      }                                                                                                                    \
+    }                                                                                                                      \
     const size_t lds = GD::lds_floats(kNsFwd, a.p.nl) * sizeof(float);                                                     \
     if (mode == 1) launch_lds(geo_fwd_kernel<GD, false, false, true>, a, grid, 256, lds, s);                              \
     else if (mode == 3) launch_lds(geo_fwd_kernel<GD, false, true, true>, a, grid, 256, lds, s);                          \
@@ -68,6 +82,8 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
     else if (mode == 5) launch_lds(geo_fwd_kernel<GD, false, true, false>, a, grid, 256, lds, s);                         \
     else launch_lds(geo_fwd_kernel<GD, false, false, false>, a, grid, 256, lds, s);                                       \
   }
+#define SDFHIP_DEFINE_GEO_FWD_INFER(NAME, NBH, NB0, NBF) SDFHIP_DEFINE_GEO_FWD_INFER_(NAME, NBH, NB0, NBF, 0)
+#define SDFHIP_DEFINE_GEO_FWD_INFER_HP(NAME, NBH, NB0, NBF) SDFHIP_DEFINE_GEO_FWD_INFER_(NAME, NBH, NB0, NBF, 1)
 
 #define SDFHIP_DEFINE_GEO_BWD(NAME, NBH, NB0, NBF)                                                                        \
   void sdfhip_geo_bwd_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s) {                                         \
@@ -83,7 +99,8 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
     launch_lds(geo_bwd_kernel<GD, false, 0, false>, a, grid, 256, GD::lds_floats(kNsGrad, a.p.nl) * sizeof(float), s);    \
   }
 
-#define SDFHIP_DEFINE_COL_AND_TABLE(NAME, NBH, NB0, NBF, NBS, NBC)                                                        \
+#define SDFHIP_DEFINE_COL_AND_TABLE(NAME, NBH, NB0, NBF, NBS, NBC) SDFHIP_DEFINE_COL_AND_TABLE_(NAME, NBH, NB0, NBF, NBS, NBC, 0)
+#define SDFHIP_DEFINE_COL_AND_TABLE_(NAME, NBH, NB0, NBF, NBS, NBC, HP)                                                   \
   void sdfhip_geo_fwd_train_##NAME(const GeoFwdArgs& a, unsigned grid, hipStream_t s);                                    \
   void sdfhip_geo_fwd_infer_##NAME(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s);                          \
   void sdfhip_geo_bwd_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s);                                          \
@@ -91,7 +108,7 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
   void sdfhip_geo_bwd1s_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s);                                        \
   namespace NAME##_ns {                                                                                                   \
   static void geo_fwd(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s) {                                      \
-    if (mode == 0) sdfhip_geo_fwd_train_##NAME(a, grid, s);                                                               \
+    if ((mode & 0xff) == 0) sdfhip_geo_fwd_train_##NAME(a, grid, s);                                                      \
     else sdfhip_geo_fwd_infer_##NAME(mode, a, grid, s);                                                                   \
   }                                                                                                                       \
   using CD = ColDims<NBF, NBS, NBC>;                                                                                      \
@@ -111,7 +128,7 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
   const FieldKernels* sdfhip_kernels_##NAME() {                                                                           \
     static const FieldKernels k = {NBH, NB0, NBF, NBS, NBC, NAME##_ns::geo_fwd, sdfhip_geo_bwd_##NAME,                    \
                                    sdfhip_geo_bwd1_##NAME, NAME##_ns::col_fwd, NAME##_ns::col_bwd, NAME##_ns::sdfrow,     \
-                                   0, 0, sdfhip_geo_bwd1s_##NAME, 1};                                                     \
+                                   0, 0, sdfhip_geo_bwd1s_##NAME, 1, HP};                                                 \
     return &k;                                                                                                            \
   }
 

@@ -114,7 +114,10 @@ SDFHIP_D const float* geo_skip_in0(const float* wp_skip) {
 // from HBM either way, so running it as its own launch (PHASE 2) after the forward (PHASE 1) moves no extra data - and every CU
 // of a launch then sits in the SAME layer loop.  That matters on the boxes of DESIGN.md section 5: two CUs share an instruction
 // cache, and a forward loop (25 KB) next to a chain loop (37 KB) does not fit its fast half.
-template <class D, bool GRAD, bool SAVE, bool FEAT, int PHASE = 0>
+// NS_: precision mode of the products (mlp_core.h).  Default kNsFwd (fp16 hi + lo: 22 mantissa bits); 3 (three bf16 parts, six terms: all 24
+// bits, the error class of an fp32 GEMM) is instantiated for the first-order modes of BASELINE config 5's shape, whose numerical normals
+// divide sdf DIFFERENCES by a delta that shrinks to 2.4e-4 (sdfhip_numfield_forward).
+template <class D, bool GRAD, bool SAVE, bool FEAT, int PHASE = 0, int NS_ = kNsFwd>
 __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
   static_assert(PHASE == 0 || GRAD, "the chain only exists with GRAD");
   static_assert(!GRAD || D::ACT == 0, "the analytic-normal chain is written for Softplus(100) networks");
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, hf = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-  constexpr int W = D::CW, NS = kNsFwd, PCS = D::pieces(NS);
+  constexpr int W = D::CW, NS = NS_, PCS = D::pieces(NS);
   const int NL = a.p.nl, SKIP = a.p.skip;
   float* cvec = lds + 2 * D::buf_floats(NS);
 
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
       const float h = act_h<D::ACT, NS == 4>(accIn[kb][e]);
       if constexpr (SAVE || GRAD) *tp_elem(ulast, tile, D::NBH, kb, e, lane) = h;
       part = fmaf(wsdf[kb * 32 + tp_row(e, hf)], h, part);
+      pin_here(part);
       return InRange{h};
     };
     if constexpr (FEAT) {
@@ -237,7 +241,10 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
       if (l == 0 || l == SKIP) {
         // hidden -> in0: layer 0, and the part of the skip layer's input gradient that goes straight to in0 (parked in e_tp,
         // layer 0 adds to it).  The hidden part of the skip layer follows with the same operands (z_l block 0)
-        f32x16 accE[D::NB0];
+        // accumulates in the first NB0 blocks of accOut: dead here (the hidden gemm below clears it before it writes), and a separate
+        // NB0-block set next to accIn / accOut does not fit the register file at NB0 = 6 (config 5's shape spilled 196 B in the backward)
+        static_assert(D::NB0 <= D::MAXO, "the in0 accumulators live in accOut");
+        auto& accE = accOut;
 #pragma unroll
         for (int b = 0; b < D::NB0; ++b) accE[b] = f32x16_zero();
         auto next_fetch = [&]() __attribute__((always_inline)) { return BlkSrc<1>{{tp_block_ptr(ul, tile, D::NBH, 0)}}; };
@@ -424,11 +431,17 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
         *tp_elem(zbl, tile, D::NBH, b, e, lane) = zb;
         return zb;
       };
-      f32x16 accE[D::NB0];
+      static_assert(D::NB0 <= D::NBH, "the in0 accumulators live in accOut");
+      auto& accE = accOut;  // dead here: see the chain of geo_fwd_kernel
 #pragma unroll
       for (int b = 0; b < D::NB0; ++b) accE[b] = f32x16_zero();
       auto next_fetch = [&]() __attribute__((always_inline)) { return bwd_src(l, 0); };
       tp_gemm<D::NBH, D::NB0, Stores<16>, NS, PCS>(accE, carry, fetch, make, next_fetch, ws, l == 0 ? a.p.wpT[0] : a.p.wpT_in0, a.p.wpT[l]);
+      // ub_{l+1} has been consumed for good: layer 0 ends the sweep, and the skip layer's hidden gemm below takes the FINISHED zb_l from
+      // memory (`done`).  The compiler cannot see that across the two run-time conditions and kept all 8 blocks alive through this gemm
+      // (NB0 = 6: 196 B of scratch); overwriting them ends their live ranges block by block as the producer passes.
+#pragma unroll
+      for (int b = 0; b < D::NBH; ++b) accIn[b] = f32x16_zero();
       if (l == 0 && SKIP > 0) {
 #pragma unroll
         for (int b = 0; b < D::NB0; ++b) accE[b] += tp_load_blk(a.in0bar_tp, tile, D::NB0, b, lane);

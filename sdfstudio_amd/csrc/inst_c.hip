@@ -3,4 +3,4 @@
 // (the preset: 1 hidden geometry layer, no skip, 4 colour layers).
 // This unit: colour network kernels and the kernel table; the geometry kernels are in inst_c_fwd.hip / inst_c_inf.hip / inst_c_bwd.hip.
 #include "field_inst.h"
-SDFHIP_DEFINE_COL_AND_TABLE(C, 8, 6, 8, 3, 8)
+SDFHIP_DEFINE_COL_AND_TABLE_(C, 8, 6, 8, 3, 8, 1)

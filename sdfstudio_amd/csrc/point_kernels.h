@@ -703,12 +703,14 @@ SDFHIP_D void prop_position(const PropArgs& a, const int64_t p, float pp[3]) {
 }
 
 // grid features (5 levels x 2) and the 16 hidden pre-activations; returns the output pre-activation
-SDFHIP_D float prop_mlp(const PropArgs& a, const float pp[3], float feat[kPropIn], float hid[kPropHidden]) {
+// lofs: 0, possibly through an opaque register (prop_bwd_kernel): the level descriptors are then re-read from the kernel arguments where they
+// are used instead of being hoisted out of the caller's grid-stride loop, where 25 of them sit in scalar registers for the whole kernel
+SDFHIP_D float prop_mlp(const PropArgs& a, const float pp[3], float feat[kPropIn], float hid[kPropHidden], const int lofs = 0) {
   const float2* tab = reinterpret_cast<const float2*>(a.table);
 #pragma unroll
   for (int l = 0; l < kPropLevels; ++l) {
     GridCell c;
-    grid_cell(a.grid.lv[l], a.grid.smoothstep != 0, pp, c);
+    grid_cell(a.grid.lv[l + lofs], a.grid.smoothstep != 0, pp, c);
     float2 v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = tab[c.idx[k]];
@@ -747,8 +749,13 @@ __global__ __launch_bounds__(256) void prop_fwd_kernel(const PropArgs a) {
 // Weight gradients: w1_bar[j][i] = sum_p hb_j[p] feat_i[p] and w2_bar[j] = sum_p relu(hid_j[p]) pb[p] are 16 x 16 products
 // contracted over the points, accumulated on the matrix core (v_mfma_f32_16x16x4_f32, 8 accumulator registers per
 // lane instead of 176): each wave transposes its 64 points through a private LDS slab ([row][64 points + 4 pad]).
-constexpr int kPropT = 64;     // LDS row stride (floats)
-constexpr int kPropRows = 27;  // rows 0..15: relu(hid_j)^T ; 16..25: feat_i^T ; 26: pb
+// Round 5: the per-level table scatter is a ROLLED loop (one copy of grid_cell + run reduction + staged scatter instead of five: 44.8 ->
+// ~15 KB of code, no scratch where the unrolled form spilled 288 B per lane under its 256-register cap); d L / d feature of the level being
+// scattered comes back from the slab (rows 27..36: written and read by the same lane).  Rows are 64 points + 4 pad floats: the b128
+// operand reads of the MFMA stage (lane (m, k) reads row m) then spread over the banks (row stride 64 put all 16 rows of a k on the same
+// four banks: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE was 0.10 for this kernel).
+constexpr int kPropT = 68;     // LDS row stride (floats): 64 points + 4 pad, rows stay 16-byte aligned
+constexpr int kPropRows = 37;  // rows 0..15: relu(hid_j)^T ; 16..25: feat_i^T ; 26: pb ; 27..36: d L / d feat_i ^T
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void prop_bwd_kernel(const PropArgs a) {
   __shared__ __attribute__((aligned(16))) float slab[4][kPropRows][kPropT];
   __shared__ float red[4][176];
@@ -765,33 +772,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     const bool live = p < a.n_points;
     const int64_t pc = live ? p : a.n_points - 1;
     const float db = live ? a.densbar[pc] : 0.0f;
-    float pp[3], feat[kPropIn], hid[kPropHidden];
-    prop_position(a, pc, pp);
-    const float pre = prop_mlp(a, pp, feat, hid);
-    const float pb = db * expf(fminf(fmaxf(pre, -15.0f), 15.0f));  // activations.py:36-39
-    float fb[kPropIn];
+    float pp[3];
+    {
+      float feat[kPropIn], hid[kPropHidden];
+      prop_position(a, pc, pp);
+      int zero;
+      asm volatile("s_mov_b32 %0, 0" : "=s"(zero));  // opaque: see prop_mlp
+      const float pre = prop_mlp(a, pp, feat, hid, zero);
+      const float pb = db * expf(fminf(fmaxf(pre, -15.0f), 15.0f));  // activations.py:36-39
+      float fb[kPropIn];
 #pragma unroll
-    for (int i = 0; i < kPropIn; ++i) fb[i] = 0.0f;
+      for (int i = 0; i < kPropIn; ++i) fb[i] = 0.0f;
 #pragma unroll
-    for (int j = 0; j < kPropHidden; ++j) {
-      const float hb = hid[j] > 0.0f ? pb * a.w2[j] : 0.0f;
-      sh[j][lane] = fmaxf(hid[j], 0.0f);
+      for (int j = 0; j < kPropHidden; ++j) {
+        const float hb = hid[j] > 0.0f ? pb * a.w2[j] : 0.0f;
+        sh[j][lane] = fmaxf(hid[j], 0.0f);
 #pragma unroll
-      for (int i = 0; i < kPropIn; ++i) fb[i] = fmaf(a.w1[j * kPropIn + i], hb, fb[i]);
+        for (int i = 0; i < kPropIn; ++i) fb[i] = fmaf(a.w1[j * kPropIn + i], hb, fb[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < kPropIn; ++i) {
+        sh[16 + i][lane] = feat[i];
+        sh[27 + i][lane] = fb[i];
+      }
+      sh[26][lane] = pb;
     }
-#pragma unroll
-    for (int i = 0; i < kPropIn; ++i) sh[16 + i][lane] = feat[i];
-    sh[26][lane] = pb;
-    // ---- table gradient
+    // ---- table gradient, level by level
     const bool contributes = live && db != 0.0f;
-#pragma unroll
+#pragma unroll 1
     for (int l = 0; l < kPropLevels; ++l) {
+      const float f0 = sh[27 + 2 * l][lane], f1 = sh[28 + 2 * l][lane];
       GridCell c;
       grid_cell(a.grid.lv[l], a.grid.smoothstep != 0, pp, c);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float w = corner_w(c, k);
-        float t0 = w * fb[2 * l], t1 = w * fb[2 * l + 1];
+        float t0 = w * f0, t1 = w * f1;
         const bool issue = wave_run_reduce(c.idx[k], contributes, t0, t1);
         scatter_stage_put(st, lane, k, issue, c.idx[k], t0, t1);
       }

@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256, 1) void wide_out_kernel(const GeoFwdArgs a) {
     constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
     const float u = raw.a[e], w = wsdf[kb * 32 + tp_row(e, hf)];
     part = fmaf(w, u, part);
+    pin_here(part);
     if constexpr (GRAD) *tp_elem(rlast, tile, D::NBH, kb, e, lane) = w * act_d1h<D::ACT>(u);
     return u;
   };

@@ -392,7 +392,9 @@ class _NumericalFieldFunction(torch.autograd.Function):
         theta_c = theta.contiguous()
         _lib.check(lib.sdfhip_field_pack(h, _lib.ptr(theta_c), _lib.ptr(packed), _lib.stream()), "field_pack")
         train = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
-        ws = torch.empty(lib.sdfhip_numfield_workspace_size(h, P), dtype=torch.uint8, device=dev)
+        # without a backward to follow nothing is saved: the inference carve is a sixth of the training one (eval renders in chunks)
+        ws_bytes = lib.sdfhip_numfield_workspace_size(h, P) if train else lib.sdfhip_numfield_inference_workspace_size(h, P)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         sdf7 = torch.empty(lib.sdfhip_numfield_sdf_rows(P), device=dev)
         grad = torch.empty(P, 3, device=dev)
         rgb = torch.empty(P, 3, device=dev)

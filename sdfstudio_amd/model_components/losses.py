@@ -68,6 +68,8 @@ class _SurfaceLosses(torch.autograd.Function):
         need = ctx.needs_input_grad
         lb = [None if t is None else t.contiguous().float() for t in lbar]
         outs = [torch.empty(shp[i], device=dev) if (shp[i] is not None and need[i]) else None for i in range(5)]
+        if outs[2] is not None and shp[3] is None:
+            outs[2] = None  # the kernel writes sdf_bar in its curvature pass only: without taps the sdf has no gradient from these losses
         # the curvature stencil differentiates sdf and its six taps in one pass: whichever of the two is asked for, both buffers exist
         # (the other one is scratch) - a sdf that requires grad next to detached taps used to lose its curvature gradient
         curv = shp[3] is not None and (need[2] or need[3])
@@ -159,6 +161,8 @@ def interlevel_loss_zip(weights_list: List[torch.Tensor], bins_list: List[torch.
     levels = []
     for cp, wp in zip(bins_list[:-1][:len(radii)], weights_list[:-1][:len(radii)]):
         levels += [cp.detach(), wp]
+    if not levels:  # no proposal level (num_proposal_iterations = 0): the reference's loop (losses.py:160-172) returns 0.0
+        return w.new_zeros(())
     if not w.is_cuda:
         raise _lib.SdfHipError("interlevel_loss_zip runs on the sdfhip kernels: HIP device tensors required (no CPU fallback)")
     return _Interlevel.apply(c, w, radii[:len(levels) // 2], *levels)

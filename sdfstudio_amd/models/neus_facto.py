@@ -35,12 +35,16 @@ class LazyOutputs(dict):
         self._lazy = {}
 
     def set_lazy(self, key, fn):
-        self._lazy[key] = fn
+        """fn is evaluated on first use under the grad mode it was REGISTERED under (an entry created inside torch.no_grad() must not
+        build a graph - and keep the frustums alive - because its first reader happens to run with grad enabled)."""
+        self._lazy[key] = (fn, torch.is_grad_enabled())
 
     def _force(self, key=None):
         for k in ([key] if key is not None else list(self._lazy)):
             if k in self._lazy:
-                super().__setitem__(k, self._lazy.pop(k)())
+                fn, grad = self._lazy.pop(k)
+                with torch.set_grad_enabled(grad):
+                    super().__setitem__(k, fn())
 
     def __getitem__(self, key):
         self._force(key)

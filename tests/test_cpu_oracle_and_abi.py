@@ -785,6 +785,9 @@ def test_every_kernel_fits_the_instruction_cache():
     train = [r for r in parsed if r[0].startswith(("geo_fwd_kernel<GeoDims<8, 3, 8>, true, true, true, 2", "geo_bwd_kernel<GeoDims<8, 3, 8>, true",
                                                    "col_fwd_kernel<ColDims<8, 3, 8>, true", "col_bwd_kernel<ColDims<8, 3, 8>", "wgrad_bf16x8_kernel"))]
     assert len(train) >= 8 and all(r[2] == 0 for r in train), [r for r in train if r[2]]
+    # round 5: NO kernel of the product library may use scratch memory (private_segment_fixed_size of its code object)
+    spilling = [(r[0], r[2]) for r in parsed if r[2] != 0]
+    assert not spilling, f"kernels with scratch: {spilling}"
 
 
 def test_no_device_pointer_is_taken_from_a_temporary():

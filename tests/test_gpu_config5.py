@@ -269,8 +269,9 @@ def test_northstar_bars_config5_on_oracle_samples(device, step):
     network per sample, finite-difference normal, colour network, "grid" background merge) and the compositing are evaluated on the
     oracle's starts / ends.  sdf and the six tap values: 1e-5 absolute at both schedule states.  Everything downstream of the normal:
     1e-4 relative while the finite difference lets the REFERENCE path itself be that reproducible (step 5 000: delta 5.4e-2), the
-    reference path's own fp32 class (within 8 x |oracle fp32 - oracle fp64|: 22-bit against 24-bit products) once delta = 2.4e-4 divides
-    the sdf's round-off by 5e-4."""
+    reference path's own fp32 class (within 3 x |oracle fp32 - oracle fp64|; round 4: 8 x, before the small-delta evaluations moved to
+    24-bit products) once delta = 2.4e-4 divides the sdf's round-off by 5e-4 - plus the fixed 1e-4 bar on every ray where the reference
+    path itself is reproducible to 2e-5."""
     from sdfstudio_amd.fields.field_heads import FieldHeadNames as H
     from sdfstudio_amd.models import background as BGM
 
@@ -306,15 +307,27 @@ def test_northstar_bars_config5_on_oracle_samples(device, step):
     assert_close("sdf", fo[H.SDF][..., 0], rf["sdf"], rtol=0, atol=1e-5)
     assert_close("sampled_sdf (six taps)", fo["sampled_sdf"], rf["sampled_sdf"], rtol=0, atol=1e-5)
     strict = step == 5000
+    stable_rays = {}
 
     def bar(name, got, r32, r64, atol=1e-6):
         if strict:
             assert_close(name, got, r32, rtol=1e-4, atol=atol)
-        else:
-            # factor 8, not 3: the forward's matrix products carry 22 mantissa bits (fp16 hi + lo parts), the fp32
-            # oracle's 24 - the sdf itself is 5e-7 from fp64 where the oracle is 1.5e-7 (both far inside the 1e-5 bar above), and a
-            # central difference over 2 delta = 4.9e-4 hands exactly that ratio to the normal and to everything that depends on it
-            assert_fp32_class(name, got, r32, r64, factor=8.0, atol=atol + 1e-4 * float(r64.abs().max()))
+            return
+        # delta = 2.4e-4: the reference path's own fp32 evaluation is not reproducible to 1e-4 here (a central difference over 4.9e-4 divides
+        # the sdf's round-off by that), so the bar is its fp32 CLASS - as close to the fp64 evaluation as the fp32 oracle is, x 3 (round 4:
+        # x 8, the forward's 22-bit products against fp32's 24; below delta = 2e-3 the seven evaluations now run with 24-bit products,
+        # sdfhip_numfield_forward) ...
+        assert_fp32_class(name, got, r32, r64, factor=3.0, atol=atol + 1e-4 * float(r64.abs().max()))
+        # ... and the FIXED north-star bar, element-wise gate included (both sides see identical samples), wherever the reference path
+        # itself is reproducible: rays (samples) on which |oracle fp32 - oracle fp64| stays below 2e-5 of the tensor's scale
+        r32d, r64d = r32.detach().double().cpu(), r64.detach().double().cpu()
+        lead = r32d.shape[0]
+        err = (r32d - r64d).abs().reshape(lead, -1).amax(dim=1)
+        sel = err < 2e-5 * max(float(r64d.abs().max()), 1e-12)
+        stable_rays[name] = (int(sel.sum()), lead)
+        if int(sel.sum()) > 0:
+            assert_close(name + f" [{int(sel.sum())} of {lead} rows where the fp32 oracle is within 2e-5 of fp64]", got.detach().cpu()[sel], r32d[sel],
+                         rtol=1e-4, atol=atol)
 
     bar("alpha (fg / bg merged)", fo[H.ALPHA][..., 0], rf["alpha"], a64)
     bar("weights", weights[..., 0], ref["weights"], w64)
@@ -324,6 +337,9 @@ def test_northstar_bars_config5_on_oracle_samples(device, step):
     assert int(hit.sum()) >= 16, "the case must have rays that hit something"
     bar("rendered depth", depth[hit.to(device)], ref["depth"][hit], depth64[hit])
     bar("rendered normal", normal, ref["normal"], normal64, atol=2e-6)
+    if not strict:  # the fixed-bar subset must not be vacuous for the rendered heads north_star names
+        print("rows under the fixed 1e-4 bar:", stable_rays)
+        assert stable_rays["rendered rgb"][0] >= 8 and stable_rays["rendered depth"][0] >= 4, stable_rays
 
 
 @pytest.mark.parametrize("S,white", [(48, False), (130, True)])
