@@ -279,6 +279,9 @@ def make_job(config, device, world, rank, small=False, hidden=256, rays=None, sa
 
         params, buckets, late = plan_buckets(groups, big_numel=(1 << 14) if small else (1 << 22))
         flat = FlatGradients(params, buckets=buckets, shard=True, late_buckets=late)
+        if os.environ.get("SDFHIP_BENCH_EARLY_TABLE", "1") == "1":
+            # the SDF field's table leaves from INSIDE the field's backward, behind the scatter and beside the weight-gradient GEMMs
+            flat.launch_from_native(model.field.encoding.params)
     else:
         flat = FlatGradients([p for g in groups.values() for p in g], buckets=list(groups.values()))
     flat.time_waits = world > 1
@@ -587,7 +590,8 @@ def collective_report(job, backend, exposed_reduce_by_rank, exposed_gather_by_ra
     rep = {"backend": backend, "exchange": "sharded: reduce-scatter -> fused Adam on the owned 1 / N slice -> all-gather" if shard else
                                           "all-reduce of the flat gradient, replicated Adam",
            "buckets": len(flat._buckets), "chunk_bytes": None if flat._chunk is None else 4 * flat._chunk,
-           "buckets_launched_during_backward": flat.last_overlapped_buckets, "parameters_outside_the_graph": flat.last_unused,
+           "buckets_launched_during_backward": flat.last_overlapped_buckets,
+           "buckets_launched_from_inside_the_native_backward": flat.last_early_buckets, "parameters_outside_the_graph": flat.last_unused,
            "adam_elements_visited_per_rank": job["opts"].adam.last_elements_visited,
            "phases": {
                "reduce": {"collective": ("reduce_scatter" if native else "all_reduce of the grid chunk (gloo has no reduce-scatter: same sum in the owned slice)") if shard else "all_reduce",

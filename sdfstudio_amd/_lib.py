@@ -94,6 +94,7 @@ _SIGNATURES = {
     "sdfhip_embedding_backward": (c_i32, [ctypes.c_void_p, c_float_p, c_i64, c_i32, c_i64, c_float_p, ctypes.c_void_p]),
     "sdfhip_numfield_workspace_size": (c_i64, [ctypes.c_void_p, c_i64]),
     "sdfhip_numfield_inference_workspace_size": (c_i64, [ctypes.c_void_p, c_i64]),
+    "sdfhip_set_table_grad_callback": (None, [ctypes.c_void_p, ctypes.c_void_p]),
     "sdfhip_numfield_sdf_rows": (c_i64, [c_i64]),
     "sdfhip_numfield_forward": (c_i32, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_i64, c_i32,
                                         c_float_p, ctypes.c_float, c_i32, ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
@@ -255,6 +256,25 @@ def grid_levels(cfg: GridCfg):
     n = c_i64(0)
     check(lib.sdfhip_grid_levels(ctypes.byref(cfg), levels, ctypes.byref(n)), "sdfhip_grid_levels")
     return list(levels), int(n.value)
+
+
+TABLE_GRAD_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
+_table_grad_cb_keepalive = None
+
+
+def set_table_grad_callback(fn) -> None:
+    """fn(table_bar_ptr: int, stream_ptr: int) is called from inside sdfhip_field_backward / sdfhip_numfield_backward right after the
+    hash-table scatter has been enqueued on `stream` (include/sdfhip.h: sdfhip_set_table_grad_callback); None clears it.  Exceptions
+    cannot cross the C frame: the callee has to catch and report them itself."""
+    global _table_grad_cb_keepalive
+    lib = load()
+    if fn is None:
+        lib.sdfhip_set_table_grad_callback(None, None)
+        _table_grad_cb_keepalive = None
+        return
+    cb = TABLE_GRAD_CB(lambda _user, table_bar, stream: fn(int(table_bar or 0), int(stream or 0)))
+    lib.sdfhip_set_table_grad_callback(ctypes.cast(cb, ctypes.c_void_p), None)
+    _table_grad_cb_keepalive = cb  # the C side holds a raw pointer to it
 
 
 def profile_enable(on: bool) -> int:

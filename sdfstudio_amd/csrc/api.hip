@@ -1,4 +1,5 @@
 // sdfhip — C ABI implementation (include/sdfhip.h): descriptor tables, workspace carving, kernel sequencing.
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -189,6 +190,23 @@ struct SideLane {
   ~SideLane() { release(); }
 };
 static thread_local SideLane g_side;
+
+// ------------------------------------------------------------------------------------------------ "the table's gradient is enqueued" hook
+// A data-parallel host wants to start the exchange of the hash table's gradient - 1.8 GB at BASELINE config 5 - the moment the scatter
+// that produces it is in the queue, not when the whole backward call (scatter, then ~2 ms of weight-gradient GEMMs) returns.  The two
+// field backwards call this right after the scatter has been enqueued on `stream` (the side lane when forked, else the caller's stream):
+// a collective the host enqueues behind `stream` inside the callback runs beside the weight-gradient GEMMs this call enqueues next on the
+// caller's stream.  Process-wide, set once (sdfhip_set_table_grad_callback); the callee must not synchronise.
+static std::atomic<sdfhip_table_grad_cb> g_table_cb{nullptr};
+static std::atomic<void*> g_table_cb_user{nullptr};
+extern "C" void sdfhip_set_table_grad_callback(sdfhip_table_grad_cb cb, void* user) {
+  g_table_cb_user.store(user);
+  g_table_cb.store(cb);
+}
+static inline void notify_table_grad(const float* table_bar, hipStream_t stream) {
+  const sdfhip_table_grad_cb cb = g_table_cb.load();
+  if (cb != nullptr) cb(g_table_cb_user.load(), table_bar, (sdfhip_stream_t)stream);
+}
 
 // ------------------------------------------------------------------------------------------------ field handle
 struct LinearInfo {
@@ -1265,6 +1283,7 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
     else grid_bwd_kernel<<<dim3((unsigned)((P + 255) / 256), f->grid.n_levels * (f->grid.n_features / 2)), 256, 0, gs>>>(ga);
   }
   if (forked) SDFHIP_CHECK_HIP(hipEventRecord(g_side.join, gs));
+  notify_table_grad(table_bar, gs);  // the table's gradient is complete on `gs` from here on: a host may start its exchange behind it
 
   // 5. weight gradients: split-K GEMMs over points
   const int64_t n_tiles = NP / 32;
@@ -1705,6 +1724,7 @@ extern "C" int sdfhip_numfield_backward(const SdfHipField* f, const float* packe
     else grid_bwd_kernel<<<dim3((unsigned)((P7 + 255) / 256), f->grid.n_levels * (f->grid.n_features / 2)), 256, 0, gs>>>(ga);
   }
   if (forked) SDFHIP_CHECK_HIP(hipEventRecord(g_side.join, gs));
+  notify_table_grad(table_bar, gs);  // the table's gradient is complete on `gs` from here on: a host may start its exchange behind it
 
   // 5. weight gradients.  Hidden layers: all 7 P points; the output layer's feature rows: the centre tiles only (no other point has a
   //    feature cotangent), its sdf row: all points

@@ -137,6 +137,12 @@ class FlatGradients:
         if self.shard:  # the grid's chunk: a multiple of the quantum (None: one chunk per bucket)
             self._chunk = None if self._chunk is None else max(self._chunk // self._quantum, 1) * self._quantum
         self._late = set(int(i) for i in late_buckets)
+        # buckets a NATIVE backward launches itself, the moment their gradient is in the queue (launch_from_native)
+        self._early: Dict[int, int] = {}        # id(param) -> bucket index (single-parameter buckets only)
+        self._early_done: set = set()
+        self._producers: Dict[int, int] = {}    # id(param) -> autograd edges into its AccumulateGrad in this step's graph (zero(loss))
+        self._cb_error: Optional[BaseException] = None
+        self.last_early_buckets = 0
         self._gather_work = []   # in-flight parameter all-gathers (sharded mode): (work, a, b, late)
         self._gather_events = []
         self.last_gather_collectives = 0
@@ -152,6 +158,25 @@ class FlatGradients:
         self._wait_events = []
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
         self._arm()
+
+    def close(self):
+        """Detach from the parameters: hooks and gradient slots removed, the native callback cleared (a second FlatGradients over the same
+        parameters - tests, a re-built optimiser - must not find this one's hooks still firing)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        for p in self.params:
+            for attr in (SLOT_ATTR, CLAIM_ATTR):
+                if hasattr(p, attr):
+                    delattr(p, attr)
+        if self._early:
+            try:
+                from sdfstudio_amd import _lib
+
+                _lib.set_table_grad_callback(None)
+            except Exception:  # noqa: BLE001 - library not loadable here: nothing was registered either
+                pass
+            self._early = {}
 
     # ---- buffer ownership
     def _view(self, p):
@@ -242,6 +267,7 @@ class FlatGradients:
         can fire in loss.backward() (DDP's find_unused_parameters walk, torch/nn/parallel/distributed.py; the reference enables it:
         pipelines/base_pipeline.py:242)."""
         seen, out = set(), set()
+        self._producers = {}
         stack = [loss.grad_fn]
         while stack:
             fn = stack.pop()
@@ -252,7 +278,11 @@ class FlatGradients:
             if var is not None:
                 out.add(id(var))
                 continue
-            stack.extend(f for f, _ in fn.next_functions)
+            for f, _ in fn.next_functions:
+                v = getattr(f, "variable", None) if f is not None else None
+                if v is not None:
+                    self._producers[id(v)] = self._producers.get(id(v), 0) + 1  # one edge = one producer of this parameter's gradient
+                stack.append(f)
         return out
 
     def _arm(self, used: Optional[set] = None):
@@ -265,6 +295,10 @@ class FlatGradients:
         self._armed = True
         self.last_overlapped_buckets = 0
         self.last_collectives = 0
+        self.last_early_buckets = 0
+        self._early_done = set()
+        if used is None:
+            self._producers = {}
         self.last_unused = 0 if used is None else sum(1 for p in self.params if id(p) not in used)
 
     def _raw_ranges(self, bi):
@@ -374,6 +408,15 @@ class FlatGradients:
             raise RuntimeError("FlatGradients: a gradient arrived for a parameter that is not in the graph of the loss zero() was given "
                                "(zero(loss) and backward() must see the same loss)")
         self._pending[bi] -= 1
+        if bi in self._early_done and self._pending[bi] == 0:
+            # launched from inside the native backward that produced it (launch_from_native): the hook only confirms that autograd adopted
+            # the slot the kernels wrote - anything else would mean the collective carried a partial gradient
+            if not self._is_view(p):
+                raise RuntimeError("FlatGradients: a bucket was launched from the native backward, but autograd delivered a gradient that is "
+                                   "not the slot it wrote (another producer appeared after the graph walk)")
+            if self._overlap:
+                self._launch_ready(from_hook=True)
+            return
         if self._pending[bi] < 0 or self._launched[bi]:
             raise RuntimeError("FlatGradients: a second backward reached a parameter before finish() - its bucket may already be "
                                "in flight (accumulate micro-batches into one loss, or call finish() / zero() between backwards)")
@@ -388,6 +431,41 @@ class FlatGradients:
         if self._overlap:
             self._launch_ready(from_hook=True)
 
+    def launch_from_native(self, param: torch.nn.Parameter):
+        """Let the native backward that produces `param`'s gradient start its bucket's exchange ITSELF, the moment the producing kernels
+        are in the queue (include/sdfhip.h: sdfhip_set_table_grad_callback): the SDF field is one autograd node, so the table's hook
+        fires only after the whole call - scatter, THEN ~2 ms of weight-gradient GEMMs - has been enqueued, and a collective launched
+        from the hook waits for all of it.  From the callback it waits for the scatter alone and travels beside the GEMMs.
+        Conditions, all checked per step (else the hook launches the bucket as usual): `param` is a bucket of its own and the next to
+        leave; zero(loss) found exactly ONE producer of its gradient in the graph; the kernels wrote the flat slot itself."""
+        from sdfstudio_amd import _lib
+
+        bi = self._bucket_of[id(param)]
+        assert len(self._buckets[bi]) == 1, "launch_from_native: the parameter must be a bucket of its own (distributed.plan_buckets)"
+        self._early[id(param)] = bi
+        _lib.set_table_grad_callback(self._native_ready)
+
+    def _native_ready(self, table_bar_ptr: int, stream_ptr: int):
+        try:
+            if not (self._armed and self._overlap and _dist_on(self.group)):
+                return
+            for pid, bi in self._early.items():
+                if table_bar_ptr != self.flat.data_ptr() + 4 * self._offset[pid]:
+                    continue  # another field's table, or a producer that was handed an ordinary tensor
+                if bi != self._next or self._launched[bi] or self._producers.get(pid, 0) != 1:
+                    return
+                if self.flat.is_cuda:
+                    with torch.cuda.stream(torch.cuda.ExternalStream(stream_ptr, device=self.flat.device)):
+                        self._launch(bi)  # the collective orders itself behind `stream`: the scatter, not the GEMMs that follow
+                else:
+                    self._launch(bi)
+                self._early_done.add(bi)
+                self.last_overlapped_buckets += 1
+                self.last_early_buckets += 1
+                return
+        except BaseException as e:  # noqa: BLE001 - cannot cross the C frame: finish() re-raises
+            self._cb_error = e
+
     def finish(self, average: bool = True, wait: bool = True) -> float:
         """Wait for the outstanding bucket all-reduces (launching, in index order, every bucket that has not left yet: e.g. one
         behind a bucket with parameters unused in this step).  average=True turns the sums into means in place; average=False
@@ -395,6 +473,9 @@ class FlatGradients:
         gradient by it as it reads it (engine/optimizers.py), which saves the pass over the buffer."""
         if not self._armed:
             raise RuntimeError("FlatGradients.finish() twice without zero() + backward in between")
+        if self._cb_error is not None:
+            err, self._cb_error = self._cb_error, None
+            raise RuntimeError("FlatGradients: the native table-gradient callback failed") from err
         for p in self.params:
             if not self._is_view(p):
                 if p.grad is None:

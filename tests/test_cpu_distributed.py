@@ -529,3 +529,86 @@ def test_sharded_exchange_matches_allreduce_world2():
 
 def test_sharded_exchange_matches_allreduce_world4():
     _check_sharded_against_allreduce(4)
+
+
+class _FieldLikeNode(torch.autograd.Function):
+    """Stands in for the SDF field's single autograd node: its backward writes the table's gradient into the gradient SLOT (grad_slots.py),
+    tells the exchange "the table's gradient is in the queue" the way the native backward does through sdfhip_set_table_grad_callback,
+    and only then produces the weight gradient."""
+
+    @staticmethod
+    def forward(ctx, table, weight, flat, scale):
+        ctx.flat, ctx.scale, ctx.table, ctx.weight = flat, scale, table, weight
+        return (table.sum() + weight.sum()) * scale
+
+    @staticmethod
+    def backward(ctx, g):
+        from sdfstudio_amd.grad_slots import grad_target
+
+        tb, is_slot = grad_target(ctx.table, zero_init=True)
+        tb.add_(float(g) * ctx.scale)
+        if is_slot:  # what api.hip's notify_table_grad hands to the registered callback: the pointer it wrote to (and a stream)
+            ctx.flat._native_ready(tb.data_ptr(), 0)
+        wb, _ = grad_target(ctx.weight, zero_init=True)
+        wb.add_(float(g) * ctx.scale)
+        return tb, wb, None, None
+
+
+def _early_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sdfstudio_amd.distributed import FlatGradients
+
+    table = torch.nn.Parameter(torch.zeros(4096))
+    weight = torch.nn.Parameter(torch.zeros(300))
+    other = torch.nn.Parameter(torch.zeros(50))
+    res = {}
+    for early in (True, False):
+        flat = FlatGradients([table, weight, other], buckets=[[table], [weight], [other]], shard=True, late_buckets=[0], chunk_numel=1024)
+        if early:
+            flat._early[id(table)] = 0  # launch_from_native without registering the C callback (the node above calls _native_ready itself)
+        order = []
+        orig = flat._launch
+        flat._launch = lambda bi, _o=orig: (order.append(bi), _o(bi))[1]
+        # step 1: one producer -> the table's bucket leaves from inside the node's backward
+        loss = _FieldLikeNode.apply(table, weight, flat, float(rank + 1)) + (other * 3.0).sum()
+        flat.zero(loss)
+        loss.backward()
+        first = (flat.last_early_buckets, list(order), flat.last_overlapped_buckets)
+        flat.finish()
+        g1 = flat.flat.clone()
+        # step 2: TWO producers of the table's gradient in the graph -> no early launch (the first producer's slot is not the whole gradient)
+        order.clear()
+        loss = _FieldLikeNode.apply(table, weight, flat, float(rank + 1)) + (table * 2.0).sum() + (other * 3.0).sum()
+        flat.zero(loss)
+        loss.backward()
+        second = (flat.last_early_buckets, list(order))
+        flat.finish()
+        res[early] = (first, second, g1, flat.flat.clone())
+        flat._early = {}  # (nothing was registered with the library)
+        flat.close()
+        for p in (table, weight, other):
+            p.grad = None
+    ret[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_table_bucket_leaves_from_inside_the_native_backward_world2():
+    """"the table's chunks are launched from the grid_bwd8 completion event inside sdfhip_numfield_backward, before the
+    weight-gradient GEMMs".  Protocol side (the native side is the callback of include/sdfhip.h, exercised on the GPU by
+    tests/test_gpu_bench_multirank.py): with ONE producer of the table's gradient its bucket leaves from inside the node's backward, first
+    and before the weight gradient exists; with two producers it waits for the hook; the reduced gradients are the same either way."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_early_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    for r in range(world):
+        (f_e, s_e, g1_e, g2_e), (f_n, s_n, g1_n, g2_n) = ret[r][True], ret[r][False]
+        assert f_e[0] == 1 and f_e[1][0] == 0 and sorted(f_e[1]) == [0, 1, 2], f_e
+        assert f_n[0] == 0 and sorted(f_n[1]) == [0, 1, 2], f_n
+        assert s_e[0] == 0 and s_n[0] == 0, (s_e, s_n)
+        assert torch.equal(g1_e, g1_n) and torch.equal(g2_e, g2_n)
+        # sums over the two ranks: table / weight 1 + 2 = 3, other 3 + 3 = 6 (finish() averages: / 2)
+        assert torch.allclose(g1_e[:4096], torch.full((4096,), 1.5)) and torch.allclose(g2_e[:4096], torch.full((4096,), 3.5))

@@ -43,6 +43,8 @@ def test_bench_self_spawns_two_ranks():
     # outside a NeuS-facto step's graph and must not keep the "fields" bucket waiting for finish()
     assert c["parameters_outside_the_graph"] >= 1, c
     assert c["buckets_launched_during_backward"] >= 1, c
+    # ... and the SDF table's chunks leave from INSIDE the field's backward (sdfhip_set_table_grad_callback), behind the scatter
+    assert c["buckets_launched_from_inside_the_native_backward"] == 1, c
 
 
 @pytest.mark.gpu
