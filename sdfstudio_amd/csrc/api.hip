@@ -337,21 +337,26 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
     return m;
   };
   auto add_pack = [&](int64_t src, int ld, int kb, int nbo, int rowmap, int colmap, int transpose, float scale) {
-    PackDesc d;
-    memset(&d, 0, sizeof(d));
-    d.src_off = src;
-    d.dst_off = poff;
-    d.ld = ld;
-    d.kb = kb;
-    d.nbo = nbo;
-    d.rowmap_off = rowmap;
-    d.colmap_off = colmap;
-    d.transpose = transpose;
-    d.scale = scale;
-    f->pack.push_back(d);
+    // layer-at-a-time kernels: a workgroup owns kWideNbo of a matrix's 2 kWideNbo out-blocks - the matrix is packed as two matrices of
+    // kWideNbo out-blocks, half after half (the map that is indexed by the OUT row moves on by 32 kWideNbo entries for the second)
+    const int parts = (f->k->layerwise && nbo == 2 * kWideNbo) ? 2 : 1;
     const int64_t at = poff;
-    poff += (int64_t)kb * nbo * kChunkBlockFloats;
-    f->max_pack_elems = std::max(f->max_pack_elems, kb * nbo * 1024);
+    for (int h = 0; h < parts; ++h) {
+      PackDesc d;
+      memset(&d, 0, sizeof(d));
+      d.src_off = src;
+      d.dst_off = poff;
+      d.ld = ld;
+      d.kb = kb;
+      d.nbo = nbo / parts;
+      d.rowmap_off = rowmap + ((!transpose) ? h * 32 * kWideNbo : 0);
+      d.colmap_off = colmap + (transpose ? h * 32 * kWideNbo : 0);
+      d.transpose = transpose;
+      d.scale = scale;
+      f->pack.push_back(d);
+      poff += (int64_t)kb * d.nbo * kChunkBlockFloats;
+      f->max_pack_elems = std::max(f->max_pack_elems, kb * d.nbo * 1024);
+    }
     return at;
   };
   auto add_vec = [&](int64_t src, int n, int map, int stride) {
@@ -572,8 +577,10 @@ static void fill_geo_ptrs(const SdfHipField* f, const float* packed, GeoPtrs* p,
   p->nl = f->nl;
   p->skip = f->skip;
   for (int l = 0; l <= f->nl; ++l) {
-    p->wp[l] = packed + f->g_wp[l] + chunk_part_offset(f->nbo_geo(l), ns);
-    p->wpT[l] = packed + f->g_wpT[l] + chunk_part_offset(l == f->skip ? f->nb3 : f->kb_geo(l), ns);
+    // (layer-at-a-time kernels: 16-out-block matrices are packed as two halves of kWideNbo, see add_pack in sdfhip_field_create)
+    auto chunk_nbo = [&](int nbo) { return (f->k->layerwise && nbo == 2 * kWideNbo) ? kWideNbo : nbo; };
+    p->wp[l] = packed + f->g_wp[l] + chunk_part_offset(chunk_nbo(f->nbo_geo(l)), ns);
+    p->wpT[l] = packed + f->g_wpT[l] + chunk_part_offset(chunk_nbo(l == f->skip ? f->nb3 : f->kb_geo(l)), ns);
     p->bias[l] = packed + f->g_bias[l];
   }
   if (f->skip >= 0) p->wpT_in0 = packed + f->g_wpT_in0 + chunk_part_offset(f->k->nb0, ns);

@@ -31,6 +31,9 @@
 #include "mlp_core.h"
 
 constexpr int kMaxLayers = 10;
+// layer-at-a-time kernels (wide_kernels.h, hidden width 512): out-blocks one workgroup owns; the packed weights of a 16-out-block matrix
+// are stored as two 8-out-block matrices, half after half (api.hip: field_create / fill_geo_ptrs)
+constexpr int kWideNbo = 8;
 // Precision modes (mlp_core.h).  Everything the forward call returns (sdf, geo feature, d sdf / dx, rgb) carries the parity
 // targets and the raw d sdf / dx feeds the colour network's ReLUs: fp32-class products, by default as fp16 hi + lo parts with
 // 3 terms (mode 4; -DSDFHIP_NS_FWD=3 selects the 6-term bf16 form, twice the matrix instructions for the last two mantissa

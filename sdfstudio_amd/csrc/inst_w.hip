@@ -17,12 +17,14 @@ static void launch(K kernel, unsigned grid, size_t lds_bytes, hipStream_t s, A..
   hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), lds_bytes, s, args...);
 }
 static size_t lds(int ns) { return WideLds<GD>::floats(ns) * sizeof(float); }
+// launches of the half-width kernels: 2 workgroups per tile group, in whole sets of 8 groups x 2 halves (wide_block)
+static unsigned halves(unsigned groups) { return (groups + 7) / 8 * 16; }
 
 template <int NS, bool ADD>
 static void down_pass(const WideDownArgs& d, unsigned grid, hipStream_t s) {
   for (int l = d.p.nl - 1; l >= 0; --l) {
-    if (l == 0 || l == d.p.skip) launch(wide_down_kernel<GD, NS, ADD, false, true>, grid, lds(NS), s, d, l);  // the part that goes to in0
-    if (l > 0) launch(wide_down_kernel<GD, NS, ADD, true, false>, grid, lds(NS), s, d, l);
+    if (l == 0 || l == d.p.skip) launch(wide_down_kernel<GD, NS, ADD, false, true>, grid, lds(NS), s, d, l, (int64_t)grid);  // the part that goes to in0
+    if (l > 0) launch(wide_down_kernel<GD, NS, ADD, true, false>, halves(grid), lds(NS), s, d, l, (int64_t)grid);
   }
 }
 
@@ -30,10 +32,11 @@ static void down_pass(const WideDownArgs& d, unsigned grid, hipStream_t s) {
 // without a backward.  The per-layer tensors are this path's only inter-layer storage: every mode writes u_l (and the chain r_l).
 static void geo_fwd(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s) {
   const int NL = a.p.nl, SKIP = a.p.skip;
+  const int64_t G = grid;
   for (int l = 0; l < NL; ++l) {
-    if (l == 0) launch(wide_fwd_kernel<GD, false, true>, grid, lds(kNsFwd), s, a, l);
-    else if (l == SKIP) launch(wide_fwd_kernel<GD, true, true>, grid, lds(kNsFwd), s, a, l);
-    else launch(wide_fwd_kernel<GD, true, false>, grid, lds(kNsFwd), s, a, l);
+    if (l == 0) launch(wide_fwd_kernel<GD, false, true>, halves(grid), lds(kNsFwd), s, a, l, G);
+    else if (l == SKIP) launch(wide_fwd_kernel<GD, true, true>, halves(grid), lds(kNsFwd), s, a, l, G);
+    else launch(wide_fwd_kernel<GD, true, false>, halves(grid), lds(kNsFwd), s, a, l, G);
   }
   const bool grad = mode == 0 || mode == 4;
   if (grad) launch(wide_out_kernel<GD, true, true>, grid, lds(kNsFwd), s, a);
@@ -55,14 +58,15 @@ static void geo_fwd(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s)
 template <bool TANGENT>
 static void bwd_impl(const GeoBwdArgs& a, unsigned grid, hipStream_t s) {
   const int NL = a.p.nl, SKIP = a.p.skip;
+  const int64_t G = grid;
   if constexpr (TANGENT) {
     for (int l = 0; l < NL; ++l) {
-      if (l == 0) launch(wide_tan_kernel<GD, false, true>, grid, lds(kNsGrad), s, a, l);
-      else if (l == SKIP) launch(wide_tan_kernel<GD, true, true>, grid, lds(kNsGrad), s, a, l);
-      else launch(wide_tan_kernel<GD, true, false>, grid, lds(kNsGrad), s, a, l);
+      if (l == 0) launch(wide_tan_kernel<GD, false, true>, halves(grid), lds(kNsGrad), s, a, l, G);
+      else if (l == SKIP) launch(wide_tan_kernel<GD, true, true>, halves(grid), lds(kNsGrad), s, a, l, G);
+      else launch(wide_tan_kernel<GD, true, false>, halves(grid), lds(kNsGrad), s, a, l, G);
     }
   }
-  launch(wide_bwd_seed_kernel<GD, TANGENT>, grid, lds(kNsGrad), s, a);
+  launch(wide_bwd_seed_kernel<GD, TANGENT>, halves(grid), lds(kNsGrad), s, a, G);
   WideDownArgs d;
   std::memset(&d, 0, sizeof(d));
   d.p = a.p;

@@ -154,8 +154,8 @@ struct Stores {
 
 // out-blocks per operand-read group: a divisor of NBO, small enough that two groups of weight fragments (the one being
 // multiplied and the one in flight from LDS) fit the register budget next to 256 accumulator registers
-constexpr int gemm_group(const int nbo, const int ns) {
-  const int gmax = ns_parts(ns) == 3 ? 2 : 4;
+constexpr int gemm_group(const int nbo, const int ns, const int gcap = 4) {
+  const int gmax = (ns_parts(ns) == 3 ? 2 : 4) < gcap ? (ns_parts(ns) == 3 ? 2 : 4) : gcap;
   for (int g = gmax; g > 1; --g)
     if (nbo % g == 0) return g;
   return nbo <= 5 ? nbo : 1;
@@ -222,7 +222,9 @@ SDFHIP_D void split_put(SplitBlk<NS>& s, const InRange r) {
   split_put<NS, E, false>(s, r.v);
 }
 
-template <int KB, int NBO, class ST, int NS, int NEXTP, int MAXA, class Fetch, class Make, class NextFetch>
+// GCAP: upper bound on the out-blocks per operand-read group (kernels that live in 256 registers - two workgroups per CU,
+// wide_kernels.h - hold two groups of 2 x 2 weight fragments instead of 2 x 4)
+template <int KB, int NBO, class ST, int NS, int NEXTP, int GCAP = 4, int MAXA, class Fetch, class Make, class NextFetch>
 SDFHIP_D void tp_gemm(f32x16 (&acc)[MAXA], Raw& carry, Fetch&& fetch, Make&& make, NextFetch&& next_fetch, WStream& ws,
                       const float* __restrict__ wp, const float* __restrict__ next_wp) {
   static_assert(NBO <= MAXA, "accumulator tile too small");
@@ -233,7 +235,7 @@ SDFHIP_D void tp_gemm(f32x16 (&acc)[MAXA], Raw& carry, Fetch&& fetch, Make&& mak
   constexpr int NT = NP == 2 ? 3 : 6;
   constexpr int ta[6] = {1, NP == 2 ? 0 : 2, 0, 1, 0, 0};
   constexpr int tb[6] = {NP == 2 ? 0 : 1, NP == 2 ? 1 : 0, NP == 2 ? 0 : 2, 0, 1, 0};
-  constexpr int G = gemm_group(NBO, NS), NG = NBO / G;  // groups per k half
+  constexpr int G = gemm_group(NBO, NS, GCAP), NG = NBO / G;  // groups per k half
   static_assert(NBO % G == 0, "operand groups must tile the out-blocks");
   constexpr int NGRP = 2 * NG, MPG = NT * G, NM = NGRP * MPG;  // groups, MFMAs per group, MFMAs per step
   const int lane = ws.lane;
