@@ -362,6 +362,69 @@ def max_over_ranks(dt, device, world):
     return float(t.item())
 
 
+def pmc_rows(select):
+    """Rows of the newest committed rocprofv3 PMC summary (profiles/<tag>_pmc_summary.csv, tools/prof_summary.py) whose file name passes
+    `select`, with the identity of the library the passes ran on: (rows, file name, library digest) or (None, None, None).  rocprofv3 cannot
+    run inside the bench, so `traffic` fields quote these files - and say `traffic_stale` when the loaded library is not the profiled one."""
+    import csv
+
+    pm_dir = os.path.join(ROOT, "profiles")
+    for f in sorted((f for f in os.listdir(pm_dir) if f.endswith("_pmc_summary.csv") and select(f)), reverse=True):
+        with open(os.path.join(pm_dir, f)) as fh:
+            rows = list(csv.DictReader(fh))
+        digest = None
+        meta = os.path.join(pm_dir, f.replace("_pmc_summary.csv", "_pmc_meta.json"))
+        if os.path.exists(meta):
+            with open(meta) as fh:
+                digest = json.load(fh).get("library_digest")
+        return rows, f, digest
+    return None, None, None
+
+
+def geo_fwd_flags(kernel_name):
+    """Template arguments after the dimensions of a geo_fwd_kernel<GeoDims<..>, GRAD, SAVE, FEAT, PHASE[, NS]> instantiation name."""
+    k = kernel_name.replace(" ", "")
+    if not k.startswith("geo_fwd_kernel<GeoDims<") or ">," not in k:
+        return []
+    return k.split(">,", 1)[1].rstrip(">").split(",")
+
+
+def pmc_traffic_per_launch(select, kernel_pred):
+    """HBM bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, the guide's gfx950 correction) summed over the kernels `kernel_pred` picks."""
+    from sdfstudio_amd import build as _build
+
+    rows, f, digest = pmc_rows(select)
+    if not rows:
+        return None
+    picked = [r for r in rows if kernel_pred(r.get("kernel", "")) and r.get("hbm_write_GB") not in (None, "", "nan")]
+    if not picked:
+        return None
+    tot = sum((float(r["hbm_read_GB_corrected_x2"]) + float(r["hbm_write_GB"])) * 1e9 for r in picked)
+    return {"traffic": tot, "traffic_kernels": [r["kernel"] for r in picked],
+            "traffic_source": f"profiles/{f} (FETCH_SIZE x 2 + WRITE_SIZE per launch, separate rocprofv3 --pmc passes)",
+            "traffic_library_digest": digest, "traffic_stale": digest != (_build.built_digest() or None)}
+
+
+def encode_step_traffic(select):
+    """HBM bytes of all geo_encode* launches of ONE training step from the newest committed PMC summary `select` accepts.  Evidence tags:
+    <round>_cfg5 (8 levels), <round>_cfg5l16 (steady state); everything else is config 2.  The slot covers every encode launch of a step
+    (config 5: the 8-feature kernel of the SDF grid and the 2-feature one of the background grid); the PMC passes sample whole training
+    steps, geo_bwd_kernel runs once per step and phase."""
+    from sdfstudio_amd import build as _build
+
+    rows, f, digest = pmc_rows(select)
+    if not rows:
+        return None
+    sampled = min([int(r["launches_sampled"]) for r in rows if r.get("kernel", "").startswith("geo_bwd_kernel")] or [0])
+    tot = sum((float(r["hbm_read_GB_corrected_x2"]) + float(r["hbm_write_GB"])) * 1e9 * int(r["launches_sampled"])
+              for r in rows if r.get("kernel", "").startswith("geo_encode") and r.get("hbm_write_GB"))
+    if sampled <= 0 or tot <= 0:
+        return None
+    return {"traffic": tot / sampled,  # HBM bytes per training step (PMC: average launch x launches, over the steps sampled)
+            "traffic_source": f"profiles/{f} (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc passes; all geo_encode* launches)",
+            "traffic_library_digest": digest, "traffic_stale": digest != (_build.built_digest() or None)}
+
+
 def encode_roofline_config5(model, prof, steps, P):
     """K1 of SURVEY 8(d) for config 5: 7 evaluations per ray-sample (centre + 6 taps); ACTIVE levels x 8 corners x 8 features x 4 B +
     position in + 6 in0 blocks out (progressive levels: the kernel skips the levels the mask has switched off: not counted either)."""
@@ -402,6 +465,9 @@ def config5_legs(device, world, rank, steps=10, warmup=3):
                      "adam_rows_live": sum(b - a for a, b in flat.live_ranges()),
                      "adam_rows_visited": job["opts"].adam.last_elements_visited,  # this rank: 1 / N of the live rows when sharded
                      "roofline": encode_roofline_config5(job["model"], prof, steps, P)}
+        if out[name]["roofline"] is not None:
+            l16 = name == "levels16"
+            out[name]["roofline"].update(encode_step_traffic(lambda f, l16=l16: "cfg5" in f and ("cfg5l16" in f) == l16) or {})
     del job
     torch.cuda.empty_cache()
     return out
@@ -664,7 +730,9 @@ def dense_sdf_leg(model, device, resolution=(512, 512, 256), reps=3):
                          "achieved_is": f"sdf-row flops {g / 1e6:.3f} MFLOP per point x 3 issued 16-bit MFMA terms per fp32-class product x "
                                         "points / the kernel's launch time (HIP events)",
                          "flops_per_point": g, "terms_per_product": 3, "points_per_s_kernel_only": round(P / k_s, 1) if k_s > 0 else None,
-                         "traffic": None},
+                         "traffic": None, "algorithmic_bytes_per_launch": (3 * 128 + 4) * P // max(1, k_n // reps if reps else 1),
+                         # HBM bytes per launch of the MODE_SDF instantiation (a launch = one chunk of the lattice) from the committed PMC passes
+                         **(pmc_traffic_per_launch(lambda f: "_eval" in f, lambda k: geo_fwd_flags(k)[:3] == ["false", "false", "false"]) or {})},
             "encode": {"GBps_on_gather_bytes": round(enc_bytes / (e_ms / reps * 1e-3) / 1e9, 1) if e_ms > 0 else None,
                        "bytes_per_point": enc_bytes // P}}
 
@@ -711,6 +779,9 @@ def forward_only_leg(job, device, n_rays, n_samples, reps=10):
                          "achieved_is": "(2G + C) flops per ray-sample x 3 issued 16-bit MFMA terms / the three launches' time (HIP events, "
                                         "instrumented pass)",
                          "mfma_kernels_ms": round(mfma_ms, 3), "traffic": None,
+                         # HBM bytes of the three launches of one batch from the committed PMC passes (forward | chain | colour, nothing-saved forms)
+                         **(pmc_traffic_per_launch(lambda f: "_eval" in f, lambda k: geo_fwd_flags(k)[:3] == ["true", "false", "true"] or
+                                                   (k.startswith("col_fwd_kernel<") and k.replace(" ", "").endswith(",false>"))) or {}),
                          "forward_to_chain_handover_bytes": handover,
                          "handover_note": "u_l = s(z_l) of all 8 layers, 8 KiB per point: written by the forward launch, read by the chain "
                                           "launch (DESIGN.md section 4.1: why no on-chip store holds it)"}}
@@ -886,23 +957,7 @@ def run(args):
                 enc = {"kernel": "geo_encode_kernel", "bound": "hbm", "achieved": round(eb / es / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                        "frac": round(eb / es / 1e9 / PEAK_HBM_GBS, 4), "algorithmic_bytes": eb, "achieved_is": what + " / its time per step",
                        "ms_per_step": round(enc_ms / args.steps, 4), "traffic": None}
-            for f in sorted((f for f in os.listdir(pm_dir) if f.endswith("_pmc_summary.csv")), reverse=True):
-                # evidence tags: <round>_cfg5 (8 levels), <round>_cfg5l16 (steady state); everything else is config 2
-                if ("cfg5" in f) != cfg5 or (cfg5 and ("cfg5l16" in f) != (args.levels == 16)):
-                    continue
-                import csv
-
-                with open(os.path.join(pm_dir, f)) as fh:
-                    prows = list(csv.DictReader(fh))
-                # the slot covers every encode launch of a step (config 5: the 8-feature kernel of the SDF grid and the 2-feature one of
-                # the background grid); the PMC passes sample whole training steps, geo_bwd_kernel runs once per step and phase
-                sampled = min([int(r["launches_sampled"]) for r in prows if r.get("kernel", "").startswith("geo_bwd_kernel")] or [0])
-                tot = sum((float(r["hbm_read_GB_corrected_x2"]) + float(r["hbm_write_GB"])) * 1e9 * int(r["launches_sampled"])
-                          for r in prows if r.get("kernel", "").startswith("geo_encode") and r.get("hbm_write_GB"))
-                if sampled > 0 and tot > 0:
-                    enc["traffic"] = tot / sampled  # HBM bytes per training step (PMC: average launch x launches, over the steps sampled)
-                    enc["traffic_source"] = f"profiles/{f} (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc passes; all geo_encode* launches)"
-                break
+            enc.update(encode_step_traffic(lambda f: "_eval" not in f and ("cfg5" in f) == cfg5 and (not cfg5 or ("cfg5l16" in f) == (args.levels == 16))) or {})
             if cfg5:
                 roof = enc
         kernels = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] / args.steps} for k, v in prof.items()}

@@ -192,6 +192,17 @@ class _ThetaFunction(torch.autograd.Function):
         return (None, *outs)
 
 
+def _graph_inputs(*tensors):
+    """The tensors a field operator takes as autograd inputs, as they must be handed to Function.apply: themselves while a graph is being
+    recorded, DETACHED under torch.no_grad().  ctx.needs_input_grad reports requires_grad of the inputs whatever the grad mode is (and
+    Function.forward always runs with grad mode off), so a Parameter passed under no_grad made the eval render run the TRAINING kernels:
+    every saved tensor written (8 KiB of r_l per point on top of the u_l handover) and the training workspace carved - found in round 5
+    from the kernel names in profiles/r5a_eval_kernel_stats.csv."""
+    if torch.is_grad_enabled():
+        return tensors
+    return tuple(None if t is None else t.detach() for t in tensors)
+
+
 class _FieldFunction(torch.autograd.Function):
     """One autograd node for the whole field: (theta, table[, emb]) -> (sdf, d sdf/dx, rgb, contracted x)."""
 
@@ -668,7 +679,8 @@ class SDFField(nn.Module):
         if self.config.use_appearance_embedding and self.training:
             emb = torch.zeros(n, self.config.appearance_embedding_dim, device=x.device)
         field_fn = self if self._cfg_c.contract == 0 else self._uncontracted()
-        _, grad, _, _ = _FieldFunction.apply(self._theta(), self.encoding.params, emb, field_fn, x.detach().contiguous(),
+        theta, table, emb = _graph_inputs(self._theta(), self.encoding.params, emb)
+        _, grad, _, _ = _FieldFunction.apply(theta, table, emb, field_fn, x.detach().contiguous(),
                                              torch.zeros(n, 3, device=x.device), zeros, self._mask(x.device))
         gradients = grad.reshape(*shape, 3)
         if return_sdf:
@@ -694,7 +706,8 @@ class SDFField(nn.Module):
         six taps, finite-difference normal, colour network on it - one native operator each way (_NumericalFieldFunction)."""
         if self.config.hidden_dim > 256:
             return self._numerical_outputs_composed(o, d, st, emb)  # layer-at-a-time (512-wide) kernels: not wired into the fused operator
-        sdf, grad, rgb, taps, x = _NumericalFieldFunction.apply(self._theta(), self.encoding.params, emb, self, o, d, st, self._mask(o.device),
+        theta, table, emb = _graph_inputs(self._theta(), self.encoding.params, emb)
+        sdf, grad, rgb, taps, x = _NumericalFieldFunction.apply(theta, table, emb, self, o, d, st, self._mask(o.device),
                                                                 self.numerical_gradients_delta)
         return sdf, grad, rgb, x, taps  # taps [N,S,6]: `sampled_sdf` (:644)
 
@@ -768,8 +781,8 @@ class SDFField(nn.Module):
         if self.config.use_numerical_gradients:
             sdf, grad, rgb, x, sampled_sdf = self._numerical_outputs(ray_samples, o, d, st, emb)
         else:
-            theta = self._theta()
-            sdf, grad, rgb, x = _FieldFunction.apply(theta, self.encoding.params, emb, self, o, d, st, self._mask(dev))
+            theta, table, emb = _graph_inputs(self._theta(), self.encoding.params, emb)
+            sdf, grad, rgb, x = _FieldFunction.apply(theta, table, emb, self, o, d, st, self._mask(dev))
         sdf3 = sdf[..., None]
         outputs = {
             FieldHeadNames.RGB: rgb,
@@ -801,4 +814,5 @@ class SDFField(nn.Module):
         if self.config.use_numerical_gradients:
             sdf, grad, rgb, x, self.last_sampled_sdf = self._numerical_outputs(ray_samples, o, d, st, emb)
             return sdf, grad, rgb, x
-        return _FieldFunction.apply(self._theta(), self.encoding.params, emb, self, o, d, st, self._mask(o.device))
+        theta, table, emb = _graph_inputs(self._theta(), self.encoding.params, emb)
+        return _FieldFunction.apply(theta, table, emb, self, o, d, st, self._mask(o.device))

@@ -1266,3 +1266,31 @@ def test_ray_and_position_vectors_of_the_reference():
         assert set(live) == set(g)
         for k in g:
             assert np.array_equal(live[k], g[k]), k
+
+
+def test_field_operators_get_detached_inputs_under_no_grad():
+    """ctx.needs_input_grad ignores the grad mode (and Function.forward always runs with it off): under torch.no_grad() the field
+    operators must be handed tensors that do not require grad, or the eval render runs the saving kernels on the training workspace."""
+    from sdfstudio_amd.fields.sdf_field import _graph_inputs
+
+    seen = []
+
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, a, b, c):
+            seen.append(tuple(ctx.needs_input_grad))
+            return a * 2
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 2, None, None
+
+    table = torch.nn.Parameter(torch.ones(4))
+    theta = torch.ones(4, requires_grad=True) * 1.0
+    Probe.apply(*_graph_inputs(theta, table, None))
+    with torch.no_grad():
+        Probe.apply(theta, table, None)  # what the call sites did until round 5
+        t, tb, e = _graph_inputs(theta, table, None)
+        Probe.apply(t, tb, e)
+        assert e is None and tb.data_ptr() == table.data_ptr() and not tb.requires_grad
+    assert seen == [(True, True, False), (True, True, False), (False, False, False)]

@@ -392,3 +392,40 @@ def test_field_forward_is_bit_reproducible(device, mode):
                 ref = out
             for name, a, b in zip(("sdf", "gradient", "rgb"), out, ref):
                 assert torch.equal(a, b), f"{name}: call {it}.{rep} differs from the first call in {int((a != b).sum())} elements, max {float((a - b).abs().max()):.3e}"
+
+
+def test_no_grad_forward_runs_the_nothing_saved_kernels(device):
+    """Rendering under torch.no_grad() must take the forward-only path: nothing saved (no r_l stores in the chain launch) and the
+    forward-only workspace.  Function.forward cannot see the caller's grad mode and ctx.needs_input_grad reports requires_grad of the
+    inputs regardless of it, so until round 5 the hash table (a Parameter) made every eval render run the TRAINING kernels on the
+    training workspace (kernel names in profiles/r5a_eval_kernel_stats.csv).  Same bits either way; a quarter of the memory."""
+    from helpers import load_golden, small_oracle_cfg
+    from sdfstudio_amd import _lib
+
+    g = load_golden("eval")
+    cfg = small_oracle_cfg()
+    model = product_model_from_params(g["param"], cfg, device).eval()
+    model.field.set_cos_anneal_ratio(float(g["in"]["cos_anneal"]))
+    n, s = 256, 64
+    gen = torch.Generator().manual_seed(3)
+    o = torch.randn(n, 3, generator=gen) * 0.3
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=gen), dim=-1)
+    rb = _bundle(o, d, torch.zeros(n, dtype=torch.long), cfg.near, cfg.far, device)
+    starts = torch.sort(torch.rand(n, s, generator=gen) * 3.0 + 0.5, dim=-1)[0].to(device)
+    rs = rb.get_ray_samples(starts, starts + 0.05)
+    with_graph = [t.detach().clone() for t in model.field.forward_fused(rs)[:3]]  # parameters require grad: the saving kernels
+    lib = _lib.load()
+    train_ws = lib.sdfhip_field_workspace_size(model.field._handle, n * s, 1)
+    infer_ws = lib.sdfhip_field_workspace_size(model.field._handle, n * s, 2)
+    assert infer_ws * 2 < train_ws
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    with torch.no_grad():
+        out = [t.clone() for t in model.field.forward_fused(rs)[:3]]
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - base
+    assert peak < infer_ws + (train_ws - infer_ws) // 4, f"no_grad forward allocated {peak} B: training workspace is {train_ws} B, forward-only {infer_ws} B"
+    for name, a, b in zip(("sdf", "gradient", "rgb"), out, with_graph):
+        assert torch.equal(a, b), f"{name}: no_grad forward differs from the saving forward in {int((a != b).sum())} elements"
