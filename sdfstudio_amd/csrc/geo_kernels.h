@@ -193,14 +193,28 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
 
   // ---- output layer: the sdf row as a lane-local dot product riding in the producer, feature rows on the MFMA path
   {
-    float part = 0.0f;
+    // The sdf row is a lane-local dot product over 128 of the last layer's 256 activations (the other half-wave holds the rest).  A plain
+    // fma chain rounds its running sum (magnitude ~1.5 at geometric initialisation: 1.2e-7 per ulp) 128 times: 1.8e-7 rms, 8e-7 worst -
+    // twice the error of the blocked sum an fp32 GEMM makes, and the LARGEST term of the 24-bit evaluation's error.  The 24-bit mode
+    // (NS == 3: the numerical normal divides sdf differences by 2 delta = 4.8e-4) therefore accumulates compensated (Kahan): the running
+    // sum's rounding errors are carried in `comp` and taken out once at the end, which leaves the final rounding (6e-8) alone.
+    constexpr bool KAHAN = NS == 3;
+    float part = 0.0f, comp = 0.0f;
     float* ulast = a.u_tp[NL - 1];
     const float* wsdf = cvec + (NL + 1) * W;
     auto make = [&](auto kbc, const Raw&, auto ec) __attribute__((always_inline)) {
       constexpr int kb = decltype(kbc)::value, e = decltype(ec)::value;
       const float h = act_h<D::ACT, NS == 4>(accIn[kb][e]);
       if constexpr (SAVE || GRAD) *tp_elem(ulast, tile, D::NBH, kb, e, lane) = h;
-      part = fmaf(wsdf[kb * 32 + tp_row(e, hf)], h, part);
+      if constexpr (KAHAN) {
+        const float y = fmaf(wsdf[kb * 32 + tp_row(e, hf)], h, -comp);
+        const float t = part + y;
+        comp = (t - part) - y;  // what the addition lost, negated: the true sum is part - comp
+        part = t;
+        pin_here(comp);
+      } else {
+        part = fmaf(wsdf[kb * 32 + tp_row(e, hf)], h, part);
+      }
       pin_here(part);
       return InRange{h};
     };
@@ -221,8 +235,19 @@ __global__ __launch_bounds__(256, 1) void geo_fwd_kernel(const GeoFwdArgs a) {
       });
       if constexpr (CHAIN) carry = load_src(chain_first_src(), lane);
     }
-    part += __shfl_xor(part, 32);
-    if (hf == 0) a.sdf[tile * 32 + lane] = part + a.p.b_sdf[0];
+    if constexpr (KAHAN) {
+      // the two half-waves' sums and the bias by error-free additions (TwoSum); every rounding error joins `comp`
+      const float p1 = __shfl_xor(part, 32), c1 = __shfl_xor(comp, 32);
+      const float s2 = part + p1, v2 = s2 - part;
+      const float e2 = (part - (s2 - v2)) + (p1 - v2);  // part + p1 == s2 + e2 exactly
+      const float b = a.p.b_sdf[0];
+      const float s3 = s2 + b, v3 = s3 - s2;
+      const float e3 = (s2 - (s3 - v3)) + (b - v3);     // s2 + b == s3 + e3 exactly
+      if (hf == 0) a.sdf[tile * 32 + lane] = s3 + ((e2 + e3) - (comp + c1));
+    } else {
+      part += __shfl_xor(part, 32);
+      if (hf == 0) a.sdf[tile * 32 + lane] = part + a.p.b_sdf[0];
+    }
   }
   }  // PHASE != 2
 
@@ -440,11 +465,16 @@ __global__ __launch_bounds__(256, 1) void geo_bwd_kernel(const GeoBwdArgs a) {
       for (int b = 0; b < D::NB0; ++b) accE[b] = f32x16_zero();
       auto next_fetch = [&]() __attribute__((always_inline)) { return bwd_src(l, 0); };
       tp_gemm<D::NBH, D::NB0, Stores<16>, NS, PCS>(accE, carry, fetch, make, next_fetch, ws, l == 0 ? a.p.wpT[0] : a.p.wpT_in0, a.p.wpT[l]);
-      // ub_{l+1} has been consumed for good: layer 0 ends the sweep, and the skip layer's hidden gemm below takes the FINISHED zb_l from
-      // memory (`done`).  The compiler cannot see that across the two run-time conditions and kept all 8 blocks alive through this gemm
-      // (NB0 = 6: 196 B of scratch); overwriting them ends their live ranges block by block as the producer passes.
+      // TANGENT: ub_{l+1} has been consumed for good - layer 0 ends the sweep, and the skip layer's hidden gemm below takes the FINISHED
+      // zb_l from memory (`done`).  The compiler cannot see that across the two run-time conditions and kept all 8 blocks alive through
+      // this gemm (NB0 = 6: 196 B of scratch); overwriting them ends their live ranges block by block as the producer passes.
+      // The first-order kernel has no zc operand to fetch zb_l back through: its hidden gemm RECOMPUTES zb_l = ub_{l+1} s'(z_l) from accIn,
+      // which must therefore survive (round 5: clearing it here zeroed every gradient at and below the skip layer in the first-order
+      // backward - forward_geonetwork under autograd, the ReLU background fields, the numerical-gradient field of networks with a skip).
+      if constexpr (TANGENT) {
 #pragma unroll
-      for (int b = 0; b < D::NBH; ++b) accIn[b] = f32x16_zero();
+        for (int b = 0; b < D::NBH; ++b) accIn[b] = f32x16_zero();
+      }
       if (l == 0 && SKIP > 0) {
 #pragma unroll
         for (int b = 0; b < D::NB0; ++b) accE[b] += tp_load_blk(a.in0bar_tp, tile, D::NB0, b, lane);

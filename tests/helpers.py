@@ -341,3 +341,16 @@ def angelo_product_grads(model):
         if p.grad is not None and k.startswith("field_background."):
             out[k] = p.grad.detach()
     return out
+
+
+def load_external_golden(path, required):
+    """A vector file minted on a CUDA box (tools/mint_*_golden.py).  Absent files make their tests SKIP; a file that is present but
+    unreadable or incomplete must FAIL loudly - a skipped test would read as "still unpinned" when the truth is "pinned data rejected"."""
+    try:
+        z = np.load(path)
+        keys = set(z.files)
+    except Exception as e:  # noqa: BLE001 - whatever numpy raises on a damaged archive
+        raise AssertionError(f"{os.path.basename(path)} is present but cannot be read as an .npz archive: {e}") from e
+    missing = [k for k in required if k not in keys]
+    assert not missing, f"{os.path.basename(path)} is present but malformed: missing arrays {missing} (has {sorted(keys)})"
+    return z

@@ -11,7 +11,11 @@ import numpy as np
 import pytest
 import torch
 
+from helpers import load_external_golden
 from oracle import hashgrid, sdf_path as O
+
+TCNN_KEYS = ['cfg', 'growth', 'x', 'table', 'cot', 'y', 'table_bar', 'x_bar']
+NERFACC_KEYS = ['origins', 'dirs', 't_min', 't_max', 'aabb', 'binary', 'step', 'packed_info', 'ray_indices', 't_starts', 't_ends', 'weights', 'resampled_packed_info', 'resampled_starts', 'resampled_ends']
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TCNN = sorted(glob.glob(os.path.join(GOLDEN, "tcnn_grid_*.npz")))
@@ -28,7 +32,7 @@ def test_mint_scripts_exist_and_name_the_files_these_tests_consume():
 @pytest.mark.skipif(not TCNN, reason="no tests/golden/tcnn_grid_*.npz (mint with tools/mint_tcnn_golden.py on a CUDA box): hash grid stays parity-unpinned")
 @pytest.mark.parametrize("path", TCNN or ["absent"])
 def test_oracle_hash_grid_against_real_tcnn(path):
-    z = np.load(path)
+    z = load_external_golden(path, TCNN_KEYS)
     L, F, log2_t, base, _, smooth = [int(v) for v in z["cfg"]]
     lv = hashgrid.make_levels(L, F, log2_t, base, float(z["growth"]), bool(smooth))
     x = torch.from_numpy(z["x"]).requires_grad_(True)
@@ -47,7 +51,7 @@ def test_oracle_hash_grid_against_real_tcnn(path):
 @pytest.mark.skipif(not NERFACC, reason="no tests/golden/nerfacc_march_*.npz (mint with tools/mint_nerfacc_golden.py on a CUDA box): march / resampling stay parity-unpinned")
 @pytest.mark.parametrize("path", NERFACC or ["absent"])
 def test_oracle_march_and_resampling_against_real_nerfacc(path):
-    z = np.load(path)
+    z = load_external_golden(path, NERFACC_KEYS)
     t = lambda k: torch.from_numpy(z[k])  # noqa: E731
     info, ray_idx, ts, te = O.ray_marching(t("origins"), t("dirs"), t("t_min"), t("t_max"), t("aabb"), t("binary"), float(z["step"]))
     assert torch.equal(info[:, 1], t("packed_info")[:, 1].long()), "samples per ray differ from nerfacc's"
@@ -57,6 +61,18 @@ def test_oracle_march_and_resampling_against_real_nerfacc(path):
     assert torch.equal(rinfo[:, 1], t("resampled_packed_info")[:, 1].long())
     assert (rs.view(-1) - t("resampled_starts").view(-1)).abs().max().item() <= 2e-6
     assert (re.view(-1) - t("resampled_ends").view(-1)).abs().max().item() <= 2e-6
+
+
+def test_a_malformed_vector_file_fails_instead_of_skipping(tmp_path):
+    """present-but-malformed vectors must not read as "still unpinned"."""
+    bad = tmp_path / "tcnn_grid_bad.npz"
+    np.savez(bad, cfg=np.zeros(6), x=np.zeros((2, 3)))
+    with pytest.raises(AssertionError, match="malformed"):
+        load_external_golden(str(bad), TCNN_KEYS)
+    junk = tmp_path / "nerfacc_march_junk.npz"
+    junk.write_bytes(b"not a zip archive")
+    with pytest.raises(AssertionError, match="cannot be read"):
+        load_external_golden(str(junk), NERFACC_KEYS)
 
 
 def test_tcnn_state_dict_layout_round_trip():
