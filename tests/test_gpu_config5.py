@@ -271,9 +271,10 @@ def test_northstar_bars_config5_on_oracle_samples(device, step):
     network per sample, finite-difference normal, colour network, "grid" background merge) and the compositing are evaluated on the
     oracle's starts / ends.  sdf and the six tap values: 1e-5 absolute at both schedule states.  Everything downstream of the normal:
     1e-4 relative while the finite difference lets the REFERENCE path itself be that reproducible (step 5 000: delta 5.4e-2), the
-    reference path's own fp32 class (within 3 x |oracle fp32 - oracle fp64|; round 4: 8 x, before the small-delta evaluations moved to
-    24-bit products) once delta = 2.4e-4 divides the sdf's round-off by 5e-4 - plus the fixed 1e-4 bar on every ray where the reference
-    path itself is reproducible to 2e-5."""
+    reference path's own fp32 class (within 2 x |oracle fp32 - oracle fp64|; round 4: 8 x, before the small-delta evaluations moved to
+    24-bit products with a compensated sdf row - measured round 5: 0.24 - 0.93 x for everything downstream of the normal, i.e. CLOSER to
+    fp64 than the fp32 oracle; 4.2 x with the default 22-bit evaluations, SDFHIP_NUMFIELD_HP=0) once delta = 2.4e-4 divides the sdf's
+    round-off by 5e-4 - plus the fixed 1e-4 bar on every ray where the reference path itself is reproducible to 2e-5."""
     from sdfstudio_amd.fields.field_heads import FieldHeadNames as H
     from sdfstudio_amd.models import background as BGM
 
@@ -310,19 +311,21 @@ def test_northstar_bars_config5_on_oracle_samples(device, step):
     assert_close("sampled_sdf (six taps)", fo["sampled_sdf"], rf["sampled_sdf"], rtol=0, atol=1e-5)
     strict = step == 5000
     stable_rays = {}
-    FP32_CLASS_FACTOR = float(os.environ.get("SDFHIP_TEST_CFG5_FACTOR", "4.0"))
+    FP32_CLASS_FACTOR = float(os.environ.get("SDFHIP_TEST_CFG5_FACTOR", "2.0"))
 
     def bar(name, got, r32, r64, atol=1e-6):
         if strict:
             assert_close(name, got, r32, rtol=1e-4, atol=atol)
             return
         # delta = 2.4e-4: the reference path's own fp32 evaluation is not reproducible to 1e-4 here (a central difference over 4.9e-4 divides
-        # the sdf's round-off by that), so the bar is its fp32 CLASS - as close to the fp64 evaluation as the fp32 oracle is, x 3 (round 4:
-        # x 8, the forward's 22-bit products against fp32's 24; below delta = 2e-3 the seven evaluations now run with 24-bit products,
-        # sdfhip_numfield_forward) ...
+        # the sdf's round-off by that), so the bar is its fp32 CLASS - as close to the fp64 evaluation as the fp32 oracle is, x 2 (round 4:
+        # x 8, the forward's 22-bit products against fp32's 24; below delta = 2e-3 the seven evaluations now run with 24-bit products and a
+        # compensated sdf-row sum, sdfhip_numfield_forward) ...
         assert_fp32_class(name, got, r32, r64, factor=FP32_CLASS_FACTOR, atol=atol + 1e-4 * float(r64.abs().max()))
-        # ... and the FIXED north-star bar, element-wise gate included (both sides see identical samples), wherever the reference path
-        # itself is reproducible: rays (samples) on which |oracle fp32 - oracle fp64| stays below 2e-5 of the tensor's scale
+        # ... and the FIXED north-star bar (1e-4 of the tensor's scale) wherever the reference path itself is reproducible: rays (samples)
+        # on which |oracle fp32 - oracle fp64| stays below 2e-5 of the tensor's scale.  Both sides see identical samples, so the
+        # element-wise gate is on - at 3e-3 instead of the default 1e-3: two fp32-class evaluations of a finite difference over 4.8e-4 are
+        # independent draws of the same noise, and an alpha of 0.05 that carries the tensor-level 7e-5 (measured) is 1.5e-3 of itself
         r32d, r64d = r32.detach().double().cpu(), r64.detach().double().cpu()
         lead = r32d.shape[0]
         err = (r32d - r64d).abs().reshape(lead, -1).amax(dim=1)
@@ -330,7 +333,7 @@ def test_northstar_bars_config5_on_oracle_samples(device, step):
         stable_rays[name] = (int(sel.sum()), lead)
         if int(sel.sum()) > 0:
             assert_close(name + f" [{int(sel.sum())} of {lead} rows where the fp32 oracle is within 2e-5 of fp64]", got.detach().cpu()[sel], r32d[sel],
-                         rtol=1e-4, atol=atol)
+                         rtol=1e-4, atol=atol, elem_rtol=3e-3)
 
     bar("alpha (fg / bg merged)", fo[H.ALPHA][..., 0], rf["alpha"], a64)
     bar("weights", weights[..., 0], ref["weights"], w64)
