@@ -252,16 +252,24 @@ class AccumulationRenderer(nn.Module):
 
 
 class DepthRenderer(nn.Module):
-    """renderers.py:200-261, method='expected'."""
+    """renderers.py:200-261: method 'expected' (what the surface models use; fused into the compositing kernels on the training path) and
+    'median' (:234-244: the mid point of the sample at which the cumulative weight reaches 0.5; not differentiable, per-head mirror only)."""
 
     def __init__(self, method: str = "expected") -> None:
         super().__init__()
-        if method != "expected":
-            raise NotImplementedError("only the 'expected' depth method is on the SDF path")
+        if method not in ("expected", "median"):
+            raise NotImplementedError(f"depth method {method!r} (the reference has 'expected' and 'median')")
         self.method = method
 
-    def forward(self, weights: torch.Tensor, ray_samples) -> torch.Tensor:
+    def forward(self, weights: torch.Tensor, ray_samples, ray_indices=None, num_rays=None) -> torch.Tensor:
         steps = (ray_samples.frustums.starts + ray_samples.frustums.ends) / 2
+        if self.method == "median":
+            if ray_indices is not None and num_rays is not None:
+                raise NotImplementedError("Median depth calculation is not implemented for packed samples.")  # the reference's message
+            cumulative = torch.cumsum(weights[..., 0], dim=-1)
+            split = torch.full((*weights.shape[:-2], 1), 0.5, device=weights.device, dtype=cumulative.dtype)
+            index = torch.searchsorted(cumulative, split, side="left").clamp_(0, steps.shape[-2] - 1)
+            return torch.gather(steps[..., 0], dim=-1, index=index)
         depth = torch.sum(weights * steps, dim=-2) / (torch.sum(weights, -2) + 1e-10)
         return torch.clip(depth, steps.min(), steps.max())
 

@@ -222,3 +222,23 @@ def test_reference_cannot_run_its_non_hash_encodings(ref, enc):
         fld.forward_geonetwork(torch.rand(5, 3))
     with pytest.raises(NotImplementedError, match="encoding_type"):
         SDFField(SDFFieldConfig(encoding_type=enc), torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_images=3)
+
+
+@pytest.mark.parametrize("method", ["median", "expected"])
+def test_depth_renderer_mirror_against_the_references(ref, method):
+    """DepthRenderer (renderers.py:200-261), both methods, on the reference's own RaySamples: same numbers as the reference's class."""
+    from nerfstudio.cameras.rays import Frustums, RaySamples
+    from nerfstudio.model_components.renderers import DepthRenderer as RefDepth
+
+    from sdfstudio_amd.model_components.renderers import DepthRenderer
+
+    gen = torch.Generator().manual_seed(7)
+    n, s = 37, 48
+    bins = torch.sort(torch.rand(n, s + 1, generator=gen) * 4.0 + 0.05, dim=-1)[0]
+    fr = Frustums(origins=torch.zeros(n, s, 3), directions=torch.ones(n, s, 3), starts=bins[:, :-1, None], ends=bins[:, 1:, None],
+                  pixel_area=torch.ones(n, s, 1))
+    rs = RaySamples(frustums=fr)
+    w = torch.rand(n, s, 1, generator=gen) ** 4
+    w = w / w.sum(dim=1, keepdim=True) * torch.rand(n, 1, 1, generator=gen)  # some rays never reach 0.5: the index clamps to the last sample
+    w[3] = 0.0
+    assert torch.equal(DepthRenderer(method)(w, rs), RefDepth(method=method)(w, rs))
