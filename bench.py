@@ -368,17 +368,33 @@ def pmc_rows(select):
     run inside the bench, so `traffic` fields quote these files - and say `traffic_stale` when the loaded library is not the profiled one."""
     import csv
 
+    from sdfstudio_amd import build as _build
+
     pm_dir = os.path.join(ROOT, "profiles")
+    want = _build.built_digest() or None
+    cands = []
     for f in sorted((f for f in os.listdir(pm_dir) if f.endswith("_pmc_summary.csv") and select(f)), reverse=True):
-        with open(os.path.join(pm_dir, f)) as fh:
-            rows = list(csv.DictReader(fh))
         digest = None
         meta = os.path.join(pm_dir, f.replace("_pmc_summary.csv", "_pmc_meta.json"))
         if os.path.exists(meta):
             with open(meta) as fh:
                 digest = json.load(fh).get("library_digest")
+        cands.append((digest != want, f, digest))  # the set taken on THIS library first; else the newest name (r1 < r2 < ...; stale)
+    for _stale, f, digest in sorted(cands, key=lambda c: c[0]):  # stable: keeps the reverse-name order inside each class
+        with open(os.path.join(pm_dir, f)) as fh:
+            rows = list(csv.DictReader(fh))
         return rows, f, digest
     return None, None, None
+
+
+def newest_matching_json(pm_dir, names_sorted, digest):
+    """Of the evidence JSONs `names_sorted` (ascending by name = by round): the newest one taken on the library `digest`, else the newest."""
+    loaded = []
+    for f in names_sorted:
+        with open(os.path.join(pm_dir, f)) as fh:
+            loaded.append(json.load(fh))
+    same = [j for j in loaded if j.get("library_digest") == digest]
+    return (same or loaded)[-1]
 
 
 def geo_fwd_flags(kernel_name):
@@ -917,8 +933,7 @@ def run(args):
             traffic, traffic_source, traffic_digest = None, None, None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the bench)
             cands = sorted(f for f in os.listdir(pm_dir) if f.endswith("_pmc_traffic.json") and "cfg5" not in f)
             if cands:
-                with open(os.path.join(pm_dir, cands[-1])) as fh:  # newest committed PMC pass (r1 < r2 < r3 ...)
-                    tj = json.load(fh)
+                tj = newest_matching_json(pm_dir, cands, lib_digest)  # the pass taken on THIS library, else the newest (r1 < r2 < ...)
                 traffic = tj["hbm_read_bytes"] + tj["hbm_write_bytes"]
                 traffic_source = tj["source"]
                 traffic_digest = tj.get("library_digest")
@@ -1006,8 +1021,7 @@ def run(args):
         cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_step_traffic.json") and ("cfg5" in f) == cfg5
                        and (not cfg5 or ("cfg5l16" in f) == (args.levels == 16)))
         if cands:
-            with open(os.path.join(ROOT, "profiles", cands[-1])) as fh:
-                sj = json.load(fh)
+            sj = newest_matching_json(os.path.join(ROOT, "profiles"), cands, lib_digest)
             step_bytes, step_digest = sj.get("hbm_GB_per_training_step"), sj.get("library_digest")
         model_tf = train_flops * P / (ms * 1e-3) / 1e12
         line["step_roofline"] = {
