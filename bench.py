@@ -746,6 +746,10 @@ def dense_sdf_leg(model, device, resolution=(512, 512, 256), reps=3):
                          "achieved_is": f"sdf-row flops {g / 1e6:.3f} MFLOP per point x 3 issued 16-bit MFMA terms per fp32-class product x "
                                         "points / the kernel's launch time (HIP events)",
                          "flops_per_point": g, "terms_per_product": 3, "points_per_s_kernel_only": round(P / k_s, 1) if k_s > 0 else None,
+                         # the same figure over the WHOLE leg (encode + host glue included), and at the yardstick VERDICT r4 used (the full
+                         # geometry network's G = 1.049 MFLOP per point, although MODE_SDF does not compute the 256 feature rows)
+                         "frac_whole_leg": round(3 * g * P / wall / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                         "frac_kernel_at_full_network_G": round(3 * flops_per_sample()[0] * P / k_s / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4) if k_s > 0 else None,
                          "traffic": None, "algorithmic_bytes_per_launch": (3 * 128 + 4) * P // max(1, k_n // reps if reps else 1),
                          # HBM bytes per launch of the MODE_SDF instantiation (a launch = one chunk of the lattice) from the committed PMC passes
                          **(pmc_traffic_per_launch(lambda f: "_eval" in f, lambda k: geo_fwd_flags(k)[:3] == ["false", "false", "false"]) or {})},
