@@ -655,7 +655,10 @@ def neus_acc_leg(device, steps=20, warmup=5):
            "samples_kept_per_ray": round(n_kept / rays, 2), "packed_samples_per_step": round(n_kept, 1), "occupied_voxel_fraction": round(occupied, 5),
            "march_step_size": float(model.sampler.step_size), "value": round(n_kept / dt, 1), "unit": "packed ray-samples/s",
            "dense_equivalent": "NeuS samples 64 + 64 per ray on every ray (models/neus.py:34-47): 128 samples per ray",
-           "kernels_ms_per_step": table, "enqueue_vs_gpu": split}
+           "kernels_ms_per_step": table, "enqueue_vs_gpu": split,
+           "enqueue_note": "the step contains ONE device -> host read (the packed sample count: nerfacc's API returns exact-size tensors, "
+                           "ray_samplers.py:1467 reads a counter the same way), so `host_enqueue` includes the wait for the previous step's GPU work "
+                           "inside that read and `host_bound` only says the host cannot run a step ahead; gpu_ms == wall_ms: the GPU does not idle"}
     del model, flat, opts, loss
     torch.cuda.empty_cache()
     return out
