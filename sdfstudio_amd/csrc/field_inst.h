@@ -157,12 +157,6 @@ constexpr int kGeoHp = 0x100;
   using GD = GeoDims<NBH, NB0, NBF, 1>;                                                                                    \
   using CD = ColDims<NBF, NBS, NBC>;                                                                                      \
   static void geo_fwd(int mode, const GeoFwdArgs& a, unsigned grid, hipStream_t s) {                                      \
-    if constexpr (PAIR != 0) { /* sdf only, default precision: the pair-wave form (pair_kernels.h) when SDFHIP_PAIR_SDF selects it */ \
-      if (mode == 2 && (mode_ & kGeoHp) == 0 && sdfhip_pair_sdf_enabled()) {                                               \
-        launch_lds(geo_sdf_pair_kernel<GD>, a, grid, 512, PairLds<GD>::floats(a.p.nl) * sizeof(float), s);                \
-        return;                                                                                                            \
-      }                                                                                                                    \
-    }                                                                                                                      \
     const size_t lds = GD::lds_floats(kNsFwd, a.p.nl) * sizeof(float);                                                     \
     if (mode == 1) launch_lds(geo_fwd_kernel<GD, false, false, true>, a, grid, 256, lds, s);                              \
     else if (mode == 3) launch_lds(geo_fwd_kernel<GD, false, true, true>, a, grid, 256, lds, s);                          \

@@ -453,6 +453,8 @@ def test_pair_wave_sdf_forward_against_oracle_and_the_one_wave_kernel(device, mo
     assert_close("one-wave sdf vs oracle", out["0"][0], ref, rtol=0, atol=1e-5)
     assert_close("pair-wave vs one-wave (points)", out["1"][0], out["0"][0], rtol=0, atol=1e-6)
     assert_close("pair-wave vs one-wave (grid)", out["1"][1], out["0"][1], rtol=0, atol=1e-6)
+    # the two forms add the sdf row's 256 terms in different orders: bit-equal results over 3000 points would mean the switch did nothing
+    assert not torch.equal(out["1"][0], out["0"][0]), "SDFHIP_PAIR_SDF had no effect: both runs took the same kernel"
     monkeypatch.setenv("SDFHIP_PAIR_SDF", "1")
     for fill in (float("nan"), 1e30, 0.0):
         blocks = [torch.full((n,), fill, device=device) for n in (1 << 24, 1 << 22, 1 << 20) for _ in range(2)]
