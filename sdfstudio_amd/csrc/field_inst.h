@@ -2,7 +2,6 @@
 // compiled in its own translation unit (inst_*.hip) so the build parallelises; the API layer picks the table.
 #pragma once
 #include "col_kernels.h"
-#include "pair_kernels.h"
 #include "sdfrow_kernel.h"
 
 struct FieldKernels {
@@ -64,7 +63,7 @@ static inline void launch_lds(K kernel, const A& a, unsigned grid, unsigned bloc
 // (HP = 1): the feature-row modes with six terms are 66 - 68 KB of code, over the 64 KB instruction cache, and nothing needs 24-bit
 // feature rows (the caller runs the feature pass at the default precision and the sdf rows again: sdfhip_numfield_forward)
 constexpr int kGeoHp = 0x100;
-#define SDFHIP_DEFINE_GEO_FWD_INFER_(NAME, NBH, NB0, NBF, HP, PAIR)                                                          \
+#define SDFHIP_DEFINE_GEO_FWD_INFER_(NAME, NBH, NB0, NBF, HP)                                                             \
   void sdfhip_geo_fwd_infer_##NAME(int mode_, const GeoFwdArgs& a, unsigned grid, hipStream_t s) {                        \
     using GD = GeoDims<NBH, NB0, NBF>;                                                                                     \
     const int mode = mode_ & 0xff;                                                                                         \
@@ -76,12 +75,6 @@ constexpr int kGeoHp = 0x100;
         return;                                                                                                            \
       }                                                                                                                    \
     }                                                                                                                      \
-    if constexpr (PAIR != 0) { /* sdf only, default precision: the pair-wave form (pair_kernels.h) when SDFHIP_PAIR_SDF selects it */ \
-      if (mode == 2 && (mode_ & kGeoHp) == 0 && sdfhip_pair_sdf_enabled()) {                                               \
-        launch_lds(geo_sdf_pair_kernel<GD>, a, grid, 512, PairLds<GD>::floats(a.p.nl) * sizeof(float), s);                \
-        return;                                                                                                            \
-      }                                                                                                                    \
-    }                                                                                                                      \
     const size_t lds = GD::lds_floats(kNsFwd, a.p.nl) * sizeof(float);                                                     \
     if (mode == 1) launch_lds(geo_fwd_kernel<GD, false, false, true>, a, grid, 256, lds, s);                              \
     else if (mode == 3) launch_lds(geo_fwd_kernel<GD, false, true, true>, a, grid, 256, lds, s);                          \
@@ -89,9 +82,8 @@ constexpr int kGeoHp = 0x100;
     else if (mode == 5) launch_lds(geo_fwd_kernel<GD, false, true, false>, a, grid, 256, lds, s);                         \
     else launch_lds(geo_fwd_kernel<GD, false, false, false>, a, grid, 256, lds, s);                                       \
   }
-#define SDFHIP_DEFINE_GEO_FWD_INFER(NAME, NBH, NB0, NBF) SDFHIP_DEFINE_GEO_FWD_INFER_(NAME, NBH, NB0, NBF, 0, 0)
-#define SDFHIP_DEFINE_GEO_FWD_INFER_HP(NAME, NBH, NB0, NBF) SDFHIP_DEFINE_GEO_FWD_INFER_(NAME, NBH, NB0, NBF, 1, 0)
-#define SDFHIP_DEFINE_GEO_FWD_INFER_PAIR(NAME, NBH, NB0, NBF) SDFHIP_DEFINE_GEO_FWD_INFER_(NAME, NBH, NB0, NBF, 0, 1)
+#define SDFHIP_DEFINE_GEO_FWD_INFER(NAME, NBH, NB0, NBF) SDFHIP_DEFINE_GEO_FWD_INFER_(NAME, NBH, NB0, NBF, 0)
+#define SDFHIP_DEFINE_GEO_FWD_INFER_HP(NAME, NBH, NB0, NBF) SDFHIP_DEFINE_GEO_FWD_INFER_(NAME, NBH, NB0, NBF, 1)
 
 #define SDFHIP_DEFINE_GEO_BWD(NAME, NBH, NB0, NBF)                                                                        \
   void sdfhip_geo_bwd_##NAME(const GeoBwdArgs& a, unsigned grid, hipStream_t s) {                                         \
