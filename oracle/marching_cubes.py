@@ -161,7 +161,7 @@ def cell_triangles(cube) -> Tuple[list, str]:
         sub = sum((1 << i) for i in range(6) if test_face(cube, L["TEST13"][cfg][i]))
         sc = int(L["SUBCONFIG13"][sub])
         tag = "13.%d" % sc
-        if sc == 0:
+        if sc <= 0:  # -1: a combination of face tests no trilinear cell produces (never seen; Lewiner prints "impossible case"): 13.1
             T = L["TILING13_1"][cfg]
         elif sc <= 6:
             T = L["TILING13_2"][cfg][sc - 1]

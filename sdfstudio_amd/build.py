@@ -85,7 +85,44 @@ def _compile(src: str) -> str:
     return obj
 
 
+# ---- libsdfmesh.so: marching cubes on the device (include/sdfmesh.h).  A separate library with its own sources: libsdfhip.so's
+# digest - the identity the profiles/ evidence is tied to - does not move when the mesh code does.
+MESH_CSRC = os.path.join(HERE, "csrc_mesh")
+MESH_LIB = os.path.join(HERE, "libsdfmesh.so")
+# -ffp-contract=off: the case tests compare products in double and the vertex arithmetic rounds where scikit-image rounds; a fused
+# multiply-add in either place changes bits (mc_cell.h)
+MESH_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result", "-Wno-unused-function"]
+
+
+def mesh_source_digest() -> str:
+    h = hashlib.sha256()
+    h.update(" ".join(MESH_FLAGS).encode())
+    for name in sorted(os.listdir(MESH_CSRC)) + [os.path.join("..", "..", "include", "sdfmesh.h")]:
+        path = os.path.join(MESH_CSRC, name)
+        if os.path.isfile(path) and name.endswith((".h", ".hip")):
+            with open(path, "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def build_mesh(verbose: bool = True) -> str:
+    digest = mesh_source_digest()
+    stamp = MESH_LIB + ".digest"
+    prev = open(stamp).read().strip() if os.path.exists(stamp) else ""
+    if prev != digest or not os.path.exists(MESH_LIB):
+        cmd = [_hipcc(), *MESH_FLAGS, "-shared", "-I", MESH_CSRC, os.path.join(MESH_CSRC, "mesh_api.hip"), "-o", MESH_LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for mesh_api.hip:\n{r.stdout}\n{r.stderr}")
+        with open(stamp, "w") as fh:
+            fh.write(digest)
+    if verbose:
+        print(f"[sdfhip] built {MESH_LIB} ({os.path.getsize(MESH_LIB) / 1e6:.1f} MB)")
+    return MESH_LIB
+
+
 def build(verbose: bool = True) -> str:
+    build_mesh(verbose)
     os.makedirs(BUILD, exist_ok=True)
     with concurrent.futures.ThreadPoolExecutor(max_workers=max(1, min(len(SOURCES), os.cpu_count() or 1))) as ex:
         objs = list(ex.map(_compile, SOURCES))

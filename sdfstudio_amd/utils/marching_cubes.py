@@ -9,8 +9,13 @@ nerfstudio/utils/marching_cubes.py:15-168.
   as an [P, 3] tensor; only the sdf row of the network is computed (SDFHIP_MODE_SDF, no feature GEMM, nothing saved);
 * ``sdf_on_points`` does the same for explicit positions (the masked levels of the pyramid);
 * ``evaluate_crop_pyramid`` is the reference's coarse-to-fine loop (marching_cubes.py:77-121) on device tensors;
-* ``get_surface_sliding`` strings them together per crop and hands the volume to skimage's marching cubes when it is
-  installed (it is CPU post-processing, not part of the hot path; absent in this image -> the volumes are returned).
+* ``marching_cubes`` is ``skimage.measure.marching_cubes`` (scikit-image==0.19.3 in the reference's pyproject; Lewiner's method, the
+  default) on a volume that STAYS on the device: libsdfmesh.so (include/sdfmesh.h, csrc_mesh/) returns scikit-image's four arrays - bit
+  for bit and in its array order, oracle/marching_cubes.py is pinned on the real package - without the 512 MB host copy and the serial
+  Cython pass the reference pays per crop;
+* ``get_surface_sliding`` strings them together per crop (marching_cubes.py:15-168: crops, coarse mask, pyramid, marching cubes, the
+  crop's offset, concatenation); ``get_surface_occupancy`` is the UniSurf variant (marching_cubes.py:171-216).  Mesh simplification and
+  the .ply writer (pymeshlab / trimesh) are file-format post-processing outside the path and are not built.
 No scene contraction is applied: ``forward_geonetwork`` takes positions as given (sdf_field.py:380-410).
 """
 from typing import Callable, List, Optional, Sequence, Tuple
@@ -18,7 +23,7 @@ from typing import Callable, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from sdfstudio_amd import _lib
+from sdfstudio_amd import _lib, _mesh
 
 
 @torch.no_grad()
@@ -102,17 +107,79 @@ def evaluate_crop_pyramid(sdf: Callable[[torch.Tensor], torch.Tensor], points: t
 
 
 @torch.no_grad()
+def marching_cubes(volume: torch.Tensor, level: Optional[float] = None, *, spacing: Sequence[float] = (1.0, 1.0, 1.0),
+                   gradient_direction: str = "descent", step_size: int = 1, allow_degenerate: bool = True, method: str = "lewiner",
+                   mask: Optional[torch.Tensor] = None):
+    """skimage.measure.marching_cubes (skimage/measure/_marching_cubes_lewiner.py: marching_cubes -> _marching_cubes_lewiner) on a CUDA
+    volume [M, N, P]; same arguments, same checks and error messages, same four results - as DEVICE tensors: verts [V,3] (float32 in
+    lattice units for unit spacing, else float64 = float32 vertex x spacing, exactly the wrapper's ``vertices * np.r_[spacing]``),
+    faces [F,3] int32, normals [V,3] float32, values [V] float32.  Only what the reference uses is built: method "lewiner",
+    step_size 1, allow_degenerate True (the defaults; marching_cubes.py:125-134 passes volume, level, spacing and mask)."""
+    if not isinstance(volume, torch.Tensor) or volume.dim() != 3:
+        raise ValueError("Input volume should be a 3D numpy array.")
+    if min(volume.shape) < 2:
+        raise ValueError("Input array must be at least 2x2x2.")
+    if method != "lewiner":
+        raise NotImplementedError(f"marching_cubes: method {method!r} is not built (the reference uses the default, 'lewiner')")
+    if int(step_size) != 1 or not allow_degenerate:
+        raise NotImplementedError("marching_cubes: step_size != 1 / allow_degenerate=False are not built (the reference uses the defaults)")
+    if len(spacing) != 3:
+        raise ValueError("`spacing` must consist of three floats.")
+    if gradient_direction not in ("descent", "ascent"):
+        raise ValueError("Incorrect input %s in `gradient_direction`, see docstring." % (gradient_direction,))
+    if mask is not None and tuple(mask.shape) != tuple(volume.shape):
+        raise ValueError("volume and mask must have the same shape.")
+    vol = volume.contiguous().float()
+    lo, hi = (float(t) for t in torch.aminmax(vol))
+    if level is None:
+        level = 0.5 * (lo + hi)
+    else:
+        level = float(level)
+        if level < lo or level > hi:
+            raise ValueError("Surface level must be within volume data range.")
+    verts, faces, normals, values = _mesh.marching_cubes_device(vol, level, mask, flip_faces=(gradient_direction == "descent"))
+    if verts.shape[0] == 0:
+        raise RuntimeError("No surface found at the given iso value.")
+    if tuple(float(t) for t in spacing) != (1.0, 1.0, 1.0):
+        verts = verts.double() * torch.tensor([float(t) for t in spacing], dtype=torch.float64, device=verts.device)
+    return verts, faces, normals, values
+
+
+def concatenate_meshes(meshes):
+    """trimesh.util.concatenate for (verts, faces, normals) triples: vertices stacked, face indices offset (marching_cubes.py:150)."""
+    if not meshes:
+        return None
+    off, vs, fs, ns = 0, [], [], []
+    for v, f, n in meshes:
+        vs.append(v.double())
+        fs.append(f.long() + off)
+        ns.append(n)
+        off += v.shape[0]
+    return torch.cat(vs), torch.cat(fs), torch.cat(ns)
+
+
+def _coarse_mask_lookup(coarse_mask: torch.Tensor, pts: torch.Tensor) -> torch.Tensor:
+    """marching_cubes.py:27-29,68-70,97-101: the scene box's coarse binary grid sampled at points [..., 3] (grid_sample's default
+    bilinear lookup on the (z, y, x)-permuted grid, > 0)."""
+    cm = coarse_mask.permute(2, 1, 0)[None, None].to(device=pts.device, dtype=torch.float32)
+    flat = pts.reshape(1, 1, 1, -1, 3)
+    return (torch.nn.functional.grid_sample(cm, flat, align_corners=False)[0, 0, 0, 0] > 0.0).reshape(pts.shape[:-1])
+
+
+@torch.no_grad()
 def get_surface_sliding(field, resolution: int = 512, bounding_box_min=(-1.0, -1.0, -1.0), bounding_box_max=(1.0, 1.0, 1.0),
-                        level: float = 0.0, crop: int = 512, device=None, return_volumes: bool = False):
-    """marching_cubes.py:15-168 without the mask / simplification options: per crop^3 block, coarse-to-fine sdf evaluation on the
-    device, then marching cubes (skimage, CPU) if available.  Returns a list of (verts, faces, normals) per block, or with
-    return_volumes=True (or without skimage) a list of ((x_min, y_min, z_min), (x_max, y_max, z_max), volume [crop^3])."""
+                        return_mesh: bool = True, level: float = 0.0, coarse_mask: Optional[torch.Tensor] = None, crop: int = 512,
+                        device=None, return_volumes: bool = False, sdf: Optional[Callable[[torch.Tensor], torch.Tensor]] = None):
+    """marching_cubes.py:15-168: per crop^3 block (the reference fixes crop = 512) the coarse-to-fine sdf evaluation, then marching cubes
+    ON THE DEVICE (libsdfmesh.so), the crop's offset added in double as the reference adds it, the crops concatenated.
+    ``field``: an SDFField (its MODE_SDF kernels evaluate the lattice) - or pass ``sdf(points [P,3]) -> [P]`` as the reference does.
+    Returns (verts [V,3] float64, faces [F,3] int64, normals [V,3] float32) on the device, or None without a surface;
+    return_mesh=False: the list of per-crop (verts, faces, normals); return_volumes=True: the list of (lo, hi, volume [crop^3]).
+    ``level`` is overwritten with 0 as at marching_cubes.py:33.  Not built: merge_vertices + .ply export + pymeshlab simplification."""
     assert resolution % crop == 0 and crop % 8 == 0
+    level = 0.0  # marching_cubes.py:33
     dev = device if device is not None else field.encoding.params.device
-    try:
-        from skimage import measure  # type: ignore
-    except Exception:  # noqa: BLE001
-        measure = None
+    fn = sdf if sdf is not None else (lambda p: sdf_on_points(field, p))
     nblk = resolution // crop
     edges = [np.linspace(bounding_box_min[a], bounding_box_max[a], nblk + 1) for a in range(3)]
     results = []
@@ -121,17 +188,46 @@ def get_surface_sliding(field, resolution: int = 512, bounding_box_min=(-1.0, -1
             for k in range(nblk):
                 lo = (edges[0][i], edges[1][j], edges[2][k])
                 hi = (edges[0][i + 1], edges[1][j + 1], edges[2][k + 1])
-                ax = [torch.linspace(float(lo[a]), float(hi[a]), crop, device=dev) for a in range(3)]
+                # np.linspace in double, cast to float: the reference's lattice (marching_cubes.py:51-56)
+                ax = [torch.from_numpy(np.linspace(lo[a], hi[a], crop)).float().to(dev) for a in range(3)]
                 xx, yy, zz = torch.meshgrid(*ax, indexing="ij")
                 pts = torch.stack([xx, yy, zz], 0)
-                z, _, _ = evaluate_crop_pyramid(lambda p: sdf_on_points(field, p), pts, float(hi[0] - lo[0]))
+                current_mask, valid = None, None
+                if coarse_mask is not None:
+                    current_mask = _coarse_mask_lookup(coarse_mask, pts.permute(1, 2, 3, 0))
+                    valid = lambda p: _coarse_mask_lookup(coarse_mask, p)  # noqa: E731
+                z, _, _ = evaluate_crop_pyramid(fn, pts, float(hi[0] - lo[0]), valid)
+                vol = z.reshape(crop, crop, crop)
+                if current_mask is not None:
+                    inside = vol[current_mask]
+                    if inside.numel() == 0 or float(inside.min()) > level or float(inside.max()) < level:
+                        continue
                 if float(z.min()) > level or float(z.max()) < level:
                     continue
-                vol = z.reshape(crop, crop, crop)
-                if measure is None or return_volumes:
+                if return_volumes:
                     results.append((lo, hi, vol))
                     continue
                 spacing = tuple((hi[a] - lo[a]) / (crop - 1) for a in range(3))
-                verts, faces, normals, _ = measure.marching_cubes(volume=vol.cpu().numpy().astype(np.float32), level=level, spacing=spacing)
-                results.append((verts + np.array(lo), faces, normals))
-    return results
+                verts, faces, normals, _ = marching_cubes(vol, level, spacing=spacing, mask=current_mask)
+                verts = verts.double() + torch.tensor(lo, dtype=torch.float64, device=verts.device)
+                results.append((verts, faces, normals))
+    if return_volumes or not return_mesh:
+        return results
+    return concatenate_meshes(results)
+
+
+@torch.no_grad()
+def get_surface_occupancy(occupancy_fn: Callable[[torch.Tensor], torch.Tensor], resolution: int = 512, bounding_box_min=(-1.0, -1.0, -1.0),
+                          bounding_box_max=(1.0, 1.0, 1.0), level: float = 0.5, device=None, chunk: int = 1 << 22):
+    """marching_cubes.py:171-216 (UniSurf: occupancy = sigmoid(10 sdf), level 0.5): one resolution^3 lattice, marching cubes on the
+    device.  Returns (verts float64, faces int32, normals) or None ("no surface skip").  The .ply export is not built."""
+    n = int(resolution)
+    ax = [torch.from_numpy(np.linspace(bounding_box_min[a], bounding_box_max[a], n)).float().to(device) for a in range(3)]
+    xx, yy, zz = torch.meshgrid(*ax, indexing="ij")
+    pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], -1)
+    z = torch.cat([occupancy_fn(pts[a:a + chunk].contiguous()).reshape(-1) for a in range(0, pts.shape[0], chunk)])
+    if float(z.min()) > level or float(z.max()) < level:
+        return None
+    spacing = tuple((bounding_box_max[a] - bounding_box_min[a]) / (n - 1) for a in range(3))
+    verts, faces, normals, _ = marching_cubes(z.reshape(n, n, n), level, spacing=spacing)
+    return verts.double() + torch.tensor(tuple(float(t) for t in bounding_box_min), dtype=torch.float64, device=verts.device), faces, normals

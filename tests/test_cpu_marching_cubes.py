@@ -109,7 +109,7 @@ def _host_check_binary():
     exe = os.path.join(out_dir, "mesh_host_check")
     deps = [src] + glob.glob(os.path.join(ROOT, "sdfstudio_amd", "csrc_mesh", "*.h"))
     if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
-        r = subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "sdfstudio_amd", "csrc_mesh"), src, "-o", exe],
+        r = subprocess.run(["g++", "-O2", "-std=c++17", "-Wno-unknown-pragmas", "-I", os.path.join(ROOT, "sdfstudio_amd", "csrc_mesh"), src, "-o", exe],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-4000:]
     return exe
