@@ -1,0 +1,182 @@
+// Standalone hardware check of libsdfmesh.so (no Python, starts in milliseconds): runs the golden cases of tests/golden/mc_*.npz - packed
+// into one binary file by tools/pack_mesh_cases.py - through the C ABI and compares every output array bit for bit, then times the
+// reference's crop size (512^3) on an analytic volume.  Appends one JSON line per step to the output file (flushed: a cut-off run still
+// leaves what it finished).
+//   build: hipcc --offload-arch=gfx950 -O2 tools/mesh_gpu_check.cpp -o tests/_bin/mesh_gpu_check -ldl
+//   run  : tests/_bin/mesh_gpu_check sdfstudio_amd/libsdfmesh.so tests/_bin/mesh_cases.bin gpurun_out/mesh_gpu_check.jsonl
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../include/sdfmesh.h"
+
+#define CK(e)                                                                              \
+    do {                                                                                   \
+        hipError_t r_ = (e);                                                               \
+        if (r_ != hipSuccess) {                                                            \
+            fprintf(out, "{\"fatal\": \"%s: %s\"}\n", #e, hipGetErrorString(r_));          \
+            fflush(out);                                                                   \
+            return 10;                                                                     \
+        }                                                                                  \
+    } while (0)
+
+__global__ void fill_volume(float* vol, int n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * n * n) return;
+    const int x = (int)(i % n), y = (int)((i / n) % n), z = (int)(i / ((int64_t)n * n));
+    const float s = 2.0f / (n - 1);
+    const float fx = -1 + x * s, fy = -1 + y * s, fz = -1 + z * s;
+    const float a = sqrtf(fx * fx + fy * fy + fz * fz) - 0.55f - 0.03f * sinf(9 * fx) * sinf(7 * fy) * sinf(5 * fz);
+    const float b = sqrtf((fx - 0.8f) * (fx - 0.8f) + (fy - 0.8f) * (fy - 0.8f) + (fz - 0.8f) * (fz - 0.8f)) - 0.1f;
+    vol[i] = a < b ? a : b;
+}
+
+typedef int (*count_fn)(const float*, const unsigned char*, int, int, int, double, void*, size_t, int64_t*, int64_t*, void*);
+typedef int (*emit_fn)(const float*, const unsigned char*, int, int, int, double, void*, size_t, int64_t, int64_t, int, float*, int32_t*,
+                       float*, float*, void*);
+typedef size_t (*ws_fn)(int, int, int);
+typedef const char* (*err_fn)(void);
+
+int main(int argc, char** argv) {
+    if (argc != 4) return 2;
+    FILE* out = fopen(argv[3], "a");
+    if (!out) return 3;
+    void* lib = dlopen(argv[1], RTLD_NOW);
+    if (!lib) {
+        fprintf(out, "{\"fatal\": \"dlopen: %s\"}\n", dlerror());
+        return 4;
+    }
+    count_fn mc_count = (count_fn)dlsym(lib, "sdfmesh_mc_count");
+    emit_fn mc_emit = (emit_fn)dlsym(lib, "sdfmesh_mc_emit");
+    ws_fn mc_ws = (ws_fn)dlsym(lib, "sdfmesh_mc_workspace_bytes");
+    err_fn mc_err = (err_fn)dlsym(lib, "sdfmesh_last_error");
+    if (!mc_count || !mc_emit || !mc_ws || !mc_err) return 5;
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    fprintf(out, "{\"device\": \"%s\", \"arch\": \"%s\"}\n", prop.name, prop.gcnArchName);
+    fflush(out);
+
+    FILE* f = fopen(argv[2], "rb");
+    if (!f) return 6;
+    int32_t ncases = 0;
+    if (fread(&ncases, 4, 1, f) != 1) return 6;
+    int all_ok = 1;
+    for (int c = 0; c < ncases; ++c) {
+        char name[64];
+        int32_t dims[3], has_mask, flip;
+        double level;
+        int64_t V, F;
+        if (fread(name, 1, 64, f) != 64 || fread(dims, 4, 3, f) != 3 || fread(&level, 8, 1, f) != 1 || fread(&has_mask, 4, 1, f) != 1 ||
+            fread(&flip, 4, 1, f) != 1 || fread(&V, 8, 1, f) != 1 || fread(&F, 8, 1, f) != 1)
+            return 6;
+        const int64_t np = (int64_t)dims[0] * dims[1] * dims[2];
+        std::vector<float> vol(np), ev(3 * V), en(3 * V), eval(V);
+        std::vector<unsigned char> mask(has_mask ? np : 0);
+        std::vector<int32_t> ef(3 * F);
+        if ((int64_t)fread(vol.data(), 4, np, f) != np) return 6;
+        if (has_mask && (int64_t)fread(mask.data(), 1, np, f) != np) return 6;
+        if ((int64_t)fread(ev.data(), 4, 3 * V, f) != 3 * V || (int64_t)fread(ef.data(), 4, 3 * F, f) != 3 * F ||
+            (int64_t)fread(en.data(), 4, 3 * V, f) != 3 * V || (int64_t)fread(eval.data(), 4, V, f) != V)
+            return 6;
+        float *dvol, *dv, *dn, *dval;
+        unsigned char* dmask = nullptr;
+        int32_t* df;
+        void* ws;
+        const size_t wsb = mc_ws(dims[0], dims[1], dims[2]);
+        CK(hipMalloc(&dvol, 4 * np));
+        CK(hipMemcpy(dvol, vol.data(), 4 * np, hipMemcpyHostToDevice));
+        if (has_mask) {
+            CK(hipMalloc(&dmask, np));
+            CK(hipMemcpy(dmask, mask.data(), np, hipMemcpyHostToDevice));
+        }
+        CK(hipMalloc(&ws, wsb ? wsb : 256));
+        int64_t gv = -1, gf = -1;
+        int rc = mc_count(dvol, dmask, dims[0], dims[1], dims[2], level, ws, wsb, &gv, &gf, nullptr);
+        int ok = rc == 0 && gv == V && gf == F;
+        int okv = 0, okf = 0, okn = 0, okval = 0;
+        if (ok) {
+            CK(hipMalloc(&dv, 12 * V + 16));
+            CK(hipMalloc(&dn, 12 * V + 16));
+            CK(hipMalloc(&dval, 4 * V + 16));
+            CK(hipMalloc(&df, 12 * F + 16));
+            rc = mc_emit(dvol, dmask, dims[0], dims[1], dims[2], level, ws, wsb, V, F, flip, dv, df, dn, dval, nullptr);
+            CK(hipDeviceSynchronize());
+            std::vector<float> gvv(3 * V), gn(3 * V), gval(V);
+            std::vector<int32_t> gff(3 * F);
+            CK(hipMemcpy(gvv.data(), dv, 12 * V, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(gn.data(), dn, 12 * V, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(gval.data(), dval, 4 * V, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(gff.data(), df, 12 * F, hipMemcpyDeviceToHost));
+            okv = memcmp(gvv.data(), ev.data(), 12 * V) == 0;
+            okf = memcmp(gff.data(), ef.data(), 12 * F) == 0;
+            okn = memcmp(gn.data(), en.data(), 12 * V) == 0;
+            okval = memcmp(gval.data(), eval.data(), 4 * V) == 0;
+            ok = rc == 0 && okv && okf && okn && okval;
+            (void)hipFree(dv); (void)hipFree(dn); (void)hipFree(dval); (void)hipFree(df);
+        }
+        all_ok &= ok;
+        fprintf(out, "{\"case\": \"%s\", \"shape\": [%d, %d, %d], \"rc\": %d, \"V\": %lld, \"V_expected\": %lld, \"F\": %lld, \"F_expected\": %lld, "
+                     "\"verts_bit_exact\": %d, \"faces_bit_exact\": %d, \"normals_bit_exact\": %d, \"values_bit_exact\": %d, \"ok\": %d, \"error\": \"%s\"}\n",
+                name, dims[0], dims[1], dims[2], rc, (long long)gv, (long long)V, (long long)gf, (long long)F, okv, okf, okn, okval, ok,
+                rc ? mc_err() : "");
+        fflush(out);
+        (void)hipFree(dvol); (void)hipFree(ws);
+        if (dmask) (void)hipFree(dmask);
+    }
+    fclose(f);
+    fprintf(out, "{\"golden_cases\": %d, \"all_bit_exact\": %d}\n", ncases, all_ok);
+    fflush(out);
+
+    // the reference's crop: 512^3, analytic volume made on the device; count and emit timed with HIP events
+    const int n = 512;
+    const int64_t np = (int64_t)n * n * n;
+    float* dvol;
+    void* ws;
+    const size_t wsb = mc_ws(n, n, n);
+    CK(hipMalloc(&dvol, 4 * np));
+    CK(hipMalloc(&ws, wsb));
+    hipLaunchKernelGGL(fill_volume, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, 0, dvol, n);
+    CK(hipDeviceSynchronize());
+    int64_t V = 0, F = 0;
+    int rc = mc_count(dvol, nullptr, n, n, n, 0.0, ws, wsb, &V, &F, nullptr);
+    if (rc) {
+        fprintf(out, "{\"crop512\": \"count failed\", \"rc\": %d, \"error\": \"%s\"}\n", rc, mc_err());
+        fflush(out);
+        return 11;
+    }
+    float *dv, *dn, *dval;
+    int32_t* df;
+    CK(hipMalloc(&dv, 12 * V));
+    CK(hipMalloc(&dn, 12 * V));
+    CK(hipMalloc(&dval, 4 * V));
+    CK(hipMalloc(&df, 12 * F));
+    hipEvent_t e0, e1, e2;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
+    float best_c = 1e30f, best_e = 1e30f;
+    for (int rep = 0; rep < 6; ++rep) {
+        CK(hipEventRecord(e0, 0));
+        rc = mc_count(dvol, nullptr, n, n, n, 0.0, ws, wsb, &V, &F, nullptr);
+        CK(hipEventRecord(e1, 0));
+        rc |= mc_emit(dvol, nullptr, n, n, n, 0.0, ws, wsb, V, F, 1, dv, df, dn, dval, nullptr);
+        CK(hipEventRecord(e2, 0));
+        CK(hipEventSynchronize(e2));
+        float tc, te;
+        CK(hipEventElapsedTime(&tc, e0, e1));
+        CK(hipEventElapsedTime(&te, e1, e2));
+        if (rep) { best_c = tc < best_c ? tc : best_c; best_e = te < best_e ? te : best_e; }
+    }
+    // algorithmic bytes: the volume once (4 B / point) + the mesh written (12 V + 12 F + 12 V + 4 V)
+    const double alg = 4.0 * np + 28.0 * V + 12.0 * F;
+    fprintf(out, "{\"crop512\": {\"rc\": %d, \"V\": %lld, \"F\": %lld, \"count_ms\": %.4f, \"emit_ms\": %.4f, \"total_ms\": %.4f, \"workspace_bytes\": %zu, "
+                 "\"algorithmic_bytes\": %.0f, \"achieved_GBps\": %.1f, \"frac_of_8TBps\": %.4f, \"lattice_points_per_s\": %.3e}}\n",
+            rc, (long long)V, (long long)F, best_c, best_e, best_c + best_e, wsb, alg, alg / ((best_c + best_e) * 1e-3) / 1e9,
+            alg / ((best_c + best_e) * 1e-3) / 8e12, np / ((best_c + best_e) * 1e-3));
+    fflush(out);
+    fclose(out);
+    return all_ok ? 0 : 1;
+}
