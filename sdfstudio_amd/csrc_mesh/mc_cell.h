@@ -2,7 +2,8 @@
 //
 // What it replaces: skimage.measure.marching_cubes as nerfstudio/utils/marching_cubes.py:125-134 calls it on every 512^3 crop
 // (scikit-image's _marching_cubes_lewiner_cy, a Cython port of Lewiner's MarchingCubes.cpp) - there a serial CPU pass over a volume that
-// first crosses PCIe; here four data-parallel passes over the volume where the SDF kernels left it (mesh_api.hip).
+// first crosses PCIe; here one streaming pass over the volume where the SDF kernels left it, then passes over the surface cells only
+// (mesh_api.hip).
 // The arithmetic follows oracle/marching_cubes.py line by line (that file lists what was fitted to the scikit-image binary): corner
 // values and every test in double, positions rounded to float once, normals accumulated in float in scikit-image's own order.
 //
@@ -206,6 +207,18 @@ MC_FN bool mc_is_creator(const McGrid& g, int x, int y, int z, int e) {
             if (mc_cell_exists(g, cx, cy, cz)) return cx == x && cy == y && cz == z;
         }
     return false;  // unreachable: (x, y, z) itself is among the candidates
+}
+
+// pass 0 (the only pass over the whole volume): does the cell exist, is it unmasked and do its corners straddle the level
+MC_FN bool mc_cell_nonempty(const McGrid& g, int x, int y, int z) {
+    if (!mc_cell_exists(g, x, y, z)) return false;
+    bool any_in = false, any_out = false;
+    for (int p = 0; p < 8; ++p) {
+        const double v = (double)g.vol[mc_point(g, x + MC_CORNER[p][0], y + MC_CORNER[p][1], z + MC_CORNER[p][2])] - g.level;
+        if (v > 0.0) any_in = true;
+        else any_out = true;
+    }
+    return any_in && any_out;
 }
 
 // pass 1: the number of face INDICES (3 per triangle) and of vertices this cell creates

@@ -1,12 +1,17 @@
 // libsdfmesh.so: marching cubes on a device-resident volume (include/sdfmesh.h).  gfx950 only.
 //
-// Data flow (HBM-bound integer / table work: one thread per cell, x fastest so a wavefront reads four contiguous 256-byte rows):
-//   mc_count_kernel      volume -> per cell: face-index count, created-vertex count            reads 4 B / point, writes 8 B / cell
-//   hipcub ExclusiveSum  x 2   -> per cell: offset into the face array, first vertex id        16 B / cell
-//   mc_vertices_kernel   non-empty cells: positions of the vertices the cell creates (+ their normals / values, gathered from the
-//                        <= 4 cells around each edge in scikit-image's own accumulation order) and the edge -> id map
-//   mc_faces_kernel      non-empty cells: triangles through the map
-// Vertex ids and face offsets come from scans over the cells in scikit-image's traversal order, so the arrays come out in ITS order.
+// Data flow.  HBM-bound integer / table work; the volume is read ONCE, everything after that touches the surface cells only:
+//   mc_classify_kernel   all cells, one thread each, x fastest (a wavefront reads four contiguous 256-byte rows; blocks are dealt to
+//                        the 8 XCDs in contiguous runs so that the rows two neighbouring blocks share are hit in ONE L2): appends
+//                        the cells whose corners straddle the level to a list (one atomic per wavefront)       4 B / lattice point read
+//   hipcub radix sort    the list, ascending = scikit-image's traversal order (z outermost, x innermost)      O(surface)
+//   mc_count_kernel      per listed cell: face-index count, created-vertex count
+//   hipcub ExclusiveSum  x 2: offset into the face array, first vertex id - so the arrays come out in scikit-image's ORDER
+//   mc_vertices_kernel   per listed cell: the vertices it creates (+ normals / values, gathered from the <= 4 cells around each edge
+//                        in scikit-image's own accumulation order) and the edge -> id map
+//   mc_faces_kernel      per listed cell: its triangles through the map
+// Round 5's first form ran count / vertices / faces with one thread per lattice cell (1 - 2 busy lanes per wavefront on the surface,
+// two 134 M-element scans): 8.6 ms per 512^3 crop on an MI355X (profiles/r5_mesh_gpu_check_v1.jsonl); this form compacts first.
 // All arithmetic is in mc_cell.h (shared with the host test harness); the kernels below only map threads to cells.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -30,83 +35,136 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
-#define MESH_HIP(expr)                                                                                         \
-    do {                                                                                                       \
-        hipError_t e_ = (expr);                                                                                \
+#define MESH_HIP(expr)                                                                                             \
+    do {                                                                                                           \
+        hipError_t e_ = (expr);                                                                                    \
         if (e_ != hipSuccess) return fail(-5, "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
 constexpr int kBlock = 256;
+constexpr int kXcds = 8;
+constexpr unsigned kMaxListBlocks = 16384;  // grid of the per-listed-cell kernels (grid-stride over the list)
+
+struct Counters {  // device-side, in the workspace
+    unsigned n_listed;             // cells appended by mc_classify_kernel (may exceed the capacity: then the call fails)
+    unsigned pad;
+    unsigned long long n_face_idx;  // 3 x triangles
+    unsigned long long n_verts;
+};
 
 struct Layout {  // carve of the caller's workspace
-    int64_t ncells, npoints;
-    size_t cnt_f, cnt_v, off_f, off_v, idmap, totals, scan_tmp, scan_tmp_bytes, total_bytes;
+    int64_t ncells, npoints, cap;
+    size_t list_a, list_b, cnt_f, cnt_v, off_f, off_v, idmap, counters, tmp, tmp_bytes, total_bytes;
 };
 
 size_t align256(size_t n) { return (n + 255) / 256 * 256; }
+
+// Capacity of the surface-cell list: every cell of a small volume; a quarter of the cells of a large one (a 512^3 SDF crop has < 1 %
+// of its cells on the surface; white noise has ~ 100 % and is refused beyond 2^20 cells with a message).
+int64_t list_capacity(int64_t ncells) {
+    const int64_t small = (int64_t)1 << 20;
+    if (ncells <= small) return ncells;
+    return ncells / 4 > small ? ncells / 4 : small;
+}
 
 bool make_layout(int n0, int n1, int n2, Layout& L) {
     if (n0 < 2 || n1 < 2 || n2 < 2) return false;
     L.npoints = (int64_t)n0 * n1 * n2;
     if (L.npoints >= ((int64_t)1 << 31)) return false;
     L.ncells = (int64_t)(n0 - 1) * (n1 - 1) * (n2 - 1);
-    size_t tmp = 0;
-    if (hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, (const unsigned*)nullptr, (unsigned*)nullptr, (int)L.ncells, (hipStream_t)0) != hipSuccess)
+    L.cap = list_capacity(L.ncells);
+    size_t t_scan = 0, t_sort = 0;
+    if (hipcub::DeviceScan::ExclusiveSum(nullptr, t_scan, (const unsigned*)nullptr, (unsigned*)nullptr, (int)L.cap, (hipStream_t)0) != hipSuccess)
         return false;
-    L.scan_tmp_bytes = tmp;
+    if (hipcub::DeviceRadixSort::SortKeys(nullptr, t_sort, (const unsigned*)nullptr, (unsigned*)nullptr, (int)L.cap, 0, 32, (hipStream_t)0) != hipSuccess)
+        return false;
+    L.tmp_bytes = t_scan > t_sort ? t_scan : t_sort;
     size_t off = 0;
-    L.cnt_f = off; off += align256(sizeof(unsigned) * L.ncells);
-    L.cnt_v = off; off += align256(sizeof(unsigned) * L.ncells);
-    L.off_f = off; off += align256(sizeof(unsigned) * L.ncells);
-    L.off_v = off; off += align256(sizeof(unsigned) * L.ncells);
+    const size_t per_list = align256(sizeof(unsigned) * (size_t)L.cap);
+    L.list_a = off; off += per_list;
+    L.list_b = off; off += per_list;
+    L.cnt_f = off; off += per_list;
+    L.cnt_v = off; off += per_list;
+    L.off_f = off; off += per_list;
+    L.off_v = off; off += per_list;
     L.idmap = off; off += align256(sizeof(int) * 4 * (size_t)L.npoints);
-    L.totals = off; off += 256;
-    L.scan_tmp = off; off += align256(tmp);
+    L.counters = off; off += 256;
+    L.tmp = off; off += align256(L.tmp_bytes);
     L.total_bytes = off;
     return true;
 }
 
-__device__ inline bool cell_of_thread(const McGrid& g, int64_t ncells, int& x, int& y, int& z, int64_t& c) {
-    c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (c >= ncells) return false;
-    const int cx = g.nx - 1, cy = g.ny - 1;
-    x = (int)(c % cx);
-    y = (int)((c / cx) % cy);
-    z = (int)(c / ((int64_t)cx * cy));
-    return true;
+__device__ inline void cell_xyz(const McGrid& g, unsigned c, int& x, int& y, int& z) {
+    const unsigned cx = (unsigned)(g.nx - 1), cy = (unsigned)(g.ny - 1);
+    const unsigned row = c / cx;
+    x = (int)(c - row * cx);
+    z = (int)(row / cy);
+    y = (int)(row - (unsigned)z * cy);
 }
 
-__global__ __launch_bounds__(kBlock) void mc_count_kernel(McGrid g, int64_t ncells, unsigned* cnt_f, unsigned* cnt_v,
-                                                          unsigned long long* totals) {
-    int x, y, z;
-    int64_t c;
-    if (!cell_of_thread(g, ncells, x, y, z, c)) return;
-    unsigned nf, nv;
-    mc_cell_count(g, x, y, z, nf, nv);
-    cnt_f[c] = nf;
-    cnt_v[c] = nv;
-    if (nf) {  // exact 64-bit totals beside the 32-bit scans: an overflow of those is detected, not wrapped
-        atomicAdd(&totals[0], (unsigned long long)nf);
-        atomicAdd(&totals[1], (unsigned long long)nv);
+// blocks_per_xcd consecutive LOGICAL blocks (a contiguous slab of cells) go to one XCD: hardware deals block b to XCD b % 8
+__global__ __launch_bounds__(kBlock) void mc_classify_kernel(McGrid g, unsigned ncells, unsigned nblocks, unsigned blocks_per_xcd,
+                                                             unsigned cap, unsigned* list, Counters* counters) {
+    const unsigned logical = (blockIdx.x % kXcds) * blocks_per_xcd + blockIdx.x / kXcds;
+    const unsigned c = logical * kBlock + threadIdx.x;
+    bool nonempty = false;
+    if (logical < nblocks && c < ncells) {
+        int x, y, z;
+        cell_xyz(g, c, x, y, z);
+        nonempty = mc_cell_nonempty(g, x, y, z);
+    }
+    // one atomic per wavefront: the leader reserves a run of the list for the wavefront's non-empty cells (no lane has left early)
+    const unsigned long long m = __ballot(nonempty);
+    if (m == 0ull) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(&counters->n_listed, (unsigned)__popcll(m));
+    base = __shfl(base, leader, 64);
+    if (nonempty) {
+        const unsigned pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+        if (pos < cap) list[pos] = c;
     }
 }
 
-__global__ __launch_bounds__(kBlock) void mc_vertices_kernel(McGrid g, int64_t ncells, const unsigned* cnt_v, const unsigned* off_v,
-                                                             int* idmap, float* verts, float* normals, float* values) {
-    int x, y, z;
-    int64_t c;
-    if (!cell_of_thread(g, ncells, x, y, z, c)) return;
-    if (cnt_v[c] == 0) return;
-    mc_cell_vertices(g, x, y, z, off_v[c], verts, normals, values, idmap);
+__global__ __launch_bounds__(kBlock) void mc_count_kernel(McGrid g, const unsigned* list, const Counters* counters, unsigned* cnt_f,
+                                                          unsigned* cnt_v) {
+    const unsigned n = counters->n_listed;
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        int x, y, z;
+        cell_xyz(g, list[i], x, y, z);
+        unsigned nf, nv;
+        mc_cell_count(g, x, y, z, nf, nv);
+        cnt_f[i] = nf;
+        cnt_v[i] = nv;
+    }
 }
 
-__global__ __launch_bounds__(kBlock) void mc_faces_kernel(McGrid g, int64_t ncells, const unsigned* cnt_f, const unsigned* off_f,
+__global__ void mc_totals_kernel(Counters* counters, const unsigned* cnt_f, const unsigned* cnt_v, const unsigned* off_f, const unsigned* off_v) {
+    const unsigned n = counters->n_listed;
+    counters->n_face_idx = n ? (unsigned long long)off_f[n - 1] + cnt_f[n - 1] : 0ull;
+    counters->n_verts = n ? (unsigned long long)off_v[n - 1] + cnt_v[n - 1] : 0ull;
+}
+
+__global__ __launch_bounds__(kBlock) void mc_vertices_kernel(McGrid g, const unsigned* list, const Counters* counters, const unsigned* cnt_v,
+                                                             const unsigned* off_v, int* idmap, float* verts, float* normals, float* values) {
+    const unsigned n = counters->n_listed;
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        if (cnt_v[i] == 0) continue;
+        int x, y, z;
+        cell_xyz(g, list[i], x, y, z);
+        mc_cell_vertices(g, x, y, z, off_v[i], verts, normals, values, idmap);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void mc_faces_kernel(McGrid g, const unsigned* list, const Counters* counters, const unsigned* off_f,
                                                           const int* idmap, int* faces, int flip) {
-    int x, y, z;
-    int64_t c;
-    if (!cell_of_thread(g, ncells, x, y, z, c)) return;
-    if (cnt_f[c] == 0) return;
-    mc_cell_faces(g, x, y, z, off_f[c], idmap, faces, flip);
+    const unsigned n = counters->n_listed;
+    for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        int x, y, z;
+        cell_xyz(g, list[i], x, y, z);
+        mc_cell_faces(g, x, y, z, off_f[i], idmap, faces, flip);
+    }
 }
 
 int check_device() {
@@ -115,11 +173,16 @@ int check_device() {
     return 0;
 }
 
+unsigned list_blocks(int64_t n) {
+    const int64_t b = (n + kBlock - 1) / kBlock;
+    return (unsigned)(b < 1 ? 1 : (b > kMaxListBlocks ? kMaxListBlocks : b));
+}
+
 }  // namespace
 
 extern "C" {
 
-int sdfmesh_version(void) { return 100; }
+int sdfmesh_version(void) { return 101; }
 
 const char* sdfmesh_last_error(void) { return g_err; }
 
@@ -140,28 +203,51 @@ int sdfmesh_mc_count(const float* volume, const unsigned char* mask, int n0, int
         return fail(-3, "sdfmesh_mc_count: workspace of %zu bytes, %zu needed (sdfmesh_mc_workspace_bytes)", workspace_bytes, L.total_bytes);
     hipStream_t stream = (hipStream_t)stream_;
     char* ws = (char*)workspace;
+    unsigned* list_a = (unsigned*)(ws + L.list_a);
+    unsigned* list_b = (unsigned*)(ws + L.list_b);
     unsigned* cnt_f = (unsigned*)(ws + L.cnt_f);
     unsigned* cnt_v = (unsigned*)(ws + L.cnt_v);
     unsigned* off_f = (unsigned*)(ws + L.off_f);
     unsigned* off_v = (unsigned*)(ws + L.off_v);
-    unsigned long long* totals = (unsigned long long*)(ws + L.totals);
+    Counters* counters = (Counters*)(ws + L.counters);
     McGrid g{volume, mask, n0, n1, n2, level};
-    MESH_HIP(hipMemsetAsync(totals, 0, 2 * sizeof(unsigned long long), stream));
-    const unsigned blocks = (unsigned)((L.ncells + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(mc_count_kernel, dim3(blocks), dim3(kBlock), 0, stream, g, L.ncells, cnt_f, cnt_v, totals);
+    MESH_HIP(hipMemsetAsync(counters, 0, sizeof(Counters), stream));
+    const unsigned nblocks = (unsigned)((L.ncells + kBlock - 1) / kBlock);
+    const unsigned blocks_per_xcd = (nblocks + kXcds - 1) / kXcds;
+    hipLaunchKernelGGL(mc_classify_kernel, dim3(blocks_per_xcd * kXcds), dim3(kBlock), 0, stream, g, (unsigned)L.ncells, nblocks,
+                       blocks_per_xcd, (unsigned)L.cap, list_a, counters);
     MESH_HIP(hipGetLastError());
-    size_t tmp = L.scan_tmp_bytes;
-    MESH_HIP(hipcub::DeviceScan::ExclusiveSum(ws + L.scan_tmp, tmp, (const unsigned*)cnt_f, off_f, (int)L.ncells, stream));
-    tmp = L.scan_tmp_bytes;
-    MESH_HIP(hipcub::DeviceScan::ExclusiveSum(ws + L.scan_tmp, tmp, (const unsigned*)cnt_v, off_v, (int)L.ncells, stream));
-    unsigned long long host_totals[2] = {0, 0};
-    MESH_HIP(hipMemcpyAsync(host_totals, totals, sizeof(host_totals), hipMemcpyDeviceToHost, stream));
+    Counters host;
+    MESH_HIP(hipMemcpyAsync(&host, counters, sizeof(Counters), hipMemcpyDeviceToHost, stream));
+    MESH_HIP(hipStreamSynchronize(stream));  // the list's length sizes the sort
+    const unsigned n = host.n_listed;
+    if ((int64_t)n > L.cap)
+        return fail(-4, "sdfmesh_mc_count: %u of %lld cells cross the level, the list holds %lld (a volume this noisy is meshed in smaller crops)",
+                    n, (long long)L.ncells, (long long)L.cap);
+    if ((unsigned long long)n * 36ull > 0xffffffffull)
+        return fail(-4, "sdfmesh_mc_count: %u surface cells can exceed 32-bit face offsets (mesh the volume in smaller crops)", n);
+    *num_vertices = 0;
+    *num_faces = 0;
+    if (n == 0) return 0;
+    size_t tmp = L.tmp_bytes;
+    MESH_HIP(hipcub::DeviceRadixSort::SortKeys(ws + L.tmp, tmp, (const unsigned*)list_a, list_b, (int)n, 0, 32, stream));
+    hipLaunchKernelGGL(mc_count_kernel, dim3(list_blocks(n)), dim3(kBlock), 0, stream, g, (const unsigned*)list_b, (const Counters*)counters,
+                       cnt_f, cnt_v);
+    MESH_HIP(hipGetLastError());
+    tmp = L.tmp_bytes;
+    MESH_HIP(hipcub::DeviceScan::ExclusiveSum(ws + L.tmp, tmp, (const unsigned*)cnt_f, off_f, (int)n, stream));
+    tmp = L.tmp_bytes;
+    MESH_HIP(hipcub::DeviceScan::ExclusiveSum(ws + L.tmp, tmp, (const unsigned*)cnt_v, off_v, (int)n, stream));
+    hipLaunchKernelGGL(mc_totals_kernel, dim3(1), dim3(1), 0, stream, counters, (const unsigned*)cnt_f, (const unsigned*)cnt_v,
+                       (const unsigned*)off_f, (const unsigned*)off_v);
+    MESH_HIP(hipGetLastError());
+    MESH_HIP(hipMemcpyAsync(&host, counters, sizeof(Counters), hipMemcpyDeviceToHost, stream));
     MESH_HIP(hipStreamSynchronize(stream));
-    if (host_totals[0] > 0x7fffffffULL || host_totals[1] > 0x7fffffffULL)
-        return fail(-4, "sdfmesh_mc_count: %llu face indices / %llu vertices do not fit 32-bit offsets (extract the mesh in smaller crops)",
-                    host_totals[0], host_totals[1]);
-    *num_faces = (int64_t)(host_totals[0] / 3);
-    *num_vertices = (int64_t)host_totals[1];
+    if (host.n_face_idx > 0x7fffffffULL || host.n_verts > 0x7fffffffULL)
+        return fail(-4, "sdfmesh_mc_count: %llu face indices / %llu vertices do not fit 32-bit indices (mesh the volume in smaller crops)",
+                    host.n_face_idx, host.n_verts);
+    *num_faces = (int64_t)(host.n_face_idx / 3);
+    *num_vertices = (int64_t)host.n_verts;
     return 0;
 }
 
@@ -181,12 +267,15 @@ int sdfmesh_mc_emit(const float* volume, const unsigned char* mask, int n0, int 
     hipStream_t stream = (hipStream_t)stream_;
     char* ws = (char*)workspace;
     McGrid g{volume, mask, n0, n1, n2, level};
-    const unsigned blocks = (unsigned)((L.ncells + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(mc_vertices_kernel, dim3(blocks), dim3(kBlock), 0, stream, g, L.ncells, (const unsigned*)(ws + L.cnt_v),
+    const unsigned* list = (const unsigned*)(ws + L.list_b);
+    const Counters* counters = (const Counters*)(ws + L.counters);
+    // the list has at most one entry per three face indices and is what the counters in the workspace say; size the grids by the mesh
+    const unsigned blocks = list_blocks(num_faces + 1);
+    hipLaunchKernelGGL(mc_vertices_kernel, dim3(blocks), dim3(kBlock), 0, stream, g, list, counters, (const unsigned*)(ws + L.cnt_v),
                        (const unsigned*)(ws + L.off_v), (int*)(ws + L.idmap), verts, normals, values);
     MESH_HIP(hipGetLastError());
-    hipLaunchKernelGGL(mc_faces_kernel, dim3(blocks), dim3(kBlock), 0, stream, g, L.ncells, (const unsigned*)(ws + L.cnt_f),
-                       (const unsigned*)(ws + L.off_f), (const int*)(ws + L.idmap), (int*)faces, flip_faces ? 1 : 0);
+    hipLaunchKernelGGL(mc_faces_kernel, dim3(blocks), dim3(kBlock), 0, stream, g, list, counters, (const unsigned*)(ws + L.off_f),
+                       (const int*)(ws + L.idmap), (int*)faces, flip_faces ? 1 : 0);
     MESH_HIP(hipGetLastError());
     return 0;
 }

@@ -1,13 +1,14 @@
 // TEST HARNESS (tests/test_cpu_marching_cubes.py builds it with g++; nothing in the product links or runs it).
 // Compiles the per-cell / per-vertex functions of sdfstudio_amd/csrc_mesh/mc_cell.h for the host and runs them in the pass structure of
-// mesh_api.hip - count, exclusive scans over the cells, vertices (+ normals, values), faces - with a serial loop where the GPU has one
-// thread per cell, so that the kernels' logic is checked against the oracle (and through it scikit-image) in a container without a GPU.
+// mesh_api.hip - classify + compact, sort, count, exclusive scans, vertices (+ normals, values), faces - with a serial loop where the GPU
+// has one thread per cell / per listed cell, so that the kernels' logic is checked against the oracle (and through it scikit-image) in a container without a GPU.
 //   usage: mesh_host_check <in> <out>
 //   in : int32 n0 n1 n2, float64 level, int32 has_mask, float32 volume[n0*n1*n2], uint8 mask[...] if has_mask
 //   out: int64 V, int64 n_face_indices, float32 verts[V*3], int32 faces[...], float32 normals[V*3], float32 values[V]
 #define MC_HOST_CHECK 1
 #include "mc_cell.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -29,33 +30,55 @@ int main(int argc, char** argv) {
     McGrid g{vol.data(), has_mask ? mask.data() : nullptr, dims[0], dims[1], dims[2], level};
     const int cx = g.nx - 1, cy = g.ny - 1, cz = g.nz - 1;
     const int64_t ncells = (int64_t)cx * cy * cz;
-    std::vector<unsigned> cnt_f(ncells), cnt_v(ncells), off_f(ncells), off_v(ncells);
-    // pass 1 (mc_count_kernel): the same linear cell index -> (x, y, z) as cell_of_thread
-    for (int64_t c = 0; c < ncells; ++c) {
-        const int x = (int)(c % cx), y = (int)((c / cx) % cy), z = (int)(c / ((int64_t)cx * cy));
-        mc_cell_count(g, x, y, z, cnt_f[c], cnt_v[c]);
+    auto xyz = [&](unsigned c, int& x, int& y, int& z) {  // cell_xyz of mesh_api.hip
+        const unsigned row = c / (unsigned)cx;
+        x = (int)(c - row * (unsigned)cx);
+        z = (int)(row / (unsigned)cy);
+        y = (int)(row - (unsigned)z * (unsigned)cy);
+    };
+    // pass 0 (mc_classify_kernel): the list of surface cells - appended in REVERSE order here (the GPU's order is whatever the
+    // wavefronts' atomics make it) - then sorted ascending, as the radix sort leaves it
+    std::vector<unsigned> list;
+    for (int64_t c = ncells - 1; c >= 0; --c) {
+        int x, y, z;
+        xyz((unsigned)c, x, y, z);
+        if (mc_cell_nonempty(g, x, y, z)) list.push_back((unsigned)c);
+    }
+    std::sort(list.begin(), list.end());
+    const size_t n = list.size();
+    std::vector<unsigned> cnt_f(n), cnt_v(n), off_f(n), off_v(n);
+    // pass 1 (mc_count_kernel) over the list
+    for (size_t i = 0; i < n; ++i) {
+        int x, y, z;
+        xyz(list[i], x, y, z);
+        mc_cell_count(g, x, y, z, cnt_f[i], cnt_v[i]);
+        if (cnt_f[i] == 0) {
+            fprintf(stderr, "a listed cell has no triangle\n");
+            return 5;
+        }
     }
     // the two exclusive scans
     uint64_t tf = 0, tv = 0;
-    for (int64_t c = 0; c < ncells; ++c) {
-        off_f[c] = (unsigned)tf;
-        off_v[c] = (unsigned)tv;
-        tf += cnt_f[c];
-        tv += cnt_v[c];
+    for (size_t i = 0; i < n; ++i) {
+        off_f[i] = (unsigned)tf;
+        off_v[i] = (unsigned)tv;
+        tf += cnt_f[i];
+        tv += cnt_v[i];
     }
     std::vector<float> verts(3 * tv), normals(3 * tv), values(tv);
     std::vector<int> faces(tf), idmap(4 * npoints, -123456789);  // the map is uninitialised on the GPU: poison it here
-    // pass 2 (mc_vertices_kernel), in REVERSE cell order: nothing may depend on the order threads run in
-    for (int64_t c = ncells - 1; c >= 0; --c) {
-        if (cnt_v[c] == 0) continue;
-        const int x = (int)(c % cx), y = (int)((c / cx) % cy), z = (int)(c / ((int64_t)cx * cy));
-        mc_cell_vertices(g, x, y, z, off_v[c], verts.data(), normals.data(), values.data(), idmap.data());
+    // pass 2 (mc_vertices_kernel), in REVERSE list order: nothing may depend on the order threads run in
+    for (size_t i = n; i-- > 0;) {
+        if (cnt_v[i] == 0) continue;
+        int x, y, z;
+        xyz(list[i], x, y, z);
+        mc_cell_vertices(g, x, y, z, off_v[i], verts.data(), normals.data(), values.data(), idmap.data());
     }
     // pass 3 (mc_faces_kernel), reverse order as well; flip = 1 (gradient_direction "descent")
-    for (int64_t c = ncells - 1; c >= 0; --c) {
-        if (cnt_f[c] == 0) continue;
-        const int x = (int)(c % cx), y = (int)((c / cx) % cy), z = (int)(c / ((int64_t)cx * cy));
-        mc_cell_faces(g, x, y, z, off_f[c], idmap.data(), faces.data(), 1);
+    for (size_t i = n; i-- > 0;) {
+        int x, y, z;
+        xyz(list[i], x, y, z);
+        mc_cell_faces(g, x, y, z, off_f[i], idmap.data(), faces.data(), 1);
     }
     for (uint64_t i = 0; i < tf; ++i)
         if (faces[i] < 0 || (uint64_t)faces[i] >= tv) {
