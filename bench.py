@@ -231,6 +231,7 @@ def main():
     ap.add_argument("--no-preset", action="store_true", help="default (config 2) run: skip the neus-facto preset leg appended as \"preset\"")
     ap.add_argument("--no-neus-acc", action="store_true", help="default (config 2) run: skip the packed-sample (NeuS-acc) leg appended as \"neus_acc\"")
     ap.add_argument("--no-dense-sdf", action="store_true", help="default (config 2) run: skip the dense-SDF (mesh extraction) leg appended as \"dense_sdf\"")
+    ap.add_argument("--no-mesh", action="store_true", help="default (config 2) run: skip the marching-cubes leg appended as \"mesh\" (a child process)")
     ap.add_argument("--only", default=None, choices=["inference"],
                     help="inference: only the forward-only and dense-SDF legs on config 2's model (no training steps; tools/ A/B and PMC runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -760,6 +761,21 @@ def dense_sdf_leg(model, device, resolution=(512, 512, 256), reps=3):
                        "bytes_per_point": enc_bytes // P}}
 
 
+def mesh_leg(timeout=300):
+    """SURVEY row f4, the step after the dense SDF evaluation: marching cubes of one 512^3 crop on the device (libsdfmesh.so), in a child
+    process (tools/mesh_leg.py says why).  Never raises: a failure is reported in the leg's own object."""
+    import subprocess
+
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mesh_leg.py")], capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"error": f"rc {r.returncode}", "stderr_tail": r.stderr[-600:]}
+    except Exception as e:  # noqa: BLE001 - the bench line must survive this leg
+        return {"error": repr(e)[:300]}
+
+
 def forward_only_leg(job, device, n_rays, n_samples, reps=10):
     """the eval-mode render (no grad, nothing saved for a backward) of one batch, timed as a whole and - in a second,
     instrumented pass - per kernel.  Its MFMA roofline: forward G, analytic-normal chain G, colour C per ray-sample, 3 issued terms."""
@@ -913,6 +929,10 @@ def run(args):
     acc_extra = None
     if not cfg5 and not args.small and not args.no_neus_acc and world == 1:
         acc_extra = neus_acc_leg(device)
+    mesh_extra = None
+    if not cfg5 and not args.small and not args.no_mesh and world == 1 and rank == 0:
+        torch.cuda.empty_cache()  # the child allocates its own 3.6 GB beside this process
+        mesh_extra = mesh_leg()
 
     if rank == 0:
         from sdfstudio_amd import build as _build
@@ -1003,13 +1023,15 @@ def run(args):
                                     "BASELINE config 2: NeuS-facto hash-grid 16x2x2^19 smoothstep + 8x256 geo MLP + 4x256 colour MLP, "
                                     "4096 rays x 128 samples (+256/96 proposal samples) per GPU per step, full train step incl. Adam"),
                        "rays_per_gpu": N_RAYS, "samples_per_ray": N_SAMPLES,
-                       "parallelism": f"dp{world} (flat-gradient RCCL all-reduce)" if world > 1 else "single GPU"},
+                       "parallelism": (f"dp{world} (flat gradient buffer; " + ("sharded exchange: reduce-scatter -> owned-slice Adam -> all-gather" if job["shard"] else
+                                                                                "bucketed all-reduce") + ", RCCL)") if world > 1 else "single GPU"},
             "roofline": roof,
             "encode_roofline": enc,
             "config5": cfg5_extra,
             "bigmlp": bigmlp_extra,
             "preset": preset_extra,
             "neus_acc": acc_extra,
+            "mesh": mesh_extra,
             "collective": None if world == 1 else collective_report(job, dist.get_backend(), exposed_by_rank, exposed_gather_by_rank),
             "forward_only": fwd_only,
             "dense_sdf": dense,

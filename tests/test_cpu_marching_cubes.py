@@ -209,3 +209,18 @@ def test_mesh_library_refuses_without_a_device():
     rc = lib.sdfmesh_mc_count(None, None, 4, 4, 4, ctypes.c_double(0.0), None, 0, ctypes.byref(nv), ctypes.byref(nf), None)
     assert rc != 0
     assert len(_mesh.last_error()) > 0
+
+
+def test_hardware_evidence_belongs_to_the_sources_as_committed():
+    """profiles/r5_mesh_gpu_check_v2.jsonl (every golden case and the 512^3 crop bit-exact on an MI355X, 2.21 ms per crop) was taken on the
+    library built from the sources with this digest.  If this fails the mesh sources changed: re-run tools/gpu_call_r5p.sh on a GPU box,
+    commit the new evidence and its meta file - until then the numbers quoted in DESIGN.md / README.md describe an older library."""
+    import json
+
+    from sdfstudio_amd import build as b
+
+    meta = json.load(open(os.path.join(ROOT, "profiles", "r5_mesh_gpu_check_v2_meta.json")))
+    assert meta["mesh_library_digest"] == b.mesh_source_digest()
+    lines = [json.loads(ln) for ln in open(os.path.join(ROOT, "profiles", "r5_mesh_gpu_check_v2.jsonl"))]
+    assert any(ln.get("golden_cases") == 6 and ln.get("all_bit_exact") == 1 for ln in lines)
+    assert any(ln.get("crop512_vs_host_harness", {}).get("bit_exact") == 1 for ln in lines)

@@ -1,0 +1,87 @@
+"""The `mesh` leg of bench.py, run as a CHILD process (bench.py::mesh_leg): marching cubes of one 512^3 crop - the reference's crop size,
+nerfstudio/utils/marching_cubes.py:31 - through the Python binding of libsdfmesh.so.  Prints ONE JSON object.
+
+A child, because this is the one leg whose Python path has not run on hardware (round 5 proved the C ABI with tools/mesh_gpu_check.cpp):
+whatever happens here, the parent's bench line survives."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    import torch
+
+    from sdfstudio_amd import _mesh
+    from sdfstudio_amd import build as _build
+    from sdfstudio_amd.utils.marching_cubes import marching_cubes
+
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+    reps = 10
+    dev = torch.device("cuda", 0)
+    ax = torch.linspace(-1, 1, n, device=dev)
+    zz, yy, xx = torch.meshgrid(ax, ax, ax, indexing="ij")
+    vol = torch.minimum(torch.sqrt(xx * xx + yy * yy + zz * zz) - 0.55 - 0.03 * torch.sin(9 * xx) * torch.sin(7 * yy) * torch.sin(5 * zz),
+                        torch.sqrt((xx - 0.8) ** 2 + (yy - 0.8) ** 2 + (zz - 0.8) ** 2) - 0.1).contiguous()
+    del xx, yy, zz
+    spacing = (2.0 / (n - 1),) * 3
+    verts, faces, normals, values = marching_cubes(vol, 0.0, spacing=spacing)  # warm-up; the call the reference makes per crop
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(reps):
+        v, f, nr, val = _mesh.marching_cubes_device(vol, 0.0)
+    e1.record()
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) / reps * 1e3
+    gpu_ms = e0.elapsed_time(e1) / reps
+    V, F = int(v.shape[0]), int(f.shape[0])
+    # sanity on the spot (the parity tests proper: tests/test_gpu_zz_mesh.py, tools/mesh_gpu_check.cpp): two closed surfaces
+    from test_gpu_zz_mesh import _manifold_stats
+
+    closed, euler = _manifold_stats(f, V)
+    again = _mesh.marching_cubes_device(vol, 0.0)
+    reproducible = all(torch.equal(a, b) for a, b in zip((v, f, nr, val), again))
+    P = n ** 3
+    alg = 4 * P + 28 * V + 12 * F  # the volume once + the mesh written: verts 12 V, normals 12 V, values 4 V, faces 12 F
+    out = {"workload": f"marching cubes (Lewiner, scikit-image's arrays bit for bit) of one {n}^3 crop of an analytic SDF (bumpy sphere + small "
+                       "sphere), volume resident in HBM; what nerfstudio/utils/marching_cubes.py:125-134 does per crop with skimage on the CPU",
+           "points": P, "vertices": V, "faces": F, "ms": round(gpu_ms, 4), "ms_wall_incl_host": round(wall_ms, 4),
+           "value": round(P / (gpu_ms * 1e-3), 1), "unit": "lattice points/s",
+           "closed_surface": bool(closed), "euler_characteristic": int(euler), "bit_reproducible": bool(reproducible),
+           "mesh_library_digest": _build.mesh_source_digest(),
+           "roofline": {"kernels": "mc_classify_kernel (the one pass over the volume) + sort / count / scan / vertices / faces over the surface cells",
+                        "bound": "hbm", "achieved": round(alg / (gpu_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(alg / (gpu_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                        "algorithmic_bytes": alg, "achieved_is": "4 B per lattice point read + 28 B per vertex + 12 B per face written, over the whole "
+                                                                  "call (count + emit, incl. its two host synchronisations)"},
+           "hardware_evidence_round5": "profiles/r5_mesh_gpu_check_v2.jsonl: 2.21 ms per 512^3 crop, every array bit-exact (C ABI, no Python)"}
+    # the reference's own CPU step beside it, when the box has the build container's scikit-image interpreter: a bounded sample (256^3)
+    py = "/opt/conda/bin/python3.9"
+    if os.path.exists(py):
+        code = ("import numpy as np, time, warnings\nwarnings.filterwarnings('ignore')\nfrom skimage import measure\nimport skimage\n"
+                "n=256\nax=np.linspace(-1,1,n,dtype=np.float32)\nzz,yy,xx=np.meshgrid(ax,ax,ax,indexing='ij')\n"
+                "vol=np.minimum(np.sqrt(xx*xx+yy*yy+zz*zz)-0.55-0.03*np.sin(9*xx)*np.sin(7*yy)*np.sin(5*zz),np.sqrt((xx-0.8)**2+(yy-0.8)**2+(zz-0.8)**2)-0.1).astype(np.float32)\n"
+                "measure.marching_cubes(vol,0.0)\nt=time.perf_counter()\nv,f,_,_=measure.marching_cubes(vol,0.0)\n"
+                "print(skimage.__version__, time.perf_counter()-t, len(v), len(f))")
+        try:
+            r = subprocess.run([py, "-c", code], capture_output=True, text=True, timeout=120)
+            ver, sec, cv, cf = r.stdout.split()[-4:]
+            out["cpu_baseline"] = {"kind": "reference", "what": f"skimage.measure.marching_cubes, scikit-image {ver}, 1 thread (the routine is serial)",
+                                   "sample": "one 256^3 volume of the same surface", "seconds": round(float(sec), 4),
+                                   "value": round(256 ** 3 / float(sec), 1), "unit": "lattice points/s", "cores": 1,
+                                   "vertices": int(cv), "faces": int(cf)}
+        except Exception as e:  # noqa: BLE001
+            out["cpu_baseline"] = {"error": repr(e)[:200]}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
