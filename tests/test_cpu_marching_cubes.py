@@ -224,3 +224,106 @@ def test_hardware_evidence_belongs_to_the_sources_as_committed():
     lines = [json.loads(ln) for ln in open(os.path.join(ROOT, "profiles", "r5_mesh_gpu_check_v2.jsonl"))]
     assert any(ln.get("golden_cases") == 6 and ln.get("all_bit_exact") == 1 for ln in lines)
     assert any(ln.get("crop512_vs_host_harness", {}).get("bit_exact") == 1 for ln in lines)
+
+
+# ---- the host mirrors (utils/marching_cubes.py) with the device call replaced by the host harness
+
+def _fake_device_call(tmp_path):
+    import torch
+
+    counter = {"n": 0}
+
+    def call(volume, level, mask=None, flip_faces=True, with_normals=True):
+        counter["n"] += 1
+        v, f, n, val = _run_host(volume.numpy(), level, None if mask is None else mask.numpy(), tmp_path, "fake%d" % counter["n"])
+        f = f if flip_faces else np.fliplr(f)
+        return (torch.from_numpy(v.copy()), torch.from_numpy(np.array(f)), torch.from_numpy(n.copy()), torch.from_numpy(val.copy()))
+
+    return call
+
+
+def test_marching_cubes_mirror_is_scikit_images_wrapper(tmp_path, monkeypatch):
+    """sdfstudio_amd.utils.marching_cubes.marching_cubes - argument checks, level default, spacing in double, orientation - against the
+    golden vectors of the real skimage.measure.marching_cubes; libsdfmesh.so's entry point is stood in for by the host harness (no GPU here)."""
+    import torch
+
+    from sdfstudio_amd import _mesh
+    from sdfstudio_amd.utils import marching_cubes as MC
+
+    monkeypatch.setattr(_mesh, "marching_cubes_device", _fake_device_call(tmp_path))
+    for path in GOLDEN:
+        g = _load(path)
+        mask = torch.from_numpy(g["mask"]) if "mask" in g else None
+        verts, faces, normals, values = MC.marching_cubes(torch.from_numpy(g["volume"]), float(g["level"]), spacing=tuple(g["spacing"]),
+                                                          gradient_direction="ascent" if bool(g["ascent"]) else "descent", mask=mask)
+        assert verts.numpy().dtype == g["verts"].dtype and np.array_equal(verts.numpy(), g["verts"]), path
+        assert np.array_equal(faces.numpy(), g["faces"]) and np.array_equal(normals.numpy(), g["normals"]) and np.array_equal(values.numpy(), g["values"])
+    v = torch.ones(4, 4, 4)
+    with pytest.raises(ValueError, match="within volume data range"):
+        MC.marching_cubes(v, 2.0)
+    with pytest.raises(ValueError, match="at least 2x2x2"):
+        MC.marching_cubes(torch.ones(1, 4, 4), 1.0)
+    with pytest.raises(RuntimeError, match="No surface found"):
+        MC.marching_cubes(v, 1.0)
+    with pytest.raises(ValueError, match="same shape"):
+        MC.marching_cubes(v, 1.0, mask=torch.ones(4, 4, 3, dtype=torch.bool))
+    with pytest.raises(NotImplementedError):
+        MC.marching_cubes(v, 1.0, step_size=2)
+    # level=None: the middle of the data range, as scikit-image
+    vol = torch.from_numpy(_load(GOLDEN[0])["volume"])
+    a = MC.marching_cubes(vol)
+    b = MC.marching_cubes(vol, 0.5 * (float(vol.min()) + float(vol.max())))
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def test_get_surface_sliding_and_occupancy_mirrors(tmp_path, monkeypatch):
+    """nerfstudio/utils/marching_cubes.py:15-168 / :171-216 on an analytic sdf (two crops per axis of 16^3, with and without the scene box's
+    coarse mask): the concatenated mesh is the oracle's marching cubes of the volumes the same call returns, crop offsets and spacing applied
+    in double as the reference applies them; the coarse-to-fine pyramid evaluates fewer points than the lattice has."""
+    import torch
+
+    from oracle import marching_cubes as OM
+    from sdfstudio_amd import _mesh
+    from sdfstudio_amd.utils import marching_cubes as MC
+
+    monkeypatch.setattr(_mesh, "marching_cubes_device", _fake_device_call(tmp_path))
+    calls = {"points": 0}
+
+    def sdf(p):
+        calls["points"] += p.shape[0]
+        return torch.sqrt((p * p).sum(-1)) - 0.62 + 0.05 * torch.sin(7 * p[:, 0]) * torch.sin(5 * p[:, 1])
+
+    kw = dict(resolution=32, bounding_box_min=(-1.0, -0.9, -0.8), bounding_box_max=(1.0, 0.9, 0.8), crop=16, device="cpu", sdf=sdf)
+    for cm in (None, (torch.rand(8, 8, 8) > 0.15)):
+        vols = MC.get_surface_sliding(None, return_volumes=True, coarse_mask=cm, **kw)
+        assert len(vols) >= 4
+        mesh = MC.get_surface_sliding(None, coarse_mask=cm, **kw)
+        per_crop = MC.get_surface_sliding(None, return_mesh=False, coarse_mask=cm, **kw)
+        assert len(per_crop) == len(vols)
+        vs, fs, ns, off = [], [], [], 0
+        for lo, hi, vol in vols:
+            spacing = tuple((hi[a] - lo[a]) / 15 for a in range(3))
+            cur = None
+            if cm is not None:
+                ax = [torch.from_numpy(np.linspace(lo[a], hi[a], 16)).float() for a in range(3)]
+                pts = torch.stack(torch.meshgrid(*ax, indexing="ij"), -1)
+                cur = MC._coarse_mask_lookup(cm, pts).numpy()
+            v, f, nrm, _ = OM.marching_cubes(vol.numpy(), 0.0, spacing=spacing, mask=cur)
+            vs.append(v + np.array(lo))
+            fs.append(f.astype(np.int64) + off)
+            ns.append(nrm)
+            off += len(v)
+        assert np.array_equal(mesh[0].numpy(), np.concatenate(vs)) and mesh[0].dtype == torch.float64
+        assert np.array_equal(mesh[1].numpy(), np.concatenate(fs))
+        assert np.array_equal(mesh[2].numpy(), np.concatenate(ns))
+    assert calls["points"] < 6 * 8 * 16 ** 3  # six sweeps over eight crops would be this many without the pyramid's masks
+    # UniSurf's variant: occupancy = sigmoid(10 sdf) at level 0.5
+    occ = MC.get_surface_occupancy(lambda p: torch.sigmoid(-10 * sdf(p)), resolution=20, bounding_box_min=(-1, -1, -1), bounding_box_max=(1, 1, 1),
+                                   device="cpu")
+    n = 20
+    ax = [torch.from_numpy(np.linspace(-1, 1, n)).float() for _ in range(3)]
+    pts = torch.stack(torch.meshgrid(*ax, indexing="ij"), -1).reshape(-1, 3)
+    z = torch.sigmoid(-10 * sdf(pts)).reshape(n, n, n).numpy()
+    v, f, nrm, _ = OM.marching_cubes(z, 0.5, spacing=(2 / 19,) * 3)
+    assert np.array_equal(occ[0].numpy(), v + np.array([-1.0, -1.0, -1.0])) and np.array_equal(occ[1].numpy(), f) and np.array_equal(occ[2].numpy(), nrm)
+    assert MC.get_surface_occupancy(lambda p: torch.zeros(p.shape[0]), resolution=8, device="cpu") is None  # "no surface skip"
