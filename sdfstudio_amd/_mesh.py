@@ -70,7 +70,7 @@ def marching_cubes_device(volume: torch.Tensor, level: float, mask: Optional[tor
     if mask is not None:
         if tuple(mask.shape) != tuple(vol.shape):
             raise ValueError("volume and mask must have the same shape.")
-        m = mask.to(device=vol.device).contiguous().to(torch.uint8)
+        m = (mask.to(device=vol.device) != 0).contiguous().to(torch.uint8)  # truthiness, as scikit-image reads its boolean mask
     need = int(lib.sdfmesh_mc_workspace_bytes(n0, n1, n2))
     if need == 0:
         raise SdfMeshError(f"marching_cubes_device: volume {tuple(vol.shape)} refused: {last_error() or 'every dimension >= 2, < 2^31 points'}")
