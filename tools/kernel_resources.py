@@ -41,5 +41,5 @@ with tempfile.TemporaryDirectory() as d:
 demangle = subprocess.run(["c++filt"], input="\n".join(rows), text=True, capture_output=True).stdout.splitlines()
 print("kernel,code_bytes,vgprs,agprs,sgprs,scratch_bytes,static_lds_bytes")
 for (name, r), dm in sorted(zip(rows.items(), demangle), key=lambda t: -t[0][1][0]):
-    short = re.sub(r"\(.*$", "", dm).replace("void ", "")
+    short = re.sub(r"\(.*$", "", dm.replace("(anonymous namespace)::", "")).replace("void ", "")
     print(f"\"{short}\",{r[0]},{r[1]},{r[2]},{r[3]},{r[4]},{r[5]}")
