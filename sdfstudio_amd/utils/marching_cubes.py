@@ -14,8 +14,10 @@ nerfstudio/utils/marching_cubes.py:15-168.
   for bit and in its array order, oracle/marching_cubes.py is pinned on the real package - without the 512 MB host copy and the serial
   Cython pass the reference pays per crop;
 * ``get_surface_sliding`` strings them together per crop (marching_cubes.py:15-168: crops, coarse mask, pyramid, marching cubes, the
-  crop's offset, concatenation); ``get_surface_occupancy`` is the UniSurf variant (marching_cubes.py:171-216).  Mesh simplification and
-  the .ply writer (pymeshlab / trimesh) are file-format post-processing outside the path and are not built.
+  crop's offset, concatenation); ``get_surface_occupancy`` is the UniSurf variant (marching_cubes.py:171-216) and
+  ``get_surface_sliding_with_contraction`` the one for contracted (unbounded) scenes (marching_cubes.py:218-335).  trimesh's
+  ``merge_vertices``, mesh simplification and the .ply writer (pymeshlab / trimesh) are file-format post-processing outside the path and
+  are not built.
 No scene contraction is applied: ``forward_geonetwork`` takes positions as given (sdf_field.py:380-410).
 """
 from typing import Callable, List, Optional, Sequence, Tuple
@@ -231,3 +233,60 @@ def get_surface_occupancy(occupancy_fn: Callable[[torch.Tensor], torch.Tensor], 
     spacing = tuple((bounding_box_max[a] - bounding_box_min[a]) / (n - 1) for a in range(3))
     verts, faces, normals, _ = marching_cubes(z.reshape(n, n, n), level, spacing=spacing)
     return verts.double() + torch.tensor(tuple(float(t) for t in bounding_box_min), dtype=torch.float64, device=verts.device), faces, normals
+
+
+_max_pool_3d = torch.nn.MaxPool3d(3, stride=1, padding=1)
+
+
+@torch.no_grad()
+def get_surface_sliding_with_contraction(field, resolution: int = 512, bounding_box_min=(-1.0, -1.0, -1.0), bounding_box_max=(1.0, 1.0, 1.0),
+                                         coarse_mask: Optional[torch.Tensor] = None, inv_contraction: Optional[Callable] = None,
+                                         max_range: float = 32.0, crop: int = 512, device=None,
+                                         sdf: Optional[Callable[[torch.Tensor], torch.Tensor]] = None):
+    """marching_cubes.py:218-335 (scenes trained under a scene contraction; scripts/extract_mesh.py:95-107): per crop the sdf is evaluated
+    only where the visibility grid ``coarse_mask`` [1, 1, D, H, W] (over the contracted cube [-2, 2]^3, grid_sample's lookup at points / 2)
+    is set, everything else starts at 100 and is replaced by the 3^3 minimum of its neighbourhood ("to remove masked marching cube
+    artefacts"), marching cubes runs with the crop's mask ON THE DEVICE, and the concatenated vertices go through ``inv_contraction`` and
+    the clip to [-max_range, max_range] in double, as the reference applies them.  Level 0 (marching_cubes.py:235).
+    Returns (verts [V,3] float64, faces [F,3] int64, normals [V,3] float32) or None."""
+    assert resolution % crop == 0 and coarse_mask is not None
+    level = 0.0
+    dev = device if device is not None else field.encoding.params.device
+    fn = sdf if sdf is not None else (lambda p: sdf_on_points(field, p))
+    cm = coarse_mask.to(device=dev, dtype=torch.float32)
+    nblk = resolution // crop
+    edges = [np.linspace(bounding_box_min[a], bounding_box_max[a], nblk + 1) for a in range(3)]
+    meshes = []
+    for i in range(nblk):
+        for j in range(nblk):
+            for k in range(nblk):
+                lo = (edges[0][i], edges[1][j], edges[2][k])
+                hi = (edges[0][i + 1], edges[1][j + 1], edges[2][k + 1])
+                ax = [torch.from_numpy(np.linspace(lo[a], hi[a], crop)).float().to(dev) for a in range(3)]
+                pts = torch.stack(torch.meshgrid(*ax, indexing="ij"), -1)  # [n, n, n, 3]
+                current = torch.nn.functional.grid_sample(cm, pts[None] * 0.5, align_corners=False)  # [1, 1, n, n, n]
+                valid = current.reshape(-1) > 0
+                flat = pts.reshape(-1, 3)
+                pts_sdf = torch.full((flat.shape[0],), 100.0, device=dev)
+                if bool(valid.any()):
+                    pts_sdf[valid] = fn(flat[valid].contiguous())
+                vol = pts_sdf.reshape(1, 1, crop, crop, crop)
+                min_sdf = _max_pool_3d(vol * -1.0) * -1.0
+                inside = (current > 0.0).float()
+                vol = (vol * inside + min_sdf * (1.0 - inside))[0, 0]
+                cur = current[0, 0] > 0.0
+                sel = vol[cur]
+                if sel.numel() == 0 or float(sel.min()) > level or float(sel.max()) < level:
+                    continue
+                if float(vol.min()) > level or float(vol.max()) < level:
+                    continue
+                spacing = tuple((hi[a] - lo[a]) / (crop - 1) for a in range(3))
+                verts, faces, normals, _ = marching_cubes(vol, level, spacing=spacing, mask=cur)
+                meshes.append((verts.double() + torch.tensor(lo, dtype=torch.float64, device=verts.device), faces, normals))
+    mesh = concatenate_meshes(meshes)
+    if mesh is None:
+        return None
+    verts, faces, normals = mesh
+    if inv_contraction is not None:
+        verts = torch.clamp(inv_contraction(verts), -max_range, max_range)
+    return verts, faces, normals

@@ -327,3 +327,58 @@ def test_get_surface_sliding_and_occupancy_mirrors(tmp_path, monkeypatch):
     v, f, nrm, _ = OM.marching_cubes(z, 0.5, spacing=(2 / 19,) * 3)
     assert np.array_equal(occ[0].numpy(), v + np.array([-1.0, -1.0, -1.0])) and np.array_equal(occ[1].numpy(), f) and np.array_equal(occ[2].numpy(), nrm)
     assert MC.get_surface_occupancy(lambda p: torch.zeros(p.shape[0]), resolution=8, device="cpu") is None  # "no surface skip"
+
+
+def test_get_surface_sliding_with_contraction_mirror(tmp_path, monkeypatch):
+    """nerfstudio/utils/marching_cubes.py:218-335 (the variant scripts/extract_mesh.py:95 uses for contracted scenes) against a plain
+    numpy / oracle restatement of its steps: visibility lookup at points / 2, sdf = 100 outside it, the 3^3 minimum fill, marching cubes with
+    the crop's mask, crop offset, inverse contraction (extract_mesh.py:70-75) and the clip."""
+    import torch
+
+    from oracle import marching_cubes as OM
+    from sdfstudio_amd import _mesh
+    from sdfstudio_amd.utils import marching_cubes as MC
+
+    monkeypatch.setattr(_mesh, "marching_cubes_device", _fake_device_call(tmp_path))
+    torch.manual_seed(3)
+    cm = (torch.rand(1, 1, 12, 12, 12) > 0.2).float()
+
+    def sdf(p):
+        return torch.sqrt((p * p).sum(-1)) - 1.3
+
+    def inv_contract(x):  # scripts/extract_mesh.py:70-75, L-inf order
+        mag = torch.linalg.norm(x, ord=float("inf"), dim=-1)
+        mask = mag >= 1
+        x_new = x.clone()
+        x_new[mask] = (1 / (2 - mag[mask][..., None])) * (x[mask] / mag[mask][..., None])
+        return x_new
+
+    kw = dict(resolution=32, bounding_box_min=(-2.0, -2.0, -2.0), bounding_box_max=(2.0, 2.0, 2.0), crop=16, device="cpu", sdf=sdf)
+    got = MC.get_surface_sliding_with_contraction(None, coarse_mask=cm, inv_contraction=inv_contract, max_range=3.0, **kw)
+    assert got is not None and got[0].dtype == torch.float64
+    vs, fs, ns, off = [], [], [], 0
+    edges = np.linspace(-2.0, 2.0, 3)
+    for i in range(2):
+        for j in range(2):
+            for k in range(2):
+                lo = (edges[i], edges[j], edges[k])
+                hi = (edges[i + 1], edges[j + 1], edges[k + 1])
+                ax = [torch.from_numpy(np.linspace(lo[a], hi[a], 16)).float() for a in range(3)]
+                pts = torch.stack(torch.meshgrid(*ax, indexing="ij"), -1)
+                cur = torch.nn.functional.grid_sample(cm, pts[None] * 0.5, align_corners=False)[0, 0]
+                vol = torch.where(cur > 0, sdf(pts.reshape(-1, 3)).reshape(16, 16, 16), torch.full((16, 16, 16), 100.0))
+                mn = -torch.nn.functional.max_pool3d(-vol[None, None], 3, stride=1, padding=1)[0, 0]
+                vol = torch.where(cur > 0, vol, mn).numpy().astype(np.float32)
+                m = (cur > 0).numpy()
+                if not m.any() or vol[m].min() > 0 or vol[m].max() < 0:
+                    continue
+                v, f, nrm, _ = OM.marching_cubes(vol, 0.0, spacing=tuple((hi[a] - lo[a]) / 15 for a in range(3)), mask=m)
+                vs.append(v + np.array(lo))
+                fs.append(f.astype(np.int64) + off)
+                ns.append(nrm)
+                off += len(v)
+    want_v = np.clip(inv_contract(torch.from_numpy(np.concatenate(vs))).numpy(), -3.0, 3.0)
+    assert len(vs) >= 4
+    assert np.array_equal(got[0].numpy(), want_v) and np.array_equal(got[1].numpy(), np.concatenate(fs)) and np.array_equal(got[2].numpy(), np.concatenate(ns))
+    assert float(np.abs(want_v).max()) == 3.0 or float(np.abs(want_v).max()) < 3.0  # the clip is in force
+    assert MC.get_surface_sliding_with_contraction(None, coarse_mask=torch.zeros(1, 1, 4, 4, 4), **kw) is None
