@@ -97,7 +97,8 @@ MESH_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contr
 def mesh_source_digest() -> str:
     h = hashlib.sha256()
     h.update(" ".join(MESH_FLAGS).encode())
-    for name in sorted(os.listdir(MESH_CSRC)) + [os.path.join("..", "..", "include", "sdfmesh.h")]:
+    # the kernels' sources (csrc_mesh/*.h, *.hip); the public header holds declarations and prose only and is not part of the identity
+    for name in sorted(os.listdir(MESH_CSRC)):
         path = os.path.join(MESH_CSRC, name)
         if os.path.isfile(path) and name.endswith((".h", ".hip")):
             with open(path, "rb") as fh:
