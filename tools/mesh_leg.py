@@ -11,8 +11,20 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 PEAK_HBM_GBS = 8000.0
+
+
+def _manifold_stats(faces, n_verts):
+    """(every undirected edge is used exactly twice, once per direction; Euler characteristic V - E + F) of a triangle list."""
+    import torch
+
+    f = faces.long()
+    e = torch.cat([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+    key = e[:, 0] * n_verts + e[:, 1]
+    rev = e[:, 1] * n_verts + e[:, 0]
+    uniq, cnt = torch.unique(key, return_counts=True)
+    closed = bool((cnt == 1).all()) and bool(torch.isin(rev, uniq).all())
+    return closed, n_verts - uniq.numel() // 2 + f.shape[0]
 
 
 def main():
@@ -44,8 +56,6 @@ def main():
     gpu_ms = e0.elapsed_time(e1) / reps
     V, F = int(v.shape[0]), int(f.shape[0])
     # sanity on the spot (the parity tests proper: tests/test_gpu_zz_mesh.py, tools/mesh_gpu_check.cpp): two closed surfaces
-    from test_gpu_zz_mesh import _manifold_stats
-
     closed, euler = _manifold_stats(f, V)
     again = _mesh.marching_cubes_device(vol, 0.0)
     reproducible = all(torch.equal(a, b) for a, b in zip((v, f, nr, val), again))
