@@ -73,6 +73,34 @@ def main():
                         "algorithmic_bytes": alg, "achieved_is": "4 B per lattice point read + 28 B per vertex + 12 B per face written, over the whole "
                                                                   "call (count + emit, incl. its two host synchronisations)"},
            "hardware_evidence_round5": "profiles/r5_mesh_gpu_check_v2.jsonl: 2.21 ms per 512^3 crop, every array bit-exact (C ABI, no Python)"}
+    # the whole operation the reference's `ns-extract-mesh --resolution 512` performs on BASELINE config 2's field (geometric init: a sphere of
+    # radius 0.5): get_surface_sliding = lattice + coarse-to-fine sdf evaluation (MODE_SDF kernels of libsdfhip.so) + marching cubes
+    # (libsdfmesh.so) + crop offset.  Guarded separately: the marching-cubes figures above stand whatever happens here.
+    try:
+        del vol, v, f, nr, val, again, verts, faces, normals, values
+        torch.cuda.empty_cache()
+        import bench as B
+        from sdfstudio_amd.utils.marching_cubes import evaluate_crop_pyramid, get_surface_sliding, sdf_on_points
+
+        model = B.build_model(dev).eval()
+        get_surface_sliding(model.field, resolution=128, crop=128)  # warm-up (allocator, kernels)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        mesh = get_surface_sliding(model.field, resolution=n, crop=n)
+        torch.cuda.synchronize()
+        ex_ms = (time.perf_counter() - t0) * 1e3
+        ax1 = torch.linspace(-1, 1, n, device=dev)
+        pts = torch.stack(torch.meshgrid(ax1, ax1, ax1, indexing="ij"), 0)
+        _, counts, _ = evaluate_crop_pyramid(lambda q: sdf_on_points(model.field, q), pts, 2.0)
+        del pts
+        out["extract_mesh"] = {"workload": f"get_surface_sliding(resolution = crop = {n}) on BASELINE config 2's field at geometric init: what scripts/extract_mesh.py:125-133 "
+                                           "runs (without its .ply export / simplification)",
+                               "ms": round(ex_ms, 3), "vertices": None if mesh is None else int(mesh[0].shape[0]),
+                               "faces": None if mesh is None else int(mesh[1].shape[0]),
+                               "network_evaluations_per_pyramid_level": [int(c) for c in counts], "lattice_points": P,
+                               "fraction_of_lattice_evaluated": round(sum(counts) / P, 5)}
+    except Exception as e:  # noqa: BLE001
+        out["extract_mesh"] = {"error": repr(e)[:300]}
     # the reference's own CPU step beside it, when the box has the build container's scikit-image interpreter: a bounded sample (256^3)
     py = "/opt/conda/bin/python3.9"
     if os.path.exists(py):
