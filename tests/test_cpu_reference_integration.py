@@ -242,3 +242,100 @@ def test_depth_renderer_mirror_against_the_references(ref, method):
     w = w / w.sum(dim=1, keepdim=True) * torch.rand(n, 1, 1, generator=gen)  # some rays never reach 0.5: the index clamps to the last sample
     w[3] = 0.0
     assert torch.equal(DepthRenderer(method)(w, rs), RefDepth(method=method)(w, rs))
+
+
+# ---- mesh extraction: the reference's own drivers (nerfstudio/utils/marching_cubes.py) calling OUR marching cubes
+
+def _reference_mesh_module(monkeypatch, tmp_path):
+    """The reference's marching_cubes module with `measure.marching_cubes` bound to our drop-in and trimesh
+    replaced by a recorder.  No GPU here: libsdfmesh.so's entry point is stood in for by the host build of its kernels' logic
+    (tests/mesh_host_check.cpp), exactly as the field tests above stand in for the native field call."""
+    import types
+
+    import numpy as np
+
+    from oracle import ref_harness
+
+    ref_harness.import_reference()
+    import nerfstudio.utils.marching_cubes as rmc
+    from test_cpu_marching_cubes import _fake_device_call
+
+    from sdfstudio_amd import _mesh
+    from sdfstudio_amd.utils import marching_cubes as ours
+
+    monkeypatch.setattr(_mesh, "marching_cubes_device", _fake_device_call(tmp_path))
+
+    def drop_in(volume, level=None, spacing=(1.0, 1.0, 1.0), mask=None, **kw):  # numpy in, numpy out: what a maintainer's adapter does
+        v, f, n, val = ours.marching_cubes(torch.from_numpy(np.ascontiguousarray(volume)), level, spacing=spacing,
+                                           mask=None if mask is None else torch.from_numpy(np.ascontiguousarray(mask)), **kw)
+        return v.numpy(), f.numpy(), n.numpy(), val.numpy()
+
+    made = []
+
+    class Trimesh:
+        def __init__(self, vertices, faces, vertex_normals=None):
+            self.vertices, self.faces, self.vertex_normals = np.asarray(vertices), np.asarray(faces), vertex_normals
+            made.append(self)
+
+        def export(self, path):
+            self.exported_to = path
+
+    def concatenate(meshes):
+        off, vs, fs = 0, [], []
+        for m in meshes:
+            vs.append(m.vertices)
+            fs.append(m.faces + off)
+            off += len(m.vertices)
+        return Trimesh(np.concatenate(vs), np.concatenate(fs))
+
+    monkeypatch.setattr(rmc, "measure", types.SimpleNamespace(marching_cubes=drop_in))
+    monkeypatch.setattr(rmc, "trimesh", types.SimpleNamespace(Trimesh=Trimesh, util=types.SimpleNamespace(concatenate=concatenate)))
+    return rmc, made
+
+
+def test_reference_get_surface_occupancy_runs_on_our_marching_cubes(monkeypatch, tmp_path):
+    """nerfstudio/utils/marching_cubes.py:171-216, unmodified, with our drop-in behind `measure.marching_cubes`: the mesh it hands to trimesh
+    is what scikit-image would have produced (the oracle, pinned on the real package) and what our own mirror of the function returns."""
+    import numpy as np
+
+    from oracle import marching_cubes as OM
+    from sdfstudio_amd.utils import marching_cubes as ours
+
+    rmc, made = _reference_mesh_module(monkeypatch, tmp_path)
+
+    def occupancy(p):
+        return torch.sigmoid(-10 * (torch.sqrt((p * p).sum(-1)) - 0.6 + 0.05 * torch.sin(6 * p[:, 0])))
+
+    n, lo, hi = 28, (-1.0, -0.9, -0.8), (1.0, 0.9, 0.8)
+    rmc.get_surface_occupancy(occupancy, resolution=n, bounding_box_min=lo, bounding_box_max=hi, level=0.5, device="cpu",
+                              output_path=tmp_path / "mesh.ply")
+    assert len(made) == 1 and made[0].exported_to.endswith("mesh.ply")
+    xs = [np.linspace(lo[a], hi[a], n) for a in range(3)]
+    pts = torch.tensor(np.vstack([g.ravel() for g in np.meshgrid(*xs, indexing="ij")]).T, dtype=torch.float)
+    z = occupancy(pts).numpy().reshape(n, n, n)
+    v, f, nrm, _ = OM.marching_cubes(z, 0.5, spacing=tuple((hi[a] - lo[a]) / (n - 1) for a in range(3)))
+    assert np.array_equal(made[0].vertices, v + np.array(lo)) and np.array_equal(made[0].faces, f) and np.array_equal(made[0].vertex_normals, nrm)
+    mine = ours.get_surface_occupancy(occupancy, resolution=n, bounding_box_min=lo, bounding_box_max=hi, level=0.5, device="cpu")
+    assert np.array_equal(mine[0].numpy(), made[0].vertices) and np.array_equal(mine[1].numpy(), made[0].faces)
+
+
+@pytest.mark.skipif(os.environ.get("SDFHIP_HEAVY_TESTS") != "1", reason="512^3 on the CPU: ~ 10 GB and a minute (SDFHIP_HEAVY_TESTS=1; the run of "
+                                                                         "round 5 is recorded in profiles/r5_reference_get_surface_sliding.txt)")
+def test_reference_get_surface_sliding_runs_on_our_marching_cubes(monkeypatch, tmp_path):
+    """nerfstudio/utils/marching_cubes.py:15-168, unmodified (its crop size is fixed at 512), on an analytic sdf with our drop-in behind
+    `measure.marching_cubes`: the combined mesh equals our own get_surface_sliding's, vertex for vertex and face for face."""
+    import numpy as np
+
+    from sdfstudio_amd.utils import marching_cubes as ours
+
+    rmc, made = _reference_mesh_module(monkeypatch, tmp_path)
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)  # the reference moves its lattice with .cuda()
+
+    def sdf(p):
+        return torch.sqrt((p * p).sum(-1)) - 0.62 + 0.03 * torch.sin(9 * p[:, 0]) * torch.sin(7 * p[:, 1])
+
+    combined = rmc.get_surface_sliding(sdf, resolution=512, return_mesh=True)
+    mine = ours.get_surface_sliding(None, resolution=512, device="cpu", sdf=sdf)
+    assert combined.vertices.shape[0] > 100_000
+    assert np.array_equal(combined.vertices, mine[0].numpy()) and np.array_equal(combined.faces, mine[1].numpy())
+    print("reference get_surface_sliding on our marching cubes: V", combined.vertices.shape[0], "F", combined.faces.shape[0], "identical to the mirror's")
