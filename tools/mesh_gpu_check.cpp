@@ -197,7 +197,7 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(gff.data(), df, 12 * F, hipMemcpyDeviceToHost));
         const uint64_t got[4] = {fnv1a(gvv.data(), 12 * V), fnv1a(gff.data(), 12 * F), fnv1a(gn.data(), 12 * V), fnv1a(gval.data(), 4 * V)};
         const int same = have_exp && V == expV && F == expF && got[0] == exp_sum[0] && got[1] == exp_sum[1] && got[2] == exp_sum[2] && got[3] == exp_sum[3];
-        all_ok &= same;
+        if (have_exp) all_ok &= same;  // a cases file packed with --no-crop512 carries no expectation for the crop
         fprintf(out, "{\"crop512_vs_host_harness\": {\"have_expected\": %d, \"V\": %lld, \"V_expected\": %lld, \"F\": %lld, \"F_expected\": %lld, "
                      "\"verts_fnv\": %d, \"faces_fnv\": %d, \"normals_fnv\": %d, \"values_fnv\": %d, \"bit_exact\": %d}}\n",
                 have_exp, (long long)V, (long long)expV, (long long)F, (long long)expF, got[0] == exp_sum[0], got[1] == exp_sum[1],
