@@ -232,8 +232,10 @@ def main():
     ap.add_argument("--no-neus-acc", action="store_true", help="default (config 2) run: skip the packed-sample (NeuS-acc) leg appended as \"neus_acc\"")
     ap.add_argument("--no-dense-sdf", action="store_true", help="default (config 2) run: skip the dense-SDF (mesh extraction) leg appended as \"dense_sdf\"")
     ap.add_argument("--no-mesh", action="store_true", help="default (config 2) run: skip the marching-cubes leg appended as \"mesh\" (a child process)")
-    ap.add_argument("--only", default=None, choices=["inference"],
-                    help="inference: only the forward-only and dense-SDF legs on config 2's model (no training steps; tools/ A/B and PMC runs)")
+    ap.add_argument("--only", default=None, choices=["inference", "exchange"],
+                    help="inference: only the forward-only and dense-SDF legs on config 2's model (no training steps; tools/ A/B and PMC runs); "
+                         "exchange: only the forced single-rank RCCL exchange legs (what the default run appends as \"exchange_at_n1\")")
+    ap.add_argument("--no-exchange-n1", action="store_true", help="default (config 2) run: skip the single-rank RCCL exchange legs (a child process)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--small", action="store_true", help="small parity configuration (control-flow tests only, not a benchmark)")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the second (untimed) pass that times every launch")
@@ -274,7 +276,11 @@ def make_job(config, device, world, rank, small=False, hidden=256, rays=None, sa
     # slice of parameters and moments, all-gather of the updated slices (the SDF table's last: it overlaps the next step's ray
     # generation and proposal sampling); the big tables are buckets of their own.  SDFHIP_BENCH_EXCHANGE=allreduce: one bucket per
     # parameter group, all-reduced (RCCL) as soon as backward has produced it, replicated Adam (rounds 1 - 4).
-    shard = world > 1 and os.environ.get("SDFHIP_BENCH_EXCHANGE", "shard") == "shard"
+    from sdfstudio_amd.distributed import force_single_rank_exchange
+
+    # SDFHIP_FORCE_EXCHANGE=1 (with a one-rank process group): the N > 1 exchange runs at N = 1 - real RCCL kernels, real stream waits
+    exchanging = world > 1 or (force_single_rank_exchange() and torch.distributed.is_initialized())
+    shard = exchanging and os.environ.get("SDFHIP_BENCH_EXCHANGE", "shard") == "shard"
     if shard:
         from sdfstudio_amd.distributed import plan_buckets
 
@@ -285,7 +291,7 @@ def make_job(config, device, world, rank, small=False, hidden=256, rays=None, sa
             flat.launch_from_native(model.field.encoding.params)
     else:
         flat = FlatGradients([p for g in groups.values() for p in g], buckets=list(groups.values()))
-    flat.time_waits = world > 1
+    flat.time_waits = exchanging
     if cfg5:
         # method_configs.py:434-447: Adam 1e-3 with MultiStepWarmup (fields; AdamW with weight_decay 0 = Adam for field_background),
         # Adam 1e-2 with MultiStepLR (proposal networks)
@@ -665,6 +671,74 @@ def neus_acc_leg(device, steps=20, warmup=5):
     return out
 
 
+def exchange_at_n1_legs(device, steps=8, warmup=3):
+    """the data-parallel exchange EXECUTED ON RCCL on the one GPU a box has.  A process group of one rank, backend "nccl"
+    (= RCCL), SDFHIP_FORCE_EXCHANGE=1: every bucket's reduce_scatter_tensor / all_gather_into_tensor (sharded) or all_reduce (bucketed) is
+    issued on RCCL's stream exactly as at N > 1 - launched from the autograd hooks and from inside the native backward (table callback),
+    waited for chunk by chunk on the compute stream, parameters gathered behind the step's Adam - and returns its input.  What it measures is
+    the exchange's OVERHEAD at N = 1 (launches, stream hand-offs, the extra pass structure), config 2 and config 5, against the same steps
+    with no process group in play; what it cannot measure is wire time (reference seam: pipelines/base_pipeline.py:241-243,
+    scripts/train.py:127-145)."""
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    out = {"backend": dist.get_backend(), "world_size": 1, "steps": steps, "warmup": warmup,
+           "what": "ms per training step with the exchange forced on (RCCL collectives of one rank) vs off; same model, rays and schedules"}
+    try:
+        for key, cfg, first, dominant in (("config2", 2, 0, "geo_bwd_kernel"), ("config5_levels8", 5, 0, "geo_encode_kernel"),
+                                          ("config5_levels16", 5, 200000, "geo_encode_kernel")):
+            res = {}
+            for mode in ("none", "shard", "allreduce"):
+                if mode == "none":
+                    os.environ.pop("SDFHIP_FORCE_EXCHANGE", None)
+                else:
+                    os.environ["SDFHIP_FORCE_EXCHANGE"] = "1"
+                    os.environ["SDFHIP_BENCH_EXCHANGE"] = mode
+                job = make_job(cfg, device, 1, 0)
+                dt, _prof, loss = timed_steps(job, first, warmup, steps, dominant, 1)
+                assert math.isfinite(float(loss.detach())), f"exchange leg {key}/{mode} diverged"
+                flat = job["flat"]
+                r = {"ms_per_step": round(dt / steps * 1e3, 3)}
+                if mode != "none":
+                    assert job["shard"] == (mode == "shard") and flat.exchanging
+                    r.update({"collectives_per_step": flat.last_collectives,
+                              "gather_collectives_per_step": flat.last_gather_collectives // max(flat._finished_steps, 1) if job["shard"] else 0,
+                              "buffer_bytes_per_step": 4 * flat.exchanged_numel(), "gathered_bytes_per_step": flat.gathered_bytes(),
+                              "buckets_launched_during_backward": flat.last_overlapped_buckets,
+                              "buckets_launched_from_inside_the_native_backward": flat.last_early_buckets,
+                              "exposed_ms_per_step": job.get("exposed")})
+                res[mode] = r
+                job["flat"].close()
+                del job, loss, flat
+                torch.cuda.empty_cache()
+            for mode in ("shard", "allreduce"):
+                res[mode]["overhead_ms_per_step"] = round(res[mode]["ms_per_step"] - res["none"]["ms_per_step"], 3)
+            out[key] = res
+    finally:
+        os.environ.pop("SDFHIP_FORCE_EXCHANGE", None)
+        os.environ.pop("SDFHIP_BENCH_EXCHANGE", None)
+        dist.destroy_process_group()
+    return out
+
+
+def child_leg(argv, timeout=420, env=None):
+    """A leg that runs in a child process (its own HIP context, its own process group) and prints one JSON object; never raises: a
+    failure is reported in the leg's own object and the bench line survives."""
+    import subprocess
+
+    try:
+        r = subprocess.run([sys.executable, *argv], capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"error": f"rc {r.returncode}", "stderr_tail": r.stderr[-600:]}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:300]}
+
+
 def collective_report(job, backend, exposed_reduce_by_rank, exposed_gather_by_rank):
     """The data-parallel exchange of the timed steps, phase by phase: bytes per step per rank and the GPU time the compute stream stalled
     on each phase (HIP events around the waits, one value per rank)."""
@@ -859,6 +933,10 @@ def run(args):
 
     from sdfstudio_amd import _lib
 
+    if getattr(args, "only", None) == "exchange":
+        assert world == 1, "--only exchange is the N = 1 leg"
+        print(json.dumps(exchange_at_n1_legs(device, steps=min(args.steps, 8), warmup=min(args.warmup, 3))), flush=True)
+        return
     job = make_job(5 if cfg5 else 2, device, world, rank, small=args.small)
     model, flat, groups = job["model"], job["flat"], job["groups"]
     step = job["step"]

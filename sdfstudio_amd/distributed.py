@@ -57,8 +57,16 @@ from sdfstudio_amd.grad_slots import CLAIM_ATTR, SLOT_ATTR  # noqa: F401
 _DEBUG_LIVE = os.environ.get("SDFHIP_DEBUG_GRADS") == "1"
 
 
+def force_single_rank_exchange() -> bool:
+    """SDFHIP_FORCE_EXCHANGE=1: a process group of ONE rank exchanges as if it had peers - every bucket's collective is issued (RCCL's
+    reduce_scatter / all_gather / all_reduce kernels run on their own stream, the waits are real stream waits, the native table-gradient
+    callback launches its bucket) and the result is the input.  The one way to execute the N > 1 path on the single MI355X a
+    `gpurun` box has (tests/test_gpu_rccl_single_rank.py, bench.py's `exchange_at_n1`); never set in production."""
+    return os.environ.get("SDFHIP_FORCE_EXCHANGE") == "1"
+
+
 def _dist_on(group=None) -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_single_rank_exchange())
 
 
 class FlatGradients:
@@ -79,6 +87,7 @@ class FlatGradients:
         self.shard = bool(shard)
         self.world = dist.get_world_size(group) if _dist_on(group) else 1
         self.rank = dist.get_rank(group) if _dist_on(group) else 0
+        self.exchanging = _dist_on(group)  # collectives are issued (world > 1, or a single rank under SDFHIP_FORCE_EXCHANGE=1)
         if buckets is None:
             buckets = [self.params]
         self._buckets: List[List[torch.nn.Parameter]] = [[p for p in b if p.requires_grad] for b in buckets]
@@ -473,6 +482,12 @@ class FlatGradients:
         gradient by it as it reads it (engine/optimizers.py), which saves the pass over the buffer."""
         if not self._armed:
             raise RuntimeError("FlatGradients.finish() twice without zero() + backward in between")
+        if self.shard and wait and _dist_on(self.group) and self._use_reduce_scatter():
+            # after a reduce-scatter only the OWNED slice of every chunk holds the sum; the rest of the buffer - most p.grad views - still
+            # holds this rank's local gradient.  Returning "means" here would hand gradient clipping / grad-norm logging different numbers
+            # than the all-reduce exchange does (ADVICE r5)
+            raise RuntimeError("FlatGradients.finish(wait=True) under the sharded exchange: p.grad is valid on owned slices only - close the "
+                               "step with Optimizers.optimizer_step_all(grad_scale=None), which takes the reduce-scatters chunk by chunk")
         if self._cb_error is not None:
             err, self._cb_error = self._cb_error, None
             raise RuntimeError("FlatGradients: the native table-gradient callback failed") from err

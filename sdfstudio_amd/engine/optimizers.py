@@ -99,11 +99,12 @@ class FusedAdam:
         self.flat_grads = flat_grads
         # moments: one element per parameter element this rank OWNS - everything, or 1 / W of the buffer under the sharded exchange
         # (distributed.py: owned_slices; a slice's offset in these local buffers is fixed for the run)
-        self.sharded = bool(getattr(flat_grads, "shard", False)) and flat_grads.world > 1
+        self.sharded = bool(getattr(flat_grads, "shard", False)) and (flat_grads.world > 1 or bool(getattr(flat_grads, "exchanging", False)))
         self.exp_avg = torch.zeros(flat_grads.local_numel(), dtype=torch.float32, device=self.flat_params.flat.device)
         self.exp_avg_sq = torch.zeros_like(self.exp_avg)
         self.betas, self.eps, self.weight_decay = betas, eps, weight_decay
         self.step_count = 0
+        self._gathered = None  # sharded mode: (exp_avg, exp_avg_sq) over the whole layout, assembled by gather_moments()
         self.last_elements_visited = 0  # parameter elements the last step() of THIS rank updated
         for name, g in groups.items():
             plist = sorted((p for p in g["params"] if p.requires_grad), key=lambda q: off_of[id(q)])
@@ -149,6 +150,7 @@ class FusedAdam:
         are still arriving."""
         self.step_count += 1
         self.last_elements_visited = 0
+        self._gathered = None  # moments assembled for a checkpoint (gather_moments) are stale from here on
         fg = self.flat_grads
         # Elements that have never carried a gradient (FlatGradients.live_ranges: table rows of hash levels that are still switched
         # off) have zero gradient and zero moments: their update is exactly 0 unless weight decay moves them, so they are skipped.
@@ -179,9 +181,16 @@ class FusedAdam:
     # ---- checkpointing (the trainer's checkpoint holds {"optimizers": {group: optimizer.state_dict()}}, engine/trainer.py:351-360,
     # and Optimizers.load_optimizers (optimizers.py:157-160) restores it: without this a resumed run would restart Adam's bias
     # correction and the warm-up)
+    def gather_moments(self) -> None:
+        """Sharded mode: assemble (exp_avg, exp_avg_sq) over the WHOLE flat layout on every rank - every rank contributes its owned slices,
+        one all-gather per grid chunk (2 x the buffer in memory until the next step() drops it).  A COLLECTIVE: EVERY rank must call it, at
+        the same point of the step.  The reference saves checkpoints on the main process only (engine/trainer.py:277 @check_main_thread),
+        so the call belongs OUTSIDE that guard; state_dict() itself is local and raises when the moments have not been gathered.
+        All-reduce mode: nothing to do."""
+        if self.sharded:
+            self._gathered = self._full_moments()
+
     def _full_moments(self):
-        """(exp_avg, exp_avg_sq) over the WHOLE flat layout.  Sharded mode: every rank contributes its owned slices (one all-gather per
-        grid chunk; called at checkpoint time only - 2 x the buffer in memory while it lasts)."""
         fg = self.flat_grads
         if not self.sharded:
             return self.exp_avg, self.exp_avg_sq
@@ -197,7 +206,14 @@ class FusedAdam:
 
     def state_dict(self) -> Dict:
         out = {"step_count": self.step_count, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "groups": {}}
-        m, v = self._full_moments()
+        if self.sharded:
+            if self._gathered is None:
+                raise RuntimeError("FusedAdam.state_dict() under the sharded exchange: this rank holds 1 / W of the moments.  Call "
+                                   "gather_moments() on EVERY rank first (a collective - outside the reference's main-process-only checkpoint "
+                                   "guard, engine/trainer.py:277), then state_dict() on the rank that writes")
+            m, v = self._gathered
+        else:
+            m, v = self.exp_avg, self.exp_avg_sq
         for name, g in self.groups.items():
             a, b = g["start"], g["end"]
             out["groups"][name] = {"lr": g["lr"], "lr_init": g["lr_init"], "numel": g["numel"], "span": b - a,
@@ -273,8 +289,15 @@ class Optimizers:
     def scheduler_step_all(self, step: int = 0):
         self.adam.scheduler_step()
 
+    def gather_moments(self) -> None:
+        """Sharded exchange only: the COLLECTIVE half of checkpointing (FusedAdam.gather_moments) - call on every rank before the rank that
+        writes the checkpoint calls state_dict().  A no-op under the all-reduce exchange and on one GPU."""
+        self.adam.gather_moments()
+
     def state_dict(self) -> Dict:
-        """What the trainer stores under "optimizers" (engine/trainer.py:351-360).  One difference from per-group torch.optim.Adam
+        """What the trainer stores under "optimizers" (engine/trainer.py:351-360).  LOCAL: under the sharded exchange it raises unless
+        gather_moments() ran on every rank since the last step (a state_dict() that gathered by itself would deadlock the reference's
+        rank-0-only save_checkpoint).  One difference from per-group torch.optim.Adam
         is documented here rather than hidden: the fused step updates EVERY element of a group, also parameters whose gradient
         is None in torch terms (their flat gradient is the zero zero() left, so moments decay and the bias-corrected update is
         0 while they were never used; once a parameter has been used, torch would freeze its moments in steps that skip it,

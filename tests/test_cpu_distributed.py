@@ -458,7 +458,14 @@ def _shard_worker(rank, world, port, ret, shard):
         exchanged.append(flat.exchanged_numel())
         gathered.append(flat.gathered_bytes())
     opts.wait_parameters()
-    sd = opts.state_dict()  # sharded mode: assembles the full moments from the ranks' slices
+    if shard:
+        try:  # state_dict() is LOCAL - it must refuse rather than start a collective the reference's rank-0-only checkpoint path would hang in
+            opts.state_dict()
+            raise AssertionError("sharded state_dict() without gather_moments() must raise")
+        except RuntimeError as e:
+            assert "gather_moments" in str(e)
+    opts.gather_moments()  # the collective half (every rank); a no-op under the all-reduce exchange
+    sd = opts.state_dict()  # local: no collective inside
     full_m = torch.zeros(flat.flat.numel())
     for name, g in opts.adam.groups.items():
         full_m[g["start"]:g["end"]] = sd["groups"][name]["exp_avg"]
@@ -612,3 +619,27 @@ def test_table_bucket_leaves_from_inside_the_native_backward_world2():
         assert torch.equal(g1_e, g1_n) and torch.equal(g2_e, g2_n)
         # sums over the two ranks: table / weight 1 + 2 = 3, other 3 + 3 = 6 (finish() averages: / 2)
         assert torch.allclose(g1_e[:4096], torch.full((4096,), 1.5)) and torch.allclose(g2_e[:4096], torch.full((4096,), 3.5))
+
+
+def test_forced_single_rank_exchange_protocol_over_gloo():
+    """SDFHIP_FORCE_EXCHANGE=1: a ONE-rank process group runs the whole N > 1 protocol - bucket launches from the hooks,
+    chunk-wise waits, owned-slice Adam, parameter gathers - and must leave the same bits as no exchange.  This is the gloo twin of
+    tests/test_gpu_rccl_single_rank.py::test_rccl_protocol_bit_identical_to_no_exchange (same worker, CPU tensors)."""
+    import json
+    import subprocess
+    import sys
+
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT=str(_free_port()))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SDFHIP_FORCE_EXCHANGE", "SDFHIP_BENCH_EXCHANGE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "rccl_single_rank_worker.py"), "protocol_cpu"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    rep = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rep["backend"] == "gloo"
+    assert rep["params_equal"] == {"shard": True, "allreduce": True} and rep["moments_equal"] == {"shard": True, "allreduce": True}, rep
+    assert rep["table_moved"] > 0.99 and rep["table_tail_untouched"]
+    assert all(c == [0, 0] for c in rep["collectives"]["none"])
+    sh = rep["collectives"]["shard"]
+    assert sh[0][0] == 4 + 2 and sh[-1][0] == 8 + 2 and sh[-1][1] > sh[0][1] > 0, sh
