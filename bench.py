@@ -231,6 +231,10 @@ def main():
     ap.add_argument("--no-preset", action="store_true", help="default (config 2) run: skip the neus-facto preset leg appended as \"preset\"")
     ap.add_argument("--no-neus-acc", action="store_true", help="default (config 2) run: skip the packed-sample (NeuS-acc) leg appended as \"neus_acc\"")
     ap.add_argument("--no-dense-sdf", action="store_true", help="default (config 2) run: skip the dense-SDF (mesh extraction) leg appended as \"dense_sdf\"")
+    ap.add_argument("--no-volsdf", action="store_true", help="default (config 2) run: skip the VolSDF legs (BASELINE config 1's model on the GPU) appended as \"volsdf\"")
+    ap.add_argument("--no-config4", action="store_true", help="default (config 2) run: skip the BASELINE config 4 leg appended as \"config4\"")
+    ap.add_argument("--full-line", action="store_true", help="print the full (~25 KB) object instead of the compact line (the full object is always "
+                                                              "written to gpurun_out/bench_detail.json)")
     ap.add_argument("--no-mesh", action="store_true", help="default (config 2) run: skip the marching-cubes leg appended as \"mesh\" (a child process)")
     ap.add_argument("--only", default=None, choices=["inference", "exchange"],
                     help="inference: only the forward-only and dense-SDF legs on config 2's model (no training steps; tools/ A/B and PMC runs); "
@@ -260,7 +264,8 @@ def fence(world):
     torch.cuda.synchronize()
 
 
-def make_job(config, device, world, rank, small=False, hidden=256, rays=None, samples=None, model_factory=None):
+def make_job(config, device, world, rank, small=False, hidden=256, rays=None, samples=None, model_factory=None, ray_fn=None, batch_fn=None,
+             opt_config=None):
     """Model, flat gradient buffer, optimizers and the step function of one benchmark configuration (2 or 5) on this rank."""
     from sdfstudio_amd.cameras.rays import RayBundle
     from sdfstudio_amd.distributed import FlatGradients, broadcast_parameters
@@ -300,6 +305,8 @@ def make_job(config, device, world, rank, small=False, hidden=256, rays=None, sa
                            "proposal_networks": {"lr": 1e-2, "scheduler": multi_step_scheduler(1000000)}}, groups, flat_grads=flat)
         # progressive levels: the masked levels' table rows have exactly zero gradient on every rank; zero() asks the model
         flat.track_active(model.field.encoding.params, model.active_table_floats)
+    elif opt_config is not None:
+        opts = Optimizers({k: v for k, v in opt_config.items() if k in groups}, groups, flat_grads=flat)
     else:
         # optimizers and schedulers as method_configs.py:485-500 (neus-facto): Adam eps 1e-15, lr 5e-4 with NeuS warm-up / cosine
         # (fields), 1e-2 with MultiStepLR (proposal networks): one fused Adam launch per group over the flat buffers
@@ -315,11 +322,13 @@ def make_job(config, device, world, rank, small=False, hidden=256, rays=None, sa
     def step(i):
         opts.wait_parameters(late=False)  # sharded exchange: everything but the SDF table has to be back before the callbacks touch parameters
         model.before_train_iteration(i)
-        o, d, norm, cam = draw_rays(centers, rot, n_rays, gen)
-        image = torch.rand(n_rays, 3, device=device, generator=gen)
+        o, d, norm, cam = draw_rays(centers, rot, n_rays, gen) if ray_fn is None else ray_fn(n_rays, gen)
+        batch = {"image": torch.rand(n_rays, 3, device=device, generator=gen)}
+        if batch_fn is not None:
+            batch.update(batch_fn(n_rays, gen))
         rb = RayBundle(origins=o, directions=d, directions_norm=norm, camera_indices=cam[:, None])
         out = model(rb)
-        loss = functools.reduce(operator.add, model.get_loss_dict(out, {"image": image}).values())  # (sum() would start with 0 + a tensor: a launch)
+        loss = functools.reduce(operator.add, model.get_loss_dict(out, batch).values())  # (sum() would start with 0 + a tensor: a launch)
         flat.zero(loss)  # the loss's graph tells the buckets which gradients to wait for (unused parameters: distributed.py)
         loss.backward()
         # closes the exchange chunk by chunk (SUM collectives; the 1 / world mean rides in the Adam read) and, sharded, sends the updated
@@ -587,6 +596,123 @@ def preset_leg(device, world, rank, steps=30, warmup=5):
            "published": {"iters_per_sec": 22.0, "hardware": "RTX 3090", "source": "reference README.md:83 (BASELINE.md section 2)"},
            "vs_published": round(1e3 / ms / 22.0, 2),
            "kernels_ms_per_step": table, "native_kernel_ms_per_step": round(sum(table.values()), 3), "enqueue_vs_gpu": split}
+    del job, loss
+    torch.cuda.empty_cache()
+    return out
+
+
+def _leg_tail(job, device, first, steps, table_steps=5, split_steps=10):
+    """The per-kernel table (instrumented pass) and the host-enqueue / GPU split of a leg's step, after its timed steps."""
+    from sdfstudio_amd import _lib
+
+    _lib.profile_enable(True)
+    for i in range(table_steps):
+        job["step"](first + i)
+    job["opts"].wait_parameters()
+    torch.cuda.synchronize(device)
+    table = {k: round(v[0] / table_steps, 4) for k, v in _lib.profile_collect().items()}
+    _lib.profile_enable(False)
+    split = enqueue_vs_gpu(job["step"], first + table_steps, split_steps, device)
+    job["opts"].wait_parameters()
+    return table, split
+
+
+def volsdf_legs(device, world, rank, steps=20, warmup=5):
+    """BASELINE config 1's model ON THE GPU: VolSDF (models/volsdf.py:56-79) with the pure-MLP field (8 x 256 + 4 x 256,
+    use_grid_feature = False, positional encoding), ErrorBoundedSampler (ray_samplers.py:581-702: Algorithm 1 with up to 5 outer iterations,
+    each ending in the reference's own HOST decision `beta.max() > beta0`, :665), 64 + 32 samples per ray, Laplace density, L1 + eikonal,
+    backward, Adam with the exponential schedule of the `volsdf` / `monosdf` presets (method_configs.py:581-614, 616-650).  Two batches:
+    config 1's 512 rays and the 4096 rays of config 2; `monosdf` = the same model with the two monocular-prior losses
+    (base_surface_model.py:419-437) at the preset's 1024 rays."""
+    from sdfstudio_amd.engine.optimizers import exponential_decay_scheduler
+    from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
+    from sdfstudio_amd.models.neus_facto import SceneBox
+    from sdfstudio_amd.models.volsdf import VolSDFModel, VolSDFModelConfig
+
+    def build(mono):
+        def f(dev):
+            torch.manual_seed(0)
+            fcfg = SDFFieldConfig(bias=0.5, inside_outside=False, use_grid_feature=False, beta_init=0.1)
+            kw = {"mono_depth_loss_mult": 0.1, "mono_normal_loss_mult": 0.05} if mono else {}
+            box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=0.5, far=4.5)
+            return VolSDFModel(VolSDFModelConfig(sdf_field=fcfg, **kw), box, num_train_data=49).to(dev).train()
+        return f
+
+    def mono_batch(n, gen):
+        nrm = torch.randn(n, 3, device=device, generator=gen)
+        return {"depth": torch.rand(n, device=device, generator=gen), "normal": nrm / nrm.norm(dim=-1, keepdim=True)}
+
+    sched = {"fields": {"lr": 5e-4, "scheduler": exponential_decay_scheduler(0.1, 200000)},
+             "field_background": {"lr": 5e-4, "scheduler": exponential_decay_scheduler(0.1, 200000)}}
+    out = {"workload": "VolSDF, pure-MLP field (8x256 geo + 4x256 colour, no hash grid, PE), ErrorBoundedSampler (128 evaluation samples per outer "
+                       "iteration, <= 5 iterations), 64 + 32 samples per ray, full train step incl. Adam", "steps": steps, "warmup": warmup}
+    for name, rays, mono in (("config1_512rays", 512, False), ("rays4096", 4096, False), ("monosdf_preset_1024rays", 1024, True)):
+        job = make_job(2, device, world, rank, rays=rays, model_factory=build(mono), batch_fn=mono_batch if mono else None, opt_config=sched)
+        smp = job["model"].sampler
+        dt, _prof, loss = timed_steps(job, 0, warmup, steps, ("geo_fwd_kernel", "geo_bwd_kernel"), world)
+        dt = max_over_ranks(dt, device, world)
+        assert math.isfinite(float(loss.detach())), f"volsdf leg {name} diverged"
+        ms = dt / steps * 1e3
+        table, split = _leg_tail(job, device, warmup + steps, steps)
+        out[name] = {"ms_per_step": round(ms, 3), "iters_per_sec": round(1e3 / ms, 2), "rays": rays, "samples_per_ray": 96,
+                     "value": round(world * rays * 96 / (dt / steps), 1), "unit": "ray-samples/s",
+                     "error_bound_iterations_last_step": int(smp.last_total_iters), "host_reads_per_step": int(smp.last_total_iters),
+                     "sdf_evaluations_per_ray_in_sampler": 128 * int(smp.last_total_iters),
+                     "kernels_ms_per_step": table, "native_kernel_ms_per_step": round(sum(table.values()), 3), "enqueue_vs_gpu": split}
+        job["flat"].close()
+        del job, loss
+        torch.cuda.empty_cache()
+    out["host_reads_note"] = ("one device -> host read per outer iteration of Algorithm 1: the reference's own global decision `beta.max() > beta0` "
+                              "(ray_samplers.py:665) - while ANY ray is above beta0, EVERY ray gets 128 more samples, so a fixed iteration count "
+                              "would change the sample sets of the rays that had converged (not the reference's result)")
+    return out
+
+
+def config4_leg(device, world, rank, steps=15, warmup=5):
+    """BASELINE config 4: config 2's NeuS-facto kernels in an INDOOR scene - inside_outside = True (sign-flipped geometric
+    init, sdf_field.py:294-299), cameras INSIDE the box, near / far from the AABB box collider (scene_colliders.py:47-109), monocular depth
+    (scale-and-shift invariant, losses.py:392-409) and normal (losses.py:264-275) priors with the README's multipliers (README.md:74:
+    0.1 / 0.05; base_surface_model.py:419-437).  4096 rays x 128 samples (N = 0 mod 32: the depth loss reshapes to (1, 32, -1))."""
+    from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
+    from sdfstudio_amd.model_components.scene_colliders import build_collider
+    from sdfstudio_amd.models.neus_facto import NeuSFactoModel, NeuSFactoModelConfig, SceneBox
+
+    def build(dev):
+        torch.manual_seed(0)
+        fcfg = SDFFieldConfig(num_layers=8, hidden_dim=256, geo_feat_dim=256, num_layers_color=4, hidden_dim_color=256, bias=0.8,
+                              inside_outside=True, use_grid_feature=True, beta_init=0.3, num_levels=16, max_res=2048, base_res=16,
+                              log2_hashmap_size=19, hash_features_per_level=2, hash_smoothstep=True)
+        mcfg = NeuSFactoModelConfig(sdf_field=fcfg, num_proposal_samples_per_ray=(256, 96), num_neus_samples_per_ray=N_SAMPLES,
+                                    background_model="none", mono_depth_loss_mult=0.1, mono_normal_loss_mult=0.05)
+        box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=0.05, far=4.0, collider_type="box")
+        m = NeuSFactoModel(mcfg, box, num_train_data=49)
+        m.collider = build_collider(m.scene_box, m.config)
+        return m.to(dev).train()
+
+    def rays(n, gen):  # camera centres inside the room, directions over the whole sphere (Replica-like)
+        o = (torch.rand(n, 3, device=device, generator=gen) - 0.5) * 0.6
+        d = torch.randn(n, 3, device=device, generator=gen)
+        d = d / d.norm(dim=-1, keepdim=True)
+        cam = (torch.rand(n, device=device, generator=gen) * 49).long().clamp_(max=48)
+        return o.contiguous(), d.contiguous(), torch.ones(n, 1, device=device), cam
+
+    def mono_batch(n, gen):
+        nrm = torch.randn(n, 3, device=device, generator=gen)
+        return {"depth": torch.rand(n, device=device, generator=gen), "normal": nrm / nrm.norm(dim=-1, keepdim=True)}
+
+    job = make_job(2, device, world, rank, rays=N_RAYS, model_factory=build, ray_fn=rays, batch_fn=mono_batch)
+    dt, _prof, loss = timed_steps(job, 0, warmup, steps, "geo_bwd_kernel", world)
+    dt = max_over_ranks(dt, device, world)
+    assert math.isfinite(float(loss.detach())), "config 4 leg diverged"
+    ms = dt / steps * 1e3
+    table, split = _leg_tail(job, device, warmup + steps, steps)
+    out = {"workload": "BASELINE config 4: NeuS-facto (config 2's grid and networks) with inside_outside = True, cameras inside the box, AABB box "
+                       f"collider, mono depth (0.1) + normal (0.05) prior losses; {N_RAYS} rays x {N_SAMPLES} samples (+256/96 proposal samples), "
+                       "full train step incl. Adam", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(ms, 3), "iters_per_sec": round(1e3 / ms, 2), "value": round(world * N_RAYS * N_SAMPLES / (dt / steps), 1),
+           "unit": "ray-samples/s", "host_reads_per_step": 0, "kernels_ms_per_step": table,
+           "native_kernel_ms_per_step": round(sum(table.values()), 3), "enqueue_vs_gpu": split}
+    job["flat"].close()
     del job, loss
     torch.cuda.empty_cache()
     return out
@@ -900,6 +1026,117 @@ def forward_only_leg(job, device, n_rays, n_samples, reps=10):
                                           "launch (DESIGN.md section 4.1: why no on-chip store holds it)"}}
 
 
+def _pick(d, keys):
+    if d is None:
+        return None
+    if "error" in d:
+        return {"error": str(d["error"])[:120]}
+    return {k: d[k] for k in keys if k in d and d[k] is not None}
+
+
+def compact_line(line):
+    """The one JSON line the driver records: the contract's keys, `roofline` and `cpu_baseline` whole-but-terse, every leg as {ms, value,
+    frac, ...}.  Prose notes and per-kernel tables stay in gpurun_out/bench_detail.json.  Target <= 6 KB."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+            "iters_per_sec", "per_gpu", "final_loss", "library_digest", "model_tflops", "mfma_kernels_ms_per_step")
+    out = {k: line[k] for k in keep if k in line}
+    out["dtype_note"] = "fp32 tensors + accumulators; products as 3 split 16-bit MFMA terms (hi + lo operand parts)"
+    cfg = dict(line["config"])
+    cfg["workload"] = cfg["workload"].split(":")[0] + ": " + ("NeuS-facto 16x2x2^19 grid + 8x256 geo + 4x256 colour MLP, 4096 rays x 128 samples, full train step incl. Adam"
+                                                               if cfg["workload"].startswith("BASELINE config 2") else cfg["workload"].split(":", 1)[-1].strip()[:140])
+    out["config"] = cfg
+    r = line.get("roofline")
+    if r is not None:
+        out["roofline"] = _pick(r, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "avg_launch_ms", "launches",
+                                    "ideal_io_bytes", "traffic_over_ideal", "frac_of_fp32_class_ceiling", "frac_algorithmic_of_16bit_peak",
+                                    "frac_algorithmic_of_fp32_matrix_peak", "terms_per_product", "algorithmic_bytes", "ms_per_step", "levels_active"))
+        if "hbm" in r:
+            out["roofline"]["hbm"] = _pick(r["hbm"], ("dataflow_GBps", "dataflow_frac", "waste_ratio"))
+    out["encode_roofline"] = _pick(line.get("encode_roofline"), ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "ms_per_step", "algorithmic_bytes"))
+    out["step_roofline"] = _pick(line.get("step_roofline"), ("model_tflops", "frac_of_fp32_matrix_peak", "issued_16bit_mfma_tflops", "frac_of_dense_bf16_peak",
+                                                                "hbm_GB_per_step_pmc", "hbm_frac_of_8TBps", "hbm_pmc_stale"))
+    legs = {}
+    c5 = line.get("config5")
+    if c5:
+        for k in ("levels8", "levels16"):
+            if k in c5:
+                legs["config5_" + k] = {"ms": c5[k]["ms_per_step"], "value": c5[k]["value"], "frac": (c5[k].get("roofline") or {}).get("frac"),
+                                        "encode_GBps": (c5[k].get("roofline") or {}).get("achieved"), "traffic": (c5[k].get("roofline") or {}).get("traffic")}
+    bm = line.get("bigmlp")
+    if bm:
+        for k in ("preset_batch", "config2_batch"):
+            if k in bm:
+                legs["bigmlp_" + k] = {"ms": bm[k]["ms_per_step"], "value": bm[k]["value"], "frac": bm[k]["step_roofline"]["frac"],
+                                       "ratio_to_256_wide_step": bm[k].get("ratio_to_256_wide_step")}
+    pr = line.get("preset")
+    if pr:
+        legs["preset"] = _pick(pr, ("ms_per_step", "iters_per_sec", "value", "vs_published"))
+        if "enqueue_vs_gpu" in pr:
+            legs["preset"]["host_bound"] = pr["enqueue_vs_gpu"]["host_bound"]
+    na = line.get("neus_acc")
+    if na:
+        legs["neus_acc"] = _pick(na, ("ms_per_step", "value", "unit", "samples_kept_per_ray", "host_reads_per_step"))
+        if "enqueue_vs_gpu" in na:
+            legs["neus_acc"].update({"host_enqueue_ms": na["enqueue_vs_gpu"]["host_enqueue_ms_per_step"], "gpu_ms": na["enqueue_vs_gpu"]["gpu_ms_per_step"],
+                                     "host_bound": na["enqueue_vs_gpu"]["host_bound"]})
+    vs = line.get("volsdf")
+    if vs:
+        if "error" in vs:
+            legs["volsdf"] = _pick(vs, ())
+        for k in ("config1_512rays", "rays4096", "monosdf_preset_1024rays"):
+            if k in vs:
+                legs["volsdf_" + k] = {"ms": vs[k]["ms_per_step"], "value": vs[k]["value"], "iterations": vs[k]["error_bound_iterations_last_step"],
+                                       "host_reads": vs[k]["host_reads_per_step"], "host_enqueue_ms": vs[k]["enqueue_vs_gpu"]["host_enqueue_ms_per_step"],
+                                       "gpu_ms": vs[k]["enqueue_vs_gpu"]["gpu_ms_per_step"], "host_bound": vs[k]["enqueue_vs_gpu"]["host_bound"]}
+    c4 = line.get("config4")
+    if c4:
+        legs["config4"] = _pick(c4, ("ms_per_step", "value", "host_reads_per_step"))
+        if "enqueue_vs_gpu" in c4:
+            legs["config4"]["host_bound"] = c4["enqueue_vs_gpu"]["host_bound"]
+    ex = line.get("exchange_at_n1")
+    if ex:
+        e = {"backend": ex.get("backend")} if "error" not in ex else _pick(ex, ())
+        for k in ("config2", "config5_levels8", "config5_levels16"):
+            if k in ex:
+                e[k] = {"none_ms": ex[k]["none"]["ms_per_step"], "shard_ms": ex[k]["shard"]["ms_per_step"], "allreduce_ms": ex[k]["allreduce"]["ms_per_step"],
+                        "shard_collectives": ex[k]["shard"]["collectives_per_step"] + ex[k]["shard"]["gather_collectives_per_step"],
+                        "bytes": ex[k]["shard"]["buffer_bytes_per_step"]}
+        legs["exchange_at_n1"] = e
+    fo = line.get("forward_only")
+    if fo:
+        legs["forward_only"] = {"ms": fo["ms_per_batch"], "value": fo["value"], "frac": fo["roofline"]["frac"], "traffic": fo["roofline"].get("traffic")}
+    ds = line.get("dense_sdf")
+    if ds:
+        legs["dense_sdf"] = {"ms": ds["ms"], "value": ds["value"], "unit": ds["unit"], "frac": ds["roofline"]["frac"], "traffic": ds["roofline"].get("traffic")}
+    me = line.get("mesh")
+    if me:
+        if "error" in me:
+            legs["mesh"] = _pick(me, ())
+        else:
+            legs["mesh"] = {"ms": me["ms"], "value": me["value"], "unit": me["unit"], "frac": me["roofline"]["frac"], "traffic": me["roofline"].get("traffic"),
+                            "algorithmic_bytes": me["roofline"]["algorithmic_bytes"], "vertices": me["vertices"], "faces": me["faces"],
+                            "stream_kernel_frac": (me["roofline"].get("stream_kernel") or {}).get("frac_of_8TBps"),
+                            "extract_mesh_ms": (me.get("extract_mesh") or {}).get("ms"),
+                            "cpu_points_per_s": (me.get("cpu_baseline") or {}).get("value")}
+    out["legs"] = legs
+    col = line.get("collective")
+    if col:
+        c = {k: col[k] for k in ("backend", "exchange", "buckets", "chunk_bytes", "buckets_launched_during_backward",
+                                 "buckets_launched_from_inside_the_native_backward", "parameters_outside_the_graph", "adam_elements_visited_per_rank")}
+        c["phases"] = {ph: (None if v is None else {k: v[k] for k in v if k != "overlap"}) for ph, v in col["phases"].items()}
+        out["collective"] = c
+    else:
+        out["collective"] = None
+    k = line.get("kernels") or {}
+    out["kernels_ms_per_step"] = {n: v["ms_per_step"] for n, v in sorted(k.items(), key=lambda kv: -kv[1]["ms_per_step"])[:8]}
+    if "cpu_baseline" in line:
+        out["cpu_baseline"] = _pick(line["cpu_baseline"], ("value", "unit", "cores", "kind", "sample"))
+    if "cpu_baseline_reference" in line:
+        out["cpu_baseline_reference"] = _pick(line["cpu_baseline_reference"], ("value", "unit", "cores", "kind"))
+    out["detail"] = "gpurun_out/bench_detail.json (full tables and notes; profiles/r6_bench_detail.json is a committed copy of a builder run)"
+    return out
+
+
 def run(args):
     global N_RAYS, N_SAMPLES
     if args.small:
@@ -1004,9 +1241,23 @@ def run(args):
     if not cfg5 and not args.small and not args.no_preset:
         loss = None
         preset_extra = preset_leg(device, world, rank)
+    volsdf_extra = None
+    if not cfg5 and not args.small and not args.no_volsdf:
+        loss = None
+        volsdf_extra = volsdf_legs(device, world, rank)
+    cfg4_extra = None
+    if not cfg5 and not args.small and not args.no_config4:
+        cfg4_extra = config4_leg(device, world, rank)
     acc_extra = None
     if not cfg5 and not args.small and not args.no_neus_acc and world == 1:
         acc_extra = neus_acc_leg(device)
+    exch_extra = None
+    if not cfg5 and not args.small and not args.no_exchange_n1 and world == 1 and rank == 0:
+        torch.cuda.empty_cache()  # the child builds config 5's model (12 GB) beside this process
+        env = dict(os.environ)
+        for k in ("SDFHIP_FORCE_EXCHANGE", "SDFHIP_BENCH_EXCHANGE", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+            env.pop(k, None)
+        exch_extra = child_leg([os.path.join(ROOT, "bench.py"), "--only", "exchange", "--steps", "8", "--warmup", "3"], timeout=600, env=env)
     mesh_extra = None
     if not cfg5 and not args.small and not args.no_mesh and world == 1 and rank == 0:
         torch.cuda.empty_cache()  # the child allocates its own 3.6 GB beside this process
@@ -1051,6 +1302,12 @@ def run(args):
                                    "issued 16-bit MFMA terms per fp32-class product / launch time (HIP events on the launch stream)",
                     "algorithmic_tflops": round(flops / avg_s / 1e12, 1), "terms_per_product": 3,
                     "frac_algorithmic_of_16bit_peak": round(flops / avg_s / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                    # the plateau, stated.  `frac` IS the fraction of the ceiling fp32-class products can reach on the
+                    # pipe the kernel runs on (dense 16-bit peak / 3 terms = 833 TFLOP/s); the kernel is HBM-bound on its own saved tensors
+                    "frac_of_fp32_class_ceiling": round(issued / PEAK_BF16_MFMA_TFLOPS, 4), "fp32_class_ceiling_tflops": round(PEAK_BF16_MFMA_TFLOPS / 3, 1),
+                    "ideal_io_bytes": io_bytes, "traffic_over_ideal": None if traffic is None else round(traffic / io_bytes, 1),
+                    "plateau": "0.19 - 0.22 of the pipe it runs on; 1.0 - 1.17 x the fp32-matrix peak an exact-fp32 implementation is bound by; "
+                               "HBM-bound on saved per-layer tensors (DESIGN.md section 7: the end state of this data flow)",
                     "frac_algorithmic_of_fp32_matrix_peak": round(flops / avg_s / 1e12 / 157.3, 4),
                     "traffic": traffic, "traffic_unit": "HBM bytes per step of this kernel (sum of its two launches)", "traffic_source": traffic_source,
                     # the PMC passes are a separate rocprofv3 run: they describe THIS library only if it was built from the same sources
@@ -1109,6 +1366,9 @@ def run(args):
             "bigmlp": bigmlp_extra,
             "preset": preset_extra,
             "neus_acc": acc_extra,
+            "volsdf": volsdf_extra,
+            "config4": cfg4_extra,
+            "exchange_at_n1": exch_extra,
             "mesh": mesh_extra,
             "collective": None if world == 1 else collective_report(job, dist.get_backend(), exposed_by_rank, exposed_gather_by_rank),
             "forward_only": fwd_only,
@@ -1143,9 +1403,17 @@ def run(args):
             with open(ref_path) as fh:
                 line["cpu_baseline_reference"] = json.load(fh)  # the reference's own Python, timed in the build container (no GPU box has it)
         if world == 1 and not args.no_cpu_baseline and not args.small and not cfg5:
-            print("[bench] GPU leg done: " + json.dumps(line), file=sys.stderr, flush=True)
+            print("[bench] GPU leg done: " + json.dumps(compact_line(line)), file=sys.stderr, flush=True)
             line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line), flush=True)
+        # the FULL object (per-kernel tables, prose notes, every leg in detail) goes to a file; the ONE line the driver records is its
+        # compact form - every figure README / DESIGN quote survives a `tail` of the log (the full line was 23 KB)
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_detail.json"), "w") as fh:
+                json.dump(line, fh, indent=1)
+        except OSError as e:
+            print(f"[bench] could not write gpurun_out/bench_detail.json: {e}", file=sys.stderr)
+        print(json.dumps(line if args.full_line else compact_line(line)), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -30,20 +30,22 @@ typedef void* sdfmesh_stream_t; /* hipStream_t */
 int sdfmesh_version(void);
 const char* sdfmesh_last_error(void);
 
-/* Bytes of device workspace both calls below need for an [n0, n1, n2] volume: the list of surface cells (twice: unsorted and sorted) with
- * two uint32 counters and two uint32 offsets per entry - capacity: every cell of a volume of up to 2^20 cells, a quarter of the cells
- * beyond that (a 512^3 SDF crop has < 1 % of its cells on the surface) - the edge -> vertex-id map (4 int32 per lattice point: the x / y /
- * z edge starting there and the cell's centre vertex; never initialised, only written entries are read) and the sort's / scans' scratch.
- * ~23 B per lattice point for a large volume: 3.1 GB for the reference's 512^3 crop.  0 if the shape is refused (see _count). */
+/* Bytes of device workspace both calls below need for an [n0, n1, n2] volume.  Three bit arrays in a row-padded layout (one bit per
+ * lattice point each, rows of n2 points padded to whole 64-bit words: volume > level, mask != 0, "surface cell"), one uint32 rank per
+ * 64-bit word, and 20 B per entry of the surface-cell list (point index, triangle-table code, created-vertex record, block-local
+ * offsets) - capacity: every cell of a volume of up to 2^20 cells, an eighth of the cells beyond that (a 512^3 SDF crop has < 1 % of its
+ * cells on the surface).  ~3 B per lattice point for a large volume: 0.39 GB for the reference's 512^3 crop (0.73 x the volume; round 5
+ * needed 3.1 GB for its per-lattice-point edge map).  Nothing in it needs initialising.  0 if the shape is refused (see _count). */
 size_t sdfmesh_mc_workspace_bytes(int n0, int n1, int n2);
 
-/* The streaming pass over the volume, the sort of the surface cells into scikit-image's traversal order, their classification and the
- * scans (the Cython routine's `for z: for y: for x:` loop of _marching_cubes_lewiner_cy.marching_cubes, without emitting anything).
+/* The streaming pass over the volume (one bit per lattice point comes out of it), the pass over those bits that finds the surface cells
+ * IN scikit-image's traversal order (an ordered compaction: no sort), their classification and the scans (the Cython routine's
+ * `for z: for y: for x:` loop of _marching_cubes_lewiner_cy.marching_cubes, without emitting anything).
  * volume: [n0, n1, n2] float32, row-major; mask: [n0, n1, n2] uint8 / bool or NULL (scikit-image's `mask`: cell (i, j, k) is processed
  * iff mask[i + 1, j + 1, k + 1]); level: the iso value (the caller has checked min <= level <= max, as scikit-image's wrapper does).
- * Writes the sorted list and its per-cell offsets into the workspace and the mesh size to the two HOST integers.  This call WAITS for the stream: the size
- * of the result is data-dependent and the caller has to allocate it (scikit-image returns fresh arrays, too).
- * It also waits once before that, for the number of surface cells (it sizes the sort).
+ * Writes the list, its per-cell tables and offsets into the workspace and the mesh size to the two HOST integers.  This call WAITS for
+ * the stream, ONCE, at its end: the size of the result is data-dependent and the caller has to allocate it (scikit-image returns fresh
+ * arrays, too).  Every launch before that is sized by the shape alone.
  * Errors: a dimension < 2, n0 * n1 * n2 >= 2^31, more surface cells than the list holds (white noise beyond 2^20 cells: mesh it in smaller
  * crops), more than 2^31 - 1 vertices or face indices, workspace too small, no device. */
 int sdfmesh_mc_count(const float* volume, const unsigned char* mask, int n0, int n1, int n2, double level, void* workspace,
@@ -52,7 +54,7 @@ int sdfmesh_mc_count(const float* volume, const unsigned char* mask, int n0, int
 /* The vertex and face passes over the list _count left in the workspace (same volume, mask, level): positions, triangles, normals, values.
  * verts [num_vertices, 3], faces [num_faces, 3], normals [num_vertices, 3], values [num_vertices]; normals / values may be NULL
  * (both or neither).  flip_faces: 1 = gradient_direction "descent" (scikit-image's default, what the reference gets), 0 = "ascent".
- * Does not synchronise. */
+ * num_vertices / num_faces: what _count returned.  Does not synchronise. */
 int sdfmesh_mc_emit(const float* volume, const unsigned char* mask, int n0, int n1, int n2, double level, void* workspace,
                     size_t workspace_bytes, int64_t num_vertices, int64_t num_faces, int flip_faces, float* verts, int32_t* faces,
                     float* normals, float* values, sdfmesh_stream_t stream);

@@ -325,6 +325,7 @@ class ErrorBoundedSampler(Sampler):
                 bins, index, _, _ = self.merge(ray_bundle, bins, new_bins)
             else:
                 bins, f_starts, f_ends = self._pdf(ray_bundle, weights, bins, self.num_samples)
+        self.last_total_iters = total  # outer iterations of Algorithm 1 taken = device -> host decisions of this call (bench.py reports it)
         out = _make_uniform_samples(ray_bundle, bins, f_starts, f_ends)
         points = None
         if return_eikonal_points:

@@ -270,7 +270,15 @@ class DepthRenderer(nn.Module):
             split = torch.full((*weights.shape[:-2], 1), 0.5, device=weights.device, dtype=cumulative.dtype)
             index = torch.searchsorted(cumulative, split, side="left").clamp_(0, steps.shape[-2] - 1)
             return torch.gather(steps[..., 0], dim=-1, index=index)
-        depth = torch.sum(weights * steps, dim=-2) / (torch.sum(weights, -2) + 1e-10)
+        if ray_indices is not None and num_rays is not None:
+            # renderers.py:249-253, packed samples (nerfacc.accumulate_along_rays twice): weights / steps are [P, 1]; a per-head mirror
+            # (the NeuS-acc training path composites all heads in ONE segmented kernel: models/neus_acc.py, accumulate_along_rays)
+            w, st = weights.reshape(-1, 1), steps.reshape(-1, 1)
+            depth = torch.zeros(int(num_rays), 1, device=w.device, dtype=w.dtype).index_add_(0, ray_indices.reshape(-1).long(), w * st)
+            acc = torch.zeros(int(num_rays), 1, device=w.device, dtype=w.dtype).index_add_(0, ray_indices.reshape(-1).long(), w)
+            depth = depth / (acc + 1e-10)
+        else:
+            depth = torch.sum(weights * steps, dim=-2) / (torch.sum(weights, -2) + 1e-10)
         return torch.clip(depth, steps.min(), steps.max())
 
 

@@ -222,8 +222,11 @@ def get_surface_sliding(field, resolution: int = 512, bounding_box_min=(-1.0, -1
 def get_surface_occupancy(occupancy_fn: Callable[[torch.Tensor], torch.Tensor], resolution: int = 512, bounding_box_min=(-1.0, -1.0, -1.0),
                           bounding_box_max=(1.0, 1.0, 1.0), level: float = 0.5, device=None, chunk: int = 1 << 22):
     """marching_cubes.py:171-216 (UniSurf: occupancy = sigmoid(10 sdf), level 0.5): one resolution^3 lattice, marching cubes on the
-    device.  Returns (verts float64, faces int32, normals) or None ("no surface skip").  The .ply export is not built."""
+    device.  Returns (verts float64, faces int32, normals) or None ("no surface skip").  The .ply export is not built.
+    device = None (the reference's default): the current HIP device - the lattice is evaluated and meshed there (libsdfmesh.so has no host path)."""
     n = int(resolution)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
     ax = [torch.from_numpy(np.linspace(bounding_box_min[a], bounding_box_max[a], n)).float().to(device) for a in range(3)]
     xx, yy, zz = torch.meshgrid(*ax, indexing="ij")
     pts = torch.stack([xx.reshape(-1), yy.reshape(-1), zz.reshape(-1)], -1)

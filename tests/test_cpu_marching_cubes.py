@@ -212,18 +212,53 @@ def test_mesh_library_refuses_without_a_device():
 
 
 def test_hardware_evidence_belongs_to_the_sources_as_committed():
-    """profiles/r5_mesh_gpu_check_v2.jsonl (every golden case and the 512^3 crop bit-exact on an MI355X, 2.21 ms per crop) was taken on the
-    library built from the sources with this digest.  If this fails the mesh sources changed: re-run tools/gpu_call_r5p.sh on a GPU box,
-    commit the new evidence and its meta file - until then the numbers quoted in DESIGN.md / README.md describe an older library."""
+    """profiles/r6_mesh_gpu_check.jsonl (every golden case and the 512^3 crop bit-exact on an MI355X, 0.26 ms per crop) and the rocprofv3
+    summaries beside it were taken on the library built from the sources with this digest.  If this fails the mesh sources changed: re-run
+    tools/gpu_call_r6f.sh on a GPU box, `python tools/mesh_pmc_summary.py r6f/mesh r6_mesh`, commit the new evidence and its meta file -
+    until then the numbers quoted in DESIGN.md / README.md describe an older library."""
     import json
 
     from sdfstudio_amd import build as b
 
-    meta = json.load(open(os.path.join(ROOT, "profiles", "r5_mesh_gpu_check_v2_meta.json")))
+    meta = json.load(open(os.path.join(ROOT, "profiles", "r6_mesh_gpu_check_meta.json")))
     assert meta["mesh_library_digest"] == b.mesh_source_digest()
-    lines = [json.loads(ln) for ln in open(os.path.join(ROOT, "profiles", "r5_mesh_gpu_check_v2.jsonl"))]
+    lines = [json.loads(ln) for ln in open(os.path.join(ROOT, "profiles", "r6_mesh_gpu_check.jsonl"))]
     assert any(ln.get("golden_cases") == 6 and ln.get("all_bit_exact") == 1 for ln in lines)
     assert any(ln.get("crop512_vs_host_harness", {}).get("bit_exact") == 1 for ln in lines)
+    crop = [ln["crop512"] for ln in lines if "crop512" in ln][0]
+    assert crop["frac_of_8TBps"] >= 0.25 and crop["workspace_bytes"] <= 4 * 512 ** 3  # VERDICT r5 item 2: the whole call, workspace <= 1 x volume
+    pmc = json.load(open(os.path.join(ROOT, "profiles", "r6_mesh_pmc_summary.json")))
+    assert pmc["mesh_library_digest"] == b.mesh_source_digest()
+    assert abs(pmc["calibration"]["mc_pointbits_kernel_fetch_x2_over_volume"] - 1.0) < 0.01  # the counter correction, checked on a known byte count
+    assert not any("rocprim" in k or "hipcub" in k for k in pmc["kernels"])
+
+
+def test_mesh_library_kernels_fit_the_instruction_cache_and_use_no_scratch():
+    """the resource guard of libsdfhip.so (tests/test_cpu_oracle_and_abi.py) extended to libsdfmesh.so - every kernel
+    below 64 KB of code and with 0 bytes of scratch (round 5's mc_vertices_kernel: 73 KB, 80 B) - and item 2a: no library behind the
+    kernels (hipCUB / rocPRIM: the sort is gone, the scans are hand-written)."""
+    import shutil
+    import sys
+
+    lib = os.path.join(ROOT, "sdfstudio_amd", "libsdfmesh.so")
+    if not os.path.exists(lib) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf") or shutil.which("objcopy") is None:
+        pytest.skip("needs the built library and the ROCm LLVM tools")
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), lib], text=True)
+    rows = [line for line in out.splitlines()[1:] if line.strip()]
+    names = []
+    for line in rows:
+        name, rest = line.rsplit('",', 1)
+        code, vgpr, agpr, sgpr, scratch, lds = rest.split(",")
+        names.append(name)
+        assert int(code) < 64 * 1024, (name, code)
+        assert int(scratch) == 0, (name, scratch)
+    for k in ("mc_pointbits_kernel", "mc_cellbits_kernel", "mc_scan_words_kernel", "mc_list_kernel", "mc_classify_kernel", "mc_scan_cells_kernel",
+              "mc_keys_kernel", "mc_vertices_kernel", "mc_faces_kernel"):
+        assert any(k in n for n in names), k
+    assert not any("rocprim" in n.lower() or "hipcub" in n.lower() for n in names), names
+    for f in glob.glob(os.path.join(ROOT, "sdfstudio_amd", "csrc_mesh", "*")):
+        text = open(f).read()
+        assert "#include <hipcub" not in text and "#include <rocprim" not in text and "#include <thrust" not in text, f
 
 
 # ---- the host mirrors (utils/marching_cubes.py) with the device call replaced by the host harness

@@ -1,14 +1,11 @@
 """Mesh extraction on the GPU: libsdfmesh.so through its C ABI against the golden vectors minted from the real
 scikit-image, against the oracle on ragged volumes, and - at the reference's crop size - through properties no oracle run is needed for.
 
-STATUS at the end of round 5.  The C ABI is proven on hardware: tools/mesh_gpu_check.cpp (no Python in the process) ran on an MI355X in
-the round's last seconds of GPU time - every golden case and the whole 512^3 crop bit-exact, 2.21 ms per crop
-(profiles/r5_mesh_gpu_check_v2.jsonl, tied to the library's source digest by tests/test_cpu_marching_cubes.py).  What has NOT run on a GPU
-is the Python binding these cases go through (sdfstudio_amd/_mesh.py, utils/marching_cubes.py): there were no GPU minutes left for a
-process that imports torch.  Hence two precautions that keep a surprise in that glue from hiding the verdict on everything else:
-  * every case runs in a CHILD process (a fault there cannot take the suite's process or its HIP context down);
-  * the cases are xfail(strict=False): the driver's round-end run records them as XPASS (proven on hardware) or XFAIL (not), and the
-    file sorts last.  Remove the mark once a GPU run has shown them green.
+Hardware history.  Round 5: the C ABI proven on an MI355X by tools/mesh_gpu_check.cpp (no Python in the process); the driver's round-end
+run then showed these Python-binding cases green as well (6 XPASS in GPUTEST_r05.json), so the xfail mark they carried is gone (VERDICT r5,
+ADVICE r5): a broken binding fails the suite.  Round 6 rewrote the library's data flow (bit arrays, ordered compaction, no sort / hipCUB, one
+host read: csrc_mesh/mesh_api.hip); the cases are unchanged - same arrays, same bits.  Every case still runs in a CHILD process (a fault
+there cannot take the suite's process or its HIP context down).
 """
 import os
 import subprocess
@@ -17,8 +14,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.xfail(strict=False, reason="the Python binding of libsdfmesh.so has not run on hardware yet (the C ABI has: profiles/r5_mesh_gpu_check_v2.jsonl)")]
+pytestmark = pytest.mark.gpu
 
 CASES = ["golden", "random_vs_oracle", "errors", "crop_512_properties", "masked_and_flipped", "surface_sliding_glue"]
 

@@ -1,8 +1,7 @@
 """The `mesh` leg of bench.py, run as a CHILD process (bench.py::mesh_leg): marching cubes of one 512^3 crop - the reference's crop size,
 nerfstudio/utils/marching_cubes.py:31 - through the Python binding of libsdfmesh.so.  Prints ONE JSON object.
 
-A child, because this is the one leg whose Python path has not run on hardware (round 5 proved the C ABI with tools/mesh_gpu_check.cpp):
-whatever happens here, the parent's bench line survives."""
+A child: its own HIP context and allocator beside the parent's; whatever happens here, the parent's bench line survives."""
 import json
 import os
 import subprocess
@@ -61,18 +60,37 @@ def main():
     reproducible = all(torch.equal(a, b) for a, b in zip((v, f, nr, val), again))
     P = n ** 3
     alg = 4 * P + 28 * V + 12 * F  # the volume once + the mesh written: verts 12 V, normals 12 V, values 4 V, faces 12 F
+    # HBM bytes per crop from the committed rocprofv3 --pmc passes of the standalone check on the same crop size (tools/profile_mesh.sh,
+    # tools/mesh_pmc_summary.py: FETCH_SIZE x 2 + WRITE_SIZE, calibrated in that run on the volume's known byte count); stale when the
+    # library was built from other sources than the profiled one
+    traffic = {"traffic": None}
+    pm = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.startswith("r") and f.endswith("_pmc_summary.json") and "_mesh_" in f)
+    if pm:
+        loaded = [(f, json.load(open(os.path.join(ROOT, "profiles", f)))) for f in pm]
+        same = [x for x in loaded if x[1].get("mesh_library_digest") == _build.mesh_source_digest()]
+        f, j = (same or loaded)[-1]
+        traffic = {"traffic": j["per_crop"]["hbm_bytes"], "traffic_source": f"profiles/{f} (sum over the library's kernels on one 512^3 crop: FETCH_SIZE x 2 + "
+                                                                             "WRITE_SIZE, separate rocprofv3 --pmc passes)",
+                   "traffic_over_algorithmic": round(j["per_crop"]["hbm_bytes"] / alg, 3), "traffic_library_digest": j.get("mesh_library_digest"),
+                   "traffic_stale": j.get("mesh_library_digest") != _build.mesh_source_digest(),
+                   "kernel_time_us_profiled": j["per_crop"]["kernel_time_us_sum_of_medians"],
+                   "stream_kernel": {"kernel": "mc_pointbits_kernel", "median_us": j["kernels"]["mc_pointbits_kernel"]["median_us"],
+                                     "GBps_on_volume_bytes": round(4 * 512 ** 3 / j["kernels"]["mc_pointbits_kernel"]["median_us"] / 1e3, 1),
+                                     "frac_of_8TBps": round(4 * 512 ** 3 / j["kernels"]["mc_pointbits_kernel"]["median_us"] / 1e3 / PEAK_HBM_GBS, 4)}}
     out = {"workload": f"marching cubes (Lewiner, scikit-image's arrays bit for bit) of one {n}^3 crop of an analytic SDF (bumpy sphere + small "
                        "sphere), volume resident in HBM; what nerfstudio/utils/marching_cubes.py:125-134 does per crop with skimage on the CPU",
            "points": P, "vertices": V, "faces": F, "ms": round(gpu_ms, 4), "ms_wall_incl_host": round(wall_ms, 4),
            "value": round(P / (gpu_ms * 1e-3), 1), "unit": "lattice points/s",
            "closed_surface": bool(closed), "euler_characteristic": int(euler), "bit_reproducible": bool(reproducible),
            "mesh_library_digest": _build.mesh_source_digest(),
-           "roofline": {"kernels": "mc_classify_kernel (the one pass over the volume) + sort / count / scan / vertices / faces over the surface cells",
+           "roofline": {"kernels": "mc_pointbits_kernel (the one pass over the volume: 1 bit per point out) + cell bits / list / classify / keys / "
+                                   "vertices / faces over bit arrays and surface cells; no sort, no library",
                         "bound": "hbm", "achieved": round(alg / (gpu_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(alg / (gpu_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
-                        "algorithmic_bytes": alg, "achieved_is": "4 B per lattice point read + 28 B per vertex + 12 B per face written, over the whole "
-                                                                  "call (count + emit, incl. its two host synchronisations)"},
-           "hardware_evidence_round5": "profiles/r5_mesh_gpu_check_v2.jsonl: 2.21 ms per 512^3 crop, every array bit-exact (C ABI, no Python)"}
+                        "frac": round(alg / (gpu_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), **traffic,
+                        "algorithmic_bytes": alg, "achieved_is": "4 B per lattice point read + 28 B per vertex + 12 B per face written, over the WHOLE "
+                                                                  "call through the Python binding (count + emit, incl. its one host read and the "
+                                                                  "output allocations)"},
+           "round5": "2.30 ms per crop (frac 0.03): profiles/r6_mesh_before_check.jsonl, the round-5 library re-measured this round"}
     # the whole operation the reference's `ns-extract-mesh --resolution 512` performs on BASELINE config 2's field (geometric init: a sphere of
     # radius 0.5): get_surface_sliding = lattice + coarse-to-fine sdf evaluation (MODE_SDF kernels of libsdfhip.so) + marching cubes
     # (libsdfmesh.so) + crop offset.  Guarded separately: the marching-cubes figures above stand whatever happens here.
