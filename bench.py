@@ -293,7 +293,7 @@ def make_job(config, device, world, rank, small=False, hidden=256, rays=None, sa
         flat = FlatGradients(params, buckets=buckets, shard=True, late_buckets=late)
         if os.environ.get("SDFHIP_BENCH_EARLY_TABLE", "1") == "1":
             # the SDF field's table leaves from INSIDE the field's backward, behind the scatter and beside the weight-gradient GEMMs
-            flat.launch_from_native(model.field.encoding.params)
+            flat.launch_from_native(model.field.encoding.params, model.field)
     else:
         flat = FlatGradients([p for g in groups.values() for p in g], buckets=list(groups.values()))
     flat.time_waits = exchanging
@@ -538,20 +538,33 @@ def bigmlp_legs(device, world, rank, ms_config2, steps=8, warmup=3):
 
 
 def enqueue_vs_gpu(step_fn, first, steps, device):
-    """Host time to ENQUEUE `steps` training steps (no synchronisation inside) against the GPU time they take (events around the run):
-    when the first is not clearly below the second, the step is launch / host bound (tools/enqueue_vs_gpu.py, inside the bench)."""
+    """Is the step HOST bound?  Two measurements.  (a) From an IDLE GPU (synchronised first), the host time to enqueue ONE step, median of 3:
+    with no device -> host read inside the step this is pure launch overhead and must sit well below the step's GPU time; a read inside the
+    step shows up as the GPU time in front of it.  `host_bound` = this time exceeds 0.9 x the GPU time of a step.  (b) The steady state:
+    host time to enqueue `steps` steps back to back against their GPU time.  (b) alone cannot tell: once the GPU is the bottleneck the HIP
+    runtime throttles a host that has run ahead (bounded queue of in-flight dispatches), so host ~ GPU there for every long step - config 2's
+    22 ms step reads 20 ms "host" in (b) and 3 ms in (a)."""
+    idle = []
+    for i in range(3):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        step_fn(first + i)
+        idle.append(time.perf_counter() - t0)
     torch.cuda.synchronize(device)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     t0 = time.perf_counter()
     for i in range(steps):
-        step_fn(first + i)
+        step_fn(first + 3 + i)
     host = time.perf_counter() - t0
     e1.record()
     torch.cuda.synchronize(device)
     wall = time.perf_counter() - t0
-    return {"host_enqueue_ms_per_step": round(host / steps * 1e3, 3), "gpu_ms_per_step": round(e0.elapsed_time(e1) / steps, 3),
-            "wall_ms_per_step": round(wall / steps * 1e3, 3), "host_bound": host > 0.9 * wall}
+    gpu_ms = e0.elapsed_time(e1) / steps
+    one = sorted(idle)[1] * 1e3
+    return {"host_enqueue_ms_one_step_from_idle": round(one, 3), "gpu_ms_per_step": round(gpu_ms, 3),
+            "host_enqueue_ms_per_step": round(host / steps * 1e3, 3), "wall_ms_per_step": round(wall / steps * 1e3, 3),
+            "host_bound": one > 0.9 * gpu_ms, "host_over_gpu": round(one / gpu_ms, 3)}
 
 
 def preset_leg(device, world, rank, steps=30, warmup=5):
@@ -1053,6 +1066,8 @@ def compact_line(line):
         if "hbm" in r:
             out["roofline"]["hbm"] = _pick(r["hbm"], ("dataflow_GBps", "dataflow_frac", "waste_ratio"))
     out["encode_roofline"] = _pick(line.get("encode_roofline"), ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "ms_per_step", "algorithmic_bytes"))
+    if line.get("enqueue_vs_gpu"):
+        out["enqueue_vs_gpu"] = _pick(line["enqueue_vs_gpu"], ("host_enqueue_ms_one_step_from_idle", "gpu_ms_per_step", "host_bound"))
     out["step_roofline"] = _pick(line.get("step_roofline"), ("model_tflops", "frac_of_fp32_matrix_peak", "issued_16bit_mfma_tflops", "frac_of_dense_bf16_peak",
                                                                 "hbm_GB_per_step_pmc", "hbm_frac_of_8TBps", "hbm_pmc_stale"))
     legs = {}
@@ -1072,12 +1087,12 @@ def compact_line(line):
     if pr:
         legs["preset"] = _pick(pr, ("ms_per_step", "iters_per_sec", "value", "vs_published"))
         if "enqueue_vs_gpu" in pr:
-            legs["preset"]["host_bound"] = pr["enqueue_vs_gpu"]["host_bound"]
+            legs["preset"].update({"host_enqueue_ms": pr["enqueue_vs_gpu"]["host_enqueue_ms_one_step_from_idle"], "host_bound": pr["enqueue_vs_gpu"]["host_bound"]})
     na = line.get("neus_acc")
     if na:
         legs["neus_acc"] = _pick(na, ("ms_per_step", "value", "unit", "samples_kept_per_ray", "host_reads_per_step"))
         if "enqueue_vs_gpu" in na:
-            legs["neus_acc"].update({"host_enqueue_ms": na["enqueue_vs_gpu"]["host_enqueue_ms_per_step"], "gpu_ms": na["enqueue_vs_gpu"]["gpu_ms_per_step"],
+            legs["neus_acc"].update({"host_enqueue_ms": na["enqueue_vs_gpu"]["host_enqueue_ms_one_step_from_idle"], "gpu_ms": na["enqueue_vs_gpu"]["gpu_ms_per_step"],
                                      "host_bound": na["enqueue_vs_gpu"]["host_bound"]})
     vs = line.get("volsdf")
     if vs:
@@ -1086,13 +1101,13 @@ def compact_line(line):
         for k in ("config1_512rays", "rays4096", "monosdf_preset_1024rays"):
             if k in vs:
                 legs["volsdf_" + k] = {"ms": vs[k]["ms_per_step"], "value": vs[k]["value"], "iterations": vs[k]["error_bound_iterations_last_step"],
-                                       "host_reads": vs[k]["host_reads_per_step"], "host_enqueue_ms": vs[k]["enqueue_vs_gpu"]["host_enqueue_ms_per_step"],
+                                       "host_reads": vs[k]["host_reads_per_step"], "host_enqueue_ms": vs[k]["enqueue_vs_gpu"]["host_enqueue_ms_one_step_from_idle"],
                                        "gpu_ms": vs[k]["enqueue_vs_gpu"]["gpu_ms_per_step"], "host_bound": vs[k]["enqueue_vs_gpu"]["host_bound"]}
     c4 = line.get("config4")
     if c4:
         legs["config4"] = _pick(c4, ("ms_per_step", "value", "host_reads_per_step"))
         if "enqueue_vs_gpu" in c4:
-            legs["config4"]["host_bound"] = c4["enqueue_vs_gpu"]["host_bound"]
+            legs["config4"].update({"host_enqueue_ms": c4["enqueue_vs_gpu"]["host_enqueue_ms_one_step_from_idle"], "host_bound": c4["enqueue_vs_gpu"]["host_bound"]})
     ex = line.get("exchange_at_n1")
     if ex:
         e = {"backend": ex.get("backend")} if "error" not in ex else _pick(ex, ())
@@ -1207,6 +1222,10 @@ def run(args):
         for k, v in _lib.profile_collect().items():  # scaled to the timed region's step count: the code below divides by args.steps
             prof.setdefault(k, (v[0] * args.steps / table_steps, v[1] * args.steps / table_steps))
         _lib.profile_enable(False)
+    main_split = None
+    if world == 1 and not args.small and table_steps:
+        main_split = enqueue_vs_gpu(step, first + args.warmup + args.steps + table_steps, 8, device)
+        job["opts"].wait_parameters()
     # SDFHIP_BENCH_ALLOW_NONFINITE=1: timing ablation builds (tools/build_variant.sh -DSDFHIP_ABL_*) compute wrong numbers on purpose
     assert math.isfinite(float(loss.detach())) or os.environ.get("SDFHIP_BENCH_ALLOW_NONFINITE") == "1", "training diverged"
     final_loss = float(loss.detach())
@@ -1374,6 +1393,7 @@ def run(args):
             "forward_only": fwd_only,
             "dense_sdf": dense,
             "final_loss": float(final_loss),
+            "enqueue_vs_gpu": main_split,
             "model_tflops": round(train_flops * P / (ms * 1e-3) / 1e12, 2),
             "mfma_kernels_ms_per_step": round(mfma_ms, 3),
             "kernels": kernels,

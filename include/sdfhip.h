@@ -459,11 +459,13 @@ int sdfhip_neus_render_bg_backward(const float* sdf, const float* grad, const fl
                                    float* variance_bar, float* bg_density_bar, float* bg_rgb_bar, sdfhip_stream_t stream);
 
 /* Data-parallel hosts (replaces nothing in the reference: DDP's bucket hooks, torch/nn/parallel/distributed.py, see the field's backward
- * as ONE autograd node): sdfhip_field_backward / sdfhip_numfield_backward call `cb(user, table_bar, stream)` right after the hash-table
- * scatter has been enqueued on `stream` and before the weight-gradient GEMMs are - work enqueued behind `stream` inside the callback
- * (a reduce-scatter of table_bar) overlaps those GEMMs.  Process-wide; NULL clears it.  The callback must not synchronise. */
+ * as ONE autograd node): sdfhip_field_backward / sdfhip_numfield_backward on THIS field call `cb(user, table_bar, stream)` right after the
+ * hash-table scatter has been enqueued on `stream` and before the weight-gradient GEMMs are - work enqueued behind `stream` inside the
+ * callback (a reduce-scatter of table_bar) overlaps those GEMMs.  State of the handle, not of the process (no global state
+ * besides immutable descriptors - a second model or the viewer's render thread, viewer/server/viewer_utils.py:109-135, has its own);
+ * thread-safe; NULL clears it.  The callback must not synchronise. */
 typedef void (*sdfhip_table_grad_cb)(void* user, const float* table_bar, sdfhip_stream_t stream);
-void sdfhip_set_table_grad_callback(sdfhip_table_grad_cb cb, void* user);
+int sdfhip_field_set_table_grad_callback(SdfHipField* field, sdfhip_table_grad_cb cb, void* user);
 
 /* ---------------------------------------------------------------------------------------------- measurement (bench.py)
  * Optional HIP-event timing of the library's own launches, recorded on the stream each kernel is launched on.

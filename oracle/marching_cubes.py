@@ -33,7 +33,11 @@ What the black box showed, beyond the paper (all reproduced here):
   - ``mask``: cell (z, y, x) is processed iff mask[z + 1, y + 1, x + 1];
   - the sub-cases 6.1.2, 7.4.2, 12.1.2 and 13.5.2 never occurred in 7 M random cells of those cases (nor in scikit-image's output; a
     vectorised search over 192 M case-6 cells with heavy-tailed magnitudes found no 6.1.2 either: with these tests a face that reads
-    "separated" never meets an interior that reads "connected"): their branches follow the paper and are not pinned.
+    "separated" never meets an interior that reads "connected") - EXCEPT through exact ties: test_face returns `face >= 0` when
+    |A C - B D| < eps, whatever the interior says.  Round 6 enumerated small-integer cells (tests/golden/find_mc_subcase_cells.py):
+    6.1.2 and 7.4.2 occur, and tests/golden/mc_lewiner_subcases.npz PINS those two branches on the real scikit-image (40 cells each,
+    bit-exact).  12.1.2 and 13.5.2 did not occur in 19 M enumerated tie cells of cases 12 and 13 either, and a penalty-minimising
+    optimiser ends on the face-test boundary for every configuration: their branches follow the paper and remain unpinned.
 Cell traversal is z (axis 0) outermost, x (axis 2) innermost; vertices are numbered by first use, so array ORDER is reproduced too.
 """
 import os

@@ -19,6 +19,10 @@ import os
 import sys
 import types
 
+# /root/reference is READ-ONLY: importing it must not leave __pycache__ directories behind.  Set before anything of
+# the tree is imported; every importer of the reference goes through this module (tests/conftest.py sets it for the test processes too).
+sys.dont_write_bytecode = True
+
 import numpy as np
 import torch
 from torch import nn

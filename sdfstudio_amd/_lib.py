@@ -94,7 +94,7 @@ _SIGNATURES = {
     "sdfhip_embedding_backward": (c_i32, [ctypes.c_void_p, c_float_p, c_i64, c_i32, c_i64, c_float_p, ctypes.c_void_p]),
     "sdfhip_numfield_workspace_size": (c_i64, [ctypes.c_void_p, c_i64]),
     "sdfhip_numfield_inference_workspace_size": (c_i64, [ctypes.c_void_p, c_i64]),
-    "sdfhip_set_table_grad_callback": (None, [ctypes.c_void_p, ctypes.c_void_p]),
+    "sdfhip_field_set_table_grad_callback": (c_i32, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "sdfhip_numfield_sdf_rows": (c_i64, [c_i64]),
     "sdfhip_numfield_forward": (c_i32, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_i64, c_i32,
                                         c_float_p, ctypes.c_float, c_i32, ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p,
@@ -259,22 +259,22 @@ def grid_levels(cfg: GridCfg):
 
 
 TABLE_GRAD_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
-_table_grad_cb_keepalive = None
+_table_grad_cb_keepalive = {}  # field handle value -> the ctypes thunk the C side holds a raw pointer to
 
 
-def set_table_grad_callback(fn) -> None:
-    """fn(table_bar_ptr: int, stream_ptr: int) is called from inside sdfhip_field_backward / sdfhip_numfield_backward right after the
-    hash-table scatter has been enqueued on `stream` (include/sdfhip.h: sdfhip_set_table_grad_callback); None clears it.  Exceptions
-    cannot cross the C frame: the callee has to catch and report them itself."""
-    global _table_grad_cb_keepalive
+def field_set_table_grad_callback(handle, fn) -> None:
+    """fn(table_bar_ptr: int, stream_ptr: int) is called from inside sdfhip_field_backward / sdfhip_numfield_backward OF THIS FIELD (handle:
+    SDFField._handle) right after the hash-table scatter has been enqueued on `stream` (include/sdfhip.h:
+    sdfhip_field_set_table_grad_callback); None clears it.  Exceptions cannot cross the C frame: the callee has to catch and report them."""
     lib = load()
+    key = int(handle.value if hasattr(handle, "value") else handle)
     if fn is None:
-        lib.sdfhip_set_table_grad_callback(None, None)
-        _table_grad_cb_keepalive = None
+        check(lib.sdfhip_field_set_table_grad_callback(handle, None, None), "field_set_table_grad_callback")
+        _table_grad_cb_keepalive.pop(key, None)
         return
     cb = TABLE_GRAD_CB(lambda _user, table_bar, stream: fn(int(table_bar or 0), int(stream or 0)))
-    lib.sdfhip_set_table_grad_callback(ctypes.cast(cb, ctypes.c_void_p), None)
-    _table_grad_cb_keepalive = cb  # the C side holds a raw pointer to it
+    check(lib.sdfhip_field_set_table_grad_callback(handle, ctypes.cast(cb, ctypes.c_void_p), None), "field_set_table_grad_callback")
+    _table_grad_cb_keepalive[key] = cb
 
 
 def profile_enable(on: bool) -> int:

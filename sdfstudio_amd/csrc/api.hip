@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/sdfhip.h"
@@ -48,8 +49,14 @@ static const char* kProfNames[PS_COUNT] = {
     "pack_kernel", "geo_encode_kernel", "geo_fwd_kernel", "grad_assemble_kernel", "col_fwd_kernel", "col_bwd_kernel",
     "bwd_prep_kernel", "geo_bwd_kernel", "grid_bwd_kernel", "wgrad_kernel", "wreduce_kernel", "prop_fwd_kernel",
     "prop_bwd_kernel", "neus_render_fwd_kernel", "neus_render_bwd_kernel", "density_weights_kernels", "sampler_kernels"};
+// The ONE piece of process-wide mutable state in the library, and it is measurement tooling: off unless bench.py / a test switches it on.
+// While off, a launch reads one atomic flag and touches nothing else.  While on, every access to the event lists happens under `mu`: the
+// launches come from several threads even in a single-model process (PyTorch runs backward() on its autograd thread, the reference's
+// viewer renders from a second Python thread: viewer/server/viewer_utils.py:109-135), so a thread-local state would miss half of a
+// training step and an unlocked one would corrupt its vectors.  Events of different threads land in the same slots, each pair complete.
 struct ProfState {
-  bool enabled = false;
+  std::atomic<bool> enabled{false};
+  std::mutex mu;
   uint64_t mask = ~0ull;  // slots that record (sdfhip_profile_enable_slots)
   std::vector<hipEvent_t> start[PS_COUNT], stop[PS_COUNT];
   size_t used[PS_COUNT] = {};
@@ -58,9 +65,13 @@ static ProfState g_prof;
 struct ProfScope {
   int slot;
   hipStream_t s;
-  bool on;
-  ProfScope(int slot_, hipStream_t s_) : slot(slot_), s(s_), on(g_prof.enabled && ((g_prof.mask >> slot_) & 1ull)) {
-    if (!on) return;
+  bool on = false;
+  hipEvent_t e_stop = nullptr;
+  ProfScope(int slot_, hipStream_t s_) : slot(slot_), s(s_) {
+    if (!g_prof.enabled.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (!g_prof.enabled.load() || !((g_prof.mask >> slot_) & 1ull)) return;
+    on = true;
     if (g_prof.used[slot] == g_prof.start[slot].size()) {
       hipEvent_t a, b;
       (void)hipEventCreate(&a);
@@ -68,16 +79,17 @@ struct ProfScope {
       g_prof.start[slot].push_back(a);
       g_prof.stop[slot].push_back(b);
     }
-    (void)hipEventRecord(g_prof.start[slot][g_prof.used[slot]], s);
+    const size_t i = g_prof.used[slot]++;  // the pair is claimed here: another thread's scope takes the next one
+    e_stop = g_prof.stop[slot][i];
+    (void)hipEventRecord(g_prof.start[slot][i], s);
   }
   ~ProfScope() {
-    if (!on) return;
-    (void)hipEventRecord(g_prof.stop[slot][g_prof.used[slot]], s);
-    g_prof.used[slot]++;
+    if (on) (void)hipEventRecord(e_stop, s);
   }
 };
 extern "C" int sdfhip_profile_enable(int enable) {
-  g_prof.enabled = enable != 0;
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  g_prof.enabled.store(enable != 0);
   g_prof.mask = ~0ull;
   for (int i = 0; i < PS_COUNT; ++i) g_prof.used[i] = 0;
   return PS_COUNT;
@@ -87,7 +99,8 @@ extern "C" int sdfhip_profile_enable(int enable) {
 // training step instrumented that is ~1 ms per step of measurement overhead, so bench.py times the step with events on the dominant
 // kernel alone and fills its per-kernel table from a separate pass.
 extern "C" int sdfhip_profile_enable_slots(uint64_t slot_mask) {
-  g_prof.enabled = slot_mask != 0;
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  g_prof.enabled.store(slot_mask != 0);
   g_prof.mask = slot_mask;
   for (int i = 0; i < PS_COUNT; ++i) g_prof.used[i] = 0;
   return PS_COUNT;
@@ -96,6 +109,7 @@ extern "C" const char* sdfhip_profile_name(int slot) { return (slot >= 0 && slot
 // total milliseconds and number of timed launches (scopes) recorded for a slot since the last enable; waits for them.
 extern "C" int sdfhip_profile_read(int slot, double* total_ms, int64_t* count) {
   SDFHIP_REQUIRE(slot >= 0 && slot < PS_COUNT && total_ms && count, "profile_read: bad argument");
+  std::lock_guard<std::mutex> lk(g_prof.mu);
   double t = 0.0;
   for (size_t i = 0; i < g_prof.used[slot]; ++i) {
     float ms = 0.0f;
@@ -194,19 +208,15 @@ static thread_local SideLane g_side;
 // ------------------------------------------------------------------------------------------------ "the table's gradient is enqueued" hook
 // A data-parallel host wants to start the exchange of the hash table's gradient - 1.8 GB at BASELINE config 5 - the moment the scatter
 // that produces it is in the queue, not when the whole backward call (scatter, then ~2 ms of weight-gradient GEMMs) returns.  The two
-// field backwards call this right after the scatter has been enqueued on `stream` (the side lane when forked, else the caller's stream):
-// a collective the host enqueues behind `stream` inside the callback runs beside the weight-gradient GEMMs this call enqueues next on the
-// caller's stream.  Process-wide, set once (sdfhip_set_table_grad_callback); the callee must not synchronise.
-static std::atomic<sdfhip_table_grad_cb> g_table_cb{nullptr};
-static std::atomic<void*> g_table_cb_user{nullptr};
-extern "C" void sdfhip_set_table_grad_callback(sdfhip_table_grad_cb cb, void* user) {
-  g_table_cb_user.store(user);
-  g_table_cb.store(cb);
-}
-static inline void notify_table_grad(const float* table_bar, hipStream_t stream) {
-  const sdfhip_table_grad_cb cb = g_table_cb.load();
-  if (cb != nullptr) cb(g_table_cb_user.load(), table_bar, (sdfhip_stream_t)stream);
-}
+// field backwards call the FIELD's callback (sdfhip_field_set_table_grad_callback: state of the handle, not of the process - two models
+// in one process, or a viewer thread beside the trainer, do not see each other's) right after the scatter has been enqueued on `stream`
+// (the side lane when forked, else the caller's stream): a collective the host enqueues behind `stream` inside the callback runs beside
+// the weight-gradient GEMMs this call enqueues next on the caller's stream.  The callee must not synchronise.
+struct TableGradHook {
+  std::mutex mu;
+  sdfhip_table_grad_cb cb = nullptr;
+  void* user = nullptr;
+};
 
 // ------------------------------------------------------------------------------------------------ field handle
 struct LinearInfo {
@@ -215,6 +225,7 @@ struct LinearInfo {
 };
 
 struct SdfHipField {
+  mutable TableGradHook table_hook;
   SdfHipFieldCfg cfg;
   const FieldKernels* k;
   GridDev grid;
@@ -245,6 +256,24 @@ static int add_map(std::vector<int32_t>& maps, const std::vector<int32_t>& m) {
   const int off = (int)maps.size();
   maps.insert(maps.end(), m.begin(), m.end());
   return off;
+}
+
+static inline void notify_table_grad(const SdfHipField* f, const float* table_bar, hipStream_t stream) {
+  sdfhip_table_grad_cb cb;
+  void* user;
+  {
+    std::lock_guard<std::mutex> lk(f->table_hook.mu);
+    cb = f->table_hook.cb;
+    user = f->table_hook.user;
+  }
+  if (cb != nullptr) cb(user, table_bar, (sdfhip_stream_t)stream);  // outside the lock: the callee may re-register
+}
+extern "C" int sdfhip_field_set_table_grad_callback(SdfHipField* f, sdfhip_table_grad_cb cb, void* user) {
+  SDFHIP_REQUIRE(f != nullptr, "field_set_table_grad_callback: null field");
+  std::lock_guard<std::mutex> lk(f->table_hook.mu);
+  f->table_hook.cb = cb;
+  f->table_hook.user = cb != nullptr ? user : nullptr;
+  return 0;
 }
 
 extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out) {
@@ -1290,7 +1319,7 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
     else grid_bwd_kernel<<<dim3((unsigned)((P + 255) / 256), f->grid.n_levels * (f->grid.n_features / 2)), 256, 0, gs>>>(ga);
   }
   if (forked) SDFHIP_CHECK_HIP(hipEventRecord(g_side.join, gs));
-  notify_table_grad(table_bar, gs);  // the table's gradient is complete on `gs` from here on: a host may start its exchange behind it
+  notify_table_grad(f, table_bar, gs);  // the table's gradient is complete on `gs` from here on: a host may start its exchange behind it
 
   // 5. weight gradients: split-K GEMMs over points
   const int64_t n_tiles = NP / 32;
@@ -1731,7 +1760,7 @@ extern "C" int sdfhip_numfield_backward(const SdfHipField* f, const float* packe
     else grid_bwd_kernel<<<dim3((unsigned)((P7 + 255) / 256), f->grid.n_levels * (f->grid.n_features / 2)), 256, 0, gs>>>(ga);
   }
   if (forked) SDFHIP_CHECK_HIP(hipEventRecord(g_side.join, gs));
-  notify_table_grad(table_bar, gs);  // the table's gradient is complete on `gs` from here on: a host may start its exchange behind it
+  notify_table_grad(f, table_bar, gs);  // the table's gradient is complete on `gs` from here on: a host may start its exchange behind it
 
   // 5. weight gradients.  Hidden layers: all 7 P points; the output layer's feature rows: the centre tiles only (no other point has a
   //    feature cotangent), its sdf row: all points

@@ -148,6 +148,7 @@ class FlatGradients:
         self._late = set(int(i) for i in late_buckets)
         # buckets a NATIVE backward launches itself, the moment their gradient is in the queue (launch_from_native)
         self._early: Dict[int, int] = {}        # id(param) -> bucket index (single-parameter buckets only)
+        self._early_fields: list = []           # fields whose native backward calls _native_ready (launch_from_native)
         self._early_done: set = set()
         self._producers: Dict[int, int] = {}    # id(param) -> autograd edges into its AccumulateGrad in this step's graph (zero(loss))
         self._cb_error: Optional[BaseException] = None
@@ -178,14 +179,15 @@ class FlatGradients:
             for attr in (SLOT_ATTR, CLAIM_ATTR):
                 if hasattr(p, attr):
                     delattr(p, attr)
-        if self._early:
+        for fld in self._early_fields:
             try:
                 from sdfstudio_amd import _lib
 
-                _lib.set_table_grad_callback(None)
+                _lib.field_set_table_grad_callback(fld._handle, None)
             except Exception:  # noqa: BLE001 - library not loadable here: nothing was registered either
                 pass
-            self._early = {}
+        self._early_fields = []
+        self._early = {}
 
     # ---- buffer ownership
     def _view(self, p):
@@ -440,9 +442,10 @@ class FlatGradients:
         if self._overlap:
             self._launch_ready(from_hook=True)
 
-    def launch_from_native(self, param: torch.nn.Parameter):
+    def launch_from_native(self, param: torch.nn.Parameter, field):
         """Let the native backward that produces `param`'s gradient start its bucket's exchange ITSELF, the moment the producing kernels
-        are in the queue (include/sdfhip.h: sdfhip_set_table_grad_callback): the SDF field is one autograd node, so the table's hook
+        are in the queue (include/sdfhip.h: sdfhip_field_set_table_grad_callback, registered on `field`, the SDFField that owns
+        `param`: the hook is state of that field's native handle, not of the process): the SDF field is one autograd node, so the table's hook
         fires only after the whole call - scatter, THEN ~2 ms of weight-gradient GEMMs - has been enqueued, and a collective launched
         from the hook waits for all of it.  From the callback it waits for the scatter alone and travels beside the GEMMs.
         Conditions, all checked per step (else the hook launches the bucket as usual): `param` is a bucket of its own and the next to
@@ -452,7 +455,8 @@ class FlatGradients:
         bi = self._bucket_of[id(param)]
         assert len(self._buckets[bi]) == 1, "launch_from_native: the parameter must be a bucket of its own (distributed.plan_buckets)"
         self._early[id(param)] = bi
-        _lib.set_table_grad_callback(self._native_ready)
+        _lib.field_set_table_grad_callback(field._handle, self._native_ready)
+        self._early_fields.append(field)
 
     def _native_ready(self, table_bar_ptr: int, stream_ptr: int):
         try:

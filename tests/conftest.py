@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the CPU tests import /root/reference (read-only) live: no bytecode files may appear there (oracle/ref_harness.py sets the same flag)
+sys.dont_write_bytecode = True
+os.environ.setdefault("PYTHONDONTWRITEBYTECODE", "1")  # child processes of the tests
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -18,6 +18,8 @@ The stratified-sampling draws (``torch.rand`` at ray_samplers.py:107,326) are in
 import os
 import sys
 
+sys.dont_write_bytecode = True  # /root/reference is read-only: importing it must leave no __pycache__ there
+
 import numpy as np
 import torch
 

@@ -20,6 +20,8 @@ import functools
 import os
 import sys
 
+sys.dont_write_bytecode = True  # /root/reference is read-only: importing it must leave no __pycache__ there
+
 import numpy as np
 import torch
 

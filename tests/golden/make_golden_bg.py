@@ -15,6 +15,8 @@ oracle/ref_harness.py with the documented PyTorch tinycudann shim) with ``backgr
 import os
 import sys
 
+sys.dont_write_bytecode = True  # /root/reference is read-only: importing it must leave no __pycache__ there
+
 import numpy as np
 import torch
 

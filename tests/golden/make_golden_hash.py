@@ -16,6 +16,8 @@ output.  The consuming test is tests/test_cpu_hash_pin.py (runs live against the
 import os
 import sys
 
+sys.dont_write_bytecode = True  # /root/reference is read-only: importing it must leave no __pycache__ there
+
 import numpy as np
 import torch
 

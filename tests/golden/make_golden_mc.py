@@ -7,7 +7,9 @@ Each file holds the volume, level, mask, spacing and what ``skimage.measure.marc
 nerfstudio/utils/marching_cubes.py:125-134 calls it) returned, plus the RAW output of the compiled routine underneath
 (_marching_cubes_lewiner_cy.marching_cubes: (x, y, z) order, unflipped faces) so that array order is pinned too.
 """
+import json
 import os
+import sys
 import warnings
 
 import numpy as np
@@ -35,6 +37,18 @@ def volumes():
     out["ties_ascent"] = dict(volume=v, level=0.0, gradient_direction="ascent")
     # tiny magnitudes: the port's epsilons decide
     out["tiny_1e-8"] = dict(volume=(rng.standard_normal((6, 7, 6)) * 1e-8).astype(np.float32), level=0.0)
+    # Lewiner's sub-cases 6.1.2 and 7.4.2 (round 6): reachable only through exact ties on the tested face (find_mc_subcase_cells.py says
+    # why); 80 such cells side by side in one [2, 2, 160] volume, every second cell switched off by the mask so that no two share a face
+    cells = json.load(open(os.path.join(HERE, "mc_subcase_cells.json")))
+    cubes = cells["6.1.2"] + cells["7.4.2"]
+    corner = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)]  # Lewiner's numbering -> (dx, dy, dz)
+    vol = np.zeros((2, 2, 2 * len(cubes)), np.float32)
+    mask = np.zeros(vol.shape, bool)
+    for k, cube in enumerate(cubes):
+        for p, (dx, dy, dz) in enumerate(corner):
+            vol[dz, dy, 2 * k + dx] = cube[p]
+        mask[1, 1, 2 * k + 1] = True  # cell (0, 0, 2 k) is processed iff mask[1, 1, 2 k + 1]
+    out["lewiner_subcases"] = dict(volume=vol, level=0.0, mask=mask)
     return out
 
 
@@ -45,7 +59,10 @@ def main():
 
     luts = M._get_mc_luts()
     raw = M._marching_cubes_lewiner_cy.marching_cubes
+    only = set(sys.argv[1:])  # names to (re)write; none: all
     for name, kw in volumes().items():
+        if only and name not in only:
+            continue
         args = dict(level=kw["level"], spacing=kw.get("spacing", (1.0, 1.0, 1.0)), gradient_direction=kw.get("gradient_direction", "descent"),
                     mask=kw.get("mask"))
         verts, faces, normals, values = measure.marching_cubes(kw["volume"], **args)

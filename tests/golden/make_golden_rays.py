@@ -15,6 +15,8 @@ Consumers: tests/test_gpu_glue.py (the kernels against these vectors), tests/tes
 import os
 import sys
 
+sys.dont_write_bytecode = True  # /root/reference is read-only: importing it must leave no __pycache__ there
+
 import numpy as np
 import torch
 

@@ -15,6 +15,8 @@ import json
 import os
 import platform
 import sys
+
+sys.dont_write_bytecode = True  # /root/reference is read-only: importing it must leave no __pycache__ there
 import time
 
 import torch
