@@ -751,6 +751,9 @@ def neus_acc_leg(device, steps=20, warmup=5):
     fcfg = SDFFieldConfig(bias=0.5, beta_init=0.3, inside_outside=False)  # the preset's SDFFieldConfig(): 8x256 + 4x256, no feature grid
     box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=0.5, far=4.5)
     model = NeuSAccModel(NeuSAccModelConfig(sdf_field=fcfg, background_model="none"), box, 49).to(device).train()
+    # the bounded packed arrays: no device -> host read inside a step - the march step stays on the device, the packed
+    # arrays are sized by a bound measured after the grid update and re-checked every 50 steps (ray_samplers.NeuSAccSampler(bounded=True))
+    model.sampler.bounded = os.environ.get("SDFHIP_BENCH_ACC_EXACT") != "1"
     with torch.no_grad():
         model.field.deviation_network.variance.fill_(0.5)
     groups = {k: v for k, v in model.get_param_groups().items() if v}
@@ -769,7 +772,8 @@ def neus_acc_leg(device, steps=20, warmup=5):
         o, d, norm, cam = draw_rays(centers, rot, rays, gen)
         image = torch.rand(rays, 3, device=device, generator=gen)
         out = model(RayBundle(origins=o, directions=d, directions_norm=norm, camera_indices=cam[:, None]))
-        kept.append(out["ray_samples"].shape[0] if "ray_indices" in out else -1)
+        nv = model.sampler.packed_valid
+        kept.append((out["ray_samples"].shape[0] if nv is None else nv) if "ray_indices" in out else -1)
         loss = functools.reduce(operator.add, model.get_loss_dict(out, {"image": image}).values())
         flat.zero(loss)
         loss.backward()
@@ -786,8 +790,10 @@ def neus_acc_leg(device, steps=20, warmup=5):
         loss = step(2001 + warmup + i)
     torch.cuda.synchronize(device)
     dt = (time.perf_counter() - t0) / steps
+    kept = [int(k) for k in kept]  # (device scalars in the bounded form: read AFTER the timed region)
     assert math.isfinite(float(loss.detach())) and min(kept) > 0, "neus-acc leg: no packed samples / diverged"
     n_kept = sum(kept) / len(kept)
+    model.sampler.check_capacity()
     _lib.profile_enable(True)
     for i in range(5):
         step(2001 + warmup + steps + i)
@@ -802,9 +808,11 @@ def neus_acc_leg(device, steps=20, warmup=5):
            "march_step_size": float(model.sampler.step_size), "value": round(n_kept / dt, 1), "unit": "packed ray-samples/s",
            "dense_equivalent": "NeuS samples 64 + 64 per ray on every ray (models/neus.py:34-47): 128 samples per ray",
            "kernels_ms_per_step": table, "enqueue_vs_gpu": split,
-           "enqueue_note": "the step contains ONE device -> host read (the packed sample count: nerfacc's API returns exact-size tensors, "
-                           "ray_samplers.py:1467 reads a counter the same way), so `host_enqueue` includes the wait for the previous step's GPU work "
-                           "inside that read and `host_bound` only says the host cannot run a step ahead; gpu_ms == wall_ms: the GPU does not idle"}
+           "bounded_packed_arrays": bool(model.sampler.bounded), "packed_capacity": model.sampler._cap,
+           "fill_of_capacity": None if not model.sampler._cap else round(n_kept / model.sampler._cap, 3),
+           "overflowed_steps": int(model.sampler.overflowed_steps), "host_reads_per_step": 0 if model.sampler.bounded else 2,
+           "enqueue_note": "bounded form: no device -> host read inside a step (the reference's nerfacc call returns exact-size tensors: one read "
+                           "for the count, one for the step size, ray_samplers.py:1379-1382,1474-1484); the bound is re-checked every 50 steps"}
     del model, flat, opts, loss
     torch.cuda.empty_cache()
     return out

@@ -84,7 +84,19 @@ typedef struct {
   int32_t activation;            /* hidden activation of the geometry-type network: 0 Softplus(beta = 100) (sdf_field.py:290), 1 ReLU */
   int32_t skip_style;            /* 0: cat([h, in0]) / sqrt(2), the layer below the skip H - in0 wide (sdf_field.py:280,403-404);
                                     1: cat([in0, h]), every layer H wide (field_components/mlp.py:86-88) */
+  /* the ref-nerf options of get_colors (sdf_field.py:536-549, 566-583, 596-607; the bakedsdf / bakedangelo field settings,
+   * configs/method_configs.py:270-286): bit 0 use_diffuse_color (the colour network's inputs lose the position and the gradient, its
+   * kernels return the bare sigmoid: combine with sdfhip_refnerf_forward), bit 1 use_specular_tint, bit 2 use_reflections (the
+   * direction encoding takes 2 (n . -d) n + d), bit 3 use_n_dot_v (one more input column).  Analytic-normal path only. */
+  int32_t ref_flags;
+  int32_t pe_off_axis;           /* SDFFieldConfig.off_axis: the position encoding projects on NeRFEncoding's 21 icosahedron directions
+                                    (field_components/encodings.py:139-163, 191): in0 = 3 + 42 pe_degree + grid features */
 } SdfHipFieldCfg;
+
+#define SDFHIP_REF_DIFFUSE 1
+#define SDFHIP_REF_TINT 2
+#define SDFHIP_REF_REFLECT 4
+#define SDFHIP_REF_NDOTV 8
 
 typedef struct SdfHipField SdfHipField;
 
@@ -145,6 +157,27 @@ int sdfhip_field_backward(const SdfHipField* f, const float* packed, const float
                           int64_t n_rays, int32_t n_samples, void* workspace,
                           const float* sdf_bar, const float* grad_bar, const float* rgb_bar,
                           float* theta_bar, float* table_bar, float* emb_bar, sdfhip_stream_t stream);
+
+/* The same with one more upstream cotangent: feat_bar [P, geo_feat_dim] (or NULL) for a consumer of the geometry feature OUTSIDE the colour
+ * network - the ref-nerf diffuse / tint heads (sdfhip_refnerf_backward), fed by sdfhip_field_forward's `feat` output in MODE_FULL. */
+int sdfhip_field_backward_feat(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
+                               int64_t n_rays, int32_t n_samples, void* workspace,
+                               const float* sdf_bar, const float* grad_bar, const float* rgb_bar, const float* feat_bar,
+                               float* theta_bar, float* table_bar, float* emb_bar, sdfhip_stream_t stream);
+
+/* The ref-nerf colour combination of SDFField.get_colors (sdf_field.py:536-540, 596-607), use_diffuse_color:
+ *   rgb = clamp(tint * s + sigmoid(W_d feat + b_d - log 3), 0, 1) * (1 + 2 pad) - pad,  tint = sigmoid(W_t feat + b_t) or 0.5 (w_t NULL)
+ * s_rgb [P,3]: the colour network's sigmoid output (sdfhip_field_forward's rgb under SDFHIP_REF_DIFFUSE), feat [P, geo_feat_dim],
+ * w_d / w_t [3, geo_feat_dim] and b_d / b_t [3]: diffuse_color_pred / specular_tint_pred (sdf_field.py:333-336; plain Linear layers).
+ * backward: workspace of sdfhip_refnerf_workspace_size bytes; s_bar [P,3] (-> sdfhip_field_backward_feat's rgb_bar), feat_bar
+ * [P, geo_feat_dim] (-> its feat_bar) and the heads' gradients are OVERWRITTEN.  Deterministic (no atomics). */
+int64_t sdfhip_refnerf_workspace_size(int64_t n_points, int32_t geo_feat_dim);
+int sdfhip_refnerf_forward(const float* s_rgb, const float* feat, const float* w_d, const float* b_d, const float* w_t, const float* b_t,
+                           int64_t n_points, int32_t geo_feat_dim, float rgb_padding, float* rgb, sdfhip_stream_t stream);
+int sdfhip_refnerf_backward(const float* s_rgb, const float* feat, const float* w_d, const float* b_d, const float* w_t, const float* b_t,
+                            int64_t n_points, int32_t geo_feat_dim, float rgb_padding, const float* rgb_bar, void* workspace,
+                            float* s_bar, float* feat_bar, float* w_d_bar, float* b_d_bar, float* w_t_bar, float* b_t_bar,
+                            sdfhip_stream_t stream);
 
 /* Differentiable geometry network on explicit positions: SDFField.forward_geonetwork (sdf_field.py:380-410) under autograd -
  * what the reference differentiates through in the sparse-SfM loss (base_surface_model.py:463) and, six more times per sample,
@@ -314,6 +347,17 @@ int sdfhip_march_count(const float* origins, const float* dirs, const float* t_m
 int sdfhip_march_write(const float* origins, const float* dirs, const float* t_min, const float* t_max, const float* roi_aabb6_host,
                        const uint8_t* binary, int64_t n_rays, int32_t resolution, float step, const int64_t* offsets,
                        int64_t* ray_indices, float* t_starts, float* t_ends, sdfhip_stream_t stream);
+/* The same two passes for a host that does not read the sample count back: step_dev (or NULL) is the step as a DEVICE scalar - NeuS-acc
+ * recomputes it from a trained parameter every iteration (ray_samplers.py:1379-1382) - and the write pass drops samples at packed positions
+ * >= capacity (< 0: unbounded): the caller allocates `capacity` entries, clamps (offsets, counts) on the device and checks for overflow at
+ * its leisure.  What the reference does instead: nerfacc returns exact-size tensors, i.e. one device -> host read per step (:1474-1484). */
+int sdfhip_march_count_dev(const float* origins, const float* dirs, const float* t_min, const float* t_max, const float* roi_aabb6_host,
+                           const uint8_t* binary, int64_t n_rays, int32_t resolution, float step, const float* step_dev, int32_t* counts,
+                           sdfhip_stream_t stream);
+int sdfhip_march_write_capped(const float* origins, const float* dirs, const float* t_min, const float* t_max, const float* roi_aabb6_host,
+                              const uint8_t* binary, int64_t n_rays, int32_t resolution, float step, const float* step_dev,
+                              const int64_t* offsets, int64_t capacity, int64_t* ray_indices, float* t_starts, float* t_ends,
+                              sdfhip_stream_t stream);
 /* nerfacc.ray_resampling (model_components/ray_samplers.py:1496-1498; NeuSAccSampler(importance_sampling=True)): every ray that has
  * samples gets n_out new intervals whose n_out + 1 edges are the inverse CDF of its packed weights (padded to a sum >= 1e-5) at
  * u_j = 1 / (2 (n_out + 1)) + j (1 - 1 / (n_out + 1)) / n_out, linear inside the source intervals.  out_offsets [n_rays]: where

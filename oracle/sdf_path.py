@@ -49,6 +49,13 @@ class FieldCfg:
     hash_features_per_level: int = 2
     hash_smoothstep: bool = True
     skip_in: Tuple[int, ...] = (4,)
+    # the ref-nerf options of get_colors and NeRFEncoding(off_axis) (sdf_field.py:154-162, 268; the bakedsdf / bakedangelo field settings,
+    # configs/method_configs.py:270-286)
+    use_diffuse_color: bool = False
+    use_specular_tint: bool = False
+    use_reflections: bool = False
+    use_n_dot_v: bool = False
+    off_axis: bool = False
 
     def growth_factor(self) -> float:
         # sdf_field.py:226
@@ -61,15 +68,17 @@ class FieldCfg:
         )
 
     def geo_in_dim(self) -> int:
-        return 3 + 3 * 2 * self.position_encoding_max_degree + self.num_levels * self.hash_features_per_level
+        # encodings.py:165-175 get_out_dim: in_dim (or the 21 directions of P, off_axis) * num_frequencies * 2
+        return 3 + (21 if self.off_axis else 3) * 2 * self.position_encoding_max_degree + self.num_levels * self.hash_features_per_level
 
     def geo_dims(self) -> List[int]:
         # sdf_field.py:279-282
         return [self.geo_in_dim()] + [self.hidden_dim] * self.num_layers + [1 + self.geo_feat_dim]
 
     def color_in_dim(self) -> int:
-        # sdf_field.py:338-347 (point, view dir PE, normal, feature, embedding)
-        return 3 + 27 + 3 + self.geo_feat_dim + self.appearance_embedding_dim
+        # sdf_field.py:338-352 (point, view dir PE, normal, feature, embedding; use_diffuse_color: dir PE, feature, embedding; + n . v)
+        base = 27 + self.geo_feat_dim + self.appearance_embedding_dim + (0 if self.use_diffuse_color else 6)
+        return base + (1 if self.use_n_dot_v else 0)
 
     def color_dims(self) -> List[int]:
         return [self.color_in_dim()] + [self.hidden_dim_color] * self.num_layers_color + [3]
@@ -122,6 +131,23 @@ def nerf_encoding(x: torch.Tensor, num_frequencies: int, include_input: bool) ->
     return enc
 
 
+# NeRFEncoding.P (field_components/encodings.py:139-163): the 21 directions of the off-axis encoding, rows as the reference lists them
+OFF_AXIS_P = torch.tensor([
+    [0.8506508, 0, 0.5257311], [0.809017, 0.5, 0.309017], [0.5257311, 0.8506508, 0], [1, 0, 0], [0.809017, 0.5, -0.309017],
+    [0.8506508, 0, -0.5257311], [0.309017, 0.809017, -0.5], [0, 0.5257311, -0.8506508], [0.5, 0.309017, -0.809017], [0, 1, 0],
+    [-0.5257311, 0.8506508, 0], [-0.309017, 0.809017, -0.5], [0, 0.5257311, 0.8506508], [-0.309017, 0.809017, 0.5],
+    [0.309017, 0.809017, 0.5], [0.5, 0.309017, 0.809017], [0.5, -0.309017, 0.809017], [0, 0, 1], [-0.5, 0.309017, 0.809017],
+    [-0.809017, 0.5, 0.309017], [-0.809017, 0.5, -0.309017]], dtype=torch.float64)
+
+
+def nerf_encoding_off_axis(x: torch.Tensor, num_frequencies: int) -> torch.Tensor:
+    """field_components/encodings.py:190-198 with off_axis=True, include_input=False: scaled = (x @ P)[..., None] * freqs."""
+    freqs = 2.0 ** torch.arange(num_frequencies, dtype=x.dtype, device=x.device)
+    proj = torch.matmul(x, OFF_AXIS_P.T.to(x))
+    scaled = (proj[..., None] * freqs).reshape(*x.shape[:-1], -1)
+    return torch.sin(torch.cat([scaled, scaled + math.pi / 2.0], dim=-1))
+
+
 def contract_inf(x: torch.Tensor) -> torch.Tensor:
     """field_components/spatial_distortions.py:66-73 with order=inf (base_surface_model.py:148-155)."""
     mag = x.abs().amax(dim=-1, keepdim=True)
@@ -165,7 +191,10 @@ def geo_network(x: torch.Tensor, p: Params, cfg: FieldCfg, mask: Optional[torch.
             feat = feat * mask.to(feat)
     else:
         feat = torch.zeros(x.shape[0], cfg.num_levels * cfg.hash_features_per_level, dtype=x.dtype)
-    pe = nerf_encoding(x, cfg.position_encoding_max_degree, include_input=False)
+    if cfg.off_axis:
+        pe = nerf_encoding_off_axis(x, cfg.position_encoding_max_degree)
+    else:
+        pe = nerf_encoding(x, cfg.position_encoding_max_degree, include_input=False)
     if not cfg.use_position_encoding:
         pe = torch.zeros_like(pe)
     inputs = torch.cat([x, pe, feat], dim=-1)
@@ -227,9 +256,23 @@ def numerical_gradient(x: torch.Tensor, p: Params, cfg: FieldCfg, delta: float, 
 
 
 def color_network(x, dirs, grad, feat, emb, p: Params, cfg: FieldCfg) -> torch.Tensor:
-    """fields/sdf_field.py:532-612 get_colors with the ref-nerf options off. Note the RAW gradient enters (572-578)."""
-    d = nerf_encoding(dirs, 4, include_input=True)
-    h = torch.cat([x, d, grad, feat, emb], dim=-1)
+    """fields/sdf_field.py:532-612 get_colors. Note the RAW gradient enters (572-578).  The ref-nerf options: diffuse / tint heads
+    (:536-540), reflected direction (:545-549), the shorter input list of use_diffuse_color (:566-571), n . v (:580-583), the
+    combination and clamp (:596-607)."""
+    if cfg.use_diffuse_color:
+        raw_rgb_diffuse = F.linear(feat, p["diffuse_color_pred.weight"], p["diffuse_color_pred.bias"])
+    if cfg.use_specular_tint:
+        tint = torch.sigmoid(F.linear(feat, p["specular_tint_pred.weight"], p["specular_tint_pred.bias"]))
+    normals = F.normalize(grad, p=2, dim=-1)
+    if cfg.use_reflections:
+        refdirs = 2.0 * torch.sum(normals * -dirs, dim=-1, keepdim=True) * normals + dirs
+        d = nerf_encoding(refdirs, 4, include_input=True)
+    else:
+        d = nerf_encoding(dirs, 4, include_input=True)
+    parts = [d, feat, emb] if cfg.use_diffuse_color else [x, d, grad, feat, emb]
+    if cfg.use_n_dot_v:
+        parts.append(torch.sum(normals * dirs, dim=-1, keepdim=True))
+    h = torch.cat(parts, dim=-1)
     n_lin = cfg.num_layers_color + 1
     for l in range(n_lin):
         h = linear_wn(p, f"clin{l}", h)
@@ -246,6 +289,10 @@ def color_network(x, dirs, grad, feat, emb, p: Params, cfg: FieldCfg) -> torch.T
                 if force is not None:  # a GIVEN branch pattern (True: the linear branch) whatever round-off makes of sign(z) in this run
                     h = torch.where(force, z, torch.zeros_like(z))
     rgb = torch.sigmoid(h)
+    if cfg.use_diffuse_color:
+        diffuse_linear = torch.sigmoid(raw_rgb_diffuse - math.log(3.0))
+        specular_linear = tint * rgb if cfg.use_specular_tint else 0.5 * rgb
+        rgb = torch.clamp(specular_linear + diffuse_linear, 0.0, 1.0)
     return rgb * (1 + 2 * cfg.rgb_padding) - cfg.rgb_padding
 
 
@@ -849,6 +896,11 @@ def init_field_params(cfg: FieldCfg, num_images: int = 49, seed: int = 0, dtype=
         p[f"clin{l}.weight_v"] = w
         p[f"clin{l}.weight_g"] = w.norm(dim=1, keepdim=True)
         p[f"clin{l}.bias"] = torch.zeros(cd[l + 1])
+    for name, on in (("diffuse_color_pred", cfg.use_diffuse_color), ("specular_tint_pred", cfg.use_specular_tint)):
+        if on:  # sdf_field.py:333-336: nn.Linear(geo_feat_dim, 3), torch's default init (kaiming_uniform(a = sqrt 5) = U(+-1 / sqrt(fan_in)))
+            bound = 1.0 / math.sqrt(cfg.geo_feat_dim)
+            p[f"{name}.weight"] = (torch.rand(3, cfg.geo_feat_dim, generator=g) * 2 - 1) * bound
+            p[f"{name}.bias"] = (torch.rand(3, generator=g) * 2 - 1) * bound
     lv = cfg.grid_levels()
     p["encoding.params"] = (torch.rand(lv.n_params, generator=g) * 2 - 1) * 1e-4
     p["laplace_density.beta"] = torch.full((1,), cfg.beta_init)

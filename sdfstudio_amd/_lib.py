@@ -38,7 +38,11 @@ class FieldCfg(ctypes.Structure):
         ("hidden_dim_color", c_i32), ("skip_layer", c_i32), ("pe_degree", c_i32), ("use_position_encoding", c_i32),
         ("appearance_dim", c_i32), ("contract", c_i32), ("rgb_padding", c_f32), ("grid", GridCfg),
         ("activation", c_i32), ("skip_style", c_i32),  # background fields: ReLU network, MLP-style skip (zero = the SDF field)
+        ("ref_flags", c_i32), ("pe_off_axis", c_i32),  # ref-nerf colour options (REF_*), NeRFEncoding(off_axis=True) for the position
     ]
+
+
+REF_DIFFUSE, REF_TINT, REF_REFLECT, REF_NDOTV = 1, 2, 4, 8
 
 
 MODE_SDF, MODE_GEO, MODE_FULL = 0, 1, 2
@@ -55,6 +59,13 @@ _SIGNATURES = {
     "sdfhip_field_theta_layout": (c_i32, [ctypes.c_void_p, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64),
                                           ctypes.POINTER(c_i32), ctypes.POINTER(c_i32)]),
     "sdfhip_field_table_size": (c_i64, [ctypes.c_void_p]),
+    "sdfhip_field_backward_feat": (c_i32, [ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_i64, c_i32, ctypes.c_void_p, c_float_p, c_float_p,
+                                           c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
+    "sdfhip_refnerf_workspace_size": (c_i64, [c_i64, c_i32]),
+    "sdfhip_refnerf_forward": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_i64, c_i32, c_f32, c_float_p,
+                                       ctypes.c_void_p]),
+    "sdfhip_refnerf_backward": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_i64, c_i32, c_f32, c_float_p,
+                                        ctypes.c_void_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
     "sdfhip_field_packed_size": (c_i64, [ctypes.c_void_p]),
     "sdfhip_field_workspace_size": (c_i64, [ctypes.c_void_p, c_i64, c_i32]),
     "sdfhip_field_pack": (c_i32, [ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_void_p]),
@@ -128,6 +139,10 @@ _SIGNATURES = {
                                    c_f32, ctypes.c_void_p, ctypes.c_void_p]),
     "sdfhip_march_write": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, c_i64, c_i32,
                                    c_f32, ctypes.c_void_p, ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_void_p]),
+    "sdfhip_march_count_dev": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, c_i64, c_i32,
+                                       c_f32, c_float_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "sdfhip_march_write_capped": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, c_i64, c_i32,
+                                          c_f32, c_float_p, ctypes.c_void_p, c_i64, ctypes.c_void_p, c_float_p, c_float_p, ctypes.c_void_p]),
     "sdfhip_packed_resample": (c_i32, [c_float_p, c_float_p, c_float_p, ctypes.c_void_p, ctypes.c_void_p, c_i64, c_i32, ctypes.c_void_p, c_float_p,
                                        c_float_p, ctypes.c_void_p]),
     "sdfhip_packed_weights_forward": (c_i32, [c_float_p, ctypes.c_void_p, ctypes.c_void_p, c_i64, c_float_p, c_float_p, ctypes.c_void_p]),

@@ -18,6 +18,7 @@
 #include "volsdf_render_kernels.h"
 #include "grid_encode_kernels.h"
 #include "theta_kernels.h"
+#include "refnerf_kernels.h"
 
 const FieldKernels* sdfhip_kernels_A();
 const FieldKernels* sdfhip_kernels_B();
@@ -250,6 +251,8 @@ struct SdfHipField {
   int kb_geo(int l) const { return l == 0 ? k->nb0 : (l == skip ? nb3 + k->nb0 : k->nbh); }
   int nbo_geo(int l) const { return l == nl ? k->nbf : ((l + 1 == skip) ? nb3 : k->nbh); }
   int kb_col(int l) const { return l == 0 ? k->nbf + k->nbs : k->nbc; }
+  int pe_code = 0;    // position_encoding_max_degree | (off_axis << 8): point_kernels.h pe_freqs / pe_axes / pe_cols
+  int ref_flags = 0;  // kRef*: the ref-nerf options of get_colors
 };
 
 static int add_map(std::vector<int32_t>& maps, const std::vector<int32_t>& m) {
@@ -296,7 +299,9 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
   f->n_feat = cfg->grid.n_levels * cfg->grid.n_features;
   const int H = cfg->hidden_dim, GF = cfg->geo_feat_dim, HC = cfg->hidden_dim_color, NL = cfg->num_layers,
             NLC = cfg->num_layers_color, E = cfg->appearance_dim;
-  const int D0 = 3 + 6 * cfg->pe_degree + f->n_feat;
+  f->pe_code = cfg->pe_degree | (cfg->pe_off_axis ? kPeOffAxis : 0);
+  f->ref_flags = cfg->ref_flags & (kRefDiffuse | kRefTint | kRefReflect | kRefNdotV);
+  const int D0 = 3 + pe_cols(f->pe_code) + f->n_feat;
   f->d0 = D0;
   const int skip = cfg->skip_layer;
   const bool mlp_skip = cfg->skip_style == 1;  // cat([in0, h]) with every layer H wide (field_components/mlp.py) instead of the SDF field's
@@ -313,15 +318,18 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
   if (NL + 1 > kMaxLayers || NLC + 1 > kMaxLayers) return fail("too many layers");
   // nb3: width (blocks) of the layer below the skip concatenation.  Its H - D0 real rows are padded to the FULL hidden width,
   // so that every hidden layer has the same shape and the fused kernels can loop over them (geo_kernels.h)
-  const int nb0 = (D0 + 31) / 32, nb3 = skip >= 0 ? H / 32 : 0, nbs = (33 + E + 31) / 32;
+  if (cfg->pe_degree < 0 || cfg->pe_degree > 16) return fail("position_encoding_max_degree out of range");
+  const CsmallLayout CL = csmall_layout(f->ref_flags, E);
+  const int nb0 = (D0 + 31) / 32, nb3 = skip >= 0 ? H / 32 : 0, nbs = (CL.width + 31) / 32;
   const FieldKernels* cands[] = {sdfhip_kernels_A(), sdfhip_kernels_B(), sdfhip_kernels_C(), sdfhip_kernels_D(), sdfhip_kernels_E(),
                                  sdfhip_kernels_W()};
   f->k = nullptr;
   for (const FieldKernels* k : cands) {
     // in0 may be narrower than the instantiation's in0 blocks (the encode kernel zero-fills the rest, the packed weights have zero
     // columns there): the narrowest instantiation that holds it wins
-    if (k->nbh == H / 32 && k->nb0 >= nb0 && k->nbf == GF / 32 && k->nbs == nbs && k->nbc == HC / 32 && k->act == cfg->activation &&
-        (f->k == nullptr || k->nb0 < f->k->nb0))
+    // (likewise the colour network's small-input blocks: with use_diffuse_color the position and the gradient are not inputs, 60 columns)
+    if (k->nbh == H / 32 && k->nb0 >= nb0 && k->nbf == GF / 32 && k->nbs >= nbs && k->nbc == HC / 32 && k->act == cfg->activation &&
+        (f->k == nullptr || k->nb0 < f->k->nb0 || (k->nb0 == f->k->nb0 && k->nbs < f->k->nbs)))
       f->k = k;
   }
   if (f->k == nullptr) return fail("no kernel instantiation was built for this shape");
@@ -347,7 +355,7 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
   }
   for (int l = 0; l <= NLC; ++l) {
     LinearInfo li;
-    li.in_dim = l == 0 ? 33 + GF + E : HC;
+    li.in_dim = l == 0 ? CL.width + GF : HC;
     li.out_dim = l == NLC ? 3 : HC;
     li.w_off = off;
     off += (int64_t)li.out_dim * li.in_dim;
@@ -455,11 +463,11 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
     const int kb = f->kb_col(l), nbo = k->nbc;
     std::vector<int32_t> rowmap = ident(nbo * 32, HC), colmap;
     if (l == 0) {
-      // reference column order (sdf_field.py:572-578): x(3) d(27) grad(3) feat(GF) emb(E); ours: [feat | x d grad emb]
+      // reference column order (sdf_field.py:566-583): [x(3)] D(27) [grad(3)] feat(GF) emb(E) [n.v]; ours: [feat | small inputs in the
+      // same order, csmall_layout]: the small columns in front of the embedding precede the feature in the reference, the rest follow it
       colmap.assign(kb * 32, -1);
-      for (int i = 0; i < GF; ++i) colmap[i] = 33 + i;
-      for (int j = 0; j < 33; ++j) colmap[k->nbf * 32 + j] = j;
-      for (int j = 0; j < E; ++j) colmap[k->nbf * 32 + 33 + j] = 33 + GF + j;
+      for (int i = 0; i < GF; ++i) colmap[i] = CL.emb + i;
+      for (int j = 0; j < CL.width; ++j) colmap[k->nbf * 32 + j] = j < CL.emb ? j : GF + j;
     } else {
       colmap = ident(kb * 32, HC);
     }
@@ -532,6 +540,7 @@ struct FieldWs {
   float *rgb;
   float *gtot, *ebar, *sdfbar, *qb[kMaxLayers + 1], *zb[kMaxLayers], *in0bar, *d[kMaxLayers], *dout, *featbar, *csmallbar;
   float *partial, *bpartial;
+  float *gsave, *dsave;  // ref-nerf options: d sdf / dx and the ray direction per point, for the backward (null otherwise)
   int n_split;
   size_t bytes;
 };
@@ -580,6 +589,10 @@ static void carve(const SdfHipField* f, int64_t n_points, int level, void* base,
     w->n_split = (int)std::min<int64_t>(256, n_tiles);
     w->partial = take((int64_t)w->n_split * f->max_partial_elems);
     w->bpartial = take((int64_t)w->n_split * f->max_partial_rows);
+    if (f->ref_flags & (kRefReflect | kRefNdotV)) {  // behind everything else: the layout without the options is what it always was
+      w->gsave = take(np * 3);
+      w->dsave = take(np * 3);
+    }
   }
   w->bytes = off;
 }
@@ -626,7 +639,9 @@ static void fill_col_ptrs(const SdfHipField* f, const float* packed, ColPtrs* p,
   }
   p->w_out = packed + f->c_wout;
   p->b_out = packed + f->c_bout;
-  p->rgb_padding = f->cfg.rgb_padding;
+  // use_diffuse_color: the network's sigmoid is the SPECULAR term, combined with the diffuse head and padded afterwards
+  // (sdfhip_refnerf_forward): the colour kernels then return (and differentiate) the bare sigmoid
+  p->rgb_padding = (f->ref_flags & kRefDiffuse) ? 0.0f : f->cfg.rgb_padding;
 }
 
 __global__ void untp_kernel(const float* __restrict__ tp, const int nb, const int n_feat, const int64_t n_rows, float* __restrict__ out) {
@@ -668,7 +683,7 @@ extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, c
   ea.S = n_samples;
   // get_outputs contracts the sample positions (sdf_field.py:629); get_sdf / forward_geonetwork do NOT (:412-418, :380)
   ea.contract = full ? f->cfg.contract : 0;  // 0 none, 1 L-inf, 2 L2
-  ea.pe_degree = f->cfg.pe_degree;
+  ea.pe_degree = f->pe_code;
   ea.use_pe = f->cfg.use_position_encoding;
   ea.nb0 = k->nb0;
   ea.table = table;
@@ -709,14 +724,17 @@ extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, c
     aa.n_points = P;
     aa.n_padded = NP;
     aa.S = n_samples;
-    aa.pe_degree = f->cfg.pe_degree;
+    aa.pe_degree = f->pe_code;
     aa.use_pe = f->cfg.use_position_encoding;
     aa.n_feat = f->n_feat;
     aa.nb0 = k->nb0;
     aa.nbs = k->nbs;
     aa.emb_dim = f->cfg.appearance_dim;
+    aa.ref_flags = f->ref_flags;
     aa.grad = grad;
     aa.csmall_tp = w.csmall;
+    aa.g_save = w.gsave;  // null unless a backward follows AND the colour inputs depend on the normal (carve)
+    aa.d_save = w.dsave;
     { ProfScope ps_(PS_ASSEMBLE, s); grad_assemble_kernel<<<(unsigned)(NP / 256 + (NP % 256 != 0)), 256, 0, s>>>(aa); }
 
     ColFwdArgs ca;
@@ -973,7 +991,7 @@ static int geo_forward_impl(const SdfHipField* f, const float* packed, const flo
   ea.n_points = P;
   ea.n_padded = NP;
   ea.S = dirs != nullptr ? n_samples : 1;
-  ea.pe_degree = f->cfg.pe_degree;
+  ea.pe_degree = f->pe_code;
   ea.use_pe = f->cfg.use_position_encoding;
   ea.nb0 = k->nb0;
   ea.table = table;
@@ -1063,7 +1081,7 @@ extern "C" int sdfhip_geo_backward_n(const SdfHipField* f, const float* packed, 
   ga.in0bar_tp = w.in0bar;
   ga.mask = level_mask;
   ga.n_points = P;
-  ga.pe_degree = f->cfg.pe_degree;
+  ga.pe_degree = f->pe_code;
   ga.nb0 = k->nb0;
   ga.tablebar = table_bar;
   if (f->grid.n_levels > 0) {  // NeRFField has no grid
@@ -1139,12 +1157,13 @@ extern "C" int sdfhip_color_forward(const SdfHipField* f, const float* packed, c
   aa.n_points = P;
   aa.n_padded = NP;
   aa.S = n_samples;
-  aa.pe_degree = f->cfg.pe_degree;
+  aa.pe_degree = f->pe_code;
   aa.use_pe = f->cfg.use_position_encoding;
   aa.n_feat = f->n_feat;
   aa.nb0 = k->nb0;
   aa.nbs = k->nbs;
   aa.emb_dim = f->cfg.appearance_dim;
+  aa.ref_flags = f->ref_flags;
   aa.csmall_tp = w.csmall;
   { ProfScope ps_(PS_ASSEMBLE, s); grad_assemble_kernel<<<(unsigned)(NP / 256 + (NP % 256 != 0)), 256, 0, s>>>(aa); }
   ColFwdArgs ca;
@@ -1161,23 +1180,23 @@ extern "C" int sdfhip_color_forward(const SdfHipField* f, const float* packed, c
 }
 
 // d L / d (normal input) [P,3] and d L / d (appearance embedding) [N, emb_dim] out of the colour backward's small-input block
-__global__ void color_unpack_kernel(const float* __restrict__ csmallbar_tp, const int nbs, const int64_t n_points,
+__global__ void color_unpack_kernel(const float* __restrict__ csmallbar_tp, const int nbs, const int64_t n_points, const int g_col,
                                     float* __restrict__ grad_bar) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_points) return;
 #pragma unroll
-  for (int d = 0; d < 3; ++d) grad_bar[p * 3 + d] = csmallbar_tp[tp_index(p, 30 + d, nbs)];
+  for (int d = 0; d < 3; ++d) grad_bar[p * 3 + d] = g_col >= 0 ? csmallbar_tp[tp_index(p, g_col + d, nbs)] : 0.0f;
 }
 // d L / d (per-ray embedding) [N, emb_dim] += sum over the ray's S consecutive points: one thread per (ray, slot), no atomics (the
 // caller's buffer is zero or holds an earlier contribution)
 __global__ void color_emb_reduce_kernel(const float* __restrict__ csmallbar_tp, const int nbs, const int64_t n_rays, const int S,
-                                        const int emb_dim, float* __restrict__ emb_bar) {
+                                        const int emb_dim, const int emb_col, float* __restrict__ emb_bar) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_rays * emb_dim) return;
   const int64_t ray = idx / emb_dim;
   const int j = (int)(idx % emb_dim);
   float s = 0.0f;
-  for (int i = 0; i < S; ++i) s += csmallbar_tp[tp_index(ray * S + i, 33 + j, nbs)];
+  for (int i = 0; i < S; ++i) s += csmallbar_tp[tp_index(ray * S + i, emb_col + j, nbs)];
   emb_bar[idx] += s;
 }
 
@@ -1185,6 +1204,9 @@ extern "C" int sdfhip_color_backward(const SdfHipField* f, const float* packed, 
                                      const float* rgb_bar, float* theta_bar, float* feat_bar, float* grad_bar, float* emb_bar,
                                      sdfhip_stream_t stream) {
   SDFHIP_REQUIRE(f && packed && workspace && rgb_bar && theta_bar, "color_backward: null argument");
+  SDFHIP_REQUIRE((f->ref_flags & (kRefReflect | kRefNdotV)) == 0,
+                 "color_backward: use_reflections / use_n_dot_v send the normal's cotangent through the reflected direction - built in "
+                 "sdfhip_field_backward (analytic normals) only");
   if (n_rays == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const FieldKernels* k = f->k;
@@ -1209,20 +1231,39 @@ extern "C" int sdfhip_color_backward(const SdfHipField* f, const float* packed, 
     const int64_t total = P * f->cfg.geo_feat_dim;
     untp_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(w.featbar, k->nbf, f->cfg.geo_feat_dim, P, feat_bar);
   }
-  if (grad_bar != nullptr) color_unpack_kernel<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(w.csmallbar, k->nbs, P, grad_bar);
+  const CsmallLayout CL = csmall_layout(f->ref_flags, f->cfg.appearance_dim);
+  if (grad_bar != nullptr) color_unpack_kernel<<<(unsigned)((P + 255) / 256), 256, 0, s>>>(w.csmallbar, k->nbs, P, CL.g, grad_bar);
   if (emb_bar != nullptr && f->cfg.appearance_dim > 0) {
     const int64_t ne = n_rays * f->cfg.appearance_dim;
-    color_emb_reduce_kernel<<<(unsigned)((ne + 255) / 256), 256, 0, s>>>(w.csmallbar, k->nbs, n_rays, n_samples, f->cfg.appearance_dim, emb_bar);
+    color_emb_reduce_kernel<<<(unsigned)((ne + 255) / 256), 256, 0, s>>>(w.csmallbar, k->nbs, n_rays, n_samples, f->cfg.appearance_dim, CL.emb,
+                                                                          emb_bar);
   }
   run_col_wgrads(f, w, NP / 32, theta_bar, s);
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }
 
+// featbar_tp += feat_bar (natural [P, GF] -> tile-packed), rows >= n_points untouched
+__global__ void tp_add_kernel(const float* __restrict__ nat, const int nb, const int n_feat, const int64_t n_rows, float* __restrict__ tp) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_rows * n_feat) return;
+  const int64_t p = idx / n_feat;
+  const int c = (int)(idx % n_feat);
+  tp[tp_index(p, c, nb)] += nat[idx];
+}
+
 extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
                                      int64_t n_rays, int32_t n_samples, void* workspace, const float* sdf_bar, const float* grad_bar,
                                      const float* rgb_bar, float* theta_bar, float* table_bar, float* emb_bar,
                                      sdfhip_stream_t stream) {
+  return sdfhip_field_backward_feat(f, packed, table, level_mask, n_rays, n_samples, workspace, sdf_bar, grad_bar, rgb_bar, nullptr, theta_bar,
+                                    table_bar, emb_bar, stream);
+}
+
+extern "C" int sdfhip_field_backward_feat(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
+                                          int64_t n_rays, int32_t n_samples, void* workspace, const float* sdf_bar, const float* grad_bar,
+                                          const float* rgb_bar, const float* feat_bar, float* theta_bar, float* table_bar, float* emb_bar,
+                                          sdfhip_stream_t stream) {
   (void)table;
   SDFHIP_REQUIRE(f && packed && level_mask && workspace && theta_bar && table_bar, "field_backward: null argument");
   SDFHIP_REQUIRE(f->k->geo_bwd != nullptr, "field_backward: no second-order kernels for this (ReLU) field");
@@ -1250,6 +1291,10 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
   cb.featbar_tp = w.featbar;
   cb.csmallbar_tp = w.csmallbar;
   { ProfScope ps_(PS_COL_BWD, s); k->col_bwd(cb, grid, s); }
+  if (feat_bar != nullptr) {  // a consumer of the geometry feature outside the colour network (the ref-nerf diffuse / tint heads)
+    const int64_t total = P * f->cfg.geo_feat_dim;
+    tp_add_kernel<<<(unsigned)((total + 255) / 256), 256, 0, s>>>(feat_bar, k->nbf, f->cfg.geo_feat_dim, P, w.featbar);
+  }
 
   // 2. total d L / d grad, tangent seed, padded sdfbar
   BwdPrepArgs pa;
@@ -1262,13 +1307,16 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
   pa.mask = level_mask;
   pa.n_points = P;
   pa.n_padded = NP;
-  pa.pe_degree = f->cfg.pe_degree;
+  pa.pe_degree = f->pe_code;
   pa.use_pe = f->cfg.use_position_encoding;
   pa.n_feat = f->n_feat;
   pa.nb0 = k->nb0;
   pa.nbs = k->nbs;
   pa.emb_dim = f->cfg.appearance_dim;
   pa.S = n_samples;
+  pa.ref_flags = f->ref_flags;
+  pa.g_pt = w.gsave;
+  pa.d_pt = w.dsave;
   pa.gtot = w.gtot;
   pa.ebar_tp = w.ebar;
   pa.sdfbar = w.sdfbar;
@@ -1302,7 +1350,7 @@ extern "C" int sdfhip_field_backward(const SdfHipField* f, const float* packed, 
   ga.gtot = w.gtot;
   ga.mask = level_mask;
   ga.n_points = P;
-  ga.pe_degree = f->cfg.pe_degree;
+  ga.pe_degree = f->pe_code;
   ga.nb0 = k->nb0;
   ga.tablebar = table_bar;
   // forked: nothing below reads table_bar, and the scatter is bound by memory-side atomics, not by CUs
@@ -1549,6 +1597,7 @@ extern "C" int sdfhip_numfield_forward(const SdfHipField* f, const float* packed
                                        const float* origins, const float* dirs, const float* starts, int64_t n_rays, int32_t n_samples,
                                        const float* emb, float delta, int32_t training, void* workspace, float* sdf7, float* grad,
                                        float* rgb, float* taps, float* x_out, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(f == nullptr || f->ref_flags == 0, "numfield_forward: the ref-nerf colour options are built on the analytic-normal path");
   SDFHIP_REQUIRE(f && packed && table && level_mask && origins && dirs && starts && workspace && sdf7 && grad && rgb,
                  "numfield_forward: null argument");
   SDFHIP_REQUIRE(n_samples >= 1 && n_rays >= 0 && delta > 0.0f, "numfield_forward: bad shape / delta");
@@ -1571,7 +1620,7 @@ extern "C" int sdfhip_numfield_forward(const SdfHipField* f, const float* packed
   ea.n_padded = N7;
   ea.S = n_samples;
   ea.contract = f->cfg.contract;  // get_outputs contracts the sample positions (sdf_field.py:629), the taps are taken in contracted space
-  ea.pe_degree = f->cfg.pe_degree;
+  ea.pe_degree = f->pe_code;
   ea.use_pe = f->cfg.use_position_encoding;
   ea.nb0 = k->nb0;
   ea.table = table;
@@ -1637,12 +1686,13 @@ extern "C" int sdfhip_numfield_forward(const SdfHipField* f, const float* packed
   aa.n_points = P;
   aa.n_padded = NC;
   aa.S = n_samples;
-  aa.pe_degree = f->cfg.pe_degree;
+  aa.pe_degree = f->pe_code;
   aa.use_pe = f->cfg.use_position_encoding;
   aa.n_feat = f->n_feat;
   aa.nb0 = k->nb0;
   aa.nbs = k->nbs;
   aa.emb_dim = f->cfg.appearance_dim;
+  aa.ref_flags = f->ref_flags;
   aa.csmall_tp = w.c.csmall;
   { ProfScope ps_(PS_ASSEMBLE, s); grad_assemble_kernel<<<(unsigned)(NC / 256 + (NC % 256 != 0)), 256, 0, s>>>(aa); }
   ColFwdArgs ca;
@@ -1664,6 +1714,7 @@ extern "C" int sdfhip_numfield_backward(const SdfHipField* f, const float* packe
                                         const float* rgb_bar, const float* taps_bar, float* theta_bar, float* table_bar, float* emb_bar,
                                         sdfhip_stream_t stream) {
   SDFHIP_REQUIRE(f && packed && level_mask && workspace && theta_bar && table_bar, "numfield_backward: null argument");
+  SDFHIP_REQUIRE(f->ref_flags == 0, "numfield_backward: the ref-nerf colour options are built on the analytic-normal path (sdfhip_field_backward_feat)");
   if (n_rays == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const FieldKernels* k = f->k;
@@ -1689,7 +1740,8 @@ extern "C" int sdfhip_numfield_backward(const SdfHipField* f, const float* packe
   { ProfScope ps_(PS_COL_BWD, s); k->col_bwd(cb, (unsigned)(NC / 128), s); }
   if (emb_bar != nullptr && f->cfg.appearance_dim > 0) {
     const int64_t ne = n_rays * f->cfg.appearance_dim;
-    color_emb_reduce_kernel<<<(unsigned)((ne + 255) / 256), 256, 0, s>>>(w.c.csmallbar, k->nbs, n_rays, n_samples, f->cfg.appearance_dim, emb_bar);
+    color_emb_reduce_kernel<<<(unsigned)((ne + 255) / 256), 256, 0, s>>>(w.c.csmallbar, k->nbs, n_rays, n_samples, f->cfg.appearance_dim,
+                                                                          csmall_layout(f->ref_flags, f->cfg.appearance_dim).emb, emb_bar);
   }
 
   // 2. adjoint of the finite differences: sdfbar of the 7 P points
@@ -1740,7 +1792,7 @@ extern "C" int sdfhip_numfield_backward(const SdfHipField* f, const float* packe
   ga.in0bar_tp = w.g.in0bar;
   ga.mask = level_mask;
   ga.n_points = 7 * P;
-  ga.pe_degree = f->cfg.pe_degree;
+  ga.pe_degree = f->pe_code;
   ga.nb0 = k->nb0;
   ga.tablebar = table_bar;
   ga.tap_points = P;
@@ -2197,6 +2249,8 @@ static void fill_march(MarchArgs* a, const float* origins, const float* dirs, co
   a->N = (int)n_rays;
   a->R = resolution;
   a->step = step;
+  a->step_dev = nullptr;
+  a->capacity = -1;
 }
 extern "C" int sdfhip_march_count(const float* origins, const float* dirs, const float* t_min, const float* t_max, const float* roi_aabb6_host,
                                   const uint8_t* binary, int64_t n_rays, int32_t resolution, float step, int32_t* counts,
@@ -2219,6 +2273,42 @@ extern "C" int sdfhip_march_write(const float* origins, const float* dirs, const
   if (n_rays == 0) return 0;
   MarchArgs a;
   fill_march(&a, origins, dirs, t_min, t_max, roi_aabb6_host, binary, n_rays, resolution, step);
+  a.offsets = offsets;
+  a.ray_indices = ray_indices;
+  a.t_starts = t_starts;
+  a.t_ends = t_ends;
+  march_kernel<true><<<(unsigned)((n_rays + 127) / 128), 128, 0, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+// The same two passes for a host that never reads the sample count back: the step may be a DEVICE scalar (step_dev,
+// overrides `step`), and the write pass drops what falls behind `capacity` packed samples (< 0: unbounded) - the caller sizes its arrays by
+// a bound, clamps (offsets, counts) to it on the device and checks an overflow flag now and then (ray_samplers.py: march_occupancy_grid).
+extern "C" int sdfhip_march_count_dev(const float* origins, const float* dirs, const float* t_min, const float* t_max,
+                                      const float* roi_aabb6_host, const uint8_t* binary, int64_t n_rays, int32_t resolution, float step,
+                                      const float* step_dev, int32_t* counts, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(origins && dirs && t_min && t_max && roi_aabb6_host && binary && counts && resolution >= 1 && (step > 0.0f || step_dev),
+                 "march_count_dev: bad argument");
+  if (n_rays == 0) return 0;
+  MarchArgs a;
+  fill_march(&a, origins, dirs, t_min, t_max, roi_aabb6_host, binary, n_rays, resolution, step);
+  a.step_dev = step_dev;
+  a.counts = counts;
+  march_kernel<false><<<(unsigned)((n_rays + 127) / 128), 128, 0, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int sdfhip_march_write_capped(const float* origins, const float* dirs, const float* t_min, const float* t_max,
+                                         const float* roi_aabb6_host, const uint8_t* binary, int64_t n_rays, int32_t resolution, float step,
+                                         const float* step_dev, const int64_t* offsets, int64_t capacity, int64_t* ray_indices,
+                                         float* t_starts, float* t_ends, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(origins && dirs && t_min && t_max && roi_aabb6_host && binary && offsets && ray_indices && t_starts && t_ends &&
+                     resolution >= 1 && (step > 0.0f || step_dev), "march_write_capped: bad argument");
+  if (n_rays == 0) return 0;
+  MarchArgs a;
+  fill_march(&a, origins, dirs, t_min, t_max, roi_aabb6_host, binary, n_rays, resolution, step);
+  a.step_dev = step_dev;
+  a.capacity = capacity;
   a.offsets = offsets;
   a.ray_indices = ray_indices;
   a.t_starts = t_starts;
@@ -2742,6 +2832,74 @@ static int neus_render_backward_impl(const float* sdf, const float* grad, const 
   if (n_rays == 0) return 0;
   const unsigned grid = (unsigned)((n_rays + 3) / 4);
   { ProfScope ps_(PS_RENDER_BWD, (hipStream_t)stream); SDFHIP_DISPATCH_C(n_samples, (neus_render_bwd_kernel<C><<<grid, 256, 0, (hipStream_t)stream>>>(a))); }
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------ ref-nerf colour combination (refnerf_kernels.h)
+static constexpr int kRefChunk = 1024;
+extern "C" int64_t sdfhip_refnerf_workspace_size(int64_t n_points, int32_t geo_feat_dim) {
+  const int64_t nb = (n_points + kRefChunk - 1) / kRefChunk;
+  return (int64_t)sizeof(float) * (n_points * 8 + nb * 6 * (geo_feat_dim + 1)) + 512;
+}
+extern "C" int sdfhip_refnerf_forward(const float* s_rgb, const float* feat, const float* w_d, const float* b_d, const float* w_t,
+                                      const float* b_t, int64_t n_points, int32_t geo_feat_dim, float rgb_padding, float* rgb,
+                                      sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(s_rgb && feat && w_d && b_d && rgb && (w_t == nullptr) == (b_t == nullptr), "refnerf_forward: null argument");
+  SDFHIP_REQUIRE(geo_feat_dim >= 1 && geo_feat_dim <= 1024 && n_points >= 0, "refnerf_forward: bad shape");
+  if (n_points == 0) return 0;
+  RefCombineArgs a;
+  memset(&a, 0, sizeof(a));
+  a.h = RefHeads{w_d, b_d, w_t, b_t};
+  a.s_rgb = s_rgb;
+  a.feat = feat;
+  a.n_points = n_points;
+  a.gf = geo_feat_dim;
+  a.rgb_padding = rgb_padding;
+  a.rgb = rgb;
+  refnerf_fwd_kernel<<<(unsigned)std::min<int64_t>((n_points + 3) / 4, 8192), 256, 0, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int sdfhip_refnerf_backward(const float* s_rgb, const float* feat, const float* w_d, const float* b_d, const float* w_t,
+                                       const float* b_t, int64_t n_points, int32_t geo_feat_dim, float rgb_padding, const float* rgb_bar,
+                                       void* workspace, float* s_bar, float* feat_bar, float* w_d_bar, float* b_d_bar, float* w_t_bar,
+                                       float* b_t_bar, sdfhip_stream_t stream) {
+  SDFHIP_REQUIRE(s_rgb && feat && w_d && b_d && rgb_bar && workspace && s_bar && feat_bar && w_d_bar && b_d_bar &&
+                     (w_t == nullptr) == (b_t == nullptr) && (w_t == nullptr) == (w_t_bar == nullptr) && (w_t == nullptr) == (b_t_bar == nullptr),
+                 "refnerf_backward: null argument");
+  SDFHIP_REQUIRE(geo_feat_dim >= 1 && geo_feat_dim <= 1024 && n_points >= 0, "refnerf_backward: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nb = (n_points + kRefChunk - 1) / kRefChunk;
+  float* delta = (float*)workspace;
+  float* partial = delta + ((n_points * 8 + 63) / 64 * 64);
+  if (n_points > 0) {
+    RefCombineBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.h = RefHeads{w_d, b_d, w_t, b_t};
+    a.s_rgb = s_rgb;
+    a.feat = feat;
+    a.rgb_bar = rgb_bar;
+    a.n_points = n_points;
+    a.gf = geo_feat_dim;
+    a.rgb_padding = rgb_padding;
+    a.s_bar = s_bar;
+    a.feat_bar = feat_bar;
+    a.delta = delta;
+    refnerf_bwd_kernel<<<(unsigned)std::min<int64_t>((n_points + 3) / 4, 8192), 256, 0, s>>>(a);
+    RefWgradArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    wa.delta = delta;
+    wa.feat = feat;
+    wa.n_points = n_points;
+    wa.gf = geo_feat_dim;
+    wa.chunk = kRefChunk;
+    wa.partial = partial;
+    refnerf_wgrad_kernel<<<(unsigned)nb, (unsigned)((geo_feat_dim + 63) / 64 * 64), 0, s>>>(wa);
+  }
+  const int total = 6 * (geo_feat_dim + 1);
+  refnerf_wreduce_kernel<<<(total + 255) / 256, 256, 0, s>>>(partial, (int)nb, geo_feat_dim, w_d_bar, b_d_bar, w_t_bar, b_t_bar);
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }

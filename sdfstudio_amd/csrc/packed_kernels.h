@@ -16,6 +16,9 @@ struct MarchArgs {
   float roi_min[3], roi_max[3];
   int32_t N, R;
   float step;             // dt of every sample (cone_angle = 0: nerfacc's calc_dt clamps to dt_min = step)
+  const float* step_dev;  // or null: the step as a DEVICE scalar (overrides `step`): NeuS-acc derives it from a trained parameter every
+                          // iteration (ray_samplers.py:1379-1382: 14 / inv_s / 16) - read here, the host never has to
+  int64_t capacity;       // write pass: samples at packed positions >= capacity are dropped (< 0: no bound)
   // count pass: counts [N].  write pass: offsets [N] (exclusive scan of the counts) -> ray_indices / t_starts / t_ends [P]
   int32_t* counts;
   const int64_t* offsets;
@@ -56,9 +59,11 @@ SDFHIP_D float march_advance(const MarchArgs& a, float t, const float x, const f
 
 // thread per ray.  WRITE = false: count the samples; WRITE = true: emit them at the ray's offset
 template <bool WRITE>
-__global__ void march_kernel(const MarchArgs a) {
+__global__ void march_kernel(const MarchArgs a_in) {
   const int ray = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ray >= a.N) return;
+  if (ray >= a_in.N) return;
+  MarchArgs a = a_in;
+  if (a.step_dev != nullptr) a.step = *a.step_dev;
   const float o[3] = {a.origins[ray * 3], a.origins[ray * 3 + 1], a.origins[ray * 3 + 2]};
   const float d[3] = {a.dirs[ray * 3], a.dirs[ray * 3 + 1], a.dirs[ray * 3 + 2]};
   const float inv_d[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
@@ -72,9 +77,11 @@ __global__ void march_kernel(const MarchArgs a) {
     const float x = __builtin_fmaf(tm, d[0], o[0]), y = __builtin_fmaf(tm, d[1], o[1]), z = __builtin_fmaf(tm, d[2], o[2]);
     if (march_occupied(a, x, y, z)) {
       if constexpr (WRITE) {
-        a.ray_indices[base + j] = ray;
-        a.t_starts[base + j] = t0;
-        a.t_ends[base + j] = t1;
+        if (a.capacity < 0 || base + j < a.capacity) {
+          a.ray_indices[base + j] = ray;
+          a.t_starts[base + j] = t0;
+          a.t_ends[base + j] = t1;
+        }
       }
       ++j;
       t0 = t1;

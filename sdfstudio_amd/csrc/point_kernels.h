@@ -130,6 +130,77 @@ SDFHIP_D bool wave_run_reduce(const uint32_t idx, const bool active, float& v0, 
   return active && ((lane == 63) || (next != key));
 }
 
+// ---- positional encoding of the geometry network's input (NeRFEncoding, field_components/encodings.py:118-208; include_input = False)
+// `pe_code` = number of frequencies | (off_axis << 8).  Axis-aligned: the 3 coordinates; off_axis (:160,:191, the bakedsdf / bakedangelo
+// field settings, configs/method_configs.py:270-286): the projections on the 21 icosahedron directions of self.P (:139-163).  Columns of the
+// block (after the 3 raw coordinates): sin(p_j 2^f) at j * nf + f, then sin(p_j 2^f + pi / 2) at na * nf + j * nf + f.
+constexpr int kPeOffAxis = 0x100;
+SDFHIP_HD int pe_freqs(const int pe_code) { return pe_code & 0xff; }
+SDFHIP_HD int pe_axes(const int pe_code) { return (pe_code & kPeOffAxis) ? 21 : 3; }
+SDFHIP_HD int pe_cols(const int pe_code) { return 2 * pe_axes(pe_code) * pe_freqs(pe_code); }
+__device__ __constant__ static const float kPeDirs[21][3] = {
+    {0.8506508f, 0.f, 0.5257311f},    {0.809017f, 0.5f, 0.309017f},    {0.5257311f, 0.8506508f, 0.f},  {1.f, 0.f, 0.f},
+    {0.809017f, 0.5f, -0.309017f},    {0.8506508f, 0.f, -0.5257311f},  {0.309017f, 0.809017f, -0.5f},  {0.f, 0.5257311f, -0.8506508f},
+    {0.5f, 0.309017f, -0.809017f},    {0.f, 1.f, 0.f},                 {-0.5257311f, 0.8506508f, 0.f}, {-0.309017f, 0.809017f, -0.5f},
+    {0.f, 0.5257311f, 0.8506508f},    {-0.309017f, 0.809017f, 0.5f},   {0.309017f, 0.809017f, 0.5f},   {0.5f, 0.309017f, 0.809017f},
+    {0.5f, -0.309017f, 0.809017f},    {0.f, 0.f, 1.f},                 {-0.5f, 0.309017f, 0.809017f},  {-0.809017f, 0.5f, 0.309017f},
+    {-0.809017f, 0.5f, -0.309017f}};
+// the j-th encoded coordinate of v
+SDFHIP_D float pe_project(const int pe_code, const float v[3], const int j) {
+  if (!(pe_code & kPeOffAxis)) return v[j];
+  return (v[0] * kPeDirs[j][0] + v[1] * kPeDirs[j][1]) + v[2] * kPeDirs[j][2];
+}
+// g += (d p_j / d v)^T s
+SDFHIP_D void pe_project_T(const int pe_code, const int j, const float s, float g[3]) {
+  if (!(pe_code & kPeOffAxis)) {
+    g[j] += s;
+    return;
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) g[d] = fmaf(kPeDirs[j][d], s, g[d]);
+}
+
+// ---- the colour network's small-input block (sdf_field.py:532-612 get_colors).  Column order = the reference's torch.cat order with the
+// geometry feature taken out (it travels as its own blocks): [x (3)] [D (27): direction encoding of the view direction - or of the
+// REFLECTED direction, use_reflections] [d sdf / dx (3)] [appearance embedding] [n . v (1), use_n_dot_v]; with use_diffuse_color x and the
+// gradient are not inputs (:566-571).  Offsets; -1 = absent.
+constexpr int kRefDiffuse = 1, kRefTint = 2, kRefReflect = 4, kRefNdotV = 8;
+struct CsmallLayout {
+  int x, D, g, emb, ndv, width;
+};
+SDFHIP_HD CsmallLayout csmall_layout(const int flags, const int emb_dim) {
+  CsmallLayout L;
+  int c = 0;
+  const bool diffuse = (flags & kRefDiffuse) != 0;
+  L.x = diffuse ? -1 : c;
+  c += diffuse ? 0 : 3;
+  L.D = c;
+  c += 27;
+  L.g = diffuse ? -1 : c;
+  c += diffuse ? 0 : 3;
+  L.emb = c;
+  c += emb_dim;
+  L.ndv = (flags & kRefNdotV) ? c : -1;
+  c += (flags & kRefNdotV) ? 1 : 0;
+  L.width = c;
+  return L;
+}
+// normal n = g / max(|g|, 1e-12) (F.normalize, :543), c = n . d, and the direction the encoding D takes: d, or 2 (n . -d) n + d (:547)
+struct RefGeom {
+  float n[3], inv_len, c, r[3];
+};
+SDFHIP_D RefGeom ref_geom(const int flags, const float g[3], const float d[3]) {
+  RefGeom R;
+  const float len = sqrtf((g[0] * g[0] + g[1] * g[1]) + g[2] * g[2]);
+  R.inv_len = 1.0f / fmaxf(len, 1e-12f);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) R.n[k] = g[k] * R.inv_len;
+  R.c = (R.n[0] * d[0] + R.n[1] * d[1]) + R.n[2] * d[2];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) R.r[k] = (flags & kRefReflect) ? 2.0f * (-R.c) * R.n[k] + d[k] : d[k];
+  return R;
+}
+
 struct EncodeArgs {
   GridDev grid;
   const float* origins;  // [N,3] (or [P,3] positions when dirs == null)
@@ -183,7 +254,7 @@ __global__ __launch_bounds__(256) void geo_encode_kernel(const EncodeArgs a) {
   const int L = a.grid.n_levels, F = a.grid.n_features, pairs = F >> 1;
   const int yy = (int)blockIdx.y - 1;
   const int level = yy / pairs, pair = yy % pairs;
-  const int pe_dims = 6 * a.pe_degree;
+  const int pe_dims = pe_cols(a.pe_degree);
   const int feat0 = 3 + pe_dims;
   if (yy < 0) {
     // position + positional encoding + zero padding  (encodings.py:167-208: sin(cat[x f, x f + pi/2]))
@@ -192,14 +263,17 @@ __global__ __launch_bounds__(256) void geo_encode_kernel(const EncodeArgs a) {
     a.x_out[p * 3 + 2] = x[2];
 #pragma unroll
     for (int d = 0; d < 3; ++d) a.in0_tp[tp_index(p, d, a.nb0)] = x[d];
-    for (int d = 0; d < 3; ++d)
-      for (int f = 0; f < a.pe_degree; ++f) {
-        const float u = x[d] * (float)(1 << f);
+    const int nf = pe_freqs(a.pe_degree), na = pe_axes(a.pe_degree);
+    for (int j = 0; j < na; ++j) {
+      const float pj = pe_project(a.pe_degree, x, j);
+      for (int f = 0; f < nf; ++f) {
+        const float u = pj * (float)(1 << f);
         const float s1 = (live && a.use_pe) ? sinf(u) : 0.0f;
         const float s2 = (live && a.use_pe) ? sinf(u + 1.57079632679489661923f) : 0.0f;
-        a.in0_tp[tp_index(p, 3 + d * a.pe_degree + f, a.nb0)] = s1;
-        a.in0_tp[tp_index(p, 3 + 3 * a.pe_degree + d * a.pe_degree + f, a.nb0)] = s2;
+        a.in0_tp[tp_index(p, 3 + j * nf + f, a.nb0)] = s1;
+        a.in0_tp[tp_index(p, 3 + na * nf + j * nf + f, a.nb0)] = s2;
       }
+    }
     for (int c = feat0 + L * a.grid.n_features; c < a.nb0 * 32; ++c) a.in0_tp[tp_index(p, c, a.nb0)] = 0.0f;
     return;
   }
@@ -254,7 +328,7 @@ __global__ __launch_bounds__(256) void geo_encode8_kernel(const EncodeArgs a) {
   if (live) encode_position(a, p, x);
   const int L = a.grid.n_levels;
   const int level = (int)blockIdx.y - 1;  // y = 0: the position / positional-encoding block, first (see geo_encode_kernel)
-  const int pe_dims = 6 * a.pe_degree;
+  const int pe_dims = pe_cols(a.pe_degree);
   const int feat0 = 3 + pe_dims;
   if (level < 0) {
     a.x_out[p * 3 + 0] = x[0];
@@ -262,14 +336,17 @@ __global__ __launch_bounds__(256) void geo_encode8_kernel(const EncodeArgs a) {
     a.x_out[p * 3 + 2] = x[2];
 #pragma unroll
     for (int d = 0; d < 3; ++d) a.in0_tp[tp_index(p, d, a.nb0)] = x[d];
-    for (int d = 0; d < 3; ++d)
-      for (int f = 0; f < a.pe_degree; ++f) {
-        const float u = x[d] * (float)(1 << f);
+    const int nf = pe_freqs(a.pe_degree), na = pe_axes(a.pe_degree);
+    for (int j = 0; j < na; ++j) {
+      const float pj = pe_project(a.pe_degree, x, j);
+      for (int f = 0; f < nf; ++f) {
+        const float u = pj * (float)(1 << f);
         const float s1 = (live && a.use_pe) ? sinf(u) : 0.0f;
         const float s2 = (live && a.use_pe) ? sinf(u + 1.57079632679489661923f) : 0.0f;
-        a.in0_tp[tp_index(p, 3 + d * a.pe_degree + f, a.nb0)] = s1;
-        a.in0_tp[tp_index(p, 3 + 3 * a.pe_degree + d * a.pe_degree + f, a.nb0)] = s2;
+        a.in0_tp[tp_index(p, 3 + j * nf + f, a.nb0)] = s1;
+        a.in0_tp[tp_index(p, 3 + na * nf + j * nf + f, a.nb0)] = s2;
       }
+    }
     for (int c = feat0 + L * 8; c < a.nb0 * 32; ++c) a.in0_tp[tp_index(p, c, a.nb0)] = 0.0f;
     return;
   }
@@ -329,10 +406,13 @@ struct AssembleArgs {
   const float* dirs;    // [N,3]
   const float* emb;     // [N][emb_dim] per-ray appearance embedding or null (zeros)
   int64_t n_points, n_padded;
-  int32_t S, pe_degree, use_pe, n_feat, nb0, nbs, emb_dim, pad_;
+  int32_t S, pe_degree, use_pe, n_feat, nb0, nbs, emb_dim;
+  int32_t ref_flags;    // kRef*: the ref-nerf options of get_colors (sdf_field.py:536-549, 566-583)
   float* grad;          // [n_padded][3]  (null with grad_in)
   float* csmall_tp;     // [T][nbs]
   const float* grad_in; // [P][3] or null: take d sdf / dx from the caller instead of assembling it from e_tp (numerical gradients)
+  float* g_save;        // [n_padded][3] or null: d sdf / dx and the ray direction per point, kept for the backward of the ref-nerf
+  float* d_save;        // [n_padded][3] or null  inputs that depend on the normal (bwd_prep_kernel)
 };
 
 // block = 256 threads over points
@@ -348,16 +428,19 @@ __global__ __launch_bounds__(256) void grad_assemble_kernel(const AssembleArgs a
       g[d] = a.grad_in != nullptr ? a.grad_in[p * 3 + d] : a.e_tp[tp_index(p, d, a.nb0)];
     }
     if (a.use_pe && a.grad_in == nullptr) {
-      for (int d = 0; d < 3; ++d)
-        for (int f = 0; f < a.pe_degree; ++f) {
+      const int nf = pe_freqs(a.pe_degree), na = pe_axes(a.pe_degree);
+      for (int j = 0; j < na; ++j) {
+        const float pj = pe_project(a.pe_degree, x, j);
+        for (int f = 0; f < nf; ++f) {
           const float fr = (float)(1 << f);
-          const float u = x[d] * fr;
-          const float e1 = a.e_tp[tp_index(p, 3 + d * a.pe_degree + f, a.nb0)];
-          const float e2 = a.e_tp[tp_index(p, 3 + 3 * a.pe_degree + d * a.pe_degree + f, a.nb0)];
-          g[d] += fr * (cosf(u) * e1 + cosf(u + 1.57079632679489661923f) * e2);
+          const float u = pj * fr;
+          const float e1 = a.e_tp[tp_index(p, 3 + j * nf + f, a.nb0)];
+          const float e2 = a.e_tp[tp_index(p, 3 + na * nf + j * nf + f, a.nb0)];
+          pe_project_T(a.pe_degree, j, fr * (cosf(u) * e1 + cosf(u + 1.57079632679489661923f) * e2), g);
         }
+      }
     }
-    const int feat0 = 3 + 6 * a.pe_degree;
+    const int feat0 = 3 + pe_cols(a.pe_degree);
     for (int c = 0; c < (a.grad_in == nullptr ? a.n_feat : 0); ++c) {
       const float ec = a.e_tp[tp_index(p, feat0 + c, a.nb0)] * a.mask[c] * 0.25f;
 #pragma unroll
@@ -371,59 +454,129 @@ __global__ __launch_bounds__(256) void grad_assemble_kernel(const AssembleArgs a
 #pragma unroll
     for (int d = 0; d < 3; ++d) a.grad[p * 3 + d] = g[d];
   }
-  // colour-network small inputs: x(3) | PE(dir): sin(d 2^f) (12), sin(d 2^f + pi/2) (12), d (3) | grad (3) | emb
+  if (a.g_save != nullptr) {
 #pragma unroll
-  for (int d = 0; d < 3; ++d) a.csmall_tp[tp_index(p, d, a.nbs)] = x[d];
+    for (int d = 0; d < 3; ++d) {
+      a.g_save[p * 3 + d] = g[d];
+      a.d_save[p * 3 + d] = dir[d];
+    }
+  }
+  // colour-network small inputs (csmall_layout): [x] | D = PE(r): sin(r 2^f) (12), sin(r 2^f + pi/2) (12), r (3) | [grad] | emb | [n . v]
+  const CsmallLayout L = csmall_layout(a.ref_flags, a.emb_dim);
+  RefGeom R;
+  if (a.ref_flags & (kRefReflect | kRefNdotV)) R = ref_geom(a.ref_flags, g, dir);
+  else {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) R.r[d] = dir[d];
+  }
+  if (L.x >= 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) a.csmall_tp[tp_index(p, L.x + d, a.nbs)] = x[d];
+  }
   for (int d = 0; d < 3; ++d)
     for (int f = 0; f < 4; ++f) {
-      const float u = dir[d] * (float)(1 << f);
-      a.csmall_tp[tp_index(p, 3 + d * 4 + f, a.nbs)] = live ? sinf(u) : 0.0f;
-      a.csmall_tp[tp_index(p, 15 + d * 4 + f, a.nbs)] = live ? sinf(u + 1.57079632679489661923f) : 0.0f;
+      const float u = R.r[d] * (float)(1 << f);
+      a.csmall_tp[tp_index(p, L.D + d * 4 + f, a.nbs)] = live ? sinf(u) : 0.0f;
+      a.csmall_tp[tp_index(p, L.D + 12 + d * 4 + f, a.nbs)] = live ? sinf(u + 1.57079632679489661923f) : 0.0f;
     }
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    a.csmall_tp[tp_index(p, 27 + d, a.nbs)] = dir[d];
-    a.csmall_tp[tp_index(p, 30 + d, a.nbs)] = g[d];
+    a.csmall_tp[tp_index(p, L.D + 24 + d, a.nbs)] = live ? R.r[d] : 0.0f;
+    if (L.g >= 0) a.csmall_tp[tp_index(p, L.g + d, a.nbs)] = g[d];
   }
   for (int j = 0; j < a.emb_dim; ++j) {
     float v = 0.0f;
     if (live && a.emb != nullptr) v = a.emb[(p / a.S) * a.emb_dim + j];
-    a.csmall_tp[tp_index(p, 33 + j, a.nbs)] = v;
+    a.csmall_tp[tp_index(p, L.emb + j, a.nbs)] = v;
   }
-  for (int c = 33 + a.emb_dim; c < a.nbs * 32; ++c) a.csmall_tp[tp_index(p, c, a.nbs)] = 0.0f;
+  if (L.ndv >= 0) a.csmall_tp[tp_index(p, L.ndv, a.nbs)] = live ? R.c : 0.0f;
+  for (int c = L.width; c < a.nbs * 32; ++c) a.csmall_tp[tp_index(p, c, a.nbs)] = 0.0f;
 }
 
 struct BwdPrepArgs {
   const float* gradbar;       // [P][3] upstream d L / d (d sdf/dx)  or null
   const float* sdfbar_in;     // [P] upstream or null
-  const float* csmallbar_tp;  // [T][nbs] from the colour backward (grad slots 30..32) or null
+  const float* csmallbar_tp;  // [T][nbs] from the colour backward or null
   const float* x;
   const float* dydp;
   const float* mask;
   int64_t n_points, n_padded;
   int32_t pe_degree, use_pe, n_feat, nb0, nbs, emb_dim;
-  int32_t S, pad_;
+  int32_t S, ref_flags;
+  const float* d_pt;          // [n_padded][3] ray direction and d sdf / dx per point (AssembleArgs::d_save / g_save; ref-nerf options only: the
+  const float* g_pt;          // [n_padded][3] normal enters the colour inputs through the reflected direction and n . v - sdf_field.py:543-549,
+                              //               580-583 - and their cotangents come back through it)
   float* gtot;       // [n_padded][3]
   float* ebar_tp;    // [T][nb0]
   float* sdfbar;     // [n_padded]
   float* embbar;     // [N][emb_dim] accumulated with atomics, or null
 };
 
+// d L / d (d sdf / dx) out of the colour backward's small-input cotangents: the gradient slot itself (when it is an input), plus - with
+// use_reflections / use_n_dot_v - the chain through the reflected direction's encoding and n . v back to the normal and through F.normalize
+SDFHIP_D void csmall_grad_cotangent(const float* __restrict__ csmallbar_tp, const int64_t p, const int nbs, const int flags, const CsmallLayout& L,
+                                    const float g[3], const float dir[3], float gb[3]) {
+  if (L.g >= 0) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) gb[d] += csmallbar_tp[tp_index(p, L.g + d, nbs)];
+  }
+  if (!(flags & (kRefReflect | kRefNdotV))) return;
+  const RefGeom R = ref_geom(flags, g, dir);
+  float nbar[3] = {0.f, 0.f, 0.f};
+  if (flags & kRefReflect) {
+    float rbar[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      float acc = csmallbar_tp[tp_index(p, L.D + 24 + d, nbs)];
+      for (int f = 0; f < 4; ++f) {
+        const float fr = (float)(1 << f);
+        const float u = R.r[d] * fr;
+        acc += fr * (cosf(u) * csmallbar_tp[tp_index(p, L.D + d * 4 + f, nbs)] +
+                     cosf(u + 1.57079632679489661923f) * csmallbar_tp[tp_index(p, L.D + 12 + d * 4 + f, nbs)]);
+      }
+      rbar[d] = acc;
+    }
+    const float nr = (R.n[0] * rbar[0] + R.n[1] * rbar[1]) + R.n[2] * rbar[2];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) nbar[d] = -2.0f * (nr * dir[d] + R.c * rbar[d]);  // r = d - 2 (n . d) n
+  }
+  if (flags & kRefNdotV) {
+    const float cb = csmallbar_tp[tp_index(p, L.ndv, nbs)];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) nbar[d] = fmaf(cb, dir[d], nbar[d]);
+  }
+  const float len2 = (g[0] * g[0] + g[1] * g[1]) + g[2] * g[2];
+  const float nn = len2 > 1e-24f ? (R.n[0] * nbar[0] + R.n[1] * nbar[1]) + R.n[2] * nbar[2] : 0.0f;  // clamped denominator: n = g / eps is linear
+#pragma unroll
+  for (int d = 0; d < 3; ++d) gb[d] += (nbar[d] - R.n[d] * nn) * R.inv_len;
+}
+
 __global__ __launch_bounds__(256) void bwd_prep_kernel(const BwdPrepArgs a) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= a.n_padded) return;
   const bool live = p < a.n_points;
+  const CsmallLayout L = csmall_layout(a.ref_flags, a.emb_dim);
   float gb[3] = {0.f, 0.f, 0.f}, x[3] = {0.f, 0.f, 0.f};
   if (live) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       x[d] = a.x[p * 3 + d];
       if (a.gradbar != nullptr) gb[d] = a.gradbar[p * 3 + d];
-      if (a.csmallbar_tp != nullptr) gb[d] += a.csmallbar_tp[tp_index(p, 30 + d, a.nbs)];
+    }
+    if (a.csmallbar_tp != nullptr) {
+      float g[3] = {0.f, 0.f, 0.f}, dir[3] = {0.f, 0.f, 0.f};
+      if (a.ref_flags & (kRefReflect | kRefNdotV)) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          g[d] = a.g_pt[p * 3 + d];
+          dir[d] = a.d_pt[p * 3 + d];
+        }
+      }
+      csmall_grad_cotangent(a.csmallbar_tp, p, a.nbs, a.ref_flags, L, g, dir, gb);
     }
     if (a.embbar != nullptr && a.csmallbar_tp != nullptr) {
       for (int j = 0; j < a.emb_dim; ++j)
-        atomicAdd(a.embbar + (p / a.S) * a.emb_dim + j, a.csmallbar_tp[tp_index(p, 33 + j, a.nbs)]);
+        atomicAdd(a.embbar + (p / a.S) * a.emb_dim + j, a.csmallbar_tp[tp_index(p, L.emb + j, a.nbs)]);
     }
   }
   a.sdfbar[p] = (live && a.sdfbar_in != nullptr) ? a.sdfbar_in[p] : 0.0f;
@@ -432,16 +585,21 @@ __global__ __launch_bounds__(256) void bwd_prep_kernel(const BwdPrepArgs a) {
     a.gtot[p * 3 + d] = gb[d];
     a.ebar_tp[tp_index(p, d, a.nb0)] = gb[d];
   }
-  for (int d = 0; d < 3; ++d)
-    for (int f = 0; f < a.pe_degree; ++f) {
-      const float fr = (float)(1 << f);
-      const float u = x[d] * fr;
-      const float c1 = (live && a.use_pe) ? fr * cosf(u) * gb[d] : 0.0f;
-      const float c2 = (live && a.use_pe) ? fr * cosf(u + 1.57079632679489661923f) * gb[d] : 0.0f;
-      a.ebar_tp[tp_index(p, 3 + d * a.pe_degree + f, a.nb0)] = c1;
-      a.ebar_tp[tp_index(p, 3 + 3 * a.pe_degree + d * a.pe_degree + f, a.nb0)] = c2;
+  {
+    const int nf = pe_freqs(a.pe_degree), na = pe_axes(a.pe_degree);
+    for (int j = 0; j < na; ++j) {
+      const float pj = pe_project(a.pe_degree, x, j), gbj = pe_project(a.pe_degree, gb, j);
+      for (int f = 0; f < nf; ++f) {
+        const float fr = (float)(1 << f);
+        const float u = pj * fr;
+        const float c1 = (live && a.use_pe) ? fr * cosf(u) * gbj : 0.0f;
+        const float c2 = (live && a.use_pe) ? fr * cosf(u + 1.57079632679489661923f) * gbj : 0.0f;
+        a.ebar_tp[tp_index(p, 3 + j * nf + f, a.nb0)] = c1;
+        a.ebar_tp[tp_index(p, 3 + na * nf + j * nf + f, a.nb0)] = c2;
+      }
     }
-  const int feat0 = 3 + 6 * a.pe_degree;
+  }
+  const int feat0 = 3 + pe_cols(a.pe_degree);
   for (int c = 0; c < a.n_feat; ++c) {
     float v = 0.0f;
     if (live) {
@@ -518,7 +676,7 @@ __global__ __launch_bounds__(256) void grid_bwd_kernel(const GridBwdArgs a) {
   const int level = blockIdx.y / pairs, pair = blockIdx.y % pairs, c0 = level * F + pair * 2;
   const float m0 = a.mask[c0 + 0], m1 = a.mask[c0 + 1];
   if (m0 == 0.0f && m1 == 0.0f) return;  // block-uniform
-  const int feat0 = 3 + 6 * a.pe_degree;
+  const int feat0 = 3 + pe_cols(a.pe_degree);
   float yb0 = 0.f, yb1 = 0.f, e0 = 0.f, e1 = 0.f, gb[3] = {0.f, 0.f, 0.f}, pp[3] = {0.5f, 0.5f, 0.5f};
   const bool second = a.e_tp != nullptr && a.gtot != nullptr;
   if (live) {
@@ -608,7 +766,7 @@ __global__ __launch_bounds__(256) void grid_bwd8_kernel(const GridBwdArgs a) {
     any |= m[f] != 0.0f;
   }
   if (!any) return;  // block-uniform: a level that is still switched off (progressive levels)
-  const int feat0 = 3 + 6 * a.pe_degree;
+  const int feat0 = 3 + pe_cols(a.pe_degree);
   float yb[8], e8[8], gb[3] = {0.f, 0.f, 0.f}, pp[3] = {0.5f, 0.5f, 0.5f};
   const bool second = a.e_tp != nullptr && a.gtot != nullptr;
 #pragma unroll

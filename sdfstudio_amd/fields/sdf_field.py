@@ -224,10 +224,13 @@ class _FieldFunction(torch.autograd.Function):
         sdf = torch.empty(NP, device=dev)
         grad = torch.empty(NP, 3, device=dev)
         rgb = torch.empty(NP, 3, device=dev)
+        # use_diffuse_color: the geometry feature leaves the node as a fifth, differentiable output (the diffuse / tint heads read it)
+        want_feat = bool(getattr(fld, "_ref_diffuse", False))
+        feat = torch.empty(P, fld.config.geo_feat_dim, device=dev) if want_feat else None
         emb_c = None if emb is None else emb.contiguous()
         _lib.check(lib.sdfhip_field_forward(h, _lib.ptr(packed), _lib.ptr(table), _lib.ptr(mask), _lib.ptr(origins),
                                             _lib.ptr(dirs), _lib.ptr(starts), n, s, _lib.ptr(emb_c), _lib.MODE_FULL, 1 if train else 0,
-                                            ctypes.c_void_p(ws.data_ptr()), _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(rgb), None,
+                                            ctypes.c_void_p(ws.data_ptr()), _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(rgb), _lib.ptr(feat),
                                             _lib.stream()), "field_forward")
         x = ws[: NP * 12].view(torch.float32).view(NP, 3)[:P].view(n, s, 3)  # contracted positions live first in the workspace
         if train:
@@ -237,10 +240,12 @@ class _FieldFunction(torch.autograd.Function):
             x = x.clone()  # lets the workspace go
         ctx.mark_non_differentiable(x)
         ctx.set_materialize_grads(False)  # no zero fill for x's cotangent or an unused head: None travels as NULL (include/sdfhip.h)
+        if want_feat:
+            return sdf[:P].view(n, s), grad[:P].view(n, s, 3), rgb[:P].view(n, s, 3), x, feat
         return sdf[:P].view(n, s), grad[:P].view(n, s, 3), rgb[:P].view(n, s, 3), x
 
     @staticmethod
-    def backward(ctx, sdf_bar, grad_bar, rgb_bar, _x_bar):
+    def backward(ctx, sdf_bar, grad_bar, rgb_bar, _x_bar, feat_bar=None):
         packed, table, mask, ws = ctx.saved_tensors
         lib = _lib.load()
         fld = ctx.fld
@@ -255,13 +260,69 @@ class _FieldFunction(torch.autograd.Function):
 
         # incoming cotangents may be stride-0 expands (e.g. from .sum()): materialise them into locals that outlive the call, a
         # temporary's storage could be recycled for the next argument's copy before the launch reads it
-        sdf_bar_c, grad_bar_c, rgb_bar_c = _contig(sdf_bar), _contig(grad_bar), _contig(rgb_bar)
-        _lib.check(lib.sdfhip_field_backward(h, _lib.ptr(packed), _lib.ptr(table), _lib.ptr(mask), n, s,
-                                             ctypes.c_void_p(ws.data_ptr()), _lib.ptr(sdf_bar_c), _lib.ptr(grad_bar_c),
-                                             _lib.ptr(rgb_bar_c), _lib.ptr(theta_bar), _lib.ptr(table_bar), _lib.ptr(emb_bar),
-                                             _lib.stream()), "field_backward")
-        del sdf_bar_c, grad_bar_c, rgb_bar_c
+        sdf_bar_c, grad_bar_c, rgb_bar_c, feat_bar_c = _contig(sdf_bar), _contig(grad_bar), _contig(rgb_bar), _contig(feat_bar)
+        _lib.check(lib.sdfhip_field_backward_feat(h, _lib.ptr(packed), _lib.ptr(table), _lib.ptr(mask), n, s,
+                                                  ctypes.c_void_p(ws.data_ptr()), _lib.ptr(sdf_bar_c), _lib.ptr(grad_bar_c),
+                                                  _lib.ptr(rgb_bar_c), _lib.ptr(feat_bar_c), _lib.ptr(theta_bar), _lib.ptr(table_bar),
+                                                  _lib.ptr(emb_bar), _lib.stream()), "field_backward")
+        del sdf_bar_c, grad_bar_c, rgb_bar_c, feat_bar_c
         return theta_bar, table_bar, emb_bar, None, None, None, None, None
+
+
+class _RefNerfCombine(torch.autograd.Function):
+    """get_colors' ref-nerf combination (sdf_field.py:536-540, 596-610), use_diffuse_color: the colour network's sigmoid s [N,S,3] and the
+    geometry feature [P, GF] -> clamp(tint * s + sigmoid(W_d feat + b_d - log 3), 0, 1) * (1 + 2 pad) - pad; tint = sigmoid(W_t feat + b_t)
+    with use_specular_tint, else 0.5.  Native both ways (sdfhip_refnerf_forward / _backward: deterministic reductions for the heads)."""
+
+    @staticmethod
+    def forward(ctx, s_rgb, feat, w_d, b_d, w_t, b_t, pad):
+        lib = _lib.load()
+        shape = s_rgb.shape
+        P, gf = feat.shape
+        s_c, f_c = s_rgb.reshape(P, 3).contiguous(), feat.contiguous()
+        wd, bd = w_d.detach().contiguous(), b_d.detach().contiguous()
+        wt = None if w_t is None else w_t.detach().contiguous()
+        bt = None if b_t is None else b_t.detach().contiguous()
+        rgb = torch.empty(P, 3, device=feat.device)
+        _lib.check(lib.sdfhip_refnerf_forward(_lib.ptr(s_c), _lib.ptr(f_c), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(wt), _lib.ptr(bt), P, gf,
+                                              float(pad), _lib.ptr(rgb), _lib.stream()), "refnerf_forward")
+        ctx.save_for_backward(s_c, f_c, wd, bd, wt, bt)
+        ctx.pad, ctx.shape, ctx.params = float(pad), shape, (w_d, b_d, w_t, b_t)
+        return rgb.view(shape)
+
+    @staticmethod
+    def backward(ctx, rgb_bar):
+        s_c, f_c, wd, bd, wt, bt = ctx.saved_tensors
+        lib = _lib.load()
+        P, gf = f_c.shape
+        dev = f_c.device
+        g = rgb_bar.reshape(P, 3).contiguous()
+        ws = torch.empty(lib.sdfhip_refnerf_workspace_size(P, gf), dtype=torch.uint8, device=dev)
+        s_bar, feat_bar = torch.empty(P, 3, device=dev), torch.empty(P, gf, device=dev)
+        wd_bar, bd_bar = torch.empty_like(wd), torch.empty_like(bd)
+        wt_bar = None if wt is None else torch.empty_like(wt)
+        bt_bar = None if bt is None else torch.empty_like(bt)
+        _lib.check(lib.sdfhip_refnerf_backward(_lib.ptr(s_c), _lib.ptr(f_c), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(wt), _lib.ptr(bt), P, gf, ctx.pad,
+                                               _lib.ptr(g), ctypes.c_void_p(ws.data_ptr()), _lib.ptr(s_bar), _lib.ptr(feat_bar), _lib.ptr(wd_bar),
+                                               _lib.ptr(bd_bar), _lib.ptr(wt_bar), _lib.ptr(bt_bar), _lib.stream()), "refnerf_backward")
+        del g
+        return s_bar.view(ctx.shape), feat_bar, wd_bar, bd_bar, wt_bar, bt_bar, None
+
+
+class _PeriodicEncodingStub(nn.Module):
+    """encoding_type = "periodic" with use_grid_feature = False (the configuration SURVEY 8(c) probed config 1 with): the reference builds a
+    PeriodicVolumeEncoding (sdf_field.py:247-256, log2_hashmap_size 18) and NEVER evaluates it - the feature block is n_output_dims zero
+    columns (:389-390).  This stands where it stands: the `hash_table` parameter in the reference's shape and init (encodings.py:655-658),
+    so that state_dict keys and shapes agree both ways, and a zero table the kernels are handed and (all levels masked) never read."""
+
+    def __init__(self, grid_cfg: _lib.GridCfg, num_levels: int, features_per_level: int):
+        super().__init__()
+        self.grid_cfg = grid_cfg
+        levels, n_entries = _lib.grid_levels(grid_cfg)
+        self.levels = levels
+        self.n_output_dims = num_levels * features_per_level
+        self.hash_table = nn.Parameter((torch.rand(size=((1 << 18) * num_levels, features_per_level)) * 2 - 1) * 0.001)
+        self.register_buffer("params", torch.zeros(n_entries * grid_cfg.n_features), persistent=False)
 
 
 class _GeoNetFunction(torch.autograd.Function):
@@ -459,12 +520,14 @@ class SDFField(nn.Module):
         super().__init__()
         c = self.config = config
         unsupported = []
-        if c.encoding_type != "hash":
-            unsupported.append(f"encoding_type={c.encoding_type!r}")
-        if c.use_diffuse_color or c.use_specular_tint or c.use_reflections or c.use_n_dot_v:
-            unsupported.append("ref-nerf colour options")
-        if c.off_axis:
-            unsupported.append("off_axis")
+        if c.encoding_type not in ("hash", "periodic"):
+            unsupported.append(f"encoding_type={c.encoding_type!r}")  # tensorf_vm: no preset, no BASELINE config uses it
+        if c.encoding_type == "periodic" and c.use_grid_feature:
+            # (the reference itself fails there: hash_encoding_mask exists in the "hash" branch only, sdf_field.py:242-245 vs :388)
+            unsupported.append("encoding_type='periodic' with use_grid_feature=True (the reference raises AttributeError on it)")
+        ref_nerf = c.use_diffuse_color or c.use_specular_tint or c.use_reflections or c.use_n_dot_v
+        if ref_nerf and c.use_numerical_gradients:
+            unsupported.append("ref-nerf colour options together with use_numerical_gradients (built on the analytic-normal path)")
         if unsupported:
             raise NotImplementedError("sdfhip does not build: " + ", ".join(unsupported))
         self.aabb = nn.Parameter(torch.as_tensor(aabb, dtype=torch.float32), requires_grad=False)
@@ -486,11 +549,12 @@ class SDFField(nn.Module):
 
         grid_cfg = _lib.GridCfg(c.num_levels, c.hash_features_per_level, c.log2_hashmap_size, c.base_res,
                                 float(self.growth_factor), 1 if c.hash_smoothstep else 0)
-        self.encoding = _HashTable(grid_cfg)
+        self.encoding = _HashTable(grid_cfg) if c.encoding_type == "hash" else _PeriodicEncodingStub(grid_cfg, c.num_levels, c.hash_features_per_level)
         self.hash_encoding_mask = torch.ones(c.num_levels * c.hash_features_per_level, dtype=torch.float32)  # :242-245
 
         # ---- geometry MLP, geometric initialisation (sdf_field.py:279-313)
-        pe_dim = 3 * 2 * c.position_encoding_max_degree
+        # NeRFEncoding(off_axis): the 21 icosahedron directions instead of the 3 axes (field_components/encodings.py:139-163, 180-182)
+        pe_dim = (21 if c.off_axis else 3) * 2 * c.position_encoding_max_degree
         in_dim = 3 + pe_dim + self.encoding.n_output_dims
         dims = [in_dim] + [c.hidden_dim] * c.num_layers + [1 + c.geo_feat_dim]
         self.num_layers = len(dims)
@@ -520,8 +584,20 @@ class SDFField(nn.Module):
         self.laplace_density = LaplaceDensity(init_val=c.beta_init)
         self.deviation_network = SingleVarianceNetwork(init_val=c.beta_init)
 
-        # ---- colour MLP (sdf_field.py:327-363)
-        cin = 3 + 27 + 3 + c.geo_feat_dim + c.appearance_embedding_dim
+        # ---- diffuse / specular-tint heads on the geometry feature (sdf_field.py:332-336: plain Linear layers, default init)
+        if c.use_diffuse_color:
+            self.diffuse_color_pred = nn.Linear(c.geo_feat_dim, 3)
+        if c.use_specular_tint:
+            self.specular_tint_pred = nn.Linear(c.geo_feat_dim, 3)
+        self._ref_diffuse = bool(c.use_diffuse_color)
+
+        # ---- colour MLP (sdf_field.py:338-363)
+        if c.use_diffuse_color:
+            cin = 27 + c.geo_feat_dim + c.appearance_embedding_dim
+        else:
+            cin = 3 + 27 + 3 + c.geo_feat_dim + c.appearance_embedding_dim
+        if c.use_n_dot_v:
+            cin += 1
         cdims = [cin] + [c.hidden_dim_color] * c.num_layers_color + [3]
         self.num_layers_color = len(cdims)
         for l in range(self.num_layers_color - 1):
@@ -539,6 +615,9 @@ class SDFField(nn.Module):
         self._cfg_c = _lib.FieldCfg(c.num_layers, c.hidden_dim, c.geo_feat_dim, c.num_layers_color, c.hidden_dim_color, skip,
                                     c.position_encoding_max_degree, 1 if c.use_position_encoding else 0,
                                     c.appearance_embedding_dim, contract, float(c.rgb_padding), grid_cfg)
+        self._cfg_c.ref_flags = ((_lib.REF_DIFFUSE if c.use_diffuse_color else 0) | (_lib.REF_TINT if c.use_specular_tint else 0) |
+                                 (_lib.REF_REFLECT if c.use_reflections else 0) | (_lib.REF_NDOTV if c.use_n_dot_v else 0))
+        self._cfg_c.pe_off_axis = 1 if c.off_axis else 0
         self._handle_v: Optional[ctypes.c_void_p] = None
         self._lin_names = [f"glin{l}" for l in range(c.num_layers + 1)] + [f"clin{l}" for l in range(c.num_layers_color + 1)]
 
@@ -680,8 +759,8 @@ class SDFField(nn.Module):
             emb = torch.zeros(n, self.config.appearance_embedding_dim, device=x.device)
         field_fn = self if self._cfg_c.contract == 0 else self._uncontracted()
         theta, table, emb = _graph_inputs(self._theta(), self.encoding.params, emb)
-        _, grad, _, _ = _FieldFunction.apply(theta, table, emb, field_fn, x.detach().contiguous(),
-                                             torch.zeros(n, 3, device=x.device), zeros, self._mask(x.device))
+        grad = _FieldFunction.apply(theta, table, emb, field_fn, x.detach().contiguous(),
+                                    torch.zeros(n, 3, device=x.device), zeros, self._mask(x.device))[1]
         gradients = grad.reshape(*shape, 3)
         if return_sdf:
             raise NotImplementedError("return_sdf is the numerical mode's tap values (sdf_field.py:439-453)")
@@ -769,6 +848,17 @@ class SDFField(nn.Module):
             return self.embedding_appearance.mean(dim=0)[None, :].expand(n, -1)
         return None
 
+    def _fused(self, theta, table, emb, o, d, st, mask):
+        """The field node (+ the ref-nerf combination behind it, use_diffuse_color): (sdf, d sdf / dx, rgb, contracted x)."""
+        if not self._ref_diffuse:
+            return _FieldFunction.apply(theta, table, emb, self, o, d, st, mask)
+        sdf, grad, s_rgb, x, feat = _FieldFunction.apply(theta, table, emb, self, o, d, st, mask)
+        dp = self.diffuse_color_pred
+        tp = self.specular_tint_pred if self.config.use_specular_tint else None
+        w_d, b_d, w_t, b_t = _graph_inputs(dp.weight, dp.bias, None if tp is None else tp.weight, None if tp is None else tp.bias)
+        rgb = _RefNerfCombine.apply(s_rgb, feat, w_d, b_d, w_t, b_t, float(self.config.rgb_padding))
+        return sdf, grad, rgb, x
+
     def get_outputs(self, ray_samples, return_alphas=False, return_occupancy=False) -> Dict:
         """sdf_field.py:614-689."""
         if ray_samples.camera_indices is None:
@@ -782,7 +872,7 @@ class SDFField(nn.Module):
             sdf, grad, rgb, x, sampled_sdf = self._numerical_outputs(ray_samples, o, d, st, emb)
         else:
             theta, table, emb = _graph_inputs(self._theta(), self.encoding.params, emb)
-            sdf, grad, rgb, x = _FieldFunction.apply(theta, table, emb, self, o, d, st, self._mask(dev))
+            sdf, grad, rgb, x = self._fused(theta, table, emb, o, d, st, self._mask(dev))
         sdf3 = sdf[..., None]
         outputs = {
             FieldHeadNames.RGB: rgb,
@@ -815,4 +905,4 @@ class SDFField(nn.Module):
             sdf, grad, rgb, x, self.last_sampled_sdf = self._numerical_outputs(ray_samples, o, d, st, emb)
             return sdf, grad, rgb, x
         theta, table, emb = _graph_inputs(self._theta(), self.encoding.params, emb)
-        return _FieldFunction.apply(theta, table, emb, self, o, d, st, self._mask(o.device))
+        return self._fused(theta, table, emb, o, d, st, self._mask(o.device))

@@ -297,7 +297,9 @@ class _PackedWeights(torch.autograd.Function):
     def forward(ctx, alpha, offsets, counts):
         lib = _lib.load()
         alpha = alpha.contiguous()
-        weights, trans = torch.empty_like(alpha), torch.empty_like(alpha)
+        # zeros, not empty: the kernel writes the rays' segments only; with bounded packed arrays (ray_samplers.march_occupancy_grid(capacity))
+        # the tail behind the last segment is a filler whose weight - and, in backward, whose alpha cotangent - must be exactly zero
+        weights, trans = torch.zeros_like(alpha), torch.empty_like(alpha)
         _lib.check(lib.sdfhip_packed_weights_forward(_lib.ptr(alpha), offsets.data_ptr(), counts.data_ptr(), counts.shape[0],
                                                      _lib.ptr(weights), _lib.ptr(trans), _lib.stream()), "packed_weights_forward")
         ctx.save_for_backward(alpha, weights, trans, offsets, counts)
@@ -307,7 +309,7 @@ class _PackedWeights(torch.autograd.Function):
     def backward(ctx, wbar):
         alpha, weights, trans, offsets, counts = ctx.saved_tensors
         lib = _lib.load()
-        abar = torch.empty_like(alpha)
+        abar = torch.zeros_like(alpha)
         kp = _lib.Keep()
         _lib.check(lib.sdfhip_packed_weights_backward(_lib.ptr(alpha), _lib.ptr(weights), _lib.ptr(trans), kp(wbar), offsets.data_ptr(),
                                                       counts.data_ptr(), counts.shape[0], _lib.ptr(abar), _lib.stream()),

@@ -87,6 +87,8 @@ class NeuSModel(NeuSFactoModel):
         loss = surface_losses(outputs["rgb"], image, eik_grad=outputs["eik_grad"], eikonal_mult=c.eikonal_loss_mult,
                               normal_pred=outputs["normal"] if nrm else None, normal_gt=batch["normal"].to(image.device) if nrm else None,
                               normal_mult=c.mono_normal_loss_mult)
+        if "eik_scale" in outputs:  # NeuS-acc's bounded packed arrays: the mean over all entries -> the mean over the valid ones (neus_acc.py)
+            loss["eikonal_loss"] = loss["eikonal_loss"] * outputs["eik_scale"]
         if "fg_mask" in batch and c.fg_mask_loss_mult > 0.0:
             fg = batch["fg_mask"].float().to(image.device)
             loss["fg_mask_loss"] = fg_mask_loss(outputs["weights"].sum(dim=1), fg, c.fg_mask_loss_mult)  # clip + BCE + mean: one launch

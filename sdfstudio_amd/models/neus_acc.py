@@ -65,7 +65,19 @@ class NeuSAccModel(NeuSModel):
             outputs = {"rgb": rgb, "accumulation": accumulation, "depth": depth, "normal": normal, "packed_weights": weights,
                        "ray_indices": ray_indices, "ray_samples": ray_samples}
             if self.training:
-                outputs["eik_grad"] = field_outputs[FieldHeadNames.GRADIENT][:, 0, :]
+                eik = field_outputs[FieldHeadNames.GRADIENT][:, 0, :]
+                n_valid = self.sampler.packed_valid
+                if n_valid is not None:
+                    # bounded packed arrays (NeuSAccSampler(bounded=True)): the filler samples behind the last ray's segment must not enter
+                    # the eikonal mean (base_surface_model.py:406: mean over ALL samples of (|grad| - 1)^2).  They are handed to the loss
+                    # as unit vectors - term 0, cotangent 0 - and the mean over P entries is rescaled to the mean over the valid ones
+                    p_all = eik.shape[0]
+                    valid = torch.arange(p_all, device=dev) < n_valid
+                    unit = torch.zeros(3, device=dev)
+                    unit[0] = 1.0
+                    eik = torch.where(valid[:, None], eik, unit)
+                    outputs["eik_scale"] = p_all / n_valid.clamp(min=1).float()
+                outputs["eik_grad"] = eik
         else:
             zeros = torch.zeros((n_rays, 3), dtype=torch.float32, device=dev)
             outputs = {"rgb": zeros, "accumulation": zeros[:, :1], "depth": zeros[:, :1], "normal": zeros}

@@ -220,8 +220,10 @@ def test_reference_cannot_run_its_non_hash_encodings(ref, enc):
     fld = RefField(cfg, aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_images=3)
     with pytest.raises(AttributeError, match="hash_encoding_mask"):
         fld.forward_geonetwork(torch.rand(5, 3))
+    # what the product refuses is exactly that combination (round 6: "periodic" WITHOUT grid features - which the reference runs, its
+    # encoding then being a block of zero columns - is accepted: tests/test_cpu_refnerf.py); "tensorf_vm" is not built at all
     with pytest.raises(NotImplementedError, match="encoding_type"):
-        SDFField(SDFFieldConfig(encoding_type=enc), torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_images=3)
+        SDFField(SDFFieldConfig(encoding_type=enc, use_grid_feature=True), torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_images=3)
 
 
 @pytest.mark.parametrize("method", ["median", "expected"])

@@ -8,7 +8,7 @@ EXTRA="$@"   # extra bench.py arguments, e.g. --config 5 (tag it r3_cfg5: bench.
 R=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $R
 cd /tmp && export TMPDIR=/tmp
-B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-config5 --no-bigmlp --no-preset --no-neus-acc --no-dense-sdf $EXTRA"  # the headline leg alone (the appended config-5 / 512-wide legs would pollute the per-step sums)
+B="python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-config5 --no-bigmlp --no-preset --no-neus-acc --no-dense-sdf --no-mesh --no-volsdf --no-config4 --no-exchange-n1 $EXTRA"  # the headline leg alone (the appended config-5 / 512-wide legs would pollute the per-step sums)
 BP="$B --no-forward-only --no-kernel-table"  # PMC passes: training steps only, so launches / steps = launches per step
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/kt -o kt -- $B --steps 10 --warmup 3 > $R/kt.log 2>&1
 timeout 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/pmc_fetch -o p -- $BP --steps 2 --warmup 1 > $R/pmc_fetch.log 2>&1
