@@ -160,6 +160,19 @@ def concatenate_meshes(meshes):
     return torch.cat(vs), torch.cat(fs), torch.cat(ns)
 
 
+def _finish_mesh(mesh, output_path, merge: bool):
+    """the reference's tail: [merge_vertices(digits_vertex=6),] export(path) - only when a path is given (the mesh is returned either way)"""
+    if mesh is None or output_path is None:
+        return mesh
+    from sdfstudio_amd.utils import mesh_io
+
+    verts, faces, normals = mesh
+    if merge:
+        verts, faces, normals = mesh_io.merge_vertices(verts, faces, normals, digits_vertex=6)
+    mesh_io.export_ply(output_path, verts, faces, normals)
+    return verts, faces, normals
+
+
 def _coarse_mask_lookup(coarse_mask: torch.Tensor, pts: torch.Tensor) -> torch.Tensor:
     """marching_cubes.py:27-29,68-70,97-101: the scene box's coarse binary grid sampled at points [..., 3] (grid_sample's default
     bilinear lookup on the (z, y, x)-permuted grid, > 0)."""
@@ -171,13 +184,16 @@ def _coarse_mask_lookup(coarse_mask: torch.Tensor, pts: torch.Tensor) -> torch.T
 @torch.no_grad()
 def get_surface_sliding(field, resolution: int = 512, bounding_box_min=(-1.0, -1.0, -1.0), bounding_box_max=(1.0, 1.0, 1.0),
                         return_mesh: bool = True, level: float = 0.0, coarse_mask: Optional[torch.Tensor] = None, crop: int = 512,
-                        device=None, return_volumes: bool = False, sdf: Optional[Callable[[torch.Tensor], torch.Tensor]] = None):
+                        device=None, return_volumes: bool = False, sdf: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
+                        output_path=None):
     """marching_cubes.py:15-168: per crop^3 block (the reference fixes crop = 512) the coarse-to-fine sdf evaluation, then marching cubes
     ON THE DEVICE (libsdfmesh.so), the crop's offset added in double as the reference adds it, the crops concatenated.
     ``field``: an SDFField (its MODE_SDF kernels evaluate the lattice) - or pass ``sdf(points [P,3]) -> [P]`` as the reference does.
     Returns (verts [V,3] float64, faces [F,3] int64, normals [V,3] float32) on the device, or None without a surface;
     return_mesh=False: the list of per-crop (verts, faces, normals); return_volumes=True: the list of (lo, hi, volume [crop^3]).
-    ``level`` is overwritten with 0 as at marching_cubes.py:33.  Not built: merge_vertices + .ply export + pymeshlab simplification."""
+    ``level`` is overwritten with 0 as at marching_cubes.py:33.  ``output_path``: the reference's return_mesh=False branch (:156-160) -
+    merge_vertices(digits_vertex=6) and the binary .ply (utils/mesh_io.py; the merged mesh is returned as well).  pymeshlab's
+    simplification (:161-167) is not built."""
     assert resolution % crop == 0 and crop % 8 == 0
     level = 0.0  # marching_cubes.py:33
     dev = device if device is not None else field.encoding.params.device
@@ -213,16 +229,16 @@ def get_surface_sliding(field, resolution: int = 512, bounding_box_min=(-1.0, -1
                 verts, faces, normals, _ = marching_cubes(vol, level, spacing=spacing, mask=current_mask)
                 verts = verts.double() + torch.tensor(lo, dtype=torch.float64, device=verts.device)
                 results.append((verts, faces, normals))
-    if return_volumes or not return_mesh:
+    if return_volumes or (not return_mesh and output_path is None):
         return results
-    return concatenate_meshes(results)
+    return _finish_mesh(concatenate_meshes(results), output_path, merge=True)
 
 
 @torch.no_grad()
 def get_surface_occupancy(occupancy_fn: Callable[[torch.Tensor], torch.Tensor], resolution: int = 512, bounding_box_min=(-1.0, -1.0, -1.0),
-                          bounding_box_max=(1.0, 1.0, 1.0), level: float = 0.5, device=None, chunk: int = 1 << 22):
+                          bounding_box_max=(1.0, 1.0, 1.0), level: float = 0.5, device=None, chunk: int = 1 << 22, output_path=None):
     """marching_cubes.py:171-216 (UniSurf: occupancy = sigmoid(10 sdf), level 0.5): one resolution^3 lattice, marching cubes on the
-    device.  Returns (verts float64, faces int32, normals) or None ("no surface skip").  The .ply export is not built.
+    device.  Returns (verts float64, faces int32, normals) or None ("no surface skip"); ``output_path``: the .ply as at :212-213 (no merge).
     device = None (the reference's default): the current HIP device - the lattice is evaluated and meshed there (libsdfmesh.so has no host path)."""
     n = int(resolution)
     if device is None:
@@ -235,7 +251,8 @@ def get_surface_occupancy(occupancy_fn: Callable[[torch.Tensor], torch.Tensor], 
         return None
     spacing = tuple((bounding_box_max[a] - bounding_box_min[a]) / (n - 1) for a in range(3))
     verts, faces, normals, _ = marching_cubes(z.reshape(n, n, n), level, spacing=spacing)
-    return verts.double() + torch.tensor(tuple(float(t) for t in bounding_box_min), dtype=torch.float64, device=verts.device), faces, normals
+    verts = verts.double() + torch.tensor(tuple(float(t) for t in bounding_box_min), dtype=torch.float64, device=verts.device)
+    return _finish_mesh((verts, faces, normals), output_path, merge=False)
 
 
 _max_pool_3d = torch.nn.MaxPool3d(3, stride=1, padding=1)
@@ -245,13 +262,16 @@ _max_pool_3d = torch.nn.MaxPool3d(3, stride=1, padding=1)
 def get_surface_sliding_with_contraction(field, resolution: int = 512, bounding_box_min=(-1.0, -1.0, -1.0), bounding_box_max=(1.0, 1.0, 1.0),
                                          coarse_mask: Optional[torch.Tensor] = None, inv_contraction: Optional[Callable] = None,
                                          max_range: float = 32.0, crop: int = 512, device=None,
-                                         sdf: Optional[Callable[[torch.Tensor], torch.Tensor]] = None):
+                                         sdf: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, output_path=None,
+                                         merge: bool = True):
     """marching_cubes.py:218-335 (scenes trained under a scene contraction; scripts/extract_mesh.py:95-107): per crop the sdf is evaluated
     only where the visibility grid ``coarse_mask`` [1, 1, D, H, W] (over the contracted cube [-2, 2]^3, grid_sample's lookup at points / 2)
     is set, everything else starts at 100 and is replaced by the 3^3 minimum of its neighbourhood ("to remove masked marching cube
     artefacts"), marching cubes runs with the crop's mask ON THE DEVICE, and the concatenated vertices go through ``inv_contraction`` and
     the clip to [-max_range, max_range] in double, as the reference applies them.  Level 0 (marching_cubes.py:235).
-    Returns (verts [V,3] float64, faces [F,3] int64, normals [V,3] float32) or None."""
+    Returns (verts [V,3] float64, faces [F,3] int64, normals [V,3] float32) or None.  ``merge``: the reference's
+    ``combined.merge_vertices(digits_vertex=6)`` at :321, BEFORE the inverse contraction, whether or not a file is written (utils/mesh_io.py;
+    merge=False returns the plain concatenation of the crops); ``output_path``: the binary .ply, as at :330-334."""
     assert resolution % crop == 0 and coarse_mask is not None
     level = 0.0
     dev = device if device is not None else field.encoding.params.device
@@ -290,6 +310,10 @@ def get_surface_sliding_with_contraction(field, resolution: int = 512, bounding_
     if mesh is None:
         return None
     verts, faces, normals = mesh
+    if merge:
+        from sdfstudio_amd.utils import mesh_io
+
+        verts, faces, normals = mesh_io.merge_vertices(verts, faces, normals, digits_vertex=6)
     if inv_contraction is not None:
         verts = torch.clamp(inv_contraction(verts), -max_range, max_range)
-    return verts, faces, normals
+    return _finish_mesh((verts, faces, normals), output_path, merge=False)

@@ -411,7 +411,7 @@ def test_get_surface_sliding_with_contraction_mirror(tmp_path, monkeypatch):
         return x_new
 
     kw = dict(resolution=32, bounding_box_min=(-2.0, -2.0, -2.0), bounding_box_max=(2.0, 2.0, 2.0), crop=16, device="cpu", sdf=sdf)
-    got = MC.get_surface_sliding_with_contraction(None, coarse_mask=cm, inv_contraction=inv_contract, max_range=3.0, **kw)
+    got = MC.get_surface_sliding_with_contraction(None, coarse_mask=cm, inv_contraction=inv_contract, max_range=3.0, merge=False, **kw)
     assert got is not None and got[0].dtype == torch.float64
     vs, fs, ns, off = [], [], [], 0
     edges = np.linspace(-2.0, 2.0, 3)
@@ -438,4 +438,78 @@ def test_get_surface_sliding_with_contraction_mirror(tmp_path, monkeypatch):
     assert len(vs) >= 4
     assert np.array_equal(got[0].numpy(), want_v) and np.array_equal(got[1].numpy(), np.concatenate(fs)) and np.array_equal(got[2].numpy(), np.concatenate(ns))
     assert float(np.abs(want_v).max()) == 3.0 or float(np.abs(want_v).max()) < 3.0  # the clip is in force
+    # the reference's default: merge_vertices(digits_vertex=6) before the inverse contraction (:321), then the .ply (:330-334)
+    ply = tmp_path / "contracted.ply"
+    merged = MC.get_surface_sliding_with_contraction(None, coarse_mask=cm, inv_contraction=inv_contract, max_range=3.0, output_path=ply, **kw)
+    assert merged[0].shape[0] <= got[0].shape[0] and merged[1].shape == got[1].shape  # seam vertices merge only where both crops give them the same normal (2 digits)
+    assert np.array_equal(merged[0][merged[1]].numpy().round(5), got[0][got[1]].numpy().round(5))  # the same triangles, corner for corner
+    from sdfstudio_amd.utils import mesh_io
+
+    v, f, nrm = mesh_io.load_ply(ply)
+    assert np.array_equal(v, merged[0].numpy().astype(np.float32)) and np.array_equal(f, merged[1].numpy()) and np.array_equal(nrm, merged[2].numpy())
     assert MC.get_surface_sliding_with_contraction(None, coarse_mask=torch.zeros(1, 1, 4, 4, 4), **kw) is None
+
+
+def test_merge_vertices_and_ply_round_trip(tmp_path):
+    """utils/mesh_io.py (the reference's trimesh tail, marching_cubes.py:159-160: PARITY UNPINNED - trimesh is absent): properties of the
+    merge (first occurrence kept, in input order; faces name the same points; normals split a seam; unreferenced vertices dropped) and
+    the byte layout of the binary .ply (header fields, record sizes, round trip)."""
+    import torch
+
+    from sdfstudio_amd.utils import mesh_io
+
+    verts = torch.tensor([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0],            # triangle A
+                          [1.0, 0.0, 0.0 + 4e-7], [0.0, 1.0, 0.0], [1.0, 1.0, 0.0],      # triangle B: two vertices shared with A (one within 1e-6)
+                          [5.0, 5.0, 5.0],                                               # unreferenced
+                          [1.0, 1.0, 0.0]], dtype=torch.float64)                         # same place as 5, another normal
+    nz = torch.tensor([0.0, 0.0, 1.0])
+    normals = torch.stack([nz, nz, nz, nz, nz, nz, nz, torch.tensor([1.0, 0.0, 0.0])]).float()
+    faces = torch.tensor([[0, 1, 2], [3, 5, 4], [4, 7, 3]], dtype=torch.int32)
+    v, f, n = mesh_io.merge_vertices(verts, faces, normals)
+    assert v.shape[0] == 5 and v.dtype == torch.float64 and f.dtype == torch.int64
+    assert torch.equal(v, verts[[0, 1, 2, 5, 7]]) and torch.equal(n, normals[[0, 1, 2, 5, 7]])  # first occurrences, input order
+    assert f.tolist() == [[0, 1, 2], [1, 3, 2], [2, 4, 1]]
+    v2, f2, _ = mesh_io.merge_vertices(verts, faces, normals, merge_norm=True)  # trimesh's merge_norm=True: normals ignored
+    assert v2.shape[0] == 4 and f2.tolist() == [[0, 1, 2], [1, 3, 2], [2, 3, 1]]
+    v3, f3, n3 = mesh_io.merge_vertices(verts, faces, None)
+    assert n3 is None and v3.shape[0] == 4
+    # idempotent
+    v4, f4, n4 = mesh_io.merge_vertices(v, f, n)
+    assert torch.equal(v4, v) and torch.equal(f4, f) and torch.equal(n4, n)
+    for with_normals in (True, False):
+        path = tmp_path / f"m{int(with_normals)}.ply"
+        mesh_io.export_ply(path, v, f, n if with_normals else None)
+        raw = open(path, "rb").read()
+        head = raw[:raw.index(b"end_header\n")].decode().splitlines()
+        assert head[:2] == ["ply", "format binary_little_endian 1.0"] and "element vertex 5" in head and "element face 3" in head
+        assert "property list uchar int vertex_indices" in head and ("property float nx" in head) == with_normals
+        assert len(raw) == raw.index(b"end_header\n") + 11 + 5 * (24 if with_normals else 12) + 3 * 13
+        lv, lf, ln = mesh_io.load_ply(path)
+        assert np.array_equal(lv, v.numpy().astype(np.float32)) and np.array_equal(lf, f.numpy())
+        assert (ln is None) == (not with_normals) and (ln is None or np.array_equal(ln, n.numpy()))
+    # get_surface_occupancy / get_surface_sliding take output_path
+    from sdfstudio_amd import _mesh
+    from sdfstudio_amd.utils import marching_cubes as MC
+
+    import pytest as _pytest
+    mp = _pytest.MonkeyPatch()
+    try:
+        mp.setattr(_mesh, "marching_cubes_device", _fake_device_call(tmp_path))
+        sdf = lambda p: torch.sqrt((p * p).sum(-1)) - 0.6  # noqa: E731
+        m = MC.get_surface_sliding(None, resolution=32, crop=16, device="cpu", sdf=sdf, return_mesh=False, output_path=tmp_path / "s.ply")
+        plain = MC.get_surface_sliding(None, resolution=32, crop=16, device="cpu", sdf=sdf)
+        assert m[0].shape[0] < plain[0].shape[0] and m[1].shape == plain[1].shape
+        lv, lf, ln = mesh_io.load_ply(tmp_path / "s.ply")
+        assert np.array_equal(lv, m[0].numpy().astype(np.float32)) and np.array_equal(lf, m[1].numpy())
+        # the merge closes crop seams (where both crops give a seam vertex the same normal to 2 digits): fewer open edges than before it
+        def open_edges(fc):
+            e = np.sort(np.concatenate([fc[:, [0, 1]], fc[:, [1, 2]], fc[:, [2, 0]]]), axis=1)
+            e = e[e[:, 0] != e[:, 1]]
+            return int((np.unique(e, axis=0, return_counts=True)[1] == 1).sum())
+
+        assert open_edges(lf) < open_edges(plain[1].numpy())
+        occ = MC.get_surface_occupancy(lambda p: torch.sigmoid(-10 * sdf(p)), resolution=20, device="cpu", output_path=tmp_path / "o.ply")
+        lv, lf, _ = mesh_io.load_ply(tmp_path / "o.ply")
+        assert np.array_equal(lv, occ[0].numpy().astype(np.float32)) and np.array_equal(lf, occ[1].numpy())
+    finally:
+        mp.undo()
