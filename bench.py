@@ -236,7 +236,7 @@ def main():
     ap.add_argument("--full-line", action="store_true", help="print the full (~25 KB) object instead of the compact line (the full object is always "
                                                               "written to gpurun_out/bench_detail.json)")
     ap.add_argument("--no-mesh", action="store_true", help="default (config 2) run: skip the marching-cubes leg appended as \"mesh\" (a child process)")
-    ap.add_argument("--only", default=None, choices=["inference", "exchange"],
+    ap.add_argument("--only", default=None, choices=["inference", "exchange", "volsdf", "config4", "neus_acc"],
                     help="inference: only the forward-only and dense-SDF legs on config 2's model (no training steps; tools/ A/B and PMC runs); "
                          "exchange: only the forced single-rank RCCL exchange legs (what the default run appends as \"exchange_at_n1\")")
     ap.add_argument("--no-exchange-n1", action="store_true", help="default (config 2) run: skip the single-rank RCCL exchange legs (a child process)")
@@ -1142,6 +1142,8 @@ def compact_line(line):
                             "extract_mesh_ms": (me.get("extract_mesh") or {}).get("ms"),
                             "cpu_points_per_s": (me.get("cpu_baseline") or {}).get("value")}
     out["legs"] = legs
+    if line.get("appended_legs"):
+        out["appended_legs"] = line["appended_legs"]
     col = line.get("collective")
     if col:
         c = {k: col[k] for k in ("backend", "exchange", "buckets", "chunk_bytes", "buckets_launched_during_backward",
@@ -1182,10 +1184,14 @@ def run(args):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # RCCL ("nccl") over xGMI; SDFHIP_BENCH_BACKEND=gloo exercises the N > 1 control flow on a single-GPU box
         backend = os.environ.get("SDFHIP_BENCH_BACKEND", "nccl")
+        # a collective that does not complete aborts the run after this long (torch's default: 10 min): a hang costs minutes, not the caller's limit
+        import datetime
+
+        pg_timeout = datetime.timedelta(seconds=int(os.environ.get("SDFHIP_BENCH_PG_TIMEOUT_S", "300")))
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=pg_timeout)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if world > 1:
         print(f"[bench] rank {rank}/{world}: backend {dist.get_backend()}{' (RCCL)' if dist.get_backend() == 'nccl' else ''}, "
@@ -1196,6 +1202,14 @@ def run(args):
     if getattr(args, "only", None) == "exchange":
         assert world == 1, "--only exchange is the N = 1 leg"
         print(json.dumps(exchange_at_n1_legs(device, steps=min(args.steps, 8), warmup=min(args.warmup, 3))), flush=True)
+        return
+    if getattr(args, "only", None) in ("volsdf", "config4", "neus_acc"):
+        # one appended leg alone (same function as in the default run): the rocprofv3 kernel stats of BASELINE configs 1 / 4 and of the
+        # packed path come from these commands (tools/gpu_call_r6p.sh -> profiles/r6_{volsdf,config4,neus_acc}_kernel_stats.csv)
+        leg = {"volsdf": lambda: volsdf_legs(device, world, rank), "config4": lambda: config4_leg(device, world, rank),
+               "neus_acc": lambda: neus_acc_leg(device)}[args.only]()
+        if rank == 0:
+            print(json.dumps({args.only: leg}), flush=True)
         return
     job = make_job(5 if cfg5 else 2, device, world, rank, small=args.small)
     model, flat, groups = job["model"], job["flat"], job["groups"]
@@ -1256,192 +1270,222 @@ def run(args):
         allr = allr[0]
         exposed_by_rank = [round(float(v), 4) for v in allr.tolist()]
     dt = float(t.item())
-    cfg5_extra = None
-    if not cfg5 and not args.small and not args.no_config5:
-        del loss  # the last step's graph (and its 25 GB field workspace) goes back to the allocator
-        cfg5_extra = config5_legs(device, world, rank)
-    bigmlp_extra = None
-    if not cfg5 and not args.small and not args.no_bigmlp:
-        loss = None
-        bigmlp_extra = bigmlp_legs(device, world, rank, dt / args.steps * 1e3)
-    preset_extra = None
-    if not cfg5 and not args.small and not args.no_preset:
-        loss = None
-        preset_extra = preset_leg(device, world, rank)
-    volsdf_extra = None
-    if not cfg5 and not args.small and not args.no_volsdf:
-        loss = None
-        volsdf_extra = volsdf_legs(device, world, rank)
-    cfg4_extra = None
-    if not cfg5 and not args.small and not args.no_config4:
-        cfg4_extra = config4_leg(device, world, rank)
-    acc_extra = None
-    if not cfg5 and not args.small and not args.no_neus_acc and world == 1:
-        acc_extra = neus_acc_leg(device)
-    exch_extra = None
-    if not cfg5 and not args.small and not args.no_exchange_n1 and world == 1 and rank == 0:
-        torch.cuda.empty_cache()  # the child builds config 5's model (12 GB) beside this process
-        env = dict(os.environ)
-        for k in ("SDFHIP_FORCE_EXCHANGE", "SDFHIP_BENCH_EXCHANGE", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
-            env.pop(k, None)
-        exch_extra = child_leg([os.path.join(ROOT, "bench.py"), "--only", "exchange", "--steps", "8", "--warmup", "3"], timeout=600, env=env)
-    mesh_extra = None
-    if not cfg5 and not args.small and not args.no_mesh and world == 1 and rank == 0:
-        torch.cuda.empty_cache()  # the child allocates its own 3.6 GB beside this process
-        mesh_extra = mesh_leg()
+    def run_appended_legs():
+        nonlocal loss
+        cfg5_extra = None
+        if not cfg5 and not args.small and not args.no_config5:
+            del loss  # the last step's graph (and its 25 GB field workspace) goes back to the allocator
+            cfg5_extra = config5_legs(device, world, rank)
+        bigmlp_extra = None
+        if not cfg5 and not args.small and not args.no_bigmlp:
+            loss = None
+            bigmlp_extra = bigmlp_legs(device, world, rank, dt / args.steps * 1e3)
+        preset_extra = None
+        if not cfg5 and not args.small and not args.no_preset:
+            loss = None
+            preset_extra = preset_leg(device, world, rank)
+        volsdf_extra = None
+        if not cfg5 and not args.small and not args.no_volsdf:
+            loss = None
+            volsdf_extra = volsdf_legs(device, world, rank)
+        cfg4_extra = None
+        if not cfg5 and not args.small and not args.no_config4:
+            cfg4_extra = config4_leg(device, world, rank)
+        acc_extra = None
+        if not cfg5 and not args.small and not args.no_neus_acc and world == 1:
+            acc_extra = neus_acc_leg(device)
+        exch_extra = None
+        if not cfg5 and not args.small and not args.no_exchange_n1 and world == 1 and rank == 0:
+            torch.cuda.empty_cache()  # the child builds config 5's model (12 GB) beside this process
+            env = dict(os.environ)
+            for k in ("SDFHIP_FORCE_EXCHANGE", "SDFHIP_BENCH_EXCHANGE", "WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+                env.pop(k, None)
+            exch_extra = child_leg([os.path.join(ROOT, "bench.py"), "--only", "exchange", "--steps", "8", "--warmup", "3"], timeout=600, env=env)
+        mesh_extra = None
+        if not cfg5 and not args.small and not args.no_mesh and world == 1 and rank == 0:
+            torch.cuda.empty_cache()  # the child allocates its own 3.6 GB beside this process
+            mesh_extra = mesh_leg()
 
-    if rank == 0:
-        from sdfstudio_amd import build as _build
+        return (cfg5_extra, bigmlp_extra, preset_extra, volsdf_extra, cfg4_extra, acc_extra, exch_extra, mesh_extra)
 
-        lib_digest = _build.built_digest() or None  # what the loaded libsdfhip.so was built from (sdfstudio_amd/build.py)
-        ms = dt / args.steps * 1e3
-        samples = world * N_RAYS * N_SAMPLES
-        value = samples / (dt / args.steps)
-        g, c = flops_per_sample()
-        train_flops = 6 * g + 3 * c  # fwd G, analytic-normal chain G, its double backward 2G, backward 2G; colour C + 2C
-        if cfg5:  # 1-hidden-layer geometry net on 167 inputs, evaluated 7 x per sample (numerical gradients), no double backward
-            g = 2 * (167 * 256 + 256 * 257)
-            train_flops = 7 * 3 * g + 3 * c
-        P = N_RAYS * N_SAMPLES
-        # dominant kernel: geo_bwd_kernel = tangent pass (G) + data backward (G) of the geometry MLP, two launches per step.
-        # the MLP kernels (K3) are priced against the MATRIX roofline: algorithmic flops (2G per ray-sample for this
-        # kernel) x the 3 split-precision terms actually issued per product, against the dense 16-bit MFMA peak.  The HBM view of
-        # the same launches (the kernel streams saved per-layer tensors) is reported beside it under "hbm", not as `frac`.
-        kt_ms, kn = prof.get("geo_bwd_kernel", (0.0, 0))
-        roof = None
-        pm_dir = os.path.join(ROOT, "profiles")
-        if kn > 0 and not cfg5:
-            avg_s = kt_ms / kn * 1e-3
-            flow_bytes = geo_bwd_algorithmic_bytes() * P
-            traffic, traffic_source, traffic_digest = None, None, None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the bench)
-            cands = sorted(f for f in os.listdir(pm_dir) if f.endswith("_pmc_traffic.json") and "cfg5" not in f)
+    def emit_line(cfg5_extra, bigmlp_extra, preset_extra, volsdf_extra, cfg4_extra, acc_extra, exch_extra, mesh_extra, legs_pending=False):
+        if rank == 0:
+            from sdfstudio_amd import build as _build
+
+            lib_digest = _build.built_digest() or None  # what the loaded libsdfhip.so was built from (sdfstudio_amd/build.py)
+            ms = dt / args.steps * 1e3
+            samples = world * N_RAYS * N_SAMPLES
+            value = samples / (dt / args.steps)
+            g, c = flops_per_sample()
+            train_flops = 6 * g + 3 * c  # fwd G, analytic-normal chain G, its double backward 2G, backward 2G; colour C + 2C
+            if cfg5:  # 1-hidden-layer geometry net on 167 inputs, evaluated 7 x per sample (numerical gradients), no double backward
+                g = 2 * (167 * 256 + 256 * 257)
+                train_flops = 7 * 3 * g + 3 * c
+            P = N_RAYS * N_SAMPLES
+            # dominant kernel: geo_bwd_kernel = tangent pass (G) + data backward (G) of the geometry MLP, two launches per step.
+            # the MLP kernels (K3) are priced against the MATRIX roofline: algorithmic flops (2G per ray-sample for this
+            # kernel) x the 3 split-precision terms actually issued per product, against the dense 16-bit MFMA peak.  The HBM view of
+            # the same launches (the kernel streams saved per-layer tensors) is reported beside it under "hbm", not as `frac`.
+            kt_ms, kn = prof.get("geo_bwd_kernel", (0.0, 0))
+            roof = None
+            pm_dir = os.path.join(ROOT, "profiles")
+            if kn > 0 and not cfg5:
+                avg_s = kt_ms / kn * 1e-3
+                flow_bytes = geo_bwd_algorithmic_bytes() * P
+                traffic, traffic_source, traffic_digest = None, None, None  # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside the bench)
+                cands = sorted(f for f in os.listdir(pm_dir) if f.endswith("_pmc_traffic.json") and "cfg5" not in f)
+                if cands:
+                    tj = newest_matching_json(pm_dir, cands, lib_digest)  # the pass taken on THIS library, else the newest (r1 < r2 < ...)
+                    traffic = tj["hbm_read_bytes"] + tj["hbm_write_bytes"]
+                    traffic_source = tj["source"]
+                    traffic_digest = tj.get("library_digest")
+                flops = 2 * g * P
+                io_bytes = geo_bwd_io_bytes() * P
+                issued = 3 * flops / avg_s / 1e12
+                roof = {"kernel": "geo_bwd_kernel", "bound": "mfma", "achieved": round(issued, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(issued / PEAK_BF16_MFMA_TFLOPS, 4),
+                        "achieved_is": "SURVEY 8(d) algorithmic flops of the kernel (2G = 2.098 MFLOP per ray-sample: tangent pass + data backward) x 3 "
+                                       "issued 16-bit MFMA terms per fp32-class product / launch time (HIP events on the launch stream)",
+                        "algorithmic_tflops": round(flops / avg_s / 1e12, 1), "terms_per_product": 3,
+                        "frac_algorithmic_of_16bit_peak": round(flops / avg_s / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
+                        # the plateau, stated.  `frac` IS the fraction of the ceiling fp32-class products can reach on the
+                        # pipe the kernel runs on (dense 16-bit peak / 3 terms = 833 TFLOP/s); the kernel is HBM-bound on its own saved tensors
+                        "frac_of_fp32_class_ceiling": round(issued / PEAK_BF16_MFMA_TFLOPS, 4), "fp32_class_ceiling_tflops": round(PEAK_BF16_MFMA_TFLOPS / 3, 1),
+                        "ideal_io_bytes": io_bytes, "traffic_over_ideal": None if traffic is None else round(traffic / io_bytes, 1),
+                        "plateau": "0.19 - 0.22 of the pipe it runs on; 1.0 - 1.17 x the fp32-matrix peak an exact-fp32 implementation is bound by; "
+                                   "HBM-bound on saved per-layer tensors (DESIGN.md section 7: the end state of this data flow)",
+                        "frac_algorithmic_of_fp32_matrix_peak": round(flops / avg_s / 1e12 / 157.3, 4),
+                        "traffic": traffic, "traffic_unit": "HBM bytes per step of this kernel (sum of its two launches)", "traffic_source": traffic_source,
+                        # the PMC passes are a separate rocprofv3 run: they describe THIS library only if it was built from the same sources
+                        "traffic_library_digest": traffic_digest, "traffic_stale": traffic is not None and traffic_digest != lib_digest,
+                        "avg_launch_ms": round(kt_ms / kn, 4), "launches": kn,
+                        # the memory side of the same launches
+                        "hbm": {"algorithmic_bytes": io_bytes, "frac_at_algorithmic_bytes": round(io_bytes / avg_s / 1e9 / PEAK_HBM_GBS, 4),
+                                "waste_ratio": round((traffic if traffic else flow_bytes) / io_bytes, 1),
+                                "dataflow_bytes": flow_bytes, "dataflow_GBps": round(flow_bytes / avg_s / 1e9, 1),
+                                "dataflow_frac": round(flow_bytes / avg_s / 1e9 / PEAK_HBM_GBS, 4),
+                                "note": "algorithmic_bytes = what must cross the kernel boundary (SURVEY 8d); dataflow_bytes = the saved per-layer "
+                                        "tensors this data flow reads and writes (DESIGN.md section 4); measured streaming ceilings of this pool: "
+                                        "read 5.5, write 4.0, mixed 5.2 TB/s (profiles/r3_hbm_ceiling.txt)"}}
+            # K1 of SURVEY 8(d), the stage north_star asks rocprof HBM GB/s for: the hash-grid gather of geo_encode_kernel
+            enc_ms, enc_n = prof.get("geo_encode_kernel", (0.0, 0))
+            enc = None
+            if enc_n > 0:
+                if cfg5:
+                    enc = encode_roofline_config5(model, prof, args.steps, P)
+                else:
+                    per_sample, what = 16 * 8 * 2 * 4 + 12 + 128, "1024 B gather + 12 B position + 128 B of features per ray-sample (SURVEY 8d: 1164 B)"
+                    eb = per_sample * P
+                    es = enc_ms / args.steps * 1e-3
+                    enc = {"kernel": "geo_encode_kernel", "bound": "hbm", "achieved": round(eb / es / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                           "frac": round(eb / es / 1e9 / PEAK_HBM_GBS, 4), "algorithmic_bytes": eb, "achieved_is": what + " / its time per step",
+                           "ms_per_step": round(enc_ms / args.steps, 4), "traffic": None}
+                enc.update(encode_step_traffic(lambda f: "_eval" not in f and ("cfg5" in f) == cfg5 and (not cfg5 or ("cfg5l16" in f) == (args.levels == 16))) or {})
+                if cfg5:
+                    roof = enc
+            kernels = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] / args.steps} for k, v in prof.items()}
+            mfma_ms = sum(prof.get(k, (0.0, 0))[0] for k in ("geo_fwd_kernel", "geo_bwd_kernel", "col_fwd_kernel", "col_bwd_kernel",
+                                                             "wgrad_kernel")) / args.steps
+            line = {
+                "library_digest": lib_digest,
+                "metric": f"ray-samples/sec (NeuS-facto train step, {N_RAYS} rays x {N_SAMPLES} samples per GPU)",
+                "value": round(value, 1), "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                "dtype_note": "fp32 tensors and accumulators; matrix products as three 16-bit MFMA terms of hi + lo operand parts: fp16 parts "
+                              "(22 mantissa bits, fp32-class) for everything the forward returns, bf16 parts (2^-17 per product, full exponent "
+                              "range) in the backward kernels and weight-gradient GEMMs",
+                "data": "synthetic", "iters_per_sec": round(1e3 / ms, 3), "per_gpu": round(value / world, 1),
+                "config": {"workload": "SMALL parity configuration (control-flow test only, NOT a benchmark)" if args.small else
+                                       ("BASELINE config 5: neus-facto-angelo preset - hash grid 16x8x2^22 linear (2.1 GB table), 1x256 geo MLP with "
+                                        "numerical SDF gradients (7 evaluations per sample), 4x256 colour MLP, 'grid' background field, progressive "
+                                        f"levels ({'all 16 on: steady state, schedules at step 200 000' if args.levels == 16 else 'level_init 8: schedules at step 0'}), "
+                                        "curvature loss; 2048 rays x 48 samples (+256/96 proposal samples) per GPU per step, "
+                                        "full train step incl. Adam" if cfg5 else
+                                        "BASELINE config 2: NeuS-facto hash-grid 16x2x2^19 smoothstep + 8x256 geo MLP + 4x256 colour MLP, "
+                                        "4096 rays x 128 samples (+256/96 proposal samples) per GPU per step, full train step incl. Adam"),
+                           "rays_per_gpu": N_RAYS, "samples_per_ray": N_SAMPLES,
+                           "parallelism": (f"dp{world} (flat gradient buffer; " + ("sharded exchange: reduce-scatter -> owned-slice Adam -> all-gather" if job["shard"] else
+                                                                                    "bucketed all-reduce") + ", RCCL)") if world > 1 else "single GPU"},
+                "roofline": roof,
+                "encode_roofline": enc,
+                "config5": cfg5_extra,
+                "bigmlp": bigmlp_extra,
+                "preset": preset_extra,
+                "neus_acc": acc_extra,
+                "volsdf": volsdf_extra,
+                "config4": cfg4_extra,
+                "exchange_at_n1": exch_extra,
+                "mesh": mesh_extra,
+                "appended_legs": ("run AFTER this line at N > 1 (config5 / bigmlp / preset / volsdf / config4, each with its own exchange): stderr "
+                                  "'[bench] appended legs' and gpurun_out/bench_detail.json") if legs_pending else None,
+                "collective": None if world == 1 else collective_report(job, dist.get_backend(), exposed_by_rank, exposed_gather_by_rank),
+                "forward_only": fwd_only,
+                "dense_sdf": dense,
+                "final_loss": float(final_loss),
+                "enqueue_vs_gpu": main_split,
+                "model_tflops": round(train_flops * P / (ms * 1e-3) / 1e12, 2),
+                "mfma_kernels_ms_per_step": round(mfma_ms, 3),
+                "kernels": kernels,
+                "kernels_note": f"{dominant}: HIP events inside the timed region; every other entry: a separate untimed pass of {table_steps} "
+                                "steps with events on every launch"
+                                + ("" if instrumented_ms is None else f", which ran at {instrumented_ms:.3f} ms/step (the events' own cost)"),
+            }
+            # whole-step view: model FLOPs (6G + 3C per sample) against the fp32 matrix peak an exact-fp32 implementation would be
+            # bound by, the issued 16-bit MFMA terms (3 per product in every pass) against the dense bf16 / fp16 peak, and the whole
+            # step's HBM bytes from the committed PMC passes
+            step_bytes, step_digest = None, None
+            cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_step_traffic.json") and ("cfg5" in f) == cfg5
+                           and (not cfg5 or ("cfg5l16" in f) == (args.levels == 16)))
             if cands:
-                tj = newest_matching_json(pm_dir, cands, lib_digest)  # the pass taken on THIS library, else the newest (r1 < r2 < ...)
-                traffic = tj["hbm_read_bytes"] + tj["hbm_write_bytes"]
-                traffic_source = tj["source"]
-                traffic_digest = tj.get("library_digest")
-            flops = 2 * g * P
-            io_bytes = geo_bwd_io_bytes() * P
-            issued = 3 * flops / avg_s / 1e12
-            roof = {"kernel": "geo_bwd_kernel", "bound": "mfma", "achieved": round(issued, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(issued / PEAK_BF16_MFMA_TFLOPS, 4),
-                    "achieved_is": "SURVEY 8(d) algorithmic flops of the kernel (2G = 2.098 MFLOP per ray-sample: tangent pass + data backward) x 3 "
-                                   "issued 16-bit MFMA terms per fp32-class product / launch time (HIP events on the launch stream)",
-                    "algorithmic_tflops": round(flops / avg_s / 1e12, 1), "terms_per_product": 3,
-                    "frac_algorithmic_of_16bit_peak": round(flops / avg_s / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4),
-                    # the plateau, stated.  `frac` IS the fraction of the ceiling fp32-class products can reach on the
-                    # pipe the kernel runs on (dense 16-bit peak / 3 terms = 833 TFLOP/s); the kernel is HBM-bound on its own saved tensors
-                    "frac_of_fp32_class_ceiling": round(issued / PEAK_BF16_MFMA_TFLOPS, 4), "fp32_class_ceiling_tflops": round(PEAK_BF16_MFMA_TFLOPS / 3, 1),
-                    "ideal_io_bytes": io_bytes, "traffic_over_ideal": None if traffic is None else round(traffic / io_bytes, 1),
-                    "plateau": "0.19 - 0.22 of the pipe it runs on; 1.0 - 1.17 x the fp32-matrix peak an exact-fp32 implementation is bound by; "
-                               "HBM-bound on saved per-layer tensors (DESIGN.md section 7: the end state of this data flow)",
-                    "frac_algorithmic_of_fp32_matrix_peak": round(flops / avg_s / 1e12 / 157.3, 4),
-                    "traffic": traffic, "traffic_unit": "HBM bytes per step of this kernel (sum of its two launches)", "traffic_source": traffic_source,
-                    # the PMC passes are a separate rocprofv3 run: they describe THIS library only if it was built from the same sources
-                    "traffic_library_digest": traffic_digest, "traffic_stale": traffic is not None and traffic_digest != lib_digest,
-                    "avg_launch_ms": round(kt_ms / kn, 4), "launches": kn,
-                    # the memory side of the same launches
-                    "hbm": {"algorithmic_bytes": io_bytes, "frac_at_algorithmic_bytes": round(io_bytes / avg_s / 1e9 / PEAK_HBM_GBS, 4),
-                            "waste_ratio": round((traffic if traffic else flow_bytes) / io_bytes, 1),
-                            "dataflow_bytes": flow_bytes, "dataflow_GBps": round(flow_bytes / avg_s / 1e9, 1),
-                            "dataflow_frac": round(flow_bytes / avg_s / 1e9 / PEAK_HBM_GBS, 4),
-                            "note": "algorithmic_bytes = what must cross the kernel boundary (SURVEY 8d); dataflow_bytes = the saved per-layer "
-                                    "tensors this data flow reads and writes (DESIGN.md section 4); measured streaming ceilings of this pool: "
-                                    "read 5.5, write 4.0, mixed 5.2 TB/s (profiles/r3_hbm_ceiling.txt)"}}
-        # K1 of SURVEY 8(d), the stage north_star asks rocprof HBM GB/s for: the hash-grid gather of geo_encode_kernel
-        enc_ms, enc_n = prof.get("geo_encode_kernel", (0.0, 0))
-        enc = None
-        if enc_n > 0:
-            if cfg5:
-                enc = encode_roofline_config5(model, prof, args.steps, P)
-            else:
-                per_sample, what = 16 * 8 * 2 * 4 + 12 + 128, "1024 B gather + 12 B position + 128 B of features per ray-sample (SURVEY 8d: 1164 B)"
-                eb = per_sample * P
-                es = enc_ms / args.steps * 1e-3
-                enc = {"kernel": "geo_encode_kernel", "bound": "hbm", "achieved": round(eb / es / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                       "frac": round(eb / es / 1e9 / PEAK_HBM_GBS, 4), "algorithmic_bytes": eb, "achieved_is": what + " / its time per step",
-                       "ms_per_step": round(enc_ms / args.steps, 4), "traffic": None}
-            enc.update(encode_step_traffic(lambda f: "_eval" not in f and ("cfg5" in f) == cfg5 and (not cfg5 or ("cfg5l16" in f) == (args.levels == 16))) or {})
-            if cfg5:
-                roof = enc
-        kernels = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] / args.steps} for k, v in prof.items()}
-        mfma_ms = sum(prof.get(k, (0.0, 0))[0] for k in ("geo_fwd_kernel", "geo_bwd_kernel", "col_fwd_kernel", "col_bwd_kernel",
-                                                         "wgrad_kernel")) / args.steps
-        line = {
-            "library_digest": lib_digest,
-            "metric": f"ray-samples/sec (NeuS-facto train step, {N_RAYS} rays x {N_SAMPLES} samples per GPU)",
-            "value": round(value, 1), "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "dtype_note": "fp32 tensors and accumulators; matrix products as three 16-bit MFMA terms of hi + lo operand parts: fp16 parts "
-                          "(22 mantissa bits, fp32-class) for everything the forward returns, bf16 parts (2^-17 per product, full exponent "
-                          "range) in the backward kernels and weight-gradient GEMMs",
-            "data": "synthetic", "iters_per_sec": round(1e3 / ms, 3), "per_gpu": round(value / world, 1),
-            "config": {"workload": "SMALL parity configuration (control-flow test only, NOT a benchmark)" if args.small else
-                                   ("BASELINE config 5: neus-facto-angelo preset - hash grid 16x8x2^22 linear (2.1 GB table), 1x256 geo MLP with "
-                                    "numerical SDF gradients (7 evaluations per sample), 4x256 colour MLP, 'grid' background field, progressive "
-                                    f"levels ({'all 16 on: steady state, schedules at step 200 000' if args.levels == 16 else 'level_init 8: schedules at step 0'}), "
-                                    "curvature loss; 2048 rays x 48 samples (+256/96 proposal samples) per GPU per step, "
-                                    "full train step incl. Adam" if cfg5 else
-                                    "BASELINE config 2: NeuS-facto hash-grid 16x2x2^19 smoothstep + 8x256 geo MLP + 4x256 colour MLP, "
-                                    "4096 rays x 128 samples (+256/96 proposal samples) per GPU per step, full train step incl. Adam"),
-                       "rays_per_gpu": N_RAYS, "samples_per_ray": N_SAMPLES,
-                       "parallelism": (f"dp{world} (flat gradient buffer; " + ("sharded exchange: reduce-scatter -> owned-slice Adam -> all-gather" if job["shard"] else
-                                                                                "bucketed all-reduce") + ", RCCL)") if world > 1 else "single GPU"},
-            "roofline": roof,
-            "encode_roofline": enc,
-            "config5": cfg5_extra,
-            "bigmlp": bigmlp_extra,
-            "preset": preset_extra,
-            "neus_acc": acc_extra,
-            "volsdf": volsdf_extra,
-            "config4": cfg4_extra,
-            "exchange_at_n1": exch_extra,
-            "mesh": mesh_extra,
-            "collective": None if world == 1 else collective_report(job, dist.get_backend(), exposed_by_rank, exposed_gather_by_rank),
-            "forward_only": fwd_only,
-            "dense_sdf": dense,
-            "final_loss": float(final_loss),
-            "enqueue_vs_gpu": main_split,
-            "model_tflops": round(train_flops * P / (ms * 1e-3) / 1e12, 2),
-            "mfma_kernels_ms_per_step": round(mfma_ms, 3),
-            "kernels": kernels,
-            "kernels_note": f"{dominant}: HIP events inside the timed region; every other entry: a separate untimed pass of {table_steps} "
-                            "steps with events on every launch"
-                            + ("" if instrumented_ms is None else f", which ran at {instrumented_ms:.3f} ms/step (the events' own cost)"),
-        }
-        # whole-step view: model FLOPs (6G + 3C per sample) against the fp32 matrix peak an exact-fp32 implementation would be
-        # bound by, the issued 16-bit MFMA terms (3 per product in every pass) against the dense bf16 / fp16 peak, and the whole
-        # step's HBM bytes from the committed PMC passes
-        step_bytes, step_digest = None, None
-        cands = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_step_traffic.json") and ("cfg5" in f) == cfg5
-                       and (not cfg5 or ("cfg5l16" in f) == (args.levels == 16)))
-        if cands:
-            sj = newest_matching_json(os.path.join(ROOT, "profiles"), cands, lib_digest)
-            step_bytes, step_digest = sj.get("hbm_GB_per_training_step"), sj.get("library_digest")
-        model_tf = train_flops * P / (ms * 1e-3) / 1e12
-        line["step_roofline"] = {
-            "model_tflops": round(model_tf, 1), "fp32_matrix_peak_tflops": 157.3, "frac_of_fp32_matrix_peak": round(model_tf / 157.3, 3),
-            "issued_16bit_mfma_tflops": round(3 * model_tf, 1), "frac_of_dense_bf16_peak": round(3 * model_tf / PEAK_BF16_MFMA_TFLOPS, 4),
-            "hbm_GB_per_step_pmc": step_bytes, "hbm_pmc_stale": step_bytes is not None and step_digest != lib_digest,
-            "hbm_GBps": None if step_bytes is None else round(step_bytes / (ms * 1e-3), 1),
-            "hbm_frac_of_8TBps": None if step_bytes is None else round(step_bytes / (ms * 1e-3) / PEAK_HBM_GBS, 4),
-        }
-        ref_path = os.path.join(ROOT, "profiles", "cpu_reference_r2.json")
-        if os.path.exists(ref_path):
-            with open(ref_path) as fh:
-                line["cpu_baseline_reference"] = json.load(fh)  # the reference's own Python, timed in the build container (no GPU box has it)
-        if world == 1 and not args.no_cpu_baseline and not args.small and not cfg5:
-            print("[bench] GPU leg done: " + json.dumps(compact_line(line)), file=sys.stderr, flush=True)
-            line["cpu_baseline"] = cpu_baseline()
-        # the FULL object (per-kernel tables, prose notes, every leg in detail) goes to a file; the ONE line the driver records is its
-        # compact form - every figure README / DESIGN quote survives a `tail` of the log (the full line was 23 KB)
-        try:
-            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-            with open(os.path.join(ROOT, "gpurun_out", "bench_detail.json"), "w") as fh:
-                json.dump(line, fh, indent=1)
-        except OSError as e:
-            print(f"[bench] could not write gpurun_out/bench_detail.json: {e}", file=sys.stderr)
-        print(json.dumps(line if args.full_line else compact_line(line)), flush=True)
+                sj = newest_matching_json(os.path.join(ROOT, "profiles"), cands, lib_digest)
+                step_bytes, step_digest = sj.get("hbm_GB_per_training_step"), sj.get("library_digest")
+            model_tf = train_flops * P / (ms * 1e-3) / 1e12
+            line["step_roofline"] = {
+                "model_tflops": round(model_tf, 1), "fp32_matrix_peak_tflops": 157.3, "frac_of_fp32_matrix_peak": round(model_tf / 157.3, 3),
+                "issued_16bit_mfma_tflops": round(3 * model_tf, 1), "frac_of_dense_bf16_peak": round(3 * model_tf / PEAK_BF16_MFMA_TFLOPS, 4),
+                "hbm_GB_per_step_pmc": step_bytes, "hbm_pmc_stale": step_bytes is not None and step_digest != lib_digest,
+                "hbm_GBps": None if step_bytes is None else round(step_bytes / (ms * 1e-3), 1),
+                "hbm_frac_of_8TBps": None if step_bytes is None else round(step_bytes / (ms * 1e-3) / PEAK_HBM_GBS, 4),
+            }
+            ref_path = os.path.join(ROOT, "profiles", "cpu_reference_r2.json")
+            if os.path.exists(ref_path):
+                with open(ref_path) as fh:
+                    line["cpu_baseline_reference"] = json.load(fh)  # the reference's own Python, timed in the build container (no GPU box has it)
+            if world == 1 and not args.no_cpu_baseline and not args.small and not cfg5:
+                print("[bench] GPU leg done: " + json.dumps(compact_line(line)), file=sys.stderr, flush=True)
+                line["cpu_baseline"] = cpu_baseline()
+            # the FULL object (per-kernel tables, prose notes, every leg in detail) goes to a file; the ONE line the driver records is its
+            # compact form - every figure README / DESIGN quote survives a `tail` of the log (the full line was 23 KB)
+            try:
+                os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(ROOT, "gpurun_out", "bench_detail.json"), "w") as fh:
+                    json.dump(line, fh, indent=1)
+            except OSError as e:
+                print(f"[bench] could not write gpurun_out/bench_detail.json: {e}", file=sys.stderr)
+            print(json.dumps(line if args.full_line else compact_line(line)), flush=True)
+
+    if world == 1:
+        emit_line(*run_appended_legs())
+    else:
+        # N > 1: the ONE line is complete without the appended legs and is printed FIRST - the legs' collectives have never run on N > 1
+        # hardware (single-GPU boxes only), and one that hangs into the process group's timeout must not take the headline along.
+        # Their results go to stderr and into gpurun_out/bench_detail.json.
+        emit_line(*([None] * 8), legs_pending=True)
+        names = ("config5", "bigmlp", "preset", "volsdf", "config4", "neus_acc", "exchange_at_n1", "mesh")
+        legs = dict(zip(names, run_appended_legs()))
+        if rank == 0:
+            legs = {k: v for k, v in legs.items() if v is not None}
+            print(f"[bench] appended legs at N = {world}: " + json.dumps(legs), file=sys.stderr, flush=True)
+            try:
+                path = os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+                with open(path) as fh:
+                    detail = json.load(fh)
+                detail.update(legs)
+                detail.pop("appended_legs", None)
+                with open(path, "w") as fh:
+                    json.dump(detail, fh, indent=1)
+            except (OSError, ValueError) as e:
+                print(f"[bench] could not extend gpurun_out/bench_detail.json: {e}", file=sys.stderr)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

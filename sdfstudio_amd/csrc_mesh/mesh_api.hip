@@ -23,6 +23,7 @@
 
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -273,7 +274,10 @@ __global__ __launch_bounds__(kBlock) void mc_classify_kernel(McGrid g, const uns
 
 // single workgroup: the [chunks][2] sums (face indices, vertices) -> exclusive chunk offsets, in place; the totals -> counters: the numbers
 // the call's one host read fetches.  Same one-round scheme as mc_scan_words_kernel.
-__global__ __launch_bounds__(kScanThreads) void mc_scan_cells_kernel(unsigned* blockoff, unsigned cap, Counters* counters) {
+// host_out (may be null): host-mapped pinned memory the totals are ALSO stored to - visible to the host once the stream has drained, so the
+// call needs no device -> host copy behind this kernel (a pageable-destination hipMemcpyAsync: a blit kernel, a staging buffer and a host
+// memcpy between the last kernel and the caller).
+__global__ __launch_bounds__(kScanThreads) void mc_scan_cells_kernel(unsigned* blockoff, unsigned cap, Counters* counters, Counters* host_out) {
     __shared__ unsigned long long lds[kScanThreads / 64];
     const unsigned n = counters->n_listed < cap ? counters->n_listed : cap;
     const unsigned nb = (n + kBlock - 1) / kBlock;
@@ -298,6 +302,12 @@ __global__ __launch_bounds__(kScanThreads) void mc_scan_cells_kernel(unsigned* b
         counters->n_face_idx = tf;
         counters->n_verts = tv;
         if (tf > 0x7fffffffull || tv > 0x7fffffffull) counters->flags |= kFlagIndexOverflow;
+        if (host_out != nullptr) {
+            host_out->n_listed = counters->n_listed;
+            host_out->flags = counters->flags;
+            host_out->n_face_idx = tf;
+            host_out->n_verts = tv;
+        }
     }
 }
 
@@ -350,6 +360,22 @@ __global__ __launch_bounds__(kBlock) void mc_vertices_kernel(McGrid g, McIndex i
 __global__ __launch_bounds__(kBlock) void mc_faces_kernel(McGrid g, McIndex ix, unsigned num_face_idx, int* faces, int flip) {
     const unsigned s = blockIdx.x * kBlock + threadIdx.x;
     if (s < num_face_idx) mc_face_slot(g, ix, s, faces, flip);
+}
+
+// One Counters block of host-mapped pinned memory per calling thread (sdfmesh_mc_count is synchronous: a thread has one call in flight),
+// allocated at the thread's first call and kept; portable across devices.  null: the allocation failed, the call copies as before.
+Counters* host_counters() {
+    thread_local Counters* buf = nullptr;
+    thread_local bool tried = false;
+    if (!tried) {
+        tried = true;
+        void* p = nullptr;
+        if (getenv("SDFMESH_NO_HOST_MAPPED") == nullptr && hipHostMalloc(&p, 256, hipHostMallocPortable | hipHostMallocMapped) == hipSuccess)
+            buf = (Counters*)p;
+        else
+            (void)hipGetLastError();
+    }
+    return buf;
 }
 
 int check_device() {
@@ -420,11 +446,14 @@ int sdfmesh_mc_count(const float* volume, const unsigned char* mask, int n0, int
     hipLaunchKernelGGL(mc_classify_kernel, dim3(L.nb_cells < kMaxListBlocks ? L.nb_cells : kMaxListBlocks), dim3(kBlock), 0, stream, g,
                        (const unsigned*)list, (const Counters*)counters, (unsigned)L.cap, (unsigned*)(ws + L.tile), (mc_u64*)(ws + L.rec),
                        (unsigned*)(ws + L.cnt), (unsigned*)(ws + L.blockoff));
-    hipLaunchKernelGGL(mc_scan_cells_kernel, dim3(1), dim3(kScanThreads), 0, stream, (unsigned*)(ws + L.blockoff), (unsigned)L.cap, counters);
+    Counters* mapped = host_counters();
+    hipLaunchKernelGGL(mc_scan_cells_kernel, dim3(1), dim3(kScanThreads), 0, stream, (unsigned*)(ws + L.blockoff), (unsigned)L.cap, counters,
+                       mapped);
     MESH_HIP(hipGetLastError());
     Counters host;
-    MESH_HIP(hipMemcpyAsync(&host, counters, sizeof(Counters), hipMemcpyDeviceToHost, stream));
+    if (mapped == nullptr) MESH_HIP(hipMemcpyAsync(&host, counters, sizeof(Counters), hipMemcpyDeviceToHost, stream));
     MESH_HIP(hipStreamSynchronize(stream));  // the ONE host read: the caller has to allocate the mesh
+    if (mapped != nullptr) host = *mapped;   // written by mc_scan_cells_kernel through the host mapping; the kernel has completed
     *num_vertices = 0;
     *num_faces = 0;
     if (host.flags & kFlagListOverflow)
