@@ -225,7 +225,30 @@ def ptr(t: Optional[torch.Tensor]):
         raise SdfHipError("sdfhip kernels need HIP device tensors (got a CPU tensor); there is no CPU fallback")
     if t.dtype != torch.float32 or not t.is_contiguous():
         raise SdfHipError(f"expected a contiguous float32 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
+    if t.numel() == 0:
+        return _empty_ptr(t.device)
     return ctypes.c_void_p(t.data_ptr())
+
+
+def rawptr(t: torch.Tensor):
+    """Device address of a workspace / index tensor of any dtype (no layout checks); the valid dummy address for an empty one."""
+    if t.numel() == 0:
+        return _empty_ptr(t.device)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+_EMPTY = {}
+
+
+def _empty_ptr(device):
+    """An EMPTY tensor has data_ptr() == 0, which the entry points would take for a missing (NULL) argument.  A present-but-empty
+    argument (zero rays in an eval chunk, zero packed samples) is passed as a valid address nobody dereferences: the entry points return
+    before launching when their element count is zero, as torch operators do on empty tensors."""
+    key = (device.type, device.index)
+    buf = _EMPTY.get(key)
+    if buf is None:
+        buf = _EMPTY[key] = torch.zeros(64, dtype=torch.float32, device=device)
+    return ctypes.c_void_p(buf.data_ptr())
 
 
 class Keep:

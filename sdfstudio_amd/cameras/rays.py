@@ -197,6 +197,6 @@ def generate_pinhole_rays(u, centers, rot, height: int, width: int, fx: float, f
     kp = _lib.Keep()
     _lib.check(lib.sdfhip_generate_rays(kp(u), kp(centers), kp(rot), int(centers.shape[0]), int(height), int(width), float(fx), float(fy),
                                         float(cx), float(cy), n, _lib.ptr(o), _lib.ptr(d), _lib.ptr(norm),
-                                        ctypes.c_void_p(cam.data_ptr()), _lib.stream()), "generate_rays")
+                                        _lib.rawptr(cam), _lib.stream()), "generate_rays")
     del kp
     return o, d, norm, cam

@@ -1267,7 +1267,10 @@ extern "C" int sdfhip_field_backward_feat(const SdfHipField* f, const float* pac
   (void)table;
   SDFHIP_REQUIRE(f && packed && level_mask && workspace && theta_bar && table_bar, "field_backward: null argument");
   SDFHIP_REQUIRE(f->k->geo_bwd != nullptr, "field_backward: no second-order kernels for this (ReLU) field");
-  if (n_rays == 0) return 0;
+  if (n_rays == 0) {  // no points: theta_bar is OVERWRITTEN by this call (table_bar / emb_bar are accumulated into) - the sum over no points is 0
+    SDFHIP_CHECK_HIP(hipMemsetAsync(theta_bar, 0, sizeof(float) * (size_t)f->theta_size, (hipStream_t)stream));
+    return 0;
+  }
   hipStream_t s = (hipStream_t)stream;
   const FieldKernels* k = f->k;
   const int64_t P = n_rays * n_samples, NP = sdfhip_padded_points(P);
@@ -1715,7 +1718,10 @@ extern "C" int sdfhip_numfield_backward(const SdfHipField* f, const float* packe
                                         sdfhip_stream_t stream) {
   SDFHIP_REQUIRE(f && packed && level_mask && workspace && theta_bar && table_bar, "numfield_backward: null argument");
   SDFHIP_REQUIRE(f->ref_flags == 0, "numfield_backward: the ref-nerf colour options are built on the analytic-normal path (sdfhip_field_backward_feat)");
-  if (n_rays == 0) return 0;
+  if (n_rays == 0) {  // as in sdfhip_field_backward_feat: theta_bar is overwritten, and the sum over no points is 0
+    SDFHIP_CHECK_HIP(hipMemsetAsync(theta_bar, 0, sizeof(float) * (size_t)f->theta_size, (hipStream_t)stream));
+    return 0;
+  }
   hipStream_t s = (hipStream_t)stream;
   const FieldKernels* k = f->k;
   const int64_t P = n_rays * n_samples;

@@ -51,7 +51,7 @@ class _ProposalDensity(torch.autograd.Function):
         kp = _lib.Keep()
         _lib.check(lib.sdfhip_proposal_backward(ctypes.byref(ctx.grid_cfg), _lib.ptr(table), _lib.ptr(w1), _lib.ptr(w2),
                                                 _lib.ptr(origins), _lib.ptr(dirs), _lib.ptr(starts), _lib.ptr(ends), n, s,
-                                                ctx.contract, kp(dbar), ctypes.c_void_p(ws.data_ptr()),
+                                                ctx.contract, kp(dbar), _lib.rawptr(ws),
                                                 _lib.ptr(table_bar), _lib.ptr(w1_bar), _lib.ptr(w2_bar), _lib.stream()),
                    "proposal_backward")
         del kp

@@ -125,7 +125,7 @@ class _EmbeddingLookup(torch.autograd.Function):
         lib = _lib.load()
         out = grad_target(ctx.weight_param)[0]  # every row is written: no zero fill needed
         g = rows_bar.contiguous()
-        _lib.check(lib.sdfhip_embedding_backward(ctypes.c_void_p(idx.data_ptr()), _lib.ptr(g), idx.numel(), ctx.shape[1], ctx.shape[0],
+        _lib.check(lib.sdfhip_embedding_backward(_lib.rawptr(idx), _lib.ptr(g), idx.numel(), ctx.shape[1], ctx.shape[0],
                                                  _lib.ptr(out), _lib.stream()), "embedding_backward")
         del g
         return out, None
@@ -230,7 +230,7 @@ class _FieldFunction(torch.autograd.Function):
         emb_c = None if emb is None else emb.contiguous()
         _lib.check(lib.sdfhip_field_forward(h, _lib.ptr(packed), _lib.ptr(table), _lib.ptr(mask), _lib.ptr(origins),
                                             _lib.ptr(dirs), _lib.ptr(starts), n, s, _lib.ptr(emb_c), _lib.MODE_FULL, 1 if train else 0,
-                                            ctypes.c_void_p(ws.data_ptr()), _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(rgb), _lib.ptr(feat),
+                                            _lib.rawptr(ws), _lib.ptr(sdf), _lib.ptr(grad), _lib.ptr(rgb), _lib.ptr(feat),
                                             _lib.stream()), "field_forward")
         x = ws[: NP * 12].view(torch.float32).view(NP, 3)[:P].view(n, s, 3)  # contracted positions live first in the workspace
         if train:
@@ -262,7 +262,7 @@ class _FieldFunction(torch.autograd.Function):
         # temporary's storage could be recycled for the next argument's copy before the launch reads it
         sdf_bar_c, grad_bar_c, rgb_bar_c, feat_bar_c = _contig(sdf_bar), _contig(grad_bar), _contig(rgb_bar), _contig(feat_bar)
         _lib.check(lib.sdfhip_field_backward_feat(h, _lib.ptr(packed), _lib.ptr(table), _lib.ptr(mask), n, s,
-                                                  ctypes.c_void_p(ws.data_ptr()), _lib.ptr(sdf_bar_c), _lib.ptr(grad_bar_c),
+                                                  _lib.rawptr(ws), _lib.ptr(sdf_bar_c), _lib.ptr(grad_bar_c),
                                                   _lib.ptr(rgb_bar_c), _lib.ptr(feat_bar_c), _lib.ptr(theta_bar), _lib.ptr(table_bar),
                                                   _lib.ptr(emb_bar), _lib.stream()), "field_backward")
         del sdf_bar_c, grad_bar_c, rgb_bar_c, feat_bar_c
@@ -303,7 +303,7 @@ class _RefNerfCombine(torch.autograd.Function):
         wt_bar = None if wt is None else torch.empty_like(wt)
         bt_bar = None if bt is None else torch.empty_like(bt)
         _lib.check(lib.sdfhip_refnerf_backward(_lib.ptr(s_c), _lib.ptr(f_c), _lib.ptr(wd), _lib.ptr(bd), _lib.ptr(wt), _lib.ptr(bt), P, gf, ctx.pad,
-                                               _lib.ptr(g), ctypes.c_void_p(ws.data_ptr()), _lib.ptr(s_bar), _lib.ptr(feat_bar), _lib.ptr(wd_bar),
+                                               _lib.ptr(g), _lib.rawptr(ws), _lib.ptr(s_bar), _lib.ptr(feat_bar), _lib.ptr(wd_bar),
                                                _lib.ptr(bd_bar), _lib.ptr(wt_bar), _lib.ptr(bt_bar), _lib.stream()), "refnerf_backward")
         del g
         return s_bar.view(ctx.shape), feat_bar, wd_bar, bd_bar, wt_bar, bt_bar, None
@@ -345,7 +345,7 @@ class _GeoNetFunction(torch.autograd.Function):
         sdf = torch.empty(NP, device=dev)
         feat = torch.empty(n_feat, fld.config.geo_feat_dim, device=dev)
         _lib.check(lib.sdfhip_geo_forward_n(h, _lib.ptr(packed), _lib.ptr(table), _lib.ptr(mask), _lib.ptr(positions), P, n_feat,
-                                            ctypes.c_void_p(ws.data_ptr()), _lib.ptr(sdf), _lib.ptr(feat), _lib.stream()), "geo_forward")
+                                            _lib.rawptr(ws), _lib.ptr(sdf), _lib.ptr(feat), _lib.stream()), "geo_forward")
         ctx.save_for_backward(packed, table, mask, ws)
         ctx.fld, ctx.P, ctx.table_param, ctx.n_feat = fld, P, table, n_feat
         return sdf[:P], feat
@@ -359,7 +359,7 @@ class _GeoNetFunction(torch.autograd.Function):
         table_bar = grad_target(ctx.table_param, zero_init=True)[0].view(-1)  # accumulated into; the flat gradient slice when there is one
 
         sdf_bar_c, feat_bar_c = _contig(sdf_bar), _contig(feat_bar)
-        _lib.check(lib.sdfhip_geo_backward_n(h, _lib.ptr(packed), _lib.ptr(mask), ctx.P, ctypes.c_void_p(ws.data_ptr()), ctx.n_feat,
+        _lib.check(lib.sdfhip_geo_backward_n(h, _lib.ptr(packed), _lib.ptr(mask), ctx.P, _lib.rawptr(ws), ctx.n_feat,
                                              _lib.ptr(sdf_bar_c), _lib.ptr(feat_bar_c), _lib.ptr(theta_bar), _lib.ptr(table_bar),
                                              _lib.stream()), "geo_backward")
         del sdf_bar_c, feat_bar_c
@@ -388,7 +388,7 @@ class _GeoNetRaysFunction(torch.autograd.Function):
         x = torch.empty(P, 3, device=dev)
         kp = _lib.Keep()
         _lib.check(lib.sdfhip_geo_forward_rays(h, _lib.ptr(packed), _lib.ptr(table), _lib.ptr(mask), kp(origins), kp(dirs), kp(starts), kp(ends),
-                                               n, s, ctypes.c_void_p(ws.data_ptr()), _lib.ptr(sdf), _lib.ptr(feat), _lib.ptr(x), _lib.stream()),
+                                               n, s, _lib.rawptr(ws), _lib.ptr(sdf), _lib.ptr(feat), _lib.ptr(x), _lib.stream()),
                    "geo_forward_rays")
         del kp
         ctx.save_for_backward(packed, table, mask, ws)
@@ -420,7 +420,7 @@ class _ColorFunction(torch.autograd.Function):
         rgb = torch.empty(NP, 3, device=dev)
         emb_c, feat_c, x_c, dirs_c, grad_c = _contig(emb), _contig(feat), _contig(x), _contig(dirs), _contig(grad)
         _lib.check(lib.sdfhip_color_forward(h, _lib.ptr(packed), _lib.ptr(feat_c), _lib.ptr(x_c), _lib.ptr(dirs_c), _lib.ptr(grad_c),
-                                            _lib.ptr(emb_c), n, s, ctypes.c_void_p(ws.data_ptr()), _lib.ptr(rgb), _lib.stream()),
+                                            _lib.ptr(emb_c), n, s, _lib.rawptr(ws), _lib.ptr(rgb), _lib.stream()),
                    "color_forward")
         del emb_c, feat_c, x_c, dirs_c, grad_c
         ctx.save_for_backward(packed, ws)
@@ -440,7 +440,7 @@ class _ColorFunction(torch.autograd.Function):
         grad_bar = torch.empty(n * s, 3, device=dev)
         emb_bar = torch.zeros(n, fld.config.appearance_embedding_dim, device=dev) if ctx.has_emb else None
         rgb_bar_c = _contig(rgb_bar)
-        _lib.check(lib.sdfhip_color_backward(h, _lib.ptr(packed), n, s, ctypes.c_void_p(ws.data_ptr()), _lib.ptr(rgb_bar_c),
+        _lib.check(lib.sdfhip_color_backward(h, _lib.ptr(packed), n, s, _lib.rawptr(ws), _lib.ptr(rgb_bar_c),
                                              _lib.ptr(theta_bar), _lib.ptr(feat_bar), _lib.ptr(grad_bar), _lib.ptr(emb_bar),
                                              _lib.stream()), "color_backward")
         del rgb_bar_c
@@ -475,7 +475,7 @@ class _NumericalFieldFunction(torch.autograd.Function):
         emb_c = None if emb is None else emb.contiguous()
         _lib.check(lib.sdfhip_numfield_forward(h, _lib.ptr(packed), _lib.ptr(table), _lib.ptr(mask), _lib.ptr(origins), _lib.ptr(dirs),
                                                _lib.ptr(starts), n, s, _lib.ptr(emb_c), float(delta), 1 if train else 0,
-                                               ctypes.c_void_p(ws.data_ptr()), _lib.ptr(sdf7), _lib.ptr(grad), _lib.ptr(rgb), _lib.ptr(taps),
+                                               _lib.rawptr(ws), _lib.ptr(sdf7), _lib.ptr(grad), _lib.ptr(rgb), _lib.ptr(taps),
                                                _lib.ptr(x), _lib.stream()), "numfield_forward")
         del emb_c
         if train:
@@ -497,7 +497,7 @@ class _NumericalFieldFunction(torch.autograd.Function):
         table_bar = grad_target(ctx.table_param, zero_init=True)[0].view(-1)  # accumulated into; the flat gradient slice when there is one
         emb_bar = torch.zeros(n, fld.config.appearance_embedding_dim, device=dev) if ctx.has_emb else None
         sdf_bar_c, grad_bar_c, rgb_bar_c, taps_bar_c = _contig(sdf_bar), _contig(grad_bar), _contig(rgb_bar), _contig(taps_bar)
-        _lib.check(lib.sdfhip_numfield_backward(h, _lib.ptr(packed), _lib.ptr(mask), n, s, ctx.delta, ctypes.c_void_p(ws.data_ptr()),
+        _lib.check(lib.sdfhip_numfield_backward(h, _lib.ptr(packed), _lib.ptr(mask), n, s, ctx.delta, _lib.rawptr(ws),
                                                 _lib.ptr(sdf_bar_c), _lib.ptr(grad_bar_c), _lib.ptr(rgb_bar_c), _lib.ptr(taps_bar_c),
                                                 _lib.ptr(theta_bar), _lib.ptr(table_bar), _lib.ptr(emb_bar), _lib.stream()), "numfield_backward")
         del sdf_bar_c, grad_bar_c, rgb_bar_c, taps_bar_c
@@ -709,7 +709,7 @@ class SDFField(nn.Module):
             feat = torch.empty(NP, self.config.geo_feat_dim, device=dev) if want_feat else None
             _lib.check(lib.sdfhip_field_forward(h, _lib.ptr(packed), _lib.ptr(self.encoding.params.detach()),
                                                 _lib.ptr(self._mask(dev)), _lib.ptr(origins), _lib.ptr(dirs), _lib.ptr(starts),
-                                                n, s, None, mode, 0, ctypes.c_void_p(ws.data_ptr()), _lib.ptr(sdf), None, None,
+                                                n, s, None, mode, 0, _lib.rawptr(ws), _lib.ptr(sdf), None, None,
                                                 _lib.ptr(feat), _lib.stream()), "field_forward")
         return sdf[:P], (None if feat is None else feat[:P])
 
