@@ -1022,6 +1022,23 @@ def forward_only_leg(job, device, n_rays, n_samples, reps=10):
         torch.cuda.synchronize()
         prof = _lib.profile_collect()
         _lib.profile_enable(False)
+        # the caller of the eval path: one camera's whole 384 x 384 image through Model.get_outputs_for_camera_ray_bundle
+        # (models/base_model.py:165-189) in row-major chunks of eval_num_rays_per_chunk (4096, the ModelConfig default)
+        image = None
+        if n_rays >= 4096:
+            from sdfstudio_amd.cameras.rays import generate_image_rays
+
+            cam_rays = generate_image_rays(job["centers"][7], job["rot"][7], 384, 384, 925.5, 922.6, 199.4, 198.1, camera_index=7)
+            model.get_outputs_for_camera_ray_bundle(cam_rays)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            img = model.get_outputs_for_camera_ray_bundle(cam_rays)
+            torch.cuda.synchronize()
+            img_ms = (time.perf_counter() - t2) * 1e3
+            image = {"ms_per_image": round(img_ms, 2), "pixels": 384 * 384, "chunks": -(-384 * 384 // int(model.config.eval_num_rays_per_chunk)),
+                     "rays_per_s": round(384 * 384 / (img_ms * 1e-3), 1), "value": round(384 * 384 * n_samples / (img_ms * 1e-3), 1),
+                     "unit": "ray-samples/s", "mean_accumulation": round(float(img["accumulation"].mean()), 4)}
+            del img, cam_rays
     model.train()
     P = n_rays * n_samples
     g, c = flops_per_sample()
@@ -1032,7 +1049,7 @@ def forward_only_leg(job, device, n_rays, n_samples, reps=10):
     # on-chip store of a 128-point workgroup holds (1 MB): written by the forward launch, read by the chain launch
     handover = 2 * 8 * 256 * 4 * P
     return {"value": round(P / (fwd_ms * 1e-3), 1), "unit": "ray-samples/s per GPU (eval-mode render, no grad)", "ms_per_batch": round(fwd_ms, 3),
-            "kernels_ms_per_batch": kernels,
+            "kernels_ms_per_batch": kernels, "image_384x384": image,
             "roofline": {"kernel": "geo_fwd_kernel (forward launch + chain launch, nothing saved) + col_fwd_kernel", "bound": "mfma",
                          "achieved": round(issued, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(issued / PEAK_BF16_MFMA_TFLOPS, 4),
@@ -1128,6 +1145,8 @@ def compact_line(line):
     fo = line.get("forward_only")
     if fo:
         legs["forward_only"] = {"ms": fo["ms_per_batch"], "value": fo["value"], "frac": fo["roofline"]["frac"], "traffic": fo["roofline"].get("traffic")}
+        if fo.get("image_384x384"):
+            legs["forward_only"]["image_384x384_ms"] = fo["image_384x384"]["ms_per_image"]
     ds = line.get("dense_sdf")
     if ds:
         legs["dense_sdf"] = {"ms": ds["ms"], "value": ds["value"], "unit": ds["unit"], "frac": ds["roofline"]["frac"], "traffic": ds["roofline"].get("traffic")}

@@ -141,7 +141,27 @@ class RayBundle:
     times: Optional[torch.Tensor] = None
 
     def __len__(self):
-        return self.origins.shape[0]
+        """rays.py:266-268: the number of rays whatever the batch shape ([N] for training batches, [H, W] for a camera's image)."""
+        return self.origins.numel() // self.origins.shape[-1]
+
+    _TENSOR_FIELDS = ("origins", "directions", "pixel_area", "directions_norm", "camera_indices", "nears", "fars", "times")
+
+    def _map(self, fn) -> "RayBundle":
+        kw = {k: (None if getattr(self, k) is None else fn(getattr(self, k))) for k in self._TENSOR_FIELDS}
+        md = None if self.metadata is None else {k: (fn(v) if isinstance(v, torch.Tensor) else v) for k, v in self.metadata.items()}
+        return RayBundle(metadata=md, **kw)
+
+    def flatten(self) -> "RayBundle":
+        """tensor_dataclass.py:159-166: batch shape [H, W] (or any) -> [H W], row major."""
+        return self._map(lambda t: t.reshape(-1, t.shape[-1]))
+
+    def __getitem__(self, idx) -> "RayBundle":
+        """tensor_dataclass.py:120-140 on the batch dimensions (every field is indexed the same way; the last dimension is data)."""
+        return self._map(lambda t: t[idx])
+
+    def get_row_major_sliced_ray_bundle(self, start_idx: int, end_idx: int) -> "RayBundle":
+        """rays.py:282-293: the flattened bundle's rays [start_idx, end_idx) (the chunk loop of Model.get_outputs_for_camera_ray_bundle)."""
+        return self.flatten()[start_idx:end_idx]
 
     def get_ray_samples(self, bin_starts, bin_ends, spacing_starts=None, spacing_ends=None,
                         spacing_to_euclidean_fn=None, flat_bins=None) -> RaySamples:
@@ -200,3 +220,19 @@ def generate_pinhole_rays(u, centers, rot, height: int, width: int, fx: float, f
                                         _lib.rawptr(cam), _lib.stream()), "generate_rays")
     del kp
     return o, d, norm, cam
+
+
+def generate_image_rays(center, rot, height: int, width: int, fx: float, fy: float, cx: float, cy: float, camera_index: int = 0) -> RayBundle:
+    """Every pixel's ray of ONE pinhole camera as a RayBundle of batch shape [H, W] - what ``Cameras.generate_rays(camera_indices=i)``
+    hands to ``Model.get_outputs_for_camera_ray_bundle`` (cameras/cameras.py:462-640 with the image's full coordinate grid: pixel
+    centres at +0.5, x right, y down).  Same native launch as the training rays (sdfhip_generate_rays): the uniform draw that selects
+    pixel (y, x) is ((y + 0.5) / H, (x + 0.5) / W), so the two paths cannot drift apart.  center [3], rot [3,3] camera-to-world."""
+    dev = center.device
+    ys = (torch.arange(height, device=dev, dtype=torch.float32) + 0.5) / height
+    xs = (torch.arange(width, device=dev, dtype=torch.float32) + 0.5) / width
+    u = torch.stack([torch.full((height, width), 0.5, device=dev), ys[:, None].expand(height, width), xs[None, :].expand(height, width)], -1)
+    o, d, norm, _ = generate_pinhole_rays(u.reshape(-1, 3).contiguous(), center.reshape(1, 3).contiguous(), rot.reshape(1, 3, 3).contiguous(),
+                                          height, width, fx, fy, cx, cy)
+    cam = torch.full((height, width, 1), int(camera_index), dtype=torch.int64, device=dev)
+    return RayBundle(origins=o.view(height, width, 3), directions=d.view(height, width, 3), directions_norm=norm.view(height, width, 1),
+                     camera_indices=cam)

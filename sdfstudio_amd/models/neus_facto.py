@@ -148,6 +148,7 @@ class NeuSFactoModelConfig:
     curvature_loss_warmup_steps: int = 20_000
     level_init: int = 4
     steps_per_level: int = 10_000
+    eval_num_rays_per_chunk: int = 4096  # models/base_model.py:58 (the neus-facto presets set 1024, method_configs.py:476)
 
     def setup(self, **kwargs):
         return self._target(self, **kwargs)
@@ -370,6 +371,27 @@ class NeuSFactoModel(nn.Module):
     def forward(self, ray_bundle: RayBundle) -> Dict:
         """models/base_model.py:131-142."""
         return self.get_outputs(self.collide(ray_bundle))
+
+    @torch.no_grad()
+    def get_outputs_for_camera_ray_bundle(self, camera_ray_bundle: RayBundle) -> Dict[str, torch.Tensor]:
+        """models/base_model.py:165-189: a camera's [H, W] rays through ``forward`` in row-major chunks of ``eval_num_rays_per_chunk``,
+        every tensor output concatenated and viewed [H, W, -1] (lists - weights_list, ray_samples_list - are dropped, as there).
+        The eval-side caller of the path: under no_grad every chunk takes the nothing-saved kernels."""
+        chunk = int(self.config.eval_num_rays_per_chunk)
+        height, width = camera_ray_bundle.origins.shape[:2]
+        num_rays = len(camera_ray_bundle)
+        flat = camera_ray_bundle.flatten()  # once (the reference re-flattens per chunk: same rays)
+        lists: Dict[str, list] = {}
+        for i in range(0, num_rays, chunk):
+            outputs = self.forward(flat[i:i + chunk])
+            for name in outputs.keys():
+                lists.setdefault(name, []).append(outputs[name])
+        out = {}
+        for name, parts in lists.items():
+            if not torch.is_tensor(parts[0]):
+                continue
+            out[name] = torch.cat(parts).view(height, width, -1)
+        return out
 
     def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, torch.Tensor]:
         """base_surface_model.py:399-437 (rgb, eikonal, fg mask, mono normal) + neus_facto.py:304-310 (interlevel)."""

@@ -11,6 +11,8 @@ Two groups of vectors, each produced by reference classes only:
 * ``pos/*``: frustum mid points ``Frustums.get_positions()`` and start points ``get_start_positions()`` (cameras/rays.py:46-73) followed
   by ``SceneContraction(order=inf | None)`` (field_components/spatial_distortions.py:42-92): what sdfhip_geo_forward_rays forms inside the
   encode kernel for the background field.
+* ``image/*``: every pixel's ray of one camera (``Cameras.generate_rays(camera_indices=i)``, batch shape [H, W]) and one row-major chunk of it
+  (``RayBundle.get_row_major_sliced_ray_bundle``): the inputs of ``Model.get_outputs_for_camera_ray_bundle`` (models/base_model.py:165-189).
 Consumers: tests/test_gpu_glue.py (the kernels against these vectors), tests/test_cpu_oracle_and_abi.py (the fixture's own consistency)."""
 import os
 import sys
@@ -69,6 +71,16 @@ def reference_vectors():
         out[f"pos/start_{name}"] = con(fr.get_start_positions()).numpy()
     mag = torch.linalg.norm(fr.get_positions(), ord=float("inf"), dim=-1)
     assert float((mag < 1).float().mean()) > 0.1 and float((mag > 1).float().mean()) > 0.3, "both branches of the contraction"
+
+    # a whole camera image, as the eval path asks for it (Cameras.generate_rays(camera_indices=i): batch shape [H, W]), and one row-major
+    # chunk of it as Model.get_outputs_for_camera_ray_bundle slices it (models/base_model.py:176-179, cameras/rays.py:282-293)
+    cam_i = 3
+    image = cams.generate_rays(camera_indices=cam_i)
+    assert tuple(image.origins.shape) == (H, W, 3) and len(image) == H * W
+    chunk = image.get_row_major_sliced_ray_bundle(100, 164)
+    out.update({"image/camera": np.array(cam_i), "image/origins": image.origins.numpy(), "image/directions": image.directions.numpy(),
+                "image/directions_norm": image.directions_norm.numpy(), "image/camera_indices": image.camera_indices.numpy(),
+                "image/chunk_100_164_directions": chunk.directions.numpy(), "image/chunk_100_164_camera_indices": chunk.camera_indices.numpy()})
     return out
 
 

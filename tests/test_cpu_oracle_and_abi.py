@@ -1256,6 +1256,23 @@ def test_ray_and_position_vectors_of_the_reference():
     for name, order in (("inf", float("inf")), ("l2", None)):
         assert torch.allclose(SceneContraction(order)(mid), torch.tensor(g[f"pos/mid_{name}"]), rtol=0, atol=3e-7)
         assert torch.allclose(SceneContraction(order)(start), torch.tensor(g[f"pos/start_{name}"]), rtol=0, atol=3e-7)
+    # a camera's whole image [H, W] and one row-major chunk of it (the inputs of Model.get_outputs_for_camera_ray_bundle): the host mirror's
+    # RayBundle flattens and slices as the reference's (cameras/rays.py:282-293), every pixel's ray is the pinhole statement above
+    from sdfstudio_amd.cameras.rays import RayBundle
+
+    ci = int(g["image/camera"])
+    img = RayBundle(origins=torch.tensor(g["image/origins"]), directions=torch.tensor(g["image/directions"]),
+                    directions_norm=torch.tensor(g["image/directions_norm"]), camera_indices=torch.tensor(g["image/camera_indices"]))
+    assert len(img) == int(H) * int(W) and tuple(img.flatten().origins.shape) == (int(H) * int(W), 3)
+    ch = img.get_row_major_sliced_ray_bundle(100, 164)
+    assert np.array_equal(ch.directions.numpy(), g["image/chunk_100_164_directions"])
+    assert np.array_equal(ch.camera_indices.numpy(), g["image/chunk_100_164_camera_indices"]) and tuple(ch.camera_indices.shape) == (64, 1)
+    assert (g["image/camera_indices"] == ci).all() and np.array_equal(g["image/origins"], np.broadcast_to(g["rays/centers"][ci], (int(H), int(W), 3)))
+    yy, xx = torch.meshgrid(torch.arange(int(H)) + 0.5, torch.arange(int(W)) + 0.5, indexing="ij")
+    dci = torch.stack([(xx - cx) / fx, (yy - cy) / fy, torch.ones_like(xx)], -1).float()
+    di = (rot[ci] * dci[..., None, :]).sum(-1)
+    assert torch.allclose(di / di.norm(dim=-1, keepdim=True), torch.tensor(g["image/directions"]), rtol=0, atol=2e-7)
+    assert torch.allclose(di.norm(dim=-1, keepdim=True), torch.tensor(g["image/directions_norm"]), rtol=2e-7, atol=0)
     if ref_harness.reference_available():
         import sys
 

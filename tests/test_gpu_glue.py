@@ -134,6 +134,57 @@ def test_generate_rays_against_the_references_cameras(device):
     assert_close("directions_norm", norm, t("rays/directions_norm"), rtol=3e-7, atol=0)
 
 
+def test_whole_image_rays_against_the_references_cameras(device):
+    """generate_image_rays (every pixel of one camera, batch shape [H, W]: the eval path's input) against the reference's own
+    Cameras.generate_rays(camera_indices=i) and RayBundle.get_row_major_sliced_ray_bundle (tests/golden/make_golden_rays.py, image/*)."""
+    from sdfstudio_amd.cameras.rays import generate_image_rays
+
+    g = _ray_vectors()
+    fx, fy, cx, cy, H, W, C = g["rays/intrinsics"]
+    ci = int(g["image/camera"])
+    t = lambda k: torch.tensor(g[k]).to(device)  # noqa: E731
+    rb = generate_image_rays(t("rays/centers")[ci], t("rays/rot")[ci], int(H), int(W), fx, fy, cx, cy, camera_index=ci)
+    assert tuple(rb.origins.shape) == (int(H), int(W), 3) and len(rb) == int(H) * int(W)
+    assert torch.equal(rb.origins, t("image/origins")) and torch.equal(rb.camera_indices, t("image/camera_indices"))
+    assert_close("image directions", rb.directions, t("image/directions"), rtol=0, atol=3e-7)
+    assert_close("image directions_norm", rb.directions_norm, t("image/directions_norm"), rtol=3e-7, atol=0)
+    ch = rb.get_row_major_sliced_ray_bundle(100, 164)
+    assert tuple(ch.origins.shape) == (64, 3) and torch.equal(ch.camera_indices, t("image/chunk_100_164_camera_indices"))
+    assert_close("chunk directions", ch.directions, t("image/chunk_100_164_directions"), rtol=0, atol=3e-7)
+
+
+def test_get_outputs_for_camera_ray_bundle_is_the_chunked_forward(device):
+    """models/base_model.py:165-189: an image's rays in row-major chunks of eval_num_rays_per_chunk (here 100: 24 x 20 = 480 rays = 4 chunks
+    and a ragged fifth of 80) give, per pixel, what ONE forward over all of them gives - bit for bit for every per-ray output (the expected
+    depth's clip to the batch's sample range, renderers.py:257, is per chunk in the reference as well: compared where it is not active) -
+    viewed [H, W, -1]; list outputs are dropped; no graph is built."""
+    from helpers import load_golden, product_model_from_params, small_oracle_cfg
+    from sdfstudio_amd.cameras.rays import generate_image_rays
+
+    g = load_golden("eval")
+    cfg = small_oracle_cfg()
+    model = product_model_from_params(g["param"], cfg, device).eval()
+    model.config.eval_num_rays_per_chunk = 100
+    H, W = 24, 20
+    center = torch.tensor([0.3, -2.4, 1.2], device=device)
+    z = -center / center.norm()
+    x = torch.linalg.cross(z, torch.tensor([0.0, 0.0, 1.0], device=device))
+    x = x / x.norm()
+    rot = torch.stack([x, torch.linalg.cross(z, x), z], dim=1)  # columns: x right, y down, z forward
+    rb = generate_image_rays(center, rot, H, W, 30.0, 30.0, W / 2, H / 2)
+    out = model.get_outputs_for_camera_ray_bundle(rb)
+    with torch.no_grad():
+        whole = model(rb.flatten())
+    assert tuple(out["rgb"].shape) == (H, W, 3) and tuple(out["accumulation"].shape) == (H, W, 1) and tuple(out["normal"].shape) == (H, W, 3)
+    assert not out["rgb"].requires_grad and "weights_list" not in out and "ray_samples_list" not in out
+    assert float(out["accumulation"].max()) > 0.5, "the camera must see the surface"
+    for k in ("rgb", "accumulation", "normal", "normal_vis"):
+        assert torch.equal(out[k].reshape(H * W, -1), whole[k].reshape(H * W, -1)), k
+    d0, d1 = out["depth"].reshape(-1), whole["depth"].reshape(-1)
+    inner = (d1 > cfg.near * 1.1) & (d1 < cfg.far * 0.97)
+    assert torch.equal(d0[inner], d1[inner])
+
+
 @pytest.mark.parametrize("name,order", [("inf", float("inf")), ("l2", None)])
 def test_ray_entry_positions_against_the_references_frustums_and_contraction(device, name, order):
     """The positions sdfhip_geo_forward_rays forms inside the encode kernel (x_out) against the reference's Frustums.get_positions() /
