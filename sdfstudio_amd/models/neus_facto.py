@@ -370,6 +370,12 @@ class NeuSFactoModel(nn.Module):
 
     def forward(self, ray_bundle: RayBundle) -> Dict:
         """models/base_model.py:131-142."""
+        if torch.is_grad_enabled() and (ray_bundle.origins.requires_grad or ray_bundle.directions.requires_grad):
+            # camera-pose refinement (cameras/camera_optimizers.py, mode != "off") differentiates the render w.r.t. the rays; the native
+            # field forms the sample positions inside its kernels and returns no gradient for origins / directions.  Every surface preset
+            # of the reference runs with camera_optimizer mode="off" (configs/method_configs.py); refuse instead of training poses on zeros.
+            raise NotImplementedError("sdfstudio_amd: gradients w.r.t. ray origins / directions (camera_optimizer mode != 'off') are not "
+                                      "built; detach the rays or keep the reference's default camera_optimizer mode='off'")
         return self.get_outputs(self.collide(ray_bundle))
 
     @torch.no_grad()

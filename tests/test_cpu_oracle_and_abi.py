@@ -264,6 +264,24 @@ def test_host_model_structure_matches_reference_parameter_names():
         getattr(model.field, n).weight_v.numel() + getattr(model.field, n).bias.numel() for n in model.field._lin_names)
 
 
+def test_pose_gradients_are_refused_loudly_and_image_bundles_slice():
+    """Gradients w.r.t. ray origins / directions (the reference's camera_optimizer with mode != "off"; every surface preset runs "off",
+    configs/method_configs.py) are not produced by the native field: the model refuses rays that require grad instead of handing the pose
+    optimiser zeros.  Under no_grad (the eval path) such rays pass the guard (and then reach the device check)."""
+    from helpers import product_model_from_params
+    from sdfstudio_amd.cameras.rays import RayBundle
+
+    g = load_golden("train")
+    model = product_model_from_params(g["param"], small_oracle_cfg(), torch.device("cpu"))
+    o = torch.zeros(4, 3, requires_grad=True)
+    rb = RayBundle(origins=o, directions=torch.ones(4, 3), camera_indices=torch.zeros(4, 1, dtype=torch.long))
+    with pytest.raises(NotImplementedError, match="camera_optimizer"):
+        model(rb)
+    with torch.no_grad(), pytest.raises(Exception) as e:  # past the guard: the HIP-only path refuses the CPU tensors
+        model(rb)
+    assert not isinstance(e.value, NotImplementedError)
+
+
 def test_product_losses_and_optimizer_have_no_cpu_path():
     """The product raises on CPU tensors instead of falling back: interlevel_loss_zip is the sdfhip kernel (its torch statement
     lives in oracle/, the checker), FusedAdam.step is the sdfhip kernel."""
