@@ -57,23 +57,32 @@ struct WStream {
   int cur;           // buffer holding the chunk that the next mfma step consumes
   int wave, lane;
 
+  // ONE 1 KiB DMA instruction: piece `piece` of the chunk at gsrc -> the same piece of the LDS buffer at dst; lane l moves bytes [16 l, 16 l + 16).
+  // The BUFFER form of the LDS-DMA (buffer_load_dwordx4 ... lds), not the global form (global_load_lds_dwordx4) rounds 1 - 5 used: hipcc
+  // (ROCm 7.2) books a global_load_lds as a FLAT access that touches both memory and LDS, and while one is pending it turns EVERY s_waitcnt it
+  // inserts - vmcnt and lgkmcnt - into a full drain ("pending flat").  A weight chunk's DMA is pending through the whole step before it, so all
+  // 161 LDS waits of the MODE_SDF kernel were lgkmcnt(0): each group's first MFMA waited for the NEXT group's eight ds_read_b128 as well - the
+  // two-deep weight-fragment registers bought nothing, and four LDS round trips per step were exposed.  The MUBUF form is an ordinary VMEM
+  // operation to the compiler: exact lgkmcnt(N) / vmcnt(N) counts come back (the hand-written vmcnt(0) + s_barrier of wait_sync stays: it is
+  // what makes the chunk visible).  -DSDFHIP_GLDS_FLAT selects the old form for A/B runs.
+  SDFHIP_D void dma_piece(const float* __restrict__ gsrc, float* dst, const int piece) const {
+#ifdef SDFHIP_GLDS_FLAT
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + piece * 256 + lane * 4),
+                                     (__attribute__((address_space(3))) void*)(dst + piece * 256), 16, 0, 0);
+#else
+    // raw buffer over the packed weights: stride 0, no range check that could bite (the chunks are over-read into slack by design), gfx9 word 3
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gsrc), 0, -1, 0x00020000);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + piece * 256), 16, lane * 16, piece * 1024, 0, 0);
+#endif
+  }
   // Start the DMA of `pieces` KiB (a multiple of 4: every wave issues the same count, so vmcnt bookkeeping is uniform)
   // from gsrc into the buffer that is NOT current.
   SDFHIP_D void issue(const float* __restrict__ gsrc, const int pieces, const bool into_current = false) {
     float* dst = lds + ((into_current ? cur : cur ^ 1) * buf_floats);
-    for (int i = 0; i < pieces; i += 4) {
-      const int piece = i + wave;  // 1 KiB per wave instruction: lane l supplies bytes [16 l, 16 l + 16)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + piece * 256 + lane * 4),
-                                       (__attribute__((address_space(3))) void*)(dst + piece * 256), 16, 0, 0);
-    }
+    for (int i = 0; i < pieces; i += 4) dma_piece(gsrc, dst, i + wave);  // 1 KiB per wave instruction
   }
   // one DMA instruction of the chunk going into the buffer that is NOT current: piece 4 j + wave
-  SDFHIP_D void issue_piece(const float* __restrict__ gsrc, const int j) {
-    float* dst = lds + (cur ^ 1) * buf_floats;
-    const int piece = 4 * j + wave;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + piece * 256 + lane * 4),
-                                     (__attribute__((address_space(3))) void*)(dst + piece * 256), 16, 0, 0);
-  }
+  SDFHIP_D void issue_piece(const float* __restrict__ gsrc, const int j) { dma_piece(gsrc, lds + (cur ^ 1) * buf_floats, 4 * j + wave); }
   // The weight chunk about to be consumed has landed in LDS for every wave, and every wave is done reading the other
   // buffer.  NEWER = vector-memory operations allowed to stay outstanding: 0 in the product (tp_gemm explains why no counted form -
   // "the operations issued after the chunk's DMA may stay in flight" - is safe here).
