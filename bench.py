@@ -919,6 +919,28 @@ def collective_report(job, backend, exposed_reduce_by_rank, exposed_gather_by_ra
     return rep
 
 
+def replicas_in_sync(job, device, world):
+    """N > 1: every rank must hold the SAME parameters after the exchange (base_pipeline.py:241-243: DDP's invariant) - bit for bit, since
+    every rank receives the same sums (all-reduce) or the same updated slices (all-gather).  A 64-bit checksum of every parameter's bit
+    pattern, MIN and MAX over the ranks: equal = in sync.  Outside the timed region; two collectives of one int64."""
+    import torch.distributed as dist
+
+    job["opts"].wait_parameters()
+    torch.cuda.synchronize()
+    h = torch.zeros(1, dtype=torch.int64, device=device)
+    n = 0
+    for g in job["groups"].values():
+        for i, p in enumerate(g):
+            bits = p.detach().contiguous().view(torch.int32).to(torch.int64)
+            h += (bits * ((n + i) % 8191 + 1)).sum()  # position-weighted: two parameters swapping their differences do not cancel
+        n += len(g)
+    lo, hi = h.clone(), h.clone()
+    if world > 1:
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    return {"bit_identical_across_ranks": bool(int(lo.item()) == int(hi.item())), "parameters_checked": n}
+
+
 def sdf_flops_per_point():
     """2 x MACs of the geometry network of config 2 evaluated for its sdf row alone (SDFHIP_MODE_SDF: the 256 feature rows of the output
     layer are not computed): 71->256, 2 x 256->256, 256->185, skip layer (185 + 71)->256, 3 x 256->256, 256->1."""
@@ -1168,6 +1190,7 @@ def compact_line(line):
         c = {k: col[k] for k in ("backend", "exchange", "buckets", "chunk_bytes", "buckets_launched_during_backward",
                                  "buckets_launched_from_inside_the_native_backward", "parameters_outside_the_graph", "adam_elements_visited_per_rank")}
         c["phases"] = {ph: (None if v is None else {k: v[k] for k in v if k != "overlap"}) for ph, v in col["phases"].items()}
+        c["replicas"] = col.get("replicas")
         out["collective"] = c
     else:
         out["collective"] = None
@@ -1289,26 +1312,34 @@ def run(args):
         allr = allr[0]
         exposed_by_rank = [round(float(v), 4) for v in allr.tolist()]
     dt = float(t.item())
+    replicas = replicas_in_sync(job, device, world) if world > 1 else None
+    if replicas is not None and not replicas["bit_identical_across_ranks"]:
+        print(f"[bench] rank {rank}: PARAMETERS DIFFER ACROSS RANKS after the exchange", file=sys.stderr, flush=True)
+
     def run_appended_legs():
         nonlocal loss
+        # N > 1: config 5 only (the one leg whose exchange differs in kind: 0.86 / 1.84 GB through 20 / 36 collectives, the progressive
+        # prefix); the 512-wide, preset, VolSDF and config-4 legs repeat config 2's exchange on other bucket plans and each would put
+        # another first-time-on-hardware collective sequence (and up to one process-group timeout) behind the line.  SDFHIP_BENCH_ALL_LEGS=1: all.
+        all_legs = world == 1 or os.environ.get("SDFHIP_BENCH_ALL_LEGS") == "1"
         cfg5_extra = None
         if not cfg5 and not args.small and not args.no_config5:
             del loss  # the last step's graph (and its 25 GB field workspace) goes back to the allocator
             cfg5_extra = config5_legs(device, world, rank)
         bigmlp_extra = None
-        if not cfg5 and not args.small and not args.no_bigmlp:
+        if not cfg5 and not args.small and not args.no_bigmlp and all_legs:
             loss = None
             bigmlp_extra = bigmlp_legs(device, world, rank, dt / args.steps * 1e3)
         preset_extra = None
-        if not cfg5 and not args.small and not args.no_preset:
+        if not cfg5 and not args.small and not args.no_preset and all_legs:
             loss = None
             preset_extra = preset_leg(device, world, rank)
         volsdf_extra = None
-        if not cfg5 and not args.small and not args.no_volsdf:
+        if not cfg5 and not args.small and not args.no_volsdf and all_legs:
             loss = None
             volsdf_extra = volsdf_legs(device, world, rank)
         cfg4_extra = None
-        if not cfg5 and not args.small and not args.no_config4:
+        if not cfg5 and not args.small and not args.no_config4 and all_legs:
             cfg4_extra = config4_leg(device, world, rank)
         acc_extra = None
         if not cfg5 and not args.small and not args.no_neus_acc and world == 1:
@@ -1435,9 +1466,9 @@ def run(args):
                 "config4": cfg4_extra,
                 "exchange_at_n1": exch_extra,
                 "mesh": mesh_extra,
-                "appended_legs": ("run AFTER this line at N > 1 (config5 / bigmlp / preset / volsdf / config4, each with its own exchange): stderr "
+                "appended_legs": ("run AFTER this line at N > 1 (config5; SDFHIP_BENCH_ALL_LEGS=1: bigmlp / preset / volsdf / config4 too, each with its own exchange): stderr "
                                   "'[bench] appended legs' and gpurun_out/bench_detail.json") if legs_pending else None,
-                "collective": None if world == 1 else collective_report(job, dist.get_backend(), exposed_by_rank, exposed_gather_by_rank),
+                "collective": None if world == 1 else dict(collective_report(job, dist.get_backend(), exposed_by_rank, exposed_gather_by_rank), replicas=replicas),
                 "forward_only": fwd_only,
                 "dense_sdf": dense,
                 "final_loss": float(final_loss),

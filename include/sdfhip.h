@@ -408,6 +408,22 @@ int sdfhip_fg_mask_loss_forward(const float* acc, const float* label, int64_t n_
 int sdfhip_fg_mask_loss_backward(const float* acc, const float* label, int64_t n_rays, float mult, const float* loss_bar, float* acc_bar,
                                  sdfhip_stream_t stream);
 
+/* Sensor-depth losses (model_components/losses.py:628-676 SensorDepthLoss, called at models/base_surface_model.py:440-449): the L1 between
+ * the rendered depth depth_pred[N] (already divided by directions_norm, :303) and the sensor depth depth_gt[N] over the valid rays
+ * (depth_gt > 0), the free-space loss on the samples in front of the truncation band (z < d - t: relu(t - sdf)^2) and the sdf loss inside
+ * it (((z + sdf) - d)^2), z = starts / directions_norm (directions_norm[N] or NULL = 1), both means over ALL N * S samples weighted by
+ * 1 - n_front / n resp. 1 - n_near / n.  losses3 = {l1, free space, sdf} WITHOUT the model's multipliers; state4 carries the weights the
+ * backward needs.  workspace: sdfhip_sensor_depth_loss_workspace_size() bytes.  Forward: two deterministic launches (per-block sums in
+ * double, one block adds them in a fixed order); backward: one launch writing sdf_bar[N * S] and depth_bar[N]. */
+size_t sdfhip_sensor_depth_loss_workspace_size(void);
+int sdfhip_sensor_depth_loss_forward(const float* depth_pred, const float* depth_gt, const float* sdf, const float* starts,
+                                     const float* directions_norm, int64_t n_rays, int64_t n_samples, float truncation, void* workspace,
+                                     float* losses3, float* state4, sdfhip_stream_t stream);
+int sdfhip_sensor_depth_loss_backward(const float* depth_pred, const float* depth_gt, const float* sdf, const float* starts,
+                                      const float* directions_norm, int64_t n_rays, int64_t n_samples, float truncation,
+                                      const float* state4, const float* losses_bar3, float* sdf_bar, float* depth_bar,
+                                      sdfhip_stream_t stream);
+
 /* interlevel_loss_zip (model_components/losses.py:116-172), the part per proposal level: the field histogram (c [n_rays, s+1]
  * spacing bins, w [n_rays, s] weights; both constants) blurred with half-width `radius` (0.03 / 0.003 for the two levels, :138)
  * and resampled at the proposal bins cp [n_rays, s_p+1]; against the proposal weights wp [n_rays, s_p]:

@@ -175,6 +175,11 @@ _SIGNATURES = {
                                                 ctypes.c_void_p]),
     "sdfhip_fg_mask_loss_forward": (c_i32, [c_float_p, c_float_p, c_i64, c_f32, c_float_p, ctypes.c_void_p]),
     "sdfhip_fg_mask_loss_backward": (c_i32, [c_float_p, c_float_p, c_i64, c_f32, c_float_p, c_float_p, ctypes.c_void_p]),
+    "sdfhip_sensor_depth_loss_workspace_size": (ctypes.c_size_t, []),
+    "sdfhip_sensor_depth_loss_forward": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_i64, c_i64, c_f32, ctypes.c_void_p,
+                                                 c_float_p, c_float_p, ctypes.c_void_p]),
+    "sdfhip_sensor_depth_loss_backward": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_i64, c_i64, c_f32, c_float_p,
+                                                  c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
     "sdfhip_profile_enable": (c_i32, [c_i32]),
     "sdfhip_profile_enable_slots": (c_i32, [ctypes.c_uint64]),
     "sdfhip_profile_name": (ctypes.c_char_p, [c_i32]),

@@ -652,6 +652,26 @@ __global__ void untp_kernel(const float* __restrict__ tp, const int nb, const in
   out[idx] = tp[tp_index(p, c, nb)];
 }
 
+// The geometry network's encode launch.  Two-feature grids: a 1-D launch in XCD order (point_kernels.h encode_item: every level's table is
+// gathered by ONE XCD); SDFHIP_ENCODE_PLAIN_GRID=1 keeps the plain (point block, job) grid for same-box A/B runs.  Eight-feature grids
+// (config 5: 128 MB per level, no L2 residency to win): the plain grid.
+static void launch_geo_encode(const SdfHipField* f, EncodeArgs& ea, const unsigned gx, hipStream_t s) {
+  static const bool plain = [] { const char* e = getenv("SDFHIP_ENCODE_PLAIN_GRID"); return e != nullptr && e[0] == '1'; }();
+  if (f->grid.n_features == 8) {
+    geo_encode8_kernel<<<dim3(gx, f->grid.n_levels + 1), 256, 0, s>>>(ea);
+    return;
+  }
+  const int pairs = f->grid.n_features / 2;
+  const int64_t items = (int64_t)encode_items_per_xcd((int)gx, f->grid.n_levels, pairs) * 8;
+  if (plain || items >= (1ll << 31) || gx == 0) {
+    ea.n_blocks = 0;
+    geo_encode_kernel<<<dim3(gx, f->grid.n_levels * pairs + 1), 256, 0, s>>>(ea);
+  } else {
+    ea.n_blocks = (int)gx;
+    geo_encode_kernel<<<dim3((unsigned)items), 256, 0, s>>>(ea);
+  }
+}
+
 extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
                                     const float* origins, const float* dirs, const float* starts, int64_t n_rays, int32_t n_samples,
                                     const float* emb, int32_t mode, int32_t training, void* workspace, float* sdf, float* grad,
@@ -694,8 +714,7 @@ extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, c
   {
     ProfScope ps_(PS_ENCODE, s);
     const unsigned gx = (unsigned)(NP / 256 + (NP % 256 != 0));
-    if (f->grid.n_features == 8) geo_encode8_kernel<<<dim3(gx, f->grid.n_levels + 1), 256, 0, s>>>(ea);
-    else geo_encode_kernel<<<dim3(gx, f->grid.n_levels * (f->grid.n_features / 2) + 1), 256, 0, s>>>(ea);
+    launch_geo_encode(f, ea, gx, s);
   }
 
   GeoFwdArgs ga;
@@ -1001,8 +1020,7 @@ static int geo_forward_impl(const SdfHipField* f, const float* packed, const flo
   {
     ProfScope ps_(PS_ENCODE, s);
     const unsigned gx = (unsigned)(NP / 256 + (NP % 256 != 0));
-    if (f->grid.n_features == 8) geo_encode8_kernel<<<dim3(gx, f->grid.n_levels + 1), 256, 0, s>>>(ea);
-    else geo_encode_kernel<<<dim3(gx, f->grid.n_levels * (f->grid.n_features / 2) + 1), 256, 0, s>>>(ea);
+    launch_geo_encode(f, ea, gx, s);
   }
   GeoFwdArgs ga;
   memset(&ga, 0, sizeof(ga));
@@ -1635,8 +1653,7 @@ extern "C" int sdfhip_numfield_forward(const SdfHipField* f, const float* packed
   {
     ProfScope ps_(PS_ENCODE, s);
     const unsigned gx = (unsigned)(N7 / 256 + (N7 % 256 != 0));
-    if (f->grid.n_features == 8) geo_encode8_kernel<<<dim3(gx, f->grid.n_levels + 1), 256, 0, s>>>(ea);
-    else geo_encode_kernel<<<dim3(gx, f->grid.n_levels * (f->grid.n_features / 2) + 1), 256, 0, s>>>(ea);
+    launch_geo_encode(f, ea, gx, s);
   }
   // The numerical normal divides DIFFERENCES of sdf values by 2 delta: an sdf error eps becomes eps / delta in the normal.  At the small
   // deltas of neus-facto-angelo's schedule (down to 2.4e-4 in contracted units) the 22-bit products of the default forward (eps ~ 3e-7)
@@ -2181,6 +2198,54 @@ extern "C" int sdfhip_fg_mask_loss_backward(const float* acc, const float* label
   a.loss_bar = loss_bar;
   a.acc_bar = acc_bar;
   fg_loss_bwd_kernel<<<(unsigned)std::min<int64_t>((n_rays + 255) / 256, 1024), 256, 0, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+static const int kSensorDepthBlocks = 512;
+static int fill_sensor_depth(SensorDepthArgs* a, const float* depth_pred, const float* depth_gt, const float* sdf, const float* starts,
+                             const float* directions_norm, int64_t n_rays, int64_t n_samples, float truncation) {
+  SDFHIP_REQUIRE(depth_pred && depth_gt && sdf && starts, "sensor_depth_loss: null argument");
+  SDFHIP_REQUIRE(n_rays >= 1 && n_samples >= 1 && n_rays < (1 << 30) && n_samples < (1 << 20), "sensor_depth_loss: bad shape");
+  memset(a, 0, sizeof(*a));
+  a->depth_pred = depth_pred;
+  a->depth_gt = depth_gt;
+  a->sdf = sdf;
+  a->starts = starts;
+  a->dnorm = directions_norm;
+  a->n_rays = (int32_t)n_rays;
+  a->n_samples = (int32_t)n_samples;
+  a->truncation = truncation;
+  a->n_blocks = (int32_t)std::min<int64_t>((n_rays * n_samples + 255) / 256, kSensorDepthBlocks);
+  return 0;
+}
+extern "C" size_t sdfhip_sensor_depth_loss_workspace_size(void) { return (size_t)kSensorDepthBlocks * 6 * sizeof(double); }
+extern "C" int sdfhip_sensor_depth_loss_forward(const float* depth_pred, const float* depth_gt, const float* sdf, const float* starts,
+                                                const float* directions_norm, int64_t n_rays, int64_t n_samples, float truncation,
+                                                void* workspace, float* losses3, float* state4, sdfhip_stream_t stream) {
+  SensorDepthArgs a;
+  if (int rc = fill_sensor_depth(&a, depth_pred, depth_gt, sdf, starts, directions_norm, n_rays, n_samples, truncation)) return rc;
+  SDFHIP_REQUIRE(workspace && losses3 && state4, "sensor_depth_loss_forward: null argument");
+  a.partial = (double*)workspace;
+  a.losses = losses3;
+  a.state = state4;
+  sensor_depth_partial_kernel<<<(unsigned)a.n_blocks, 256, 0, (hipStream_t)stream>>>(a);
+  sensor_depth_final_kernel<<<1, 256, 0, (hipStream_t)stream>>>(a);
+  SDFHIP_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+extern "C" int sdfhip_sensor_depth_loss_backward(const float* depth_pred, const float* depth_gt, const float* sdf, const float* starts,
+                                                 const float* directions_norm, int64_t n_rays, int64_t n_samples, float truncation,
+                                                 const float* state4, const float* losses_bar3, float* sdf_bar, float* depth_bar,
+                                                 sdfhip_stream_t stream) {
+  SensorDepthArgs a;
+  if (int rc = fill_sensor_depth(&a, depth_pred, depth_gt, sdf, starts, directions_norm, n_rays, n_samples, truncation)) return rc;
+  SDFHIP_REQUIRE(state4 && losses_bar3 && sdf_bar && depth_bar, "sensor_depth_loss_backward: null argument");
+  a.state = const_cast<float*>(state4);
+  a.losses_bar = losses_bar3;
+  a.sdf_bar = sdf_bar;
+  a.depth_bar = depth_bar;
+  sensor_depth_bwd_kernel<<<(unsigned)std::min<int64_t>((n_rays * n_samples + 255) / 256, 4096), 256, 0, (hipStream_t)stream>>>(a);
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
 }

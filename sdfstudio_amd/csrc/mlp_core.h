@@ -22,7 +22,7 @@
 // The matrix pipe runs 16-bit inputs 16x faster than fp32 (MI355X: 2.5 PFLOP/s vs 157 TFLOP/s), so the 3-term forms are ~5x cheaper
 // than v_mfma_f32_32x32x2_f32.  The forward passes (whose outputs have parity targets: 1e-5 on SDF) use NS = 4; the derivative /
 // gradient passes, whose operands have arbitrary scale, use NS = 2.  Activations never leave the register file between layers and
-// the weights move L2 -> LDS by DMA (global_load_lds_dwordx4) without passing through registers.
+// the weights move L2 -> LDS by DMA (buffer_load_dwordx4 ... lds: WStream::dma_piece) without passing through registers.
 //
 // Weight chunk layout (pack_kernel), 16-bit:  Wp[kb][part 0..4 = bf16 x 3, fp16 x 2][ob][kk 0..1][lane][j 0..7]
 //   = part of  W[out = 32 ob + (lane & 31)][k = 32 kb + tp_row(8 kk + j, lane >> 5)]

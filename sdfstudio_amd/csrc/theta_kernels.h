@@ -362,3 +362,106 @@ __global__ __launch_bounds__(256) void fg_loss_bwd_kernel(const FgLossArgs a) {
     a.acc_bar[i] = inside ? lb * (c - y) / (c * (1.0f - c)) : 0.0f;
   }
 }
+
+// Sensor-depth losses (model_components/losses.py:628-676, SensorDepthLoss, as models/base_surface_model.py:440-449 calls it): with the sensor
+// depth d of a ray (d > 0 = valid), its samples' z = start / directions_norm and sdf values,
+//   l1         = sum_valid |d - depth_pred| / (n_valid + 1e-6)
+//   free space = mean over ALL samples of (relu(t - sdf) * front)^2 * (1 - n_front / n),   front = valid and z < d - t
+//   sdf        = mean over ALL samples of ((z + sdf) - d)^2 * near * (1 - n_near / n),     near  = valid, not front, not (z > d + t)
+// with n = n_front + n_near + 1e-6 (counts: constants of the backward, as in the reference where they come out of integer sums).
+// Two launches forward (per-block partial sums in double, then ONE block adds them in a fixed order: deterministic), one backward.
+struct SensorDepthArgs {
+  const float* depth_pred;  // [N]
+  const float* depth_gt;    // [N]
+  const float* sdf;         // [N * S]
+  const float* starts;      // [N * S]
+  const float* dnorm;       // [N] directions_norm, or null (1)
+  int32_t n_rays, n_samples, n_blocks;
+  float truncation;
+  double* partial;          // [n_blocks][6]
+  float* losses;            // [3]: l1, free space, sdf
+  float* state;             // [4]: free-space weight / (N S), sdf weight / (N S), 1 / (n_valid + 1e-6), unused
+  const float* losses_bar;  // [3]
+  float* sdf_bar;           // [N * S]
+  float* depth_bar;         // [N]
+};
+struct SensorSample {
+  bool front, near;
+  float fs, res;  // relu(t - sdf), (z + sdf) - d
+};
+SDFHIP_D SensorSample sensor_sample(const SensorDepthArgs& a, const int64_t i) {
+  const int ray = (int)(i / a.n_samples);
+  const float d = a.depth_gt[ray], t = a.truncation;
+  const bool valid = d > 0.0f;
+  const float z = a.dnorm != nullptr ? a.starts[i] / a.dnorm[ray] : a.starts[i];
+  SensorSample s;
+  s.front = valid && z < d - t;
+  const bool back = valid && z > d + t;
+  s.near = valid && !s.front && !back;
+  const float x = a.sdf[i];
+  s.fs = fmaxf(t - x, 0.0f);
+  s.res = (z + x) - d;
+  return s;
+}
+__global__ __launch_bounds__(256) void sensor_depth_partial_kernel(const SensorDepthArgs a) {
+  __shared__ double red[6 * 4];
+  double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // sum |d - pred| over valid rays, n_valid, n_front, n_near, sum fs^2 front, sum res^2 near
+  const int64_t total = (int64_t)a.n_rays * a.n_samples;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const SensorSample s = sensor_sample(a, i);
+    if (s.front) {
+      v[2] += 1.0;
+      v[4] += (double)(s.fs * s.fs);
+    }
+    if (s.near) {
+      v[3] += 1.0;
+      v[5] += (double)(s.res * s.res);
+    }
+  }
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < a.n_rays; r += gridDim.x * 256) {
+    const float d = a.depth_gt[r];
+    if (d > 0.0f) {
+      v[0] += (double)fabsf(d - a.depth_pred[r]);
+      v[1] += 1.0;
+    }
+  }
+  block_sum_double<6>(v, red);
+  if (threadIdx.x < 6) a.partial[(size_t)blockIdx.x * 6 + threadIdx.x] = v[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void sensor_depth_final_kernel(const SensorDepthArgs a) {
+  __shared__ double red[6 * 4];
+  double v[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int b = threadIdx.x; b < a.n_blocks; b += 256)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) v[k] += a.partial[(size_t)b * 6 + k];
+  block_sum_double<6>(v, red);
+  if (threadIdx.x == 0) {
+    const double ns = (double)a.n_rays * (double)a.n_samples;
+    // the reference's fp32 scalars: int64 count + 1e-6 -> float32
+    const float n = (float)(v[2] + v[3]) + 1e-6f;
+    const float fs_w = 1.0f - (float)v[2] / n, sdf_w = 1.0f - (float)v[3] / n;
+    const float inv_valid = 1.0f / ((float)v[1] + 1e-6f);
+    a.losses[0] = (float)(v[0] * (double)inv_valid);
+    a.losses[1] = (float)(v[4] / ns * (double)fs_w);
+    a.losses[2] = (float)(v[5] / ns * (double)sdf_w);
+    a.state[0] = (float)((double)fs_w / ns);
+    a.state[1] = (float)((double)sdf_w / ns);
+    a.state[2] = inv_valid;
+    a.state[3] = 0.0f;
+  }
+}
+__global__ __launch_bounds__(256) void sensor_depth_bwd_kernel(const SensorDepthArgs a) {
+  const float g_l1 = a.losses_bar[0] * a.state[2], g_fs = a.losses_bar[1] * a.state[0], g_sdf = a.losses_bar[2] * a.state[1];
+  const int64_t total = (int64_t)a.n_rays * a.n_samples;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const SensorSample s = sensor_sample(a, i);
+    float g = 0.0f;
+    if (s.front) g -= g_fs * 2.0f * s.fs;  // d relu(t - x)^2 / d x = -2 relu(t - x)
+    if (s.near) g += g_sdf * 2.0f * s.res;
+    a.sdf_bar[i] = g;
+  }
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < a.n_rays; r += gridDim.x * 256) {
+    const float d = a.depth_gt[r];
+    a.depth_bar[r] = d > 0.0f ? g_l1 * depth_sign(a.depth_pred[r] - d) : 0.0f;
+  }
+}

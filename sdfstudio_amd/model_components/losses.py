@@ -277,3 +277,63 @@ def fg_mask_loss(weights_sum: torch.Tensor, fg_label: torch.Tensor, mult: float)
     if weights_sum.is_cuda:
         return _FgMaskLoss.apply(weights_sum, fg_label, mult)
     return torch.nn.functional.binary_cross_entropy(weights_sum.clip(1e-3, 1.0 - 1e-3), fg_label) * mult
+
+
+class _SensorDepthLoss(torch.autograd.Function):
+    """SensorDepthLoss (model_components/losses.py:628-676) as one native operator: {l1, free space, sdf} from the rendered depth, the
+    sensor depth and the field's per-sample sdf; gradients for the rendered depth and the sdf values (sdfhip_sensor_depth_loss_*)."""
+
+    @staticmethod
+    def forward(ctx, depth_pred, depth_gt, sdf, starts, directions_norm, truncation):
+        lib = _lib.load()
+        n, s = sdf.shape[0], sdf.shape[1]
+        dp = depth_pred.detach().reshape(-1).contiguous().float()
+        dg = depth_gt.detach().reshape(-1).contiguous().float()
+        x = sdf.detach().reshape(n, s).contiguous().float()
+        st = starts.detach().reshape(n, s).contiguous().float()
+        dn = None if directions_norm is None else directions_norm.detach().reshape(-1).contiguous().float()
+        if n == 0 or s == 0:
+            raise _lib.SdfHipError("sensor_depth_loss: empty batch")
+        assert dp.numel() == n and dg.numel() == n and (dn is None or dn.numel() == n)
+        ws = torch.empty(int(lib.sdfhip_sensor_depth_loss_workspace_size()), dtype=torch.uint8, device=x.device)
+        losses, state = torch.empty(3, device=x.device), torch.empty(4, device=x.device)
+        _lib.check(lib.sdfhip_sensor_depth_loss_forward(_lib.ptr(dp), _lib.ptr(dg), _lib.ptr(x), _lib.ptr(st), _lib.ptr(dn), n, s, float(truncation),
+                                                        _lib.rawptr(ws), _lib.ptr(losses), _lib.ptr(state), _lib.stream()), "sensor_depth_loss_forward")
+        ctx.save_for_backward(dp, dg, x, st, state, *(() if dn is None else (dn,)))
+        ctx.t, ctx.shapes = float(truncation), (depth_pred.shape, sdf.shape)
+        return losses
+
+    @staticmethod
+    def backward(ctx, lbar):
+        lib = _lib.load()
+        dp, dg, x, st, state, *rest = ctx.saved_tensors
+        dn = rest[0] if rest else None
+        lb = lbar.reshape(3).contiguous().float()
+        sdf_bar, depth_bar = torch.empty_like(x), torch.empty_like(dp)
+        _lib.check(lib.sdfhip_sensor_depth_loss_backward(_lib.ptr(dp), _lib.ptr(dg), _lib.ptr(x), _lib.ptr(st), _lib.ptr(dn), x.shape[0], x.shape[1], ctx.t,
+                                                         _lib.ptr(state), _lib.ptr(lb), _lib.ptr(sdf_bar), _lib.ptr(depth_bar), _lib.stream()),
+                   "sensor_depth_loss_backward")
+        return depth_bar.view(ctx.shapes[0]), None, sdf_bar.view(ctx.shapes[1]), None, None, None
+
+
+def sensor_depth_loss(depth_pred: torch.Tensor, depth_gt: torch.Tensor, pred_sdf: torch.Tensor, starts: torch.Tensor,
+                      directions_norm: Optional[torch.Tensor], truncation: float):
+    """SensorDepthLoss.forward (model_components/losses.py:635-676) on explicit tensors: depth_pred [N, 1] (outputs["depth"]), depth_gt [N]
+    (batch["sensor_depth"]; <= 0 = no measurement), pred_sdf [N, S] (field_outputs[SDF][..., 0]), starts [N, S] (ray_samples.frustums.starts[..., 0]),
+    directions_norm [N, 1].  Returns (l1_loss, free_space_loss, sdf_loss) without the model's multipliers.  On the device: ONE native
+    operator each way; CPU tensors (host-side checks against the reference's class) take the statement below."""
+    if pred_sdf.is_cuda:
+        out = _SensorDepthLoss.apply(depth_pred, depth_gt, pred_sdf, starts, directions_norm, truncation)
+        return out[0], out[1], out[2]
+    depth_gt = depth_gt.reshape(-1, 1)
+    valid = depth_gt > 0.0
+    l1 = torch.sum(valid * torch.abs(depth_gt - depth_pred.reshape(-1, 1))) / (valid.sum() + 1e-6)
+    z = starts if directions_norm is None else starts / directions_norm.reshape(-1, 1)
+    front = valid & (z < (depth_gt - truncation))
+    back = valid & (z > (depth_gt + truncation))
+    near = valid & (~front) & (~back)
+    n_front, n_near = front.sum(), near.sum()
+    n = n_front + n_near + 1e-6
+    fs = torch.mean((torch.relu(truncation - pred_sdf) * front) ** 2) * (1.0 - n_front / n)
+    sd = torch.mean(((z + pred_sdf) - depth_gt) ** 2 * near) * (1.0 - n_near / n)
+    return l1, fs, sd

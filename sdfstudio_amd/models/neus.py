@@ -94,7 +94,7 @@ class NeuSModel(NeuSFactoModel):
             loss["fg_mask_loss"] = fg_mask_loss(outputs["weights"].sum(dim=1), fg, c.fg_mask_loss_mult)  # clip + BCE + mean: one launch
         if "depth" in batch and c.mono_depth_loss_mult > 0.0:  # base_surface_model.py:427-437
             loss["depth_loss"] = monosdf_depth_loss(outputs["depth"], batch["depth"].to(image.device)[..., None]) * c.mono_depth_loss_mult
-        return loss
+        return self.data_prior_losses(outputs, batch, loss)
 
     def get_metrics_dict(self, outputs, batch) -> Dict[str, torch.Tensor]:
         m = super().get_metrics_dict(outputs, batch)

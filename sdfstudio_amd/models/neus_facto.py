@@ -18,7 +18,7 @@ from sdfstudio_amd.cameras.rays import RayBundle
 from sdfstudio_amd.fields.density_fields import HashMLPDensityField
 from sdfstudio_amd.fields.field_heads import FieldHeadNames
 from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
-from sdfstudio_amd.model_components.losses import fg_mask_loss, interlevel_loss_zip, monosdf_depth_loss, surface_losses
+from sdfstudio_amd.model_components.losses import fg_mask_loss, interlevel_loss_zip, monosdf_depth_loss, sensor_depth_loss, surface_losses
 from sdfstudio_amd.model_components.ray_samplers import ProposalNetworkSampler
 from sdfstudio_amd.model_components.renderers import neus_render
 from sdfstudio_amd.model_components.scene_colliders import build_collider
@@ -114,6 +114,11 @@ class NeuSFactoModelConfig:
     fg_mask_loss_mult: float = 0.01
     mono_normal_loss_mult: float = 0.0
     mono_depth_loss_mult: float = 0.0
+    sensor_depth_truncation: float = 0.015         # base_surface_model.py:101-109 (RGB-D scenes: batch["sensor_depth"])
+    sensor_depth_l1_loss_mult: float = 0.0
+    sensor_depth_freespace_loss_mult: float = 0.0
+    sensor_depth_sdf_loss_mult: float = 0.0
+    sparse_points_sdf_loss_mult: float = 0.0       # :109 (batch["sparse_sfm_points"])
     sdf_field: SDFFieldConfig = field(default_factory=SDFFieldConfig)
     overwrite_near_far_plane: bool = False  # base_surface_model.py:75: fixed planes replace the scene box's collider
     background_model: str = "none"   # the reference's default is "mlp" (base_surface_model.py:123); "mlp", "grid", "none" are built
@@ -399,6 +404,29 @@ class NeuSFactoModel(nn.Module):
             out[name] = torch.cat(parts).view(height, width, -1)
         return out
 
+    def data_prior_losses(self, outputs, batch, loss: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """base_surface_model.py:439-466: the losses on measured geometry - sensor depth (RGB-D: l1 on the rendered depth, free-space and
+        sdf losses on the field's per-sample sdf; SensorDepthLoss, model_components/losses.py:628-676) and the sdf at sparse SfM points
+        (forward_geonetwork under autograd).  Shared by every surface model's get_loss_dict (training only)."""
+        c = self.config
+        if "sensor_depth" in batch and (c.sensor_depth_l1_loss_mult > 0.0 or c.sensor_depth_freespace_loss_mult > 0.0
+                                        or c.sensor_depth_sdf_loss_mult > 0.0):
+            if "ray_samples" not in outputs or "field_outputs" not in outputs:
+                raise NotImplementedError("sensor depth losses need the per-sample outputs of a dense-sample surface model")
+            rs = outputs["ray_samples"]
+            starts = rs.flat_starts if getattr(rs, "flat_starts", None) is not None else rs.frustums.starts[..., 0]
+            l1, fs, sd = sensor_depth_loss(outputs["depth"], batch["sensor_depth"].to(outputs["depth"].device),
+                                           outputs["field_outputs"][FieldHeadNames.SDF][..., 0], starts, outputs["directions_norm"],
+                                           c.sensor_depth_truncation)
+            loss["sensor_l1_loss"] = l1 * c.sensor_depth_l1_loss_mult
+            loss["sensor_freespace_loss"] = fs * c.sensor_depth_freespace_loss_mult
+            loss["sensor_sdf_loss"] = sd * c.sensor_depth_sdf_loss_mult
+        if "sparse_sfm_points" in batch and c.sparse_points_sdf_loss_mult > 0.0:
+            pts = batch["sparse_sfm_points"].to(outputs["rgb"].device)
+            sdf = self.field.forward_geonetwork(pts)[:, 0].contiguous()
+            loss["sparse_sfm_points_sdf_loss"] = torch.mean(torch.abs(sdf)) * c.sparse_points_sdf_loss_mult
+        return loss
+
     def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, torch.Tensor]:
         """base_surface_model.py:399-437 (rgb, eikonal, fg mask, mono normal) + neus_facto.py:304-310 (interlevel)."""
         c = self.config
@@ -426,7 +454,7 @@ class NeuSFactoModel(nn.Module):
         weights = [w[..., 0] for w in outputs["weights_list"]]
         bins = [rs.flat_bins for rs in outputs["ray_samples_list"]]
         loss["interlevel_loss"] = c.interlevel_loss_mult * interlevel_loss_zip(weights, bins)
-        return loss
+        return self.data_prior_losses(outputs, batch, loss)
 
     def get_metrics_dict(self, outputs, batch) -> Dict[str, torch.Tensor]:
         image = batch["image"].to(outputs["rgb"].device)

@@ -326,6 +326,56 @@ def test_mono_prior_losses_against_reference():
         assert abs(ln.item() - RL.monosdf_normal_loss(n_pred, n_gt).item()) <= 1e-6
 
 
+def _sensor_depth_case(seed, n, s, dtype=torch.float32):
+    """An RGB-D batch: sorted sample starts, a sensor depth per ray (every 7th ray without a measurement), sdf values near the truncated
+    signed distance to the measured surface + noise (samples in front of, inside and behind the truncation band), a rendered depth."""
+    g = torch.Generator().manual_seed(seed)
+    dn = 1.0 + 0.2 * torch.rand(n, 1, generator=g)
+    starts = torch.sort(torch.rand(n, s, generator=g) * 3.0 + 0.2, dim=-1)[0]
+    depth_gt = torch.rand(n, generator=g) * 2.5 + 0.3
+    depth_gt[::7] = 0.0
+    z = starts / dn
+    sdf = (depth_gt[:, None] - z) * 0.8 + 0.05 * torch.randn(n, s, generator=g)
+    depth_pred = depth_gt[:, None] + 0.05 * torch.randn(n, 1, generator=g)
+    return tuple(t.to(dtype) for t in (depth_pred, depth_gt, sdf, starts, dn))
+
+
+def test_sensor_depth_loss_against_reference():
+    """SensorDepthLoss (model_components/losses.py:628-676; RGB-D scenes, base_surface_model.py:440-449): the host statement of
+    sensor_depth_loss against the reference's own class when /root/reference is present (build container) and against known answers
+    minted from it (GPU box) - the statement is what tests/test_gpu_northstar.py checks the native operator against."""
+    from sdfstudio_amd.model_components.losses import sensor_depth_loss
+
+    case = _sensor_depth_case(5, 64, 24)
+    known = {0.015: (0.03908504545688629, 1.5538761033440096e-07, 4.62475472886581e-05),
+             0.1: (0.03908504545688629, 4.557403372018598e-06, 0.00014831787848379463)}
+    for t, want in known.items():
+        got = [float(x) for x in sensor_depth_loss(*case, t)]
+        for a, b in zip(got, want):
+            assert abs(a - b) <= 2e-6 * abs(b), (t, got, want)
+    # no valid ray at all: every loss is exactly zero (0 / 1e-6, empty masks)
+    dp, dg, sdf, st, dn = case
+    assert [float(x) for x in sensor_depth_loss(dp, torch.zeros_like(dg), sdf, st, dn, 0.015)] == [0.0, 0.0, 0.0]
+    if os.path.isdir("/root/reference/nerfstudio"):
+        from oracle import ref_harness
+
+        ref_harness.import_reference()
+        from nerfstudio.fields.base_field import FieldHeadNames as RF
+        from nerfstudio.model_components import losses as RL
+
+        class _NS:
+            pass
+
+        rs = _NS()
+        rs.frustums = _NS()
+        rs.frustums.starts = st[..., None]
+        outputs = {"depth": dp, "ray_samples": rs, "field_outputs": {RF.SDF: sdf[..., None]}, "directions_norm": dn}
+        for t in known:
+            ref = RL.SensorDepthLoss(truncation=t)({"sensor_depth": dg}, outputs)
+            got = sensor_depth_loss(dp, dg, sdf, st, dn, t)
+            assert [float(x) for x in ref] == [float(x) for x in got], t  # the same torch statement: bit for bit
+
+
 def test_bench_algorithmic_bytes_of_geo_bwd():
     """bench.py's roofline numerator: the tile-packed blocks geo_bwd_kernel reads and writes per ray-sample, enumerated
     independently here (config 2: 8x256 geometry MLP, skip at layer 4, in0 = 3 blocks, h_3 padded to the full 8 blocks)."""

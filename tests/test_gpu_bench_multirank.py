@@ -45,6 +45,9 @@ def test_bench_self_spawns_two_ranks():
     assert c["buckets_launched_during_backward"] >= 1, c
     # ... and the SDF table's chunks leave from INSIDE the field's backward (sdfhip_set_table_grad_callback), behind the scatter
     assert c["buckets_launched_from_inside_the_native_backward"] == 1, c
+    # DDP's invariant, checked by the bench itself after the timed steps: both ranks hold the same parameters, bit for bit
+    assert c["replicas"] == {"bit_identical_across_ranks": True, "parameters_checked": c["replicas"]["parameters_checked"]}, c
+    assert c["replicas"]["parameters_checked"] > 10
 
 
 @pytest.mark.gpu
@@ -55,4 +58,5 @@ def test_bench_two_ranks_allreduce_exchange_reaches_the_same_loss():
     b, _ = _run_bench({})
     assert a["collective"]["exchange"].startswith("all-reduce") and a["collective"]["phases"]["gather"] is None
     assert a["collective"]["buckets_launched_during_backward"] >= 1
+    assert a["collective"]["replicas"]["bit_identical_across_ranks"] and b["collective"]["replicas"]["bit_identical_across_ranks"]
     assert a["final_loss"] == pytest.approx(b["final_loss"], rel=1e-4), (a["final_loss"], b["final_loss"])

@@ -325,6 +325,78 @@ def test_mono_depth_and_fg_mask_losses_against_torch(device, n):
     assert_close("d fg loss / d acc", g_in.grad[inside], r_in.grad.float()[inside], rtol=1e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize("n,s,t", [(4096, 128, 0.015), (96, 24, 0.1), (7, 1, 0.05)])
+def test_sensor_depth_loss_against_torch(device, n, s, t):
+    """SensorDepthLoss (model_components/losses.py:628-676) as ONE native operator each way against its torch statement in fp64 (pinned on
+    the reference's class by the CPU suite): the three values and the gradients w.r.t. the per-sample sdf and the rendered depth."""
+    from test_cpu_oracle_and_abi import _sensor_depth_case
+    from sdfstudio_amd.model_components.losses import sensor_depth_loss
+
+    dp, dg, sdf, st, dn = _sensor_depth_case(n + s, n, s)
+    mult = torch.tensor([1.7, 0.3, 10.0])
+    r_dp, r_sdf = dp.double().requires_grad_(True), sdf.double().requires_grad_(True)
+    ref = torch.stack(sensor_depth_loss(r_dp, dg.double(), r_sdf, st.double(), dn.double(), t))
+    (ref * mult.double()).sum().backward()
+    g_dp, g_sdf = dp.to(device).requires_grad_(True), sdf.to(device).requires_grad_(True)
+    got = torch.stack(sensor_depth_loss(g_dp, dg.to(device), g_sdf, st.to(device), dn.to(device), t))
+    (got * mult.to(device)).sum().backward()
+    # fp32 forms z = start / norm, d - t and (z + sdf) - d: a sample within an ulp of a band edge may sit on the other side in fp64
+    z64 = st.double() / dn.double()
+    edge = ((z64 - (dg.double()[:, None] - t)).abs() < 1e-5) | ((z64 - (dg.double()[:, None] + t)).abs() < 1e-5)
+    assert int(edge.sum()) <= max(4, n * s // 2000), int(edge.sum())
+    slack = 4.0 * float(edge.sum()) / (n * s) * (t + 0.05) ** 2  # what the edge samples can move a mean by
+    assert_close("sensor l1", got[0], ref[0].float(), rtol=2e-6, atol=1e-9)
+    assert_close("sensor free space", got[1], ref[1].float(), rtol=2e-5, atol=1e-12 + slack)
+    assert_close("sensor sdf", got[2], ref[2].float(), rtol=2e-5, atol=1e-12 + slack)
+    keep = ~edge
+    assert_close("d / d sdf", g_sdf.grad.cpu()[keep], r_sdf.grad.float()[keep], rtol=2e-5, atol=1e-12, elem_rtol=float("inf"))
+    assert_close("d / d depth", g_dp.grad, r_dp.grad.float(), rtol=2e-6, atol=1e-12)
+    # rays without a measurement get no gradient at all
+    assert float(g_sdf.grad.cpu()[dg <= 0].abs().max() if (dg <= 0).any() else 0.0) == 0.0
+
+
+def test_rgbd_losses_through_the_model(device):
+    """base_surface_model.py:439-466 through NeuSFactoModel.get_loss_dict: the three sensor-depth losses and the sparse-SfM-point loss
+    appear with the reference's keys, carry the multipliers, and their backward reaches the SDF field's parameters (hash table and MLP)."""
+    from helpers import load_golden, small_oracle_cfg
+    from sdfstudio_amd.cameras.rays import RayBundle
+    import bench as B
+
+    model = B.build_model(device, small=True)
+    c = model.config
+    c.sensor_depth_l1_loss_mult, c.sensor_depth_freespace_loss_mult, c.sensor_depth_sdf_loss_mult = 0.1, 10.0, 6000.0
+    c.sparse_points_sdf_loss_mult = 1.0
+    model.train()
+    gen = torch.Generator(device=device)
+    gen.manual_seed(3)
+    centers, rot = B.synthetic_cameras(device)
+    o, d, norm, cam = B.draw_rays(centers, rot, 512, gen)
+    out = model(RayBundle(origins=o, directions=d, directions_norm=norm, camera_indices=cam[:, None]))
+    batch = {"image": torch.rand(512, 3, device=device, generator=gen),
+             "sensor_depth": out["depth"].detach()[:, 0] * (1.0 + 0.05 * torch.randn(512, device=device, generator=gen)),
+             "sparse_sfm_points": torch.randn(300, 3, device=device, generator=gen) * 0.3}
+    batch["sensor_depth"][::5] = 0.0
+    base = model.get_loss_dict(out, {"image": batch["image"]})
+    loss = model.get_loss_dict(out, batch)
+    extra = {"sensor_l1_loss", "sensor_freespace_loss", "sensor_sdf_loss", "sparse_sfm_points_sdf_loss"}
+    assert set(loss) == set(base) | extra
+    # against the statement on the same tensors
+    from sdfstudio_amd.fields.field_heads import FieldHeadNames
+    from sdfstudio_amd.model_components.losses import sensor_depth_loss
+    rs = out["ray_samples"]
+    want = sensor_depth_loss(out["depth"].detach().cpu().double(), batch["sensor_depth"].cpu().double(),
+                             out["field_outputs"][FieldHeadNames.SDF][..., 0].detach().cpu().double(), rs.flat_starts.cpu().double(),
+                             out["directions_norm"].cpu().double(), c.sensor_depth_truncation)
+    for k, w, m in zip(("sensor_l1_loss", "sensor_freespace_loss", "sensor_sdf_loss"), want, (0.1, 10.0, 6000.0)):
+        assert_close(k, loss[k], (w * m).float(), rtol=5e-5, atol=1e-9)
+    for p in model.parameters():
+        p.grad = None
+    sum(loss[k] for k in extra).backward()
+    table, w0 = model.field.encoding.params.grad, model.field.glin0.weight_v.grad
+    assert table is not None and torch.isfinite(table).all() and float(table.abs().max()) > 0.0
+    assert w0 is not None and torch.isfinite(w0).all() and float(w0.abs().max()) > 0.0
+
+
 def test_gradient_slots_give_the_same_gradients_as_plain_autograd(device):
     """grad_slots.py end to end on the golden NeuS-facto model: with a FlatGradients the native backward kernels write parameter
     gradients straight into the flat buffer (no AccumulateGrad launch); the flat buffer must equal what plain autograd leaves in
