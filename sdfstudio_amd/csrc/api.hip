@@ -652,26 +652,6 @@ __global__ void untp_kernel(const float* __restrict__ tp, const int nb, const in
   out[idx] = tp[tp_index(p, c, nb)];
 }
 
-// The geometry network's encode launch.  Two-feature grids: a 1-D launch in XCD order (point_kernels.h encode_item: every level's table is
-// gathered by ONE XCD); SDFHIP_ENCODE_PLAIN_GRID=1 keeps the plain (point block, job) grid for same-box A/B runs.  Eight-feature grids
-// (config 5: 128 MB per level, no L2 residency to win): the plain grid.
-static void launch_geo_encode(const SdfHipField* f, EncodeArgs& ea, const unsigned gx, hipStream_t s) {
-  static const bool plain = [] { const char* e = getenv("SDFHIP_ENCODE_PLAIN_GRID"); return e != nullptr && e[0] == '1'; }();
-  if (f->grid.n_features == 8) {
-    geo_encode8_kernel<<<dim3(gx, f->grid.n_levels + 1), 256, 0, s>>>(ea);
-    return;
-  }
-  const int pairs = f->grid.n_features / 2;
-  const int64_t items = (int64_t)encode_items_per_xcd((int)gx, f->grid.n_levels, pairs) * 8;
-  if (plain || items >= (1ll << 31) || gx == 0) {
-    ea.n_blocks = 0;
-    geo_encode_kernel<<<dim3(gx, f->grid.n_levels * pairs + 1), 256, 0, s>>>(ea);
-  } else {
-    ea.n_blocks = (int)gx;
-    geo_encode_kernel<<<dim3((unsigned)items), 256, 0, s>>>(ea);
-  }
-}
-
 extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, const float* table, const float* level_mask,
                                     const float* origins, const float* dirs, const float* starts, int64_t n_rays, int32_t n_samples,
                                     const float* emb, int32_t mode, int32_t training, void* workspace, float* sdf, float* grad,
@@ -714,7 +694,8 @@ extern "C" int sdfhip_field_forward(const SdfHipField* f, const float* packed, c
   {
     ProfScope ps_(PS_ENCODE, s);
     const unsigned gx = (unsigned)(NP / 256 + (NP % 256 != 0));
-    launch_geo_encode(f, ea, gx, s);
+    if (f->grid.n_features == 8) geo_encode8_kernel<<<dim3(gx, f->grid.n_levels + 1), 256, 0, s>>>(ea);
+    else geo_encode_kernel<<<dim3(gx, f->grid.n_levels * (f->grid.n_features / 2) + 1), 256, 0, s>>>(ea);
   }
 
   GeoFwdArgs ga;
@@ -1020,7 +1001,8 @@ static int geo_forward_impl(const SdfHipField* f, const float* packed, const flo
   {
     ProfScope ps_(PS_ENCODE, s);
     const unsigned gx = (unsigned)(NP / 256 + (NP % 256 != 0));
-    launch_geo_encode(f, ea, gx, s);
+    if (f->grid.n_features == 8) geo_encode8_kernel<<<dim3(gx, f->grid.n_levels + 1), 256, 0, s>>>(ea);
+    else geo_encode_kernel<<<dim3(gx, f->grid.n_levels * (f->grid.n_features / 2) + 1), 256, 0, s>>>(ea);
   }
   GeoFwdArgs ga;
   memset(&ga, 0, sizeof(ga));
@@ -1653,7 +1635,8 @@ extern "C" int sdfhip_numfield_forward(const SdfHipField* f, const float* packed
   {
     ProfScope ps_(PS_ENCODE, s);
     const unsigned gx = (unsigned)(N7 / 256 + (N7 % 256 != 0));
-    launch_geo_encode(f, ea, gx, s);
+    if (f->grid.n_features == 8) geo_encode8_kernel<<<dim3(gx, f->grid.n_levels + 1), 256, 0, s>>>(ea);
+    else geo_encode_kernel<<<dim3(gx, f->grid.n_levels * (f->grid.n_features / 2) + 1), 256, 0, s>>>(ea);
   }
   // The numerical normal divides DIFFERENCES of sdf values by 2 delta: an sdf error eps becomes eps / delta in the normal.  At the small
   // deltas of neus-facto-angelo's schedule (down to 2.4e-4 in contracted units) the 22-bit products of the default forward (eps ~ 3e-7)

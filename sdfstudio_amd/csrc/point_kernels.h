@@ -220,36 +220,7 @@ struct EncodeArgs {
   float tap_delta;
   const float* ends;     // [N,S] or null.  Non-null (with dirs): the frustum MID point o + d (start + end) / 2 (rays.py:46-55, what the
                          // density / nerfacto fields evaluate) instead of the start point
-  // geo_encode_kernel's XCD-aware launch (encode_item below): point blocks of 256 in the launch; 0 = the plain (x = point block, y = job) grid
-  int32_t n_blocks;
 };
-
-// ---- which (point block, job) a workgroup of geo_encode_kernel's 1-D launch works on.  job -1 = the position / positional-encoding
-// block, job >= 0 = level * pairs + feature pair.  The dispatcher hands workgroup b to XCD b % 8 (observed, not promised: MI355X_MICROARCH.md
-// "Workgroup dispatch"; a different placement costs speed, never correctness - every (block, job) is still visited exactly once), each XCD
-// has its own 4 MiB L2, and a hashed level of config 2 is exactly 4 MiB.  With the plain 2-D grid every XCD walks EVERY level for an
-// eighth of the points, so each level's table crosses the fabric eight times: PMC, 0.55 GB fetched per step for a 49 MB table.  Here
-// level l belongs to XCD l % 8 (a coarse and a fine level each at 16 levels), which gathers it for ALL points; the position blocks are
-// dealt round-robin and come first (36 sinf per point: the longest jobs).  Returns false for the padding workgroups of the launch.
-SDFHIP_HD int encode_items_per_xcd(const int n_blocks, const int n_levels, const int pairs) {
-  return (n_blocks + 7) / 8 + (n_levels + 7) / 8 * pairs * n_blocks;
-}
-SDFHIP_D bool encode_item(const int b, const int n_blocks, const int n_levels, const int pairs, int& block, int& job) {
-  const int xcd = b & 7;
-  int j = b >> 3;
-  const int npe = (n_blocks - xcd + 7) >> 3;  // position blocks xcd, xcd + 8, ...
-  if (j < npe) {
-    block = xcd + 8 * j;
-    job = -1;
-    return true;
-  }
-  j -= npe;
-  const int k = j / n_blocks;  // k-th (owned level, pair) of this XCD
-  const int level = xcd + 8 * (k / pairs);
-  block = j - k * n_blocks;
-  job = level * pairs + k % pairs;
-  return level < n_levels;
-}
 
 // position of encode point p: the start (or mid) position of point q = p mod tap_points (or p), contracted, then displaced by its tap
 SDFHIP_D void encode_position(const EncodeArgs& a, const int64_t p, float x[3]) {
@@ -269,11 +240,13 @@ SDFHIP_D void encode_position(const EncodeArgs& a, const int64_t p, float x[3]) 
   }
 }
 
-// grid = encode_items_per_xcd() * 8 workgroups (a.n_blocks > 0: encode_item above), or (n_padded / 256, n_levels * pairs + 1); block = 256
+// grid = (n_padded / 256, n_levels + 1), block = 256
+// (Round 6 tried the launch in XCD order - level l gathered for ALL points by XCD l % 8, so that a level's table crosses the fabric once
+// instead of eight times: FETCH_SIZE 264 -> 162 MB per launch, and the kernel 0.204 -> 0.243 ms, two alternating runs each on one box.
+// The gather is not bound by the fabric: 67 M eight-byte gathers in 0.2 ms are 21 TB/s of 64-byte L2 -> L1 transfers against the L2s'
+// 34.5 TB/s.  Not shipped; tools/experiments/encode_xcd_order.patch, profiles/r6_encode_xcd_order_ab.txt.)
 __global__ __launch_bounds__(256) void geo_encode_kernel(const EncodeArgs a) {
-  int blk = (int)blockIdx.x, job = (int)blockIdx.y - 1;
-  if (a.n_blocks > 0 && !encode_item((int)blockIdx.x, a.n_blocks, a.grid.n_levels, a.grid.n_features >> 1, blk, job)) return;
-  const int64_t p = (int64_t)blk * 256 + threadIdx.x;
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= a.n_padded) return;
   const bool live = p < a.n_points;
   float x[3] = {0.f, 0.f, 0.f};
@@ -283,7 +256,7 @@ __global__ __launch_bounds__(256) void geo_encode_kernel(const EncodeArgs a) {
   // blockIdx.y = 0: the position / positional-encoding block (36 sinf per point: the longest blocks of the launch - scheduled FIRST, they
   // overlap with the gathers instead of forming its tail); y - 1 = level * (F / 2) + feature pair
   const int L = a.grid.n_levels, F = a.grid.n_features, pairs = F >> 1;
-  const int yy = job;
+  const int yy = (int)blockIdx.y - 1;
   const int level = yy / pairs, pair = yy % pairs;
   const int pe_dims = pe_cols(a.pe_degree);
   const int feat0 = 3 + pe_dims;
