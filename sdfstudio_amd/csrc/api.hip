@@ -245,6 +245,9 @@ struct SdfHipField {
   int32_t* d_maps = nullptr;
   int max_pack_elems = 0, max_vec_n = 0;
   int64_t max_partial_elems = 0, max_partial_rows = 0;
+  // every split-K GEMM of a backward call with a partial region of its own (wreduce_batch_kernel): floats per split over all layers
+  int64_t total_partial_elems = 0, total_partial_rows = 0;
+  bool batch_wreduce = false;
 
   // network depth is a run-time property of the field (the kernels loop over the layers); the table k fixes the block widths
   int nl = 0, skip = -1, nlc = 0, nb3 = 0;  // hidden geometry layers, skip layer (-1: none), hidden colour layers, width below the skip
@@ -496,6 +499,19 @@ extern "C" int sdfhip_field_create(const SdfHipFieldCfg* cfg, SdfHipField** out)
   for (int l = 0; l < NLC; ++l) upd(k->nbc, f->kb_col(l));
   upd(1, k->nbc);
   f->max_partial_elems = std::max<int64_t>(f->max_partial_elems, k->nbh * 32 + 32);
+  {
+    auto add = [&](int rows_blocks, int col_blocks) {
+      f->total_partial_elems += (int64_t)rows_blocks * 32 * col_blocks * 32;
+      f->total_partial_rows += (int64_t)rows_blocks * 32;
+    };
+    for (int l = 0; l <= NL; ++l) add(f->nbo_geo(l), f->kb_geo(l));
+    for (int l = 0; l < NLC; ++l) add(k->nbc, f->kb_col(l));
+    add(1, k->nbc);
+    // one region per GEMM while that stays a modest part of the training workspace (256-wide networks: ~0.9 GB at 256 splits; the
+    // 512-wide layer-at-a-time path keeps the one shared buffer); SDFHIP_WREDUCE_PER_GEMM=1: the per-GEMM reductions of rounds 1 - 6 (A/B)
+    static const bool per_gemm = [] { const char* e = getenv("SDFHIP_WREDUCE_PER_GEMM"); return e != nullptr && e[0] == '1'; }();
+    f->batch_wreduce = !per_gemm && (int)f->lin.size() <= kWreduceBatchMax && f->total_partial_elems * 256 * 4 <= (int64_t)2 << 30;
+  }
 
   hipError_t e = hipMalloc((void**)&f->d_pack, f->pack.size() * sizeof(PackDesc));
   if (e == hipSuccess) e = hipMalloc((void**)&f->d_vec, f->vec.size() * sizeof(VecDesc));
@@ -540,10 +556,27 @@ struct FieldWs {
   float *rgb;
   float *gtot, *ebar, *sdfbar, *qb[kMaxLayers + 1], *zb[kMaxLayers], *in0bar, *d[kMaxLayers], *dout, *featbar, *csmallbar;
   float *partial, *bpartial;
+  float* sdfrow_partial;  // the sdf row's own split partials (behind the GEMMs' regions when those are batched)
+  struct WreduceBatch* batch;  // non-null: run_wgrad defers its reduction to flush_wreduce (set by the backward entry points)
   float *gsave, *dsave;  // ref-nerf options: d sdf / dx and the ray direction per point, for the backward (null otherwise)
   int n_split;
   size_t bytes;
 };
+
+// split-K partial buffers of a training workspace: one region per GEMM + the sdf row's (batched reductions) or the largest GEMM's (shared)
+struct WreduceBatch {
+  WreduceBatchArgs args;
+  int64_t used = 0, bused = 0, cap = 0, bcap = 0;
+  WreduceBatch() { args.n = 0; }
+};
+static int64_t partial_floats_per_split(const SdfHipField* f) {
+  return f->batch_wreduce ? f->total_partial_elems + (f->k->nbh * 32 + 32) : f->max_partial_elems;
+}
+static int64_t bpartial_floats_per_split(const SdfHipField* f) { return f->batch_wreduce ? f->total_partial_rows : f->max_partial_rows; }
+static float* sdfrow_region(const SdfHipField* f, float* partial, int n_split) {
+  return (partial != nullptr && f->batch_wreduce) ? partial + (int64_t)n_split * f->total_partial_elems : partial;
+}
+
 
 // level: 0 = point modes (sdf / geonetwork inference), 1 = MODE_FULL with a backward to follow (every saved tensor, gradient
 // staging, split-K partials), 2 = MODE_FULL forward only (z_l for the analytic-normal chain; no r_l, h_l or gradient buffers)
@@ -587,8 +620,9 @@ static void carve(const SdfHipField* f, int64_t n_points, int level, void* base,
     w->csmallbar = take(np * k->nbs * 32);
     const int64_t n_tiles = np / 32;
     w->n_split = (int)std::min<int64_t>(256, n_tiles);
-    w->partial = take((int64_t)w->n_split * f->max_partial_elems);
-    w->bpartial = take((int64_t)w->n_split * f->max_partial_rows);
+    w->partial = take((int64_t)w->n_split * partial_floats_per_split(f));
+    w->bpartial = take((int64_t)w->n_split * bpartial_floats_per_split(f));
+    w->sdfrow_partial = sdfrow_region(f, w->partial, w->n_split);
     if (f->ref_flags & (kRefReflect | kRefNdotV)) {  // behind everything else: the layout without the options is what it always was
       w->gsave = take(np * 3);
       w->dsave = take(np * 3);
@@ -774,12 +808,21 @@ __global__ __launch_bounds__(1024) void sdfrow_reduce_kernel(const float* __rest
   }
 }
 
+static void flush_wreduce(WreduceBatch& B, hipStream_t s);
 static void run_wgrad(const SdfHipField* f, const FieldWs& w, const WgradArgs& base, int rowmap, int colmap, int64_t w_off, int ld,
                       float scale, int64_t b_off, float* theta_bar, hipStream_t s) {
   WgradArgs a = base;
   a.tiles_per_split = (int)((a.n_tiles + w.n_split - 1) / w.n_split);
-  a.partial = w.partial;
-  a.bpartial = b_off >= 0 ? w.bpartial : nullptr;
+  // a region of its own and a deferred reduction (flush_wreduce), or the shared buffer and the reduction right behind the GEMM
+  WreduceBatch* B = w.batch;
+  const int64_t need = (int64_t)w.n_split * a.nba * 32 * a.nbb * 32, bneed = (int64_t)w.n_split * a.nba * 32;
+  if (B != nullptr && (B->args.n >= kWreduceBatchMax || B->used + need > B->cap || B->bused + bneed > B->bcap))
+    flush_wreduce(*B, s);  // no room left: reduce what is pending (in stream order: before this GEMM reuses the regions) and start over
+  const bool defer = B != nullptr && need <= B->cap && bneed <= B->bcap;
+  float* const part = defer ? w.partial + B->used : w.partial;
+  float* const bpart = defer ? w.bpartial + B->bused : w.bpartial;
+  a.partial = part;
+  a.bpartial = b_off >= 0 ? bpart : nullptr;
   {
     ProfScope ps_(PS_WGRAD, s);
     a.n_split = w.n_split;
@@ -805,7 +848,7 @@ static void run_wgrad(const SdfHipField* f, const FieldWs& w, const WgradArgs& b
   }
   WreduceArgs r;
   memset(&r, 0, sizeof(r));
-  r.partial = w.partial;
+  r.partial = part;
   r.bpartial = a.bpartial;
   r.n_split = w.n_split;
   r.rows = a.nba * 32;
@@ -818,9 +861,34 @@ static void run_wgrad(const SdfHipField* f, const FieldWs& w, const WgradArgs& b
   r.scale = scale;
   r.b_off = b_off;
   r.accumulate = 0;
-  const int total = r.rows * r.cols;
-  // 256 elements per block; the bias rows (64 per block) need ceil(rows / 64) blocks, which rows * cols / 256 covers for cols >= 4
-  { ProfScope ps_(PS_WREDUCE, s); wreduce_kernel<<<(unsigned)std::max((total + 255) / 256, (r.rows + 63) / 64), 64 * kWrG, 0, s>>>(r); }
+  if (defer) {
+    WreduceBatchArgs& ba = B->args;
+    if (ba.n == 0) ba.first_block[0] = 0;
+    ba.r[ba.n] = r;
+    ba.first_block[ba.n + 1] = ba.first_block[ba.n] + wreduce_blocks(r);
+    ++ba.n;
+    B->used += need;
+    B->bused += bneed;
+    return;
+  }
+  { ProfScope ps_(PS_WREDUCE, s); wreduce_kernel<<<(unsigned)wreduce_blocks(r), 64 * kWrG, 0, s>>>(r); }
+}
+// the deferred reductions of one backward call, one launch
+static void flush_wreduce(WreduceBatch& B, hipStream_t s) {
+  if (B.args.n == 0) return;
+  ProfScope ps_(PS_WREDUCE, s);
+  wreduce_batch_kernel<<<(unsigned)B.args.first_block[B.args.n], 64 * kWrG, 0, s>>>(B.args);
+  B.args.n = 0;
+  B.used = B.bused = 0;
+}
+static void begin_wreduce_batch(const SdfHipField* f, FieldWs& w, WreduceBatch& B) {
+  w.batch = nullptr;
+  if (!f->batch_wreduce || w.partial == nullptr) return;
+  B.args.n = 0;
+  B.used = B.bused = 0;
+  B.cap = (int64_t)w.n_split * f->total_partial_elems;
+  B.bcap = (int64_t)w.n_split * f->total_partial_rows;
+  w.batch = &B;
 }
 
 static TpOperand seg1(const float* p, int nb) {
@@ -881,9 +949,9 @@ static void run_geo_wgrads(const SdfHipField* f, const FieldWs& w, const bool ta
     a.B[0] = seg1(w.u[f->nl - 1], k->nbh);
     run_wgrad(f, w, a, f->g_rowmap[f->nl], f->g_colmap[f->nl], li.w_off, li.in_dim, 1.0f, li.b_off, theta_bar, s);
     const int tps = (int)((n_tiles + w.n_split - 1) / w.n_split);
-    { ProfScope ps_(PS_WGRAD, s); k->sdfrow(w.u[f->nl - 1], tangent ? w.qb[f->nl] : nullptr, w.sdfbar, n_tiles, tps, w.partial, (unsigned)w.n_split, s); }
+    { ProfScope ps_(PS_WGRAD, s); k->sdfrow(w.u[f->nl - 1], tangent ? w.qb[f->nl] : nullptr, w.sdfbar, n_tiles, tps, w.sdfrow_partial, (unsigned)w.n_split, s); }
     const int stride = k->nbh * 32 + 32;
-    sdfrow_reduce_kernel<<<(stride + 31) / 32, 1024, 0, s>>>(w.partial, w.n_split, stride, f->cfg.hidden_dim, theta_bar + li.w_off,
+    sdfrow_reduce_kernel<<<(stride + 31) / 32, 1024, 0, s>>>(w.sdfrow_partial, w.n_split, stride, f->cfg.hidden_dim, theta_bar + li.w_off,
                                                               theta_bar + li.b_off);
   }
 }
@@ -941,8 +1009,9 @@ static void carve_geo(const SdfHipField* f, int64_t n_points, void* base, FieldW
   w->featbar = take(np * k->nbf * 32);
   const int64_t n_tiles = np / 32;
   w->n_split = (int)std::min<int64_t>(256, n_tiles);
-  w->partial = take((int64_t)w->n_split * f->max_partial_elems);
-  w->bpartial = take((int64_t)w->n_split * f->max_partial_rows);
+  w->partial = take((int64_t)w->n_split * partial_floats_per_split(f));
+  w->bpartial = take((int64_t)w->n_split * bpartial_floats_per_split(f));
+  w->sdfrow_partial = sdfrow_region(f, w->partial, w->n_split);
   w->bytes = off;
 }
 
@@ -1124,8 +1193,9 @@ static void carve_col(const SdfHipField* f, int64_t n_points, void* base, FieldW
   w->csmallbar = take(np * k->nbs * 32);
   const int64_t n_tiles = np / 32;
   w->n_split = (int)std::min<int64_t>(256, n_tiles);
-  w->partial = take((int64_t)w->n_split * f->max_partial_elems);
-  w->bpartial = take((int64_t)w->n_split * f->max_partial_rows);
+  w->partial = take((int64_t)w->n_split * partial_floats_per_split(f));
+  w->bpartial = take((int64_t)w->n_split * bpartial_floats_per_split(f));
+  w->sdfrow_partial = sdfrow_region(f, w->partial, w->n_split);
   w->bytes = off;
 }
 
@@ -1374,8 +1444,11 @@ extern "C" int sdfhip_field_backward_feat(const SdfHipField* f, const float* pac
 
   // 5. weight gradients: split-K GEMMs over points
   const int64_t n_tiles = NP / 32;
+  WreduceBatch wb;
+  begin_wreduce_batch(f, w, wb);
   run_geo_wgrads(f, w, true, n_tiles, theta_bar, s);
   run_col_wgrads(f, w, n_tiles, theta_bar, s);
+  flush_wreduce(wb, s);
   if (forked) SDFHIP_CHECK_HIP(hipStreamWaitEvent(s, g_side.join, 0));
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
@@ -1556,8 +1629,9 @@ static void carve_num(const SdfHipField* f, int64_t P, void* base, NumWs* w, con
   if (training) {
     const int64_t n_tiles = n7 / 32;
     g.n_split = (int)std::min<int64_t>(256, n_tiles);
-    g.partial = take((int64_t)g.n_split * f->max_partial_elems);
-    g.bpartial = take((int64_t)g.n_split * f->max_partial_rows);
+    g.partial = take((int64_t)g.n_split * partial_floats_per_split(f));
+    g.bpartial = take((int64_t)g.n_split * bpartial_floats_per_split(f));
+    g.sdfrow_partial = sdfrow_region(f, g.partial, g.n_split);
     c.n_split = (int)std::min<int64_t>(256, nc / 32);
     c.partial = g.partial;  // the weight-gradient GEMMs run one after the other on one stream
     c.bpartial = g.bpartial;
@@ -1822,8 +1896,12 @@ extern "C" int sdfhip_numfield_backward(const SdfHipField* f, const float* packe
 
   // 5. weight gradients.  Hidden layers: all 7 P points; the output layer's feature rows: the centre tiles only (no other point has a
   //    feature cotangent), its sdf row: all points
+  WreduceBatch wb;  // one batch over both parts: w.c shares w.g's partial buffers (carve_numfield)
+  begin_wreduce_batch(f, w.g, wb);
+  w.c.batch = w.g.batch;
   run_geo_wgrads(f, w.g, false, N7 / 32, theta_bar, s, split ? NC / 32 : N7 / 32);
   run_col_wgrads(f, w.c, NC / 32, theta_bar, s);
+  flush_wreduce(wb, s);
   if (forked) SDFHIP_CHECK_HIP(hipStreamWaitEvent(s, g_side.join, 0));
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;

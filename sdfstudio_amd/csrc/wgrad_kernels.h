@@ -376,11 +376,10 @@ struct WreduceArgs {
 #define SDFHIP_WREDUCE_GROUPS 8
 #endif
 constexpr int kWrG = SDFHIP_WREDUCE_GROUPS;
-static __global__ __launch_bounds__(64 * kWrG) void wreduce_kernel(const WreduceArgs a) {
-  __shared__ f32x4 red[kWrG][64];
+SDFHIP_D void wreduce_block(const WreduceArgs& a, const int bx, f32x4 (*red)[64]) {
   const int ix = threadIdx.x & 63, sg = threadIdx.x >> 6;
   const int total = a.rows * a.cols;  // a multiple of 1024 (both are multiples of 32)
-  const int idx = (blockIdx.x * 64 + ix) * 4;
+  const int idx = (bx * 64 + ix) * 4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (idx < total) {
     const float* p = a.partial + (size_t)(idx >> 8) * a.n_split * 256 + (idx & 255);  // chunk-major (wg_partial_index): split stride 256
@@ -414,8 +413,8 @@ static __global__ __launch_bounds__(64 * kWrG) void wreduce_kernel(const Wreduce
     }
   }
   // bias gradients: rows elements, 64 per block, handled by the first ceil(rows / 64) blocks
-  if (a.bpartial != nullptr && a.b_off >= 0 && blockIdx.x * 64 < a.rows) {  // block-uniform condition (barriers inside)
-    const int row = blockIdx.x * 64 + ix;
+  if (a.bpartial != nullptr && a.b_off >= 0 && bx * 64 < a.rows) {  // block-uniform condition (barriers inside)
+    const int row = bx * 64 + ix;
     float t = 0.0f;
     if (row < a.rows)
       for (int k = sg; k < a.n_split; k += kWrG) t += a.bpartial[(size_t)k * a.rows + row];
@@ -434,4 +433,33 @@ static __global__ __launch_bounds__(64 * kWrG) void wreduce_kernel(const Wreduce
     }
   }
 }
-
+static __global__ __launch_bounds__(64 * kWrG) void wreduce_kernel(const WreduceArgs a) {
+  __shared__ f32x4 red[kWrG][64];
+  wreduce_block(a, (int)blockIdx.x, red);
+}
+SDFHIP_HD int wreduce_blocks(const WreduceArgs& r) {
+  // 256 elements per block; the bias rows (64 per block) need ceil(rows / 64) blocks, which rows * cols / 256 covers for cols >= 4
+  const int total = r.rows * r.cols;
+  const int a = (total + 255) / 256, b = (r.rows + 63) / 64;
+  return a > b ? a : b;
+}
+// Every reduction of one backward call in ONE launch: each split-K GEMM keeps its own partial region and the reductions run together
+// at the end of the call.  One reduction per GEMM (rounds 1 - 6) was 14 launches of ~44 us on config 2 (0.60 ms per step: 67 MB each, too
+// short to stream) in BETWEEN the GEMMs; here the GEMMs follow each other and ~0.9 GB of partials are read by one launch that fills the
+// chip: 0.17 ms.  The GEMMs lose part of it (their partials no longer sit in the Infinity Cache under the next GEMM's writes: 5.85 -> 6.15 ms
+// by the events); net -0.07 ms per config-2 step, -0.16 ms per config-5 step, same box, alternating runs (profiles/r6_wgrad_launch_forms.txt).
+// Same sums in the same order: the gradients are bit-identical to the per-GEMM form (tests/test_gpu_bitrepro.py).
+// (Also measured there: the GEMMs of one kernel instantiation merged into ONE launch - no gain, +0.09 ms; not kept.)
+constexpr int kWreduceBatchMax = 24;
+struct WreduceBatchArgs {
+  WreduceArgs r[kWreduceBatchMax];
+  int32_t first_block[kWreduceBatchMax + 1];
+  int32_t n;
+};
+static __global__ __launch_bounds__(64 * kWrG) void wreduce_batch_kernel(const WreduceBatchArgs a) {
+  __shared__ f32x4 red[kWrG][64];
+  const int b = (int)blockIdx.x;
+  int i = 0;
+  while (i + 1 < a.n && b >= a.first_block[i + 1]) ++i;  // wave-uniform, <= 24 steps
+  wreduce_block(a.r[i], b - a.first_block[i], red);
+}

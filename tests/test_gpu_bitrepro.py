@@ -177,3 +177,58 @@ def test_config5_numerical_gradient_step_is_bit_reproducible(device):
     assert len(runs[0]) >= 3 + 6 + 15
     _same_bits("config-5 field", runs, atomic=("encoding.params", "embedding"))
     assert math.isfinite(float(runs[0]["sdf"].abs().max()))
+
+
+_WREDUCE_WORKER = r"""
+import hashlib, json, sys, torch
+sys.path.insert(0, sys.argv[1])
+import bench as B
+from sdfstudio_amd.cameras.rays import RayBundle
+dev = torch.device("cuda", 0)
+out = {}
+for name, kw in (("small", dict(small=True)), ("config2_shape", dict(small=False, samples=32))):
+    torch.manual_seed(0)
+    model = B.build_model(dev, **kw)
+    model.train()
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    centers, rot = B.synthetic_cameras(dev)
+    o, d, norm, cam = B.draw_rays(centers, rot, 512, gen)
+    res = model(RayBundle(origins=o, directions=d, directions_norm=norm, camera_indices=cam[:, None]))
+    loss = sum(model.get_loss_dict(res, {"image": torch.rand(512, 3, device=dev, generator=gen)}).values())
+    loss.backward()
+    out[name] = {k: hashlib.sha256(p.grad.detach().cpu().numpy().tobytes()).hexdigest()[:16]
+                 for k, p in sorted(model.field.named_parameters()) if p.grad is not None}
+    out[name]["loss"] = float(loss)
+print(json.dumps(out))
+"""
+
+
+@pytest.mark.gpu
+def test_batched_weight_gradient_reduction_is_bit_identical_to_the_per_gemm_form():
+    """wreduce_batch_kernel (ONE launch reduces the split-K partials of every weight-gradient GEMM of a backward call, each GEMM with a
+    partial region of its own) against SDFHIP_WREDUCE_PER_GEMM=1 (rounds 1 - 6: one shared partial buffer, a reduction behind every GEMM).
+    Same partial sums added in the same order: every weight and bias gradient of the two MLPs (through the weight-norm backward) must be
+    the same bits - on the small golden network and on config 2's 8 x 256 + 4 x 256 network.  (The hash table's gradient is a sum of
+    atomics and is left out.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for mode, var in (("batched", None), ("per_gemm", "SDFHIP_WREDUCE_PER_GEMM")):
+        env = dict(os.environ)
+        env.pop("SDFHIP_WREDUCE_PER_GEMM", None)
+        if var is not None:
+            env[var] = "1"
+        r = subprocess.run([sys.executable, "-c", _WREDUCE_WORKER, root], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (mode, r.stderr[-3000:])
+        got[mode] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    for name in got["batched"]:
+        ref = got["per_gemm"][name]
+        mlp = [k for k in ref if k.startswith(("glin", "clin"))]
+        assert len(mlp) > 10, sorted(ref)
+        diff = [k for k in mlp if got["batched"][name][k] != ref[k]]
+        assert not diff, (name, diff)
+        assert got["batched"][name]["loss"] == ref["loss"]

@@ -392,9 +392,12 @@ def test_rgbd_losses_through_the_model(device):
     for p in model.parameters():
         p.grad = None
     sum(loss[k] for k in extra).backward()
-    table, w0 = model.field.encoding.params.grad, model.field.glin0.weight_v.grad
-    assert table is not None and torch.isfinite(table).all() and float(table.abs().max()) > 0.0
-    assert w0 is not None and torch.isfinite(w0).all() and float(w0.abs().max()) > 0.0
+    # (the hash table itself has an exactly zero gradient here: the geometric initialisation zeroes layer 0's feature columns, sdf_field.py:300-303)
+    for name in ("glin0", "glin4", "glin8"):
+        g = getattr(model.field, name).weight_v.grad
+        assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0.0, name
+    # layer 0's FEATURE columns receive gradient (the features are not zero), which is what moves the table from the second step on
+    assert float(model.field.glin0.weight_v.grad[:, 3:].abs().max()) > 0.0
 
 
 def test_gradient_slots_give_the_same_gradients_as_plain_autograd(device):
