@@ -72,7 +72,8 @@ class NeuSModel(NeuSFactoModel):
             ray_samples.flat_ends, self.field._cos_anneal_ratio, bg)
         field_outputs = {
             FieldHeadNames.RGB: rgb, FieldHeadNames.SDF: sdf[..., None], FieldHeadNames.GRADIENT: grad,
-            FieldHeadNames.ALPHA: alpha[..., None], "points_norm": x.norm(dim=-1, keepdim=True), "sampled_sdf": None,
+            FieldHeadNames.ALPHA: alpha[..., None], "points_norm": x.norm(dim=-1, keepdim=True),
+            "sampled_sdf": self.field.last_sampled_sdf if self.field.config.use_numerical_gradients else None,  # sdf_field.py:639-655
         }
         return {"ray_samples": ray_samples, "field_outputs": field_outputs, "weights": weights[..., None],
                 "rendered": (out_rgb, depth, normal, acc)}
@@ -84,9 +85,18 @@ class NeuSModel(NeuSFactoModel):
         if not self.training:
             return {"rgb_loss": surface_losses(outputs["rgb"], image)["rgb_loss"]}
         nrm = "normal" in batch and c.mono_normal_loss_mult > 0.0  # base_surface_model.py:419-424 (mono-neus / monosdf presets)
+        fo = outputs.get("field_outputs") or {}
+        curv = c.curvature_loss_multi > 0.0  # neuralangelo.py:163-178 (numerical-gradient field: the six tap values are on hand)
+        if curv and fo.get("sampled_sdf") is None:
+            raise ValueError("curvature_loss_multi > 0 needs sdf_field.use_numerical_gradients=True")
         loss = surface_losses(outputs["rgb"], image, eik_grad=outputs["eik_grad"], eikonal_mult=c.eikonal_loss_mult,
+                              sdf=fo[FieldHeadNames.SDF] if curv else None, sampled_sdf=fo["sampled_sdf"] if curv else None,
+                              delta=self.field.numerical_gradients_delta,
+                              curvature_mult=c.curvature_loss_multi * getattr(self, "curvature_loss_multi_factor", 1.0) if curv else 0.0,
                               normal_pred=outputs["normal"] if nrm else None, normal_gt=batch["normal"].to(image.device) if nrm else None,
                               normal_mult=c.mono_normal_loss_mult)
+        if curv and "curvature_loss" not in loss:  # weight exactly 0 (step 0 of the warm-up): the reference still reports the entry
+            loss["curvature_loss"] = outputs["rgb"].new_zeros(())
         if "eik_scale" in outputs:  # NeuS-acc's bounded packed arrays: the mean over all entries -> the mean over the valid ones (neus_acc.py)
             loss["eikonal_loss"] = loss["eikonal_loss"] * outputs["eik_scale"]
         if "fg_mask" in batch and c.fg_mask_loss_mult > 0.0:

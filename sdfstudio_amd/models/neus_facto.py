@@ -446,6 +446,8 @@ class NeuSFactoModel(nn.Module):
             curvature_mult=c.curvature_loss_multi * getattr(self, "curvature_loss_multi_factor", 1.0) if curv else 0.0,
             normal_pred=outputs["normal"] if nrm else None, normal_gt=batch["normal"].to(image.device) if nrm else None,
             normal_mult=c.mono_normal_loss_mult)
+        if curv and "curvature_loss" not in loss:  # weight exactly 0 (step 0 of the warm-up): the reference still reports the entry
+            loss["curvature_loss"] = outputs["rgb"].new_zeros(())
         if "fg_mask" in batch and c.fg_mask_loss_mult > 0.0:
             fg = batch["fg_mask"].float().to(image.device)
             loss["fg_mask_loss"] = fg_mask_loss(outputs["weights"].sum(dim=1), fg, c.fg_mask_loss_mult)  # clip + BCE + mean: one launch

@@ -376,6 +376,48 @@ def test_sensor_depth_loss_against_reference():
             assert [float(x) for x in ref] == [float(x) for x in got], t  # the same torch statement: bit for bit
 
 
+def test_neuralangelo_schedules_against_reference():
+    """models/neuralangelo.py:75-150: the three step schedules (numerical-gradient delta, progressive levels, curvature-loss factor) as
+    the pure function NeuralangeloModel.before_train_iteration applies - known answers minted from the reference's own callbacks, and,
+    where /root/reference is present, those callbacks themselves (the reference model built on CPU through the harness) step by step."""
+    import numpy as np
+    from sdfstudio_amd.models.neuralangelo import NeuralangeloModelConfig, neuralangelo_schedule
+
+    cfg = NeuralangeloModelConfig()
+    base, mx, n = 64, 4096, 16
+    growth = np.exp((np.log(mx) - np.log(base)) / (n - 1))  # sdf_field.py:226
+    known = {0: (0.03125, 4, 0.0), 2500: (0.027204705103003882, 4, 0.5), 5000: (0.023683071351724972, 4, 1.0),
+             7500: (0.020617311105826475, 4, 0.8705505632961242), 30000: (0.005920767837931244, 7, 0.25000000000000006),
+             100000: (0.00048828125, 21, 0.015625)}
+    for step, (delta, level, factor) in known.items():
+        s = neuralangelo_schedule(step, cfg, base, mx, growth)
+        assert s.level == level and abs(s.delta - delta) <= 1e-15 and abs(s.curvature_factor - factor) <= 1e-15, (step, s)
+    off = NeuralangeloModelConfig(enable_progressive_hash_encoding=False, enable_numerical_gradients_schedule=False, enable_curvature_loss_schedule=False)
+    assert neuralangelo_schedule(12345, off, base, mx, growth) == (None, None, 1.0)
+    if os.path.isdir("/root/reference/nerfstudio"):
+        from oracle import ref_harness
+
+        ns = ref_harness.import_reference()
+        import nerfstudio.models.neuralangelo as rna
+        from nerfstudio.data.scene_box import SceneBox
+
+        sb = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=0.5, far=4.5, radius=1.0, collider_type="near_far")
+        fcfg = ns.sf.SDFFieldConfig(use_grid_feature=True, num_layers=1, num_layers_color=2, hidden_dim=32, hidden_dim_color=32, bias=0.5, beta_init=0.3,
+                                    inside_outside=False, use_appearance_embedding=False, use_numerical_gradients=True, base_res=64, max_res=4096,
+                                    log2_hashmap_size=8, hash_features_per_level=8, hash_smoothstep=False, use_position_encoding=False)
+        model = rna.NeuralangeloModelConfig(sdf_field=fcfg, background_model="none").setup(scene_box=sb, num_train_data=4, world_size=1, local_rank=0)
+        cbs = model.get_training_callbacks(None)
+        assert [c.func.__name__ for c in cbs] == ["set_anneal", "set_delta", "set_mask", "set_curvature_loss_mult_factor"]
+        f = model.field
+        for step in (0, 1, 2500, 4999, 5000, 7500, 20000, 29999, 30000, 100000, 499999):
+            for c in cbs:
+                c.func(step)
+            s = neuralangelo_schedule(step, cfg, f.base_res, f.max_res, f.growth_factor)
+            active = int((f.hash_encoding_mask.reshape(f.num_levels, -1).amax(dim=1) > 0).sum())
+            assert f.numerical_gradients_delta == s.delta and active == min(s.level, f.num_levels), (step, s)
+            assert model.curvature_loss_multi_factor == s.curvature_factor, (step, s)
+
+
 def test_bench_algorithmic_bytes_of_geo_bwd():
     """bench.py's roofline numerator: the tile-packed blocks geo_bwd_kernel reads and writes per ray-sample, enumerated
     independently here (config 2: 8x256 geometry MLP, skip at layer 4, in0 = 3 blocks, h_3 padded to the full 8 blocks)."""

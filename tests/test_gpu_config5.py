@@ -403,3 +403,62 @@ def test_neus_render_with_background_merge_fwd_bwd(device, S, white):
     out_m = (inside == 0).to(device)
     assert float(got_leaves[0].grad[out_m].abs().max()) == 0.0 and float(got_leaves[2].grad[out_m].abs().max()) == 0.0
     assert float(got_leaves[4].grad[~out_m].abs().max()) == 0.0 and float(got_leaves[5].grad[~out_m].abs().max()) == 0.0
+
+
+def test_neuralangelo_model_steps_through_its_schedules(device):
+    """models/neuralangelo.py on the native path: NeuS's hierarchical sampler on the numerical-gradient field of the `neuralangelo` preset's
+    shape (1 x 256 + 4 x 256, 16 levels x 8 features, no position encoding; a small table), stepped through the schedule: the field
+    carries the schedule's delta and level mask, the loss dictionary has the reference's entries (curvature_loss included, exactly 0 at
+    step 0 of the warm-up), the masked levels' table rows get exactly zero gradient, and a numerical-gradient NeuS step equals the same
+    step through NeuSModel with the state set by hand."""
+    from sdfstudio_amd.cameras.rays import RayBundle
+    from sdfstudio_amd.fields.field_heads import FieldHeadNames
+    from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
+    from sdfstudio_amd.models.neuralangelo import NeuralangeloModel, NeuralangeloModelConfig, neuralangelo_schedule
+    from sdfstudio_amd.models.neus_facto import SceneBox
+    import bench as B
+
+    torch.manual_seed(0)
+    fcfg = SDFFieldConfig(use_grid_feature=True, num_layers=1, num_layers_color=4, hidden_dim=256, hidden_dim_color=256, geometric_init=True, bias=0.5,
+                          beta_init=0.3, inside_outside=False, use_appearance_embedding=False, use_numerical_gradients=True, base_res=64,
+                          max_res=4096, log2_hashmap_size=14, hash_features_per_level=8, hash_smoothstep=False, use_position_encoding=False)
+    mcfg = NeuralangeloModelConfig(sdf_field=fcfg, background_model="none", num_samples=32, num_samples_importance=32, num_up_sample_steps=2)
+    box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=0.5, far=4.5)
+    model = NeuralangeloModel(mcfg, box, num_train_data=49).to(device).train()
+    f = model.field
+    with torch.no_grad():  # off the geometric initialisation: layer 0's feature columns are zero there and the table would get no gradient at all
+        f.glin0.weight_v[:, 3:] += 0.05 * torch.randn_like(f.glin0.weight_v[:, 3:])
+    gen = torch.Generator(device=device)
+    gen.manual_seed(11)
+    centers, rot = B.synthetic_cameras(device)
+    feats = f.features_per_level
+    for step in (0, 5000, 30000):
+        model.before_train_iteration(step)
+        s = neuralangelo_schedule(step, mcfg, f.base_res, f.max_res, f.growth_factor)
+        assert f.numerical_gradients_delta == s.delta and model.curvature_loss_multi_factor == s.curvature_factor
+        mask = f.hash_encoding_mask.cpu()
+        assert float(mask[:s.level * feats].min()) == 1.0 and float(mask[s.level * feats:].abs().max()) == 0.0
+        o, d, norm, cam = B.draw_rays(centers, rot, 256, gen)
+        out = model(RayBundle(origins=o, directions=d, directions_norm=norm, camera_indices=cam[:, None]))
+        assert out["field_outputs"]["sampled_sdf"].shape == (256, 64, 6)
+        loss = model.get_loss_dict(out, {"image": torch.rand(256, 3, device=device, generator=gen)})
+        assert set(loss) == {"rgb_loss", "eikonal_loss", "curvature_loss"}, sorted(loss)
+        assert all(torch.isfinite(v).all() for v in loss.values())
+        if step == 0:
+            assert float(loss["curvature_loss"]) == 0.0
+        else:
+            # the reference's statement (neuralangelo.py:166-176) on the returned tensors
+            fo = out["field_outputs"]
+            sur = fo["sampled_sdf"].reshape(256, 64, 3, 2)
+            curv = (sur.sum(dim=-1) - 2 * fo[FieldHeadNames.SDF]) / (s.delta * s.delta)
+            want = torch.abs(curv).mean() * mcfg.curvature_loss_multi * s.curvature_factor
+            assert_close("curvature loss", loss["curvature_loss"], want, rtol=2e-5, atol=1e-10)
+        for p in model.parameters():
+            p.grad = None
+        sum(loss.values()).backward()
+        tg = f.encoding.params.grad.view(-1, feats)
+        lv = f.encoding.levels
+        assert float(tg[:int(lv[s.level].offset)].abs().max()) > 0.0
+        assert float(tg[int(lv[s.level].offset):].abs().max()) == 0.0  # levels above the mask: exactly zero
+        m = model.get_metrics_dict(out, {"image": torch.rand(256, 3, device=device, generator=gen)})
+        assert m["numerical_gradients_delta"] == s.delta and abs(m["activated_encoding"] - s.level / 16) < 1e-6
