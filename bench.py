@@ -648,7 +648,7 @@ def volsdf_legs(device, world, rank, steps=20, warmup=5):
             fcfg = SDFFieldConfig(bias=0.5, inside_outside=False, use_grid_feature=False, beta_init=0.1)
             kw = {"mono_depth_loss_mult": 0.1, "mono_normal_loss_mult": 0.05} if mono else {}
             box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=0.5, far=4.5)
-            return VolSDFModel(VolSDFModelConfig(sdf_field=fcfg, **kw), box, num_train_data=49).to(dev).train()
+            return VolSDFModel(VolSDFModelConfig(sdf_field=fcfg, background_model="none", **kw), box, num_train_data=49).to(dev).train()
         return f
 
     def mono_batch(n, gen):

@@ -15,6 +15,7 @@ as an image, losses.py:278-409; BASELINE config 4) and the foreground-mask BCE a
 scales) for callers outside the surface models.
 """
 import ctypes
+import math
 from typing import Dict, List, Optional
 
 import torch
@@ -337,3 +338,36 @@ def sensor_depth_loss(depth_pred: torch.Tensor, depth_gt: torch.Tensor, pred_sdf
     fs = torch.mean((torch.relu(truncation - pred_sdf) * front) ** 2) * (1.0 - n_front / n)
     sd = torch.mean(((z + pred_sdf) - depth_gt) ** 2 * near) * (1.0 - n_near / n)
     return l1, fs, sd
+
+
+def _s3im_window(kernel_size: int, channel: int, like: torch.Tensor) -> torch.Tensor:
+    """S3IM.create_kernel (model_components/losses.py:701-709): the outer product of the reference's (off-centre, x - size // 2) Gaussian
+    of sigma 1.5, one copy per channel (grouped convolution)."""
+    g = torch.tensor([math.exp(-((x - kernel_size // 2) ** 2) / float(2 * 1.5 ** 2)) for x in range(kernel_size)])
+    g = (g / g.sum()).unsqueeze(1)
+    w = g.mm(g.t()).float().unsqueeze(0).unsqueeze(0)
+    return w.expand(channel, 1, kernel_size, kernel_size).contiguous().to(device=like.device, dtype=like.dtype)
+
+
+def s3im_loss(src_vec: torch.Tensor, tar_vec: torch.Tensor, kernel_size: int = 4, stride: int = 4, repeat_time: int = 10,
+              patch_height: int = 32) -> torch.Tensor:
+    """S3IM (model_components/losses.py:689-771; base_surface_model.py:408-409 calls it as s3im_loss(image, outputs["rgb"])): the batch of
+    N pixel colours, once in order and repeat_time - 1 times shuffled, laid out as ONE virtual image of patch_height rows; 1 - the mean
+    SSIM of the two images under a kernel_size window with the given stride.  The permutations come from torch.randperm on the host's
+    default generator, as in the reference (same seed, same patches).  Plain torch operators on the device (two grouped convolutions'
+    worth of 30 K pixels: not a kernel of this path); N * repeat_time must be a multiple of patch_height."""
+    n = len(tar_vec)
+    idx = torch.cat([torch.arange(n) if i == 0 else torch.randperm(n) for i in range(repeat_time)]).to(tar_vec.device)
+    tar = tar_vec[idx].permute(1, 0).reshape(1, 3, patch_height, -1)
+    src = src_vec[idx].permute(1, 0).reshape(1, 3, patch_height, -1)
+    w = _s3im_window(kernel_size, 3, src)
+    pad = (kernel_size - 1) // 2
+    conv = lambda x: torch.nn.functional.conv2d(x, w, padding=pad, groups=3, stride=stride)  # noqa: E731
+    mu1, mu2 = conv(src), conv(tar)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1.pow(2), mu2.pow(2), mu1 * mu2
+    sigma1_sq = conv(src * src) - mu1_sq
+    sigma2_sq = conv(tar * tar) - mu2_sq
+    sigma12 = conv(src * tar) - mu1_mu2
+    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    ssim_map = ((2 * mu1_mu2 + c1) * (2 * sigma12 + c2)) / ((mu1_sq + mu2_sq + c1) * (sigma1_sq + sigma2_sq + c2))
+    return 1 - ssim_map.mean()

@@ -7,7 +7,7 @@ Host glue only; every heavy stage is one native call:
   renderers.neus_render  (alpha + transmittance scan + rgb/depth/normal/accumulation, one wavefront per ray)
 """
 from dataclasses import dataclass, field
-from typing import Dict, List, Tuple, Type
+from typing import Dict, List, Optional, Tuple, Type
 
 import numpy as np
 import torch
@@ -18,7 +18,8 @@ from sdfstudio_amd.cameras.rays import RayBundle
 from sdfstudio_amd.fields.density_fields import HashMLPDensityField
 from sdfstudio_amd.fields.field_heads import FieldHeadNames
 from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
-from sdfstudio_amd.model_components.losses import fg_mask_loss, interlevel_loss_zip, monosdf_depth_loss, sensor_depth_loss, surface_losses
+from sdfstudio_amd.model_components.losses import (fg_mask_loss, interlevel_loss_zip, monosdf_depth_loss, s3im_loss, sensor_depth_loss,
+                                                    surface_losses)
 from sdfstudio_amd.model_components.ray_samplers import ProposalNetworkSampler
 from sdfstudio_amd.model_components.renderers import neus_render
 from sdfstudio_amd.model_components.scene_colliders import build_collider
@@ -114,14 +115,42 @@ class NeuSFactoModelConfig:
     fg_mask_loss_mult: float = 0.01
     mono_normal_loss_mult: float = 0.0
     mono_depth_loss_mult: float = 0.0
+    use_average_appearance_embedding: bool = False  # base_surface_model.py:81 -> SDFField / the "grid" background field (eval: mean embedding instead of zeros)
     sensor_depth_truncation: float = 0.015         # base_surface_model.py:101-109 (RGB-D scenes: batch["sensor_depth"])
     sensor_depth_l1_loss_mult: float = 0.0
     sensor_depth_freespace_loss_mult: float = 0.0
     sensor_depth_sdf_loss_mult: float = 0.0
     sparse_points_sdf_loss_mult: float = 0.0       # :109 (batch["sparse_sfm_points"])
+    s3im_loss_mult: float = 0.0                    # :111-119 (S3IM on the batch's colours; torch operators)
+    s3im_kernel_size: int = 4
+    s3im_stride: int = 4
+    s3im_repeat_time: int = 10
+    s3im_patch_height: int = 32
+    # accepted for configuration compatibility, refused when switched on (populate_modules): the multi-view patch-warping loss needs the
+    # data manager's neighbouring images (:91-100, model_components/patch_warping.py); the periodic-volume TV loss belongs to an encoding
+    # the reference itself cannot run with grid features
+    patch_warp_loss_mult: float = 0.0
+    patch_size: int = 11
+    patch_warp_angle_thres: float = 0.3
+    min_patch_variance: float = 0.01
+    topk: int = 4
+    periodic_tvl_mult: float = 0.0
+    # models/base_model.py:45-49 and models/neus_facto.py:51-54: read by nothing on the surface models' path (SurfaceModel.populate_modules
+    # replaces the collider, base_surface_model.py:165-176; the proposal sampler's update schedule is the constant -1, neus_facto.py:138)
+    enable_collider: bool = True
+    collider_params: Optional[Dict[str, float]] = None
+    loss_coefficients: Optional[Dict[str, float]] = None
+    proposal_update_every: int = 5
+    proposal_warmup: int = 5000
+    # models/neus.py:38-47 (the reference's NeuSFactoModelConfig IS a NeuSModelConfig; its proposal sampler never reads them)
+    num_samples: int = 64
+    num_samples_importance: int = 64
+    num_up_sample_steps: int = 4
+    base_variance: float = 64
+    perturb: bool = True
     sdf_field: SDFFieldConfig = field(default_factory=SDFFieldConfig)
     overwrite_near_far_plane: bool = False  # base_surface_model.py:75: fixed planes replace the scene box's collider
-    background_model: str = "none"   # the reference's default is "mlp" (base_surface_model.py:123); "mlp", "grid", "none" are built
+    background_model: str = "mlp"    # base_surface_model.py:123; "mlp", "grid", "none" are built (the BASELINE configs run with "none")
     far_plane_bg: float = 1000.0
     num_samples_outside: int = 32
     num_proposal_samples_per_ray: Tuple[int, ...] = (256, 96)
@@ -211,12 +240,15 @@ class NeuSFactoModel(nn.Module):
         """SurfaceModel.populate_modules (base_surface_model.py:144-216): contraction, SDF field, background field + sampler,
         renderers - shared by the three model mirrors."""
         c = self.config
+        if c.patch_warp_loss_mult > 0.0 or c.periodic_tvl_mult > 0.0:
+            raise NotImplementedError("patch_warp_loss_mult / periodic_tvl_mult > 0: the multi-view patch-warping loss and the periodic-volume "
+                                      "TV loss are not built (sdfstudio_amd/models/neus_facto.py NeuSFactoModelConfig)")
         if c.scene_contraction_norm not in ("inf", "l2"):
             raise ValueError("Invalid scene contraction norm")  # base_surface_model.py:148-155
         self.collider = build_collider(self.scene_box, c)  # base_surface_model.py:165-176: near_far / box / sphere
         self.scene_contraction = SceneContraction(order=float("inf") if c.scene_contraction_norm == "inf" else None)
         self.field = c.sdf_field.setup(aabb=self.scene_box.aabb, spatial_distortion=self.scene_contraction,
-                                       num_images=self.num_train_data, use_average_appearance_embedding=False)
+                                       num_images=self.num_train_data, use_average_appearance_embedding=c.use_average_appearance_embedding)  # :158-163
         B.build_background(self, c)
 
     def _background_params(self) -> List[nn.Parameter]:
@@ -421,6 +453,9 @@ class NeuSFactoModel(nn.Module):
             loss["sensor_l1_loss"] = l1 * c.sensor_depth_l1_loss_mult
             loss["sensor_freespace_loss"] = fs * c.sensor_depth_freespace_loss_mult
             loss["sensor_sdf_loss"] = sd * c.sensor_depth_sdf_loss_mult
+        if c.s3im_loss_mult > 0.0:  # :408-409
+            loss["s3im_loss"] = s3im_loss(batch["image"].to(outputs["rgb"].device), outputs["rgb"], c.s3im_kernel_size, c.s3im_stride,
+                                          c.s3im_repeat_time, c.s3im_patch_height) * c.s3im_loss_mult
         if "sparse_sfm_points" in batch and c.sparse_points_sdf_loss_mult > 0.0:
             pts = batch["sparse_sfm_points"].to(outputs["rgb"].device)
             sdf = self.field.forward_geonetwork(pts)[:, 0].contiguous()

@@ -200,7 +200,7 @@ def product_model_from_params(params, cfg: O.ModelCfg, device, field_kwargs=None
             {"hidden_dim": p.hidden_dim, "log2_hashmap_size": p.log2_hashmap_size, "num_levels": p.num_levels,
              "max_res": p.max_res, "base_res": p.base_res} for p in cfg.proposals
         ],
-        eikonal_loss_mult=cfg.eikonal_loss_mult, interlevel_loss_mult=cfg.interlevel_loss_mult,
+        eikonal_loss_mult=cfg.eikonal_loss_mult, interlevel_loss_mult=cfg.interlevel_loss_mult, background_model="none",
     )
     box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=cfg.near, far=cfg.far)
     model = NeuSFactoModel(mcfg, box, num_train_data=49)

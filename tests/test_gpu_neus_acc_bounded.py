@@ -33,7 +33,7 @@ def _model(device, bounded):
                           log2_hashmap_size=fc.log2_hashmap_size, hash_features_per_level=fc.hash_features_per_level,
                           hash_smoothstep=fc.hash_smoothstep)
     box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=cfg.near, far=cfg.far)
-    model = NeuSAccModel(NeuSAccModelConfig(sdf_field=fcfg, num_samples=16, num_samples_importance=16, num_up_sample_steps=2), box, 49)
+    model = NeuSAccModel(NeuSAccModelConfig(sdf_field=fcfg, num_samples=16, num_samples_importance=16, num_up_sample_steps=2, background_model="none"), box, 49)
     load_params(model, params)
     model = model.to(device).train()
     model.sampler.bounded = bounded

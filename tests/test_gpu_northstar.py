@@ -88,7 +88,7 @@ def test_northstar_bars_full_shape_volsdf_on_oracle_samples(device):
             p[k] = p[k] + 0.02 * torch.randn(p[k].shape, generator=gen)
     fcfg = SDFFieldConfig(bias=0.5, inside_outside=False, use_grid_feature=False, beta_init=0.1)
     box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=cfg.near, far=cfg.far)
-    model = VolSDFModel(VolSDFModelConfig(sdf_field=fcfg), box, num_train_data=49)
+    model = VolSDFModel(VolSDFModelConfig(sdf_field=fcfg, background_model="none"), box, num_train_data=49)
     load_params(model, p)
     model = model.to(device).eval()
     n = 96
@@ -366,6 +366,7 @@ def test_rgbd_losses_through_the_model(device):
     c = model.config
     c.sensor_depth_l1_loss_mult, c.sensor_depth_freespace_loss_mult, c.sensor_depth_sdf_loss_mult = 0.1, 10.0, 6000.0
     c.sparse_points_sdf_loss_mult = 1.0
+    c.s3im_loss_mult = 1.0  # base_surface_model.py:408-409 (512 rays x 10 repeats = a 32-row virtual image)
     model.train()
     gen = torch.Generator(device=device)
     gen.manual_seed(3)
@@ -379,7 +380,9 @@ def test_rgbd_losses_through_the_model(device):
     base = model.get_loss_dict(out, {"image": batch["image"]})
     loss = model.get_loss_dict(out, batch)
     extra = {"sensor_l1_loss", "sensor_freespace_loss", "sensor_sdf_loss", "sparse_sfm_points_sdf_loss"}
-    assert set(loss) == set(base) | extra
+    assert set(loss) == set(base) | extra and "s3im_loss" in base
+    assert 0.0 < float(loss["s3im_loss"]) < 1.0  # 1 - SSIM of a random image against the render
+    extra = extra | {"s3im_loss"}
     # against the statement on the same tensors
     from sdfstudio_amd.fields.field_heads import FieldHeadNames
     from sdfstudio_amd.model_components.losses import sensor_depth_loss

@@ -261,7 +261,7 @@ def test_neus_model_against_reference_golden(device, mode):
     steps = int(g["in"]["steps"])
     mcfg = NeuSModelConfig(sdf_field=fcfg, num_samples=int(g["in"]["num_samples"]),
                            num_samples_importance=int(g["in"]["num_importance"]), num_up_sample_steps=steps,
-                           base_variance=float(g["in"]["base_variance"]), eikonal_loss_mult=cfg.eikonal_loss_mult)
+                           base_variance=float(g["in"]["base_variance"]), eikonal_loss_mult=cfg.eikonal_loss_mult, background_model="none")
     box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=cfg.near, far=cfg.far)
     model = NeuSModel(mcfg, box, num_train_data=49)
     load_params(model, g["param"])
@@ -436,7 +436,7 @@ def test_volsdf_model_against_reference_golden(device, mode):
                           max_res=fc.max_res, base_res=fc.base_res, log2_hashmap_size=fc.log2_hashmap_size,
                           hash_features_per_level=fc.hash_features_per_level, hash_smoothstep=fc.hash_smoothstep)
     mcfg = VolSDFModelConfig(sdf_field=fcfg, num_samples=int(g["in"]["num_samples"]), num_samples_eval=int(g["in"]["num_samples_eval"]),
-                             num_samples_extra=int(g["in"]["num_samples_extra"]), eikonal_loss_mult=cfg.eikonal_loss_mult)
+                             num_samples_extra=int(g["in"]["num_samples_extra"]), eikonal_loss_mult=cfg.eikonal_loss_mult, background_model="none")
     box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=cfg.near, far=cfg.far)
     model = VolSDFModel(mcfg, box, num_train_data=49)
     load_params(model, g["param"])
@@ -1171,7 +1171,7 @@ def test_config1_volsdf_pure_mlp_full_size(device):
     torch.manual_seed(0)
     fcfg = SDFFieldConfig(bias=0.5, inside_outside=False, use_grid_feature=False, beta_init=0.1)
     box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=0.5, far=4.5)
-    model = VolSDFModel(VolSDFModelConfig(sdf_field=fcfg), box, num_train_data=49).to(device).train()
+    model = VolSDFModel(VolSDFModelConfig(sdf_field=fcfg, background_model="none"), box, num_train_data=49).to(device).train()
     n = 512
     o, d, cam = O.synthetic_rays(n)
     out = model(_bundle(o, d, cam, 0.5, 4.5, device))
@@ -1726,7 +1726,7 @@ def test_config1_full_shape_volsdf_against_oracle(device):
             p[k] = p[k] + 0.02 * torch.randn(p[k].shape, generator=gen)
     fcfg = SDFFieldConfig(bias=0.5, inside_outside=False, use_grid_feature=False, beta_init=0.1)
     box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=cfg.near, far=cfg.far)
-    model = VolSDFModel(VolSDFModelConfig(sdf_field=fcfg), box, num_train_data=49)
+    model = VolSDFModel(VolSDFModelConfig(sdf_field=fcfg, background_model="none"), box, num_train_data=49)
     load_params(model, p)
     model = model.to(device).eval()
     n = 96
@@ -1814,7 +1814,7 @@ def test_analytic_gradient_on_points_and_unisurf_step(device):
                           hash_smoothstep=fc.hash_smoothstep)
     box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=cfg.near, far=cfg.far)
     model = UniSurfModel(UniSurfModelConfig(sdf_field=fcfg, num_samples_interval=16, num_samples_importance=8, num_marching_steps=48,
-                                            num_samples_outside=8), box, 49)
+                                            num_samples_outside=8, background_model="none"), box, 49)
     load_params(model, {k: v for k, v in g["param"].items() if not k.startswith("proposal_networks")})
     model = model.to(device).train()
     x = (torch.rand(301, 3) * 2 - 1) * 1.6  # some points outside the unit cube: the contraction matters
@@ -1924,7 +1924,7 @@ def test_neus_acc_model_packed_path(device):
                           log2_hashmap_size=fc.log2_hashmap_size, hash_features_per_level=fc.hash_features_per_level,
                           hash_smoothstep=fc.hash_smoothstep)
     box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=cfg.near, far=cfg.far)
-    model = NeuSAccModel(NeuSAccModelConfig(sdf_field=fcfg, num_samples=16, num_samples_importance=16, num_up_sample_steps=2), box, 49)
+    model = NeuSAccModel(NeuSAccModelConfig(sdf_field=fcfg, num_samples=16, num_samples_importance=16, num_up_sample_steps=2, background_model="none"), box, 49)
     load_params(model, params)
     model = model.to(device).train()
     smp = model.sampler
