@@ -69,10 +69,12 @@ class _PropParams(nn.Module):
 
 
 class HashMLPDensityField(nn.Module):
-    """density_fields.py:40-121.  Only the shape neus-facto uses is built: 5 levels x 2 features, 16 hidden, 1 layer."""
+    """density_fields.py:40-121.  Signature and defaults as the reference's; only the shape neus-facto's proposal networks use is built
+    (5 levels x 2 features, 16 hidden, one hidden layer: neus_facto.py:59-64 passes exactly these) - the class defaults themselves
+    (8 levels, 64 hidden) are refused, not silently replaced."""
 
-    def __init__(self, aabb, num_layers: int = 2, hidden_dim: int = 16, spatial_distortion=None, use_linear=False,
-                 num_levels=5, max_res=64, base_res=16, log2_hashmap_size=17, features_per_level=2) -> None:
+    def __init__(self, aabb, num_layers: int = 2, hidden_dim: int = 64, spatial_distortion=None, use_linear=False,
+                 num_levels=8, max_res=1024, base_res=16, log2_hashmap_size=18, features_per_level=2) -> None:
         super().__init__()
         if use_linear or num_layers != 2 or hidden_dim != 16 or num_levels != 5 or features_per_level != 2:
             raise NotImplementedError(
@@ -91,9 +93,11 @@ class HashMLPDensityField(nn.Module):
         _, n_entries = _lib.grid_levels(self.grid_cfg)
         self.mlp_base = _PropParams(n_entries * features_per_level, hidden_dim, num_levels * features_per_level)
 
-    def density_fn(self, positions_or_samples) -> torch.Tensor:
-        """base_field.py:48-65: densities [..., 1] at explicit positions [...,3], or (fused) at a RaySamples' midpoints."""
+    def density_fn(self, positions) -> torch.Tensor:
+        """base_field.py:48-65: densities [..., 1] at explicit positions [...,3]; given a RaySamples instead (an extension the proposal
+        sampler uses) the fused kernel forms the frustum mid points itself."""
         p = self.mlp_base
+        positions_or_samples = positions
         if isinstance(positions_or_samples, torch.Tensor):
             pos = positions_or_samples
             flat = pos.reshape(-1, 3).contiguous().float()
@@ -106,6 +110,8 @@ class HashMLPDensityField(nn.Module):
     def get_density(self, ray_samples):
         return self.density_fn(ray_samples), None
 
-    def forward(self, ray_samples):
+    def forward(self, ray_samples, compute_normals: bool = False):
+        if compute_normals:  # base_field.py:104-121: normals of a DENSITY field; nothing on the surface models' path asks for them
+            raise NotImplementedError("HashMLPDensityField: compute_normals is not built")
         density, _ = self.get_density(ray_samples)
         return {"density": density}

@@ -812,6 +812,38 @@ class SDFField(nn.Module):
         sampled_sdf = taps.view(6, n, s).permute(1, 2, 0).contiguous()  # :644
         return sdf.view(n, s), grad.view(n, s, 3), rgb.view(n, s, 3), x.detach().view(n, s, 3), sampled_sdf
 
+    def density_fn(self, positions: torch.Tensor) -> torch.Tensor:
+        """Field.density_fn (fields/base_field.py:48-65): the density at explicit positions [..., 3] - the reference wraps them in
+        zero-length frustums and calls get_density, i.e. the Laplace density of the geometry network's sdf at the positions as given."""
+        h = self.forward_geonetwork(positions.reshape(-1, 3))
+        return self.laplace_density(h[:, :1]).view(*positions.shape[:-1], 1)
+
+    def get_normals(self):
+        """Field.get_normals (fields/base_field.py:78-92) differentiates a density the field recorded under compute_normals; SDFField never
+        records one (its normals are d sdf / dx, FieldHeadNames.NORMAL of get_outputs): same assertion as the reference's."""
+        raise AssertionError("Sample locations must be set before calling get_normals.")
+
+    def get_colors(self, points, directions, gradients, geo_features, camera_indices):
+        """sdf_field.py:532-612 on caller-supplied tensors: points / directions / gradients [N, S, 3], geo_features [N, S, geo_feat_dim],
+        camera_indices [N, S] -> rgb [N, S, 3], through the native colour operator (sdfhip_color_forward / _backward; the operator takes
+        directions and the appearance embedding PER RAY: both are constant along a ray in every caller of the reference, whose RaySamples
+        broadcast them over the samples, and are read from sample 0 here)."""
+        c = self.config
+        if c.use_diffuse_color or c.use_specular_tint or c.use_reflections or c.use_n_dot_v:
+            raise NotImplementedError("get_colors on caller-supplied tensors with the ref-nerf options is not built (they run inside forward / get_outputs)")
+        n, s = points.shape[0], points.shape[1]
+        d = directions.reshape(n, s, 3)[:, 0].contiguous().float()
+        cam = camera_indices.reshape(n, -1)[:, 0]
+        emb = None
+        if self.config.use_appearance_embedding:
+            if self.training:
+                emb = self.embedding_appearance(cam)
+            elif self.use_average_appearance_embedding:
+                emb = self.embedding_appearance.mean(dim=0)[None, :].expand(n, -1)
+        rgb = _ColorFunction.apply(self._theta(), geo_features.reshape(n * s, -1), gradients.reshape(n * s, 3), emb, self,
+                                   points.reshape(n * s, 3).detach(), d, n, s)
+        return rgb.view(n, s, 3)
+
     def get_density(self, ray_samples):
         """sdf_field.py:469-475: Laplace density and geometry feature at the frustum START positions (no contraction, no grad)."""
         o, d, st, _ = unpack_ray_samples(ray_samples)

@@ -65,24 +65,44 @@ def _make_uniform_samples(ray_bundle: RayBundle, bins, starts, ends) -> RaySampl
     return _make_samples(ray_bundle, bins, starts, ends, "uniform")
 
 
+def _identify_spacing(spacing_fn: Callable, spacing_fn_inv: Callable) -> str:
+    """Which built spacing a (spacing_fn, spacing_fn_inv) pair of the reference's SpacedSampler constructor (ray_samplers.py:66-78) is: the
+    kernel holds the five pairs the reference's own samplers use (:130-247), recognised by their values at a few points."""
+    t = torch.tensor([0.25, 0.75, 1.0, 2.0, 7.5], dtype=torch.float64)
+    for name, (_, fn, inv) in _SPACINGS.items():
+        try:
+            if torch.allclose(torch.as_tensor(spacing_fn(t), dtype=torch.float64), fn(t), rtol=1e-12, atol=0.0) and \
+                    torch.allclose(torch.as_tensor(spacing_fn_inv(fn(t)), dtype=torch.float64), inv(fn(t)), rtol=1e-12, atol=0.0):
+                return name
+        except Exception:  # noqa: BLE001 - a callable that does not take tensors is simply not one of the five
+            continue
+    raise NotImplementedError("SpacedSampler: the native sampler is built for the reference's own spacing functions (uniform, 1 / x, sqrt, "
+                              "log, uniform + linear-disparity piecewise: ray_samplers.py:130-247), not for arbitrary callables")
+
+
 class SpacedSampler(Sampler):
     """ray_samplers.py:55-127: stratified bins in a spacing domain mapped back to euclidean distances, ONE kernel launch
-    (sdfhip_sample_spacing) for the whole family.  `spacing` names the (spacing_fn, spacing_fn_inv) pair; the reference's
-    default is per-bin-edge jitter (single_jitter=False, ray_samplers.py:105-113), neus-facto uses one draw per ray."""
+    (sdfhip_sample_spacing) for the whole family.  Constructor as the reference's (spacing_fn, spacing_fn_inv, num_samples,
+    train_stratified, single_jitter); `spacing` names the pair directly.  The reference's default is per-bin-edge jitter
+    (single_jitter=False, ray_samplers.py:105-113), neus-facto uses one draw per ray."""
 
     spacing = "uniform"
 
-    def __init__(self, num_samples: Optional[int] = None, train_stratified=True, single_jitter=False, spacing: Optional[str] = None) -> None:
+    def __init__(self, spacing_fn: Optional[Callable] = None, spacing_fn_inv: Optional[Callable] = None, num_samples: Optional[int] = None,
+                 train_stratified=True, single_jitter=False, spacing: Optional[str] = None) -> None:
         super().__init__(num_samples=num_samples)
         if spacing is not None:
             self.spacing = spacing
+        elif spacing_fn is not None or spacing_fn_inv is not None:
+            self.spacing = _identify_spacing(spacing_fn, spacing_fn_inv)
         if self.spacing not in _SPACINGS:
             raise ValueError(f"unknown spacing {self.spacing!r}; built: {sorted(_SPACINGS)}")
+        self.spacing_fn, self.spacing_fn_inv = _SPACINGS[self.spacing][1], _SPACINGS[self.spacing][2]
         self.train_stratified = train_stratified
         self.single_jitter = single_jitter
         self.jitter_override: Optional[torch.Tensor] = None  # tests inject the draw: [N] / [N,1] (single) or [N,S+1] (per edge)
 
-    def generate_ray_samples(self, ray_bundle: RayBundle, num_samples: Optional[int] = None) -> RaySamples:
+    def generate_ray_samples(self, ray_bundle: Optional[RayBundle] = None, num_samples: Optional[int] = None) -> RaySamples:
         lib = _lib.load()
         assert ray_bundle is not None and ray_bundle.nears is not None and ray_bundle.fars is not None
         s = num_samples or self.num_samples
@@ -110,11 +130,17 @@ class UniformSampler(SpacedSampler):
 
     spacing = "uniform"
 
+    def __init__(self, num_samples: Optional[int] = None, train_stratified=True, single_jitter=False) -> None:
+        super().__init__(num_samples=num_samples, train_stratified=train_stratified, single_jitter=single_jitter, spacing=self.spacing)
+
 
 class LinearDisparitySampler(SpacedSampler):
     """ray_samplers.py:154-175 (the background sampler of the surface models, base_surface_model.py:214)."""
 
     spacing = "lindisp"
+
+    def __init__(self, num_samples: Optional[int] = None, train_stratified=True, single_jitter=False) -> None:
+        super().__init__(num_samples=num_samples, train_stratified=train_stratified, single_jitter=single_jitter, spacing=self.spacing)
 
 
 class SqrtSampler(SpacedSampler):
@@ -122,11 +148,17 @@ class SqrtSampler(SpacedSampler):
 
     spacing = "sqrt"
 
+    def __init__(self, num_samples: Optional[int] = None, train_stratified=True, single_jitter=False) -> None:
+        super().__init__(num_samples=num_samples, train_stratified=train_stratified, single_jitter=single_jitter, spacing=self.spacing)
+
 
 class LogSampler(SpacedSampler):
     """ray_samplers.py:201-218."""
 
     spacing = "log"
+
+    def __init__(self, num_samples: Optional[int] = None, train_stratified=True, single_jitter=False) -> None:
+        super().__init__(num_samples=num_samples, train_stratified=train_stratified, single_jitter=single_jitter, spacing=self.spacing)
 
 
 class UniformLinDispPiecewiseSampler(SpacedSampler):
@@ -136,7 +168,7 @@ class UniformLinDispPiecewiseSampler(SpacedSampler):
 
     def __init__(self, num_samples: Optional[int] = None, train_stratified=True, single_jitter=False) -> None:
         # defaults as the reference's (ray_samplers.py:235-240); every caller on the path passes single_jitter (neus_facto.py:145)
-        super().__init__(num_samples=num_samples, train_stratified=train_stratified, single_jitter=single_jitter)
+        super().__init__(num_samples=num_samples, train_stratified=train_stratified, single_jitter=single_jitter, spacing=self.spacing)
 
 
 class NeuSSampler(Sampler):
@@ -357,11 +389,15 @@ class PDFSampler(Sampler):
         self.spacing = spacing  # the spacing domain the incoming ray samples' bins live in (RaySamples carry only the closure)
         self.jitter_override: Optional[torch.Tensor] = None
 
-    def generate_ray_samples(self, ray_bundle: RayBundle, ray_samples: RaySamples, weights: torch.Tensor,
-                             num_samples: Optional[int] = None, anneal: float = 1.0) -> RaySamples:
+    def generate_ray_samples(self, ray_bundle: Optional[RayBundle] = None, ray_samples: Optional[RaySamples] = None,
+                             weights: Optional[torch.Tensor] = None, num_samples: Optional[int] = None, eps: float = 1e-5,
+                             anneal: float = 1.0) -> RaySamples:
         lib = _lib.load()
         if ray_samples is None or ray_bundle is None:
             raise ValueError("ray_samples and ray_bundle must be provided")
+        assert weights is not None, "weights must be provided"
+        if eps != 1e-5:  # ray_samplers.py:281,307: the padding threshold of the weight sum is a constant of the kernel
+            raise NotImplementedError("PDFSampler: eps is fixed at the reference's default 1e-5 in pdf_sample_kernel")
         s_out = num_samples or self.num_samples
         w = weights[..., 0] if weights.dim() == 3 else weights
         w = w.detach()
@@ -395,7 +431,7 @@ class ProposalNetworkSampler(Sampler):
     """ray_samplers.py:497-578.  density_fns take a RaySamples (fused midpoint + contraction + grid + MLP kernel)."""
 
     def __init__(self, num_proposal_samples_per_ray: Tuple[int, ...] = (64,), num_nerf_samples_per_ray: int = 32,
-                 num_proposal_network_iterations: int = 2, use_uniform_sampler: bool = False, single_jitter: bool = True,
+                 num_proposal_network_iterations: int = 2, use_uniform_sampler: bool = False, single_jitter: bool = False,
                  update_sched: Callable = lambda x: 1) -> None:
         super().__init__()
         if num_proposal_network_iterations < 1:
@@ -422,7 +458,9 @@ class ProposalNetworkSampler(Sampler):
         self._step = step
         self._steps_since_update += 1
 
-    def generate_ray_samples(self, ray_bundle: RayBundle, density_fns: List[Callable]):
+    def generate_ray_samples(self, ray_bundle: Optional[RayBundle] = None, density_fns: Optional[List[Callable]] = None):
+        assert ray_bundle is not None
+        assert density_fns is not None
         weights_list, ray_samples_list = [], []
         n = self.num_proposal_network_iterations
         weights, ray_samples = None, None

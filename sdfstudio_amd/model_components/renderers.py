@@ -217,19 +217,34 @@ def volsdf_render(sdf, gradients, rgb, beta, starts, ends, background: Optional[
     return _VolsdfRender.apply(sdf, gradients, rgb, beta, starts.contiguous(), ends.contiguous(), background)
 
 
-class RGBRenderer(nn.Module):
-    """renderers.py:42-118 for dense [N,S] samples: sum_s w rgb + bg (1 - sum_s w); clamp to [0,1] in eval.
-    background_color: an RGB tensor, "random" (a fresh uniform colour per ray and call, :86-87), "last_sample" (the colour of
-    the ray's last sample, :84-85), or None (black)."""
+def _sum_along_rays(values: torch.Tensor, ray_indices: Optional[torch.Tensor], num_rays: Optional[int]) -> torch.Tensor:
+    """Sum over the samples of a ray: dim -2 of dense [..., S, D] samples, or - packed samples [P, D] with their ray index, as
+    nerfacc.accumulate_along_rays (renderers.py:74-79,192-194) - an index_add into [num_rays, D]."""
+    if ray_indices is not None and num_rays is not None:
+        out = torch.zeros(int(num_rays), values.shape[-1], device=values.device, dtype=values.dtype)
+        return out.index_add_(0, ray_indices.reshape(-1).long(), values.reshape(-1, values.shape[-1]))
+    return torch.sum(values, dim=-2)
 
-    def __init__(self, background_color=None) -> None:
+
+class RGBRenderer(nn.Module):
+    """renderers.py:42-118: sum_s w rgb + bg (1 - sum_s w); clamp to [0,1] in eval.  background_color: an RGB tensor, "random" (the
+    reference's default: a fresh uniform colour per ray and call, :86-87), "last_sample" (the colour of the ray's last sample, :84-85;
+    dense samples only), or None (black: an extension - the reference asserts a tensor)."""
+
+    def __init__(self, background_color="random") -> None:
         super().__init__()
         self.background_color = background_color
 
-    def forward(self, rgb: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
-        comp = torch.sum(weights * rgb, dim=-2)
-        acc = torch.sum(weights, dim=-2)
-        bg = self.background_color
+    @classmethod
+    def combine_rgb(cls, rgb: torch.Tensor, weights: torch.Tensor, background_color="random", ray_indices: Optional[torch.Tensor] = None,
+                    num_rays: Optional[int] = None) -> torch.Tensor:
+        """renderers.py:53-92 (dense [..., S, .] samples, or packed samples with ray_indices / num_rays)."""
+        packed = ray_indices is not None and num_rays is not None
+        if packed and isinstance(background_color, str) and background_color == "last_sample":
+            raise NotImplementedError("Background color 'last_sample' not implemented for packed samples.")
+        comp = _sum_along_rays(weights * rgb, ray_indices, num_rays)
+        acc = _sum_along_rays(weights, ray_indices, num_rays)
+        bg = background_color
         if isinstance(bg, str):
             if bg == "last_sample":
                 bg = rgb[..., -1, :]
@@ -239,6 +254,11 @@ class RGBRenderer(nn.Module):
                 raise ValueError(f"background_color must be an RGB tensor, 'random' or 'last_sample', not {bg!r}")
         if isinstance(bg, torch.Tensor):
             comp = comp + bg.to(comp) * (1.0 - acc)
+        return comp
+
+    def forward(self, rgb: torch.Tensor, weights: torch.Tensor, ray_indices: Optional[torch.Tensor] = None,
+                num_rays: Optional[int] = None) -> torch.Tensor:
+        comp = self.combine_rgb(rgb, weights, background_color=self.background_color, ray_indices=ray_indices, num_rays=num_rays)
         if not self.training:
             comp = comp.clamp(0.0, 1.0)
         return comp
@@ -247,15 +267,15 @@ class RGBRenderer(nn.Module):
 class AccumulationRenderer(nn.Module):
     """renderers.py:171-197."""
 
-    def forward(self, weights: torch.Tensor) -> torch.Tensor:
-        return torch.sum(weights, dim=-2)
+    def forward(self, weights: torch.Tensor, ray_indices: Optional[torch.Tensor] = None, num_rays: Optional[int] = None) -> torch.Tensor:
+        return _sum_along_rays(weights, ray_indices, num_rays)
 
 
 class DepthRenderer(nn.Module):
     """renderers.py:200-261: method 'expected' (what the surface models use; fused into the compositing kernels on the training path) and
     'median' (:234-244: the mid point of the sample at which the cumulative weight reaches 0.5; not differentiable, per-head mirror only)."""
 
-    def __init__(self, method: str = "expected") -> None:
+    def __init__(self, method: str = "median") -> None:  # the reference's default (renderers.py:211); the surface models pass "expected"
         super().__init__()
         if method not in ("expected", "median"):
             raise NotImplementedError(f"depth method {method!r} (the reference has 'expected' and 'median')")

@@ -109,7 +109,8 @@ def test_tcnn_state_dict_model_round_trip():
             super().__init__()
             aabb = torch.tensor([[-1.0, -1, -1], [1, 1, 1]])
             self.proposal_networks = torch.nn.ModuleList([
-                HashMLPDensityField(aabb, spatial_distortion=SceneContraction(order=float("inf")), log2_hashmap_size=9, max_res=32)])
+                HashMLPDensityField(aabb, spatial_distortion=SceneContraction(order=float("inf")), hidden_dim=16, num_levels=5, log2_hashmap_size=9,
+                                    max_res=32)])
             self.field_background = TCNNNerfactoField(aabb, num_images=3, num_levels=4, max_res=32, log2_hashmap_size=8,
                                                       spatial_distortion=SceneContraction(order=float("inf")))
             self.other = torch.nn.Linear(3, 2)

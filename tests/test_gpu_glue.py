@@ -204,3 +204,53 @@ def test_ray_entry_positions_against_the_references_frustums_and_contraction(dev
         for ends, key in ((en, f"pos/mid_{name}"), (None, f"pos/start_{name}")):
             _, _, x = _GeoNetRaysFunction.apply(theta, fld.mlp_base.table, fld._native, o, d, st, ends, mask)
             assert_close(key, x.view(*st.shape, 3), t(key), rtol=0, atol=4e-7)
+
+
+def test_field_methods_of_the_plugin_surface(device):
+    """The SDFField methods a reference caller may use besides forward (fields/sdf_field.py, fields/base_field.py):
+    get_colors on caller-supplied tensors reproduces the colour the fused forward computed from the same inputs; density_fn equals
+    get_density's density at zero-length frustums; get_normals raises the reference's assertion."""
+    from helpers import load_golden, product_model_from_params, small_oracle_cfg
+    from sdfstudio_amd.cameras.rays import RayBundle
+    from sdfstudio_amd.fields.field_heads import FieldHeadNames
+    from oracle import sdf_path as O
+
+    g = load_golden("train")
+    model = product_model_from_params(g["param"], small_oracle_cfg(), device).train()
+    f = model.field
+    n, s = 32, 8
+    o, d, cam = O.synthetic_rays(n, seed=5)
+    starts = torch.sort(torch.rand(n, s) * 2.0 + 1.5, dim=-1)[0]
+    rb = RayBundle(origins=o.to(device), directions=d.to(device), camera_indices=cam[:, None].to(device),
+                   nears=torch.full((n, 1), 0.5, device=device), fars=torch.full((n, 1), 4.5, device=device))
+    rs = rb.get_ray_samples(starts.to(device), starts.to(device) + 0.1)
+    out = f(rs)
+    x = f.spatial_distortion(rs.frustums.get_start_positions()) if f.spatial_distortion is not None else rs.frustums.get_start_positions()
+    feat = f.forward_geonetwork(x.reshape(-1, 3))[:, 1:].reshape(n, s, -1)  # (get_outputs evaluates the geometry network at the contracted points)
+    rgb = f.get_colors(x, rs.frustums.directions, out[FieldHeadNames.GRADIENT], feat, rs.camera_indices.expand(n, s))
+    assert rgb.shape == (n, s, 3)
+    assert_close("get_colors vs the fused forward", rgb, out[FieldHeadNames.RGB], rtol=0, atol=5e-5)
+    # the gradient of the colour reaches the colour network's parameters and the supplied normal
+    gin = out[FieldHeadNames.GRADIENT].detach().clone().requires_grad_(True)
+    f.get_colors(x, rs.frustums.directions, gin, feat.detach(), rs.camera_indices.expand(n, s)).sum().backward()
+    assert gin.grad is not None and float(gin.grad.abs().max()) > 0.0 and float(f.clin0.weight_v.grad.abs().max()) > 0.0
+    pos = rs.frustums.get_start_positions()
+    with torch.no_grad():
+        dens, _ = f.get_density(rs)
+        assert torch.equal(f.density_fn(pos), dens)
+    with pytest.raises(AssertionError):
+        f.get_normals()
+
+
+def test_spaced_sampler_from_spacing_functions(device):
+    """SpacedSampler(spacing_fn, spacing_fn_inv, ...) as the reference constructs it (ray_samplers.py:66-78) equals the named sampler."""
+    from sdfstudio_amd.cameras.rays import RayBundle
+    from sdfstudio_amd.model_components.ray_samplers import LinearDisparitySampler, SpacedSampler
+
+    n = 10
+    rb = RayBundle(origins=torch.zeros(n, 3, device=device), directions=torch.ones(n, 3, device=device), pixel_area=torch.ones(n, 1, device=device),
+                   nears=torch.full((n, 1), 2.0, device=device), fars=torch.full((n, 1), 4.0, device=device))
+    a = SpacedSampler(spacing_fn=lambda x: 1 / x, spacing_fn_inv=lambda x: 1 / x, num_samples=15).eval()(rb)
+    b = LinearDisparitySampler(num_samples=15).eval()(rb)
+    assert a.frustums.get_positions().shape[-2] == 15  # the reference's own check (tests/model_components/test_ray_sampler.py)
+    assert torch.equal(a.frustums.starts, b.frustums.starts) and torch.equal(a.frustums.ends, b.frustums.ends)
