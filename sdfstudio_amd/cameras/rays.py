@@ -11,9 +11,77 @@ from typing import Callable, Dict, Optional
 import torch
 
 
+class _TensorDataclass:
+    """The batch operations of utils/tensor_dataclass.py:149-257 for the three ray containers: every tensor field has the batch
+    dimensions in front and ONE data dimension behind (`_field_custom_dimensions` is not used by these classes); nested containers and
+    dictionaries of tensors are mapped the same way.  `_BATCH_FIELDS` names the fields that take part; the kernels' flat views (ours) follow
+    `to` and are dropped by everything that changes the batch shape (unpack_ray_samples then reads the frustums)."""
+
+    _BATCH_FIELDS: tuple = ()
+    _FLAT_FIELDS: tuple = ()
+
+    def _apply(self, fn, keep_flat: bool = False):
+        kw = {}
+        for f in self.__dataclass_fields__:
+            v = getattr(self, f)
+            if f in self._BATCH_FIELDS:
+                if isinstance(v, torch.Tensor):
+                    v = fn(v)
+                elif isinstance(v, _TensorDataclass):
+                    v = v._apply(fn, keep_flat)
+                elif isinstance(v, dict):
+                    v = {k: (fn(t) if isinstance(t, torch.Tensor) else t) for k, t in v.items()}
+            elif f in self._FLAT_FIELDS:
+                v = fn(v) if (keep_flat and isinstance(v, torch.Tensor)) else None
+            kw[f] = v
+        return type(self)(**kw)
+
+    @property
+    def size(self) -> int:
+        n = 1
+        for d in self.shape:
+            n *= int(d)
+        return n
+
+    @property
+    def ndim(self) -> int:
+        return len(self.shape)
+
+    def reshape(self, shape):
+        """tensor_dataclass.py:197-217."""
+        shape = (shape,) if isinstance(shape, int) else tuple(shape)
+        return self._apply(lambda t: t.reshape((*shape, t.shape[-1])))
+
+    def flatten(self):
+        """tensor_dataclass.py:219-225."""
+        return self.reshape((-1,))
+
+    def broadcast_to(self, shape):
+        """tensor_dataclass.py:227-246."""
+        shape = tuple(shape)
+        return self._apply(lambda t: t.broadcast_to((*shape, t.shape[-1])))
+
+    def to(self, device):
+        """tensor_dataclass.py:248-257."""
+        return self._apply(lambda t: t.to(device), keep_flat=True)
+
+    def __getitem__(self, indices):
+        """tensor_dataclass.py:149-162: the same index on the batch dimensions of every field."""
+        if isinstance(indices, (torch.Tensor, int, slice, type(Ellipsis))):
+            indices = (indices,)
+        return self._apply(lambda t: t[tuple(indices) + (slice(None),)])
+
+    def __len__(self) -> int:
+        if len(self.shape) == 0:
+            raise TypeError("len() of a 0-d tensor")
+        return int(self.shape[0])
+
+
 @dataclass
-class Frustums:
+class Frustums(_TensorDataclass):
     """Region of space along a ray (rays.py:30-106). origins/directions are [N,1,3] broadcast views."""
+
+    _BATCH_FIELDS = ("origins", "directions", "starts", "ends", "pixel_area", "offsets")
 
     origins: torch.Tensor
     directions: torch.Tensor
@@ -31,14 +99,27 @@ class Frustums:
         """Frustum start points, used by the SDF field (rays.py:61-73)."""
         return self.origins + self.directions * self.starts
 
+    def set_offsets(self, offsets):
+        """rays.py:57-59: offsets the samples' positions [..., 3]."""
+        self.offsets = offsets
+
+    @classmethod
+    def get_mock_frustum(cls, device="cpu") -> "Frustums":
+        """rays.py:93-106: a size-1 placeholder frustum."""
+        return Frustums(origins=torch.ones((1, 3)).to(device), directions=torch.ones((1, 3)).to(device), starts=torch.ones((1, 1)).to(device),
+                        ends=torch.ones((1, 1)).to(device), pixel_area=torch.ones((1, 1)).to(device))
+
     @property
     def shape(self):
         return self.starts.shape[:-1]
 
 
 @dataclass
-class RaySamples:
+class RaySamples(_TensorDataclass):
     """Samples along rays (rays.py:109-230)."""
+
+    _BATCH_FIELDS = ("frustums", "camera_indices", "deltas", "spacing_starts", "spacing_ends", "metadata", "times")
+    _FLAT_FIELDS = ("flat_origins", "flat_directions", "flat_starts", "flat_ends", "flat_bins", "nears", "fars")
 
     frustums: Frustums
     camera_indices: Optional[torch.Tensor] = None  # [N,1,1]
@@ -143,6 +224,43 @@ class RayBundle:
     def __len__(self):
         """rays.py:266-268: the number of rays whatever the batch shape ([N] for training batches, [H, W] for a camera's image)."""
         return self.origins.numel() // self.origins.shape[-1]
+
+    @property
+    def shape(self):
+        return self.origins.shape[:-1]
+
+    @property
+    def size(self) -> int:
+        return len(self)
+
+    @property
+    def ndim(self) -> int:
+        return self.origins.dim() - 1
+
+    def reshape(self, shape) -> "RayBundle":
+        """tensor_dataclass.py:197-217."""
+        shape = (shape,) if isinstance(shape, int) else tuple(shape)
+        return self._map(lambda t: t.reshape((*shape, t.shape[-1])))
+
+    def broadcast_to(self, shape) -> "RayBundle":
+        """tensor_dataclass.py:227-246."""
+        shape = tuple(shape)
+        return self._map(lambda t: t.broadcast_to((*shape, t.shape[-1])))
+
+    def to(self, device) -> "RayBundle":
+        """tensor_dataclass.py:248-257."""
+        return self._map(lambda t: t.to(device))
+
+    def set_camera_indices(self, camera_index: int) -> None:
+        """rays.py:256-262."""
+        self.camera_indices = torch.ones_like(self.origins[..., 0:1]).long() * camera_index
+
+    def sample(self, num_rays: int) -> "RayBundle":
+        """rays.py:270-280: a random subset of the rays (python's `random`, as the reference)."""
+        import random
+
+        assert num_rays <= len(self)
+        return self[random.sample(range(len(self)), k=num_rays)]
 
     _TENSOR_FIELDS = ("origins", "directions", "pixel_area", "directions_norm", "camera_indices", "nears", "fars", "times")
 

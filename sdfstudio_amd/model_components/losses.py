@@ -371,3 +371,60 @@ def s3im_loss(src_vec: torch.Tensor, tar_vec: torch.Tensor, kernel_size: int = 4
     c1, c2 = 0.01 ** 2, 0.03 ** 2
     ssim_map = ((2 * mu1_mu2 + c1) * (2 * sigma12 + c2)) / ((mu1_sq + mu2_sq + c1) * (sigma1_sq + sigma2_sq + c2))
     return 1 - ssim_map.mean()
+
+
+# ---- the reference's loss OBJECTS (model_components/losses.py), for host code that constructs them as SurfaceModel.populate_modules does
+# (base_surface_model.py:224-231); each is the operator above behind the reference's constructor and call signature.
+class ScaleAndShiftInvariantLoss(torch.nn.Module):
+    """losses.py:392-413.  forward(prediction, target, mask) on [B, H, W] images; reduction "batch-based" (the only one the path uses,
+    base_surface_model.py:227)."""
+
+    def __init__(self, alpha=0.5, scales=4, reduction="batch-based"):
+        super().__init__()
+        if reduction != "batch-based":
+            raise NotImplementedError("ScaleAndShiftInvariantLoss: only the batch-based reduction is built")
+        self.alpha, self.scales = alpha, scales
+
+    def forward(self, prediction, target, mask):
+        return scale_and_shift_invariant_loss(prediction, target, mask, self.alpha, self.scales)
+
+
+class SensorDepthLoss(torch.nn.Module):
+    """losses.py:628-676.  forward(batch, outputs) -> (l1_loss, free_space_loss, sdf_loss) from batch["sensor_depth"] and the surface
+    model's outputs (depth, ray_samples, field_outputs[SDF], directions_norm)."""
+
+    def __init__(self, truncation: float):
+        super().__init__()
+        self.truncation = truncation
+
+    def forward(self, batch, outputs):
+        from sdfstudio_amd.fields.field_heads import FieldHeadNames
+
+        rs = outputs["ray_samples"]
+        starts = rs.flat_starts if getattr(rs, "flat_starts", None) is not None else rs.frustums.starts[..., 0]
+        depth = outputs["depth"]
+        return sensor_depth_loss(depth, batch["sensor_depth"].to(depth.device), outputs["field_outputs"][FieldHeadNames.SDF][..., 0], starts,
+                                 outputs["directions_norm"], self.truncation)
+
+
+class S3IM(torch.nn.Module):
+    """losses.py:689-771.  forward(src_vec, tar_vec) on [N, 3] colours."""
+
+    def __init__(self, s3im_kernel_size=4, s3im_stride=4, s3im_repeat_time=10, s3im_patch_height=64, size_average=True):
+        super().__init__()
+        if not size_average:
+            raise NotImplementedError("S3IM: size_average=False is not built")
+        self.s3im_kernel_size, self.s3im_stride = s3im_kernel_size, s3im_stride
+        self.s3im_repeat_time, self.s3im_patch_height = s3im_repeat_time, s3im_patch_height
+
+    def forward(self, src_vec, tar_vec):
+        return s3im_loss(src_vec, tar_vec, self.s3im_kernel_size, self.s3im_stride, self.s3im_repeat_time, self.s3im_patch_height)
+
+
+def monosdf_normal_loss(normal_pred: torch.Tensor, normal_gt: torch.Tensor) -> torch.Tensor:
+    """losses.py:264-275: L1 + cosine between the rendered and the monocular normal.  (The surface models take it inside the fused loss
+    operator, surface_losses(normal_pred=..., normal_gt=...); this is the stand-alone statement for host code that calls it by name.)"""
+    n_gt = torch.nn.functional.normalize(normal_gt, p=2, dim=-1)
+    n_pr = torch.nn.functional.normalize(normal_pred, p=2, dim=-1)
+    return torch.abs(n_pr - n_gt).sum(dim=-1).mean() + (1.0 - torch.sum(n_pr * n_gt, dim=-1)).mean()
+

@@ -182,10 +182,27 @@ def _coarse_mask_lookup(coarse_mask: torch.Tensor, pts: torch.Tensor) -> torch.T
 
 
 @torch.no_grad()
-def get_surface_sliding(field, resolution: int = 512, bounding_box_min=(-1.0, -1.0, -1.0), bounding_box_max=(1.0, 1.0, 1.0),
+def _field_or_sdf(field, sdf, device):
+    """The first argument of the reference's drivers is the sdf callable (marching_cubes.py:15-17, :218-220); here it may also be an
+    SDFField, whose MODE_SDF kernels then evaluate the lattice.  Returns (sdf callable, device)."""
+    if sdf is None and field is not None and not hasattr(field, "forward_geonetwork") and callable(field):
+        sdf, field = field, None  # a reference-style call: get_surface_sliding(sdf, ...)
+    if sdf is None and field is None:
+        raise TypeError("an SDFField or an sdf(points [P, 3]) -> [P] callable is required")
+    if device is None:
+        device = field.encoding.params.device if field is not None else torch.device("cuda", torch.cuda.current_device())
+    return (sdf if sdf is not None else (lambda p: sdf_on_points(field, p))), device
+
+
+def _no_simplify(simplify_mesh: bool):
+    if simplify_mesh:  # marching_cubes.py:161-167, :337-343: pymeshlab's quadric edge collapse on the written file
+        raise NotImplementedError("simplify_mesh=True: pymeshlab's mesh simplification is not built (pass simplify_mesh=False)")
+
+
+def get_surface_sliding(field=None, resolution: int = 512, bounding_box_min=(-1.0, -1.0, -1.0), bounding_box_max=(1.0, 1.0, 1.0),
                         return_mesh: bool = True, level: float = 0.0, coarse_mask: Optional[torch.Tensor] = None, crop: int = 512,
                         device=None, return_volumes: bool = False, sdf: Optional[Callable[[torch.Tensor], torch.Tensor]] = None,
-                        output_path=None):
+                        output_path=None, simplify_mesh: bool = False):
     """marching_cubes.py:15-168: per crop^3 block (the reference fixes crop = 512) the coarse-to-fine sdf evaluation, then marching cubes
     ON THE DEVICE (libsdfmesh.so), the crop's offset added in double as the reference adds it, the crops concatenated.
     ``field``: an SDFField (its MODE_SDF kernels evaluate the lattice) - or pass ``sdf(points [P,3]) -> [P]`` as the reference does.
@@ -195,9 +212,9 @@ def get_surface_sliding(field, resolution: int = 512, bounding_box_min=(-1.0, -1
     merge_vertices(digits_vertex=6) and the binary .ply (utils/mesh_io.py; the merged mesh is returned as well).  pymeshlab's
     simplification (:161-167) is not built."""
     assert resolution % crop == 0 and crop % 8 == 0
+    _no_simplify(simplify_mesh)
     level = 0.0  # marching_cubes.py:33
-    dev = device if device is not None else field.encoding.params.device
-    fn = sdf if sdf is not None else (lambda p: sdf_on_points(field, p))
+    fn, dev = _field_or_sdf(field, sdf, device)
     nblk = resolution // crop
     edges = [np.linspace(bounding_box_min[a], bounding_box_max[a], nblk + 1) for a in range(3)]
     results = []
@@ -236,7 +253,8 @@ def get_surface_sliding(field, resolution: int = 512, bounding_box_min=(-1.0, -1
 
 @torch.no_grad()
 def get_surface_occupancy(occupancy_fn: Callable[[torch.Tensor], torch.Tensor], resolution: int = 512, bounding_box_min=(-1.0, -1.0, -1.0),
-                          bounding_box_max=(1.0, 1.0, 1.0), level: float = 0.5, device=None, chunk: int = 1 << 22, output_path=None):
+                          bounding_box_max=(1.0, 1.0, 1.0), level: float = 0.5, device=None, chunk: int = 1 << 22, output_path=None,
+                          return_mesh: bool = True):
     """marching_cubes.py:171-216 (UniSurf: occupancy = sigmoid(10 sdf), level 0.5): one resolution^3 lattice, marching cubes on the
     device.  Returns (verts float64, faces int32, normals) or None ("no surface skip"); ``output_path``: the .ply as at :212-213 (no merge).
     device = None (the reference's default): the current HIP device - the lattice is evaluated and meshed there (libsdfmesh.so has no host path)."""
@@ -259,11 +277,11 @@ _max_pool_3d = torch.nn.MaxPool3d(3, stride=1, padding=1)
 
 
 @torch.no_grad()
-def get_surface_sliding_with_contraction(field, resolution: int = 512, bounding_box_min=(-1.0, -1.0, -1.0), bounding_box_max=(1.0, 1.0, 1.0),
+def get_surface_sliding_with_contraction(field=None, resolution: int = 512, bounding_box_min=(-1.0, -1.0, -1.0), bounding_box_max=(1.0, 1.0, 1.0),
                                          coarse_mask: Optional[torch.Tensor] = None, inv_contraction: Optional[Callable] = None,
                                          max_range: float = 32.0, crop: int = 512, device=None,
                                          sdf: Optional[Callable[[torch.Tensor], torch.Tensor]] = None, output_path=None,
-                                         merge: bool = True):
+                                         merge: bool = True, return_mesh: bool = True, level: float = 0.0, simplify_mesh: bool = False):
     """marching_cubes.py:218-335 (scenes trained under a scene contraction; scripts/extract_mesh.py:95-107): per crop the sdf is evaluated
     only where the visibility grid ``coarse_mask`` [1, 1, D, H, W] (over the contracted cube [-2, 2]^3, grid_sample's lookup at points / 2)
     is set, everything else starts at 100 and is replaced by the 3^3 minimum of its neighbourhood ("to remove masked marching cube
@@ -273,9 +291,9 @@ def get_surface_sliding_with_contraction(field, resolution: int = 512, bounding_
     ``combined.merge_vertices(digits_vertex=6)`` at :321, BEFORE the inverse contraction, whether or not a file is written (utils/mesh_io.py;
     merge=False returns the plain concatenation of the crops); ``output_path``: the binary .ply, as at :330-334."""
     assert resolution % crop == 0 and coarse_mask is not None
-    level = 0.0
-    dev = device if device is not None else field.encoding.params.device
-    fn = sdf if sdf is not None else (lambda p: sdf_on_points(field, p))
+    _no_simplify(simplify_mesh)
+    level = 0.0  # marching_cubes.py:235 (the argument is overwritten there as well); return_mesh: the mesh is returned either way
+    fn, dev = _field_or_sdf(field, sdf, device)
     cm = coarse_mask.to(device=dev, dtype=torch.float32)
     nblk = resolution // crop
     edges = [np.linspace(bounding_box_min[a], bounding_box_max[a], nblk + 1) for a in range(3)]
