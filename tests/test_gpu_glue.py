@@ -227,12 +227,12 @@ def test_field_methods_of_the_plugin_surface(device):
     out = f(rs)
     x = f.spatial_distortion(rs.frustums.get_start_positions()) if f.spatial_distortion is not None else rs.frustums.get_start_positions()
     feat = f.forward_geonetwork(x.reshape(-1, 3))[:, 1:].reshape(n, s, -1)  # (get_outputs evaluates the geometry network at the contracted points)
-    rgb = f.get_colors(x, rs.frustums.directions, out[FieldHeadNames.GRADIENT], feat, rs.camera_indices.expand(n, s))
+    rgb = f.get_colors(x, rs.frustums.directions, out[FieldHeadNames.GRADIENT], feat, rs.camera_indices.reshape(n, 1).expand(n, s))
     assert rgb.shape == (n, s, 3)
     assert_close("get_colors vs the fused forward", rgb, out[FieldHeadNames.RGB], rtol=0, atol=5e-5)
     # the gradient of the colour reaches the colour network's parameters and the supplied normal
     gin = out[FieldHeadNames.GRADIENT].detach().clone().requires_grad_(True)
-    f.get_colors(x, rs.frustums.directions, gin, feat.detach(), rs.camera_indices.expand(n, s)).sum().backward()
+    f.get_colors(x, rs.frustums.directions, gin, feat.detach(), rs.camera_indices.reshape(n, 1).expand(n, s)).sum().backward()
     assert gin.grad is not None and float(gin.grad.abs().max()) > 0.0 and float(f.clin0.weight_v.grad.abs().max()) > 0.0
     pos = rs.frustums.get_start_positions()
     with torch.no_grad():
