@@ -832,7 +832,7 @@ class SDFField(nn.Module):
         if c.use_diffuse_color or c.use_specular_tint or c.use_reflections or c.use_n_dot_v:
             raise NotImplementedError("get_colors on caller-supplied tensors with the ref-nerf options is not built (they run inside forward / get_outputs)")
         n, s = points.shape[0], points.shape[1]
-        d = directions.reshape(n, s, 3)[:, 0].contiguous().float()
+        d = directions.reshape(n, -1, 3)[:, 0].contiguous().float()  # [N, S, 3] or the containers' [N, 1, 3] broadcast view
         cam = camera_indices.reshape(n, -1)[:, 0]
         emb = None
         if self.config.use_appearance_embedding:
