@@ -248,13 +248,49 @@ class FusedAdam:
         self.betas, self.eps, self.weight_decay = tuple(state["betas"]), float(state["eps"]), float(state["weight_decay"])
 
 
+def group_config_from_reference(entry: Dict) -> Dict:
+    """One parameter group of the reference's optimizer dictionary (configs/method_configs.py: {"optimizer": AdamOptimizerConfig(lr, eps,
+    weight_decay), "scheduler": NeuSSchedulerConfig(...) | MultiStepSchedulerConfig(...) | ... | None}; engine/optimizers.py:30-71,
+    engine/schedulers.py:118-222) -> this module's {"lr", "eps", "weight_decay", "scheduler": step -> factor}.  The config objects are read by
+    attribute (duck-typed: the reference's classes or anything with the same fields); entries already in this module's form pass through."""
+    if "optimizer" not in entry:
+        return entry
+    opt = entry["optimizer"]
+    kind = getattr(getattr(opt, "_target", None), "__name__", type(opt).__name__)
+    wd = float(getattr(opt, "weight_decay", 0.0) or 0.0)
+    if "RAdam" in kind:
+        raise NotImplementedError("RAdamOptimizerConfig: the fused optimiser is Adam (no surface preset of the reference uses RAdam)")
+    if "AdamW" in kind and wd != 0.0:
+        raise NotImplementedError("AdamWOptimizerConfig with weight_decay != 0: decoupled weight decay is not built (the fused step implements "
+                                  "torch.optim.Adam, incl. its L2 weight_decay)")
+    out = {"lr": float(opt.lr), "eps": float(getattr(opt, "eps", 1e-8)), "weight_decay": wd}
+    sch = entry.get("scheduler")
+    if sch is None or callable(sch):
+        out["scheduler"] = sch
+        return out
+    name = type(sch).__name__
+    if name.startswith("NeuSScheduler"):
+        out["scheduler"] = neus_scheduler(sch.warm_up_end, sch.learning_rate_alpha, sch.max_steps)
+    elif name.startswith("MultiStepWarmupScheduler"):
+        out["scheduler"] = multi_step_warmup_scheduler(sch.warm_up_end, tuple(sch.milestones), sch.gamma)
+    elif name.startswith("MultiStepScheduler"):
+        out["scheduler"] = multi_step_scheduler(sch.max_steps)
+    elif name.startswith("ExponentialScheduler"):
+        out["scheduler"] = exponential_decay_scheduler(sch.decay_rate, sch.max_steps)
+    else:
+        raise NotImplementedError(f"scheduler config {name}: built are NeuS, MultiStep, MultiStepWarmup and Exponential (engine/schedulers.py)")
+    return out
+
+
 class Optimizers:
     """engine/optimizers.py:93-160: the trainer-facing wrapper (zero_grad_all / optimizer_step_all / scheduler_step_all)."""
 
     def __init__(self, config: Dict[str, Dict], param_groups: Dict[str, List[torch.nn.Parameter]],
                  flat_grads: Optional[FlatGradients] = None, shard: bool = False):
-        """config[name] = {"lr": float, "scheduler": callable | None, ...}; groups without parameters are skipped.
+        """config[name] = {"lr": float, "scheduler": callable | None, ...} or the reference's {"optimizer": AdamOptimizerConfig, "scheduler":
+        SchedulerConfig | None} (group_config_from_reference); groups without parameters are skipped.
         shard (when no FlatGradients is handed in): the sharded exchange of distributed.py."""
+        config = {k: group_config_from_reference(v) for k, v in config.items()}  # the reference's {"optimizer": ..., "scheduler": ...} entries
         groups = {k: {"params": v, **config[k]} for k, v in param_groups.items() if len(v) > 0}
         if flat_grads is None:
             flat_grads = FlatGradients([p for g in groups.values() for p in g["params"]], buckets=[g["params"] for g in groups.values()],
@@ -263,7 +299,9 @@ class Optimizers:
         self._group_params = {k: list(g["params"]) for k, g in groups.items()}  # full lists (incl. requires_grad=False), as the reference indexes them
         eps = {config[k].get("eps", 1e-15) for k in groups}
         assert len(eps) == 1, "one eps for all groups (the reference uses 1e-15 throughout)"
-        self.adam = FusedAdam(groups, flat_grads, eps=eps.pop())
+        wd = {float(config[k].get("weight_decay", 0.0)) for k in groups}
+        assert len(wd) == 1, "one weight_decay for all groups (one fused step over the flat buffers)"
+        self.adam = FusedAdam(groups, flat_grads, eps=eps.pop(), weight_decay=wd.pop())
 
     def zero_grad_all(self):
         self.adam.zero_grad()
@@ -279,6 +317,24 @@ class Optimizers:
                 raise RuntimeError("sharded exchange: call optimizer_step_all(grad_scale=None) - the step waits for the reduce-scatters chunk "
                                    "by chunk and sends the updated slices back")
             self.adam.step(grad_scale)
+
+    def optimizer_scaler_step_all(self, grad_scaler) -> None:
+        """engine/optimizers.py:136-143 - what the reference's trainer calls every iteration (engine/trainer.py:320-324), with a GradScaler
+        that is DISABLED unless mixed precision is on (no surface preset turns it on: configs/method_configs.py `mixed_precision=False`).
+        A disabled scaler's step(optimizer) is optimizer.step(); an enabled one would have to unscale and inf-check inside the fused
+        step, which is not built (the path computes in fp32: there is nothing to scale)."""
+        if grad_scaler is not None and getattr(grad_scaler, "is_enabled", lambda: False)():
+            raise NotImplementedError("Optimizers.optimizer_scaler_step_all: an ENABLED GradScaler (mixed precision) is not built - the native "
+                                      "path trains in fp32; run with mixed_precision=False as every surface preset of the reference does")
+        self.optimizer_step_all(grad_scale=None if self.adam.sharded else 1.0)
+
+    def optimizer_step(self, param_group_name: str) -> None:
+        """engine/optimizers.py:112-118 (one group's optimiser).  The fused Adam steps every group in ONE launch over the flat buffers."""
+        raise NotImplementedError("Optimizers.optimizer_step(param_group_name): the fused Adam steps all groups at once - optimizer_step_all()")
+
+    def scheduler_step(self, param_group_name: str) -> None:
+        """engine/optimizers.py:120-127 (one group's scheduler); here the groups' schedules advance together - scheduler_step_all()."""
+        raise NotImplementedError("Optimizers.scheduler_step(param_group_name): the schedules advance together - scheduler_step_all(step)")
 
     def wait_parameters(self, late: bool = True):
         """Sharded exchange: the parameters updated by the last step are complete on this rank after this (stream wait).  Call it before

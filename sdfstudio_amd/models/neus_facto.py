@@ -312,6 +312,38 @@ class NeuSFactoModel(nn.Module):
     def after_train_iteration(self, step: int):
         self.proposal_sampler.step_cb(step)
 
+    def get_training_callbacks(self, training_callback_attributes=None) -> list:
+        """Model.get_training_callbacks (models/base_model.py:95-101; neus.py:73-93, neus_facto.py:154-282, neus_acc.py:64-90,
+        neuralangelo.py:75-150): what the reference's trainer runs around every iteration (engine/trainer.py:185-206).  The reference
+        registers one callback per schedule; here the two hooks that apply them in the reference's order are the callbacks."""
+        from sdfstudio_amd.engine.callbacks import TrainingCallback, TrainingCallbackLocation
+
+        return [TrainingCallback(where_to_run=[TrainingCallbackLocation.BEFORE_TRAIN_ITERATION], update_every_num_iters=1,
+                                 func=lambda step: self.before_train_iteration(step)),
+                TrainingCallback(where_to_run=[TrainingCallbackLocation.AFTER_TRAIN_ITERATION], update_every_num_iters=1,
+                                 func=lambda step: self.after_train_iteration(step))]
+
+    @property
+    def device(self):
+        """models/base_model.py:90-93."""
+        return next(self.parameters()).device
+
+    def load_model(self, loaded_state: Dict) -> None:
+        """models/base_model.py:208-215: a checkpoint's "model" entry, DDP's "module." prefix stripped."""
+        self.load_state_dict({key.replace("module.", ""): value for key, value in loaded_state["model"].items()})
+
+    def get_foreground_mask(self, ray_samples) -> torch.Tensor:
+        """base_surface_model.py:256-264."""
+        return B.foreground_mask(ray_samples)
+
+    def forward_background_field_and_merge(self, ray_samples, field_outputs: Dict) -> Dict:
+        """base_surface_model.py:266-290."""
+        return B.forward_background_field_and_merge(self, ray_samples, field_outputs)
+
+    def get_outputs_flexible(self, ray_bundle: RayBundle, additional_inputs: Dict) -> Dict:
+        """base_surface_model.py:367-397: collide, get_outputs; the patch-warping branch is refused at construction (patch_warp_loss_mult > 0)."""
+        return self.get_outputs(self.collide(ray_bundle))
+
     def collide(self, ray_bundle: RayBundle) -> RayBundle:
         """Model.forward (models/base_model.py:139-140): the collider sets nears / fars unless the bundle already carries them."""
         return self.collider(ray_bundle)

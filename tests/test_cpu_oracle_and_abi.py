@@ -550,6 +550,96 @@ def test_plugin_classes_keep_the_references_signatures():
         assert o_rs.ProposalNetworkSampler().update_sched(step) == r_rs.ProposalNetworkSampler().update_sched(step)
 
 
+def test_models_and_optimizers_expose_the_references_trainer_facing_methods():
+    """What the reference's trainer and pipeline call on a model and on the optimizers (engine/trainer.py:185-206, 320-324; models/base_model.py):
+    every public method of the reference's surface models exists here (get_image_metrics_and_images, the viewer / eval-image side, aside),
+    and the training callbacks are objects the reference's trainer loop can run: run_callback_at_location(step, location) with the
+    reference's own location enum."""
+    from sdfstudio_amd.engine.callbacks import TrainingCallback, TrainingCallbackLocation
+    from sdfstudio_amd.engine.optimizers import Optimizers
+    from sdfstudio_amd.models.neuralangelo import NeuralangeloModel
+    from sdfstudio_amd.models.neus import NeuSModel
+    from sdfstudio_amd.models.neus_acc import NeuSAccModel
+    from sdfstudio_amd.models.neus_facto import NeuSFactoModel
+    from sdfstudio_amd.models.unisurf import UniSurfModel
+    from sdfstudio_amd.models.volsdf import VolSDFModel
+
+    seen = []
+    cb = TrainingCallback([TrainingCallbackLocation.BEFORE_TRAIN_ITERATION], func=lambda step: seen.append(step), update_every_num_iters=2)
+    for step in range(5):
+        cb.run_callback_at_location(step, TrainingCallbackLocation.BEFORE_TRAIN_ITERATION)
+        cb.run_callback_at_location(step, TrainingCallbackLocation.AFTER_TRAIN_ITERATION)
+    assert seen == [0, 2, 4]
+    for m in ("zero_grad_all", "optimizer_step_all", "optimizer_scaler_step_all", "scheduler_step_all", "load_optimizers", "optimizer_step", "scheduler_step"):
+        assert callable(getattr(Optimizers, m)), m
+    if not os.path.isdir("/root/reference/nerfstudio"):
+        return
+    from oracle import ref_harness
+
+    ref_harness.import_reference()
+    import nerfstudio.engine.callbacks as r_cb
+    import nerfstudio.models.neuralangelo as r_na
+    import nerfstudio.models.neus as r_n
+    import nerfstudio.models.neus_acc as r_acc
+    import nerfstudio.models.neus_facto as r_nf
+    import nerfstudio.models.unisurf as r_u
+    import nerfstudio.models.volsdf as r_v
+
+    seen.clear()
+    for step in range(3):  # the reference's own enum members select the callback
+        cb.run_callback_at_location(step, r_cb.TrainingCallbackLocation.BEFORE_TRAIN_ITERATION)
+        cb.run_callback_at_location(step, r_cb.TrainingCallbackLocation.AFTER_TRAIN_ITERATION)
+    assert seen == [0, 2]
+    base = set(dir(torch.nn.Module))
+    viewer_side = {"get_image_metrics_and_images"}  # PSNR / SSIM / LPIPS images of an eval view: torchmetrics, the viewer's side of the model
+    for theirs, ours in ((r_nf.NeuSFactoModel, NeuSFactoModel), (r_n.NeuSModel, NeuSModel), (r_v.VolSDFModel, VolSDFModel), (r_u.UniSurfModel, UniSurfModel),
+                         (r_acc.NeuSAccModel, NeuSAccModel), (r_na.NeuralangeloModel, NeuralangeloModel)):
+        missing = [m for m in dir(theirs) if not m.startswith("_") and m not in base and m not in viewer_side and not hasattr(ours, m)]
+        assert not missing, (theirs.__name__, missing)
+
+
+def test_optimizer_dictionary_of_a_reference_preset_is_accepted():
+    """The `optimizers` dictionary of a method_configs.py entry (AdamOptimizerConfig / AdamWOptimizerConfig + SchedulerConfig objects,
+    configs/method_configs.py:485-500, 434-447) converts to this module's group configs: same lr / eps, schedule factors equal to the
+    reference's own scheduler objects stepping a torch optimiser; what the fused step cannot do (RAdam, decoupled weight decay) is refused."""
+    from sdfstudio_amd.engine.optimizers import group_config_from_reference
+
+    passthrough = {"lr": 1e-3, "scheduler": None}
+    assert group_config_from_reference(passthrough) is passthrough
+    if not os.path.isdir("/root/reference/nerfstudio"):
+        return
+    from oracle import ref_harness
+
+    ref_harness.import_reference()
+    import nerfstudio.engine.optimizers as r_o
+    import nerfstudio.engine.schedulers as r_s
+
+    cases = [(r_o.AdamOptimizerConfig(lr=5e-4, eps=1e-15), r_s.NeuSSchedulerConfig(warm_up_end=500, learning_rate_alpha=0.05, max_steps=20000)),
+             (r_o.AdamOptimizerConfig(lr=1e-2, eps=1e-15), r_s.MultiStepSchedulerConfig(max_steps=2000)),
+             (r_o.AdamWOptimizerConfig(lr=1e-3, eps=1e-15), r_s.MultiStepWarmupSchedulerConfig(warm_up_end=50, milestones=[600, 800], gamma=0.1)),
+             (r_o.AdamOptimizerConfig(lr=1e-3), r_s.ExponentialSchedulerConfig(decay_rate=0.1, max_steps=1000)),
+             (r_o.AdamOptimizerConfig(lr=1e-3, eps=1e-15), None)]
+    for opt_cfg, sch_cfg in cases:
+        ours = group_config_from_reference({"optimizer": opt_cfg, "scheduler": sch_cfg})
+        assert ours["lr"] == opt_cfg.lr and ours["eps"] == opt_cfg.eps and ours["weight_decay"] == 0.0
+        if sch_cfg is None:
+            assert ours["scheduler"] is None
+            continue
+        p = torch.nn.Parameter(torch.zeros(1))
+        topt = opt_cfg.setup(params=[p])
+        tsch = sch_cfg.setup(optimizer=topt, lr_init=opt_cfg.lr)
+        for step in range(1100):
+            if step in (0, 1, 49, 50, 51, 499, 500, 501, 600, 601, 800, 999, 1000, 1001, 1099):
+                want = tsch.get_last_lr()[0] / opt_cfg.lr
+                assert abs(ours["scheduler"](step) - want) <= 1e-12 + 1e-9 * abs(want), (type(sch_cfg).__name__, step, ours["scheduler"](step), want)
+            topt.step()
+            tsch.step()
+    with pytest.raises(NotImplementedError):
+        group_config_from_reference({"optimizer": r_o.AdamWOptimizerConfig(lr=1e-3, weight_decay=0.01), "scheduler": None})
+    with pytest.raises(NotImplementedError):
+        group_config_from_reference({"optimizer": r_o.RAdamOptimizerConfig(lr=1e-3), "scheduler": None})
+
+
 def test_spaced_sampler_recognises_the_references_spacing_functions():
     """SpacedSampler's constructor takes (spacing_fn, spacing_fn_inv) like the reference's (ray_samplers.py:66-78); the native sampler holds
     the five pairs the reference's own samplers pass (:130-247) and recognises them by value; anything else is refused."""
