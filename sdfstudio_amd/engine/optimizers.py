@@ -8,6 +8,7 @@ and the two Adam moments of ALL groups live in four flat fp32 buffers (parameter
 There is no PyTorch fallback (``FusedAdam.step`` raises without the library or on CPU tensors); the formula as plain torch ops
 is ``oracle.sdf_path.adam_reference``, the checker the tests compare with.
 """
+import dataclasses
 import math
 from typing import Callable, Dict, Iterable, List, Optional
 
@@ -246,6 +247,48 @@ class FusedAdam:
             g["lr"], g["lr_init"] = float(sg["lr"]), float(sg["lr_init"])
         self.step_count = int(state["step_count"])
         self.betas, self.eps, self.weight_decay = tuple(state["betas"]), float(state["eps"]), float(state["weight_decay"])
+
+
+# ---- the reference's optimiser / scheduler CONFIG objects (engine/optimizers.py:30-71, engine/schedulers.py:118-222) as plain data: what the
+# entries of a method config's `optimizers` dictionary are made of (configs/method_configs.py).  Optimizers() converts them
+# (group_config_from_reference below); the reference's own objects are accepted just the same.
+@dataclasses.dataclass
+class AdamOptimizerConfig:
+    lr: float = 0.0005
+    eps: float = 1e-08
+    weight_decay: float = 0
+
+
+@dataclasses.dataclass
+class AdamWOptimizerConfig:
+    lr: float = 0.0005
+    eps: float = 1e-08
+    weight_decay: float = 0
+
+
+@dataclasses.dataclass
+class MultiStepSchedulerConfig:
+    max_steps: int = 1000000
+
+
+@dataclasses.dataclass
+class ExponentialSchedulerConfig:
+    decay_rate: float = 0.1
+    max_steps: int = 1000000
+
+
+@dataclasses.dataclass
+class NeuSSchedulerConfig:
+    warm_up_end: int = 5000
+    learning_rate_alpha: float = 0.05
+    max_steps: int = 300000
+
+
+@dataclasses.dataclass
+class MultiStepWarmupSchedulerConfig:
+    warm_up_end: int = 5000
+    milestones: List[int] = dataclasses.field(default_factory=lambda: [300000, 400000, 500000])
+    gamma: float = 0.33
 
 
 def group_config_from_reference(entry: Dict) -> Dict:

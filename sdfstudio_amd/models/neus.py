@@ -25,7 +25,7 @@ class NeuSModelConfig(NeuSFactoModelConfig):
     num_samples_importance: int = 64
     num_samples_outside: int = 32
     num_up_sample_steps: int = 4
-    base_variance: float = 64.0
+    base_variance: float = 64
     perturb: bool = True
 
 

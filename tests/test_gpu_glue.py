@@ -254,3 +254,54 @@ def test_spaced_sampler_from_spacing_functions(device):
     b = LinearDisparitySampler(num_samples=15).eval()(rb)
     assert a.frustums.get_positions().shape[-2] == 15  # the reference's own check (tests/model_components/test_ray_sampler.py)
     assert torch.equal(a.frustums.starts, b.frustums.starts) and torch.equal(a.frustums.ends, b.frustums.ends)
+
+
+@pytest.mark.parametrize("name", ["neus-facto", "neus", "mono-neus", "volsdf", "monosdf", "unisurf", "neus-acc"])
+def test_method_presets_train_a_step(device, name):
+    """configs/method_configs.py end to end: the preset's model config builds its model, the preset's optimizer dictionary (the reference's
+    config objects) builds the fused optimiser, the training callbacks run as the reference's trainer runs them, one step trains: finite
+    losses under the reference's keys, parameters move."""
+    import copy
+
+    from sdfstudio_amd.cameras.rays import RayBundle
+    from sdfstudio_amd.configs.method_configs import method_configs
+    from sdfstudio_amd.engine.callbacks import TrainingCallbackLocation
+    from sdfstudio_amd.engine.optimizers import Optimizers
+    from sdfstudio_amd.models.neus_facto import SceneBox
+    import bench as B
+
+    m = method_configs[name]
+    cfg = copy.deepcopy(m.model)
+    cfg.background_model = "none"  # (the presets' default NeRFField background: its own tests; here the method's own path)
+    torch.manual_seed(0)
+    box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=0.5, far=4.5)
+    model = cfg.setup(scene_box=box, num_train_data=49).to(device).train()
+    groups = {k: v for k, v in model.get_param_groups().items() if v}
+    opts = Optimizers({k: m.optimizers[k] for k in groups}, groups)
+    callbacks = model.get_training_callbacks(None)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(1)
+    centers, rot = B.synthetic_cameras(device)
+    n = 256
+    before = {k: p.detach().clone() for k, p in list(model.field.named_parameters())[:4]}
+    for step in range(2):
+        for cb in callbacks:
+            cb.run_callback_at_location(step, TrainingCallbackLocation.BEFORE_TRAIN_ITERATION)
+        o, d, norm, cam = B.draw_rays(centers, rot, n, gen)
+        out = model(RayBundle(origins=o, directions=d, directions_norm=norm, camera_indices=cam[:, None]))
+        batch = {"image": torch.rand(n, 3, device=device, generator=gen)}
+        if "mono" in name:
+            batch["depth"] = torch.rand(n, device=device, generator=gen)
+            batch["normal"] = torch.nn.functional.normalize(torch.randn(n, 3, device=device, generator=gen), dim=-1)
+        loss = model.get_loss_dict(out, batch)
+        assert {"rgb_loss"} <= set(loss) and all(torch.isfinite(v).all() for v in loss.values()), loss
+        if "mono" in name:
+            assert {"depth_loss", "normal_loss"} <= set(loss)
+        opts.zero_grad_all()
+        sum(loss.values()).backward()
+        opts.optimizer_scaler_step_all(torch.amp.GradScaler("cuda", enabled=False))  # engine/trainer.py:320-324
+        opts.scheduler_step_all(step)
+        for cb in callbacks:
+            cb.run_callback_at_location(step, TrainingCallbackLocation.AFTER_TRAIN_ITERATION)
+    moved = [k for k, p in list(model.field.named_parameters())[:4] if not torch.equal(p.detach(), before[k])]
+    assert moved, "two optimiser steps must move the field's parameters"
