@@ -305,6 +305,11 @@ int sdfhip_sample_spacing(int32_t spacing, const float* nears, const float* fars
  * (same offset from a 16-byte boundary); n in floats. */
 int sdfhip_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
                      float eps, float weight_decay, int64_t step, float grad_scale, sdfhip_stream_t stream);
+/* torch.optim.AdamW step (engine/optimizers.py:60-64 AdamWOptimizerConfig; the `fields` group of the neuralangelo / bakedangelo presets,
+ * configs/method_configs.py:229-232, 156-159): as sdfhip_adam_step, with weight_decay DECOUPLED - the parameter is multiplied by
+ * 1 - lr * weight_decay ahead of the Adam update and the gradient carries no L2 term (optim/adamw.py). */
+int sdfhip_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, int64_t step, float grad_scale, sdfhip_stream_t stream);
 /* PDFSampler (ray_samplers.py:250-370) in any spacing domain and with either jitter mode (one draw per ray, or per bin edge with
  * jitter_per_sample != 0: jitter [n_rays, s_out + 1], :321-326); include_original = False (the merge with the existing bins of
  * include_original = True is a sort of the two bin sets on the host side).  Otherwise as sdfhip_sample_pdf. */

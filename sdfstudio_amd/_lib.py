@@ -129,6 +129,8 @@ _SIGNATURES = {
                                       ctypes.c_void_p]),
     "sdfhip_adam_step": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_f32,
                                  ctypes.c_void_p]),
+    "sdfhip_adamw_step": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_f32,
+                                 ctypes.c_void_p]),
     "sdfhip_sample_pdf_spacing": (c_i32, [c_i32, c_float_p, c_float_p, c_float_p, c_float_p, c_float_p, c_i32, c_i64, c_i32, c_i32, c_f32,
                                           c_f32, c_float_p, c_float_p, c_float_p, ctypes.c_void_p]),
     "sdfhip_surface_root": (c_i32, [c_float_p, c_float_p, c_float_p, c_float_p, c_i64, c_i32, c_f32, ctypes.c_void_p, c_float_p,

@@ -93,8 +93,7 @@ method_configs["neus-facto-angelo"] = MethodConfig(
      "field_background": _adam(1e-3, MultiStepWarmupSchedulerConfig(warm_up_end=5000, milestones=[300_000, 400_000], gamma=0.1), cls=AdamWOptimizerConfig)},
     train_num_rays_per_batch=2048, eval_num_rays_per_batch=1024, max_num_iterations=1000_001)
 
-# :184-243.  (Its "fields" group is AdamW with weight_decay 0.01: DECOUPLED weight decay, which the fused Adam does not implement - Optimizers()
-# refuses this entry as it stands; the model, its schedules and its losses run.)
+# :184-243.  (Its "fields" group is AdamW with weight_decay 0.01: sdfhip_adamw_step, the fused step with decoupled decay.)
 method_configs["neuralangelo"] = MethodConfig(
     "neuralangelo",
     NeuralangeloModelConfig(sdf_field=SDFFieldConfig(use_appearance_embedding=False, position_encoding_max_degree=6, **_ANGELO_FIELD),

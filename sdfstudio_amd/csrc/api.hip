@@ -2031,8 +2031,8 @@ extern "C" int sdfhip_interlevel_terms(const float* c, const float* w, const flo
   return 0;
 }
 
-extern "C" int sdfhip_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
-                                float beta2, float eps, float weight_decay, int64_t step, float grad_scale, sdfhip_stream_t stream) {
+static int adam_step_impl(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, int64_t step, float grad_scale, bool decoupled, sdfhip_stream_t stream) {
   SDFHIP_REQUIRE(param && grad && exp_avg && exp_avg_sq && n >= 0 && step >= 1, "adam_step: bad argument");
   const unsigned mis = (unsigned)(((uintptr_t)param >> 2) & 3);
   SDFHIP_REQUIRE(((uintptr_t)grad >> 2 & 3) == mis && ((uintptr_t)exp_avg >> 2 & 3) == mis && ((uintptr_t)exp_avg_sq >> 2 & 3) == mis &&
@@ -2053,13 +2053,22 @@ extern "C" int sdfhip_adam_step(float* param, const float* grad, float* exp_avg,
   a.beta1 = beta1;
   a.beta2 = beta2;
   a.eps = eps;
-  a.weight_decay = weight_decay;
+  a.weight_decay = decoupled ? 0.0f : weight_decay;
+  a.decay_mul = decoupled ? (float)(1.0 - (double)lr * (double)weight_decay) : 1.0f;  // python-float arithmetic, as torch's 1 - lr * weight_decay
   a.grad_scale = grad_scale;
   const int64_t n4 = (n + 3) / 4;
   const unsigned grid = (unsigned)std::min<int64_t>((n4 + 255) / 256, 256 * 16);
   adam_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(a);
   SDFHIP_CHECK_HIP(hipGetLastError());
   return 0;
+}
+extern "C" int sdfhip_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                                float beta2, float eps, float weight_decay, int64_t step, float grad_scale, sdfhip_stream_t stream) {
+  return adam_step_impl(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, false, stream);
+}
+extern "C" int sdfhip_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                                 float beta2, float eps, float weight_decay, int64_t step, float grad_scale, sdfhip_stream_t stream) {
+  return adam_step_impl(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, true, stream);
 }
 
 extern "C" int sdfhip_surface_root(const float* sdf, const float* starts, const float* nears, const float* fars, int64_t n_rays,

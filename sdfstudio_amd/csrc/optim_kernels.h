@@ -5,6 +5,9 @@
 //   m <- m + (1 - b1) (g - m)                      (exp_avg.lerp_(grad, 1 - beta1))
 //   v <- b2 v + (1 - b2) g g                       (exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2))
 //   p <- p - (lr / (1 - b1^t)) m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// weight_decay: torch.optim.Adam's L2 form (g <- g + wd p).  decay_mul: torch.optim.AdamW's DECOUPLED form, p <- p (1 - lr wd) ahead of the
+// update (optim/adamw.py _single_tensor_adamw: param.mul_(1 - lr * weight_decay)); 1 = none.  The reference's neuralangelo / bakedangelo
+// presets train their fields with AdamW, weight decay 0.01 (configs/method_configs.py:229-232, 156-159).
 // Pure streaming: 16 B read + 12 B written per parameter; bound by HBM.
 #pragma once
 #include "common.h"
@@ -16,11 +19,12 @@ struct AdamArgs {
   float* exp_avg_sq;
   int64_t n;
   int32_t head;  // leading elements before the first 16-byte boundary (all four slices share the misalignment)
-  float lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, weight_decay, grad_scale;
+  float lr_over_bc1, inv_sqrt_bc2, beta1, beta2, eps, weight_decay, grad_scale, decay_mul;
 };
 
 SDFHIP_D void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a) {
   g *= a.grad_scale;
+  if (a.decay_mul != 1.0f) p *= a.decay_mul;
   if (a.weight_decay != 0.0f) g = fmaf(a.weight_decay, p, g);
   m = m + (1.0f - a.beta1) * (g - m);
   v = a.beta2 * v + (1.0f - a.beta2) * g * g;

@@ -114,8 +114,11 @@ class FusedAdam:
             end = flat_grads._offset[id(plist[-1])] + plist[-1].numel()  # incl. the padding BETWEEN this group's buckets (zeros: a no-op update)
             sched = g.get("scheduler")
             # LambdaLR semantics: the factor of step 0 applies from construction (a warm-up schedule starts at lr = 0)
+            # weight decay per group: torch.optim.Adam's L2 form, or (decoupled) torch.optim.AdamW's - AdamWOptimizerConfig of the reference
             self.groups[name] = {"start": start, "end": end, "numel": n, "lr_init": float(g["lr"]), "scheduler": sched,
-                                 "lr": float(g["lr"]) * (sched(0) if sched is not None else 1.0)}
+                                 "lr": float(g["lr"]) * (sched(0) if sched is not None else 1.0),
+                                 "weight_decay": float(g.get("weight_decay", weight_decay)), "decoupled": bool(g.get("decoupled", False))}
+        self._cur_decay = (float(weight_decay), False)
 
     def scheduler_step(self):
         """Optimizers.scheduler_step_all (optimizers.py:146-156): LambdaLR semantics, lr = lr_init * factor(number of scheduler steps)."""
@@ -131,13 +134,15 @@ class FusedAdam:
             raise _lib.SdfHipError("FusedAdam.step needs HIP device tensors; there is no CPU fallback")
         lib = _lib.load()
         n = b - a
-        _lib.check(lib.sdfhip_adam_step(_lib.ptr(P[a:b]), _lib.ptr(G[a:b]), _lib.ptr(self.exp_avg[loc:loc + n]),
-                                        _lib.ptr(self.exp_avg_sq[loc:loc + n]), n, lr, self.betas[0], self.betas[1], self.eps,
-                                        self.weight_decay, self.step_count, float(grad_scale), _lib.stream()), "adam_step")
+        wd, decoupled = self._cur_decay  # of the group being visited (_visit)
+        fn = lib.sdfhip_adamw_step if decoupled else lib.sdfhip_adam_step
+        _lib.check(fn(_lib.ptr(P[a:b]), _lib.ptr(G[a:b]), _lib.ptr(self.exp_avg[loc:loc + n]), _lib.ptr(self.exp_avg_sq[loc:loc + n]), n, lr,
+                      self.betas[0], self.betas[1], self.eps, wd, self.step_count, float(grad_scale), _lib.stream()), "adam_step")
 
     def _visit(self, lo: int, hi: int, slices, grad_scale: float):
         """Adam on the part of `slices` ([(a, b, local offset)]) that lies inside [lo, hi), group by group (a group = one lr)."""
         for g in self.groups.values():
+            self._cur_decay = (g["weight_decay"], g["decoupled"])
             for a, b, loc in slices:
                 x, y = max(a, g["start"], lo), min(b, g["end"], hi)
                 if y > x:
@@ -155,7 +160,7 @@ class FusedAdam:
         fg = self.flat_grads
         # Elements that have never carried a gradient (FlatGradients.live_ranges: table rows of hash levels that are still switched
         # off) have zero gradient and zero moments: their update is exactly 0 unless weight decay moves them, so they are skipped.
-        if self.weight_decay == 0.0:
+        if all(g["weight_decay"] == 0.0 for g in self.groups.values()):
             slices = fg.owned_live()
         else:
             slices = fg.owned_slices()
@@ -303,10 +308,7 @@ def group_config_from_reference(entry: Dict) -> Dict:
     wd = float(getattr(opt, "weight_decay", 0.0) or 0.0)
     if "RAdam" in kind:
         raise NotImplementedError("RAdamOptimizerConfig: the fused optimiser is Adam (no surface preset of the reference uses RAdam)")
-    if "AdamW" in kind and wd != 0.0:
-        raise NotImplementedError("AdamWOptimizerConfig with weight_decay != 0: decoupled weight decay is not built (the fused step implements "
-                                  "torch.optim.Adam, incl. its L2 weight_decay)")
-    out = {"lr": float(opt.lr), "eps": float(getattr(opt, "eps", 1e-8)), "weight_decay": wd}
+    out = {"lr": float(opt.lr), "eps": float(getattr(opt, "eps", 1e-8)), "weight_decay": wd, "decoupled": "AdamW" in kind}  # AdamW: sdfhip_adamw_step
     sch = entry.get("scheduler")
     if sch is None or callable(sch):
         out["scheduler"] = sch
@@ -342,9 +344,7 @@ class Optimizers:
         self._group_params = {k: list(g["params"]) for k, g in groups.items()}  # full lists (incl. requires_grad=False), as the reference indexes them
         eps = {config[k].get("eps", 1e-15) for k in groups}
         assert len(eps) == 1, "one eps for all groups (the reference uses 1e-15 throughout)"
-        wd = {float(config[k].get("weight_decay", 0.0)) for k in groups}
-        assert len(wd) == 1, "one weight_decay for all groups (one fused step over the flat buffers)"
-        self.adam = FusedAdam(groups, flat_grads, eps=eps.pop(), weight_decay=wd.pop())
+        self.adam = FusedAdam(groups, flat_grads, eps=eps.pop())  # weight decay (L2 or decoupled) is a property of each group
 
     def zero_grad_all(self):
         self.adam.zero_grad()
@@ -447,11 +447,12 @@ class Optimizers:
                 if id(p) in adam.flat_params.offset:  # else: requires_grad = False here
                     plan.append((adam.flat_params.offset[id(p)], p.numel(), st))
             pg = ref["param_groups"][0]
-            betas, eps, wd = tuple(pg.get("betas", adam.betas)), float(pg.get("eps", adam.eps)), float(pg.get("weight_decay", adam.weight_decay))
-            if tuple(float(b) for b in betas) != tuple(float(b) for b in adam.betas) or eps != float(adam.eps) or wd != float(adam.weight_decay):
+            gwd = float(adam.groups[name]["weight_decay"])
+            betas, eps, wd = tuple(pg.get("betas", adam.betas)), float(pg.get("eps", adam.eps)), float(pg.get("weight_decay", gwd))
+            if tuple(float(b) for b in betas) != tuple(float(b) for b in adam.betas) or eps != float(adam.eps) or wd != gwd:
                 raise ValueError(f"group {name!r}: the checkpoint was trained with betas {betas}, eps {eps}, weight_decay {wd}; this optimizer is "
-                                 f"configured with betas {tuple(adam.betas)}, eps {adam.eps}, weight_decay {adam.weight_decay} (one setting for "
-                                 "all groups: FusedAdam)")
+                                 f"configured with betas {tuple(adam.betas)}, eps {adam.eps}, weight_decay {gwd} (betas and eps: one setting for "
+                                 "all groups, FusedAdam)")
         # pass 2: copy.  Loaded moments may be non-zero anywhere: every row is live from here on
         adam.flat_grads.mark_all_live()
         for a0, n, st in plan:

@@ -634,8 +634,8 @@ def test_optimizer_dictionary_of_a_reference_preset_is_accepted():
                 assert abs(ours["scheduler"](step) - want) <= 1e-12 + 1e-9 * abs(want), (type(sch_cfg).__name__, step, ours["scheduler"](step), want)
             topt.step()
             tsch.step()
-    with pytest.raises(NotImplementedError):
-        group_config_from_reference({"optimizer": r_o.AdamWOptimizerConfig(lr=1e-3, weight_decay=0.01), "scheduler": None})
+    w = group_config_from_reference({"optimizer": r_o.AdamWOptimizerConfig(lr=1e-3, weight_decay=0.01), "scheduler": None})
+    assert w["decoupled"] and w["weight_decay"] == 0.01
     with pytest.raises(NotImplementedError):
         group_config_from_reference({"optimizer": r_o.RAdamOptimizerConfig(lr=1e-3), "scheduler": None})
 
@@ -649,13 +649,11 @@ def test_method_presets_against_the_references_method_configs():
 
     assert set(method_configs) == {"neus-facto", "neus-facto-bigmlp", "neus-facto-angelo", "neuralangelo", "neus", "mono-neus", "volsdf", "monosdf",
                                    "unisurf", "mono-unisurf", "neus-acc"}
-    for name, m in method_configs.items():  # every group converts, except neuralangelo's decoupled weight decay (refused, said so in the file)
+    for name, m in method_configs.items():  # every group converts; AdamW entries become decoupled-decay groups (sdfhip_adamw_step)
         for g, e in m.optimizers.items():
-            if name == "neuralangelo" and g == "fields":
-                with pytest.raises(NotImplementedError):
-                    group_config_from_reference(e)
-            else:
-                assert callable(group_config_from_reference(e)["scheduler"])
+            c = group_config_from_reference(e)
+            assert callable(c["scheduler"]) and c["decoupled"] == (type(e["optimizer"]).__name__ == "AdamWOptimizerConfig")
+    assert group_config_from_reference(method_configs["neuralangelo"].optimizers["fields"])["weight_decay"] == 0.01
     if not os.path.isdir("/root/reference/nerfstudio"):
         return
     import dataclasses

@@ -660,6 +660,45 @@ def test_fused_adam_against_torch_adam(device, world):
     assert ga[0].data_ptr() == opts.adam.flat_params.flat.data_ptr()  # parameters really live in the flat buffer
 
 
+def test_fused_adamw_groups_against_torch(device):
+    """sdfhip_adamw_step: the optimizer dictionary of the reference's neuralangelo / bakedangelo presets (configs/method_configs.py:229-236,
+    156-163) - `fields` on AdamW with DECOUPLED weight decay 0.01, `field_background` on AdamW with weight decay 0, both under the
+    MultiStepWarmup schedule - handed over as the reference's config objects and stepped beside torch.optim.AdamW; plus a group on
+    torch.optim.Adam's L2 weight decay.  Per-group decay: one launch per group over the flat buffers."""
+    from sdfstudio_amd.engine.optimizers import (AdamOptimizerConfig, AdamWOptimizerConfig, MultiStepWarmupSchedulerConfig, Optimizers,
+                                                 multi_step_warmup_scheduler)
+
+    torch.manual_seed(2)
+    mk = lambda shp: [torch.nn.Parameter(torch.randn(*s_, device=device)) for s_ in shp]
+    ga, gb, gc = mk([(37, 5), (3,), (1001,)]), mk([(64, 7), (2,)]), mk([(129,), (5, 5)])
+    refs = [[torch.nn.Parameter(p.detach().clone()) for p in g] for g in (ga, gb, gc)]
+    sch = lambda: MultiStepWarmupSchedulerConfig(warm_up_end=3, milestones=[5, 8], gamma=0.1)
+    opts = Optimizers({"fields": {"optimizer": AdamWOptimizerConfig(lr=1e-3, eps=1e-15, weight_decay=0.01), "scheduler": sch()},
+                       "field_background": {"optimizer": AdamWOptimizerConfig(lr=1e-3, eps=1e-15), "scheduler": sch()},
+                       "proposal_networks": {"optimizer": AdamOptimizerConfig(lr=1e-2, eps=1e-15, weight_decay=0.003), "scheduler": None}},
+                      {"fields": ga, "field_background": gb, "proposal_networks": gc})
+    assert opts.adam.groups["fields"]["decoupled"] and opts.adam.groups["fields"]["weight_decay"] == 0.01
+    assert not opts.adam.groups["proposal_networks"]["decoupled"]
+    t = [torch.optim.AdamW(refs[0], lr=1e-3, eps=1e-15, weight_decay=0.01), torch.optim.AdamW(refs[1], lr=1e-3, eps=1e-15, weight_decay=0),
+         torch.optim.Adam(refs[2], lr=1e-2, eps=1e-15, weight_decay=0.003)]
+    f = multi_step_warmup_scheduler(3, (5, 8), 0.1)
+    ts = [torch.optim.lr_scheduler.LambdaLR(t[0], f), torch.optim.lr_scheduler.LambdaLR(t[1], f)]
+    for step in range(10):
+        opts.zero_grad_all()
+        for p, r in zip(ga + gb + gc, refs[0] + refs[1] + refs[2]):
+            g = torch.randn_like(p) * 10.0 ** torch.randint(-5, 1, p.shape, device=device).float()
+            opts.flat_grads._view(p).add_(g)
+            r.grad = g.clone()
+        opts.optimizer_step_all()
+        opts.scheduler_step_all(step)
+        for o in t:
+            o.step()
+        for s_ in ts:
+            s_.step()
+        for i, (p, r) in enumerate(zip(ga + gb + gc, refs[0] + refs[1] + refs[2])):
+            assert_close(f"step {step} param {i}", p, r, rtol=2e-6, atol=1e-7)
+
+
 def test_fused_adam_skips_never_active_table_rows_exactly(device):
     """Progressive hash levels: FlatGradients.set_active_numel keeps the table rows of switched-off levels out of zero() and of the
     Adam step (FlatGradients.live_ranges).  torch.optim.Adam with explicit zero gradients there must end at the same parameters: the
