@@ -8,14 +8,16 @@ Not the trainer / pipeline / data-manager configuration around them: that is the
     model = m.model.setup(scene_box=..., num_train_data=...)
     opts = Optimizers(m.optimizers, model.get_param_groups())
 
-Not here: geo-neus / geo-volsdf / geo-unisurf (multi-view patch warping: the data manager's neighbouring images), bakedsdf / bakedsdf-mlp /
-bakedangelo (their field sizes have no kernel instantiation), dto, neusW."""
+Not here: geo-neus / geo-volsdf / geo-unisurf (multi-view patch warping: the data manager's neighbouring images), bakedsdf / bakedsdf-mlp
+(the model is built - models/bakedsdf.py - but the presets' field sizes, a 371-column input resp. 1024-wide layers, have no kernel
+instantiation), dto, neusW."""
 import dataclasses
 from typing import Any, Dict
 
 from sdfstudio_amd.engine.optimizers import (AdamOptimizerConfig, AdamWOptimizerConfig, ExponentialSchedulerConfig, MultiStepSchedulerConfig,
                                              MultiStepWarmupSchedulerConfig, NeuSSchedulerConfig)
 from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
+from sdfstudio_amd.models.bakedsdf import BakedAngeloModelConfig
 from sdfstudio_amd.models.neuralangelo import NeuralangeloModelConfig
 from sdfstudio_amd.models.neus import NeuSModelConfig
 from sdfstudio_amd.models.neus_acc import NeuSAccModelConfig
@@ -120,3 +122,21 @@ method_configs["mono-unisurf"] = MethodConfig("mono-unisurf",
 # :937-970
 method_configs["neus-acc"] = MethodConfig("neus-acc", NeuSAccModelConfig(eval_num_rays_per_chunk=1024), _neus_groups(max_steps=20000, warm_up_end=500),
                                           2048, 1024, 20000)
+
+# :111-181: BakedSDF's model on the neuralangelo-type field (BASELINE config 5's field shape), AdamW with weight decay on the fields
+method_configs["bakedangelo"] = MethodConfig(
+    "bakedangelo",
+    BakedAngeloModelConfig(near_plane=0.01, far_plane=1000.0, overwrite_near_far_plane=True,
+                           sdf_field=SDFFieldConfig(use_grid_feature=True, num_layers=1, num_layers_color=4, hidden_dim=256, hidden_dim_color=256,
+                                                    geometric_init=True, bias=1.5, beta_init=0.1, inside_outside=True, use_appearance_embedding=True,
+                                                    use_numerical_gradients=True, base_res=64, max_res=4096, log2_hashmap_size=22,
+                                                    hash_features_per_level=8, hash_smoothstep=False, use_position_encoding=False),
+                           background_model="grid", eval_num_rays_per_chunk=1024, proposal_weights_anneal_max_num_iters=10000, use_anneal_beta=True,
+                           beta_anneal_max_num_iters=1000000, beta_anneal_init=0.1, beta_anneal_end=0.0002, eikonal_loss_mult=0.01,
+                           level_init=4, steps_per_level=10000, curvature_loss_warmup_steps=20000, curvature_loss_multi=5e-4),
+    {"proposal_networks": _adam(1e-2, MultiStepSchedulerConfig(max_steps=1000000)),
+     "fields": _adam(1e-3, MultiStepWarmupSchedulerConfig(warm_up_end=5000, milestones=[600_000, 800_000], gamma=0.1), cls=AdamWOptimizerConfig,
+                     weight_decay=0.01),
+     "field_background": _adam(1e-3, MultiStepWarmupSchedulerConfig(warm_up_end=5000, milestones=[300_000, 400_000], gamma=0.1), cls=AdamWOptimizerConfig)},
+    train_num_rays_per_batch=8192, eval_num_rays_per_batch=1024, max_num_iterations=1000_001)
+

@@ -428,3 +428,33 @@ def monosdf_normal_loss(normal_pred: torch.Tensor, normal_gt: torch.Tensor) -> t
     n_pr = torch.nn.functional.normalize(normal_pred, p=2, dim=-1)
     return torch.abs(n_pr - n_gt).sum(dim=-1).mean() + (1.0 - torch.sum(n_pr * n_gt, dim=-1)).mean()
 
+
+# ---- the mip-NeRF-360 proposal loss (the BakedSDF / BakedAngelo models; NeuS-facto uses the Zip-NeRF form above)
+def _outer(t0_starts, t0_ends, t1_starts, t1_ends, y1):
+    """losses.py:36-67: for every interval [t0_start, t0_end) the mass of the step function (t1, y1) over the t1 intervals it touches -
+    an upper bound of the mass inside it - from the cumulative sums at the two enclosing t1 edges (two searchsorted's and two gathers)."""
+    cy1 = torch.cat([torch.zeros_like(y1[..., :1]), torch.cumsum(y1, dim=-1)], dim=-1)
+    idx_lo = torch.searchsorted(t1_starts.contiguous(), t0_starts.contiguous(), side="right") - 1
+    idx_lo = torch.clamp(idx_lo, min=0, max=y1.shape[-1] - 1)
+    idx_hi = torch.searchsorted(t1_ends.contiguous(), t0_ends.contiguous(), side="right")
+    idx_hi = torch.clamp(idx_hi, min=0, max=y1.shape[-1] - 1)
+    return torch.take_along_dim(cy1[..., 1:], idx_hi, dim=-1) - torch.take_along_dim(cy1[..., :-1], idx_lo, dim=-1)
+
+
+def lossfun_outer(t, w, t_env, w_env):
+    """losses.py:70-87: (max(w - w_outer, 0))^2 / (w + 1e-7): the field's histogram (t, w) may not exceed the envelope a proposal level's
+    histogram (t_env, w_env) gives it."""
+    w_outer = _outer(t[..., :-1], t[..., 1:], t_env[..., :-1], t_env[..., 1:], w_env)
+    return torch.clip(w - w_outer, min=0) ** 2 / (w + 1e-7)
+
+
+def interlevel_loss(weights_list: List[torch.Tensor], bins_list: List[torch.Tensor]) -> torch.Tensor:
+    """losses.py:98-113 on the same arguments as interlevel_loss_zip: weights_list[i] [N, S_i] (last = the field's, detached here),
+    bins_list[i] [N, S_i + 1] spacing-domain bin edges (ray_samples_to_sdist).  Plain torch operators on [N, S] tensors (per level: a
+    cumsum, two searchsorted's, two gathers): the proposal levels' weights receive the gradient."""
+    c, w = bins_list[-1].detach(), weights_list[-1].detach()
+    loss = w.new_zeros(())
+    for cp, wp in zip(bins_list[:-1], weights_list[:-1]):
+        loss = loss + torch.mean(lossfun_outer(c, w, cp, wp))
+    return loss
+

@@ -476,6 +476,11 @@ def test_model_configs_accept_every_field_of_the_references():
     pairs = [(ns.sf.SDFFieldConfig, SDFFieldConfig), (r_nf.NeuSFactoModelConfig, NeuSFactoModelConfig), (r_n.NeuSModelConfig, NeuSModelConfig),
              (r_v.VolSDFModelConfig, VolSDFModelConfig), (r_u.UniSurfModelConfig, UniSurfModelConfig), (r_acc.NeuSAccModelConfig, NeuSAccModelConfig),
              (r_na.NeuralangeloModelConfig, NeuralangeloModelConfig)]
+    import nerfstudio.models.bakedangelo as r_ba
+    import nerfstudio.models.bakedsdf as r_b
+    from sdfstudio_amd.models.bakedsdf import BakedAngeloModelConfig, BakedSDFModelConfig
+
+    pairs += [(r_b.BakedSDFModelConfig, BakedSDFModelConfig), (r_ba.BakedAngeloModelConfig, BakedAngeloModelConfig)]
     skip = {"_target", "sdf_field", "collider_params", "loss_coefficients"}
     for theirs, ours in pairs:
         rf, of = fields(theirs), fields(ours)
@@ -584,6 +589,9 @@ def test_models_and_optimizers_expose_the_references_trainer_facing_methods():
     import nerfstudio.models.neus_facto as r_nf
     import nerfstudio.models.unisurf as r_u
     import nerfstudio.models.volsdf as r_v
+    import nerfstudio.models.bakedangelo as r_ba
+    import nerfstudio.models.bakedsdf as r_b
+    from sdfstudio_amd.models.bakedsdf import BakedAngeloModel, BakedSDFFactoModel
 
     seen.clear()
     for step in range(3):  # the reference's own enum members select the callback
@@ -593,7 +601,8 @@ def test_models_and_optimizers_expose_the_references_trainer_facing_methods():
     base = set(dir(torch.nn.Module))
     viewer_side = {"get_image_metrics_and_images"}  # PSNR / SSIM / LPIPS images of an eval view: torchmetrics, the viewer's side of the model
     for theirs, ours in ((r_nf.NeuSFactoModel, NeuSFactoModel), (r_n.NeuSModel, NeuSModel), (r_v.VolSDFModel, VolSDFModel), (r_u.UniSurfModel, UniSurfModel),
-                         (r_acc.NeuSAccModel, NeuSAccModel), (r_na.NeuralangeloModel, NeuralangeloModel)):
+                         (r_acc.NeuSAccModel, NeuSAccModel), (r_na.NeuralangeloModel, NeuralangeloModel), (r_b.BakedSDFFactoModel, BakedSDFFactoModel),
+                         (r_ba.BakedAngeloModel, BakedAngeloModel)):
         missing = [m for m in dir(theirs) if not m.startswith("_") and m not in base and m not in viewer_side and not hasattr(ours, m)]
         assert not missing, (theirs.__name__, missing)
 
@@ -643,12 +652,12 @@ def test_optimizer_dictionary_of_a_reference_preset_is_accepted():
 def test_method_presets_against_the_references_method_configs():
     """sdfstudio_amd/configs/method_configs.py against nerfstudio/configs/method_configs.py, entry by entry: every field of the model config
     (nested SDFFieldConfig included), every optimizer group (class, lr, eps, weight decay, scheduler class and fields), the ray batch sizes,
-    the iteration count and mixed_precision - for the eleven surface methods whose model is built."""
+    the iteration count and mixed_precision - for the twelve surface methods whose model is built at the preset's size."""
     from sdfstudio_amd.configs.method_configs import method_configs
     from sdfstudio_amd.engine.optimizers import group_config_from_reference
 
     assert set(method_configs) == {"neus-facto", "neus-facto-bigmlp", "neus-facto-angelo", "neuralangelo", "neus", "mono-neus", "volsdf", "monosdf",
-                                   "unisurf", "mono-unisurf", "neus-acc"}
+                                   "unisurf", "mono-unisurf", "neus-acc", "bakedangelo"}
     for name, m in method_configs.items():  # every group converts; AdamW entries become decoupled-decay groups (sdfhip_adamw_step)
         for g, e in m.optimizers.items():
             c = group_config_from_reference(e)
@@ -695,6 +704,73 @@ def test_method_presets_against_the_references_method_configs():
             problems.append(f"{name}: batch sizes / iterations {want}")
         assert r.pipeline.datamanager.camera_optimizer.mode == "off"
     assert not problems, "\n".join(problems)
+
+
+def test_bakedsdf_losses_and_schedules_against_reference():
+    """models/bakedsdf.py / bakedangelo.py: the mip-NeRF-360 proposal loss (model_components/losses.py:36-113) equal to the reference's
+    function bit for bit with its gradient; the beta / eikonal-weight schedules and the spatially varying eikonal weights as the pure
+    functions the model applies - known answers, and the reference's own callbacks on its own BakedAngeloModel (built on CPU through the
+    harness) step by step, incl. the angelo schedules in their x 4 form."""
+    from sdfstudio_amd.model_components.losses import interlevel_loss
+    from sdfstudio_amd.models.bakedsdf import (BakedAngeloModelConfig, BakedSDFModelConfig, bakedsdf_beta, bakedsdf_eikonal_mult,
+                                               spatially_varying_eikonal_weights)
+
+    cfg = BakedSDFModelConfig()
+    assert abs(bakedsdf_beta(0, cfg) - 0.1) < 1e-15 and abs(bakedsdf_beta(250000, cfg) - 0.001) < 1e-15 and abs(bakedsdf_beta(10**7, cfg) - 0.001) < 1e-15
+    assert abs(bakedsdf_eikonal_mult(0, cfg) - 0.01) < 1e-12 and abs(bakedsdf_eikonal_mult(250000, cfg) - 0.1) < 1e-12
+    pn = torch.tensor([0.2, 1.0, 1.5, 2.0])
+    w = spatially_varying_eikonal_weights(pn, cfg)
+    assert torch.allclose(w, torch.tensor([0.01, 0.01, 0.1 / (1 + 9 * 0.25), 0.1]), atol=1e-7)
+    g = torch.Generator().manual_seed(8)
+    n = 16
+    bins = [torch.sort(torch.rand(n, s + 1, generator=g), dim=-1)[0] for s in (32, 24, 12)]
+    ws = [torch.rand(n, s, generator=g).requires_grad_(True) for s in (32, 24, 12)]
+    ours = interlevel_loss(ws, bins)
+    grads = torch.autograd.grad(ours, ws[:2])
+    assert ws[2].grad is None and float(ours) > 0 and all(float(x.abs().max()) > 0 for x in grads)
+    if not os.path.isdir("/root/reference/nerfstudio"):
+        return
+    from oracle import ref_harness
+
+    ns = ref_harness.import_reference()
+    import nerfstudio.models.bakedangelo as r_ba
+    from nerfstudio.data.scene_box import SceneBox
+    from nerfstudio.model_components import losses as RL
+
+    class _RS:  # ray_samples_to_sdist reads spacing_starts / spacing_ends
+        def __init__(self, b):
+            self.spacing_starts, self.spacing_ends = b[:, :-1, None], b[:, 1:, None]
+
+    ref = RL.interlevel_loss([w_[..., None] for w_ in ws], [_RS(b) for b in bins])
+    assert float(ref) == float(ours)
+    for a, b in zip(torch.autograd.grad(ref, ws[:2]), grads):
+        assert torch.equal(a, b)
+    sb = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=0.5, far=4.5, radius=1.0, collider_type="near_far")
+    fcfg = ns.sf.SDFFieldConfig(use_grid_feature=True, num_layers=1, num_layers_color=2, hidden_dim=32, hidden_dim_color=32, bias=0.5, beta_init=0.3,
+                                inside_outside=False, use_appearance_embedding=False, use_numerical_gradients=True, base_res=64, max_res=4096,
+                                log2_hashmap_size=8, hash_features_per_level=8, hash_smoothstep=False, use_position_encoding=False)
+    props = [{"hidden_dim": 16, "log2_hashmap_size": 8, "num_levels": 5, "max_res": 64}]
+    kw = dict(use_anneal_eikonal_weight=True, beta_anneal_max_num_iters=1000, eikonal_anneal_max_num_iters=2000, steps_per_level=100,
+              curvature_loss_warmup_steps=150)
+    model = r_ba.BakedAngeloModelConfig(sdf_field=fcfg, background_model="none", proposal_net_args_list=props, use_same_proposal_network=True,
+                                        **kw).setup(scene_box=sb, num_train_data=4, world_size=1, local_rank=0)
+    cbs = [c for c in model.get_training_callbacks(None) if c.func.__name__ != "step_cb"]
+    ours_cfg = BakedAngeloModelConfig(**kw)
+    f = model.field
+    for step in (0, 1, 99, 100, 150, 151, 640, 1000, 1999, 2000, 5000):
+        for c in cbs:
+            c.func(step)
+        assert float(f.laplace_density.beta.data) == pytest.approx(bakedsdf_beta(step, ours_cfg), rel=1e-6)
+        assert model.config.eikonal_loss_mult == bakedsdf_eikonal_mult(step, ours_cfg)
+        delta = max(1.0 / (4.0 * f.max_res), 1.0 / (f.base_res * f.growth_factor ** (step / 100))) * 4.0  # BakedAngeloModel.before_train_iteration
+        assert f.numerical_gradients_delta == delta
+        active = int((f.hash_encoding_mask.reshape(f.num_levels, -1).amax(dim=1) > 0).sum())
+        assert active == min(max(int(step / 100) + 1, 4), f.num_levels)
+        if step < 150:
+            want = step / 150
+        else:
+            want = max(1.0 / (f.max_res * 10.0), 1.0 / (f.base_res * f.growth_factor ** ((step - 150) / 100))) / (1.0 / f.base_res)
+        assert model.curvature_loss_multi_factor == want
 
 
 def test_spaced_sampler_recognises_the_references_spacing_functions():

@@ -462,3 +462,101 @@ def test_neuralangelo_model_steps_through_its_schedules(device):
         assert float(tg[int(lv[s.level].offset):].abs().max()) == 0.0  # levels above the mask: exactly zero
         m = model.get_metrics_dict(out, {"image": torch.rand(256, 3, device=device, generator=gen)})
         assert m["numerical_gradients_delta"] == s.delta and abs(m["activated_encoding"] - s.level / 16) < 1e-6
+
+
+def test_bakedangelo_and_bakedsdf_models_step(device):
+    """models/bakedsdf.py on the native path.  BakedAngelo on the `bakedangelo` preset's field shape (1 x 256 + 4 x 256, 16 levels x 8 features,
+    numerical gradients; a small table), from the registry entry with its AdamW optimizer dictionary, and BakedSDF on an analytic-gradient field
+    with the spatially varying eikonal weight: the proposal sampler feeds the per-head Laplace-density compositing, the loss dictionary has
+    the reference's entries, every loss equals its torch statement on the returned tensors, the proposal networks receive the gradient of
+    the mip-NeRF-360 proposal loss, the schedules leave the reference's state, two optimiser steps move the parameters."""
+    import copy
+
+    from sdfstudio_amd.cameras.rays import RayBundle
+    from sdfstudio_amd.configs.method_configs import method_configs
+    from sdfstudio_amd.engine.optimizers import Optimizers
+    from sdfstudio_amd.fields.field_heads import FieldHeadNames
+    from sdfstudio_amd.fields.sdf_field import SDFFieldConfig
+    from sdfstudio_amd.model_components.losses import interlevel_loss
+    from sdfstudio_amd.models.bakedsdf import (BakedSDFFactoModel, BakedSDFModelConfig, bakedsdf_beta, spatially_varying_eikonal_weights)
+    from sdfstudio_amd.models.neus_facto import SceneBox
+    import bench as B
+
+    box = SceneBox(aabb=torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), near=0.5, far=4.5)
+    centers, rot = B.synthetic_cameras(device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(21)
+    n = 256
+
+    def run(model, opts, steps, check):
+        for step in steps:
+            model.before_train_iteration(step)
+            o, d, norm, cam = B.draw_rays(centers, rot, n, gen)
+            out = model(RayBundle(origins=o, directions=d, directions_norm=norm, camera_indices=cam[:, None]))
+            loss = model.get_loss_dict(out, {"image": torch.rand(n, 3, device=device, generator=gen)})
+            assert all(torch.isfinite(v).all() for v in loss.values()), loss
+            check(step, out, loss)
+            opts.zero_grad_all()
+            sum(loss.values()).backward()
+            opts.optimizer_step_all()
+            opts.scheduler_step_all(step)
+            model.after_train_iteration(step)
+
+    # ---- BakedAngelo from the registry (small table, no background network, few samples)
+    m = method_configs["bakedangelo"]
+    cfg = copy.deepcopy(m.model)
+    cfg.sdf_field.log2_hashmap_size = 14
+    cfg.sdf_field.inside_outside = False
+    cfg.sdf_field.bias = 0.5
+    cfg.background_model = "none"
+    cfg.overwrite_near_far_plane = False
+    cfg.num_proposal_samples_per_ray, cfg.num_neus_samples_per_ray = (64, 32), 24
+    cfg.proposal_net_args_list = [{"hidden_dim": 16, "log2_hashmap_size": 12, "num_levels": 5, "max_res": 64},
+                                  {"hidden_dim": 16, "log2_hashmap_size": 12, "num_levels": 5, "max_res": 128}]
+    torch.manual_seed(0)
+    model = cfg.setup(scene_box=box, num_train_data=49).to(device).train()
+    with torch.no_grad():  # off the geometric initialisation, so that the table takes part
+        model.field.glin0.weight_v[:, 3:] += 0.05 * torch.randn_like(model.field.glin0.weight_v[:, 3:])
+    groups = {k: v for k, v in model.get_param_groups().items() if v}
+    assert not any(p is model.field.laplace_density.beta for p in groups["fields"])  # the annealed beta is not trained (bakedsdf.py:154-159)
+    opts = Optimizers({k: m.optimizers[k] for k in groups}, groups)
+    assert opts.adam.groups["fields"]["decoupled"] and opts.adam.groups["fields"]["weight_decay"] == 0.01
+    before = model.field.glin0.weight_v.detach().clone()
+
+    def check_angelo(step, out, loss):
+        assert set(loss) == {"rgb_loss", "eikonal_loss", "interlevel_loss", "curvature_loss"}, sorted(loss)
+        assert float(model.field.laplace_density.beta.detach()) == pytest.approx(bakedsdf_beta(step, cfg), rel=1e-6)
+        fo = out["field_outputs"]
+        assert fo["sampled_sdf"].shape == (n, 24, 6) and fo[FieldHeadNames.DENSITY].shape == (n, 24, 1)
+        w = [x[..., 0] for x in out["weights_list"]]
+        bins = [rs.flat_bins for rs in out["ray_samples_list"]]
+        assert_close("interlevel", loss["interlevel_loss"], interlevel_loss(w, bins).detach(), rtol=1e-6, atol=1e-10)
+        grad = out["eik_grad"]
+        assert_close("eikonal", loss["eikonal_loss"], ((grad.norm(2, dim=-1) - 1) ** 2).mean().detach() * cfg.eikonal_loss_mult, rtol=2e-5, atol=1e-10)
+        # alpha compositing of the Laplace density, per head (bakedsdf.py:238-246)
+        rs = out["ray_samples"]
+        alpha = 1 - torch.exp(-(rs.flat_ends - rs.flat_starts)[..., None] * fo[FieldHeadNames.DENSITY])
+        assert_close("alpha", fo[FieldHeadNames.ALPHA], alpha.detach(), rtol=1e-5, atol=1e-7)
+
+    run(model, opts, (0, 1, 20000), check_angelo)
+    assert not torch.equal(model.field.glin0.weight_v.detach(), before)
+    assert float(model.proposal_networks[0].mlp_base.table.grad.abs().max()) > 0.0
+
+    # ---- BakedSDF, analytic normals, spatially varying eikonal weight
+    fcfg = SDFFieldConfig(use_grid_feature=True, num_layers=2, num_layers_color=2, hidden_dim=256, hidden_dim_color=256, bias=0.5, beta_init=0.1,
+                          inside_outside=False, use_appearance_embedding=False, log2_hashmap_size=14)
+    bcfg = BakedSDFModelConfig(sdf_field=fcfg, background_model="none", use_spatial_varying_eikonal_loss=True, num_proposal_samples_per_ray=(64, 32),
+                               num_neus_samples_per_ray=24, proposal_net_args_list=cfg.proposal_net_args_list)
+    torch.manual_seed(0)
+    bmodel = BakedSDFFactoModel(bcfg, box, num_train_data=49).to(device).train()
+    bgroups = {k: v for k, v in bmodel.get_param_groups().items() if v}
+    bopts = Optimizers({k: {"lr": 1e-3, "scheduler": None} for k in bgroups}, bgroups)
+
+    def check_baked(step, out, loss):
+        assert set(loss) == {"rgb_loss", "eikonal_loss", "interlevel_loss"}, sorted(loss)
+        wts = spatially_varying_eikonal_weights(out["points_norm"][..., 0], bcfg)
+        want = (((out["eik_grad"].norm(2, dim=-1) - 1) ** 2) * wts).mean()
+        assert_close("spatially varying eikonal", loss["eikonal_loss"], want.detach(), rtol=1e-6, atol=1e-12)
+        assert bmodel.get_metrics_dict(out, {"image": torch.rand(n, 3, device=device, generator=gen)})["eikonal_loss_mult"] == bcfg.eikonal_loss_mult
+
+    run(bmodel, bopts, (0, 1), check_baked)
