@@ -150,8 +150,9 @@ class TCNNNerfactoField(nn.Module):
     """nerfacto_field.py:65-332 with the defaults base_surface_model.py:181-187 relies on."""
 
     def __init__(self, aabb, num_images: int, num_layers: int = 2, hidden_dim: int = 64, geo_feat_dim: int = 15, num_levels: int = 16,
-                 max_res: int = 1024, log2_hashmap_size: int = 19, num_layers_color: int = 3, hidden_dim_color: int = 64,
-                 appearance_embedding_dim: int = 32, use_transient_embedding: bool = False, use_semantics: bool = False,
+                 max_res: int = 1024, log2_hashmap_size: int = 19, num_layers_color: int = 3, num_layers_transient: int = 2,
+                 hidden_dim_color: int = 64, hidden_dim_transient: int = 64, appearance_embedding_dim: int = 32, transient_embedding_dim: int = 16,
+                 use_transient_embedding: bool = False, use_semantics: bool = False, num_semantic_classes: int = 100,
                  use_pred_normals: bool = False, use_average_appearance_embedding: bool = False, spatial_distortion=None) -> None:
         super().__init__()
         if use_transient_embedding or use_semantics or use_pred_normals:
@@ -291,8 +292,21 @@ class TCNNNerfactoField(nn.Module):
         rgb = _ColorFunction.apply(theta, feat, self._const("zero_normal", tuple(x.shape), 0.0, x.device), slots, self._native, x, d.contiguous(), n, s)
         return {FieldHeadNames.RGB: rgb.view(n, s, 3)}
 
-    def forward(self, ray_samples) -> Dict:
+    def density_fn(self, positions: torch.Tensor) -> torch.Tensor:
+        """Field.density_fn (fields/base_field.py:48-65): the density at explicit positions [..., 3] (zero-length frustums at the positions)."""
+        from sdfstudio_amd.cameras.rays import Frustums, RaySamples
+
+        flat = positions.reshape(-1, 1, 3)
+        one = torch.ones_like(flat[..., :1])
+        rs = RaySamples(frustums=Frustums(origins=flat, directions=torch.ones_like(flat), starts=torch.zeros_like(one), ends=torch.zeros_like(one),
+                                          pixel_area=one))
+        density, _ = self.get_density(rs)
+        return density.view(*positions.shape[:-1], 1)
+
+    def forward(self, ray_samples, compute_normals: bool = False) -> Dict:
         """fields/base_field.py:111-126."""
+        if compute_normals:
+            raise NotImplementedError("compute_normals (normals of a density field, base_field.py:104-121) is not built")
         density, emb = self.get_density(ray_samples)
         out = self.get_outputs(ray_samples, density_embedding=emb)
         out[FieldHeadNames.DENSITY] = density

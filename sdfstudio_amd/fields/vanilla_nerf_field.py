@@ -126,10 +126,19 @@ class NeRFField(nn.Module):
 
     def __init__(self, position_encoding: Optional[nn.Module] = None, direction_encoding: Optional[nn.Module] = None,
                  base_mlp_num_layers: int = 8, base_mlp_layer_width: int = 256, head_mlp_num_layers: int = 2,
-                 head_mlp_layer_width: int = 128, skip_connections: Tuple[int, ...] = (4,), spatial_distortion=None) -> None:
+                 head_mlp_layer_width: int = 128, skip_connections: Tuple[int, ...] = (4,), field_heads=None,
+                 use_integrated_encoding: bool = False, spatial_distortion=None) -> None:
         super().__init__()
-        self.position_encoding = position_encoding or NeRFEncoding(3, 10, 0.0, 9.0, include_input=True)
-        self.direction_encoding = direction_encoding or NeRFEncoding(3, 4, 0.0, 3.0, include_input=True)
+        # The reference's defaults are Identity encodings and an RGB head (vanilla_nerf_field.py:52-61); the surface models always pass the
+        # 10- / 4-frequency encodings (base_surface_model.py:189-200), which is what the fused kernels are built for: an encoding left out
+        # is refused, not replaced.
+        if position_encoding is None or direction_encoding is None:
+            raise NotImplementedError("NeRFField: pass position_encoding / direction_encoding (NeRFEncoding, include_input=True) as "
+                                      "base_surface_model.py:189-200 does; the reference's Identity defaults are not built")
+        if use_integrated_encoding or (field_heads is not None and len(field_heads) != 1):
+            raise NotImplementedError("NeRFField: integrated (mip-NeRF) encodings and heads other than the RGB head are not built")
+        self.position_encoding = position_encoding
+        self.direction_encoding = direction_encoding
         self.spatial_distortion = spatial_distortion
         self.mlp_base = MLP(self.position_encoding.get_out_dim(), base_mlp_num_layers, base_mlp_layer_width,
                             skip_connections=skip_connections, out_activation=nn.ReLU())
@@ -207,7 +216,18 @@ class NeRFField(nn.Module):
         density = torch.nn.functional.softplus(pre).view(*shape, 1)  # DensityFieldHead: Softplus (field_heads.py:99-107)
         return density, (part, theta, x)
 
-    def get_outputs(self, ray_samples, density_embedding) -> Dict:
+    def density_fn(self, positions: torch.Tensor) -> torch.Tensor:
+        """Field.density_fn (fields/base_field.py:48-65): the density at explicit positions [..., 3] (zero-length frustums at the positions)."""
+        from sdfstudio_amd.cameras.rays import Frustums, RaySamples
+
+        flat = positions.reshape(-1, 1, 3)
+        one = torch.ones_like(flat[..., :1])
+        rs = RaySamples(frustums=Frustums(origins=flat, directions=torch.ones_like(flat), starts=torch.zeros_like(one), ends=torch.zeros_like(one),
+                                          pixel_area=one))
+        density, _ = self.get_density(rs)
+        return density.view(*positions.shape[:-1], 1)
+
+    def get_outputs(self, ray_samples, density_embedding=None) -> Dict:
         """vanilla_nerf_field.py:106-114."""
         from sdfstudio_amd.cameras.rays import unpack_ray_samples
         from sdfstudio_amd.fields.sdf_field import _ColorFunction
@@ -218,8 +238,10 @@ class NeRFField(nn.Module):
         rgb = _ColorFunction.apply(theta, part, torch.zeros_like(x), None, self._native, x, d.contiguous(), n, s)
         return {FieldHeadNames.RGB: rgb.view(n, s, 3)}
 
-    def forward(self, ray_samples) -> Dict:
+    def forward(self, ray_samples, compute_normals: bool = False) -> Dict:
         """fields/base_field.py:111-126."""
+        if compute_normals:
+            raise NotImplementedError("compute_normals (normals of a density field, base_field.py:104-121) is not built")
         density, emb = self.get_density(ray_samples)
         out = self.get_outputs(ray_samples, density_embedding=emb)
         out[FieldHeadNames.DENSITY] = density

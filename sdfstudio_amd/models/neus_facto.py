@@ -91,9 +91,10 @@ class LazyOutputs(dict):
 
 
 class SceneContraction(nn.Module):
-    """field_components/spatial_distortions.py:42-92 (order = inf, or None for L2); a marker for the kernels, callable for host code."""
+    """field_components/spatial_distortions.py:42-92 (order = None: the L2 norm, the reference's default; the surface models pass inf,
+    base_surface_model.py:148-155); a marker for the kernels, callable for host code."""
 
-    def __init__(self, order=float("inf")) -> None:
+    def __init__(self, order=None) -> None:
         super().__init__()
         self.order = order
 

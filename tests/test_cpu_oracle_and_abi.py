@@ -550,6 +550,18 @@ def test_plugin_classes_keep_the_references_signatures():
     sdf_methods = [m for m in dir(r_sf.SDFField) if not m.startswith("_") and callable(getattr(r_sf.SDFField, m)) and m not in dir(torch.nn.Module)]
     assert {"forward_geonetwork", "get_sdf", "get_alpha", "get_outputs", "get_colors", "gradient", "density_fn"} <= set(sdf_methods)
     compare(r_sf, o_sf, ["SDFField", "LaplaceDensity", "SingleVarianceNetwork"], tuple(sdf_methods) + ("__init__", "forward", "get_variance", "get_beta"))
+    import nerfstudio.field_components.spatial_distortions as r_sd
+    import nerfstudio.fields.nerfacto_field as r_nf
+    import nerfstudio.fields.vanilla_nerf_field as r_vf
+    import sdfstudio_amd.fields.nerfacto_field as o_nf
+    import sdfstudio_amd.fields.vanilla_nerf_field as o_vf
+    import sdfstudio_amd.models.neus_facto as o_m
+
+    callable_defaults |= {("NeRFField", "__init__", "position_encoding"), ("NeRFField", "__init__", "direction_encoding"),
+                          ("NeRFField", "__init__", "field_heads")}  # Identity encodings / head objects: refused when left out (not built)
+    compare(r_vf, o_vf, ["NeRFField"], ("__init__", "get_density", "get_outputs", "forward", "density_fn"))
+    compare(r_nf, o_nf, ["TCNNNerfactoField"], ("__init__", "get_density", "get_outputs", "forward", "density_fn"))
+    compare(r_sd, o_m, ["SceneContraction"], ("__init__", "forward"))
     assert not problems, "\n".join(problems)
     for step in (0, 1, 17, 5000):
         assert o_rs.ProposalNetworkSampler().update_sched(step) == r_rs.ProposalNetworkSampler().update_sched(step)

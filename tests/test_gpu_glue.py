@@ -92,7 +92,7 @@ def test_permuted_theta_writes_gradient_slots(device):
 
     torch.manual_seed(2)
     fld = TCNNNerfactoField(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_images=3, num_levels=4, max_res=32, log2_hashmap_size=8,
-                            spatial_distortion=SceneContraction()).to(device).train()
+                            spatial_distortion=SceneContraction(order=float("inf"))).to(device).train()
     params = [fld.mlp_base.w1, fld.mlp_base.w2, fld.mlp_head.w1, fld.mlp_head.w2, fld.mlp_head.w3]
     theta = fld._theta()
     assert fld._theta_invs is not None and theta.grad_fn is not None and "PermutedTheta" in type(theta.grad_fn).__name__
@@ -305,3 +305,33 @@ def test_method_presets_train_a_step(device, name):
             cb.run_callback_at_location(step, TrainingCallbackLocation.AFTER_TRAIN_ITERATION)
     moved = [k for k, p in list(model.field.named_parameters())[:4] if not torch.equal(p.detach(), before[k])]
     assert moved, "two optimiser steps must move the field's parameters"
+
+
+def test_background_fields_density_fn(device):
+    """Field.density_fn (fields/base_field.py:48-65) of the two background fields: the density at explicit positions equals get_density on
+    ray samples whose frustum mid points are those positions."""
+    from sdfstudio_amd.cameras.rays import RayBundle
+    from sdfstudio_amd.fields.nerfacto_field import TCNNNerfactoField
+    from sdfstudio_amd.fields.vanilla_nerf_field import NeRFEncoding, NeRFField
+    from sdfstudio_amd.models.neus_facto import SceneContraction
+
+    torch.manual_seed(0)
+    n, s = 16, 6
+    o, d = torch.randn(n, 3, device=device) * 0.3, torch.nn.functional.normalize(torch.randn(n, 3, device=device), dim=-1)
+    starts = torch.sort(torch.rand(n, s, device=device) * 3.0, dim=-1)[0]
+    rb = RayBundle(origins=o, directions=d, camera_indices=torch.zeros(n, 1, dtype=torch.long, device=device), nears=torch.zeros(n, 1, device=device),
+                   fars=torch.full((n, 1), 4.0, device=device))
+    rs = rb.get_ray_samples(starts, starts + 0.2)
+    pos = rs.frustums.get_positions()
+    sc = SceneContraction(order=float("inf"))
+    fields = [NeRFField(position_encoding=NeRFEncoding(in_dim=3, num_frequencies=10, min_freq_exp=0.0, max_freq_exp=9.0, include_input=True),
+                        direction_encoding=NeRFEncoding(in_dim=3, num_frequencies=4, min_freq_exp=0.0, max_freq_exp=3.0, include_input=True),
+                        spatial_distortion=sc).to(device),
+              TCNNNerfactoField(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), num_images=3, num_levels=4, max_res=32, log2_hashmap_size=8,
+                                spatial_distortion=sc).to(device)]
+    with torch.no_grad():
+        for f in fields:
+            dens, _ = f.get_density(rs)
+            assert_close(type(f).__name__ + ".density_fn", f.density_fn(pos), dens, rtol=1e-5, atol=1e-7)
+    with pytest.raises(NotImplementedError):
+        NeRFField()  # the reference's Identity encodings are not built: refused, not replaced

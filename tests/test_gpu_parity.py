@@ -524,7 +524,7 @@ def test_proposal_field_fwd_bwd(device):
     coef = torch.randn(n, s)
     (ref * coef).sum().backward()
 
-    net = HashMLPDensityField(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), spatial_distortion=SceneContraction(),
+    net = HashMLPDensityField(torch.tensor([[-1.0, -1, -1], [1, 1, 1]]), spatial_distortion=SceneContraction(order=float("inf")),
                               hidden_dim=16, num_levels=5, max_res=64, base_res=16, log2_hashmap_size=12)
     with torch.no_grad():
         net.mlp_base.table.copy_(p["proposal_networks.0.table"])
@@ -2057,7 +2057,11 @@ def test_nerf_background_field_fwd_bwd(device, contraction):
     from sdfstudio_amd.models.neus_facto import SceneContraction
 
     torch.manual_seed(13)
-    fld = NeRFField(spatial_distortion=SceneContraction(order=float("inf")) if contraction else None)
+    from sdfstudio_amd.fields.vanilla_nerf_field import NeRFEncoding as _Enc
+
+    fld = NeRFField(position_encoding=_Enc(in_dim=3, num_frequencies=10, min_freq_exp=0.0, max_freq_exp=9.0, include_input=True),
+                    direction_encoding=_Enc(in_dim=3, num_frequencies=4, min_freq_exp=0.0, max_freq_exp=3.0, include_input=True),
+                    spatial_distortion=SceneContraction(order=float("inf")) if contraction else None)
     with torch.no_grad():  # biases away from zero so that every ReLU pattern occurs
         for prm in fld.parameters():
             if prm.dim() == 1:
