@@ -76,6 +76,15 @@ class _TensorDataclass:
             raise TypeError("len() of a 0-d tensor")
         return int(self.shape[0])
 
+    def __bool__(self) -> bool:
+        """tensor_dataclass.py:172-178."""
+        if len(self) == 0:
+            raise ValueError(f"The truth value of {self.__class__.__name__} when `len(x) == 0` is ambiguous. Use `len(x)` or `x is not None`.")
+        return True
+
+    def __setitem__(self, indices, value):
+        raise RuntimeError("Index assignment is not supported for TensorDataclass")
+
 
 @dataclass
 class Frustums(_TensorDataclass):
